@@ -1,0 +1,74 @@
+"""Case table for the golden fixtures (``tests/golden/*.npz``).
+
+TEST INFRASTRUCTURE ONLY.  Each case names a seeded synthetic input and the keyword arguments of
+the reference calls whose outputs are stored.  ``oracle/make_golden.py`` runs the UNMODIFIED
+reference on them (build container only); the tests replay the same inputs through the oracle
+(CPU) and through the HIP path (GPU) and compare with the stored reference outputs.
+
+Sizes follow the reference's own test parametrisations (``tests/test_core.py:256-292, 317-371,
+813-828``; ``tests/test_multichannel.py:96-111, 266-285, 685-714``) plus BASELINE.json's configs.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SR = 22050
+
+
+def make_signal(kind, n, seed, channels=None, dtype="float32"):
+    """Seeded synthetic PCM: 'noise', 'tone' (440 Hz), 'mix' (0.1 noise + 0.5 tone), 'chirp'."""
+    rng = np.random.default_rng(seed)
+    shape = (n,) if channels is None else tuple(channels) + (n,)
+    t = np.arange(n, dtype=np.float64) / SR
+    if kind == "noise":
+        y = 0.3 * rng.standard_normal(shape)
+    elif kind == "tone":
+        y = np.broadcast_to(np.sin(2 * np.pi * 440.0 * t), shape).copy()
+    elif kind == "mix":
+        y = 0.1 * rng.standard_normal(shape) + 0.5 * np.sin(2 * np.pi * 440.0 * t)
+    elif kind == "chirp":
+        # exponential chirp 55 Hz -> 55*2^7 Hz, like tests/test_core.py:749-753
+        dur = n / SR
+        k = (55.0 * 2**7 / 55.0) ** (1.0 / dur)
+        phase = 2 * np.pi * 55.0 * (k**t - 1.0) / np.log(k)
+        y = np.broadcast_to(np.cos(phase), shape).copy()
+    else:
+        raise ValueError(kind)
+    return np.clip(y, -1.0, 1.0).astype(dtype)
+
+
+# name -> dict(signal=(kind, n, seed, channels, dtype), stft=kwargs, mel=kwargs|None, istft=bool)
+CASES = {
+    # reference test_stft sizes (tests/test_core.py:256-292)
+    "stft_n256_h64": dict(signal=("mix", 4000, 1, None, "float32"), stft=dict(n_fft=256, hop_length=64), mel=dict(n_mels=20), istft=True),
+    "stft_n256_default_hop_ones": dict(signal=("noise", 3000, 2, None, "float32"), stft=dict(n_fft=256, window="ones"), mel=None, istft=True),
+    "stft_n256_nocenter": dict(signal=("noise", 4000, 3, None, "float32"), stft=dict(n_fft=256, hop_length=128, center=False), mel=dict(n_mels=16), istft=True),
+    "stft_n501_odd": dict(signal=("noise", 3000, 4, None, "float32"), stft=dict(n_fft=501, hop_length=128), mel=None, istft=True),
+    "stft_n1023_h129": dict(signal=("mix", 8192, 5, None, "float32"), stft=dict(n_fft=1023, hop_length=129), mel=None, istft=False),
+    # headline shape at 1 s
+    "stft_n2048_h512_1s": dict(signal=("mix", 22050, 6, None, "float32"), stft=dict(n_fft=2048, hop_length=512), mel=dict(n_mels=128), istft=True),
+    # pad modes / window variants (tests/test_core.py:2583-2711 use reflect + win_length<n_fft)
+    "stft_n512_reflect": dict(signal=("chirp", 6000, 7, None, "float32"), stft=dict(n_fft=512, hop_length=128, pad_mode="reflect"), mel=dict(n_mels=40), istft=True),
+    "stft_n512_edge_win400": dict(signal=("mix", 5000, 8, None, "float32"), stft=dict(n_fft=512, hop_length=100, win_length=400, pad_mode="edge"), mel=None, istft=True),
+    "stft_n1024_blackmanharris": dict(signal=("chirp", 12000, 9, None, "float32"), stft=dict(n_fft=1024, hop_length=256, window="blackmanharris"), mel=None, istft=True),
+    "stft_n4096_h512": dict(signal=("mix", 30000, 10, None, "float32"), stft=dict(n_fft=4096, hop_length=512), mel=dict(n_mels=64), istft=True),
+    "stft_n8192_h512": dict(signal=("mix", 40000, 11, None, "float32"), stft=dict(n_fft=8192, hop_length=512), mel=None, istft=False),
+    "stft_n512_h512_hop_eq": dict(signal=("noise", 9000, 12, None, "float32"), stft=dict(n_fft=512, hop_length=512), mel=None, istft=False),
+    "stft_short_signal": dict(signal=("noise", 300, 13, None, "float32"), stft=dict(n_fft=512, hop_length=128), mel=None, istft=True),
+    # multichannel (tests/test_multichannel.py)
+    "stft_stereo_n1024": dict(signal=("noise", 6000, 14, (2,), "float32"), stft=dict(n_fft=1024, hop_length=256), mel=dict(n_mels=32), istft=True),
+    "stft_batch_2x3_n512": dict(signal=("noise", 4096, 15, (2, 3), "float32"), stft=dict(n_fft=512, hop_length=128), mel=dict(n_mels=24), istft=True),
+    # float64 -> complex128
+    "stft_f64_n2048": dict(signal=("chirp", 16000, 16, None, "float64"), stft=dict(n_fft=2048, hop_length=512), mel=dict(n_mels=128), istft=True),
+    # mel variants
+    "mel_htk_fmin_fmax": dict(signal=("mix", 16000, 17, None, "float32"), stft=dict(n_fft=1024, hop_length=256), mel=dict(n_mels=40, htk=True, fmin=50.0, fmax=8000.0), istft=False),
+    "mel_norm_none_power1": dict(signal=("mix", 16000, 18, None, "float32"), stft=dict(n_fft=2048, hop_length=512), mel=dict(n_mels=64, norm=None, power=1.0), istft=False),
+    "mel_norm_1": dict(signal=("mix", 12000, 19, None, "float32"), stft=dict(n_fft=1024, hop_length=512), mel=dict(n_mels=32, norm=1), istft=False),
+}
+
+
+def split_mel_kwargs(mel_kwargs):
+    """melspectrogram kwargs -> (power, filter kwargs)."""
+    kw = dict(mel_kwargs)
+    power = kw.pop("power", 2.0)
+    return power, kw

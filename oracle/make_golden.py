@@ -1,0 +1,93 @@
+"""Generate ``tests/golden/*.npz`` by running the UNMODIFIED reference through ``ref_shim``.
+
+TEST INFRASTRUCTURE ONLY; runs only where ``/root/reference`` exists (the build container):
+
+    python oracle/make_golden.py
+
+Each fixture stores the input PCM, the call parameters (JSON) and the reference outputs
+(``librosa.stft``, ``librosa.feature.melspectrogram``, ``librosa.istft``).  The fixtures travel to
+the GPU box with the repo; the reference tree does not.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+import golden_cases  # noqa: E402
+import ref_shim  # noqa: E402
+import stft_oracle  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+SUBSET_FRAMES_CFG1 = [0, 1, 2, 3, 215, 427, 428, 429, 430]
+SUBSET_FRAMES_CFG2 = [0, 1, 2, 3, 645, 1288, 1289, 1290, 1291]
+
+
+def main():
+    librosa = ref_shim.load_reference()
+    import scipy
+
+    os.makedirs(OUT, exist_ok=True)
+    meta = dict(numpy=np.__version__, scipy=scipy.__version__, reference_version=str(librosa.__version__))
+
+    for name, case in golden_cases.CASES.items():
+        kind, n, seed, channels, dtype = case["signal"]
+        y = golden_cases.make_signal(kind, n, seed, channels, dtype)
+        skw = dict(case["stft"])
+        D = librosa.stft(y, **skw)
+        arrays = dict(y=y, D=np.ascontiguousarray(D))
+        if case["mel"] is not None:
+            power, fkw = golden_cases.split_mel_kwargs(case["mel"])
+            mkw = {k: v for k, v in skw.items()}
+            mkw.setdefault("hop_length", int(skw.get("win_length", skw["n_fft"]) // 4))
+            arrays["mel"] = librosa.feature.melspectrogram(y=y, sr=golden_cases.SR, power=power, **mkw, **fkw)
+            arrays["mel_basis"] = librosa.filters.mel(sr=golden_cases.SR, n_fft=skw["n_fft"], **fkw)
+        if case["istft"]:
+            ikw = {k: v for k, v in skw.items() if k in ("hop_length", "win_length", "n_fft", "window", "center")}
+            arrays["y_istft_len"] = librosa.istft(D, length=y.shape[-1], **ikw)
+            arrays["y_istft_nolen"] = librosa.istft(D, **ikw)
+        np.savez_compressed(os.path.join(OUT, f"{name}.npz"), params=json.dumps(dict(case=name, **meta)), **arrays)
+        print(f"{name}: D{D.shape} {D.dtype}")
+
+    # BASELINE config 1: 10 s 440 Hz sine (stored: all mel frames, a frame subset of D)
+    y = stft_oracle.config1_input()
+    D = librosa.stft(y, n_fft=2048, hop_length=512)
+    M = librosa.feature.melspectrogram(y=y, sr=22050, n_fft=2048, hop_length=512, n_mels=128)
+    yh = librosa.istft(D, hop_length=512, length=len(y))
+    np.savez_compressed(
+        os.path.join(OUT, "config1_sine10s.npz"),
+        params=json.dumps(dict(case="config1", **meta)),
+        frames=np.array(SUBSET_FRAMES_CFG1),
+        D_frames=np.ascontiguousarray(D[:, SUBSET_FRAMES_CFG1]),
+        D_absmax=np.abs(D).max(),
+        mel=M,
+        y_istft_head=yh[:4096],
+        y_istft_tail=yh[-4096:],
+    )
+    print("config1", D.shape, M.shape)
+
+    # BASELINE config 2 clips 0 and 37 (30 s): all mel frames of clip 0, subset of clip 37, D subset
+    Y = np.stack([stft_oracle.config_input(1, first_clip=i)[0] for i in (0, 37)])
+    store = dict(clips=np.array([0, 37]), frames=np.array(SUBSET_FRAMES_CFG2))
+    for j, i in enumerate((0, 37)):
+        D = librosa.stft(Y[j], n_fft=2048, hop_length=512)
+        M = librosa.feature.melspectrogram(y=Y[j], sr=22050, n_fft=2048, hop_length=512, n_mels=128)
+        store[f"D_frames_{i}"] = np.ascontiguousarray(D[:, SUBSET_FRAMES_CFG2])
+        store[f"D_absmax_{i}"] = np.abs(D).max()
+        store[f"y_head_{i}"] = Y[j][:2048].copy()  # guards the seeded generator itself
+        if i == 0:
+            store["mel_0"] = M
+        else:
+            store[f"mel_frames_{i}"] = np.ascontiguousarray(M[:, SUBSET_FRAMES_CFG2])
+            store[f"mel_absmax_{i}"] = M.max()
+    np.savez_compressed(os.path.join(OUT, "config2_clips.npz"), params=json.dumps(dict(case="config2", **meta)), **store)
+    print("config2 done")
+
+
+if __name__ == "__main__":
+    main()

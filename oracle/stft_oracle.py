@@ -1,0 +1,379 @@
+"""CPU oracle: a NumPy restatement of librosa's STFT -> mel (+ ISTFT) hot path.
+
+TEST INFRASTRUCTURE ONLY.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import this module.  Nothing under ``librosa_amd/``
+does; the product path fails loudly when the HIP library is missing.
+
+Parity pinning
+--------------
+Every function cites the reference lines it restates (paths relative to ``/root/reference``).
+The restatement is pinned three ways (see ``tests/test_oracle.py``):
+
+1. against the reference's own known-answer vectors for this path
+   (``tests/test_filters.py:35-98`` mel-scale KATs, ``tests/test_core.py:256-292`` rfft-of-frames
+   definition of the STFT, ``tests/test_core.py:813-828`` round trip);
+2. against outputs of the reference itself, generated in the build container by importing the
+   unmodified reference through ``oracle/ref_shim.py`` and committed as fixtures under
+   ``tests/golden/`` (script: ``oracle/make_golden.py``);
+3. when ``/root/reference`` is present, live against the reference on seeded random cases.
+
+Third-party arithmetic on the path that is NOT under ``/root/reference`` and is used here
+through the very same library the reference calls: ``scipy.fft.rfft/irfft`` (pocketfft, scipy
+1.15.3 in this image; call sites ``librosa/core/spectrum.py:372,376,388,566,598``),
+``scipy.signal.get_window`` (``librosa/filters.py:968``), ``np.pad``
+(``librosa/core/spectrum.py:287,298,313``), ``np.fft.rfftfreq`` (``librosa/core/convert.py:1391``).
+
+The restatement deliberately does NOT copy the reference's head/middle/tail copy-avoidance
+split (``core/spectrum.py:273-328``) or its ``MAX_MEM_BLOCK`` column blocking (``:380-390``,
+``:588-603``): the result is *defined* (and tested by the reference,
+``tests/test_core.py:279-292``) as the rfft of the fully padded, framed, windowed signal.
+"""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+import scipy.fft
+import scipy.signal
+
+
+class ParameterError(ValueError):
+    """Mirror of ``librosa/util/exceptions.py:12`` for the oracle's own argument checks."""
+
+
+# ----------------------------------------------------------------------------- helpers (L1/L2)
+def dtype_r2c(d, default=np.complex64):
+    """``librosa/util/utils.py:2400-2416``: f32->c64, f64->c128, complex passes, else default."""
+    dt = np.dtype(d)
+    if dt.kind == "c":
+        return dt
+    return np.dtype({np.dtype(np.float32): np.complex64, np.dtype(np.float64): np.complex128}.get(dt, default))
+
+
+def dtype_c2r(d, default=np.float32):
+    """``librosa/util/utils.py:2462-2476``."""
+    dt = np.dtype(d)
+    if dt.kind == "f":
+        return dt
+    return np.dtype({np.dtype(np.complex64): np.float32, np.dtype(np.complex128): np.float64}.get(dt, default))
+
+
+def tiny(x):
+    """``librosa/util/utils.py:1985-2000``: smallest normal of x's float dtype (f32 default)."""
+    x = np.asarray(x)
+    if np.issubdtype(x.dtype, np.floating) or np.issubdtype(x.dtype, np.complexfloating):
+        dtype = x.dtype
+    else:
+        dtype = np.dtype(np.float32)
+    return np.finfo(dtype).tiny
+
+
+def pad_center(data, size):
+    """``librosa/util/utils.py:440-458`` (axis=-1, constant mode): lpad=(size-n)//2."""
+    n = data.shape[-1]
+    lpad = int((size - n) // 2)
+    if lpad < 0:
+        raise ParameterError(f"Target size ({size:d}) must be at least input size ({n:d})")
+    lengths = [(0, 0)] * data.ndim
+    lengths[-1] = (lpad, int(size - n - lpad))
+    return np.pad(data, lengths, mode="constant")
+
+
+def fix_length(data, size):
+    """``librosa/util/utils.py:570-588`` (axis=-1): truncate or zero-pad on the right."""
+    n = data.shape[-1]
+    if n > size:
+        return data[..., :size]
+    if n < size:
+        lengths = [(0, 0)] * data.ndim
+        lengths[-1] = (0, size - n)
+        return np.pad(data, lengths, mode="constant")
+    return data
+
+
+def get_window(window, Nx, fftbins=True):
+    """``librosa/filters.py:960-977``: callable / name|tuple|scalar -> scipy / explicit vector."""
+    if callable(window):
+        return window(Nx)
+    if isinstance(window, (str, tuple)) or np.isscalar(window):
+        return scipy.signal.get_window(window, Nx, fftbins=fftbins)
+    if isinstance(window, (np.ndarray, list)):
+        if len(window) == Nx:
+            return np.asarray(window)
+        raise ParameterError(f"Window size mismatch: {len(window):d} != {Nx:d}")
+    raise ParameterError(f"Invalid window specification: {window!r}")
+
+
+def normalize(S, norm=np.inf, axis=-1):
+    """``librosa/util/utils.py:960-1025`` restricted to threshold=None, fill=None."""
+    threshold = tiny(S)
+    if not np.all(np.isfinite(S)):
+        raise ParameterError("Input must be finite")
+    mag = np.abs(S).astype(float)
+    if norm is None:
+        return S
+    if norm == np.inf:
+        length = np.max(mag, axis=axis, keepdims=True)
+    elif norm == -np.inf:
+        length = np.min(mag, axis=axis, keepdims=True)
+    elif norm == 0:
+        length = np.sum(mag > 0, axis=axis, keepdims=True, dtype=mag.dtype)
+    elif np.issubdtype(type(norm), np.number) and norm > 0:
+        length = np.sum(mag**norm, axis=axis, keepdims=True) ** (1.0 / norm)
+    else:
+        raise ParameterError(f"Unsupported norm: {norm!r}")
+    small_idx = length < threshold
+    Snorm = np.empty_like(S)
+    length[small_idx] = 1.0
+    Snorm[:] = S / length
+    return Snorm
+
+
+def hz_to_mel(frequencies, htk=False):
+    """``librosa/core/convert.py:1032-1058``: Slaney (linear<1 kHz, log above) or HTK scale."""
+    frequencies = np.asanyarray(frequencies)[()]
+    if htk:
+        return 2595.0 * np.log10(1.0 + frequencies / 700.0)
+    f_min = 0.0
+    f_sp = 200.0 / 3
+    mels = (frequencies - f_min) / f_sp
+    min_log_hz = 1000.0
+    min_log_mel = (min_log_hz - f_min) / f_sp
+    logstep = np.log(6.4) / 27.0
+    if frequencies.ndim:
+        log_t = frequencies >= min_log_hz
+        mels[log_t] = min_log_mel + np.log(frequencies[log_t] / min_log_hz) / logstep
+    elif frequencies >= min_log_hz:
+        mels = min_log_mel + np.log(frequencies / min_log_hz) / logstep
+    return mels
+
+
+def mel_to_hz(mels, htk=False):
+    """``librosa/core/convert.py:1098-1121``."""
+    mels = np.asanyarray(mels)[()]
+    if htk:
+        return 700.0 * (10.0 ** (mels / 2595.0) - 1.0)
+    f_min = 0.0
+    f_sp = 200.0 / 3
+    freqs = f_min + f_sp * mels
+    min_log_hz = 1000.0
+    min_log_mel = (min_log_hz - f_min) / f_sp
+    logstep = np.log(6.4) / 27.0
+    if mels.ndim:
+        log_t = mels >= min_log_mel
+        freqs[log_t] = min_log_hz * np.exp(logstep * (mels[log_t] - min_log_mel))
+    elif mels >= min_log_mel:
+        freqs = min_log_hz * np.exp(logstep * (mels - min_log_mel))
+    return freqs
+
+
+def fft_frequencies(sr=22050, n_fft=2048):
+    """``librosa/core/convert.py:1391``."""
+    return np.fft.rfftfreq(n=n_fft, d=1.0 / sr)
+
+
+def mel_frequencies(n_mels=128, fmin=0.0, fmax=11025.0, htk=False):
+    """``librosa/core/convert.py:1505-1511``: linspace in mel, mapped back to Hz."""
+    min_mel = hz_to_mel(fmin, htk=htk)
+    max_mel = hz_to_mel(fmax, htk=htk)
+    mels = np.linspace(min_mel, max_mel, n_mels)
+    return mel_to_hz(mels, htk=htk)
+
+
+def mel(*, sr, n_fft, n_mels=128, fmin=0.0, fmax=None, htk=False, norm="slaney", dtype=np.float32):
+    """``librosa/filters.py:206-251``: triangles in f64, stored in ``dtype``, slaney area norm."""
+    if fmax is None:
+        fmax = float(sr) / 2
+    n_mels = int(n_mels)
+    weights = np.zeros((n_mels, int(1 + n_fft // 2)), dtype=dtype)
+    fftfreqs = fft_frequencies(sr=sr, n_fft=n_fft)
+    mel_f = mel_frequencies(n_mels + 2, fmin=fmin, fmax=fmax, htk=htk)
+    fdiff = np.diff(mel_f)
+    ramps = np.subtract.outer(mel_f, fftfreqs)
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        weights[i] = np.maximum(0, np.minimum(lower, upper))
+    if isinstance(norm, str):
+        if norm == "slaney":
+            enorm = 2.0 / (mel_f[2 : n_mels + 2] - mel_f[:n_mels])
+            weights *= enorm[:, np.newaxis]
+        else:
+            raise ParameterError(f"Unsupported norm={norm}")
+    else:
+        weights = normalize(weights, norm=norm, axis=-1)
+    if not np.all((mel_f[:-2] == 0) | (weights.max(axis=1) > 0)):
+        warnings.warn("Empty filters detected in mel frequency basis.", stacklevel=2)
+    return weights
+
+
+def window_sumsquare(*, window, n_frames, hop_length=512, win_length=None, n_fft=2048, dtype=np.float32, norm=None):
+    """``librosa/filters.py:1325-1339`` + fill loop ``:1258-1265``.
+
+    The accumulator has ``dtype`` (f32 by default) while ``win_sq`` is f64, exactly as in the
+    reference: each ``+=`` is an f64 add rounded back to ``dtype``.
+    """
+    if win_length is None:
+        win_length = n_fft
+    n = n_fft + hop_length * (n_frames - 1)
+    x = np.zeros(n, dtype=dtype)
+    win_sq = get_window(window, win_length)
+    win_sq = normalize(win_sq, norm=norm) ** 2
+    win_sq = pad_center(win_sq, size=n_fft)
+    for i in range(n_frames):
+        sample = i * hop_length
+        x[sample : min(n, sample + n_fft)] += win_sq[: max(0, min(n_fft, n - sample))]
+    return x
+
+
+# ----------------------------------------------------------------------------- L3: stft / istft
+def _frame(x, frame_length, hop_length):
+    """``librosa/util/utils.py:210-242`` (axis=-1): (..., n) -> (..., frame_length, n_frames) view."""
+    if x.shape[-1] < frame_length:
+        raise ParameterError(f"Input is too short (n={x.shape[-1]:d}) for frame_length={frame_length:d}")
+    xw = np.lib.stride_tricks.sliding_window_view(x, frame_length, axis=-1)  # (..., n-L+1, L)
+    xw = np.moveaxis(xw, -1, -2)
+    return xw[..., ::hop_length]
+
+
+_BAD_PAD_MODES = ("wrap", "maximum", "mean", "median", "minimum")
+
+
+def stft(y, *, n_fft=2048, hop_length=None, win_length=None, window="hann", center=True, dtype=None, pad_mode="constant"):
+    """``librosa/core/spectrum.py:230-391``.
+
+    D[..., f, t] = rfft(w * yhat[..., t*hop : t*hop + n_fft])[f]; the f64 window times the
+    framed signal is an f64 product, pocketfft runs in double, and the result is rounded once to
+    the output complex dtype (``:340-341, :388-390``).
+    """
+    if win_length is None:
+        win_length = n_fft
+    if hop_length is None:
+        hop_length = int(win_length // 4)
+    elif not (isinstance(hop_length, (int, np.integer)) and hop_length > 0):
+        raise ParameterError(f"hop_length={hop_length} must be a positive integer")
+    if not np.isfinite(y).all():
+        raise ParameterError("Audio buffer is not finite everywhere")
+    fft_window = pad_center(get_window(window, win_length, fftbins=True), size=n_fft)
+    fft_window = fft_window.reshape((1,) * (y.ndim - 1) + (n_fft, 1))
+    if center:
+        if pad_mode in _BAD_PAD_MODES:
+            raise ParameterError(f"pad_mode='{pad_mode}' is not supported by librosa.stft")
+        padding = [(0, 0)] * y.ndim
+        padding[-1] = (n_fft // 2, n_fft // 2)
+        y = np.pad(y, padding, mode=pad_mode)
+    elif n_fft > y.shape[-1]:
+        raise ParameterError(f"n_fft={n_fft} is too large for uncentered analysis of input signal of length={y.shape[-1]}")
+    if dtype is None:
+        dtype = dtype_r2c(y.dtype)
+    y_frames = _frame(y, n_fft, hop_length)
+    shape = list(y_frames.shape)
+    shape[-2] = 1 + n_fft // 2
+    D = np.zeros(shape, dtype=dtype, order="F")
+    # bounded-memory blocking (not the reference's block size; blocking does not change values)
+    n_frames = y_frames.shape[-1]
+    lead = int(np.prod(y_frames.shape[:-1]))
+    block = max(1, (1 << 24) // max(1, lead))
+    for s in range(0, n_frames, block):
+        t = min(n_frames, s + block)
+        D[..., s:t] = scipy.fft.rfft(fft_window * y_frames[..., s:t], axis=-2)
+    return D
+
+
+def istft(D, *, hop_length=None, win_length=None, n_fft=None, window="hann", center=True, dtype=None, length=None):
+    """``librosa/core/spectrum.py:506-626`` + ``__overlap_add`` ``:629-643``.
+
+    Frames are inverse-transformed (c64 -> f32 irfft, c128 -> f64), multiplied by the f64 window
+    and added in increasing frame order into a buffer of the output dtype, then divided by the
+    window sum-square where it exceeds ``tiny``.  The head block / offset bookkeeping of the
+    reference (``:557-603``) is equivalent to adding frame t at padded position t*hop and
+    dropping the first n_fft//2 samples; frames used are [0, min(T, start_frame)) from the head
+    block plus [start_frame, n_frames) from the main loop.
+    """
+    if n_fft is None:
+        n_fft = 2 * (D.shape[-2] - 1)
+    if win_length is None:
+        win_length = n_fft
+    if hop_length is None:
+        hop_length = int(win_length // 4)
+    ifft_window = pad_center(get_window(window, win_length, fftbins=True), size=n_fft)
+    if length:
+        padded_length = length + 2 * (n_fft // 2) if center else length
+        n_frames = min(D.shape[-1], int(np.ceil(padded_length / hop_length)))
+    else:
+        n_frames = D.shape[-1]
+    if dtype is None:
+        dtype = dtype_c2r(D.dtype)
+    expected_signal_len = n_fft + hop_length * (n_frames - 1)
+    if length:
+        expected_signal_len = length
+    elif center:
+        expected_signal_len -= 2 * (n_fft // 2)
+    lead = D.shape[:-2]
+    if center:
+        start_frame = int(np.ceil((n_fft // 2) / hop_length))
+        used = max(n_frames, min(D.shape[-1], start_frame))
+        drop = n_fft // 2
+    else:
+        used = n_frames
+        drop = 0
+    # accumulate in the padded coordinate system, in the output dtype, frame by frame
+    total = max(drop + expected_signal_len, 0)
+    buf = np.zeros(lead + (total,), dtype=dtype)
+    for t in range(used):
+        s = t * hop_length
+        if s >= total:
+            break
+        ytmp = ifft_window * scipy.fft.irfft(D[..., t], n=n_fft, axis=-1)
+        N = min(n_fft, total - s)
+        buf[..., s : s + N] += ytmp[..., :N]
+    y = np.ascontiguousarray(buf[..., drop : drop + expected_signal_len])
+    wss = window_sumsquare(window=window, n_frames=n_frames, win_length=win_length, n_fft=n_fft, hop_length=hop_length, dtype=dtype)
+    wss = fix_length(wss[drop:], size=y.shape[-1])
+    nz = wss > tiny(wss)
+    y[..., nz] /= wss[nz]
+    return y
+
+
+# ----------------------------------------------------------------------------- L4: spectrogram / mel
+def spectrogram(*, y=None, S=None, n_fft=2048, hop_length=512, power=1, win_length=None, window="hann", center=True, pad_mode="constant"):
+    """``librosa/core/spectrum.py:2988-3015`` (``_spectrogram``): abs(stft)**power or pass-through."""
+    if S is not None:
+        if n_fft is None or n_fft // 2 + 1 != S.shape[-2]:
+            n_fft = 2 * (S.shape[-2] - 1)
+    else:
+        if n_fft is None:
+            raise ParameterError(f"Unable to compute spectrogram with n_fft={n_fft}")
+        if y is None:
+            raise ParameterError("Input signal must be provided to compute a spectrogram")
+        S = np.abs(stft(y, n_fft=n_fft, hop_length=hop_length, win_length=win_length, center=center, window=window, pad_mode=pad_mode)) ** power
+    return S, n_fft
+
+
+def melspectrogram(*, y=None, sr=22050, S=None, n_fft=2048, hop_length=512, win_length=None, window="hann", center=True, pad_mode="constant", power=2.0, **kwargs):
+    """``librosa/feature/spectral.py:2145-2161``: einsum('...ft,mf->...mt', S, mel_basis)."""
+    S, n_fft = spectrogram(y=y, S=S, n_fft=n_fft, hop_length=hop_length, power=power, win_length=win_length, window=window, center=center, pad_mode=pad_mode)
+    mel_basis = mel(sr=sr, n_fft=n_fft, **kwargs)
+    return np.einsum("...ft,mf->...mt", S, mel_basis, optimize=True)
+
+
+# ----------------------------------------------------------------------------- synthetic inputs
+def config_input(batch, n=661500, sr=22050, seed=440, first_clip=0):
+    """SURVEY.md 8(d) config-2/3 generator: 0.1*noise + 0.5*sin(2 pi f_i t), f_i = 110*2^((i%72)/12).
+
+    Clip ``i`` depends only on (seed, i), so shards generated on different ranks agree with the
+    unsharded batch.
+    """
+    t = np.arange(n, dtype=np.float64) / sr
+    out = np.empty((batch, n), dtype=np.float32)
+    for b in range(batch):
+        i = first_clip + b
+        rng = np.random.default_rng([seed, i])
+        f = 110.0 * 2.0 ** ((i % 72) / 12.0)
+        out[b] = np.clip(0.1 * rng.standard_normal(n) + 0.5 * np.sin(2 * np.pi * f * t), -1.0, 1.0).astype(np.float32)
+    return out
+
+
+def config1_input():
+    """10 s, 440 Hz sine at 22.05 kHz, f32."""
+    return np.sin(2 * np.pi * 440.0 * np.arange(220500) / 22050.0).astype(np.float32)

@@ -1,0 +1,222 @@
+"""Pins the CPU oracle (oracle/stft_oracle.py): reference KATs, committed reference outputs, and
+(when /root/reference exists) the live reference.  CPU only."""
+import glob
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+import golden_cases
+import ref_shim
+import stft_oracle as O
+
+from conftest import GOLDEN_DIR
+
+
+# ---- reference known-answer vectors: tests/test_filters.py:35-98 (reference repo) -------------
+def test_hz_to_mel_kat_slaney():
+    freqs = np.array([0, 500, 1000, 2000, 3000])
+    mels = np.array([0.0, 7.5, 15.0, 25.08188016, 30.97940199])
+    assert np.allclose(O.hz_to_mel(freqs), mels)
+    for f, m in zip(freqs, mels):
+        assert np.isclose(O.hz_to_mel(f), m)
+
+
+def test_hz_to_mel_kat_htk():
+    # tests/test_filters.py:35-46 (reference repo)
+    freqs = np.array([0, 500, 1000, 2000, 3000])
+    mels = np.array([0.0, 607.44591966, 999.98553714, 1521.35955416, 1876.45406012])
+    assert np.allclose(O.hz_to_mel(freqs, htk=True), mels)
+    for f, m in zip(freqs, mels):
+        assert np.isclose(O.hz_to_mel(f, htk=True), m)
+
+
+def test_mel_to_hz_kat():
+    # tests/test_filters.py:63-98 (reference repo)
+    mels = np.array([0.0, 200, 400, 600, 800, 1000, 1200, 1400, 1600, 1800])
+    freqs = np.array([0.0, 135.92888249, 298.25299511, 492.09787234, 723.58434605, 1000.02181646,
+                      1330.13905319, 1724.35981432, 2195.13198618, 2757.32063694])
+    assert np.allclose(O.mel_to_hz(mels, htk=True), freqs)
+    for f, m in zip(freqs, mels):
+        assert np.isclose(O.mel_to_hz(m, htk=True), f)
+    mels = np.array([0, 5, 10, 15, 25, 30])
+    freqs = np.array([0.0, 333.33333333, 666.66666667, 1000.0, 1988.77281813, 2804.64413074])
+    assert np.allclose(O.mel_to_hz(mels, htk=False), freqs)
+    for f, m in zip(freqs, mels):
+        assert np.isclose(O.mel_to_hz(m, htk=False), f)
+
+
+def test_mel_to_hz_inverse():
+    f = np.array([0.0, 220.0, 999.0, 1000.0, 4000.0, 11025.0])
+    for htk in (False, True):
+        np.testing.assert_allclose(O.mel_to_hz(O.hz_to_mel(f, htk=htk), htk=htk), f, rtol=1e-10, atol=1e-9)
+
+
+def test_fft_frequencies():
+    # tests/test_convert.py:314-325: DC = 0, Nyquist = sr/2, linear
+    f = O.fft_frequencies(sr=22050, n_fft=2048)
+    assert f[0] == 0 and f[-1] == 11025.0 and len(f) == 1025
+    np.testing.assert_allclose(np.diff(f), 22050 / 2048)
+
+
+def test_mel_basis_properties():
+    # tests/test_filters.py:120-189: shape, non-negativity, slaney area normalisation
+    B = O.mel(sr=22050, n_fft=2048, n_mels=128)
+    assert B.shape == (128, 1025) and B.dtype == np.float32 and (B >= 0).all()
+    assert abs(float(B[0, 1]) - 0.016182853) < 1e-9  # filters.py:185 docstring value
+    assert np.count_nonzero(B) == 2018
+    assert (np.count_nonzero(B, axis=0) <= 2).all()
+    mel_f = O.mel_frequencies(130, fmin=0.0, fmax=11025.0)
+    df = 22050 / 2048
+    assert np.all(np.abs(B.sum(axis=1) * df - 1) < 5e-2)
+    with pytest.raises(O.ParameterError):
+        O.mel(sr=22050, n_fft=2048, norm="bogus")
+
+
+def test_window_matches_scipy_and_sumsquare_interior():
+    w = O.get_window("hann", 2048)
+    n = np.arange(2048)
+    np.testing.assert_allclose(w, 0.5 - 0.5 * np.cos(2 * np.pi * n / 2048), atol=3e-16)
+    wss = O.window_sumsquare(window="hann", n_frames=50, hop_length=512, n_fft=2048)
+    np.testing.assert_allclose(wss[2048:-2048], 1.5, rtol=1e-6)
+    assert wss.dtype == np.float32 and len(wss) == 2048 + 512 * 49
+
+
+# ---- the reference's own definition of the STFT: tests/test_core.py:256-292 ---------------------
+@pytest.mark.parametrize("n_fft", [256, 501])
+@pytest.mark.parametrize("window", ["hann", "ones"])
+@pytest.mark.parametrize("hop", [None, 128])
+@pytest.mark.parametrize("center", [False, True])
+def test_stft_is_rfft_of_frames(n_fft, window, hop, center):
+    import scipy.fft
+    import scipy.signal
+    y = golden_cases.make_signal("chirp", 22050, 0)
+    D = O.stft(y, n_fft=n_fft, hop_length=hop, window=window, center=center)
+    h = hop or n_fft // 4
+    if center:
+        assert D.shape == (1 + n_fft // 2, 1 + len(y) // h)
+        yp = np.pad(y, n_fft // 2)
+    else:
+        assert D.shape == (1 + n_fft // 2, 1 + (len(y) - n_fft) // h)
+        yp = y
+    w = scipy.signal.get_window(window, n_fft, fftbins=True)
+    for t in (0, 1, D.shape[1] // 2, D.shape[1] - 1):
+        ref = scipy.fft.rfft(w * yp[t * h : t * h + n_fft])
+        assert np.allclose(D[:, t], ref, rtol=1e-5, atol=1e-6)
+
+
+def test_stft_errors():
+    y = np.zeros(100, dtype=np.float32)
+    with pytest.raises(O.ParameterError):
+        O.stft(y, n_fft=256, center=False)
+    with pytest.raises(O.ParameterError):
+        O.stft(np.zeros(1000, np.float32), n_fft=256, pad_mode="wrap")
+    with pytest.raises(O.ParameterError):
+        O.stft(np.zeros(1000, np.float32), n_fft=256, hop_length=0)
+
+
+# ---- committed reference outputs ---------------------------------------------------------------
+def _cases():
+    return sorted(golden_cases.CASES)
+
+
+@pytest.mark.parametrize("name", _cases())
+def test_oracle_vs_golden(name):
+    case = golden_cases.CASES[name]
+    g = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))
+    y = g["y"]
+    # the seeded generator must reproduce the stored input bit-for-bit
+    kind, n, seed, channels, dtype = case["signal"]
+    assert np.array_equal(golden_cases.make_signal(kind, n, seed, channels, dtype), y)
+    skw = dict(case["stft"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        D = O.stft(y, **skw)
+    assert D.shape == g["D"].shape and D.dtype == g["D"].dtype
+    scale = np.abs(g["D"]).max()
+    assert np.abs(D - g["D"]).max() <= 1e-6 * scale
+    if case["mel"] is not None:
+        power, fkw = golden_cases.split_mel_kwargs(case["mel"])
+        mkw = dict(skw)
+        mkw.setdefault("hop_length", int(skw.get("win_length", skw["n_fft"]) // 4))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            M = O.melspectrogram(y=y, sr=golden_cases.SR, power=power, **mkw, **fkw)
+        assert M.shape == g["mel"].shape and M.dtype == g["mel"].dtype
+        np.testing.assert_allclose(M, g["mel"], rtol=1e-5, atol=1e-6 * g["mel"].max())
+        B = O.mel(sr=golden_cases.SR, n_fft=skw["n_fft"], **fkw)
+        assert np.array_equal(B, g["mel_basis"])
+    if case["istft"]:
+        ikw = {k: v for k, v in skw.items() if k in ("hop_length", "win_length", "n_fft", "window", "center")}
+        y1 = O.istft(g["D"], length=y.shape[-1], **ikw)
+        y2 = O.istft(g["D"], **ikw)
+        assert y1.shape == g["y_istft_len"].shape and y2.shape == g["y_istft_nolen"].shape
+        np.testing.assert_allclose(y1, g["y_istft_len"], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(y2, g["y_istft_nolen"], rtol=0, atol=2e-6)
+
+
+def test_oracle_vs_golden_config1():
+    g = np.load(os.path.join(GOLDEN_DIR, "config1_sine10s.npz"))
+    y = O.config1_input()
+    D = O.stft(y, n_fft=2048, hop_length=512)
+    assert D.shape == (1025, 431) and D.dtype == np.complex64
+    assert np.abs(D[:, g["frames"]] - g["D_frames"]).max() <= 1e-6 * g["D_absmax"]
+    M = O.melspectrogram(y=y, sr=22050, n_fft=2048, hop_length=512, n_mels=128)
+    np.testing.assert_allclose(M, g["mel"], rtol=1e-5, atol=1e-6 * g["mel"].max())
+    yh = O.istft(D, hop_length=512, length=len(y))
+    np.testing.assert_allclose(yh[:4096], g["y_istft_head"], atol=2e-6)
+    np.testing.assert_allclose(yh[-4096:], g["y_istft_tail"], atol=2e-6)
+    snr = 10 * np.log10(np.sum(y.astype(np.float64) ** 2) / np.sum((y - yh).astype(np.float64) ** 2))
+    assert snr > 100
+
+
+def test_oracle_vs_golden_config2():
+    g = np.load(os.path.join(GOLDEN_DIR, "config2_clips.npz"))
+    for i in (0, 37):
+        y = O.config_input(1, first_clip=i)[0]
+        assert np.array_equal(y[:2048], g[f"y_head_{i}"])
+        D = O.stft(y, n_fft=2048, hop_length=512)
+        assert D.shape == (1025, 1292)
+        assert np.abs(D[:, g["frames"]] - g[f"D_frames_{i}"]).max() <= 1e-6 * g[f"D_absmax_{i}"]
+        M = O.melspectrogram(y=y, sr=22050, n_fft=2048, hop_length=512, n_mels=128)
+        assert M.shape == (128, 1292)
+        if i == 0:
+            np.testing.assert_allclose(M, g["mel_0"], rtol=1e-5, atol=1e-6 * g["mel_0"].max())
+        else:
+            np.testing.assert_allclose(M[:, g["frames"]], g[f"mel_frames_{i}"], rtol=1e-5, atol=1e-6 * g[f"mel_absmax_{i}"])
+
+
+def test_config_input_is_shard_invariant():
+    a = O.config_input(4, n=4096)
+    b = np.concatenate([O.config_input(2, n=4096, first_clip=0), O.config_input(2, n=4096, first_clip=2)])
+    assert np.array_equal(a, b)
+
+
+# ---- live reference (build container only) ------------------------------------------------------
+@pytest.mark.skipif(not ref_shim.available(), reason="/root/reference not present (GPU box)")
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_oracle_vs_live_reference(seed):
+    librosa = ref_shim.load_reference()
+    rng = np.random.default_rng(seed)
+    n_fft = int(rng.choice([256, 400, 512, 1024, 1025, 2048]))
+    hop = int(rng.integers(n_fft // 8, n_fft // 2))
+    n = int(rng.integers(2 * n_fft, 6 * n_fft))
+    y = rng.standard_normal((2, n)).astype(np.float32)
+    pad_mode = str(rng.choice(["constant", "reflect", "edge"]))
+    D0 = librosa.stft(y, n_fft=n_fft, hop_length=hop, pad_mode=pad_mode)
+    D1 = O.stft(y, n_fft=n_fft, hop_length=hop, pad_mode=pad_mode)
+    assert np.abs(D0 - D1).max() <= 1e-6 * np.abs(D0).max()
+    # (lengths that cut whole frames off the end make the reference itself raise: its
+    #  __overlap_add, core/spectrum.py:640-643, gets a negative N; not a defined behaviour)
+    for length in (None, n, n - 37, n + 100):
+        y0 = librosa.istft(D0, hop_length=hop, n_fft=n_fft, length=length)
+        y1 = O.istft(D0, hop_length=hop, n_fft=n_fft, length=length)
+        assert y0.shape == y1.shape
+        np.testing.assert_allclose(y0, y1, atol=2e-6)
+    M0 = librosa.feature.melspectrogram(y=y, sr=22050, n_fft=n_fft, hop_length=hop, n_mels=40, pad_mode=pad_mode)
+    M1 = O.melspectrogram(y=y, sr=22050, n_fft=n_fft, hop_length=hop, n_mels=40, pad_mode=pad_mode)
+    np.testing.assert_allclose(M0, M1, rtol=1e-5, atol=1e-6 * M0.max())
+    wss0 = librosa.filters.window_sumsquare(window="hann", n_frames=17, hop_length=hop, n_fft=n_fft)
+    assert np.array_equal(wss0, O.window_sumsquare(window="hann", n_frames=17, hop_length=hop, n_fft=n_fft))
