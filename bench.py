@@ -1,0 +1,222 @@
+#!/usr/bin/env python
+"""bench.py -- STFT+mel frames/sec on MI355X (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path -- feature.melspectrogram (fused framing + window + FFT +
+|X|^2 + banded mel, one kernel launch) -- over one batch of synthetic 22.05 kHz clips already
+resident in HBM: BASELINE.json configs[1], batch=256 clips x 30 s, n_fft=2048 hop=512 n_mels=128,
+per GPU (weak scaling: clips are independent, every rank gets its own 256, no data-path collective).
+Plans/tables are created outside the timed region.  The timed region is bracketed by a
+barrier + device synchronize on both sides; the max over ranks is reported.
+
+Extra keys on the JSON line:
+  roofline       dominant kernel of the step (the fused mel kernel): algorithmic bytes / HIP-event time
+  roofline_stft  the complex64-out STFT kernel on the same input (the north star's >=70 %-of-HBM bar
+                 is attached to this kernel: 10 248 B/frame), timed in the same process
+  cpu_baseline   the NumPy/scipy.fft oracle (a port of the reference path) on this box's host cores,
+                 rank 0 at N=1 only, on a bounded sample of the same workload
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SR, N_FFT, HOP, N_MELS = 22050, 2048, 512, 128
+CLIP_SECONDS = 30
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+BYTES_PER_FRAME_MEL = HOP * 4 + N_MELS * 4            # 2 560 B: PCM read once + mel written once
+BYTES_PER_FRAME_STFT = HOP * 4 + (N_FFT // 2 + 1) * 8  # 10 248 B: PCM read once + complex64 spectrum written once
+
+
+def make_batch(torch, batch, n, first_clip, device):
+    """SURVEY.md 8(d) config-2 style input generated on the device: 0.1*noise + 0.5*tone(f_i), clipped."""
+    g = torch.Generator(device=device)
+    g.manual_seed(440 + first_clip)
+    t = torch.arange(n, device=device, dtype=torch.float32) / SR
+    idx = torch.arange(first_clip, first_clip + batch, device=device)
+    f = 110.0 * torch.pow(torch.tensor(2.0, device=device), (idx % 72).float() / 12.0)
+    y = 0.1 * torch.randn(batch, n, device=device, generator=g)
+    y += 0.5 * torch.sin(2 * np.pi * f[:, None] * t[None, :])
+    return y.clamp_(-1.0, 1.0).contiguous()
+
+
+def cpu_baseline(seconds=12.0):
+    """Oracle (NumPy restatement of the reference path, oracle/stft_oracle.py) timed on this host, 1 core."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import stft_oracle as O
+
+    import contextlib
+
+    try:
+        from threadpoolctl import threadpool_limits
+
+        limiter = threadpool_limits(limits=1)
+    except Exception:  # pragma: no cover
+        limiter = contextlib.nullcontext()
+    y = O.config_input(4, n=SR * CLIP_SECONDS)
+    O.melspectrogram(y=y[0], sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS)  # warm
+    frames = 0
+    clips = 0
+    with limiter:
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            M = O.melspectrogram(y=y[clips % 4], sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS)
+            frames += M.shape[-1]
+            clips += 1
+    dt = time.perf_counter() - t0
+    return {
+        "value": frames / dt,
+        "unit": "frames/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{clips} clips x {CLIP_SECONDS} s melspectrogram (n_fft={N_FFT} hop={HOP} n_mels={N_MELS}) in {dt:.1f} s, "
+                  f"1 process, BLAS limited to 1 thread; host has {os.cpu_count()} logical cores",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sweep", action="store_true", help="time kernel tuning variants (development aid), prints extra lines to stderr")
+    ap.add_argument("--variant", type=int, default=None)
+    ap.add_argument("--iters", type=int, default=None)
+    args = ap.parse_args()
+
+    import torch
+
+    import librosa_amd as L
+    from librosa_amd import filters
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    n = SR * CLIP_SECONDS
+    batch = args.batch
+    y = make_batch(torch, batch, n, rank * batch, device)
+    ctx = L.get_context(local_rank)
+    ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
+    if args.variant is not None:
+        ctx.set_option("variant", args.variant)
+    if args.iters is not None:
+        ctx.set_option("stft_iters", args.iters)
+    window = np.asarray(filters.get_window("hann", N_FFT, fftbins=True), dtype=np.float32)
+    plan = ctx.stft_plan(N_FFT, HOP, window, True, "constant", np.float32)
+    mel_plan = ctx.mel_plan(filters.mel(sr=SR, n_fft=N_FFT, n_mels=N_MELS))
+    n_frames = ctx.stft_num_frames(plan, n)
+    frames_per_step = batch * n_frames
+    M = torch.empty((batch, N_MELS, n_frames), dtype=torch.float32, device=device)
+    D = torch.empty((batch, n_frames, N_FFT // 2 + 1), dtype=torch.complex64, device=device)
+    yp, Mp, Dp = y.data_ptr(), M.data_ptr(), D.data_ptr()
+
+    def step_mel():
+        ctx.melspectrogram_exec(plan, mel_plan, yp, batch, n, n, 2.0, Mp)
+
+    def step_stft():
+        ctx.stft_exec(plan, yp, batch, n, n, Dp)
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        barrier()
+        e0, e1 = ctx.event(), ctx.event()
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(steps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(device)
+        wall = time.perf_counter() - t0
+        barrier()
+        return wall, e0.elapsed_ms(e1) / 1e3
+
+    if args.sweep and rank == 0:
+        for variant in range(4):
+            for iters in (1, 2, 4, 8, 16, 32):
+                ctx.set_option("variant", variant)
+                ctx.set_option("stft_iters", iters)
+                _, ev_m = timed(step_mel, args.steps, 3)
+                _, ev_s = timed(step_stft, args.steps, 3)
+                fm, fs = frames_per_step * args.steps / ev_m, frames_per_step * args.steps / ev_s
+                print(f"[sweep] variant={variant} iters={iters:2d}  mel {fm / 1e6:8.1f} Mframes/s ({fm * BYTES_PER_FRAME_MEL / 1e9:7.0f} GB/s)   "
+                      f"stft {fs / 1e6:8.1f} Mframes/s ({fs * BYTES_PER_FRAME_STFT / 1e9:7.0f} GB/s = {fs * BYTES_PER_FRAME_STFT / 1e9 / HBM_PEAK_GBS:.1%} of HBM peak)",
+                      file=sys.stderr, flush=True)
+        ctx.set_option("variant", args.variant or 0)
+        ctx.set_option("stft_iters", args.iters or 0)
+
+    wall, ev = timed(step_mel, args.steps, args.warmup)
+    if world > 1:
+        tw = torch.tensor([wall], dtype=torch.float64, device=device)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+    _, ev_stft = timed(step_stft, args.steps, args.warmup)
+
+    if rank == 0:
+        total_frames = frames_per_step * args.steps * world
+        value = total_frames / wall
+        launch_s = ev / args.steps
+        achieved = frames_per_step * BYTES_PER_FRAME_MEL / launch_s / 1e9
+        stft_launch_s = ev_stft / args.steps
+        achieved_stft = frames_per_step * BYTES_PER_FRAME_STFT / stft_launch_s / 1e9
+        line = {
+            "metric": "STFT+mel frames/sec (n_fft=2048 hop=512)",
+            "value": value,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"feature.melspectrogram: batch={batch} clips x {CLIP_SECONDS} s @ 22.05 kHz per GPU, n_fft={N_FFT} hop={HOP} n_mels={N_MELS}, "
+                                   f"inputs resident in HBM, outputs left sharded (no gather)", "frames_per_step_per_gpu": frames_per_step,
+                       "parallelism": f"clips sharded over {world} GPU(s), no collective on the data path", "device": ctx.device_name()},
+            "roofline": {"bound": "hbm", "kernel": "stft_kernel<n_fft=2048, OUT_MEL> (fused melspectrogram)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_frame": BYTES_PER_FRAME_MEL,
+                         "launch_ms": launch_s * 1e3, "frames_per_s_single_gpu": frames_per_step / launch_s,
+                         "note": "this kernel sits on the VALU side of the ridge (~65 kFLOP per 2 560 B); see roofline_stft for the HBM-bound kernel"},
+            "roofline_stft": {"bound": "hbm", "kernel": "stft_kernel<n_fft=2048, OUT_COMPLEX> (librosa.stft, complex64 out)", "achieved": achieved_stft,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_stft / HBM_PEAK_GBS, "traffic": None,
+                              "bytes_per_frame": BYTES_PER_FRAME_STFT, "launch_ms": stft_launch_s * 1e3, "frames_per_s_single_gpu": frames_per_step / stft_launch_s},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

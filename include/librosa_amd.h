@@ -1,0 +1,141 @@
+/* librosa_amd.h -- C ABI of the MI355X (gfx950) implementation of librosa's STFT -> mel (+ ISTFT)
+ * hot path.
+ *
+ * The reference (librosa, pure Python) exposes no C ABI / FFI for this path; its only swap point
+ * is scipy.fft's uarray backend at the rfft/irfft call sites (librosa/core/spectrum.py:372,376,
+ * 388,566,598), which hands over host float64 blocks of <= 32 frames and is the wrong granularity
+ * for a GPU.  The drop-in boundary is therefore librosa's Python function level,
+ * and this header is what the Python shim (librosa_amd/, ctypes) binds underneath it.  Every entry
+ * point cites the reference code whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 (LRA_OK) or a negative LRA_E* code, and
+ *     lra_last_error() returns the message of the calling thread's last failure;
+ *   - every data pointer is a DEVICE pointer unless the parameter is documented as "host";
+ *     the caller owns all buffers; the library never frees or reallocates them;
+ *   - all work is enqueued on the context's stream (its own, or one adopted with
+ *     lra_ctx_set_stream, e.g. PyTorch's current stream); calls are asynchronous with respect to
+ *     the host unless documented otherwise;
+ *   - device layouts are row-major:  PCM y[batch][n];  spectrum D[batch][n_frames][n_bins]
+ *     (n_bins = 1 + n_fft/2, interleaved re/im) -- librosa's (..., n_bins, n_frames) array is a
+ *     transposed view of this buffer, exactly like the Fortran-ordered array the reference
+ *     allocates (core/spectrum.py:356);  mel M[batch][n_mels][n_frames] (C order, as the
+ *     reference's einsum returns, feature/spectral.py:2160).
+ */
+#ifndef LIBROSA_AMD_H
+#define LIBROSA_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LRA_OK 0
+#define LRA_EINVAL (-1)   /* bad argument (maps to librosa.ParameterError in the shim) */
+#define LRA_EHIP (-2)     /* HIP runtime error */
+#define LRA_EROCFFT (-3)  /* rocFFT error */
+#define LRA_ENODEV (-4)   /* no usable gfx950 device */
+#define LRA_ENOMEM (-5)
+
+#define LRA_F32 0 /* float32 PCM  <-> complex64  spectrum (util.dtype_r2c, util/utils.py:2404-2416) */
+#define LRA_F64 1 /* float64 PCM  <-> complex128 spectrum */
+
+/* np.pad modes that depend only on edge values (the ones stft supports natively on the device;
+ * the shim pre-pads for the exotic ones; "wrap/maximum/mean/median/minimum" are rejected as in
+ * core/spectrum.py:253-265). */
+#define LRA_PAD_CONSTANT 0
+#define LRA_PAD_REFLECT 1
+#define LRA_PAD_EDGE 2
+#define LRA_PAD_SYMMETRIC 3
+
+typedef struct lra_ctx lra_ctx;
+typedef struct lra_event lra_event;
+typedef struct lra_stft_plan lra_stft_plan;
+typedef struct lra_mel_plan lra_mel_plan;
+typedef struct lra_istft_plan lra_istft_plan;
+
+/* ---- library / context ------------------------------------------------------------------ */
+const char* lra_last_error(void);
+const char* lra_version(void);
+int lra_device_count(int* count);
+/* One context = one device + one stream + error state.  Fails with LRA_ENODEV when no GPU. */
+int lra_ctx_create(int device, lra_ctx** out);
+void lra_ctx_destroy(lra_ctx* ctx);
+/* Adopt an existing hipStream_t (NULL restores the context's own stream). */
+int lra_ctx_set_stream(lra_ctx* ctx, void* hip_stream);
+int lra_ctx_sync(lra_ctx* ctx);
+/* Tuning knobs: "stft_iters" (frame groups per workgroup), "istft_strip_groups", "variant". */
+int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value);
+int lra_ctx_device_name(lra_ctx* ctx, char* buf, size_t buflen);
+/* Device-side half of util.valid_audio (librosa/util/utils.py:294-306): the fused power-of-two STFT
+ * kernels raise a sticky flag when a frame's DC bin is not finite, which (barring overflow) happens
+ * iff some sample of the frame is NaN/Inf.  reset clears it (async); read syncs the stream. */
+int lra_ctx_nonfinite_reset(lra_ctx* ctx);
+int lra_ctx_nonfinite_read(lra_ctx* ctx, int* flag);
+/* 1 when the plan runs the fused power-of-two kernels (and therefore feeds the flag above). */
+int lra_stft_plan_is_fused(const lra_stft_plan* plan);
+
+/* device memory helpers for hosts that do not bring their own allocator (NumPy path of the shim) */
+int lra_malloc(lra_ctx* ctx, size_t bytes, void** dptr);
+int lra_free(lra_ctx* ctx, void* dptr);
+int lra_memset(lra_ctx* ctx, void* dptr, int value, size_t bytes);
+int lra_memcpy_h2d(lra_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes); /* synchronous */
+int lra_memcpy_d2h(lra_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes); /* synchronous */
+
+/* HIP events on the context's stream (bench.py times the kernels with these) */
+int lra_event_create(lra_ctx* ctx, lra_event** out);
+void lra_event_destroy(lra_event* ev);
+int lra_event_record(lra_event* ev);
+int lra_event_elapsed_ms(lra_event* start, lra_event* stop, float* ms); /* syncs on stop */
+
+/* ---- STFT: librosa.stft, librosa/core/spectrum.py:57-391 ------------------------------- */
+/* window: host pointer, n_fft reals of `dtype` = pad_center(get_window(window, win_length), n_fft)
+ * (core/spectrum.py:243-246), built by the shim with the reference's own scipy call.
+ * center != 0 pads n_fft/2 samples each side with pad_mode (core/spectrum.py:252-328).  Power-of-two
+ * n_fft in [32, 16384] (f64: 8192) runs the fused LDS-FFT kernels; any other n_fft runs a framing
+ * kernel + rocFFT batched R2C. */
+int lra_stft_plan_create(lra_ctx* ctx, int n_fft, int hop_length, const void* window_host, int center, int pad_mode, int dtype,
+                         lra_stft_plan** out);
+void lra_stft_plan_destroy(lra_stft_plan* plan);
+/* n_frames = 1 + (n + 2*(n_fft/2)*center - n_fft) / hop  (core/spectrum.py:344-353); LRA_EINVAL when
+ * n_fft > n and not centred (core/spectrum.py:330-333). */
+int lra_stft_num_frames(const lra_stft_plan* plan, int64_t n, int64_t* n_frames);
+/* D[batch][n_frames][n_bins] = rfft(window * frames)  (core/spectrum.py:380-390). */
+int lra_stft_exec(lra_stft_plan* plan, const void* y, int64_t batch, int64_t n, int64_t y_stride, void* D);
+/* S[batch][n_frames][n_bins] = |stft|**power  (_spectrogram, core/spectrum.py:3000-3013). */
+int lra_spectrogram_exec(lra_stft_plan* plan, const void* y, int64_t batch, int64_t n, int64_t y_stride, double power, void* S);
+
+/* ---- mel: librosa.filters.mel (filters.py:116-251) applied as in feature/spectral.py:2158-2160 */
+/* basis: host pointer, dense [n_mels][n_bins] reals of `dtype`, built by the shim on the host with
+ * the reference's float64 recipe (so it is bit-identical to filters.mel); stored on the device in
+ * band form (first/last non-zero column per row; 2018 of 131200 entries at the default config). */
+int lra_mel_plan_create(lra_ctx* ctx, int n_mels, int n_bins, const void* basis_host, int dtype, lra_mel_plan** out);
+void lra_mel_plan_destroy(lra_mel_plan* plan);
+/* Fused feature.melspectrogram(y=...): M[batch][n_mels][n_frames]; the complex spectrum never
+ * reaches HBM (feature/spectral.py:2145-2160). */
+int lra_melspectrogram_exec(lra_stft_plan* stft, lra_mel_plan* mel, const void* y, int64_t batch, int64_t n, int64_t y_stride, double power,
+                            void* M);
+/* feature.melspectrogram(S=...): M[b][m][t] = sum_f basis[m][f] * S[b*batch_stride + f*bin_stride + t*frame_stride]. */
+int lra_mel_apply_exec(lra_mel_plan* mel, const void* S, int64_t batch, int64_t n_frames, int64_t batch_stride, int64_t bin_stride,
+                       int64_t frame_stride, void* M);
+
+/* ---- ISTFT: librosa.istft, librosa/core/spectrum.py:394-626 (+ __overlap_add :629-643) ---- */
+int lra_istft_plan_create(lra_ctx* ctx, int n_fft, int hop_length, const void* window_host, int center, int dtype, lra_istft_plan** out);
+void lra_istft_plan_destroy(lra_istft_plan* plan);
+/* D: [batch] x frames x n_bins with the given element strides (d_frame_stride >= n_bins);
+ * frames [0, n_used) are inverse-transformed, windowed and overlap-added in frame order; sample s of
+ * the output is padded position s + n_fft/2 (centred) or s; wss (device, [out_len]) is
+ * fix_length(window_sumsquare(...)[start:], out_len) computed by the shim exactly as the reference
+ * does (core/spectrum.py:606-620); y[batch][out_len] = ola / wss where wss > tiny (:622-624). */
+int lra_istft_exec(lra_istft_plan* plan, const void* D, int64_t batch, int64_t d_batch_stride, int64_t d_frame_stride, int64_t n_used,
+                   const void* wss, void* y, int64_t out_len, int64_t y_stride);
+
+/* ---- layout helper: dst[b][c][r] = src[b][r][c], elem_bytes in {4, 8, 16} ------------------ */
+int lra_transpose(lra_ctx* ctx, const void* src, void* dst, int64_t batch, int64_t rows, int64_t cols, int elem_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIBROSA_AMD_H */

@@ -1,0 +1,136 @@
+"""Marshalling between host/device array types and raw device pointers.
+
+Two kinds of caller are served:
+  * NumPy arrays (the drop-in path): data is uploaded to HBM, the kernels run, results come back
+    as ``np.ndarray`` -- signatures and return types identical to the reference's;
+  * ``torch`` tensors already resident on a ROCm device (the fast path used by ``bench.py`` and by
+    pipelines that keep audio on the GPU): pointers are passed through, work is enqueued on
+    torch's current stream and device tensors are returned.  PyTorch is only plumbing here
+    (allocator + streams); all arithmetic is in the HIP library.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _native
+from .util.exceptions import ParameterError
+from .util.utils import is_torch_tensor
+
+_NP2TORCH = {}
+
+
+def _torch():
+    import torch
+
+    if not _NP2TORCH:
+        _NP2TORCH.update({np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
+                          np.dtype(np.complex64): torch.complex64, np.dtype(np.complex128): torch.complex128})
+    return torch
+
+
+def torch_dtype(np_dtype):
+    _torch()
+    return _NP2TORCH[np.dtype(np_dtype)]
+
+
+def numpy_dtype_of(x):
+    """NumPy dtype of a numpy array or torch tensor."""
+    if is_torch_tensor(x):
+        torch = _torch()
+        for k, v in _NP2TORCH.items():
+            if v == x.dtype:
+                return k
+        if x.dtype in (torch.float16, torch.bfloat16):
+            return np.dtype(np.float16)
+        raise ParameterError(f"unsupported tensor dtype {x.dtype}")
+    return x.dtype
+
+
+class Session:
+    """Per-call device session: resolves the context/stream and tracks temporary buffers."""
+
+    def __init__(self, like):
+        self.is_torch = is_torch_tensor(like)
+        if self.is_torch:
+            torch = _torch()
+            if like.device.type != "cuda":
+                raise ParameterError("torch inputs must live on a ROCm device (tensor.device.type == 'cuda'); pass a numpy array for host data")
+            self.device = like.device
+            self.ctx = _native.get_context(like.device.index if like.device.index is not None else torch.cuda.current_device())
+            self.ctx.set_stream(torch.cuda.current_stream(like.device).cuda_stream)
+        else:
+            self.device = None
+            self.ctx = _native.get_context()
+            self.ctx.set_stream(None)
+        self._keep = []
+
+    # ---- inputs ---------------------------------------------------------------------------------
+    def input_2d(self, x, dtype):
+        """(…, n) array/tensor -> (ptr, batch, n, row_stride) of a C-contiguous (batch, n) device array."""
+        dtype = np.dtype(dtype)
+        if self.is_torch:
+            t = x.to(torch_dtype(dtype)).reshape(-1, x.shape[-1]).contiguous()
+            self._keep.append(t)
+            return t.data_ptr(), t.shape[0], t.shape[1], t.shape[1]
+        a = np.ascontiguousarray(x, dtype=dtype).reshape(-1, x.shape[-1])
+        buf = self.ctx.alloc(max(a.nbytes, 16)).upload(a)
+        self._keep.append(buf)
+        return buf.ptr, a.shape[0], a.shape[1], a.shape[1]
+
+    def input_raw(self, a, dtype):
+        """Upload/borrow a contiguous array as-is; returns ptr."""
+        if self.is_torch:
+            t = a.to(torch_dtype(dtype)).contiguous()
+            self._keep.append(t)
+            return t.data_ptr()
+        a = np.ascontiguousarray(a, dtype=dtype)
+        buf = self.ctx.alloc(max(a.nbytes, 16)).upload(a)
+        self._keep.append(buf)
+        return buf.ptr
+
+    # ---- outputs --------------------------------------------------------------------------------
+    def output(self, shape, dtype):
+        """Allocate a device result; returns (ptr, handle) where handle is finalised by ``result``."""
+        dtype = np.dtype(dtype)
+        if self.is_torch:
+            t = _torch().empty(tuple(int(s) for s in shape), dtype=torch_dtype(dtype), device=self.device)
+            return t.data_ptr(), t
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        buf = self.ctx.alloc(max(nbytes, 16))
+        return buf.ptr, (buf, tuple(int(s) for s in shape), dtype)
+
+    def result(self, handle):
+        """Device result -> tensor (torch) or downloaded ndarray (numpy)."""
+        if self.is_torch:
+            return handle
+        buf, shape, dtype = handle
+        out = buf.download(shape, dtype)
+        buf.free()
+        return out
+
+    def scratch(self, nbytes):
+        if self.is_torch:
+            t = _torch().empty(int(max(nbytes, 16)), dtype=_torch().uint8, device=self.device)
+            self._keep.append(t)
+            return t.data_ptr()
+        buf = self.ctx.alloc(max(int(nbytes), 16))
+        self._keep.append(buf)
+        return buf.ptr
+
+    def close(self):
+        for k in self._keep:
+            if isinstance(k, _native.DeviceBuffer):
+                k.free()
+        self._keep = []
+
+
+def swap_last_two(x):
+    return x.transpose(-1, -2) if is_torch_tensor(x) else np.swapaxes(x, -1, -2)
+
+
+def cast(x, dtype):
+    dtype = np.dtype(dtype)
+    if is_torch_tensor(x):
+        td = torch_dtype(dtype)
+        return x if x.dtype == td else x.to(td)
+    return x if x.dtype == dtype else x.astype(dtype)

@@ -1,0 +1,315 @@
+"""ctypes binding of ``include/librosa_amd.h`` (the gfx950 library ``_liblibrosa_amd.so``).
+
+There is NO CPU fallback: if the shared library is missing or no HIP device is present, every
+compute entry point raises :class:`NativeError` (a ``LibrosaError``).  The library is built
+in-tree by ``__graft_entry__.build()`` / ``python -m librosa_amd.build``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
+
+import numpy as np
+
+from .util.exceptions import LibrosaError, ParameterError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_liblibrosa_amd.so")
+
+LRA_OK, LRA_EINVAL, LRA_EHIP, LRA_EROCFFT, LRA_ENODEV, LRA_ENOMEM = 0, -1, -2, -3, -4, -5
+LRA_F32, LRA_F64 = 0, 1
+PAD_MODES = {"constant": 0, "reflect": 1, "edge": 2, "symmetric": 3}
+
+
+class NativeError(LibrosaError):
+    """The HIP library is missing, or a HIP / rocFFT call failed."""
+
+
+# name -> (restype, argtypes); every symbol declared in include/librosa_amd.h
+SIGNATURES = {
+    "lra_last_error": (c_char_p, []),
+    "lra_version": (c_char_p, []),
+    "lra_device_count": (c_int, [POINTER(c_int)]),
+    "lra_ctx_create": (c_int, [c_int, POINTER(c_void_p)]),
+    "lra_ctx_destroy": (None, [c_void_p]),
+    "lra_ctx_set_stream": (c_int, [c_void_p, c_void_p]),
+    "lra_ctx_sync": (c_int, [c_void_p]),
+    "lra_ctx_set_option": (c_int, [c_void_p, c_char_p, c_int]),
+    "lra_ctx_device_name": (c_int, [c_void_p, c_char_p, c_size_t]),
+    "lra_ctx_nonfinite_reset": (c_int, [c_void_p]),
+    "lra_ctx_nonfinite_read": (c_int, [c_void_p, POINTER(c_int)]),
+    "lra_stft_plan_is_fused": (c_int, [c_void_p]),
+    "lra_malloc": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
+    "lra_free": (c_int, [c_void_p, c_void_p]),
+    "lra_memset": (c_int, [c_void_p, c_void_p, c_int, c_size_t]),
+    "lra_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    "lra_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    "lra_event_create": (c_int, [c_void_p, POINTER(c_void_p)]),
+    "lra_event_destroy": (None, [c_void_p]),
+    "lra_event_record": (c_int, [c_void_p]),
+    "lra_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
+    "lra_stft_plan_create": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, POINTER(c_void_p)]),
+    "lra_stft_plan_destroy": (None, [c_void_p]),
+    "lra_stft_num_frames": (c_int, [c_void_p, c_int64, POINTER(c_int64)]),
+    "lra_stft_exec": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "lra_spectrogram_exec": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p]),
+    "lra_mel_plan_create": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, POINTER(c_void_p)]),
+    "lra_mel_plan_destroy": (None, [c_void_p]),
+    "lra_melspectrogram_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p]),
+    "lra_mel_apply_exec": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p]),
+    "lra_istft_plan_create": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    "lra_istft_plan_destroy": (None, [c_void_p]),
+    "lra_istft_exec": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64]),
+    "lra_transpose": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library():
+    """dlopen the in-tree HIP library and attach signatures; raises NativeError when absent."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise NativeError(
+                    f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(librosa_amd has no CPU fallback)"
+                )
+            try:
+                lib = ctypes.CDLL(LIB_PATH)
+            except OSError as exc:  # missing libamdhip64 / librocfft
+                raise NativeError(f"cannot load {LIB_PATH}: {exc}") from exc
+            for name, (restype, argtypes) in SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype = restype
+                fn.argtypes = argtypes
+            _lib = lib
+    return _lib
+
+
+def _check(rc):
+    if rc == LRA_OK:
+        return
+    msg = load_library().lra_last_error().decode("utf-8", "replace")
+    if rc == LRA_EINVAL:
+        raise ParameterError(msg)
+    raise NativeError(f"librosa_amd native error {rc}: {msg}")
+
+
+def device_count():
+    n = c_int(0)
+    lib = load_library()
+    rc = lib.lra_device_count(byref(n))
+    return n.value if rc == LRA_OK else 0
+
+
+def dtype_code(dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return LRA_F32
+    if dtype == np.float64:
+        return LRA_F64
+    raise ParameterError(f"unsupported real dtype {dtype}")
+
+
+class DeviceBuffer:
+    """Owning device allocation made through lra_malloc (NumPy path)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = c_void_p()
+        _check(ctx.lib.lra_malloc(ctx.handle, self.nbytes, byref(p)))
+        self.ptr = p.value or 0
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        if arr.nbytes:
+            _check(self.ctx.lib.lra_memcpy_h2d(self.ctx.handle, self.ptr, arr.ctypes.data, arr.nbytes))
+        return self
+
+    def download(self, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        if out.nbytes:
+            _check(self.ctx.lib.lra_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.lra_free(self.ctx.handle, self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = c_void_p()
+        _check(ctx.lib.lra_event_create(ctx.handle, byref(h)))
+        self.handle = h
+
+    def record(self):
+        _check(self.ctx.lib.lra_event_record(self.handle))
+        return self
+
+    def elapsed_ms(self, stop):
+        ms = c_float(0)
+        _check(self.ctx.lib.lra_event_elapsed_ms(self.handle, stop.handle, byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            self.ctx.lib.lra_event_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class Context:
+    """One device + stream + plan caches.  ``get_context(device)`` returns the shared instance."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = c_void_p()
+        _check(self.lib.lra_ctx_create(int(device), byref(h)))
+        self.handle = h
+        self.device = int(device)
+        self._stft_plans = {}
+        self._istft_plans = {}
+        self._mel_plans = {}
+        self._wss_cache = {}
+        self._lock = threading.RLock()
+
+    # -- context ------------------------------------------------------------------------------
+    def device_name(self):
+        buf = ctypes.create_string_buffer(256)
+        _check(self.lib.lra_ctx_device_name(self.handle, buf, 256))
+        return buf.value.decode()
+
+    def set_stream(self, stream_ptr):
+        _check(self.lib.lra_ctx_set_stream(self.handle, c_void_p(stream_ptr or None)))
+
+    def sync(self):
+        _check(self.lib.lra_ctx_sync(self.handle))
+
+    def set_option(self, key, value):
+        _check(self.lib.lra_ctx_set_option(self.handle, key.encode(), int(value)))
+
+    def nonfinite_reset(self):
+        _check(self.lib.lra_ctx_nonfinite_reset(self.handle))
+
+    def nonfinite_read(self):
+        f = c_int(0)
+        _check(self.lib.lra_ctx_nonfinite_read(self.handle, byref(f)))
+        return bool(f.value)
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def event(self):
+        return Event(self)
+
+    # -- plans (cached; keyed by the bytes of the host tables so any window spec works) -----------
+    def stft_plan(self, n_fft, hop, window, center, pad_mode, dtype):
+        window = np.ascontiguousarray(window, dtype=dtype)
+        key = (int(n_fft), int(hop), window.tobytes(), bool(center), pad_mode, np.dtype(dtype).str)
+        with self._lock:
+            plan = self._stft_plans.get(key)
+            if plan is None:
+                h = c_void_p()
+                _check(self.lib.lra_stft_plan_create(self.handle, int(n_fft), int(hop), window.ctypes.data, int(bool(center)), PAD_MODES[pad_mode],
+                                                     dtype_code(dtype), byref(h)))
+                plan = h
+                self._stft_plans[key] = plan
+        return plan
+
+    def istft_plan(self, n_fft, hop, window, center, dtype):
+        window = np.ascontiguousarray(window, dtype=dtype)
+        key = (int(n_fft), int(hop), window.tobytes(), bool(center), np.dtype(dtype).str)
+        with self._lock:
+            plan = self._istft_plans.get(key)
+            if plan is None:
+                h = c_void_p()
+                _check(self.lib.lra_istft_plan_create(self.handle, int(n_fft), int(hop), window.ctypes.data, int(bool(center)), dtype_code(dtype), byref(h)))
+                plan = h
+                self._istft_plans[key] = plan
+        return plan
+
+    def mel_plan(self, basis):
+        basis = np.ascontiguousarray(basis)
+        key = (basis.shape, basis.dtype.str, basis.tobytes())
+        with self._lock:
+            plan = self._mel_plans.get(key)
+            if plan is None:
+                h = c_void_p()
+                _check(self.lib.lra_mel_plan_create(self.handle, int(basis.shape[0]), int(basis.shape[1]), basis.ctypes.data, dtype_code(basis.dtype), byref(h)))
+                plan = h
+                self._mel_plans[key] = plan
+        return plan
+
+    def device_table(self, key, host_array):
+        """Small read-only device table (e.g. a window sum-square), cached by key."""
+        with self._lock:
+            buf = self._wss_cache.get(key)
+            if buf is None:
+                if len(self._wss_cache) > 64:
+                    self._wss_cache.clear()
+                buf = self.alloc(max(host_array.nbytes, 16)).upload(host_array)
+                self._wss_cache[key] = buf
+        return buf
+
+    # -- execution ----------------------------------------------------------------------------------
+    def stft_num_frames(self, plan, n):
+        out = c_int64(0)
+        _check(self.lib.lra_stft_num_frames(plan, int(n), byref(out)))
+        return out.value
+
+    def stft_is_fused(self, plan):
+        return bool(self.lib.lra_stft_plan_is_fused(plan))
+
+    def stft_exec(self, plan, y_ptr, batch, n, y_stride, out_ptr):
+        _check(self.lib.lra_stft_exec(plan, c_void_p(y_ptr), batch, n, y_stride, c_void_p(out_ptr)))
+
+    def spectrogram_exec(self, plan, y_ptr, batch, n, y_stride, power, out_ptr):
+        _check(self.lib.lra_spectrogram_exec(plan, c_void_p(y_ptr), batch, n, y_stride, float(power), c_void_p(out_ptr)))
+
+    def melspectrogram_exec(self, plan, mel_plan, y_ptr, batch, n, y_stride, power, out_ptr):
+        _check(self.lib.lra_melspectrogram_exec(plan, mel_plan, c_void_p(y_ptr), batch, n, y_stride, float(power), c_void_p(out_ptr)))
+
+    def mel_apply_exec(self, mel_plan, s_ptr, batch, n_frames, batch_stride, bin_stride, frame_stride, out_ptr):
+        _check(self.lib.lra_mel_apply_exec(mel_plan, c_void_p(s_ptr), batch, n_frames, batch_stride, bin_stride, frame_stride, c_void_p(out_ptr)))
+
+    def istft_exec(self, plan, d_ptr, batch, d_batch_stride, d_frame_stride, n_used, wss_ptr, y_ptr, out_len, y_stride):
+        _check(self.lib.lra_istft_exec(plan, c_void_p(d_ptr), batch, d_batch_stride, d_frame_stride, n_used, c_void_p(wss_ptr), c_void_p(y_ptr), out_len, y_stride))
+
+    def transpose(self, src_ptr, dst_ptr, batch, rows, cols, elem_bytes):
+        _check(self.lib.lra_transpose(self.handle, c_void_p(src_ptr), c_void_p(dst_ptr), batch, rows, cols, elem_bytes))
+
+
+_contexts = {}
+_ctx_lock = threading.Lock()
+
+
+def get_context(device=None):
+    """Shared per-device context.  ``device=None`` -> LOCAL_RANK's device under torchrun, else 0."""
+    if device is None:
+        device = int(os.environ.get("LIBROSA_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        n = device_count()
+        if n > 0:
+            device %= n
+    with _ctx_lock:
+        ctx = _contexts.get(device)
+        if ctx is None:
+            ctx = Context(device)
+            _contexts[device] = ctx
+    return ctx

@@ -1,0 +1,313 @@
+"""``stft`` / ``istft`` / ``_spectrogram`` with librosa's signatures, executed on MI355X.
+
+Host side of the drop-in boundary: argument defaults, validation, warnings and
+error types follow ``librosa/core/spectrum.py`` (``stft`` :57-391, ``istft`` :394-626,
+``_spectrogram`` :2920-3015) and run BEFORE any device work; the arithmetic itself is done by the
+gfx950 library through ``librosa_amd._native`` (fused LDS-FFT kernels for power-of-two ``n_fft``,
+rocFFT otherwise).  There is no CPU fallback.
+
+Extensions beyond the reference (which only accepts ``np.ndarray``):
+  * ``y`` / ``stft_matrix`` may be a ``torch`` tensor resident on a ROCm device; a device tensor is
+    returned and nothing crosses PCIe.  ``check_finite`` then controls the ``valid_audio`` scan.
+"""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+
+from .. import _arrays
+from .. import filters
+from ..util import utils as util
+from ..util.exceptions import ParameterError
+from ..util.utils import is_torch_tensor
+
+__all__ = ["stft", "istft", "_spectrogram"]
+
+# np.pad modes that do not depend only on edge values: rejected exactly as the reference does
+_REJECTED_PAD_MODES = ("wrap", "maximum", "mean", "median", "minimum")
+# pad modes the framing kernel evaluates on the fly; anything else is pre-padded by np.pad
+_DEVICE_PAD_MODES = ("constant", "reflect", "edge", "symmetric")
+
+
+def _real_compute_dtype(in_dtype, out_complex_dtype):
+    """Precision the device computes in: f64 if either side is double, else f32."""
+    if np.dtype(in_dtype) == np.float64 or np.dtype(out_complex_dtype) == np.complex128:
+        return np.dtype(np.float64)
+    return np.dtype(np.float32)
+
+
+def _validate_audio(y, check_finite):
+    """``util.valid_audio`` (``util/utils.py:294-306``) for ndarrays; dtype/ndim checks for tensors.
+
+    Returns True when the finite-scan still has to be done on the device (tensor inputs)."""
+    if is_torch_tensor(y):
+        if not y.is_floating_point():
+            raise ParameterError("Audio data must be floating-point")
+        if y.ndim == 0:
+            raise ParameterError(f"Audio data must be at least one-dimensional, given y.shape={tuple(y.shape)}")
+        return bool(check_finite)
+    util.valid_audio(y)
+    return False
+
+
+def _prepare_stft(y, n_fft, hop_length, win_length, window, center, pad_mode):
+    """Shared front end of stft/_spectrogram/melspectrogram: defaults, checks, window, padding.
+
+    Returns (y, hop_length, fft_window (float64, length n_fft), center, pad_mode)."""
+    if win_length is None:
+        win_length = n_fft
+    if hop_length is None:
+        hop_length = int(win_length // 4)
+    elif not util.is_positive_int(hop_length):
+        raise ParameterError(f"hop_length={hop_length} must be a positive integer")
+    if not util.is_positive_int(n_fft):
+        raise ParameterError(f"n_fft={n_fft} must be a positive integer")
+    fft_window = filters.get_window(window, win_length, fftbins=True)
+    fft_window = util.pad_center(np.asarray(fft_window, dtype=np.float64), size=n_fft)
+    n = y.shape[-1]
+    if center:
+        if pad_mode in _REJECTED_PAD_MODES:
+            raise ParameterError(f"pad_mode='{pad_mode}' is not supported by librosa.stft")
+        if n_fft > n:
+            warnings.warn(f"n_fft={n_fft} is too large for input signal of length={n}", stacklevel=3)
+        if not (isinstance(pad_mode, str) and pad_mode in _DEVICE_PAD_MODES):
+            # exotic np.pad modes (linear_ramp, empty, callables, ...): pad on the host, then run uncentred
+            if is_torch_tensor(y):
+                raise ParameterError(f"pad_mode={pad_mode!r} is only supported for numpy inputs")
+            widths = [(0, 0)] * y.ndim
+            widths[-1] = (n_fft // 2, n_fft // 2)
+            y = np.pad(y, widths, mode=pad_mode)
+            center, pad_mode = False, "constant"
+    else:
+        if n_fft > n:
+            raise ParameterError(f"n_fft={n_fft} is too large for uncentered analysis of input signal of length={n}")
+        pad_mode = "constant"
+    return y, int(hop_length), fft_window, bool(center), pad_mode
+
+
+def _finite_check_covers_input(n, n_fft, hop, center):
+    """True when every input sample lies in some frame, so the kernels' DC-bin flag sees it."""
+    if hop > n_fft:
+        return False
+    padded = n + (2 * (n_fft // 2) if center else 0)
+    n_frames = 1 + (padded - n_fft) // hop
+    covered_hi = (n_frames - 1) * hop + n_fft  # exclusive, padded coordinates
+    return covered_hi >= (n + (n_fft // 2 if center else 0))
+
+
+def _run_stft_family(kind, y, *, n_fft, hop_length, win_length, window, center, pad_mode, dtype=None, power=1.0, mel_basis=None, check_finite=True):
+    """kind in {"stft", "power", "mel"}.  Returns the result laid out like the reference's."""
+    need_device_check = _validate_audio(y, check_finite)
+    y, hop, fft_window, center, pad_mode = _prepare_stft(y, n_fft, hop_length, win_length, window, center, pad_mode)
+    in_dtype = _arrays.numpy_dtype_of(y)
+    if kind == "stft":
+        out_dtype = np.dtype(util.dtype_r2c(in_dtype)) if dtype is None else np.dtype(dtype)
+        if out_dtype.kind != "c":
+            raise ParameterError(f"stft dtype={out_dtype} is not of complex type")
+        real = _real_compute_dtype(in_dtype, out_dtype)
+    else:
+        real = np.dtype(np.float64) if in_dtype == np.float64 else np.dtype(np.float32)
+        if kind == "mel" and np.dtype(mel_basis.dtype) == np.float64:
+            real = np.dtype(np.float64)
+    lead = tuple(y.shape[:-1])
+    n = int(y.shape[-1])
+    n_bins = 1 + n_fft // 2
+    sess = _arrays.Session(y)
+    try:
+        ctx = sess.ctx
+        plan = ctx.stft_plan(n_fft, hop, fft_window.astype(real), center, pad_mode, real)
+        n_frames = ctx.stft_num_frames(plan, n)
+        fused = ctx.stft_is_fused(plan)
+        if need_device_check:
+            if fused and _finite_check_covers_input(n, n_fft, hop, center):
+                ctx.nonfinite_reset()
+            else:
+                need_device_check = False
+                if not bool(_arrays._torch().isfinite(y).all()):
+                    raise ParameterError("Audio buffer is not finite everywhere")
+        y_ptr, batch, _, y_stride = sess.input_2d(y, real)
+        if kind == "stft":
+            ptr, handle = sess.output((batch, n_frames, n_bins), util.dtype_r2c(real))
+            ctx.stft_exec(plan, y_ptr, batch, n, y_stride, ptr)
+        elif kind == "power":
+            ptr, handle = sess.output((batch, n_frames, n_bins), real)
+            ctx.spectrogram_exec(plan, y_ptr, batch, n, y_stride, power, ptr)
+        else:
+            n_mels = int(mel_basis.shape[0])
+            mel_plan = ctx.mel_plan(np.ascontiguousarray(mel_basis, dtype=real))
+            ptr, handle = sess.output((batch, n_mels, n_frames), real)
+            ctx.melspectrogram_exec(plan, mel_plan, y_ptr, batch, n, y_stride, power, ptr)
+        if need_device_check and ctx.nonfinite_read():
+            raise ParameterError("Audio buffer is not finite everywhere")
+        res = sess.result(handle)
+    finally:
+        sess.close()
+    if kind == "mel":
+        return res.reshape(lead + (n_mels, n_frames))
+    res = _arrays.swap_last_two(res.reshape(lead + (n_frames, n_bins)))  # (..., n_bins, n_frames) view
+    if kind == "stft":
+        res = _arrays.cast(res, out_dtype)
+    return res
+
+
+def stft(y, *, n_fft=2048, hop_length=None, win_length=None, window="hann", center=True, dtype=None, pad_mode="constant", out=None,
+         check_finite=True):
+    """Short-time Fourier transform; drop-in for ``librosa.stft`` (``librosa/core/spectrum.py:57-391``).
+
+    Returns ``D[..., f, t]`` of shape ``(..., 1 + n_fft//2, n_frames)``, complex64 for float32 audio and
+    complex128 for float64 (or ``dtype``).  As in the reference (which allocates Fortran-ordered,
+    ``:356``) each frame's spectrum is contiguous in memory: the array is a transposed view of the
+    device layout ``[..., t, f]``.
+
+    ``out`` (numpy only): a pre-allocated complex array with matching leading shape and at least
+    ``n_frames`` columns; the same object (or ``out[..., :n_frames]``) is returned (``:355-367``).
+    """
+    if out is not None and is_torch_tensor(y):
+        raise ParameterError("out= is only supported for numpy inputs")
+    D = _run_stft_family("stft", y, n_fft=n_fft, hop_length=hop_length, win_length=win_length, window=window, center=center, pad_mode=pad_mode,
+                         dtype=dtype if out is None else (dtype or util.dtype_r2c(_arrays.numpy_dtype_of(y))), check_finite=check_finite)
+    if out is None:
+        return D
+    shape = list(D.shape)
+    if not (np.allclose(out.shape[:-1], shape[:-1]) and out.shape[-1] >= shape[-1]):
+        raise ParameterError(f"Shape mismatch for provided output array out.shape={out.shape} and target shape={shape}")
+    if not np.iscomplexobj(out):
+        raise ParameterError(f"output with dtype={out.dtype} is not of complex type")
+    target = out if np.allclose(shape, out.shape) else out[..., : shape[-1]]
+    target[...] = D
+    return target
+
+
+def _spectrogram(*, y=None, S=None, n_fft=2048, hop_length=512, power=1, win_length=None, window="hann", center=True, pad_mode="constant"):
+    """``librosa.core.spectrum._spectrogram`` (``librosa/core/spectrum.py:2920-3015``).
+
+    With ``S`` given, only ``n_fft`` is inferred; otherwise ``S = |stft(y)|**power`` is produced by the
+    fused kernel (magnitude/power taken in registers, the complex spectrum never reaches HBM).
+    """
+    if S is not None:
+        if n_fft is None or n_fft // 2 + 1 != S.shape[-2]:
+            n_fft = 2 * (S.shape[-2] - 1)
+        return S, n_fft
+    if n_fft is None:
+        raise ParameterError(f"Unable to compute spectrogram with n_fft={n_fft}")
+    if y is None:
+        raise ParameterError("Input signal must be provided to compute a spectrogram")
+    S = _run_stft_family("power", y, n_fft=n_fft, hop_length=hop_length, win_length=win_length, window=window, center=center, pad_mode=pad_mode,
+                         power=float(power))
+    return S, n_fft
+
+
+def _istft_frame_counts(n_total_frames, n_fft, hop_length, center, length):
+    """Frame bookkeeping of ``librosa/core/spectrum.py:523-544, 557-603``.
+
+    Returns (n_frames for the window-sum-square, n_used frames that contribute, expected length)."""
+    if length:
+        padded_length = length + 2 * (n_fft // 2) if center else length
+        n_frames = min(n_total_frames, int(np.ceil(padded_length / hop_length)))
+    else:
+        n_frames = n_total_frames
+    expected = n_fft + hop_length * (n_frames - 1)
+    if length:
+        expected = length
+    elif center:
+        expected -= 2 * (n_fft // 2)
+    if center:
+        # the reference always folds the first ceil((n_fft/2)/hop) frames in through its head block
+        start_frame = int(np.ceil((n_fft // 2) / hop_length))
+        n_used = max(n_frames, min(n_total_frames, start_frame))
+    else:
+        n_used = n_frames
+    return n_frames, n_used, expected
+
+
+def istft(stft_matrix, *, hop_length=None, win_length=None, n_fft=None, window="hann", center=True, dtype=None, length=None, out=None):
+    """Inverse STFT; drop-in for ``librosa.istft`` (``librosa/core/spectrum.py:394-626``).
+
+    Frames are inverse-transformed, windowed and overlap-added in frame order, then divided by the
+    window sum-square envelope wherever it exceeds ``tiny`` (``:606-624``).  ``length`` trims/zero-pads
+    the output and limits the frames used (``:523-531``).
+    """
+    D = stft_matrix
+    if D.ndim < 2:
+        raise ParameterError(f"stft_matrix must have at least 2 dimensions, given shape={tuple(D.shape)}")
+    if n_fft is None:
+        n_fft = 2 * (D.shape[-2] - 1)
+    if D.shape[-2] != 1 + n_fft // 2:
+        raise ParameterError(f"stft_matrix has {D.shape[-2]} frequency bins, expected {1 + n_fft // 2} for n_fft={n_fft}")
+    if win_length is None:
+        win_length = n_fft
+    if hop_length is None:
+        hop_length = int(win_length // 4)
+    elif not util.is_positive_int(hop_length):
+        raise ParameterError(f"hop_length={hop_length} must be a positive integer")
+    ifft_window = util.pad_center(np.asarray(filters.get_window(window, win_length, fftbins=True), dtype=np.float64), size=n_fft)
+    in_dtype = _arrays.numpy_dtype_of(D)
+    if in_dtype.kind != "c":
+        raise ParameterError(f"stft_matrix with dtype={in_dtype} is not of complex type")
+    out_dtype = np.dtype(util.dtype_c2r(in_dtype)) if dtype is None else np.dtype(dtype)
+    real = np.dtype(np.float64) if (in_dtype == np.complex128 or out_dtype == np.float64) else np.dtype(np.float32)
+    cplx = np.dtype(util.dtype_r2c(real))
+    n_total = int(D.shape[-1])
+    n_frames, n_used, expected = _istft_frame_counts(n_total, n_fft, int(hop_length), bool(center), length)
+    lead = tuple(D.shape[:-2])
+    shape = lead + (int(expected),)
+    if out is not None:
+        if is_torch_tensor(D):
+            raise ParameterError("out= is only supported for numpy inputs")
+        if not np.allclose(out.shape, shape):
+            raise ParameterError(f"Shape mismatch for provided output array out.shape={out.shape} != {list(shape)}")
+    # window sum-square on the host, in the output precision, exactly as the reference (:606-620)
+    wss = filters.window_sumsquare(window=window, n_frames=n_frames, win_length=win_length, n_fft=n_fft, hop_length=int(hop_length), dtype=out_dtype)
+    wss = util.fix_length(wss[(n_fft // 2 if center else 0) :], size=int(expected))
+    wss = np.ascontiguousarray(wss, dtype=real)
+    n_bins = 1 + n_fft // 2
+    sess = _arrays.Session(D)
+    try:
+        ctx = sess.ctx
+        plan = ctx.istft_plan(n_fft, int(hop_length), ifft_window.astype(real), bool(center), real)
+        batch = int(np.prod(lead, dtype=np.int64)) if lead else 1
+        # bring the spectrum into the device layout [batch][frame][bin]
+        Dt = _arrays.swap_last_two(D)  # (..., T, bins)
+        if sess.is_torch:
+            if Dt.is_contiguous() and Dt.dtype == _arrays.torch_dtype(cplx):
+                d_ptr = Dt.data_ptr()
+                sess._keep.append(Dt)
+            else:
+                src = D.to(_arrays.torch_dtype(cplx)).contiguous()
+                sess._keep.append(src)
+                d_ptr = sess.scratch(batch * n_total * n_bins * cplx.itemsize)
+                _transpose_batched(ctx, src.data_ptr(), d_ptr, batch, n_bins, n_total, cplx.itemsize)
+        else:
+            if Dt.flags["C_CONTIGUOUS"]:
+                d_ptr = sess.input_raw(Dt, cplx)
+            else:
+                src_ptr = sess.input_raw(np.ascontiguousarray(D, dtype=cplx), cplx)
+                d_ptr = sess.scratch(batch * n_total * n_bins * cplx.itemsize)
+                _transpose_batched(ctx, src_ptr, d_ptr, batch, n_bins, n_total, cplx.itemsize)
+        wss_ptr = sess.input_raw(_as_like(sess, wss), real)
+        y_ptr, handle = sess.output((batch, int(expected)), real)
+        ctx.istft_exec(plan, d_ptr, batch, n_total * n_bins, n_bins, n_used, wss_ptr, y_ptr, int(expected), int(expected))
+        y = sess.result(handle)
+    finally:
+        sess.close()
+    y = _arrays.cast(y.reshape(shape), out_dtype)
+    if out is not None:
+        out[...] = y
+        return out
+    return y
+
+
+def _as_like(sess, host_array):
+    if sess.is_torch:
+        return _arrays._torch().from_numpy(np.ascontiguousarray(host_array)).to(sess.device)
+    return host_array
+
+
+def _transpose_batched(ctx, src_ptr, dst_ptr, batch, rows, cols, elem_bytes):
+    """dst[b][c][r] = src[b][r][c]; the native call takes at most 65535 batches per launch."""
+    step = 65535
+    for b0 in range(0, batch, step):
+        nb = min(step, batch - b0)
+        off = b0 * rows * cols * elem_bytes
+        ctx.transpose(src_ptr + off, dst_ptr + off, nb, rows, cols, elem_bytes)

@@ -1,0 +1,947 @@
+// lra_api.hip -- gfx950 library behind include/librosa_amd.h.
+//
+// Two execution paths per transform:
+//   * power-of-two n_fft: the fused LDS-FFT kernels of lra_kernels.h (hand-written Stockham FFT,
+//     window/pad fused into the gather, |X|^p and the banded mel reduce fused into the epilogue,
+//     overlap-add with an LDS carry for the inverse);
+//   * any other n_fft (the reference's tests use 501, 755, 1023, 1025, 2049): a framing kernel +
+//     rocFFT batched R2C/C2R + small elementwise kernels.
+// No CPU fallback exists: without a device every entry point that touches data fails.
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/librosa_amd.h"
+#include "lra_dispatch.h"
+
+using namespace lra;
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define LRA_HIP(expr)                                                                                        \
+    do {                                                                                                     \
+        hipError_t e__ = (expr);                                                                             \
+        if (e__ != hipSuccess) return fail(LRA_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__));    \
+    } while (0)
+#define LRA_FFT(expr)                                                                                        \
+    do {                                                                                                     \
+        rocfft_status s__ = (expr);                                                                          \
+        if (s__ != rocfft_status_success) return fail(LRA_EROCFFT, std::string(#expr) + ": rocfft status " + std::to_string((int)s__)); \
+    } while (0)
+#define LRA_TRY(expr)              \
+    do {                           \
+        int rc__ = (expr);         \
+        if (rc__ != LRA_OK) return rc__; \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// objects
+// ------------------------------------------------------------------------------------------------
+struct lra_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int n_cu = 256;
+    int opt_stft_iters = 0;          // 0 = auto
+    int opt_istft_strip_groups = 0;  // 0 = auto
+    int opt_variant = 0;             // kernel tuning variant (f32 n_fft = 2048 only)
+    unsigned int* d_flag = nullptr;  // non-finite input flag (device)
+    std::string name;
+};
+
+struct lra_event {
+    lra_ctx* ctx;
+    hipEvent_t ev;
+};
+
+namespace {
+
+struct FftPlanCache {
+    std::map<long long, rocfft_plan> plans;  // key = number of transforms
+    rocfft_execution_info info = nullptr;
+    void* work = nullptr;
+    size_t work_bytes = 0;
+    ~FftPlanCache() {
+        for (auto& kv : plans) rocfft_plan_destroy(kv.second);
+        if (info) rocfft_execution_info_destroy(info);
+        if (work) (void)hipFree(work);
+    }
+};
+
+struct Scratch {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return LRA_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        LRA_HIP(hipMalloc(&p, need));
+        bytes = need;
+        return LRA_OK;
+    }
+    ~Scratch() {
+        if (p) (void)hipFree(p);
+    }
+};
+
+std::once_flag g_rocfft_once;
+void rocfft_setup_once() {
+    std::call_once(g_rocfft_once, [] { rocfft_setup(); });
+}
+
+int upload(void** dptr, const void* host, size_t bytes) {
+    *dptr = nullptr;
+    LRA_HIP(hipMalloc(dptr, bytes ? bytes : 16));
+    if (bytes) LRA_HIP(hipMemcpy(*dptr, host, bytes, hipMemcpyHostToDevice));
+    return LRA_OK;
+}
+
+int ctx_bind(lra_ctx* ctx) {
+    if (!ctx) return fail(LRA_EINVAL, "null context");
+    LRA_HIP(hipSetDevice(ctx->device));
+    return LRA_OK;
+}
+
+inline size_t real_bytes(int dtype) { return dtype == LRA_F64 ? 8 : 4; }
+
+}  // namespace
+
+struct lra_stft_plan {
+    lra_ctx* ctx = nullptr;
+    int n_fft = 0, hop = 0, center = 0, pad_mode = 0, dtype = 0;
+    bool pow2 = false;
+    int logm = 0;
+    void* d_win = nullptr;
+    void* d_tw = nullptr;
+    void* d_twr = nullptr;
+    FftPlanCache fft;
+    Scratch frames, spec;
+};
+
+struct lra_mel_plan {
+    lra_ctx* ctx = nullptr;
+    int n_mels = 0, n_bins = 0, dtype = 0;
+    int* d_c0 = nullptr;
+    int* d_len = nullptr;
+    int* d_off = nullptr;
+    void* d_val = nullptr;
+};
+
+struct lra_istft_plan {
+    lra_ctx* ctx = nullptr;
+    int n_fft = 0, hop = 0, center = 0, dtype = 0;
+    bool pow2 = false;
+    int logm = 0;
+    void* d_win_scaled = nullptr;  // window / n_fft
+    void* d_tw = nullptr;
+    void* d_twr = nullptr;
+    FftPlanCache fft;
+    Scratch spec, frames;
+};
+
+// ------------------------------------------------------------------------------------------------
+// kernels: fused power-of-two path
+// ------------------------------------------------------------------------------------------------
+template <class Cfg, int MODE> __global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void stft_kernel(const StftArgs<typename Cfg::real> a) {
+    extern __shared__ __attribute__((aligned(16))) char lra_smem[];
+    Lds lds;
+    lds.base = lra_smem;
+    stft_block<Cfg, MODE>(a, (int)blockIdx.x, lds);
+}
+
+template <class Cfg> __global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void istft_kernel(const IstftArgs<typename Cfg::real> a) {
+    extern __shared__ __attribute__((aligned(16))) char lra_smem[];
+    Lds lds;
+    lds.base = lra_smem;
+    istft_block<Cfg>(a, (int)blockIdx.x, lds);
+}
+
+namespace {
+
+template <class T> struct StftLaunch {
+    StftArgs<T> a;
+    int mode = 0;
+    long long batch = 0;
+    int iters_opt = 0;  // 0 = auto
+    hipStream_t stream = nullptr;
+    hipError_t err = hipSuccess;
+    template <class Cfg> void operator()() {
+        static_assert(Cfg::P <= 4, "at most four Stockham passes are wired up");
+        // frame groups per workgroup: amortises the table loads (HOIST) and gives the mel epilogue
+        // longer contiguous rows, but keeps >= ~8 workgroups per clip for load balance
+        int iters = iters_opt;
+        if (iters <= 0) iters = (int)std::min<long long>(Cfg::HOIST ? 8 : 4, std::max<long long>(1, a.n_frames / (8LL * Cfg::FPB)));
+        a.frames_per_wg = Cfg::FPB * iters;
+        a.wg_per_clip = (a.n_frames + a.frames_per_wg - 1) / a.frames_per_wg;
+        const long long grid = batch * a.wg_per_clip;
+        if (grid > 0x7fffffffLL) { err = hipErrorInvalidConfiguration; return; }
+        constexpr int lds = stft_lds_bytes<Cfg>();
+        void (*kern)(const StftArgs<T>) = mode == OUT_COMPLEX ? stft_kernel<Cfg, OUT_COMPLEX> : mode == OUT_POWER ? stft_kernel<Cfg, OUT_POWER> : stft_kernel<Cfg, OUT_MEL>;
+        if (lds > 65536) {
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (err != hipSuccess) return;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NT), lds, stream, a);
+        err = hipGetLastError();
+    }
+};
+
+template <class T> struct IstftLaunch {
+    IstftArgs<T> a;
+    long long batch = 0;
+    int strip_groups = 16;
+    hipStream_t stream = nullptr;
+    hipError_t err = hipSuccess;
+    template <class Cfg> void operator()() {
+        static_assert(Cfg::P <= 4, "at most four Stockham passes are wired up");
+        constexpr int FPB = Cfg::FPB, N = Cfg::N;
+        const int H = a.hop;
+        a.strip_frames = strip_groups * FPB;
+        a.strips_per_clip = (a.n_used + a.strip_frames - 1) / a.strip_frames;
+        const int W = (N + H - 1) / H - 1;
+        a.warm_groups = (W + FPB - 1) / FPB;
+        const long long rem = N > H ? N - H : 0;
+        a.drain_groups = (int)((rem + (long long)FPB * H - 1) / ((long long)FPB * H));
+        const long long grid = batch * a.strips_per_clip;
+        constexpr int lds = istft_lds_bytes<Cfg>();
+        void (*kern)(const IstftArgs<T>) = istft_kernel<Cfg>;
+        if (lds > 65536) {
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (err != hipSuccess) return;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NT), lds, stream, a);
+        err = hipGetLastError();
+    }
+};
+
+template <class T> struct TableBuild {
+    std::vector<cx<T>> tw, twr;
+    template <class Cfg> void operator()() {
+        tw.assign(Cfg::TW_TOTAL, mk<T>((T)1, (T)0));
+        twr.assign(Cfg::M / 2 + 1, mk<T>((T)1, (T)0));
+        build_pass_twiddles<Cfg>(tw.data());
+        build_split_twiddles<Cfg>(twr.data());
+    }
+};
+
+template <class T> int build_tables(int logm, void** d_tw, void** d_twr) {
+    TableBuild<T> tb;
+    if (!dispatch_logm<T>(logm, 0, tb)) return fail(LRA_EINVAL, "unsupported power-of-two size");
+    LRA_TRY(upload(d_tw, tb.tw.data(), tb.tw.size() * sizeof(cx<T>)));
+    LRA_TRY(upload(d_twr, tb.twr.data(), tb.twr.size() * sizeof(cx<T>)));
+    return LRA_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// kernels: general (rocFFT) path and helpers
+// ------------------------------------------------------------------------------------------------
+// frames[f][i] = win[i] * ypad[clip][t*hop - pad + i], f = (clip - clip0)*n_frames + t
+template <class T>
+__global__ void frame_window_kernel(const T* __restrict__ y, long long y_stride, long long n, int n_frames, int hop, int pad, int pad_mode,
+                                    const T* __restrict__ win, int N, long long clip0, long long total_frames, T* __restrict__ out) {
+    const int chunks = (N + 255) / 256;
+    const long long f = blockIdx.x / chunks;
+    const int i = (int)(blockIdx.x % chunks) * 256 + threadIdx.x;
+    if (f >= total_frames || i >= N) return;
+    const long long clip = clip0 + f / n_frames;
+    const long long t = f % n_frames;
+    const long long g = t * hop - pad + i;
+    const long long idx = pad_index(g, n, pad_mode);
+    const T v = idx >= 0 ? y[clip * y_stride + idx] : (T)0;
+    out[f * N + i] = v * win[i];
+}
+
+template <class T> __global__ void power_kernel(const cx<T>* __restrict__ D, T* __restrict__ S, long long count, int power_mode, T power) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) S[i] = spec_power<T>(D[i], power_mode, power);
+}
+
+// M[b][m][t] = sum_i val[off[m]+i] * S[b*bs + (c0[m]+i)*fs_bin + t*fs_frame]
+template <class T>
+__global__ void mel_apply_kernel(const T* __restrict__ S, long long batch_stride, long long bin_stride, long long frame_stride, long long n_frames,
+                                 int n_mels, const int* __restrict__ c0, const int* __restrict__ len, const int* __restrict__ off,
+                                 const T* __restrict__ val, T* __restrict__ Mout) {
+    const long long tblocks = (n_frames + 255) / 256;
+    const long long bm = blockIdx.x / tblocks;
+    const long long t = (blockIdx.x % tblocks) * 256 + threadIdx.x;
+    if (t >= n_frames) return;
+    const int m = (int)(bm % n_mels);
+    const long long b = bm / n_mels;
+    const T* __restrict__ src = S + b * batch_stride + (long long)c0[m] * bin_stride + t * frame_stride;
+    const T* __restrict__ w = val + off[m];
+    const int L = len[m];
+    T acc = (T)0;
+    for (int i = 0; i < L; ++i) acc += w[i] * src[(long long)i * bin_stride];
+    Mout[(b * n_mels + m) * n_frames + t] = acc;
+}
+
+// copies [clip][t][k] (strided) into a packed [f][bins] buffer and clears the imaginary parts that
+// a real inverse transform ignores (DC always, Nyquist for even n_fft), as pocketfft's c2r does
+template <class T>
+__global__ void spec_pack_kernel(const cx<T>* __restrict__ D, long long d_batch_stride, long long d_frame_stride, int n_used, int bins, int even,
+                                 long long clip0, long long total_frames, cx<T>* __restrict__ out) {
+    const int chunks = (bins + 255) / 256;
+    const long long f = blockIdx.x / chunks;
+    const int k = (int)(blockIdx.x % chunks) * 256 + threadIdx.x;
+    if (f >= total_frames || k >= bins) return;
+    const long long clip = clip0 + f / n_used;
+    const long long t = f % n_used;
+    cx<T> v = D[clip * d_batch_stride + t * d_frame_stride + k];
+    if (k == 0 || (even && k == bins - 1)) v.y = (T)0;
+    out[f * bins + k] = v;
+}
+
+// gather overlap-add: y[clip][s] = sum_t ws[s' - tH] * x[f(clip,t)][s' - tH] (increasing t), / wss
+template <class T>
+__global__ void ola_gather_kernel(const T* __restrict__ x, int N, int hop, int n_used, int drop, const T* __restrict__ ws, const T* __restrict__ wss,
+                                  T tinyv, long long clip0, long long clips, T* __restrict__ y, long long y_stride, long long out_len) {
+    const long long chunks = (out_len + 255) / 256;
+    const long long c = blockIdx.x / chunks;
+    const long long s = (blockIdx.x % chunks) * 256 + threadIdx.x;
+    if (c >= clips || s >= out_len) return;
+    const long long sp = s + drop;
+    long long t_lo = sp - N + 1;
+    t_lo = t_lo <= 0 ? 0 : (t_lo + hop - 1) / hop;
+    long long t_hi = sp / hop;
+    if (t_hi > n_used - 1) t_hi = n_used - 1;
+    T acc = (T)0;
+    for (long long t = t_lo; t <= t_hi; ++t) {
+        const long long off = sp - t * hop;
+        acc += ws[off] * x[(c * n_used + t) * N + off];
+    }
+    const T w = wss[s];
+    y[(clip0 + c) * y_stride + s] = (w > tinyv) ? acc / w : acc;
+}
+
+template <class E> __global__ void transpose_kernel(const E* __restrict__ src, E* __restrict__ dst, long long rows, long long cols) {
+    __shared__ E tile[32][33];
+    const long long b = blockIdx.z;
+    const long long r0 = (long long)blockIdx.y * 32, c0 = (long long)blockIdx.x * 32;
+    const E* s = src + b * rows * cols;
+    E* d = dst + b * rows * cols;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const long long r = r0 + j, c = c0 + threadIdx.x;
+        if (r < rows && c < cols) tile[j][threadIdx.x] = s[r * cols + c];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const long long c = c0 + j, r = r0 + threadIdx.x;
+        if (r < rows && c < cols) d[c * rows + r] = tile[threadIdx.x][j];
+    }
+}
+
+namespace {
+
+int get_rocfft_plan(FftPlanCache& cache, lra_ctx* ctx, rocfft_transform_type type, int dtype, int n_fft, long long count, rocfft_plan* out) {
+    rocfft_setup_once();
+    auto it = cache.plans.find(count);
+    if (it == cache.plans.end()) {
+        rocfft_plan plan = nullptr;
+        size_t lengths[1] = {(size_t)n_fft};
+        LRA_FFT(rocfft_plan_create(&plan, rocfft_placement_notinplace, type, dtype == LRA_F64 ? rocfft_precision_double : rocfft_precision_single, 1,
+                                   lengths, (size_t)count, nullptr));
+        it = cache.plans.emplace(count, plan).first;
+    }
+    size_t wb = 0;
+    LRA_FFT(rocfft_plan_get_work_buffer_size(it->second, &wb));
+    if (!cache.info) LRA_FFT(rocfft_execution_info_create(&cache.info));
+    if (wb > cache.work_bytes) {
+        if (cache.work) (void)hipFree(cache.work);
+        cache.work = nullptr;
+        LRA_HIP(hipMalloc(&cache.work, wb));
+        cache.work_bytes = wb;
+    }
+    if (wb) LRA_FFT(rocfft_execution_info_set_work_buffer(cache.info, cache.work, cache.work_bytes));
+    LRA_FFT(rocfft_execution_info_set_stream(cache.info, ctx->stream));
+    *out = it->second;
+    return LRA_OK;
+}
+
+int power_mode_of(double power) { return power == 2.0 ? POW_TWO : (power == 1.0 ? POW_ONE : POW_GENERAL); }
+
+// clips per pass of the general path so that the frame scratch stays <= ~4 GiB
+long long general_clip_group(long long batch, long long frames_per_clip, int n_fft, size_t elem) {
+    const double per_clip = (double)frames_per_clip * (double)n_fft * (double)elem;
+    long long g = (long long)(4.0e9 / std::max(per_clip, 1.0));
+    if (g < 1) g = 1;
+    if (g > batch) g = batch;
+    return g;
+}
+
+template <class T>
+int stft_general(lra_stft_plan* p, const T* y, long long batch, long long n, long long y_stride, long long n_frames, cx<T>* D) {
+    lra_ctx* ctx = p->ctx;
+    const int N = p->n_fft, bins = N / 2 + 1;
+    const long long group = general_clip_group(batch, n_frames, N, sizeof(T));
+    LRA_TRY(p->frames.ensure((size_t)group * n_frames * N * sizeof(T)));
+    for (long long c0 = 0; c0 < batch; c0 += group) {
+        const long long clips = std::min(group, batch - c0);
+        const long long total = clips * n_frames;
+        const int chunks = (N + 255) / 256;
+        hipLaunchKernelGGL(frame_window_kernel<T>, dim3((unsigned)(total * chunks)), dim3(256), 0, ctx->stream, y, y_stride, n, (int)n_frames, p->hop,
+                           p->center ? N / 2 : 0, p->pad_mode, (const T*)p->d_win, N, c0, total, (T*)p->frames.p);
+        LRA_HIP(hipGetLastError());
+        rocfft_plan plan;
+        LRA_TRY(get_rocfft_plan(p->fft, ctx, rocfft_transform_type_real_forward, p->dtype, N, total, &plan));
+        void* in[1] = {p->frames.p};
+        void* out[1] = {(void*)(D + c0 * n_frames * bins)};
+        LRA_FFT(rocfft_execute(plan, in, out, p->fft.info));
+    }
+    return LRA_OK;
+}
+
+template <class T>
+int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n, int64_t y_stride, double power, lra_mel_plan* mel, void* out) {
+    LRA_TRY(ctx_bind(p->ctx));
+    int64_t n_frames = 0;
+    LRA_TRY(lra_stft_num_frames(p, n, &n_frames));
+    if (batch <= 0) return LRA_OK;
+    if (!y || !out) return fail(LRA_EINVAL, "null data pointer");
+    if (y_stride < n) return fail(LRA_EINVAL, "y_stride smaller than n");
+    if (n_frames > 0x7fffffffLL / 4) return fail(LRA_EINVAL, "too many frames per clip");
+    lra_ctx* ctx = p->ctx;
+    const int bins = p->n_fft / 2 + 1;
+    if (mode == OUT_MEL) {
+        if (!mel) return fail(LRA_EINVAL, "null mel plan");
+        if (mel->n_bins != bins) return fail(LRA_EINVAL, "mel basis has " + std::to_string(mel->n_bins) + " bins, stft has " + std::to_string(bins));
+        if (mel->dtype != p->dtype) return fail(LRA_EINVAL, "mel plan dtype differs from stft plan dtype");
+    }
+    if (p->pow2) {
+        StftLaunch<T> L;
+        L.a = StftArgs<T>();
+        L.a.y = (const T*)y;
+        L.a.y_stride = y_stride;
+        L.a.n = n;
+        L.a.n_frames = (int)n_frames;
+        L.a.hop = p->hop;
+        L.a.pad = p->center ? p->n_fft / 2 : 0;
+        L.a.pad_mode = p->pad_mode;
+        L.a.win = (const T*)p->d_win;
+        L.a.tw = (const cx<T>*)p->d_tw;
+        L.a.twr = (const cx<T>*)p->d_twr;
+        L.a.D = (cx<T>*)out;
+        L.a.S = (T*)out;
+        L.a.Mel = (T*)out;
+        L.a.power_mode = power_mode_of(power);
+        L.a.power = (T)power;
+        if (mel) {
+            L.a.mel_c0 = mel->d_c0;
+            L.a.mel_len = mel->d_len;
+            L.a.mel_off = mel->d_off;
+            L.a.mel_val = (const T*)mel->d_val;
+            L.a.n_mels = mel->n_mels;
+        }
+        L.a.nonfinite_flag = ctx->d_flag;
+        L.mode = mode;
+        L.batch = batch;
+        L.stream = ctx->stream;
+        L.iters_opt = ctx->opt_stft_iters;
+        if (!dispatch_logm<T>(p->logm, ctx->opt_variant, L)) return fail(LRA_EINVAL, "unsupported power-of-two size");
+        if (L.err != hipSuccess) return fail(LRA_EHIP, std::string("stft kernel launch: ") + hipGetErrorString(L.err));
+        return LRA_OK;
+    }
+    // general path
+    if (mode == OUT_COMPLEX) return stft_general<T>(p, (const T*)y, batch, n, y_stride, n_frames, (cx<T>*)out);
+    // power / mel need the complex spectrum in scratch, one clip group at a time
+    const long long group = general_clip_group(batch, n_frames, p->n_fft, sizeof(T));
+    LRA_TRY(p->spec.ensure((size_t)group * n_frames * bins * sizeof(cx<T>) + (mode == OUT_MEL ? (size_t)group * n_frames * bins * sizeof(T) : 0)));
+    cx<T>* Dtmp = (cx<T>*)p->spec.p;
+    T* Stmp = (T*)((char*)p->spec.p + (size_t)group * n_frames * bins * sizeof(cx<T>));
+    for (long long c0 = 0; c0 < batch; c0 += group) {
+        const long long clips = std::min<long long>(group, batch - c0);
+        LRA_TRY(stft_general<T>(p, (const T*)y + c0 * y_stride, clips, n, y_stride, n_frames, Dtmp));
+        const long long count = clips * n_frames * bins;
+        T* Sdst = mode == OUT_POWER ? (T*)out + c0 * n_frames * bins : Stmp;
+        hipLaunchKernelGGL(power_kernel<T>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, Dtmp, Sdst, count, power_mode_of(power), (T)power);
+        LRA_HIP(hipGetLastError());
+        if (mode == OUT_MEL) {
+            const long long tblocks = (n_frames + 255) / 256;
+            hipLaunchKernelGGL(mel_apply_kernel<T>, dim3((unsigned)(tblocks * mel->n_mels * clips)), dim3(256), 0, ctx->stream, Stmp, n_frames * bins, 1LL,
+                               (long long)bins, n_frames, mel->n_mels, mel->d_c0, mel->d_len, mel->d_off, (const T*)mel->d_val,
+                               (T*)out + c0 * mel->n_mels * n_frames);
+            LRA_HIP(hipGetLastError());
+        }
+    }
+    return LRA_OK;
+}
+
+template <class T>
+int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_stride, int64_t d_frame_stride, int64_t n_used, const void* wss, void* y,
+              int64_t out_len, int64_t y_stride) {
+    LRA_TRY(ctx_bind(p->ctx));
+    lra_ctx* ctx = p->ctx;
+    const int N = p->n_fft, bins = N / 2 + 1;
+    if (batch <= 0 || out_len <= 0) return LRA_OK;
+    if (!y || !wss) return fail(LRA_EINVAL, "null data pointer");
+    if (y_stride < out_len) return fail(LRA_EINVAL, "y_stride smaller than out_len");
+    if (y_stride == out_len) {
+        LRA_HIP(hipMemsetAsync(y, 0, (size_t)batch * out_len * sizeof(T), ctx->stream));
+    } else {
+        LRA_HIP(hipMemset2DAsync(y, (size_t)y_stride * sizeof(T), 0, (size_t)out_len * sizeof(T), (size_t)batch, ctx->stream));
+    }
+    if (n_used <= 0) return LRA_OK;
+    if (!D) return fail(LRA_EINVAL, "null spectrum pointer");
+    if (d_frame_stride < bins) return fail(LRA_EINVAL, "d_frame_stride smaller than n_bins");
+    const T tinyv = sizeof(T) == 8 ? (T)2.2250738585072014e-308 : (T)1.17549435e-38f;
+    if (p->pow2) {
+        IstftLaunch<T> L;
+        L.a = IstftArgs<T>();
+        L.a.D = (const cx<T>*)D;
+        L.a.d_batch_stride = d_batch_stride;
+        L.a.d_frame_stride = d_frame_stride;
+        L.a.n_used = (int)n_used;
+        L.a.hop = p->hop;
+        L.a.drop = p->center ? N / 2 : 0;
+        L.a.win_scaled = (const T*)p->d_win_scaled;
+        L.a.tw = (const cx<T>*)p->d_tw;
+        L.a.twr = (const cx<T>*)p->d_twr;
+        L.a.wss = (const T*)wss;
+        L.a.tiny = tinyv;
+        L.a.y = (T*)y;
+        L.a.y_stride = y_stride;
+        L.a.out_len = out_len;
+        L.batch = batch;
+        L.stream = ctx->stream;
+        L.strip_groups = ctx->opt_istft_strip_groups > 0 ? ctx->opt_istft_strip_groups : 16;
+        if (!dispatch_logm<T>(p->logm, ctx->opt_variant, L)) return fail(LRA_EINVAL, "unsupported power-of-two size");
+        if (L.err != hipSuccess) return fail(LRA_EHIP, std::string("istft kernel launch: ") + hipGetErrorString(L.err));
+        return LRA_OK;
+    }
+    // general path: pack -> rocFFT C2R -> gather overlap-add, one clip group at a time
+    const long long group = general_clip_group(batch, n_used, N, sizeof(T));
+    LRA_TRY(p->spec.ensure((size_t)group * n_used * bins * sizeof(cx<T>)));
+    LRA_TRY(p->frames.ensure((size_t)group * n_used * N * sizeof(T)));
+    for (long long c0 = 0; c0 < batch; c0 += group) {
+        const long long clips = std::min<long long>(group, batch - c0);
+        const long long total = clips * n_used;
+        const int chunks = (bins + 255) / 256;
+        hipLaunchKernelGGL(spec_pack_kernel<T>, dim3((unsigned)(total * chunks)), dim3(256), 0, ctx->stream, (const cx<T>*)D, (long long)d_batch_stride,
+                           (long long)d_frame_stride, (int)n_used, bins, (N % 2) == 0 ? 1 : 0, c0, total, (cx<T>*)p->spec.p);
+        LRA_HIP(hipGetLastError());
+        rocfft_plan plan;
+        LRA_TRY(get_rocfft_plan(p->fft, ctx, rocfft_transform_type_real_inverse, p->dtype, N, total, &plan));
+        void* in[1] = {p->spec.p};
+        void* outb[1] = {p->frames.p};
+        LRA_FFT(rocfft_execute(plan, in, outb, p->fft.info));
+        const long long ochunks = (out_len + 255) / 256;
+        hipLaunchKernelGGL(ola_gather_kernel<T>, dim3((unsigned)(clips * ochunks)), dim3(256), 0, ctx->stream, (const T*)p->frames.p, N, p->hop, (int)n_used,
+                           p->center ? N / 2 : 0, (const T*)p->d_win_scaled, (const T*)wss, tinyv, c0, clips, (T*)y, (long long)y_stride, (long long)out_len);
+        LRA_HIP(hipGetLastError());
+    }
+    return LRA_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* lra_last_error(void) { return g_err.c_str(); }
+const char* lra_version(void) { return "librosa_amd 0.1 (gfx950)"; }
+
+int lra_device_count(int* count) {
+    if (!count) return fail(LRA_EINVAL, "null count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(LRA_ENODEV, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *count = n;
+    return LRA_OK;
+}
+
+int lra_ctx_create(int device, lra_ctx** out) {
+    if (!out) return fail(LRA_EINVAL, "null out");
+    *out = nullptr;
+    int n = 0;
+    if (lra_device_count(&n) != LRA_OK || n <= 0) return fail(LRA_ENODEV, "no HIP device available: librosa_amd has no CPU fallback");
+    if (device < 0 || device >= n) return fail(LRA_EINVAL, "device index out of range");
+    LRA_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    LRA_HIP(hipGetDeviceProperties(&prop, device));
+    lra_ctx* c = new lra_ctx();
+    c->device = device;
+    c->n_cu = prop.multiProcessorCount;
+    c->name = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    hipError_t e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(LRA_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    c->stream = c->own_stream;
+    e = hipMalloc((void**)&c->d_flag, sizeof(unsigned int));
+    if (e == hipSuccess) e = hipMemset(c->d_flag, 0, sizeof(unsigned int));
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(c->own_stream);
+        delete c;
+        return fail(LRA_EHIP, std::string("flag allocation: ") + hipGetErrorString(e));
+    }
+    *out = c;
+    return LRA_OK;
+}
+
+void lra_ctx_destroy(lra_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->d_flag) (void)hipFree(ctx->d_flag);
+    delete ctx;
+}
+
+int lra_ctx_set_stream(lra_ctx* ctx, void* hip_stream) {
+    if (!ctx) return fail(LRA_EINVAL, "null context");
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return LRA_OK;
+}
+
+int lra_ctx_sync(lra_ctx* ctx) {
+    LRA_TRY(ctx_bind(ctx));
+    LRA_HIP(hipStreamSynchronize(ctx->stream));
+    return LRA_OK;
+}
+
+int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value) {
+    if (!ctx || !key) return fail(LRA_EINVAL, "null argument");
+    if (!std::strcmp(key, "stft_iters")) ctx->opt_stft_iters = value;
+    else if (!std::strcmp(key, "istft_strip_groups")) ctx->opt_istft_strip_groups = value;
+    else if (!std::strcmp(key, "variant")) ctx->opt_variant = (value >= 0 && value < kNumVariants) ? value : 0;
+    else return fail(LRA_EINVAL, std::string("unknown option ") + key);
+    return LRA_OK;
+}
+
+int lra_ctx_nonfinite_reset(lra_ctx* ctx) {
+    LRA_TRY(ctx_bind(ctx));
+    LRA_HIP(hipMemsetAsync(ctx->d_flag, 0, sizeof(unsigned int), ctx->stream));
+    return LRA_OK;
+}
+
+int lra_ctx_nonfinite_read(lra_ctx* ctx, int* flag) {
+    LRA_TRY(ctx_bind(ctx));
+    if (!flag) return fail(LRA_EINVAL, "null flag");
+    unsigned int h = 0;
+    LRA_HIP(hipMemcpyAsync(&h, ctx->d_flag, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    LRA_HIP(hipStreamSynchronize(ctx->stream));
+    *flag = (int)h;
+    return LRA_OK;
+}
+
+int lra_ctx_device_name(lra_ctx* ctx, char* buf, size_t buflen) {
+    if (!ctx || !buf || !buflen) return fail(LRA_EINVAL, "null argument");
+    std::snprintf(buf, buflen, "%s, %d CUs", ctx->name.c_str(), ctx->n_cu);
+    return LRA_OK;
+}
+
+int lra_malloc(lra_ctx* ctx, size_t bytes, void** dptr) {
+    LRA_TRY(ctx_bind(ctx));
+    if (!dptr) return fail(LRA_EINVAL, "null dptr");
+    *dptr = nullptr;
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? LRA_ENOMEM : LRA_EHIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return LRA_OK;
+}
+
+int lra_free(lra_ctx* ctx, void* dptr) {
+    LRA_TRY(ctx_bind(ctx));
+    if (dptr) LRA_HIP(hipFree(dptr));
+    return LRA_OK;
+}
+
+int lra_memset(lra_ctx* ctx, void* dptr, int value, size_t bytes) {
+    LRA_TRY(ctx_bind(ctx));
+    LRA_HIP(hipMemsetAsync(dptr, value, bytes, ctx->stream));
+    return LRA_OK;
+}
+
+int lra_memcpy_h2d(lra_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+    LRA_TRY(ctx_bind(ctx));
+    LRA_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    LRA_HIP(hipStreamSynchronize(ctx->stream));
+    return LRA_OK;
+}
+
+int lra_memcpy_d2h(lra_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+    LRA_TRY(ctx_bind(ctx));
+    LRA_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    LRA_HIP(hipStreamSynchronize(ctx->stream));
+    return LRA_OK;
+}
+
+int lra_event_create(lra_ctx* ctx, lra_event** out) {
+    LRA_TRY(ctx_bind(ctx));
+    if (!out) return fail(LRA_EINVAL, "null out");
+    lra_event* e = new lra_event();
+    e->ctx = ctx;
+    hipError_t err = hipEventCreate(&e->ev);
+    if (err != hipSuccess) {
+        delete e;
+        return fail(LRA_EHIP, std::string("hipEventCreate: ") + hipGetErrorString(err));
+    }
+    *out = e;
+    return LRA_OK;
+}
+
+void lra_event_destroy(lra_event* ev) {
+    if (!ev) return;
+    (void)hipEventDestroy(ev->ev);
+    delete ev;
+}
+
+int lra_event_record(lra_event* ev) {
+    if (!ev) return fail(LRA_EINVAL, "null event");
+    LRA_TRY(ctx_bind(ev->ctx));
+    LRA_HIP(hipEventRecord(ev->ev, ev->ctx->stream));
+    return LRA_OK;
+}
+
+int lra_event_elapsed_ms(lra_event* start, lra_event* stop, float* ms) {
+    if (!start || !stop || !ms) return fail(LRA_EINVAL, "null argument");
+    LRA_TRY(ctx_bind(stop->ctx));
+    LRA_HIP(hipEventSynchronize(stop->ev));
+    LRA_HIP(hipEventElapsedTime(ms, start->ev, stop->ev));
+    return LRA_OK;
+}
+
+// ---- STFT ---------------------------------------------------------------------------------------
+int lra_stft_plan_create(lra_ctx* ctx, int n_fft, int hop_length, const void* window_host, int center, int pad_mode, int dtype, lra_stft_plan** out) {
+    LRA_TRY(ctx_bind(ctx));
+    if (!out) return fail(LRA_EINVAL, "null out");
+    *out = nullptr;
+    if (n_fft < 1) return fail(LRA_EINVAL, "n_fft must be positive");
+    if (hop_length < 1) return fail(LRA_EINVAL, "hop_length=" + std::to_string(hop_length) + " must be a positive integer");
+    if (!window_host) return fail(LRA_EINVAL, "null window");
+    if (dtype != LRA_F32 && dtype != LRA_F64) return fail(LRA_EINVAL, "bad dtype");
+    if (pad_mode < LRA_PAD_CONSTANT || pad_mode > LRA_PAD_SYMMETRIC) return fail(LRA_EINVAL, "bad pad_mode");
+    lra_stft_plan* p = new lra_stft_plan();
+    p->ctx = ctx;
+    p->n_fft = n_fft;
+    p->hop = hop_length;
+    p->center = center ? 1 : 0;
+    p->pad_mode = pad_mode;
+    p->dtype = dtype;
+    p->pow2 = pow2_supported(n_fft, dtype == LRA_F64);
+    int rc = upload(&p->d_win, window_host, (size_t)n_fft * real_bytes(dtype));
+    if (rc == LRA_OK && p->pow2) {
+        p->logm = log2_exact(n_fft) - 1;
+        rc = dtype == LRA_F64 ? build_tables<double>(p->logm, &p->d_tw, &p->d_twr) : build_tables<float>(p->logm, &p->d_tw, &p->d_twr);
+    }
+    if (rc != LRA_OK) {
+        lra_stft_plan_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return LRA_OK;
+}
+
+void lra_stft_plan_destroy(lra_stft_plan* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    if (p->d_win) (void)hipFree(p->d_win);
+    if (p->d_tw) (void)hipFree(p->d_tw);
+    if (p->d_twr) (void)hipFree(p->d_twr);
+    delete p;
+}
+
+int lra_stft_num_frames(const lra_stft_plan* p, int64_t n, int64_t* n_frames) {
+    if (!p || !n_frames) return fail(LRA_EINVAL, "null argument");
+    if (n < 0) return fail(LRA_EINVAL, "negative signal length");
+    const int64_t padded = n + (p->center ? 2 * (int64_t)(p->n_fft / 2) : 0);
+    if (padded < p->n_fft) {
+        if (p->center) return fail(LRA_EINVAL, "Input is too short (n=" + std::to_string(padded) + ") for frame_length=" + std::to_string(p->n_fft));
+        return fail(LRA_EINVAL, "n_fft=" + std::to_string(p->n_fft) + " is too large for uncentered analysis of input signal of length=" + std::to_string(n));
+    }
+    *n_frames = 1 + (padded - p->n_fft) / p->hop;
+    return LRA_OK;
+}
+
+int lra_stft_plan_is_fused(const lra_stft_plan* p) { return p && p->pow2 ? 1 : 0; }
+
+int lra_stft_exec(lra_stft_plan* p, const void* y, int64_t batch, int64_t n, int64_t y_stride, void* D) {
+    if (!p) return fail(LRA_EINVAL, "null plan");
+    return p->dtype == LRA_F64 ? stft_run<double>(p, OUT_COMPLEX, y, batch, n, y_stride, 1.0, nullptr, D)
+                               : stft_run<float>(p, OUT_COMPLEX, y, batch, n, y_stride, 1.0, nullptr, D);
+}
+
+int lra_spectrogram_exec(lra_stft_plan* p, const void* y, int64_t batch, int64_t n, int64_t y_stride, double power, void* S) {
+    if (!p) return fail(LRA_EINVAL, "null plan");
+    return p->dtype == LRA_F64 ? stft_run<double>(p, OUT_POWER, y, batch, n, y_stride, power, nullptr, S)
+                               : stft_run<float>(p, OUT_POWER, y, batch, n, y_stride, power, nullptr, S);
+}
+
+// ---- mel ----------------------------------------------------------------------------------------
+int lra_mel_plan_create(lra_ctx* ctx, int n_mels, int n_bins, const void* basis_host, int dtype, lra_mel_plan** out) {
+    LRA_TRY(ctx_bind(ctx));
+    if (!out) return fail(LRA_EINVAL, "null out");
+    *out = nullptr;
+    if (n_mels < 1 || n_bins < 1 || !basis_host) return fail(LRA_EINVAL, "bad mel basis");
+    if (dtype != LRA_F32 && dtype != LRA_F64) return fail(LRA_EINVAL, "bad dtype");
+    std::vector<int> c0(n_mels, 0), len(n_mels, 0), off(n_mels, 0);
+    std::vector<char> vals;
+    const size_t es = real_bytes(dtype);
+    const char* B = (const char*)basis_host;
+    auto nonzero = [&](int m, int c) {
+        return dtype == LRA_F64 ? ((const double*)B)[(size_t)m * n_bins + c] != 0.0 : ((const float*)B)[(size_t)m * n_bins + c] != 0.0f;
+    };
+    int pos = 0;
+    for (int m = 0; m < n_mels; ++m) {
+        int first = -1, last = -1;
+        for (int c = 0; c < n_bins; ++c)
+            if (nonzero(m, c)) {
+                if (first < 0) first = c;
+                last = c;
+            }
+        off[m] = pos;
+        if (first >= 0) {
+            c0[m] = first;
+            len[m] = last - first + 1;
+            vals.insert(vals.end(), B + ((size_t)m * n_bins + first) * es, B + ((size_t)m * n_bins + last + 1) * es);
+            pos += len[m];
+        }
+    }
+    lra_mel_plan* p = new lra_mel_plan();
+    p->ctx = ctx;
+    p->n_mels = n_mels;
+    p->n_bins = n_bins;
+    p->dtype = dtype;
+    int rc = upload((void**)&p->d_c0, c0.data(), c0.size() * sizeof(int));
+    if (rc == LRA_OK) rc = upload((void**)&p->d_len, len.data(), len.size() * sizeof(int));
+    if (rc == LRA_OK) rc = upload((void**)&p->d_off, off.data(), off.size() * sizeof(int));
+    if (rc == LRA_OK) rc = upload(&p->d_val, vals.data(), vals.size());
+    if (rc != LRA_OK) {
+        lra_mel_plan_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return LRA_OK;
+}
+
+void lra_mel_plan_destroy(lra_mel_plan* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    if (p->d_c0) (void)hipFree(p->d_c0);
+    if (p->d_len) (void)hipFree(p->d_len);
+    if (p->d_off) (void)hipFree(p->d_off);
+    if (p->d_val) (void)hipFree(p->d_val);
+    delete p;
+}
+
+int lra_melspectrogram_exec(lra_stft_plan* stft, lra_mel_plan* mel, const void* y, int64_t batch, int64_t n, int64_t y_stride, double power, void* M) {
+    if (!stft || !mel) return fail(LRA_EINVAL, "null plan");
+    return stft->dtype == LRA_F64 ? stft_run<double>(stft, OUT_MEL, y, batch, n, y_stride, power, mel, M)
+                                  : stft_run<float>(stft, OUT_MEL, y, batch, n, y_stride, power, mel, M);
+}
+
+int lra_mel_apply_exec(lra_mel_plan* mel, const void* S, int64_t batch, int64_t n_frames, int64_t batch_stride, int64_t bin_stride, int64_t frame_stride,
+                       void* M) {
+    if (!mel) return fail(LRA_EINVAL, "null plan");
+    LRA_TRY(ctx_bind(mel->ctx));
+    if (batch <= 0 || n_frames <= 0) return LRA_OK;
+    if (!S || !M) return fail(LRA_EINVAL, "null data pointer");
+    const long long tblocks = (n_frames + 255) / 256;
+    const long long grid = tblocks * mel->n_mels * batch;
+    if (grid > 0x7fffffffLL) return fail(LRA_EINVAL, "grid too large");
+    if (mel->dtype == LRA_F64)
+        hipLaunchKernelGGL(mel_apply_kernel<double>, dim3((unsigned)grid), dim3(256), 0, mel->ctx->stream, (const double*)S, (long long)batch_stride,
+                           (long long)bin_stride, (long long)frame_stride, (long long)n_frames, mel->n_mels, mel->d_c0, mel->d_len, mel->d_off,
+                           (const double*)mel->d_val, (double*)M);
+    else
+        hipLaunchKernelGGL(mel_apply_kernel<float>, dim3((unsigned)grid), dim3(256), 0, mel->ctx->stream, (const float*)S, (long long)batch_stride,
+                           (long long)bin_stride, (long long)frame_stride, (long long)n_frames, mel->n_mels, mel->d_c0, mel->d_len, mel->d_off,
+                           (const float*)mel->d_val, (float*)M);
+    LRA_HIP(hipGetLastError());
+    return LRA_OK;
+}
+
+// ---- ISTFT --------------------------------------------------------------------------------------
+int lra_istft_plan_create(lra_ctx* ctx, int n_fft, int hop_length, const void* window_host, int center, int dtype, lra_istft_plan** out) {
+    LRA_TRY(ctx_bind(ctx));
+    if (!out) return fail(LRA_EINVAL, "null out");
+    *out = nullptr;
+    if (n_fft < 1) return fail(LRA_EINVAL, "n_fft must be positive");
+    if (hop_length < 1) return fail(LRA_EINVAL, "hop_length must be a positive integer");
+    if (!window_host) return fail(LRA_EINVAL, "null window");
+    if (dtype != LRA_F32 && dtype != LRA_F64) return fail(LRA_EINVAL, "bad dtype");
+    lra_istft_plan* p = new lra_istft_plan();
+    p->ctx = ctx;
+    p->n_fft = n_fft;
+    p->hop = hop_length;
+    p->center = center ? 1 : 0;
+    p->dtype = dtype;
+    p->pow2 = pow2_supported(n_fft, dtype == LRA_F64);
+    int rc;
+    if (dtype == LRA_F64) {
+        std::vector<double> ws(n_fft);
+        for (int i = 0; i < n_fft; ++i) ws[i] = ((const double*)window_host)[i] / (double)n_fft;
+        rc = upload(&p->d_win_scaled, ws.data(), ws.size() * sizeof(double));
+    } else {
+        std::vector<float> ws(n_fft);
+        for (int i = 0; i < n_fft; ++i) ws[i] = (float)((double)((const float*)window_host)[i] / (double)n_fft);
+        rc = upload(&p->d_win_scaled, ws.data(), ws.size() * sizeof(float));
+    }
+    if (rc == LRA_OK && p->pow2) {
+        p->logm = log2_exact(n_fft) - 1;
+        rc = dtype == LRA_F64 ? build_tables<double>(p->logm, &p->d_tw, &p->d_twr) : build_tables<float>(p->logm, &p->d_tw, &p->d_twr);
+    }
+    if (rc != LRA_OK) {
+        lra_istft_plan_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return LRA_OK;
+}
+
+void lra_istft_plan_destroy(lra_istft_plan* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    if (p->d_win_scaled) (void)hipFree(p->d_win_scaled);
+    if (p->d_tw) (void)hipFree(p->d_tw);
+    if (p->d_twr) (void)hipFree(p->d_twr);
+    delete p;
+}
+
+int lra_istft_exec(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_stride, int64_t d_frame_stride, int64_t n_used, const void* wss,
+                   void* y, int64_t out_len, int64_t y_stride) {
+    if (!p) return fail(LRA_EINVAL, "null plan");
+    return p->dtype == LRA_F64 ? istft_run<double>(p, D, batch, d_batch_stride, d_frame_stride, n_used, wss, y, out_len, y_stride)
+                               : istft_run<float>(p, D, batch, d_batch_stride, d_frame_stride, n_used, wss, y, out_len, y_stride);
+}
+
+// ---- transpose ----------------------------------------------------------------------------------
+int lra_transpose(lra_ctx* ctx, const void* src, void* dst, int64_t batch, int64_t rows, int64_t cols, int elem_bytes) {
+    LRA_TRY(ctx_bind(ctx));
+    if (batch <= 0 || rows <= 0 || cols <= 0) return LRA_OK;
+    if (!src || !dst) return fail(LRA_EINVAL, "null data pointer");
+    if (batch > 65535) return fail(LRA_EINVAL, "transpose batch too large");
+    dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32), (unsigned)batch), block(32, 8);
+    if (grid.y > 65535) return fail(LRA_EINVAL, "transpose rows too large");
+    switch (elem_bytes) {
+        case 4: hipLaunchKernelGGL(transpose_kernel<uint32_t>, grid, block, 0, ctx->stream, (const uint32_t*)src, (uint32_t*)dst, (long long)rows, (long long)cols); break;
+        case 8: hipLaunchKernelGGL(transpose_kernel<uint64_t>, grid, block, 0, ctx->stream, (const uint64_t*)src, (uint64_t*)dst, (long long)rows, (long long)cols); break;
+        case 16: hipLaunchKernelGGL(transpose_kernel<double2>, grid, block, 0, ctx->stream, (const double2*)src, (double2*)dst, (long long)rows, (long long)cols); break;
+        default: return fail(LRA_EINVAL, "elem_bytes must be 4, 8 or 16");
+    }
+    LRA_HIP(hipGetLastError());
+    return LRA_OK;
+}
+
+}  // extern "C"

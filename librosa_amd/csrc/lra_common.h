@@ -1,0 +1,146 @@
+// lra_common.h -- shared definitions for the gfx950 kernels of the STFT -> mel / ISTFT path.
+//
+// The kernel bodies in lra_fft.h / lra_kernels.h are written once and compiled two ways:
+//   * by hipcc for gfx950 (the product), where a "phase" is straight-line code executed by every
+//     thread of the workgroup followed by __syncthreads();
+//   * by g++ with -DLRA_HOSTSIM (tests/hostsim, test infrastructure only), where a phase is a
+//     loop over the workgroup's threads and every LDS access goes through a shadow that reports
+//     cross-thread races inside a phase and reads of never-written LDS.  This is how index math
+//     and barrier placement are checked in the build container, which has no GPU.
+// The host simulation is never linked into the product library.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+
+#ifdef LRA_HOSTSIM
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#define LRA_HD inline
+#define LRA_UNROLL _Pragma("GCC unroll 64")
+#else
+#include <hip/hip_runtime.h>
+#define LRA_HD __host__ __device__ __forceinline__
+#define LRA_UNROLL _Pragma("unroll")
+#endif
+
+namespace lra {
+
+// ----------------------------------------------------------------------------- complex helpers
+template <class T> struct alignas(2 * sizeof(T)) cx {
+    T x, y;
+};
+template <class T> LRA_HD cx<T> mk(T x, T y) { cx<T> r; r.x = x; r.y = y; return r; }
+template <class T> LRA_HD cx<T> cadd(cx<T> a, cx<T> b) { return mk<T>(a.x + b.x, a.y + b.y); }
+template <class T> LRA_HD cx<T> csub(cx<T> a, cx<T> b) { return mk<T>(a.x - b.x, a.y - b.y); }
+template <class T> LRA_HD cx<T> cmul(cx<T> a, cx<T> b) { return mk<T>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+template <class T> LRA_HD cx<T> cconj(cx<T> a) { return mk<T>(a.x, -a.y); }
+// multiply by -i (forward-transform quarter turn)
+template <class T> LRA_HD cx<T> cmul_mi(cx<T> a) { return mk<T>(a.y, -a.x); }
+
+// pad modes for centred framing (np.pad modes the reference forwards, core/spectrum.py:287)
+enum PadMode : int { PAD_CONSTANT = 0, PAD_REFLECT = 1, PAD_EDGE = 2, PAD_SYMMETRIC = 3 };
+
+// Index into a signal of length n for a (possibly out-of-range) position g under a pad mode.
+// Returns -1 for "zero" (constant mode or empty signal).  Matches np.pad, including repeated
+// reflection when the pad is longer than the signal.
+LRA_HD long long pad_index(long long g, long long n, int mode) {
+    if (g >= 0 && g < n) return g;
+    if (n <= 0 || mode == PAD_CONSTANT) return -1;
+    if (mode == PAD_EDGE || n == 1) return g < 0 ? 0 : n - 1;
+    if (mode == PAD_REFLECT) {
+        const long long period = 2 * (n - 1);
+        long long m = g % period;
+        if (m < 0) m += period;
+        return m < n ? m : period - m;
+    }
+    // symmetric
+    const long long period = 2 * n;
+    long long m = g % period;
+    if (m < 0) m += period;
+    return m < n ? m : period - 1 - m;
+}
+
+// ----------------------------------------------------------------------------- LDS access layer
+#ifdef LRA_HOSTSIM
+namespace sim {
+struct State {
+    std::vector<unsigned char> mem;
+    std::vector<int> w_epoch, w_tid, r_epoch, r_tid;  // per 4-byte word
+    std::vector<unsigned char> ever;
+    int epoch = 1;
+    int cur_tid = 0;
+    long long races = 0, uninit = 0;
+    void resize(size_t bytes) {
+        mem.assign(bytes, 0xCD);
+        size_t w = (bytes + 3) / 4;
+        w_epoch.assign(w, 0); w_tid.assign(w, -1); r_epoch.assign(w, 0); r_tid.assign(w, -1); ever.assign(w, 0);
+    }
+    void barrier() { ++epoch; }
+    void note_read(size_t off, size_t bytes) {
+        if (off + bytes > mem.size()) { std::fprintf(stderr, "hostsim: LDS read out of bounds off=%zu\n", off); std::abort(); }
+        for (size_t w = off / 4; w < (off + bytes + 3) / 4; ++w) {
+            if (!ever[w]) ++uninit;
+            if (w_epoch[w] == epoch && w_tid[w] != cur_tid) ++races;
+            if (r_epoch[w] != epoch) { r_epoch[w] = epoch; r_tid[w] = cur_tid; }
+            else if (r_tid[w] != cur_tid) r_tid[w] = -2;  // several readers this phase
+        }
+    }
+    void note_write(size_t off, size_t bytes) {
+        if (off + bytes > mem.size()) { std::fprintf(stderr, "hostsim: LDS write out of bounds off=%zu\n", off); std::abort(); }
+        for (size_t w = off / 4; w < (off + bytes + 3) / 4; ++w) {
+            if (w_epoch[w] == epoch && w_tid[w] != cur_tid) ++races;
+            if (r_epoch[w] == epoch && r_tid[w] != cur_tid) ++races;
+            w_epoch[w] = epoch; w_tid[w] = cur_tid; ever[w] = 1;
+        }
+    }
+};
+inline State& state() { static thread_local State s; return s; }
+}  // namespace sim
+
+struct Lds {
+    size_t base;  // byte offset of this view inside the simulated LDS
+};
+template <class V> inline V lds_ld(Lds l, int byte_off) {
+    auto& s = sim::state();
+    s.note_read(l.base + byte_off, sizeof(V));
+    V v; std::memcpy(&v, s.mem.data() + l.base + byte_off, sizeof(V)); return v;
+}
+template <class V> inline void lds_st(Lds l, int byte_off, V v) {
+    auto& s = sim::state();
+    s.note_write(l.base + byte_off, sizeof(V));
+    std::memcpy(s.mem.data() + l.base + byte_off, &v, sizeof(V));
+}
+inline Lds lds_sub(Lds l, int byte_off) { Lds r; r.base = l.base + byte_off; return r; }
+
+#define LRA_LAUNDER(p) ((void)0)
+#define LRA_ATOMIC_OR(ptr, v) (*(ptr) |= (v))
+#define LRA_PHASE(NT, tid) for (int tid = 0; tid < (NT); ++tid) { ::lra::sim::state().cur_tid = tid;
+#define LRA_PHASE_END } ::lra::sim::state().barrier();
+#define LRA_REGS(Type, name, NT) std::vector<Type> name##_all(NT)
+#define LRA_R(name) name##_all[tid]
+
+#else  // device build
+
+struct Lds {
+    char* base;
+};
+template <class V> LRA_HD V lds_ld(Lds l, int byte_off) { return *reinterpret_cast<const V*>(l.base + byte_off); }
+template <class V> LRA_HD void lds_st(Lds l, int byte_off, V v) { *reinterpret_cast<V*>(l.base + byte_off) = v; }
+LRA_HD Lds lds_sub(Lds l, int byte_off) { Lds r; r.base = l.base + byte_off; return r; }
+
+// makes the compiler forget what it knows about a (uniform) pointer: loads through it cannot be
+// hoisted out of the enclosing loop
+#define LRA_LAUNDER(p) asm volatile("" : "+s"(p))
+#define LRA_ATOMIC_OR(ptr, v) atomicOr((ptr), (v))
+#define LRA_PHASE(NT, tid) { const int tid = (int)threadIdx.x;
+#define LRA_PHASE_END } __syncthreads();
+#define LRA_REGS(Type, name, NT) Type name
+#define LRA_R(name) name
+
+#endif
+
+}  // namespace lra

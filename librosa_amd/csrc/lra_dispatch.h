@@ -1,0 +1,73 @@
+// lra_dispatch.h -- n_fft -> compile-time FFT configuration, shared by the gfx950 library
+// (lra_api.hip) and the CPU thread simulator (tests/hostsim).
+#pragma once
+
+#include "lra_kernels.h"
+
+namespace lra {
+
+constexpr int kMinLogM = 4;     // n_fft = 32
+constexpr int kMaxLogM = 13;    // n_fft = 16384 (M = 8192 complex: 68 KiB of LDS per frame in f32)
+constexpr int kMaxLogM64 = 12;  // f64: n_fft <= 8192
+constexpr int kNumVariants = 4; // tuning variants exist for f32 n_fft = 2048 only
+
+// Compile-time configuration per (dtype, log2 M, variant).  Variant 0 is the default:
+//   f32: 16 complex points per thread, 256-VGPR budget (2 waves/SIMD), window/twiddle values kept
+//        in registers across the frame loop for n_fft <= 2048 (no table traffic in steady state);
+//   f64:  8 complex points per thread, 256-VGPR budget, tables re-read from L1/L2 every frame.
+// Variants 1..3 (f32, n_fft = 2048) trade registers for occupancy; bench.py --sweep times them.
+template <class T, int L, int VAR> struct CfgSel {
+    using type = FftCfg<L, 4, T, 256, 2, (L <= 10)>;
+};
+template <int L, int VAR> struct CfgSel<double, L, VAR> {
+    using type = FftCfg<L, 3, double, 256, 2, false>;
+};
+template <> struct CfgSel<float, 10, 1> {
+    using type = FftCfg<10, 3, float, 256, 4, false>;
+};
+template <> struct CfgSel<float, 10, 2> {
+    using type = FftCfg<10, 4, float, 256, 3, false>;
+};
+template <> struct CfgSel<float, 10, 3> {
+    using type = FftCfg<10, 4, float, 256, 4, false>;
+};
+
+// true when n_fft is a power of two handled by the fused LDS kernels
+inline bool pow2_supported(int n_fft, bool f64) {
+    if (n_fft <= 0 || (n_fft & (n_fft - 1))) return false;
+    int logn = 0;
+    while ((1 << logn) < n_fft) ++logn;
+    const int logm = logn - 1;
+    return logm >= kMinLogM && logm <= (f64 ? kMaxLogM64 : kMaxLogM);
+}
+
+inline int log2_exact(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+// Calls f.template operator()<Cfg>() for the configuration of (T, logm, variant); returns false if
+// unsupported.
+template <class T, class F> inline bool dispatch_logm(int logm, int variant, F&& f) {
+    switch (logm) {
+#define LRA_CASE(L) \
+    case L: f.template operator()<typename CfgSel<T, L, 0>::type>(); return true;
+        LRA_CASE(4) LRA_CASE(5) LRA_CASE(6) LRA_CASE(7) LRA_CASE(8) LRA_CASE(9) LRA_CASE(11) LRA_CASE(12)
+#undef LRA_CASE
+        case 10:
+            if constexpr (sizeof(T) == 4) {
+                if (variant == 1) { f.template operator()<typename CfgSel<T, 10, 1>::type>(); return true; }
+                if (variant == 2) { f.template operator()<typename CfgSel<T, 10, 2>::type>(); return true; }
+                if (variant == 3) { f.template operator()<typename CfgSel<T, 10, 3>::type>(); return true; }
+            }
+            f.template operator()<typename CfgSel<T, 10, 0>::type>();
+            return true;
+        case 13:
+            if constexpr (sizeof(T) == 4) { f.template operator()<typename CfgSel<T, 13, 0>::type>(); return true; }
+            return false;
+        default: return false;
+    }
+}
+
+}  // namespace lra

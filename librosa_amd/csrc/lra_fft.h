@@ -1,0 +1,177 @@
+// lra_fft.h -- power-of-two complex FFT machinery for one frame held in LDS.
+//
+// A real frame of N = 2M samples is transformed through an M-point complex FFT of
+// z[n] = x[2n] + i x[2n+1] (the standard even/odd packing), followed by a split step.  The
+// M-point FFT is a Stockham autosort FFT with P passes of radix 2^logr(p) <= R; every thread
+// keeps R complex points in registers, so one frame occupies TF = M/R threads and a workgroup
+// of NT threads transforms FPB = NT/TF frames at once (one wave64 per frame at n_fft = 2048,
+// R = 16).  Between passes the data round-trips through LDS; the first pass reads straight from
+// global memory (window multiply fused), so per frame the LDS sees P writes + P reads of 8M bytes.
+//
+// LDS layout of one frame: complex element i lives at slot phys(i) = i + (i >> logr(0)).  The
+// one-slot pad every r0 elements makes the first pass's stride-r0 stores conflict-free
+// (stride r0+1 slots = 2(r0+1) dwords: the 16 lanes of a ds_write_b64 group hit 16 distinct
+// even banks) while keeping the later unit-stride accesses essentially contiguous.
+//
+// Reference semantics implemented by the callers (lra_kernels.h): librosa/core/spectrum.py:
+// 380-390 (rfft of windowed frames) and :598 (irfft of spectrogram columns).
+#pragma once
+
+#include <cmath>
+
+#include "lra_common.h"
+
+namespace lra {
+
+// MINW_: occupancy target handed to __launch_bounds__ (waves per SIMD; 0 = default).  HOIST_: let
+// the compiler keep the per-thread window/twiddle values in registers across the frame loop (they
+// are loop-invariant); when false the table pointers are laundered every iteration so the tables
+// are re-read from L1/L2 and the register budget stays small.
+template <int LOGM_, int LOGR_, class T_, int NTMIN_ = 256, int MINW_ = 0, bool HOIST_ = true> struct FftCfg {
+    using real = T_;
+    using cplx = cx<T_>;
+    static constexpr int LOGM = LOGM_;
+    static constexpr int M = 1 << LOGM_;  // complex points per frame
+    static constexpr int N = 2 * M;       // n_fft
+    static constexpr int LOGR = LOGR_ < LOGM_ ? LOGR_ : LOGM_;
+    static constexpr int R = 1 << LOGR;  // complex points per thread
+    static constexpr int TF = M / R;     // threads per frame
+    static constexpr int NT = TF > NTMIN_ ? TF : NTMIN_;
+    static constexpr int FPB = NT / TF;  // frames per workgroup iteration
+    static constexpr int P = (LOGM + LOGR - 1) / LOGR;
+    static constexpr int logr(int p) { return LOGM / P + (p < LOGM % P ? 1 : 0); }
+    static constexpr int logs(int p) {
+        int s = 0;
+        for (int q = 0; q < p; ++q) s += logr(q);
+        return s;
+    }
+    // offset (complex elements) of pass p's twiddle block; pass 0 has none
+    static constexpr int tw_off(int p) {
+        int o = 0;
+        for (int q = 1; q < p; ++q) o += ((1 << logr(q)) - 1) << logs(q);
+        return o;
+    }
+    static constexpr int TW_TOTAL = tw_off(P) > 0 ? tw_off(P) : 1;
+    static constexpr int PADSHIFT = logr(0);
+    static constexpr int FRAME_ELEMS = M + (M >> PADSHIFT) + 1;
+    static constexpr int FRAME_BYTES = ((FRAME_ELEMS * (int)sizeof(cplx) + 15) / 16) * 16;
+    static constexpr int phys(int i) { return i + (i >> PADSHIFT); }
+    static constexpr int MIN_WAVES = MINW_ > 0 ? MINW_ : 2;
+    static constexpr bool HOIST = HOIST_;
+};
+
+// ----------------------------------------------------------------------------- small DFTs
+// W16^idx = exp(-2 pi i idx / 16), idx in [0, 8)
+template <class T> LRA_HD cx<T> mul_w16(cx<T> a, int idx) {
+    const T h = (T)0.70710678118654752440;
+    const T c1 = (T)0.92387953251128675613, s1 = (T)0.38268343236508977173;
+    switch (idx) {
+        case 0: return a;
+        case 4: return cmul_mi(a);
+        case 2: return mk<T>((a.x + a.y) * h, (a.y - a.x) * h);
+        case 6: return mk<T>((a.y - a.x) * h, -(a.x + a.y) * h);
+        case 1: return mk<T>(a.x * c1 + a.y * s1, a.y * c1 - a.x * s1);
+        case 3: return mk<T>(a.x * s1 + a.y * c1, a.y * s1 - a.x * c1);
+        case 5: return mk<T>(a.y * c1 - a.x * s1, -(a.x * c1 + a.y * s1));
+        default: /* 7 */ return mk<T>(a.y * s1 - a.x * c1, -(a.x * s1 + a.y * c1));
+    }
+}
+
+// In-place forward DFT of r points (natural order in, natural order out), r in {1,2,4,8,16}.
+template <int r, class T> struct Dft {
+    static LRA_HD void run(cx<T>* v) {
+        cx<T> e[r / 2], o[r / 2];
+        LRA_UNROLL
+        for (int k = 0; k < r / 2; ++k) { e[k] = v[2 * k]; o[k] = v[2 * k + 1]; }
+        Dft<r / 2, T>::run(e);
+        Dft<r / 2, T>::run(o);
+        LRA_UNROLL
+        for (int k = 0; k < r / 2; ++k) {
+            const cx<T> t = mul_w16<T>(o[k], k * (16 / r));
+            v[k] = cadd(e[k], t);
+            v[k + r / 2] = csub(e[k], t);
+        }
+    }
+};
+template <class T> struct Dft<1, T> {
+    static LRA_HD void run(cx<T>*) {}
+};
+template <class T> struct Dft<2, T> {
+    static LRA_HD void run(cx<T>* v) {
+        const cx<T> a = v[0], b = v[1];
+        v[0] = cadd(a, b);
+        v[1] = csub(a, b);
+    }
+};
+
+// ----------------------------------------------------------------------------- Stockham passes
+// Pass p: butterfly b in [0, M/r) takes inputs at b + j*(M/r), multiplies input j by
+// W_{s r}^{(b mod s) j}, and writes output j to (b - b mod s) r + (b mod s) + j s, where s is the
+// product of the earlier radices.  Thread tf owns butterflies b = tf + i*TF.
+template <class Cfg, int p> LRA_HD void pass_read(typename Cfg::cplx* v, Lds fr, int tf) {
+    using C = typename Cfg::cplx;
+    constexpr int lr = Cfg::logr(p), r = 1 << lr, nb = Cfg::R >> lr, sin = Cfg::M >> lr;
+    LRA_UNROLL
+    for (int i = 0; i < nb; ++i) {
+        const int b = tf + i * Cfg::TF;
+        LRA_UNROLL
+        for (int j = 0; j < r; ++j) v[i * r + j] = lds_ld<C>(fr, Cfg::phys(b + j * sin) * (int)sizeof(C));
+    }
+}
+
+template <class Cfg, int p> LRA_HD void pass_twiddle_dft(typename Cfg::cplx* v, int tf, const typename Cfg::cplx* __restrict__ tw) {
+    using T = typename Cfg::real;
+    constexpr int lr = Cfg::logr(p), r = 1 << lr, nb = Cfg::R >> lr, s = 1 << Cfg::logs(p);
+    LRA_UNROLL
+    for (int i = 0; i < nb; ++i) {
+        const int b = tf + i * Cfg::TF;
+        if (p > 0) {
+            const int k = b & (s - 1);
+            LRA_UNROLL
+            for (int j = 1; j < r; ++j) v[i * r + j] = cmul(v[i * r + j], tw[Cfg::tw_off(p) + (j - 1) * s + k]);
+        }
+        Dft<r, T>::run(v + i * r);
+    }
+}
+
+template <class Cfg, int p> LRA_HD void pass_write(const typename Cfg::cplx* v, Lds fr, int tf) {
+    using C = typename Cfg::cplx;
+    constexpr int lr = Cfg::logr(p), r = 1 << lr, nb = Cfg::R >> lr, s = 1 << Cfg::logs(p);
+    LRA_UNROLL
+    for (int i = 0; i < nb; ++i) {
+        const int b = tf + i * Cfg::TF;
+        const int k = b & (s - 1);
+        const int base = ((b - k) << lr) + k;
+        LRA_UNROLL
+        for (int j = 0; j < r; ++j) lds_st<C>(fr, Cfg::phys(base + j * s) * (int)sizeof(C), v[i * r + j]);
+    }
+}
+
+// Output position (natural order) of register slot (i, j) after the LAST pass.
+template <class Cfg> LRA_HD int last_pass_pos(int tf, int i, int j) {
+    constexpr int p = Cfg::P - 1, s = 1 << Cfg::logs(p);
+    return (tf + i * Cfg::TF) + j * s;
+}
+
+// Host-side table builders (double precision, rounded once to T).
+template <class Cfg> inline void build_pass_twiddles(typename Cfg::cplx* out) {
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int p = 1; p < Cfg::P; ++p) {
+        const int r = 1 << Cfg::logr(p), s = 1 << Cfg::logs(p);
+        for (int j = 1; j < r; ++j)
+            for (int k = 0; k < s; ++k) {
+                const double ang = -two_pi * (double)k * (double)j / ((double)s * (double)r);
+                out[Cfg::tw_off(p) + (j - 1) * s + k] = mk<typename Cfg::real>((typename Cfg::real)std::cos(ang), (typename Cfg::real)std::sin(ang));
+            }
+    }
+}
+// W_N^k = exp(-2 pi i k / N), k = 0 .. M/2
+template <class Cfg> inline void build_split_twiddles(typename Cfg::cplx* out) {
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int k = 0; k <= Cfg::M / 2; ++k) {
+        const double ang = -two_pi * (double)k / (double)Cfg::N;
+        out[k] = mk<typename Cfg::real>((typename Cfg::real)std::cos(ang), (typename Cfg::real)std::sin(ang));
+    }
+}
+
+}  // namespace lra

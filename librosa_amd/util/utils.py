@@ -1,0 +1,135 @@
+"""Host-side helpers whose semantics the STFT/mel/ISTFT path must honour.
+
+Each helper mirrors the behaviour (names, argument meaning, error type) of the reference helper it
+cites; they operate on small host arrays (windows, filter tables) or validate arguments before any
+device work is enqueued.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .exceptions import ParameterError
+
+# librosa/util/utils.py:40-41 -- the reference's only performance knob (column blocking of its CPU
+# loops).  Kept for API compatibility; the device kernels do not block by columns.
+MAX_MEM_BLOCK = 2**8 * 2**10
+
+
+def is_torch_tensor(x) -> bool:
+    mod = type(x).__module__
+    return mod == "torch" or mod.startswith("torch.")
+
+
+def valid_audio(y) -> bool:
+    """``librosa/util/utils.py:294-306``: ndarray, floating, >= 1-d, finite everywhere."""
+    if not isinstance(y, np.ndarray):
+        raise ParameterError("Audio data must be of type numpy.ndarray")
+    if not np.issubdtype(y.dtype, np.floating):
+        raise ParameterError("Audio data must be floating-point")
+    if y.ndim == 0:
+        raise ParameterError(f"Audio data must be at least one-dimensional, given y.shape={y.shape}")
+    if not np.isfinite(y).all():
+        raise ParameterError("Audio buffer is not finite everywhere")
+    return True
+
+
+def is_positive_int(x) -> bool:
+    """``librosa/util/utils.py:344-358``."""
+    return isinstance(x, (int, np.integer)) and (x > 0)
+
+
+def pad_center(data, *, size, axis=-1, **kwargs):
+    """``librosa/util/utils.py:387-458``: centre ``data`` in a length-``size`` axis, lpad=(size-n)//2."""
+    kwargs.setdefault("mode", "constant")
+    n = data.shape[axis]
+    lpad = int((size - n) // 2)
+    if lpad < 0:
+        raise ParameterError(f"Target size ({size:d}) must be at least input size ({n:d})")
+    widths = [(0, 0)] * data.ndim
+    widths[axis] = (lpad, int(size - n - lpad))
+    return np.pad(data, widths, **kwargs)
+
+
+def fix_length(data, *, size, axis=-1, **kwargs):
+    """``librosa/util/utils.py:532-588``: truncate or right-pad ``axis`` to exactly ``size``."""
+    kwargs.setdefault("mode", "constant")
+    n = data.shape[axis]
+    if n > size:
+        index = [slice(None)] * data.ndim
+        index[axis] = slice(0, size)
+        return data[tuple(index)]
+    if n < size:
+        widths = [(0, 0)] * data.ndim
+        widths[axis] = (0, size - n)
+        return np.pad(data, widths, **kwargs)
+    return data
+
+
+def tiny(x):
+    """``librosa/util/utils.py:1935-2000``: smallest positive normal of x's float type (f32 otherwise)."""
+    x = np.asarray(x)
+    if np.issubdtype(x.dtype, np.floating) or np.issubdtype(x.dtype, np.complexfloating):
+        dtype = x.dtype
+    else:
+        dtype = np.dtype(np.float32)
+    return np.finfo(dtype).tiny
+
+
+def dtype_r2c(d, *, default=np.complex64):
+    """``librosa/util/utils.py:2362-2416``: float32->complex64, float64->complex128, complex passes."""
+    table = {np.dtype(np.float32): np.complex64, np.dtype(np.float64): np.complex128}
+    dt = np.dtype(d)
+    if dt.kind == "c":
+        return dt
+    return np.dtype(table.get(dt, default))
+
+
+def dtype_c2r(d, *, default=np.float32):
+    """``librosa/util/utils.py:2419-2476``."""
+    table = {np.dtype(np.complex64): np.float32, np.dtype(np.complex128): np.float64}
+    dt = np.dtype(d)
+    if dt.kind == "f":
+        return dt
+    return np.dtype(table.get(dt, default))
+
+
+def normalize(S, *, norm=np.inf, axis=0, threshold=None, fill=None):
+    """``librosa/util/utils.py:796-1025`` (host tables only: window and filterbank normalisation)."""
+    if threshold is None:
+        threshold = tiny(S)
+    elif threshold <= 0:
+        raise ParameterError(f"threshold={threshold} must be strictly positive")
+    if fill not in [None, False, True]:
+        raise ParameterError(f"fill={fill} must be None or boolean")
+    if not np.all(np.isfinite(S)):
+        raise ParameterError("Input must be finite")
+    mag = np.abs(S).astype(float)
+    fill_norm = 1
+    if norm is None:
+        return S
+    if norm == np.inf:
+        length = np.max(mag, axis=axis, keepdims=True)
+    elif norm == -np.inf:
+        length = np.min(mag, axis=axis, keepdims=True)
+    elif norm == 0:
+        if fill is True:
+            raise ParameterError("Cannot normalize with norm=0 and fill=True")
+        length = np.sum(mag > 0, axis=axis, keepdims=True, dtype=mag.dtype)
+    elif np.issubdtype(type(norm), np.number) and norm > 0:
+        length = np.sum(mag**norm, axis=axis, keepdims=True) ** (1.0 / norm)
+        fill_norm = (mag.size if axis is None else mag.shape[axis]) ** (-1.0 / norm)
+    else:
+        raise ParameterError(f"Unsupported norm: {norm!r}")
+    small = length < threshold
+    out = np.empty_like(S)
+    if fill is None:
+        length[small] = 1.0
+        out[:] = S / length
+    elif fill:
+        length[small] = np.nan
+        out[:] = S / length
+        out[np.isnan(out)] = fill_norm
+    else:
+        length[small] = np.inf
+        out[:] = S / length
+    return out

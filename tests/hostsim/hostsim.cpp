@@ -1,0 +1,130 @@
+// hostsim.cpp -- CPU thread simulator for the kernel bodies in librosa_amd/csrc/lra_kernels.h.
+//
+// TEST INFRASTRUCTURE ONLY.  Built by tests (g++ -DLRA_HOSTSIM) into tests/hostsim/_hostsim.so and
+// loaded with ctypes by tests/test_hostsim.py.  It executes the SAME templated workgroup bodies the
+// gfx950 library launches, one phase at a time over all threads of a workgroup, with an LDS shadow
+// that counts cross-thread races inside a phase and reads of never-written LDS.  It is never
+// linked into, imported by, or used as a fallback for the product library.
+#define LRA_HOSTSIM 1
+#include "../../librosa_amd/csrc/lra_dispatch.h"
+
+#include <vector>
+
+using namespace lra;
+
+namespace {
+
+template <class T> struct StftSim {
+    StftArgs<T> a;
+    int mode;
+    long long blocks;
+    long long* diag;
+    template <class Cfg> void operator()() {
+        std::vector<cx<T>> tw(Cfg::TW_TOTAL), twr(Cfg::M / 2 + 1);
+        build_pass_twiddles<Cfg>(tw.data());
+        build_split_twiddles<Cfg>(twr.data());
+        a.tw = tw.data();
+        a.twr = twr.data();
+        a.frames_per_wg = a.frames_per_wg * Cfg::FPB;  // caller passes the iteration count
+        a.wg_per_clip = (a.n_frames + a.frames_per_wg - 1) / a.frames_per_wg;
+        auto& st = sim::state();
+        const long long nblk = blocks * a.wg_per_clip;
+        for (long long blk = 0; blk < nblk; ++blk) {
+            st.resize(stft_lds_bytes<Cfg>());
+            Lds lds; lds.base = 0;
+            if (mode == OUT_COMPLEX) stft_block<Cfg, OUT_COMPLEX>(a, (int)blk, lds);
+            else if (mode == OUT_POWER) stft_block<Cfg, OUT_POWER>(a, (int)blk, lds);
+            else stft_block<Cfg, OUT_MEL>(a, (int)blk, lds);
+            diag[0] += st.races; diag[1] += st.uninit;
+            st.races = st.uninit = 0;
+        }
+        diag[2] = Cfg::NT; diag[3] = Cfg::FPB; diag[4] = Cfg::P; diag[5] = stft_lds_bytes<Cfg>();
+    }
+};
+
+template <class T> struct IstftSim {
+    IstftArgs<T> a;
+    long long batch;
+    long long* diag;
+    int strip_groups;
+    template <class Cfg> void operator()() {
+        std::vector<cx<T>> tw(Cfg::TW_TOTAL), twr(Cfg::M / 2 + 1);
+        build_pass_twiddles<Cfg>(tw.data());
+        build_split_twiddles<Cfg>(twr.data());
+        a.tw = tw.data();
+        a.twr = twr.data();
+        const int FPB = Cfg::FPB, N = Cfg::N, H = a.hop;
+        a.strip_frames = strip_groups * FPB;
+        a.strips_per_clip = (a.n_used + a.strip_frames - 1) / a.strip_frames;
+        const int W = (N + H - 1) / H - 1;
+        a.warm_groups = (W + FPB - 1) / FPB;
+        const long long rem = N > H ? N - H : 0;
+        a.drain_groups = (int)((rem + (long long)FPB * H - 1) / ((long long)FPB * H));
+        auto& st = sim::state();
+        const long long nblk = batch * a.strips_per_clip;
+        for (long long blk = 0; blk < nblk; ++blk) {
+            st.resize(istft_lds_bytes<Cfg>());
+            Lds lds; lds.base = 0;
+            istft_block<Cfg>(a, (int)blk, lds);
+            diag[0] += st.races; diag[1] += st.uninit;
+            st.races = st.uninit = 0;
+        }
+        diag[2] = Cfg::NT; diag[3] = Cfg::FPB; diag[4] = Cfg::P; diag[5] = istft_lds_bytes<Cfg>();
+    }
+};
+
+template <class T>
+int run_stft(int n_fft, int mode, const T* y, long long n, long long batch, int n_frames, int hop, int center, int pad_mode, const T* win,
+             int iters_per_wg, void* out, int power_mode, double power, const int* mel_c0, const int* mel_len, const int* mel_off, const T* mel_val,
+             int n_mels, int variant, long long* diag) {
+    if (!pow2_supported(n_fft, sizeof(T) == 8)) return 1;
+    StftSim<T> s;
+    s.a = StftArgs<T>();
+    s.a.y = y; s.a.y_stride = n; s.a.n = n; s.a.n_frames = n_frames; s.a.hop = hop; s.a.pad = center ? n_fft / 2 : 0; s.a.pad_mode = pad_mode;
+    s.a.win = win; s.a.frames_per_wg = iters_per_wg;
+    s.a.D = (cx<T>*)out; s.a.S = (T*)out; s.a.Mel = (T*)out;
+    s.a.power_mode = power_mode; s.a.power = (T)power;
+    s.a.mel_c0 = mel_c0; s.a.mel_len = mel_len; s.a.mel_off = mel_off; s.a.mel_val = mel_val; s.a.n_mels = n_mels;
+    s.mode = mode; s.blocks = batch; s.diag = diag;
+    for (int i = 0; i < 8; ++i) diag[i] = 0;
+    return dispatch_logm<T>(log2_exact(n_fft) - 1, variant, s) ? 0 : 1;
+}
+
+template <class T>
+int run_istft(int n_fft, const T* D /* interleaved complex [batch][T][M+1] */, long long batch, int n_frames_total, int n_used, int hop, int center,
+              const T* win_scaled, const T* wss, double tiny, T* y, long long out_len, int strip_groups, int variant, long long* diag) {
+    if (!pow2_supported(n_fft, sizeof(T) == 8)) return 1;
+    IstftSim<T> s;
+    s.a = IstftArgs<T>();
+    const int M = n_fft / 2;
+    s.a.D = (const cx<T>*)D; s.a.d_frame_stride = M + 1; s.a.d_batch_stride = (long long)n_frames_total * (M + 1);
+    s.a.n_used = n_used; s.a.hop = hop; s.a.drop = center ? n_fft / 2 : 0; s.a.win_scaled = win_scaled; s.a.wss = wss; s.a.tiny = (T)tiny;
+    s.a.y = y; s.a.y_stride = out_len; s.a.out_len = out_len;
+    s.batch = batch; s.diag = diag; s.strip_groups = strip_groups;
+    for (int i = 0; i < 8; ++i) diag[i] = 0;
+    return dispatch_logm<T>(log2_exact(n_fft) - 1, variant, s) ? 0 : 1;
+}
+
+}  // namespace
+
+extern "C" {
+int hostsim_stft_f32(int n_fft, int mode, const float* y, long long n, long long batch, int n_frames, int hop, int center, int pad_mode,
+                     const float* win, int iters_per_wg, void* out, int power_mode, double power, const int* mel_c0, const int* mel_len,
+                     const int* mel_off, const float* mel_val, int n_mels, int variant, long long* diag) {
+    return run_stft<float>(n_fft, mode, y, n, batch, n_frames, hop, center, pad_mode, win, iters_per_wg, out, power_mode, power, mel_c0, mel_len, mel_off, mel_val, n_mels, variant, diag);
+}
+int hostsim_stft_f64(int n_fft, int mode, const double* y, long long n, long long batch, int n_frames, int hop, int center, int pad_mode,
+                     const double* win, int iters_per_wg, void* out, int power_mode, double power, const int* mel_c0, const int* mel_len,
+                     const int* mel_off, const double* mel_val, int n_mels, int variant, long long* diag) {
+    return run_stft<double>(n_fft, mode, y, n, batch, n_frames, hop, center, pad_mode, win, iters_per_wg, out, power_mode, power, mel_c0, mel_len, mel_off, mel_val, n_mels, variant, diag);
+}
+int hostsim_istft_f32(int n_fft, const float* D, long long batch, int n_frames_total, int n_used, int hop, int center, const float* win_scaled,
+                      const float* wss, double tiny, float* y, long long out_len, int strip_groups, int variant, long long* diag) {
+    return run_istft<float>(n_fft, D, batch, n_frames_total, n_used, hop, center, win_scaled, wss, tiny, y, out_len, strip_groups, variant, diag);
+}
+int hostsim_istft_f64(int n_fft, const double* D, long long batch, int n_frames_total, int n_used, int hop, int center, const double* win_scaled,
+                      const double* wss, double tiny, double* y, long long out_len, int strip_groups, int variant, long long* diag) {
+    return run_istft<double>(n_fft, D, batch, n_frames_total, n_used, hop, center, win_scaled, wss, tiny, y, out_len, strip_groups, variant, diag);
+}
+long long hostsim_pad_index(long long g, long long n, int mode) { return pad_index(g, n, mode); }
+}

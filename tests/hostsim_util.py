@@ -1,0 +1,115 @@
+"""ctypes wrapper around tests/hostsim/_hostsim.so (CPU thread simulator of the kernel bodies).
+
+TEST INFRASTRUCTURE ONLY -- see tests/hostsim/hostsim.cpp.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "hostsim", "hostsim.cpp")
+SO = os.path.join(HERE, "hostsim", "_hostsim.so")
+CSRC = os.path.join(os.path.dirname(HERE), "librosa_amd", "csrc")
+
+PAD_MODES = {"constant": 0, "reflect": 1, "edge": 2, "symmetric": 3}
+
+
+def _stale():
+    if not os.path.exists(SO):
+        return True
+    t = os.path.getmtime(SO)
+    deps = [SRC] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build():
+    if _stale():
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-shared", "-fPIC", "-o", SO, SRC])
+    return SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(build())
+        _lib.hostsim_pad_index.restype = ctypes.c_longlong
+        _lib.hostsim_pad_index.argtypes = [ctypes.c_longlong, ctypes.c_longlong, ctypes.c_int]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def mel_band(B):
+    """Dense (n_mels, n_bins) basis -> band form (c0, len, off, val)."""
+    n_mels = B.shape[0]
+    c0 = np.zeros(n_mels, np.int32)
+    ln = np.zeros(n_mels, np.int32)
+    off = np.zeros(n_mels, np.int32)
+    vals = []
+    pos = 0
+    for m in range(n_mels):
+        nz = np.nonzero(B[m])[0]
+        if len(nz):
+            c0[m], ln[m] = nz[0], nz[-1] - nz[0] + 1
+            vals.append(B[m, nz[0] : nz[-1] + 1])
+        off[m] = pos
+        pos += ln[m]
+    val = np.concatenate(vals) if vals else np.zeros(1, B.dtype)
+    return c0, ln, off, np.ascontiguousarray(val)
+
+
+def stft(y, n_fft, hop, win, center=True, pad_mode="constant", mode=0, iters_per_wg=1, power=2.0, mel_basis=None, variant=0):
+    """y: (batch, n) f32/f64.  mode 0 -> complex (batch, T, M+1); 1 -> power; 2 -> mel (batch, n_mels, T)."""
+    y = np.ascontiguousarray(y)
+    assert y.ndim == 2
+    f64 = y.dtype == np.float64
+    batch, n = y.shape
+    if center:
+        n_frames = 1 + (n + 2 * (n_fft // 2) - n_fft) // hop
+    else:
+        n_frames = 1 + (n - n_fft) // hop
+    M = n_fft // 2
+    win = np.ascontiguousarray(win, dtype=y.dtype)
+    pm = 2 if power == 2.0 else (1 if power == 1.0 else 3)
+    c0 = ln = off = val = None
+    n_mels = 0
+    if mode == 0:
+        out = np.full((batch, n_frames, M + 1), np.nan, dtype=np.complex128 if f64 else np.complex64)
+    elif mode == 1:
+        out = np.full((batch, n_frames, M + 1), np.nan, dtype=y.dtype)
+    else:
+        c0, ln, off, val = mel_band(np.asarray(mel_basis, dtype=y.dtype))
+        n_mels = mel_basis.shape[0]
+        out = np.full((batch, n_mels, n_frames), np.nan, dtype=y.dtype)
+    diag = np.zeros(8, np.int64)
+    fn = lib().hostsim_stft_f64 if f64 else lib().hostsim_stft_f32
+    rc = fn(ctypes.c_int(n_fft), ctypes.c_int(mode), _p(y), ctypes.c_longlong(n), ctypes.c_longlong(batch), ctypes.c_int(n_frames),
+            ctypes.c_int(hop), ctypes.c_int(int(center)), ctypes.c_int(PAD_MODES[pad_mode]), _p(win), ctypes.c_int(iters_per_wg), _p(out),
+            ctypes.c_int(pm), ctypes.c_double(power), _p(c0), _p(ln), _p(off), _p(val), ctypes.c_int(n_mels), ctypes.c_int(variant), _p(diag))
+    assert rc == 0, "unsupported n_fft for the pow2 kernels"
+    return out, dict(races=int(diag[0]), uninit=int(diag[1]), NT=int(diag[2]), FPB=int(diag[3]), P=int(diag[4]), lds=int(diag[5]))
+
+
+def istft(D, n_fft, hop, win, wss, out_len, n_used, center=True, strip_groups=4, variant=0):
+    """D: (batch, T, M+1) complex, native layout.  win: padded window (n_fft).  wss: (out_len,)."""
+    D = np.ascontiguousarray(D)
+    f64 = D.dtype == np.complex128
+    rt = np.float64 if f64 else np.float32
+    batch, T, bins = D.shape
+    assert bins == n_fft // 2 + 1
+    ws = np.ascontiguousarray(np.asarray(win, dtype=np.float64) / n_fft, dtype=rt)
+    wss = np.ascontiguousarray(wss, dtype=rt)
+    y = np.zeros((batch, out_len), dtype=rt)
+    diag = np.zeros(8, np.int64)
+    fn = lib().hostsim_istft_f64 if f64 else lib().hostsim_istft_f32
+    rc = fn(ctypes.c_int(n_fft), _p(D), ctypes.c_longlong(batch), ctypes.c_int(T), ctypes.c_int(n_used), ctypes.c_int(hop), ctypes.c_int(int(center)),
+            _p(ws), _p(wss), ctypes.c_double(float(np.finfo(rt).tiny)), _p(y), ctypes.c_longlong(out_len), ctypes.c_int(strip_groups), ctypes.c_int(variant), _p(diag))
+    assert rc == 0
+    return y, dict(races=int(diag[0]), uninit=int(diag[1]), NT=int(diag[2]), FPB=int(diag[3]), P=int(diag[4]), lds=int(diag[5]))

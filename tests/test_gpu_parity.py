@@ -1,0 +1,365 @@
+"""GPU parity tests (run with ``-m gpu`` on the MI355X box): the HIP path, called through the C ABI by
+the Python drop-in, against (1) the committed reference outputs in tests/golden/, (2) the CPU oracle
+on seeded inputs, (3) size-independent properties at BASELINE.json's full sizes.
+
+Tolerances (float32 pipeline vs the reference's float64-FFT-rounded-to-complex64):
+  STFT   |d| <= 1e-5 |ref| + 2e-6 max|ref|        (observed ~2e-7 max|ref|)
+  mel    |d| <= 1e-4 |ref| + 1e-4 max|ref|        (north-star bar; observed ~1e-6)
+  ISTFT  |d| <= 4e-6 max|ref| / sqrt(wss) where the window sum-square is well conditioned; SNR >= 60 dB
+  float64 pipeline: 1e-12 relative.
+"""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+import golden_cases
+import stft_oracle as O
+
+from conftest import GOLDEN_DIR
+
+pytestmark = pytest.mark.gpu
+
+warnings.filterwarnings("ignore", message="n_fft=.*is too large")
+
+
+@pytest.fixture(scope="module")
+def L():
+    import librosa_amd
+
+    assert librosa_amd.device_count() > 0, "no HIP device: the product has no CPU fallback"
+    return librosa_amd
+
+
+def _stft_close(D, ref):
+    scale = np.abs(ref).max()
+    if D.dtype == np.complex128:
+        return np.all(np.abs(D - ref) <= 1e-12 * scale)
+    return np.all(np.abs(D - ref) <= 1e-5 * np.abs(ref) + 2e-6 * scale)
+
+
+def _mel_close(M, ref):
+    if M.dtype == np.float64:
+        return np.all(np.abs(M - ref) <= 1e-11 * ref.max())
+    return np.all(np.abs(M - ref) <= 1e-4 * np.abs(ref) + 1e-4 * ref.max())
+
+
+def _istft_close(y, ref, wss):
+    eps = 1e-12 if y.dtype == np.float64 else 4e-6
+    cond = 1.0 / np.sqrt(np.maximum(wss.astype(np.float64), np.finfo(np.float32).tiny))
+    tol = eps * np.abs(ref).max() * np.maximum(1.0, cond)
+    well = wss > 1e-3 * wss.max()
+    return np.all(np.abs(y - ref)[..., well] <= tol[well]) and np.all(np.abs(y - ref)[..., ~well] <= 50 * tol[~well] + 1e-3)
+
+
+def _wss_for(skw, n_total_frames, out_len, length, dtype):
+    n_fft = skw["n_fft"]
+    win_length = skw.get("win_length")
+    hop = skw.get("hop_length") or (win_length or n_fft) // 4
+    center = skw.get("center", True)
+    if length:
+        padded = length + 2 * (n_fft // 2) if center else length
+        n_frames = min(n_total_frames, int(np.ceil(padded / hop)))
+    else:
+        n_frames = n_total_frames
+    wss = O.window_sumsquare(window=skw.get("window", "hann"), n_frames=n_frames, win_length=win_length, n_fft=n_fft, hop_length=hop, dtype=dtype)
+    return O.fix_length(wss[(n_fft // 2 if center else 0) :], size=out_len)
+
+
+# ---------------------------------------------------------------------------------------------------
+# 1. committed reference outputs
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(golden_cases.CASES))
+def test_golden_case(L, name):
+    case = golden_cases.CASES[name]
+    g = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))
+    y = g["y"]
+    skw = dict(case["stft"])
+    D = L.stft(y, **skw)
+    assert D.shape == g["D"].shape and D.dtype == g["D"].dtype
+    assert _stft_close(D, g["D"])
+    if case["mel"] is not None:
+        power, fkw = golden_cases.split_mel_kwargs(case["mel"])
+        mkw = dict(skw)
+        mkw.setdefault("hop_length", int(skw.get("win_length", skw["n_fft"]) // 4))
+        M = L.feature.melspectrogram(y=y, sr=golden_cases.SR, power=power, **mkw, **fkw)
+        assert M.shape == g["mel"].shape and M.dtype == g["mel"].dtype
+        assert _mel_close(M, g["mel"])
+        assert np.array_equal(L.filters.mel(sr=golden_cases.SR, n_fft=skw["n_fft"], **fkw), g["mel_basis"])
+        # melspectrogram(S=...) with the reference's power spectrogram as input
+        S = np.abs(g["D"]) ** power
+        M2 = L.feature.melspectrogram(S=S, sr=golden_cases.SR, **fkw)
+        assert _mel_close(M2, g["mel"])
+        # _spectrogram
+        S3, nf = L._spectrogram(y=y, power=power, **mkw)
+        assert nf == skw["n_fft"] and S3.shape == S.shape
+        assert np.all(np.abs(S3 - S) <= 1e-4 * np.abs(S) + 1e-5 * S.max())
+    if case["istft"]:
+        ikw = {k: v for k, v in skw.items() if k in ("hop_length", "win_length", "n_fft", "window", "center")}
+        for key, length in (("y_istft_len", y.shape[-1]), ("y_istft_nolen", None)):
+            ref = g[key]
+            yh = L.istft(g["D"], length=length, **ikw)
+            assert yh.shape == ref.shape and yh.dtype == ref.dtype
+            wss = _wss_for(skw, g["D"].shape[-1], ref.shape[-1], length, ref.dtype)
+            assert _istft_close(yh, ref, wss), (name, key)
+
+
+def test_golden_config1(L):
+    g = np.load(os.path.join(GOLDEN_DIR, "config1_sine10s.npz"))
+    y = O.config1_input()
+    D = L.stft(y, n_fft=2048, hop_length=512)
+    assert D.shape == (1025, 431) and D.dtype == np.complex64
+    # pure tone: element-wise relative error is meaningless below f32's leakage floor
+    assert np.abs(D[:, g["frames"]] - g["D_frames"]).max() <= 2e-6 * g["D_absmax"]
+    M = L.feature.melspectrogram(y=y, sr=22050, n_fft=2048, hop_length=512, n_mels=128)
+    assert np.all(np.abs(M - g["mel"]) <= 1e-4 * np.abs(g["mel"]) + 1e-4 * g["mel"].max())
+    yh = L.istft(D, hop_length=512, length=len(y))
+    assert np.abs(yh[:4096] - g["y_istft_head"]).max() <= 4e-6 and np.abs(yh[-4096:] - g["y_istft_tail"]).max() <= 4e-6
+    snr = 10 * np.log10(np.sum(y.astype(np.float64) ** 2) / np.sum((y - yh).astype(np.float64) ** 2))
+    assert snr >= 60
+
+
+def test_golden_config2_clips(L):
+    g = np.load(os.path.join(GOLDEN_DIR, "config2_clips.npz"))
+    Y = np.stack([O.config_input(1, first_clip=i)[0] for i in (0, 37)])
+    D = L.stft(Y, n_fft=2048, hop_length=512)
+    M = L.feature.melspectrogram(y=Y, sr=22050, n_fft=2048, hop_length=512, n_mels=128)
+    assert D.shape == (2, 1025, 1292) and M.shape == (2, 128, 1292)
+    for j, i in enumerate((0, 37)):
+        assert np.abs(D[j][:, g["frames"]] - g[f"D_frames_{i}"]).max() <= 2e-6 * g[f"D_absmax_{i}"]
+    assert _mel_close(M[0], g["mel_0"])
+    ref37 = g["mel_frames_37"]
+    assert np.all(np.abs(M[1][:, g["frames"]] - ref37) <= 1e-4 * np.abs(ref37) + 1e-4 * g["mel_absmax_37"])
+
+
+# ---------------------------------------------------------------------------------------------------
+# 2. oracle on seeded inputs (reference test parametrisations: tests/test_core.py:256-371, 813-828)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_fft", [256, 501, 1023, 2048])
+@pytest.mark.parametrize("hop", [None, 128, 129])
+@pytest.mark.parametrize("center", [False, True])
+@pytest.mark.parametrize("window", ["hann", "ones"])
+def test_stft_vs_oracle(L, n_fft, hop, center, window):
+    y = golden_cases.make_signal("chirp", 8192, 0) + golden_cases.make_signal("noise", 8192, n_fft) * 0.1
+    D = L.stft(y, n_fft=n_fft, hop_length=hop, center=center, window=window)
+    ref = O.stft(y, n_fft=n_fft, hop_length=hop, center=center, window=window)
+    assert D.shape == ref.shape and D.dtype == ref.dtype
+    assert _stft_close(D, ref)
+
+
+@pytest.mark.parametrize("n_fft", [1024, 1025, 2048, 4096])
+@pytest.mark.parametrize("hop", [128, 256, 512])
+@pytest.mark.parametrize("window", ["hann", "blackmanharris"])
+def test_istft_reconstruction(L, n_fft, hop, window):
+    # tests/test_core.py:813-828 (reference): stft -> istft reproduces the signal
+    x = golden_cases.make_signal("chirp", 22050, 0)
+    D = L.stft(x, n_fft=n_fft, hop_length=hop, window=window)
+    xh = L.istft(D, hop_length=hop, window=window, n_fft=n_fft, length=len(x))
+    assert xh.shape == x.shape and np.isfinite(xh).all()
+    assert np.abs(x - xh).max() <= 2e-5
+    ref = O.istft(O.stft(x, n_fft=n_fft, hop_length=hop, window=window), hop_length=hop, window=window, n_fft=n_fft, length=len(x))
+    assert np.abs(xh - ref).max() <= 2e-5
+
+
+@pytest.mark.parametrize("pad_mode", ["constant", "reflect", "edge", "symmetric", "linear_ramp"])
+def test_pad_modes(L, pad_mode):
+    y = golden_cases.make_signal("noise", 3000, 5, (2,))
+    D = L.stft(y, n_fft=512, hop_length=128, pad_mode=pad_mode)
+    assert _stft_close(D, O.stft(y, n_fft=512, hop_length=128, pad_mode=pad_mode))
+
+
+def test_multichannel_equals_per_channel(L):
+    # tests/test_multichannel.py:96-111, 685-714: leading axes are independent
+    y = golden_cases.make_signal("noise", 9000, 3, (2, 3))
+    D = L.stft(y, n_fft=1024, hop_length=256)
+    M = L.feature.melspectrogram(y=y, n_fft=1024, hop_length=256, n_mels=40)
+    for i in range(2):
+        for j in range(3):
+            assert np.array_equal(D[i, j], L.stft(y[i, j], n_fft=1024, hop_length=256))
+            assert np.array_equal(M[i, j], L.feature.melspectrogram(y=y[i, j], n_fft=1024, hop_length=256, n_mels=40))
+    yh = L.istft(D, hop_length=256, length=9000)
+    assert np.array_equal(yh[1, 2], L.istft(D[1, 2], hop_length=256, length=9000))
+
+
+def test_float64_path(L):
+    y = golden_cases.make_signal("chirp", 16000, 1, None, "float64")
+    D = L.stft(y, n_fft=2048, hop_length=512)
+    ref = O.stft(y, n_fft=2048, hop_length=512)
+    assert D.dtype == np.complex128 and _stft_close(D, ref)
+    yh = L.istft(D, hop_length=512, length=len(y))
+    assert yh.dtype == np.float64 and np.abs(yh - y).max() < 1e-12
+    M = L.feature.melspectrogram(y=y, n_fft=2048, hop_length=512)
+    assert M.dtype == np.float64 and _mel_close(M, O.melspectrogram(y=y, n_fft=2048, hop_length=512))
+    # dtype= overrides: f32 audio -> complex128 result is the exact-mode transform of the f32 samples
+    y32 = y.astype(np.float32)
+    D2 = L.stft(y32, n_fft=2048, hop_length=512, dtype=np.complex128)
+    assert D2.dtype == np.complex128 and _stft_close(D2, O.stft(y32, n_fft=2048, hop_length=512, dtype=np.complex128))
+
+
+def test_out_parameter(L):
+    # tests/test_core.py:317-371, 2941-2963 (reference)
+    y = golden_cases.make_signal("noise", 8192, 2, (2,))
+    D = L.stft(y, n_fft=2048, hop_length=512)
+    out = np.zeros_like(D, order="C")
+    D2 = L.stft(y, n_fft=2048, hop_length=512, out=out)
+    assert D2 is out and np.array_equal(D2, D)
+    big = np.zeros(D.shape[:-1] + (D.shape[-1] + 5,), dtype=D.dtype)
+    D3 = L.stft(y, n_fft=2048, hop_length=512, out=big)
+    assert D3.shape == D.shape and np.array_equal(D3, D) and np.shares_memory(D3, big)
+    with pytest.raises(L.ParameterError):
+        L.stft(y, n_fft=2048, hop_length=512, out=np.zeros(D.shape[:-1] + (D.shape[-1] - 1,), dtype=D.dtype))
+    with pytest.raises(L.ParameterError):
+        L.stft(y, n_fft=2048, hop_length=512, out=np.zeros(D.shape, dtype=np.float32))
+    yo = np.ones((2, 8192), dtype=np.float32)
+    y2 = L.istft(D, hop_length=512, length=8192, out=yo)
+    assert y2 is yo and np.abs(y2 - y).max() < 2e-5
+    with pytest.raises(L.ParameterError):
+        L.istft(D, hop_length=512, length=8192, out=np.zeros((2, 8000), dtype=np.float32))
+
+
+def test_c_order_spectrogram_input(L):
+    """istft / melspectrogram(S=) accept a C-ordered (bins, frames) array, as the reference does."""
+    y = golden_cases.make_signal("mix", 22050, 4)
+    D = np.ascontiguousarray(O.stft(y, n_fft=2048, hop_length=512))
+    yh = L.istft(D, hop_length=512, length=len(y))
+    assert np.abs(yh - y).max() < 2e-5
+    S = np.ascontiguousarray(np.abs(D) ** 2)
+    M = L.feature.melspectrogram(S=S, sr=22050)
+    assert _mel_close(M, O.melspectrogram(S=S, sr=22050))
+
+
+def test_errors_and_warnings(L):
+    y = np.zeros(1000, dtype=np.float32)
+    with pytest.raises(L.ParameterError):
+        L.stft(y, n_fft=2048, center=False)
+    with pytest.warns(UserWarning):
+        D = L.stft(y, n_fft=2048)
+    assert D.shape == (1025, 1)
+    with pytest.raises(L.ParameterError):
+        L.stft(y, n_fft=512, pad_mode="wrap")
+    with pytest.raises(L.ParameterError):
+        L.stft(np.array([0.0, np.inf, 1.0] * 400, dtype=np.float32), n_fft=512)
+    with pytest.raises(L.ParameterError):
+        L.feature.melspectrogram(y=y, n_fft=512, norm="bogus")
+
+
+# ---------------------------------------------------------------------------------------------------
+# 3. device-resident (torch tensor) interface
+# ---------------------------------------------------------------------------------------------------
+def test_torch_device_tensors(L):
+    import torch
+
+    y = O.config_input(3, n=30000)
+    yt = torch.from_numpy(y).cuda()
+    D = L.stft(yt, n_fft=2048, hop_length=512)
+    assert D.is_cuda and D.dtype == torch.complex64 and tuple(D.shape) == (3, 1025, 59)
+    ref = O.stft(y, n_fft=2048, hop_length=512)
+    assert _stft_close(D.cpu().numpy(), ref)
+    M = L.feature.melspectrogram(y=yt, sr=22050, n_fft=2048, hop_length=512, n_mels=128)
+    assert M.is_cuda and _mel_close(M.cpu().numpy(), O.melspectrogram(y=y, sr=22050, n_fft=2048, hop_length=512, n_mels=128))
+    yh = L.istft(D, hop_length=512, length=30000)
+    assert yh.is_cuda and np.abs(yh.cpu().numpy() - y).max() < 2e-5
+    # the in-kernel non-finite flag replaces valid_audio's host scan for device tensors
+    bad = yt.clone()
+    bad[1, 12345] = float("nan")
+    with pytest.raises(L.ParameterError):
+        L.stft(bad, n_fft=2048, hop_length=512)
+    with pytest.raises(L.ParameterError):
+        L.feature.melspectrogram(y=bad, n_fft=2048, hop_length=512)
+    L.stft(bad, n_fft=2048, hop_length=512, check_finite=False)  # opt-out does not raise
+    with pytest.raises(L.ParameterError):
+        L.stft(bad, n_fft=1023, hop_length=512)  # general (rocFFT) path: explicit device scan
+
+
+def test_tuning_variants_agree(L):
+    """The tuning variants of the n_fft=2048 kernels must agree with the default to round-off."""
+    import torch
+
+    y = torch.from_numpy(O.config_input(2, n=44100)).cuda()
+    ctx = L.get_context(0)
+    outs = []
+    try:
+        for v in range(4):
+            ctx.set_option("variant", v)
+            for iters in (1, 3):
+                ctx.set_option("stft_iters", iters)
+                outs.append((L.stft(y, n_fft=2048, hop_length=512).cpu().numpy(), L.feature.melspectrogram(y=y, n_fft=2048, hop_length=512).cpu().numpy(),
+                             L.istft(L.stft(y, n_fft=2048, hop_length=512), hop_length=512, length=44100).cpu().numpy()))
+    finally:
+        ctx.set_option("variant", 0)
+        ctx.set_option("stft_iters", 0)
+    D0, M0, y0 = outs[0]
+    for D, M, yy in outs[1:]:
+        assert np.abs(D - D0).max() <= 2e-6 * np.abs(D0).max()
+        assert np.all(np.abs(M - M0) <= 1e-5 * np.abs(M0) + 1e-5 * M0.max())
+        assert np.abs(yy - y0).max() <= 4e-6
+
+
+# ---------------------------------------------------------------------------------------------------
+# 4. BASELINE.json full sizes: size-independent properties (the oracle would take minutes here)
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def full_batch():
+    import torch
+
+    torch.manual_seed(440)
+    B, n = 256, 661500
+    t = torch.arange(n, device="cuda", dtype=torch.float32) / 22050.0
+    f = 110.0 * 2.0 ** ((torch.arange(B, device="cuda") % 72).float() / 12.0)
+    y = 0.1 * torch.randn(B, n, device="cuda") + 0.5 * torch.sin(2 * np.pi * f[:, None] * t[None, :])
+    return y.clamp_(-1, 1).contiguous()
+
+
+def test_full_size_mel_properties(L, full_batch):
+    """config 2: batch=256 x 30 s.  Batch == per-clip; a sampled subset equals the oracle; linearity in
+    power (scaling the audio by a scales mel by a^2)."""
+    y = full_batch
+    M = L.feature.melspectrogram(y=y, sr=22050, n_fft=2048, hop_length=512, n_mels=128)
+    assert tuple(M.shape) == (256, 128, 1292)
+    Mh = M.cpu().numpy()
+    assert np.isfinite(Mh).all() and (Mh >= 0).all()
+    for i in (0, 1, 100, 255):
+        yi = y[i].cpu().numpy()
+        ref = O.melspectrogram(y=yi, sr=22050, n_fft=2048, hop_length=512, n_mels=128)
+        assert _mel_close(Mh[i], ref), i
+        assert np.array_equal(L.feature.melspectrogram(y=y[i], sr=22050, n_fft=2048, hop_length=512, n_mels=128).cpu().numpy(), Mh[i])
+    M2 = L.feature.melspectrogram(y=2.0 * y[:32], sr=22050, n_fft=2048, hop_length=512, n_mels=128).cpu().numpy()
+    assert np.allclose(M2, 4.0 * Mh[:32], rtol=1e-5, atol=0)
+
+
+def test_full_size_stft_istft_round_trip(L, full_batch):
+    """config 4: stft -> istft on batch=256 x 30 s, reconstruction SNR >= 60 dB for every clip; plus
+    Parseval: sum_t sum_f c_f |D|^2 / n_fft == sum_t sum_n (w x)^2 per frame (checked via window power)."""
+    y = full_batch
+    D = L.stft(y, n_fft=2048, hop_length=512)
+    assert tuple(D.shape) == (256, 1025, 1292)
+    yh = L.istft(D, hop_length=512, length=y.shape[-1])
+    err = (y - yh).double().pow(2).sum(dim=1)
+    sig = y.double().pow(2).sum(dim=1)
+    snr = 10 * np.log10((sig / err).cpu().numpy())
+    assert snr.min() >= 60, snr.min()
+    # a sampled clip against the oracle
+    ref = O.stft(y[17].cpu().numpy(), n_fft=2048, hop_length=512)
+    assert _stft_close(D[17].cpu().numpy(), ref)
+    # Parseval on the Hermitian half-spectrum: energy of each windowed frame
+    P = D.abs().double().pow(2)
+    c = np.full(1025, 2.0)
+    c[0] = c[-1] = 1.0
+    import torch
+
+    e_freq = (P * torch.from_numpy(c).cuda()[None, :, None]).sum(dim=1) / 2048.0  # (256, 1292)
+    frames = y[:4].unfold(-1, 2048, 512)  # interior frames of 4 clips: t = 2 .. (centred offset of 2 frames)
+    w = torch.from_numpy(O.get_window("hann", 2048).astype(np.float32)).cuda()
+    e_time = (frames * w).double().pow(2).sum(dim=-1)  # (4, 1288)
+    assert torch.allclose(e_freq[:4, 2 : 2 + e_time.shape[1]], e_time, rtol=1e-5)
+
+
+def test_multi_resolution_stack(L, full_batch):
+    """config 5 (CQT-lite): three STFTs at n_fft = 512 / 2048 / 8192 sharing hop = 512 share a time grid."""
+    y = full_batch[:8]
+    outs = [L.stft(y, n_fft=n, hop_length=512) for n in (512, 2048, 8192)]
+    assert [tuple(o.shape) for o in outs] == [(8, 257, 1292), (8, 1025, 1292), (8, 4097, 1292)]
+    yi = y[3].cpu().numpy()
+    for n, o in zip((512, 2048, 8192), outs):
+        assert _stft_close(o[3].cpu().numpy(), O.stft(yi, n_fft=n, hop_length=512))

@@ -1,0 +1,153 @@
+"""CPU checks of the gfx950 kernel BODIES (librosa_amd/csrc/lra_kernels.h) through the host thread
+simulator: same templated code the GPU runs, executed phase by phase over a workgroup's threads,
+with an LDS shadow that flags cross-thread races inside a phase and reads of unwritten LDS.
+
+This validates index math, barrier placement and numerics against the oracle in the build
+container (no GPU).  It is test infrastructure; the product library never runs on the CPU.
+"""
+import warnings
+
+import numpy as np
+import pytest
+
+import hostsim_util as H
+import stft_oracle as O
+
+warnings.filterwarnings("ignore", message="n_fft=.*is too large")
+
+
+def _check_diag(d):
+    assert d["races"] == 0, f"LDS race inside a phase: {d}"
+    assert d["uninit"] == 0, f"read of never-written LDS: {d}"
+
+
+def _tol(dtype):
+    return 2e-6 if dtype == np.float32 else 1e-13
+
+
+@pytest.mark.parametrize(
+    "n_fft,hop,center,pad_mode,iters,dtype,n,variant",
+    [
+        (32, 8, True, "constant", 1, np.float32, 500, 0),
+        (64, 16, True, "reflect", 1, np.float32, 20, 0),  # pad longer than the signal: repeated reflection
+        (256, 64, True, "symmetric", 2, np.float32, 879, 0),
+        (512, 128, True, "reflect", 1, np.float32, 300, 0),
+        (512, 100, True, "edge", 3, np.float32, 1647, 0),
+        (1024, 256, False, "constant", 2, np.float32, 3183, 0),
+        (2048, 512, True, "constant", 2, np.float32, 22050, 0),
+        (2048, 512, True, "constant", 3, np.float32, 9000, 1),
+        (2048, 512, True, "reflect", 1, np.float32, 9000, 2),
+        (2048, 512, True, "constant", 1, np.float32, 9000, 3),
+        (2048, 511, True, "constant", 1, np.float32, 9001, 0),  # odd hop: unaligned 8-byte loads path
+        (4096, 1024, True, "constant", 1, np.float32, 20000, 0),
+        (8192, 512, True, "constant", 1, np.float32, 24687, 0),
+        (16384, 4096, True, "constant", 1, np.float32, 49263, 0),
+        (64, 16, True, "constant", 1, np.float64, 700, 0),
+        (512, 128, True, "reflect", 1, np.float64, 1647, 0),
+        (2048, 512, True, "constant", 2, np.float64, 9000, 0),
+        (8192, 2048, False, "constant", 1, np.float64, 30000, 0),
+    ],
+)
+def test_stft_body(n_fft, hop, center, pad_mode, iters, dtype, n, variant):
+    rng = np.random.default_rng(n_fft + hop + n)
+    y = rng.standard_normal((2, n)).astype(dtype)
+    win = O.get_window("hann", n_fft)
+    out, d = H.stft(y, n_fft, hop, win, center=center, pad_mode=pad_mode, iters_per_wg=iters, variant=variant)
+    _check_diag(d)
+    ref = np.moveaxis(O.stft(y, n_fft=n_fft, hop_length=hop, center=center, pad_mode=pad_mode), -1, -2)
+    assert out.shape == ref.shape and out.dtype == ref.dtype
+    assert np.isfinite(out.view(dtype)).all()
+    assert np.abs(out - ref).max() <= _tol(dtype) * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("n_fft,hop,power,n_mels,dtype,variant", [(2048, 512, 2.0, 128, np.float32, 0), (2048, 512, 2.0, 128, np.float32, 1), (1024, 256, 1.0, 40, np.float32, 0),
+                                                          (512, 128, 1.5, 20, np.float32, 0), (2048, 512, 2.0, 64, np.float64, 0)])
+def test_power_and_mel_body(n_fft, hop, power, n_mels, dtype, variant):
+    rng = np.random.default_rng(7)
+    y = rng.standard_normal((2, 9000)).astype(dtype)
+    win = O.get_window("hann", n_fft)
+    S, d = H.stft(y, n_fft, hop, win, mode=1, power=power, variant=variant)
+    _check_diag(d)
+    Sref = np.moveaxis(O.spectrogram(y=y, n_fft=n_fft, hop_length=hop, power=power)[0], -1, -2)
+    assert np.abs(S - Sref).max() <= 4 * _tol(dtype) * Sref.max()
+    B = O.mel(sr=22050, n_fft=n_fft, n_mels=n_mels, dtype=dtype)
+    Mo, d = H.stft(y, n_fft, hop, win, mode=2, power=power, mel_basis=B, iters_per_wg=2, variant=variant)
+    _check_diag(d)
+    Mref = O.melspectrogram(y=y, sr=22050, n_fft=n_fft, hop_length=hop, power=power, n_mels=n_mels, dtype=dtype)
+    assert Mo.shape == Mref.shape
+    # mel parity bar |d| <= 1e-4 |ref| + 1e-4 max|ref|; the f32 pipeline is ~100x inside it
+    assert np.all(np.abs(Mo - Mref) <= 1e-5 * np.abs(Mref) + 1e-5 * Mref.max())
+
+
+def _istft_inputs(y, n_fft, hop, center, length, window="hann", win_length=None):
+    D = O.stft(y, n_fft=n_fft, hop_length=hop, center=center, window=window, win_length=win_length)
+    ref = O.istft(D, hop_length=hop, n_fft=n_fft, center=center, length=length, window=window, win_length=win_length)
+    out_len = ref.shape[-1]
+    T = D.shape[-1]
+    if length:
+        padded = length + 2 * (n_fft // 2) if center else length
+        n_frames = min(T, int(np.ceil(padded / hop)))
+    else:
+        n_frames = T
+    if center:
+        sf = int(np.ceil((n_fft // 2) / hop))
+        n_used, drop = max(n_frames, min(T, sf)), n_fft // 2
+    else:
+        n_used, drop = n_frames, 0
+    wss = O.window_sumsquare(window=window, n_frames=n_frames, win_length=win_length, n_fft=n_fft, hop_length=hop, dtype=ref.dtype)
+    wss = O.fix_length(wss[drop:], size=out_len)
+    win = O.pad_center(O.get_window(window, win_length or n_fft), size=n_fft)
+    return np.ascontiguousarray(np.moveaxis(D, -1, -2)), ref, wss, win, out_len, n_used
+
+
+@pytest.mark.parametrize(
+    "n_fft,hop,n,center,length,dtype,strip_groups,window,win_length,variant",
+    [
+        (2048, 512, 22050, True, "n", np.float32, 2, "hann", None, 0),
+        (2048, 512, 22050, True, None, np.float32, 3, "hann", None, 1),
+        (2048, 512, 9000, True, "n", np.float32, 1, "hann", None, 3),
+        (1024, 256, 9000, False, None, np.float32, 2, "hann", None, 0),
+        (512, 128, 5000, True, 4000, np.float32, 2, "hann", None, 0),
+        (512, 128, 5000, True, 6000, np.float32, 2, "hann", None, 0),  # length beyond the frames: zero tail
+        (512, 100, 5000, True, "n", np.float32, 2, "hann", None, 0),  # hop does not divide n_fft
+        (512, 512, 9000, True, "n", np.float32, 2, "hann", None, 0),  # hop == n_fft
+        (256, 300, 5000, True, None, np.float32, 2, "hann", None, 0),  # hop > n_fft: gaps
+        (256, 64, 3000, True, "n", np.float64, 2, "hann", None, 0),
+        (2048, 512, 9000, True, "n", np.float64, 1, "hann", None, 0),
+        (4096, 512, 30000, True, "n", np.float32, 1, "hann", None, 0),
+        (512, 128, 300, True, "n", np.float32, 2, "hann", None, 0),
+        (64, 16, 1000, True, "n", np.float32, 1, "hann", None, 0),
+        (1024, 256, 12000, True, "n", np.float32, 2, "blackmanharris", None, 0),
+        (512, 100, 5000, True, "n", np.float32, 2, "hann", 400, 0),
+    ],
+)
+def test_istft_body(n_fft, hop, n, center, length, dtype, strip_groups, window, win_length, variant):
+    rng = np.random.default_rng(n_fft + hop)
+    y = rng.standard_normal((2, n)).astype(dtype)
+    L = n if length == "n" else length
+    Dn, ref, wss, win, out_len, n_used = _istft_inputs(y, n_fft, hop, center, L, window, win_length)
+    out, d = H.istft(Dn, n_fft, hop, win, wss, out_len, n_used, center=center, strip_groups=strip_groups, variant=variant)
+    _check_diag(d)
+    assert out.shape == ref.shape
+    # Where the window sum-square is tiny (frame edges without overlap) the division amplifies the
+    # round-off of ANY implementation by 1/sqrt(wss): compare with that conditioning factored in.
+    cond = 1.0 / np.sqrt(np.maximum(wss, np.finfo(np.float32).tiny))
+    tol = (4e-6 if dtype == np.float32 else 1e-13) * np.abs(ref).max() * np.maximum(1.0, cond)
+    well = wss > 1e-3 * wss.max()
+    assert np.all(np.abs(out - ref)[..., well] <= tol[well])
+    assert np.all(np.abs(out - ref)[..., ~well] <= 50 * tol[~well] + 1e-3)
+
+
+def test_pad_index_matches_numpy():
+    lib = H.lib()
+    for n in (1, 2, 5, 17):
+        x = np.arange(n)
+        for mode, code in (("reflect", 1), ("edge", 2), ("symmetric", 3)):
+            if mode == "reflect" and n == 1:
+                ref = np.pad(x, 12, mode="edge")
+            else:
+                ref = np.pad(x, 12, mode=mode)
+            got = np.array([lib.hostsim_pad_index(g, n, code) for g in range(-12, n + 12)])
+            assert np.array_equal(got, ref), (n, mode)
+        got = [lib.hostsim_pad_index(g, n, 0) for g in (-3, -1, n, n + 4)]
+        assert got == [-1, -1, -1, -1]
