@@ -159,8 +159,8 @@ def main():
         return wall, e0.elapsed_ms(e1) / 1e3
 
     if args.sweep and rank == 0:
-        for variant in range(4):
-            for iters in (1, 2, 4, 8, 16, 32):
+        for variant in range(5):
+            for iters in (4, 8, 16, 32, 64):
                 ctx.set_option("variant", variant)
                 ctx.set_option("stft_iters", iters)
                 _, ev_m = timed(step_mel, args.steps, 3)

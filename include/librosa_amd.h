@@ -63,8 +63,11 @@ int lra_device_count(int* count);
 /* One context = one device + one stream + error state.  Fails with LRA_ENODEV when no GPU. */
 int lra_ctx_create(int device, lra_ctx** out);
 void lra_ctx_destroy(lra_ctx* ctx);
-/* Adopt an existing hipStream_t (NULL restores the context's own stream). */
+/* Enqueue on an existing hipStream_t, e.g. PyTorch's current stream.  NULL means HIP's default
+ * (null) stream -- which is what torch.cuda.current_stream() is unless the caller changed it. */
 int lra_ctx_set_stream(lra_ctx* ctx, void* hip_stream);
+/* Go back to the context's own (non-blocking) stream. */
+int lra_ctx_use_own_stream(lra_ctx* ctx);
 int lra_ctx_sync(lra_ctx* ctx);
 /* Tuning knobs: "stft_iters" (frame groups per workgroup), "istft_strip_groups", "variant". */
 int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value);

@@ -61,7 +61,7 @@ class Session:
         else:
             self.device = None
             self.ctx = _native.get_context()
-            self.ctx.set_stream(None)
+            self.ctx.use_own_stream()
         self._keep = []
 
     # ---- inputs ---------------------------------------------------------------------------------

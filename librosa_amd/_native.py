@@ -35,6 +35,7 @@ SIGNATURES = {
     "lra_ctx_create": (c_int, [c_int, POINTER(c_void_p)]),
     "lra_ctx_destroy": (None, [c_void_p]),
     "lra_ctx_set_stream": (c_int, [c_void_p, c_void_p]),
+    "lra_ctx_use_own_stream": (c_int, [c_void_p]),
     "lra_ctx_sync": (c_int, [c_void_p]),
     "lra_ctx_set_option": (c_int, [c_void_p, c_char_p, c_int]),
     "lra_ctx_device_name": (c_int, [c_void_p, c_char_p, c_size_t]),
@@ -79,6 +80,15 @@ def load_library():
                     f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                     "(librosa_amd has no CPU fallback)"
                 )
+            # PyTorch wheels bundle their own ROCm runtime (libamdhip64.so.7, libhsa-runtime64, librocfft
+            # ... same SONAMEs as /opt/rocm).  Two different HIP runtimes in one process cannot both
+            # own the device, so if torch is installed its runtime must be the one that is loaded first;
+            # our library then binds to it through the shared SONAMEs.  Without torch the system ROCm
+            # runtime is used.
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
             try:
                 lib = ctypes.CDLL(LIB_PATH)
             except OSError as exc:  # missing libamdhip64 / librocfft
@@ -197,7 +207,11 @@ class Context:
         return buf.value.decode()
 
     def set_stream(self, stream_ptr):
+        """Enqueue on this hipStream_t (0 / None = HIP's default stream, torch's usual current stream)."""
         _check(self.lib.lra_ctx_set_stream(self.handle, c_void_p(stream_ptr or None)))
+
+    def use_own_stream(self):
+        _check(self.lib.lra_ctx_use_own_stream(self.handle))
 
     def sync(self):
         _check(self.lib.lra_ctx_sync(self.handle))

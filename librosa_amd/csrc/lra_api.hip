@@ -60,6 +60,8 @@ struct lra_ctx {
     int opt_stft_iters = 0;          // 0 = auto
     int opt_istft_strip_groups = 0;  // 0 = auto
     int opt_variant = 0;             // kernel tuning variant (f32 n_fft = 2048 only)
+    int opt_mel_tile = 0;            // frames staged per mel row before a flush (0 = auto)
+    int opt_ablate = 0;              // development aid, see StftArgs::ablate
     unsigned int* d_flag = nullptr;  // non-finite input flag (device)
     std::string name;
 };
@@ -128,7 +130,7 @@ struct lra_stft_plan {
     bool pow2 = false;
     int logm = 0;
     void* d_win = nullptr;
-    void* d_tw = nullptr;
+    void* d_tw[kNumVariants] = {};  // pass-twiddle tables; their layout depends on the kernel configuration
     void* d_twr = nullptr;
     FftPlanCache fft;
     Scratch frames, spec;
@@ -149,7 +151,7 @@ struct lra_istft_plan {
     bool pow2 = false;
     int logm = 0;
     void* d_win_scaled = nullptr;  // window / n_fft
-    void* d_tw = nullptr;
+    void* d_tw[kNumVariants] = {};
     void* d_twr = nullptr;
     FftPlanCache fft;
     Scratch spec, frames;
@@ -179,19 +181,29 @@ template <class T> struct StftLaunch {
     int mode = 0;
     long long batch = 0;
     int iters_opt = 0;  // 0 = auto
+    int mel_tile_opt = 0;
+    int n_cu = 256;
     hipStream_t stream = nullptr;
     hipError_t err = hipSuccess;
     template <class Cfg> void operator()() {
         static_assert(Cfg::P <= 4, "at most four Stockham passes are wired up");
-        // frame groups per workgroup: amortises the table loads (HOIST) and gives the mel epilogue
-        // longer contiguous rows, but keeps >= ~8 workgroups per clip for load balance
+        // frames per slot: a slot pays n_fft - hop extra sample loads for its first frame, so long runs
+        // are cheap in HBM traffic; but keep >= ~4 workgroups per CU in the launch for load balance
         int iters = iters_opt;
-        if (iters <= 0) iters = (int)std::min<long long>(Cfg::HOIST ? 8 : 4, std::max<long long>(1, a.n_frames / (8LL * Cfg::FPB)));
+        if (iters <= 0) {
+            iters = 32;
+            while (iters > 4 && batch * ((a.n_frames + Cfg::FPB * iters - 1) / (Cfg::FPB * iters)) < 4LL * n_cu) iters /= 2;
+            while (iters > 1 && Cfg::FPB * (iters / 2) >= a.n_frames) iters /= 2;
+        }
+        a.mel_tile = mel_tile_opt > 0 ? mel_tile_opt : 4;
+        if (a.mel_tile > iters) a.mel_tile = iters;
         a.frames_per_wg = Cfg::FPB * iters;
         a.wg_per_clip = (a.n_frames + a.frames_per_wg - 1) / a.frames_per_wg;
+        a.slot_bytes = stft_slot_bytes<Cfg>(mode, a.n_mels, a.mel_tile);
         const long long grid = batch * a.wg_per_clip;
         if (grid > 0x7fffffffLL) { err = hipErrorInvalidConfiguration; return; }
-        constexpr int lds = stft_lds_bytes<Cfg>();
+        const int lds = Cfg::FPB * a.slot_bytes;
+        if (lds > 160 * 1024) { err = hipErrorInvalidValue; return; }
         void (*kern)(const StftArgs<T>) = mode == OUT_COMPLEX ? stft_kernel<Cfg, OUT_COMPLEX> : mode == OUT_POWER ? stft_kernel<Cfg, OUT_POWER> : stft_kernel<Cfg, OUT_MEL>;
         if (lds > 65536) {
             err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -205,20 +217,20 @@ template <class T> struct StftLaunch {
 template <class T> struct IstftLaunch {
     IstftArgs<T> a;
     long long batch = 0;
-    int strip_groups = 16;
+    int strip_frames = 64;
     hipStream_t stream = nullptr;
     hipError_t err = hipSuccess;
     template <class Cfg> void operator()() {
         static_assert(Cfg::P <= 4, "at most four Stockham passes are wired up");
         constexpr int FPB = Cfg::FPB, N = Cfg::N;
         const int H = a.hop;
-        a.strip_frames = strip_groups * FPB;
+        a.strip_frames = strip_frames;
         a.strips_per_clip = (a.n_used + a.strip_frames - 1) / a.strip_frames;
-        const int W = (N + H - 1) / H - 1;
-        a.warm_groups = (W + FPB - 1) / FPB;
-        const long long rem = N > H ? N - H : 0;
-        a.drain_groups = (int)((rem + (long long)FPB * H - 1) / ((long long)FPB * H));
-        const long long grid = batch * a.strips_per_clip;
+        a.warm_frames = (N + H - 1) / H - 1;
+        a.drain_steps = N > H ? (N - H + H - 1) / H : 0;
+        a.batch = batch;
+        const long long grid = (batch * a.strips_per_clip + FPB - 1) / FPB;
+        if (grid > 0x7fffffffLL) { err = hipErrorInvalidConfiguration; return; }
         constexpr int lds = istft_lds_bytes<Cfg>();
         void (*kern)(const IstftArgs<T>) = istft_kernel<Cfg>;
         if (lds > 65536) {
@@ -240,11 +252,13 @@ template <class T> struct TableBuild {
     }
 };
 
-template <class T> int build_tables(int logm, void** d_tw, void** d_twr) {
-    TableBuild<T> tb;
-    if (!dispatch_logm<T>(logm, 0, tb)) return fail(LRA_EINVAL, "unsupported power-of-two size");
-    LRA_TRY(upload(d_tw, tb.tw.data(), tb.tw.size() * sizeof(cx<T>)));
-    LRA_TRY(upload(d_twr, tb.twr.data(), tb.twr.size() * sizeof(cx<T>)));
+template <class T> int build_tables(int logm, void** d_tw /* [kNumVariants] */, void** d_twr) {
+    for (int v = 0; v < kNumVariants; ++v) {
+        TableBuild<T> tb;
+        if (!dispatch_logm<T>(logm, v, tb)) return fail(LRA_EINVAL, "unsupported power-of-two size");
+        LRA_TRY(upload(&d_tw[v], tb.tw.data(), tb.tw.size() * sizeof(cx<T>)));
+        if (v == 0) LRA_TRY(upload(d_twr, tb.twr.data(), tb.twr.size() * sizeof(cx<T>)));
+    }
     return LRA_OK;
 }
 
@@ -435,7 +449,7 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
         L.a.pad = p->center ? p->n_fft / 2 : 0;
         L.a.pad_mode = p->pad_mode;
         L.a.win = (const T*)p->d_win;
-        L.a.tw = (const cx<T>*)p->d_tw;
+        L.a.tw = (const cx<T>*)p->d_tw[(ctx->opt_variant >= 0 && ctx->opt_variant < kNumVariants) ? ctx->opt_variant : 0];
         L.a.twr = (const cx<T>*)p->d_twr;
         L.a.D = (cx<T>*)out;
         L.a.S = (T*)out;
@@ -450,10 +464,13 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
             L.a.n_mels = mel->n_mels;
         }
         L.a.nonfinite_flag = ctx->d_flag;
+        L.a.ablate = ctx->opt_ablate;
         L.mode = mode;
         L.batch = batch;
         L.stream = ctx->stream;
         L.iters_opt = ctx->opt_stft_iters;
+        L.n_cu = ctx->n_cu;
+        L.mel_tile_opt = ctx->opt_mel_tile;
         if (!dispatch_logm<T>(p->logm, ctx->opt_variant, L)) return fail(LRA_EINVAL, "unsupported power-of-two size");
         if (L.err != hipSuccess) return fail(LRA_EHIP, std::string("stft kernel launch: ") + hipGetErrorString(L.err));
         return LRA_OK;
@@ -511,7 +528,7 @@ int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_s
         L.a.hop = p->hop;
         L.a.drop = p->center ? N / 2 : 0;
         L.a.win_scaled = (const T*)p->d_win_scaled;
-        L.a.tw = (const cx<T>*)p->d_tw;
+        L.a.tw = (const cx<T>*)p->d_tw[(ctx->opt_variant >= 0 && ctx->opt_variant < kNumVariants) ? ctx->opt_variant : 0];
         L.a.twr = (const cx<T>*)p->d_twr;
         L.a.wss = (const T*)wss;
         L.a.tiny = tinyv;
@@ -520,7 +537,7 @@ int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_s
         L.a.out_len = out_len;
         L.batch = batch;
         L.stream = ctx->stream;
-        L.strip_groups = ctx->opt_istft_strip_groups > 0 ? ctx->opt_istft_strip_groups : 16;
+        L.strip_frames = ctx->opt_istft_strip_groups > 0 ? ctx->opt_istft_strip_groups : 64;
         if (!dispatch_logm<T>(p->logm, ctx->opt_variant, L)) return fail(LRA_EINVAL, "unsupported power-of-two size");
         if (L.err != hipSuccess) return fail(LRA_EHIP, std::string("istft kernel launch: ") + hipGetErrorString(L.err));
         return LRA_OK;
@@ -611,7 +628,13 @@ void lra_ctx_destroy(lra_ctx* ctx) {
 
 int lra_ctx_set_stream(lra_ctx* ctx, void* hip_stream) {
     if (!ctx) return fail(LRA_EINVAL, "null context");
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = (hipStream_t)hip_stream;  // NULL is HIP's default (null) stream, a valid choice
+    return LRA_OK;
+}
+
+int lra_ctx_use_own_stream(lra_ctx* ctx) {
+    if (!ctx) return fail(LRA_EINVAL, "null context");
+    ctx->stream = ctx->own_stream;
     return LRA_OK;
 }
 
@@ -625,6 +648,8 @@ int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value) {
     if (!ctx || !key) return fail(LRA_EINVAL, "null argument");
     if (!std::strcmp(key, "stft_iters")) ctx->opt_stft_iters = value;
     else if (!std::strcmp(key, "istft_strip_groups")) ctx->opt_istft_strip_groups = value;
+    else if (!std::strcmp(key, "mel_tile")) ctx->opt_mel_tile = value;
+    else if (!std::strcmp(key, "ablate")) ctx->opt_ablate = value;
     else if (!std::strcmp(key, "variant")) ctx->opt_variant = (value >= 0 && value < kNumVariants) ? value : 0;
     else return fail(LRA_EINVAL, std::string("unknown option ") + key);
     return LRA_OK;
@@ -743,7 +768,7 @@ int lra_stft_plan_create(lra_ctx* ctx, int n_fft, int hop_length, const void* wi
     int rc = upload(&p->d_win, window_host, (size_t)n_fft * real_bytes(dtype));
     if (rc == LRA_OK && p->pow2) {
         p->logm = log2_exact(n_fft) - 1;
-        rc = dtype == LRA_F64 ? build_tables<double>(p->logm, &p->d_tw, &p->d_twr) : build_tables<float>(p->logm, &p->d_tw, &p->d_twr);
+        rc = dtype == LRA_F64 ? build_tables<double>(p->logm, p->d_tw, &p->d_twr) : build_tables<float>(p->logm, p->d_tw, &p->d_twr);
     }
     if (rc != LRA_OK) {
         lra_stft_plan_destroy(p);
@@ -757,7 +782,8 @@ void lra_stft_plan_destroy(lra_stft_plan* p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
     if (p->d_win) (void)hipFree(p->d_win);
-    if (p->d_tw) (void)hipFree(p->d_tw);
+    for (int v = 0; v < kNumVariants; ++v)
+        if (p->d_tw[v]) (void)hipFree(p->d_tw[v]);
     if (p->d_twr) (void)hipFree(p->d_twr);
     delete p;
 }
@@ -900,7 +926,7 @@ int lra_istft_plan_create(lra_ctx* ctx, int n_fft, int hop_length, const void* w
     }
     if (rc == LRA_OK && p->pow2) {
         p->logm = log2_exact(n_fft) - 1;
-        rc = dtype == LRA_F64 ? build_tables<double>(p->logm, &p->d_tw, &p->d_twr) : build_tables<float>(p->logm, &p->d_tw, &p->d_twr);
+        rc = dtype == LRA_F64 ? build_tables<double>(p->logm, p->d_tw, &p->d_twr) : build_tables<float>(p->logm, p->d_tw, &p->d_twr);
     }
     if (rc != LRA_OK) {
         lra_istft_plan_destroy(p);
@@ -914,7 +940,8 @@ void lra_istft_plan_destroy(lra_istft_plan* p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
     if (p->d_win_scaled) (void)hipFree(p->d_win_scaled);
-    if (p->d_tw) (void)hipFree(p->d_tw);
+    for (int v = 0; v < kNumVariants; ++v)
+        if (p->d_tw[v]) (void)hipFree(p->d_tw[v]);
     if (p->d_twr) (void)hipFree(p->d_twr);
     delete p;
 }

@@ -51,17 +51,12 @@ LRA_HD long long pad_index(long long g, long long n, int mode) {
     if (g >= 0 && g < n) return g;
     if (n <= 0 || mode == PAD_CONSTANT) return -1;
     if (mode == PAD_EDGE || n == 1) return g < 0 ? 0 : n - 1;
-    if (mode == PAD_REFLECT) {
-        const long long period = 2 * (n - 1);
-        long long m = g % period;
-        if (m < 0) m += period;
-        return m < n ? m : period - m;
-    }
-    // symmetric
-    const long long period = 2 * n;
-    long long m = g % period;
-    if (m < 0) m += period;
-    return m < n ? m : period - 1 - m;
+    // reflect / symmetric: fold back into [0, n).  A loop instead of a modulo: one trip unless the
+    // pad is longer than the signal, and no 64-bit division in the kernels.
+    const long long lo = mode == PAD_REFLECT ? 0 : -1;               // g < 0  ->  lo - g
+    const long long hi = mode == PAD_REFLECT ? 2 * (n - 1) : 2 * n - 1;  // g >= n ->  hi - g
+    while (g < 0 || g >= n) g = g < 0 ? lo - g : hi - g;
+    return g;
 }
 
 // ----------------------------------------------------------------------------- LDS access layer
@@ -70,23 +65,32 @@ namespace sim {
 struct State {
     std::vector<unsigned char> mem;
     std::vector<int> w_epoch, w_tid, r_epoch, r_tid;  // per 4-byte word
+    std::vector<int> w_wg, r_wg, r_wave;                // workgroup-barrier epoch of last write / read
     std::vector<unsigned char> ever;
-    int epoch = 1;
+    int epoch = 1;     // advances at every phase end (wave-level or workgroup-level sync)
+    int wg_epoch = 1;  // advances only at workgroup barriers
     int cur_tid = 0;
     long long races = 0, uninit = 0;
     void resize(size_t bytes) {
         mem.assign(bytes, 0xCD);
         size_t w = (bytes + 3) / 4;
         w_epoch.assign(w, 0); w_tid.assign(w, -1); r_epoch.assign(w, 0); r_tid.assign(w, -1); ever.assign(w, 0);
+        w_wg.assign(w, 0); r_wg.assign(w, 0); r_wave.assign(w, -1);
     }
-    void barrier() { ++epoch; }
+    // wave_only: the phase boundary is a wave-level fence, not __syncthreads(): data may only flow
+    // between lanes of the same wave64 across it
+    void barrier(bool wave_only = false) { ++epoch; if (!wave_only) ++wg_epoch; }
     void note_read(size_t off, size_t bytes) {
         if (off + bytes > mem.size()) { std::fprintf(stderr, "hostsim: LDS read out of bounds off=%zu\n", off); std::abort(); }
         for (size_t w = off / 4; w < (off + bytes + 3) / 4; ++w) {
             if (!ever[w]) ++uninit;
             if (w_epoch[w] == epoch && w_tid[w] != cur_tid) ++races;
+            // written by another wave with no workgroup barrier in between
+            if (ever[w] && w_wg[w] == wg_epoch && w_tid[w] / 64 != cur_tid / 64) ++races;
             if (r_epoch[w] != epoch) { r_epoch[w] = epoch; r_tid[w] = cur_tid; }
             else if (r_tid[w] != cur_tid) r_tid[w] = -2;  // several readers this phase
+            if (r_wg[w] != wg_epoch) { r_wg[w] = wg_epoch; r_wave[w] = cur_tid / 64; }
+            else if (r_wave[w] != cur_tid / 64) r_wave[w] = -2;  // several waves since the last barrier
         }
     }
     void note_write(size_t off, size_t bytes) {
@@ -94,7 +98,9 @@ struct State {
         for (size_t w = off / 4; w < (off + bytes + 3) / 4; ++w) {
             if (w_epoch[w] == epoch && w_tid[w] != cur_tid) ++races;
             if (r_epoch[w] == epoch && r_tid[w] != cur_tid) ++races;
-            w_epoch[w] = epoch; w_tid[w] = cur_tid; ever[w] = 1;
+            if (ever[w] && w_wg[w] == wg_epoch && w_tid[w] / 64 != cur_tid / 64) ++races;   // cross-wave WAW
+            if (r_wg[w] == wg_epoch && r_wave[w] != cur_tid / 64) ++races;                    // cross-wave WAR
+            w_epoch[w] = epoch; w_tid[w] = cur_tid; w_wg[w] = wg_epoch; ever[w] = 1;
         }
     }
 };
@@ -120,6 +126,7 @@ inline Lds lds_sub(Lds l, int byte_off) { Lds r; r.base = l.base + byte_off; ret
 #define LRA_ATOMIC_OR(ptr, v) (*(ptr) |= (v))
 #define LRA_PHASE(NT, tid) for (int tid = 0; tid < (NT); ++tid) { ::lra::sim::state().cur_tid = tid;
 #define LRA_PHASE_END } ::lra::sim::state().barrier();
+#define LRA_PHASE_END_SYNC(WAVE) } ::lra::sim::state().barrier(WAVE);
 #define LRA_REGS(Type, name, NT) std::vector<Type> name##_all(NT)
 #define LRA_R(name) name##_all[tid]
 
@@ -136,8 +143,21 @@ LRA_HD Lds lds_sub(Lds l, int byte_off) { Lds r; r.base = l.base + byte_off; ret
 // hoisted out of the enclosing loop
 #define LRA_LAUNDER(p) asm volatile("" : "+s"(p))
 #define LRA_ATOMIC_OR(ptr, v) atomicOr((ptr), (v))
+// Phase boundary.  WAVE = true: every lane that exchanges data through LDS across this boundary is
+// in the same wave64 (a wave's DS instructions execute in order), so a compiler-level fence is
+// enough and the waves of the workgroup are free to drift apart; otherwise a workgroup barrier.
+template <bool WAVE> __device__ __forceinline__ void phase_sync() {
+    if constexpr (WAVE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
 #define LRA_PHASE(NT, tid) { const int tid = (int)threadIdx.x;
 #define LRA_PHASE_END } __syncthreads();
+#define LRA_PHASE_END_SYNC(WAVE) } ::lra::phase_sync<(WAVE)>();
 #define LRA_REGS(Type, name, NT) Type name
 #define LRA_R(name) name
 

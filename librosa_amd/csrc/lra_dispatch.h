@@ -9,27 +9,33 @@ namespace lra {
 constexpr int kMinLogM = 4;     // n_fft = 32
 constexpr int kMaxLogM = 13;    // n_fft = 16384 (M = 8192 complex: 68 KiB of LDS per frame in f32)
 constexpr int kMaxLogM64 = 12;  // f64: n_fft <= 8192
-constexpr int kNumVariants = 4; // tuning variants exist for f32 n_fft = 2048 only
+constexpr int kNumVariants = 5; // tuning variants exist for f32 n_fft = 2048 only
 
 // Compile-time configuration per (dtype, log2 M, variant).  Variant 0 is the default:
 //   f32: 16 complex points per thread, 256-VGPR budget (2 waves/SIMD), window/twiddle values kept
 //        in registers across the frame loop for n_fft <= 2048 (no table traffic in steady state);
 //   f64:  8 complex points per thread, 256-VGPR budget, tables re-read from L1/L2 every frame.
+// A workgroup is ONE wave64 (several frame slots when n_fft < 2048) unless a frame needs more threads:
+// slots are private pipelines, so small workgroups only add scheduling freedom and keep the LDS
+// footprint (frame area + PCM ring + mel tile, ~17-19 KiB per slot at n_fft = 2048) granular.
 // Variants 1..3 (f32, n_fft = 2048) trade registers for occupancy; bench.py --sweep times them.
 template <class T, int L, int VAR> struct CfgSel {
-    using type = FftCfg<L, 4, T, 256, 2, (L <= 10)>;
+    using type = FftCfg<L, 4, T, 64, 2, (L <= 10)>;
 };
 template <int L, int VAR> struct CfgSel<double, L, VAR> {
-    using type = FftCfg<L, 3, double, 256, 2, false>;
+    using type = FftCfg<L, 3, double, 64, 2, false>;
 };
 template <> struct CfgSel<float, 10, 1> {
-    using type = FftCfg<10, 3, float, 256, 4, false>;
+    using type = FftCfg<10, 3, float, 128, 4, false>;
 };
 template <> struct CfgSel<float, 10, 2> {
-    using type = FftCfg<10, 4, float, 256, 3, false>;
+    using type = FftCfg<10, 4, float, 64, 3, false>;
 };
 template <> struct CfgSel<float, 10, 3> {
-    using type = FftCfg<10, 4, float, 256, 4, false>;
+    using type = FftCfg<10, 4, float, 64, 4, false>;
+};
+template <> struct CfgSel<float, 10, 4> {
+    using type = FftCfg<10, 3, float, 128, 3, true>;  // two waves per frame, tables in registers, 3 waves/SIMD
 };
 
 // true when n_fft is a power of two handled by the fused LDS kernels
@@ -60,6 +66,7 @@ template <class T, class F> inline bool dispatch_logm(int logm, int variant, F&&
                 if (variant == 1) { f.template operator()<typename CfgSel<T, 10, 1>::type>(); return true; }
                 if (variant == 2) { f.template operator()<typename CfgSel<T, 10, 2>::type>(); return true; }
                 if (variant == 3) { f.template operator()<typename CfgSel<T, 10, 3>::type>(); return true; }
+                if (variant == 4) { f.template operator()<typename CfgSel<T, 10, 4>::type>(); return true; }
             }
             f.template operator()<typename CfgSel<T, 10, 0>::type>();
             return true;

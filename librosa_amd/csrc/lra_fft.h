@@ -52,12 +52,23 @@ template <int LOGM_, int LOGR_, class T_, int NTMIN_ = 256, int MINW_ = 0, bool 
         return o;
     }
     static constexpr int TW_TOTAL = tw_off(P) > 0 ? tw_off(P) : 1;
+    // per-thread register copies of the pass twiddles (HOIST).  Only the power-of-two powers
+    // w^1, w^2, w^4, ... of each butterfly's base twiddle are kept (log2 r values instead of r - 1);
+    // the others are one complex multiply away: w^j = w^(j - msb j) * w^(msb j)
+    static constexpr int treg_off(int p) {
+        int o = 0;
+        for (int q = 1; q < p; ++q) o += (R >> logr(q)) * logr(q);
+        return o;
+    }
+    static constexpr int TREG_TOTAL = treg_off(P) > 0 ? treg_off(P) : 1;
     static constexpr int PADSHIFT = logr(0);
     static constexpr int FRAME_ELEMS = M + (M >> PADSHIFT) + 1;
     static constexpr int FRAME_BYTES = ((FRAME_ELEMS * (int)sizeof(cplx) + 15) / 16) * 16;
     static constexpr int phys(int i) { return i + (i >> PADSHIFT); }
     static constexpr int MIN_WAVES = MINW_ > 0 ? MINW_ : 2;
     static constexpr bool HOIST = HOIST_;
+    // a frame slot (TF threads) never spans two waves: slot-private LDS traffic needs no s_barrier
+    static constexpr bool WAVE_SYNC = TF <= 64;
 };
 
 // ----------------------------------------------------------------------------- small DFTs
@@ -108,14 +119,31 @@ template <class T> struct Dft<2, T> {
 // Pass p: butterfly b in [0, M/r) takes inputs at b + j*(M/r), multiplies input j by
 // W_{s r}^{(b mod s) j}, and writes output j to (b - b mod s) r + (b mod s) + j s, where s is the
 // product of the earlier radices.  Thread tf owns butterflies b = tf + i*TF.
+// LDS addressing.  phys(i) = i + (i >> PADSHIFT) is affine over any step that is a multiple of
+// Q = 2^PADSHIFT: phys(x + c) = phys(x) + c + c/Q.  Every access pattern of the passes is
+// "per-thread base + compile-time multiples of TF / stride", so when TF is a multiple of Q the
+// whole pass needs ONE runtime address and immediate DS offsets; spelling it out that way keeps
+// hipcc from materialising (and hoisting) one address VGPR per access.
+template <class Cfg> constexpr int pstride(int c) { return c + (c >> Cfg::PADSHIFT); }
+template <class Cfg> constexpr bool affine_tf() { return Cfg::TF % (1 << Cfg::PADSHIFT) == 0; }
+
 template <class Cfg, int p> LRA_HD void pass_read(typename Cfg::cplx* v, Lds fr, int tf) {
     using C = typename Cfg::cplx;
-    constexpr int lr = Cfg::logr(p), r = 1 << lr, nb = Cfg::R >> lr, sin = Cfg::M >> lr;
-    LRA_UNROLL
-    for (int i = 0; i < nb; ++i) {
-        const int b = tf + i * Cfg::TF;
+    constexpr int lr = Cfg::logr(p), r = 1 << lr, nb = Cfg::R >> lr, sin = Cfg::M >> lr, Q = 1 << Cfg::PADSHIFT;
+    if constexpr (affine_tf<Cfg>() && sin % Q == 0) {
+        const int base = Cfg::phys(tf) * (int)sizeof(C);
         LRA_UNROLL
-        for (int j = 0; j < r; ++j) v[i * r + j] = lds_ld<C>(fr, Cfg::phys(b + j * sin) * (int)sizeof(C));
+        for (int i = 0; i < nb; ++i) {
+            LRA_UNROLL
+            for (int j = 0; j < r; ++j) v[i * r + j] = lds_ld<C>(fr, base + (i * pstride<Cfg>(Cfg::TF) + j * pstride<Cfg>(sin)) * (int)sizeof(C));
+        }
+    } else {
+        LRA_UNROLL
+        for (int i = 0; i < nb; ++i) {
+            const int b = tf + i * Cfg::TF;
+            LRA_UNROLL
+            for (int j = 0; j < r; ++j) v[i * r + j] = lds_ld<C>(fr, Cfg::phys(b + j * sin) * (int)sizeof(C));
+        }
     }
 }
 
@@ -134,16 +162,76 @@ template <class Cfg, int p> LRA_HD void pass_twiddle_dft(typename Cfg::cplx* v, 
     }
 }
 
+// Same, with this thread's twiddles already sitting in registers (see load_pass_twiddles).
+template <class Cfg, int p> LRA_HD void pass_twiddle_dft_reg(typename Cfg::cplx* v, const typename Cfg::cplx* treg) {
+    using T = typename Cfg::real;
+    using C = typename Cfg::cplx;
+    constexpr int lr = Cfg::logr(p), r = 1 << lr, nb = Cfg::R >> lr;
+    LRA_UNROLL
+    for (int i = 0; i < nb; ++i) {
+        if (p > 0) {
+            C w[r];  // w[j] = W^(k j); built from the stored powers of two
+            LRA_UNROLL
+            for (int j = 1; j < r; ++j) {
+                int msb = 0;
+                LRA_UNROLL
+                for (int t = 0; t < lr; ++t) if ((j >> t) & 1) msb = t;
+                const int rest = j - (1 << msb);
+                w[j] = rest == 0 ? treg[Cfg::treg_off(p) + i * lr + msb] : cmul(w[rest], treg[Cfg::treg_off(p) + i * lr + msb]);
+                v[i * r + j] = cmul(v[i * r + j], w[j]);
+            }
+        }
+        Dft<r, T>::run(v + i * r);
+    }
+}
+
+// Copies this thread's base twiddles of pass p (they depend only on tf) from the global table to
+// registers: W^(k 2^t), t = 0 .. log2(r) - 1.
+template <class Cfg, int p> LRA_HD void load_pass_twiddles(typename Cfg::cplx* treg, int tf, const typename Cfg::cplx* __restrict__ tw) {
+    constexpr int lr = Cfg::logr(p), nb = Cfg::R >> lr, s = 1 << Cfg::logs(p);
+    LRA_UNROLL
+    for (int i = 0; i < nb; ++i) {
+        const int k = (tf + i * Cfg::TF) & (s - 1);
+        LRA_UNROLL
+        for (int t = 0; t < lr; ++t) treg[Cfg::treg_off(p) + i * lr + t] = tw[Cfg::tw_off(p) + ((1 << t) - 1) * s + k];
+    }
+}
+
 template <class Cfg, int p> LRA_HD void pass_write(const typename Cfg::cplx* v, Lds fr, int tf) {
     using C = typename Cfg::cplx;
     constexpr int lr = Cfg::logr(p), r = 1 << lr, nb = Cfg::R >> lr, s = 1 << Cfg::logs(p);
-    LRA_UNROLL
-    for (int i = 0; i < nb; ++i) {
-        const int b = tf + i * Cfg::TF;
-        const int k = b & (s - 1);
-        const int base = ((b - k) << lr) + k;
+    constexpr bool last = p == Cfg::P - 1;  // then b < s, so k = b and the output position is b + j s
+    if constexpr (affine_tf<Cfg>() && p == 0) {
+        // s = 1, k = 0: position b r + j with b r a multiple of Q = r: phys = b (r + 1) + j
+        const int base = tf * (r + 1) * (int)sizeof(C);
         LRA_UNROLL
-        for (int j = 0; j < r; ++j) lds_st<C>(fr, Cfg::phys(base + j * s) * (int)sizeof(C), v[i * r + j]);
+        for (int i = 0; i < nb; ++i) {
+            LRA_UNROLL
+            for (int j = 0; j < r; ++j) lds_st<C>(fr, base + (i * Cfg::TF * (r + 1) + j) * (int)sizeof(C), v[i * r + j]);
+        }
+    } else if constexpr (affine_tf<Cfg>() && p > 0 && (last || Cfg::TF % s == 0)) {
+        int base;
+        if (last) {
+            base = Cfg::phys(tf) * (int)sizeof(C);  // position tf + i TF + j s
+        } else {
+            const int k = tf & (s - 1);  // TF % s == 0: k does not depend on i
+            base = Cfg::phys(((tf - k) << lr) + k) * (int)sizeof(C);
+        }
+        constexpr int istep = last ? pstride<Cfg>(Cfg::TF) : pstride<Cfg>(Cfg::TF << lr);
+        LRA_UNROLL
+        for (int i = 0; i < nb; ++i) {
+            LRA_UNROLL
+            for (int j = 0; j < r; ++j) lds_st<C>(fr, base + (i * istep + j * pstride<Cfg>(s)) * (int)sizeof(C), v[i * r + j]);
+        }
+    } else {
+        LRA_UNROLL
+        for (int i = 0; i < nb; ++i) {
+            const int b = tf + i * Cfg::TF;
+            const int k = b & (s - 1);
+            const int base = ((b - k) << lr) + k;
+            LRA_UNROLL
+            for (int j = 0; j < r; ++j) lds_st<C>(fr, Cfg::phys(base + j * s) * (int)sizeof(C), v[i * r + j]);
+        }
     }
 }
 

@@ -44,8 +44,10 @@ template <class T> struct StftArgs {
     const cx<T>* tw;    // pass twiddles (FftCfg::tw_off layout)
     const cx<T>* twr;   // split twiddles W_N^k, k = 0..M/2
     // work decomposition
-    int frames_per_wg;  // multiple of FPB
+    int frames_per_wg;  // FPB * iters: slot s owns frames [s*iters, (s+1)*iters) of the workgroup's range
     int wg_per_clip;
+    int slot_bytes;     // LDS bytes per frame slot (frame area + PCM ring + mel staging tile)
+    int mel_tile;       // frames staged per mel row before a flush
     // outputs (one of)
     cx<T>* D;  // [batch][T][M+1]
     T* S;      // [batch][T][M+1]
@@ -61,12 +63,60 @@ template <class T> struct StftArgs {
     // set to 1 when a frame's DC bin is not finite, i.e. (barring overflow) when some sample of the
     // frame is NaN/Inf: the device-side half of util.valid_audio (util/utils.py:305)
     unsigned int* nonfinite_flag;
+    // development aid (ctx option "ablate"): bit 0 = suppress the spectrum/mel stores, bit 1 = no PCM
+    // loads, bit 2 = skip the middle FFT passes.  Results are wrong when non-zero; used only to
+    // attribute time by subtraction (cdna_hip_programming.md 5.4 rule 17: values stay live).
+    int ablate;
 };
 
 template <class Cfg> struct FftRegs {
     typename Cfg::cplx v[Cfg::R];
     typename Cfg::cplx mid;
+    // next frame's new hop samples, in flight while the current frame is transformed (hop <= n_fft/4)
+    static constexpr int NPF = (Cfg::N / 4) / Cfg::TF > 0 ? (Cfg::N / 4) / Cfg::TF : 1;
+    typename Cfg::real pf[NPF];
+    // HOIST configurations: this thread's table values, loaded once before the frame loop.  (hipcc
+    // does not hoist them by itself across the per-phase fences; re-reading ~52 table values per
+    // frame from L2 left the waves 65 % of their time in s_waitcnt.)
+    static constexpr int NH = Cfg::HOIST ? 1 : 0;
+    typename Cfg::cplx win2[NH * Cfg::R + 1 - NH];       // window pairs in pass-0 register order
+    typename Cfg::cplx treg[NH * Cfg::TREG_TOTAL + 1 - NH];
+    typename Cfg::cplx twr[NH * (Cfg::R / 2) + 1 - NH];  // split twiddles W_N^k, k = tf + i*TF
 };
+
+// prologue of HOIST kernels: window, pass twiddles and split twiddles -> registers
+template <class Cfg> LRA_HD void hoist_tables(FftRegs<Cfg>& rg, int tf, const typename Cfg::real* __restrict__ win, const typename Cfg::cplx* __restrict__ tw,
+                                              const typename Cfg::cplx* __restrict__ twr, bool window_in_last_pass_order) {
+    using C = typename Cfg::cplx;
+    if (!Cfg::HOIST) return;
+    const C* __restrict__ win2 = reinterpret_cast<const C*>(win);
+    if (window_in_last_pass_order) {
+        constexpr int p = Cfg::P - 1, lr = Cfg::logr(p), r = 1 << lr, nb = Cfg::R >> lr;
+        LRA_UNROLL
+        for (int i = 0; i < nb; ++i) {
+            LRA_UNROLL
+            for (int j = 0; j < r; ++j) rg.win2[i * r + j] = win2[last_pass_pos<Cfg>(tf, i, j)];
+        }
+    } else {
+        constexpr int lr = Cfg::logr(0), r = 1 << lr, nb = Cfg::R >> lr, sin = Cfg::M >> lr;
+        LRA_UNROLL
+        for (int i = 0; i < nb; ++i) {
+            LRA_UNROLL
+            for (int j = 0; j < r; ++j) rg.win2[i * r + j] = win2[tf + i * Cfg::TF + j * sin];
+        }
+    }
+    if (Cfg::P > 1) load_pass_twiddles<Cfg, (1 < Cfg::P ? 1 : 0)>(rg.treg, tf, tw);
+    if (Cfg::P > 2) load_pass_twiddles<Cfg, (2 < Cfg::P ? 2 : 0)>(rg.treg, tf, tw);
+    if (Cfg::P > 3) load_pass_twiddles<Cfg, (3 < Cfg::P ? 3 : 0)>(rg.treg, tf, tw);
+    LRA_UNROLL
+    for (int i = 0; i < Cfg::R / 2; ++i) rg.twr[i] = twr[tf + i * Cfg::TF];
+}
+
+// twiddle + butterflies of pass p from whichever source the configuration uses
+template <class Cfg, int p> LRA_HD void pass_dft(FftRegs<Cfg>& rg, int tf, const typename Cfg::cplx* __restrict__ tw) {
+    if (Cfg::HOIST) pass_twiddle_dft_reg<Cfg, p>(rg.v, rg.treg);
+    else pass_twiddle_dft<Cfg, p>(rg.v, tf, tw);
+}
 
 template <class T> LRA_HD T spec_power(cx<T> x, int power_mode, T power) {
     const T p2 = x.x * x.x + x.y * x.y;
@@ -76,89 +126,127 @@ template <class T> LRA_HD T spec_power(cx<T> x, int power_mode, T power) {
     return std::pow(mag, power);
 }
 
-// ---- phase (edge groups only): stage a frame that touches the np.pad region into LDS ------------
-// The frame's N real samples (pad mode applied, no window yet) go to the start of its own LDS
-// region; keeping the 64-bit index arithmetic of pad_index() out of the unrolled hot path.
-template <class Cfg> LRA_HD void stft_stage_edge(const StftArgs<typename Cfg::real>& a, int clip, int frame, bool valid, int tf, Lds fr) {
+// ---- PCM ring -------------------------------------------------------------------------------------
+// Each frame slot keeps the N samples of its current frame in an LDS ring indexed by the padded
+// sample position modulo N.  A slot walks CONSECUTIVE frames, so going from frame t to t+1 only the
+// last min(hop, N) samples are new: every PCM sample is fetched from HBM once per slot (instead of
+// n_fft/hop = 4 times), and because the new samples are few (n_fft/4 per frame = R/2 registers per
+// thread) they are prefetched into registers one whole frame ahead, hiding the HBM latency behind
+// the FFT of the current frame.  np.pad semantics (core/spectrum.py:287) are applied at fetch time.
+template <class T> LRA_HD T fetch_sample(const T* __restrict__ yb, long long p, int pad, long long n, int pad_mode) {
+    const long long g = p - pad;
+    if (g >= 0 && g < n) return yb[g];
+    const long long idx = pad_index(g, n, pad_mode);
+    return idx >= 0 ? yb[idx] : (T)0;
+}
+
+// phase A: bring the ring up to date for frame `frame` (iteration `it` of the slot), then start the
+// prefetch of the following frame's new samples
+template <class Cfg> LRA_HD void stft_ring_update(const StftArgs<typename Cfg::real>& a, int clip, int frame, int it, int iters, int tf,
+                                                  FftRegs<Cfg>& rg, Lds ring) {
     using T = typename Cfg::real;
+    constexpr int N = Cfg::N, NPF = FftRegs<Cfg>::NPF;
+    const int H = a.hop;
+    const int Hn = H < N ? H : N;          // samples that are new per frame
+    const bool use_pf = 4 * Hn <= N;       // they fit the prefetch registers
+    const bool active = frame < a.n_frames;
     const T* __restrict__ yb = a.y + (long long)clip * a.y_stride;
-    const long long base = (long long)frame * a.hop - a.pad;
-    for (int q = tf; q < Cfg::N; q += Cfg::TF) {
-        T x = (T)0;
-        if (valid) {
-            const long long i0 = pad_index(base + q, a.n, a.pad_mode);
-            if (i0 >= 0) x = yb[i0];
+    const long long p0 = (long long)frame * H;  // padded position of the frame's first sample
+    if (active) {
+        if (it == 0) {
+            for (int i = tf; i < N; i += Cfg::TF) lds_st<T>(ring, (int)((p0 + i) & (N - 1)) * (int)sizeof(T), fetch_sample<T>(yb, p0 + i, a.pad, a.n, a.pad_mode));
+        } else if (use_pf) {
+            LRA_UNROLL
+            for (int c = 0; c < NPF; ++c) {
+                const int e = tf + c * Cfg::TF;
+                if (e < Hn) lds_st<T>(ring, (int)((p0 + (N - Hn) + e) & (N - 1)) * (int)sizeof(T), rg.pf[c]);
+            }
+        } else {
+            for (int e = tf; e < Hn; e += Cfg::TF) {
+                const long long p = p0 + (N - Hn) + e;
+                lds_st<T>(ring, (int)(p & (N - 1)) * (int)sizeof(T), fetch_sample<T>(yb, p, a.pad, a.n, a.pad_mode));
+            }
         }
-        lds_st<T>(fr, q * (int)sizeof(T), x);
+    }
+    if (use_pf && it + 1 < iters && frame + 1 < a.n_frames) {
+        const long long p1 = p0 + H + (N - Hn);  // first new padded position of the next frame
+        const long long g1 = p1 - a.pad;
+        if (g1 >= 0 && g1 + Hn <= a.n) {  // uniform per slot: the whole block is inside the clip
+            LRA_UNROLL
+            for (int c = 0; c < NPF; ++c) {
+                const int e = tf + c * Cfg::TF;
+                rg.pf[c] = e < Hn ? ((a.ablate & 2) ? (T)(e & 7) : yb[g1 + e]) : (T)0;
+            }
+        } else {
+            LRA_UNROLL
+            for (int c = 0; c < NPF; ++c) {
+                const int e = tf + c * Cfg::TF;
+                rg.pf[c] = e < Hn ? fetch_sample<T>(yb, p1 + e, a.pad, a.n, a.pad_mode) : (T)0;
+            }
+        }
     }
 }
 
-// frame [base, base+N) lies entirely inside the clip: the hot path may read it straight from HBM
-template <class Cfg> LRA_HD bool frame_interior(const StftArgs<typename Cfg::real>& a, int frame) {
-    const long long base = (long long)frame * a.hop - a.pad;
-    return frame < a.n_frames && base >= 0 && base + Cfg::N <= a.n;
-}
-
-// ---- phase: gather + window (+ pass 0 butterflies when fused) ----------------------------------
-// FROM_LDS: samples come from the staged copy (edge groups), else directly from global memory.
-template <class Cfg, bool FROM_LDS> LRA_HD void stft_load(const StftArgs<typename Cfg::real>& a, int clip, int frame, int tf, typename Cfg::cplx* v, Lds fr) {
+// phase B: frame samples (ring) x window -> registers -> pass-0 butterflies -> frame area
+template <class Cfg> LRA_HD void stft_ring_load_pass0(const StftArgs<typename Cfg::real>& a, int frame, int tf, FftRegs<Cfg>& rg, Lds ring, Lds fr) {
     using T = typename Cfg::real;
     using C = typename Cfg::cplx;
-    constexpr int lr = Cfg::logr(0), r = 1 << lr, nb = Cfg::R >> lr, sin = Cfg::M >> lr;
+    constexpr int lr = Cfg::logr(0), r = 1 << lr, nb = Cfg::R >> lr, sin = Cfg::M >> lr, N = Cfg::N;
     const C* __restrict__ win2 = reinterpret_cast<const C*>(a.win);
-    if (FROM_LDS) {
+    C* v = rg.v;
+    const int base = (int)(((long long)frame * a.hop) & (N - 1));
+    if (frame >= a.n_frames) {
+        LRA_UNROLL
+        for (int i = 0; i < Cfg::R; ++i) v[i] = mk<T>((T)0, (T)0);
+    } else if ((base & 1) == 0) {
         LRA_UNROLL
         for (int i = 0; i < nb; ++i) {
             LRA_UNROLL
             for (int j = 0; j < r; ++j) {
-                const int q = tf + i * Cfg::TF + j * sin;  // complex index: samples 2q, 2q+1
-                const C x = lds_ld<C>(fr, q * (int)sizeof(C));
-                const C w = win2[q];
+                const int q = tf + i * Cfg::TF + j * sin;  // complex index: samples 2q, 2q+1 of the frame
+                const C x = lds_ld<C>(ring, ((base + 2 * q) & (N - 1)) * (int)sizeof(T));
+                const C w = Cfg::HOIST ? rg.win2[i * r + j] : win2[q];
                 v[i * r + j] = mk<T>(x.x * w.x, x.y * w.y);
             }
         }
-        return;
-    }
-    const T* __restrict__ yf = a.y + (long long)clip * a.y_stride + ((long long)frame * a.hop - a.pad);
-    if ((reinterpret_cast<uintptr_t>(yf) & (sizeof(C) - 1)) == 0) {
-        const C* __restrict__ y2 = reinterpret_cast<const C*>(yf);
+    } else {  // odd hop: the sample pair is not 8-byte aligned in the ring
         LRA_UNROLL
         for (int i = 0; i < nb; ++i) {
             LRA_UNROLL
             for (int j = 0; j < r; ++j) {
                 const int q = tf + i * Cfg::TF + j * sin;
-                const C x = y2[q];
-                const C w = win2[q];
-                v[i * r + j] = mk<T>(x.x * w.x, x.y * w.y);
-            }
-        }
-    } else {
-        LRA_UNROLL
-        for (int i = 0; i < nb; ++i) {
-            LRA_UNROLL
-            for (int j = 0; j < r; ++j) {
-                const int q = tf + i * Cfg::TF + j * sin;
-                const C w = win2[q];
-                v[i * r + j] = mk<T>(yf[2 * q] * w.x, yf[2 * q + 1] * w.y);
+                const T x0 = lds_ld<T>(ring, ((base + 2 * q) & (N - 1)) * (int)sizeof(T));
+                const T x1 = lds_ld<T>(ring, ((base + 2 * q + 1) & (N - 1)) * (int)sizeof(T));
+                const C w = Cfg::HOIST ? rg.win2[i * r + j] : win2[q];
+                v[i * r + j] = mk<T>(x0 * w.x, x1 * w.y);
             }
         }
     }
-}
-
-template <class Cfg> LRA_HD void stft_pass0(const StftArgs<typename Cfg::real>& a, int tf, typename Cfg::cplx* v, Lds fr) {
-    pass_twiddle_dft<Cfg, 0>(v, tf, a.tw);
+    pass_dft<Cfg, 0>(rg, tf, a.tw);
     pass_write<Cfg, 0>(v, fr, tf);
 }
 
 // ---- phase: read Z[k], Z[M-k] pairs for the split step ----------------------------------------
 template <class Cfg> LRA_HD void split_read(FftRegs<Cfg>& rg, Lds fr, int tf) {
     using C = typename Cfg::cplx;
-    LRA_UNROLL
-    for (int i = 0; i < Cfg::R / 2; ++i) {
-        const int k = tf + i * Cfg::TF;
-        const int km = (Cfg::M - k) & (Cfg::M - 1);
-        rg.v[2 * i] = lds_ld<C>(fr, Cfg::phys(k) * (int)sizeof(C));
-        rg.v[2 * i + 1] = lds_ld<C>(fr, Cfg::phys(km) * (int)sizeof(C));
+    if constexpr (affine_tf<Cfg>()) {
+        // k = tf + i TF and M - k: two runtime bases, immediate offsets (see lra_fft.h)
+        const int bk = Cfg::phys(tf) * (int)sizeof(C);
+        const int bm0 = Cfg::phys((Cfg::M - tf) & (Cfg::M - 1)) * (int)sizeof(C);  // i = 0 (wraps to 0 for tf = 0)
+        const int bm = (Cfg::M - tf + ((Cfg::M - tf) >> Cfg::PADSHIFT)) * (int)sizeof(C);
+        LRA_UNROLL
+        for (int i = 0; i < Cfg::R / 2; ++i) {
+            rg.v[2 * i] = lds_ld<C>(fr, bk + i * pstride<Cfg>(Cfg::TF) * (int)sizeof(C));
+            rg.v[2 * i + 1] = lds_ld<C>(fr, i == 0 ? bm0 : bm - i * pstride<Cfg>(Cfg::TF) * (int)sizeof(C));
+        }
+    } else {
+        LRA_UNROLL
+        for (int i = 0; i < Cfg::R / 2; ++i) {
+            const int k = tf + i * Cfg::TF;
+            const int km = (Cfg::M - k) & (Cfg::M - 1);
+            rg.v[2 * i] = lds_ld<C>(fr, Cfg::phys(k) * (int)sizeof(C));
+            rg.v[2 * i + 1] = lds_ld<C>(fr, Cfg::phys(km) * (int)sizeof(C));
+        }
     }
     if (tf == 0) rg.mid = lds_ld<C>(fr, Cfg::phys(Cfg::M / 2) * (int)sizeof(C));
 }
@@ -193,11 +281,11 @@ template <class Cfg, int MODE> LRA_HD void stft_split_store(const StftArgs<typen
             km = M;
             if (valid && a.nonfinite_flag && !(std::fabs(xk.x) <= std::numeric_limits<T>::max())) LRA_ATOMIC_OR(a.nonfinite_flag, 1u);
         } else {
-            split_pair<T>(rg.v[2 * i], rg.v[2 * i + 1], a.twr[k], xk, xm);
+            split_pair<T>(rg.v[2 * i], rg.v[2 * i + 1], Cfg::HOIST ? rg.twr[i] : a.twr[k], xk, xm);
             km = M - k;
         }
         if (MODE == OUT_COMPLEX) {
-            if (valid) { a.D[row + k] = xk; a.D[row + km] = xm; }
+            if (valid && (!(a.ablate & 1) || xk.x == (T)1.2345e30)) { a.D[row + k] = xk; a.D[row + km] = xm; }
         } else {
             const T pk = spec_power<T>(xk, a.power_mode, a.power), pm = spec_power<T>(xm, a.power_mode, a.power);
             if (MODE == OUT_POWER) {
@@ -223,85 +311,107 @@ template <class Cfg, int MODE> LRA_HD void stft_split_store(const StftArgs<typen
     }
 }
 
-// ---- phase: sparse (banded) mel reduce over the power spectra held in LDS ----------------------
-template <class Cfg> LRA_HD void mel_reduce_store(const StftArgs<typename Cfg::real>& a, int clip, int frame0, int tid, Lds lds) {
+// ---- phase: banded mel reduce of ONE frame (its power spectrum sits in the slot's frame area) ----
+// Thread tf of the slot owns mel rows tf, tf+TF, ...; results go to the slot's staging tile
+// stage[m][it] so that the flush after the frame loop writes rows of `iters` consecutive frames.
+template <class Cfg> LRA_HD void mel_reduce_slot(const StftArgs<typename Cfg::real>& a, int tf, int it, int iters, Lds fr, Lds stage) {
     using T = typename Cfg::real;
-    const int total = a.n_mels * Cfg::FPB;
-    for (int idx = tid; idx < total; idx += Cfg::NT) {
-        const int slot = idx % Cfg::FPB, m = idx / Cfg::FPB;
-        const int frame = frame0 + slot;
-        if (frame >= a.n_frames) continue;
+    for (int m = tf; m < a.n_mels; m += Cfg::TF) {
         const int c0 = a.mel_c0[m], len = a.mel_len[m];
         const T* __restrict__ w = a.mel_val + a.mel_off[m];
-        const Lds fr = lds_sub(lds, slot * Cfg::FRAME_BYTES);
         T acc = (T)0;
         for (int i = 0; i < len; ++i) acc += w[i] * lds_ld<T>(fr, (c0 + i) * (int)sizeof(T));
-        a.Mel[((long long)clip * a.n_mels + m) * a.n_frames + frame] = acc;
+        lds_st<T>(stage, (m * iters + it) * (int)sizeof(T), acc);
     }
 }
 
-#define LRA_MID_PASS(Cfg, p, rg, lds, tw)                                                                 \
+// ---- phase: flush the slot's staging tile: M[clip][m][f0 .. f0+nv) ------------------------------
+template <class Cfg> LRA_HD void mel_flush_slot(const StftArgs<typename Cfg::real>& a, int clip, int f0, int nv, int tf, int iters, Lds stage) {
+    using T = typename Cfg::real;
+    const int total = a.n_mels * iters;
+    for (int idx = tf; idx < total; idx += Cfg::TF) {
+        const int m = idx / iters, i = idx - m * iters;
+        if (i < nv) a.Mel[((long long)clip * a.n_mels + m) * a.n_frames + f0 + i] = lds_ld<T>(stage, idx * (int)sizeof(T));
+    }
+}
+
+#define LRA_MID_PASS(Cfg, p, rg, lds, tw, slot_bytes)                                                     \
     if (Cfg::P > p) {                                                                                     \
         LRA_PHASE(Cfg::NT, tid) {                                                                         \
-            pass_read<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(rg).v, lds_sub(lds, (tid / Cfg::TF) * Cfg::FRAME_BYTES), tid % Cfg::TF); \
-        } LRA_PHASE_END                                                                                   \
+            pass_read<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(rg).v, lds_sub(lds, (tid / Cfg::TF) * (slot_bytes)), tid % Cfg::TF); \
+        } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)                                                              \
         LRA_PHASE(Cfg::NT, tid) {                                                                         \
-            pass_twiddle_dft<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(rg).v, tid % Cfg::TF, tw);                \
-            pass_write<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(rg).v, lds_sub(lds, (tid / Cfg::TF) * Cfg::FRAME_BYTES), tid % Cfg::TF); \
-        } LRA_PHASE_END                                                                                   \
+            pass_dft<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(rg), tid % Cfg::TF, tw);                          \
+            pass_write<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(rg).v, lds_sub(lds, (tid / Cfg::TF) * (slot_bytes)), tid % Cfg::TF); \
+        } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)                                                              \
     }
 
-// One workgroup: clip = blk / wg_per_clip, frames [wg*frames_per_wg, +frames_per_wg).
+// bytes of LDS one frame slot needs (frame area + mel staging tile), multiple of 16
+// slot layout: [frame area | PCM ring of N reals | mel staging tile n_mels x tile]
+template <class Cfg> constexpr int stft_ring_off() { return Cfg::FRAME_BYTES; }
+template <class Cfg> constexpr int stft_tile_off() { return Cfg::FRAME_BYTES + Cfg::N * (int)sizeof(typename Cfg::real); }
+template <class Cfg> inline int stft_slot_bytes(int mode, int n_mels, int tile) {
+    int b = stft_tile_off<Cfg>();
+    if (mode == OUT_MEL) b += ((n_mels * tile * (int)sizeof(typename Cfg::real) + 15) / 16) * 16;
+    return b;
+}
+
+// One workgroup = FPB frame slots; slot s transforms the `iters` CONSECUTIVE frames
+// f_first + s*iters + it of clip blk / wg_per_clip, as a private pipeline: all LDS traffic of a slot
+// stays inside the slot (and, when TF <= 64, inside one wave: no s_barrier anywhere).  The mel
+// epilogue stages `mel_tile` frames per row before flushing them as contiguous runs.
 template <class Cfg, int MODE> LRA_HD void stft_block(const StftArgs<typename Cfg::real>& a_in, const int blk, Lds lds) {
     StftArgs<typename Cfg::real> a = a_in;
     const int clip = blk / a.wg_per_clip;
     const int f_first = (blk % a.wg_per_clip) * a.frames_per_wg;
     const int iters = a.frames_per_wg / Cfg::FPB;
+    const int slot_bytes = a.slot_bytes;
+    const int tile = a.mel_tile;
     LRA_REGS(FftRegs<Cfg>, rg, Cfg::NT);
+    LRA_PHASE(Cfg::NT, tid) { hoist_tables<Cfg>(LRA_R(rg), tid % Cfg::TF, a.win, a.tw, a.twr, false); } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
     for (int it = 0; it < iters; ++it) {
+        if (f_first + it >= a.n_frames) break;  // slot 0 has the smallest frame index: uniform exit
         if (!Cfg::HOIST) { LRA_LAUNDER(a.win); LRA_LAUNDER(a.tw); LRA_LAUNDER(a.twr); }
-        const int frame0 = f_first + it * Cfg::FPB;
-        if (frame0 >= a.n_frames) break;  // uniform across the workgroup
-        // a group is "interior" when all of its FPB frames exist and lie inside the clip
-        const bool group_interior = frame_interior<Cfg>(a, frame0) && frame_interior<Cfg>(a, frame0 + Cfg::FPB - 1);
-        if (group_interior) {
-            LRA_PHASE(Cfg::NT, tid) {
-                const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
-                const Lds fr = lds_sub(lds, slot * Cfg::FRAME_BYTES);
-                stft_load<Cfg, false>(a, clip, frame0 + slot, tf, LRA_R(rg).v, fr);
-                stft_pass0<Cfg>(a, tf, LRA_R(rg).v, fr);
-            } LRA_PHASE_END
-        } else {
-            LRA_PHASE(Cfg::NT, tid) {
-                const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = frame0 + slot;
-                stft_stage_edge<Cfg>(a, clip, frame, frame < a.n_frames, tf, lds_sub(lds, slot * Cfg::FRAME_BYTES));
-            } LRA_PHASE_END
-            LRA_PHASE(Cfg::NT, tid) {
-                const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
-                stft_load<Cfg, true>(a, clip, frame0 + slot, tf, LRA_R(rg).v, lds_sub(lds, slot * Cfg::FRAME_BYTES));
-            } LRA_PHASE_END
-            LRA_PHASE(Cfg::NT, tid) {
-                const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
-                stft_pass0<Cfg>(a, tf, LRA_R(rg).v, lds_sub(lds, slot * Cfg::FRAME_BYTES));
-            } LRA_PHASE_END
+        LRA_PHASE(Cfg::NT, tid) {
+            const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
+            stft_ring_update<Cfg>(a, clip, frame, it, iters, tf, LRA_R(rg), lds_sub(lds, slot * slot_bytes + stft_ring_off<Cfg>()));
+        } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+        LRA_PHASE(Cfg::NT, tid) {
+            const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
+            const Lds sl = lds_sub(lds, slot * slot_bytes);
+            stft_ring_load_pass0<Cfg>(a, frame, tf, LRA_R(rg), lds_sub(sl, stft_ring_off<Cfg>()), sl);
+        } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+        if (!(a.ablate & 4)) {
+            LRA_MID_PASS(Cfg, 1, rg, lds, a.tw, slot_bytes)
+            LRA_MID_PASS(Cfg, 2, rg, lds, a.tw, slot_bytes)
+            LRA_MID_PASS(Cfg, 3, rg, lds, a.tw, slot_bytes)
         }
-        LRA_MID_PASS(Cfg, 1, rg, lds, a.tw)
-        LRA_MID_PASS(Cfg, 2, rg, lds, a.tw)
-        LRA_MID_PASS(Cfg, 3, rg, lds, a.tw)
         LRA_PHASE(Cfg::NT, tid) {
-            split_read<Cfg>(LRA_R(rg), lds_sub(lds, (tid / Cfg::TF) * Cfg::FRAME_BYTES), tid % Cfg::TF);
-        } LRA_PHASE_END
+            split_read<Cfg>(LRA_R(rg), lds_sub(lds, (tid / Cfg::TF) * slot_bytes), tid % Cfg::TF);
+        } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         LRA_PHASE(Cfg::NT, tid) {
-            const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = frame0 + slot;
-            stft_split_store<Cfg, MODE>(a, clip, frame, frame < a.n_frames, tf, LRA_R(rg), lds_sub(lds, slot * Cfg::FRAME_BYTES));
-        } LRA_PHASE_END
+            const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
+            stft_split_store<Cfg, MODE>(a, clip, frame, frame < a.n_frames, tf, LRA_R(rg), lds_sub(lds, slot * slot_bytes));
+        } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         if (MODE == OUT_MEL) {
-            LRA_PHASE(Cfg::NT, tid) { mel_reduce_store<Cfg>(a, clip, frame0, tid, lds); } LRA_PHASE_END
+            LRA_PHASE(Cfg::NT, tid) {
+                const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
+                const Lds sl = lds_sub(lds, slot * slot_bytes);
+                if (frame < a.n_frames) mel_reduce_slot<Cfg>(a, tf, it % tile, tile, sl, lds_sub(sl, stft_tile_off<Cfg>()));
+            } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+            if ((it + 1) % tile == 0 || it + 1 == iters || f_first + it + 1 >= a.n_frames) {
+                LRA_PHASE(Cfg::NT, tid) {
+                    const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
+                    const int f0 = f_first + slot * iters + (it / tile) * tile;  // first frame of the staged tile
+                    int nv = a.n_frames - f0;
+                    const int staged = it % tile + 1;
+                    nv = nv < 0 ? 0 : (nv > staged ? staged : nv);
+                    mel_flush_slot<Cfg>(a, clip, f0, nv, tf, tile, lds_sub(lds, slot * slot_bytes + stft_tile_off<Cfg>()));
+                } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+            }
         }
     }
 }
-
-template <class Cfg> constexpr int stft_lds_bytes() { return Cfg::FPB * Cfg::FRAME_BYTES; }
 
 // =================================================================================================
 // ISTFT
@@ -321,23 +431,25 @@ template <class T> struct IstftArgs {
     T* y;                       // [batch][out_len], pre-zeroed by the host wrapper
     long long y_stride;
     long long out_len;
-    int strip_frames;           // frames finalised per workgroup, multiple of FPB
+    long long batch;
+    int strip_frames;           // frames whose hop-blocks one slot finalises
     int strips_per_clip;
-    int warm_groups;            // groups of FPB frames replayed before the strip
-    int drain_groups;           // extra groups the last strip runs to flush the carry
+    int warm_frames;            // frames replayed before the strip: ceil(N/hop) - 1
+    int drain_steps;            // extra steps the last strip of a clip runs to flush the carry
 };
 
-template <class Cfg> constexpr int istft_carry_elems() { return Cfg::N; }  // >= N - hop for any hop >= 1
-template <class Cfg> constexpr int istft_lds_bytes() { return Cfg::FPB * Cfg::FRAME_BYTES + 2 * istft_carry_elems<Cfg>() * (int)sizeof(typename Cfg::real); }
+// per slot: frame area + double-buffered carry of N reals (>= N - hop for any hop >= 1)
+template <class Cfg> constexpr int istft_slot_bytes() { return Cfg::FRAME_BYTES + 2 * Cfg::N * (int)sizeof(typename Cfg::real); }
+template <class Cfg> constexpr int istft_lds_bytes() { return Cfg::FPB * istft_slot_bytes<Cfg>(); }
 
 // ---- phase: Hermitian split of X[0..M] into conj(Z'[0..M-1]) in LDS ---------------------------
 // Z'[k] = E' + i O',  E' = X[k] + conj(X[M-k]),  O' = (X[k] - conj(X[M-k])) conj(W_N^k); the
 // imaginary parts of X[0] and X[M] are ignored, as pocketfft's c2r does.
-template <class Cfg> LRA_HD void istft_split_write(const IstftArgs<typename Cfg::real>& a, int clip, int frame, bool valid, int tf, Lds fr) {
+template <class Cfg> LRA_HD void istft_split_write(const IstftArgs<typename Cfg::real>& a, long long clip, int frame, bool valid, int tf, const FftRegs<Cfg>& rg, Lds fr) {
     using T = typename Cfg::real;
     using C = typename Cfg::cplx;
     constexpr int M = Cfg::M;
-    const C* __restrict__ X = a.D + (long long)clip * a.d_batch_stride + (long long)frame * a.d_frame_stride;
+    const C* __restrict__ X = a.D + clip * a.d_batch_stride + (long long)frame * a.d_frame_stride;
     const C zero = mk<T>((T)0, (T)0);
     LRA_UNROLL
     for (int i = 0; i < Cfg::R / 2; ++i) {
@@ -349,7 +461,7 @@ template <class Cfg> LRA_HD void istft_split_write(const IstftArgs<typename Cfg:
             const C xk = valid ? X[k] : zero, xm = valid ? X[M - k] : zero;
             const C E = mk<T>(xk.x + xm.x, xk.y - xm.y);
             const C Dif = mk<T>(xk.x - xm.x, xk.y + xm.y);
-            const C O = cmul(Dif, cconj(a.twr[k]));
+            const C O = cmul(Dif, cconj(Cfg::HOIST ? rg.twr[i] : a.twr[k]));
             // Z'[k] = (E.x - O.y, E.y + O.x);  Z'[M-k] = (E.x + O.y, O.x - E.y); store conjugates
             lds_st<C>(fr, Cfg::phys(k) * (int)sizeof(C), mk<T>(E.x - O.y, -(E.y + O.x)));
             lds_st<C>(fr, Cfg::phys(M - k) * (int)sizeof(C), mk<T>(E.x + O.y, -(O.x - E.y)));
@@ -362,104 +474,122 @@ template <class Cfg> LRA_HD void istft_split_write(const IstftArgs<typename Cfg:
 }
 
 // ---- phase: last pass butterflies, then windowed time-domain frame -> LDS (natural order) ------
-template <class Cfg> LRA_HD void istft_last_write(const IstftArgs<typename Cfg::real>& a, typename Cfg::cplx* v, int tf, Lds fr) {
+template <class Cfg> LRA_HD void istft_last_write(const IstftArgs<typename Cfg::real>& a, FftRegs<Cfg>& rg, int tf, Lds fr) {
     using T = typename Cfg::real;
     using C = typename Cfg::cplx;
     constexpr int p = Cfg::P - 1, lr = Cfg::logr(p), r = 1 << lr, nb = Cfg::R >> lr;
-    pass_twiddle_dft<Cfg, p>(v, tf, a.tw);
+    const C* __restrict__ ws2 = reinterpret_cast<const C*>(a.win_scaled);
+    C* v = rg.v;
+    pass_dft<Cfg, p>(rg, tf, a.tw);
     LRA_UNROLL
     for (int i = 0; i < nb; ++i) {
         LRA_UNROLL
         for (int j = 0; j < r; ++j) {
             const int q = last_pass_pos<Cfg>(tf, i, j);
             const C z = v[i * r + j];  // = conj(z'[q]); x[2q] = Re z', x[2q+1] = Im z'
-            lds_st<C>(fr, q * (int)sizeof(C), mk<T>(z.x * a.win_scaled[2 * q], -z.y * a.win_scaled[2 * q + 1]));
+            const C w = Cfg::HOIST ? rg.win2[i * r + j] : ws2[q];
+            lds_st<C>(fr, q * (int)sizeof(C), mk<T>(z.x * w.x, -z.y * w.y));
         }
     }
 }
 
-// ---- phase: overlap-add of the FPB frames of this group + carry, finalise FPB*hop samples ------
-template <class Cfg> LRA_HD void istft_ola(const IstftArgs<typename Cfg::real>& a, int clip, int group_first_frame, long long write_lo,
-                                           long long write_hi, int parity, int tid, Lds lds) {
+// ---- phase: overlap-add of ONE frame into the slot's carry; finalise one hop of output -----------
+// Padded positions [t*hop, t*hop + max(N, hop)): value = carry_in[u] + frame[u]; the first `hop`
+// positions are final after frame t (later frames start beyond them) and are normalised and stored,
+// the rest become the carry for frame t+1.  Contributions are therefore added in increasing frame
+// order, the reference's accumulation order (core/spectrum.py:593-603, 629-643).
+template <class Cfg> LRA_HD void istft_ola_step(const IstftArgs<typename Cfg::real>& a, long long clip, int t, bool contribute, long long write_lo,
+                                                long long write_hi, int parity, int tf, Lds slot_lds) {
     using T = typename Cfg::real;
-    constexpr int N = Cfg::N, FPB = Cfg::FPB;
+    constexpr int N = Cfg::N;
     const int H = a.hop;
-    const int CL = N > H ? N - H : 0;                    // carry length
-    const long long L = (long long)(FPB - 1) * H + N;    // positions touched by this group
-    const long long pa = (long long)group_first_frame * H;  // padded position of u = 0
-    const long long fin = (long long)FPB * H;            // positions finalised by this group
-    const Lds carry_in = lds_sub(lds, FPB * Cfg::FRAME_BYTES + parity * istft_carry_elems<Cfg>() * (int)sizeof(T));
-    const Lds carry_out = lds_sub(lds, FPB * Cfg::FRAME_BYTES + (1 - parity) * istft_carry_elems<Cfg>() * (int)sizeof(T));
-    const long long span = L > fin ? L : fin;
-    for (long long u = tid; u < span; u += Cfg::NT) {
+    const int CL = N > H ? N - H : 0;
+    const int span = N > H ? N : H;
+    const Lds fr = slot_lds;
+    const Lds carry_in = lds_sub(slot_lds, Cfg::FRAME_BYTES + parity * N * (int)sizeof(T));
+    const Lds carry_out = lds_sub(slot_lds, Cfg::FRAME_BYTES + (1 - parity) * N * (int)sizeof(T));
+    const long long pa = (long long)t * H;
+    for (int u = tf; u < span; u += Cfg::TF) {
         T val = (T)0;
-        if (u < CL) val = lds_ld<T>(carry_in, (int)u * (int)sizeof(T));
-        LRA_UNROLL
-        for (int slot = 0; slot < FPB; ++slot) {
-            const int t = group_first_frame + slot;
-            const long long off = u - (long long)slot * H;
-            if (t >= 0 && t < a.n_used && off >= 0 && off < N) val += lds_ld<T>(lds_sub(lds, slot * Cfg::FRAME_BYTES), (int)off * (int)sizeof(T));
-        }
-        if (u < fin) {
-            const long long sp = pa + u;  // padded position
+        if (u < CL) val = lds_ld<T>(carry_in, u * (int)sizeof(T));
+        if (contribute && u < N) val += lds_ld<T>(fr, u * (int)sizeof(T));
+        if (u < H) {
+            const long long sp = pa + u;
             const long long s = sp - a.drop;
             if (sp >= write_lo && sp < write_hi && s >= 0 && s < a.out_len) {
                 const T w = a.wss[s];
-                a.y[(long long)clip * a.y_stride + s] = (w > a.tiny) ? val / w : val;
+                a.y[clip * a.y_stride + s] = (w > a.tiny) ? val / w : val;
             }
-        } else if (u - fin < CL) {
-            lds_st<T>(carry_out, (int)(u - fin) * (int)sizeof(T), val);
+        } else if (u - H < CL) {
+            lds_st<T>(carry_out, (u - H) * (int)sizeof(T), val);
         }
     }
 }
 
+// One workgroup = FPB slots; slot s owns strip (blk*FPB + s) of the (clip, strip) grid and walks its
+// frames one at a time: warm-up frames (their contribution to the strip's positions), the strip's
+// own frames, and -- for the last strip of a clip -- drain steps that flush the carry.
 template <class Cfg> LRA_HD void istft_block(const IstftArgs<typename Cfg::real>& a_in, const int blk, Lds lds) {
     IstftArgs<typename Cfg::real> a = a_in;
     using T = typename Cfg::real;
     constexpr int FPB = Cfg::FPB;
-    const int clip = blk / a.strips_per_clip;
-    const int strip = blk % a.strips_per_clip;
-    const bool last = strip == a.strips_per_clip - 1;
-    const int t0 = strip * a.strip_frames;
-    int t1 = t0 + a.strip_frames;
-    if (t1 > a.n_used) t1 = a.n_used;
-    const int ta = t0 - a.warm_groups * FPB;
-    int groups = a.warm_groups + (t1 - t0 + FPB - 1) / FPB;
-    if (last) groups += a.drain_groups;
-    const long long write_lo = (long long)t0 * a.hop;
-    const long long write_hi = last ? (long long)0x7fffffffffffffffLL : (long long)t1 * a.hop;
+    constexpr int SB = istft_slot_bytes<Cfg>();
+    // uniform step count: drain steps only when one of this workgroup's slots owns a clip's last strip
+    bool has_last = false;
+    for (int s = 0; s < FPB; ++s) has_last = has_last || (((long long)blk * FPB + s) % a.strips_per_clip) == a.strips_per_clip - 1;
+    const int steps = a.warm_frames + a.strip_frames + (has_last ? a.drain_steps : 0);
     LRA_REGS(FftRegs<Cfg>, rg, Cfg::NT);
-    // the first group's carry-in is all zeros
     LRA_PHASE(Cfg::NT, tid) {
-        const Lds c0 = lds_sub(lds, FPB * Cfg::FRAME_BYTES);
-        for (int u = tid; u < istft_carry_elems<Cfg>(); u += Cfg::NT) lds_st<T>(c0, u * (int)sizeof(T), (T)0);
-    } LRA_PHASE_END
-    for (int g = 0; g < groups; ++g) {
+        hoist_tables<Cfg>(LRA_R(rg), tid % Cfg::TF, a.win_scaled, a.tw, a.twr, true);
+        const Lds c0 = lds_sub(lds, (tid / Cfg::TF) * SB + Cfg::FRAME_BYTES);
+        for (int u = tid % Cfg::TF; u < Cfg::N; u += Cfg::TF) lds_st<T>(c0, u * (int)sizeof(T), (T)0);
+    } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+    for (int j = 0; j < steps; ++j) {
         if (!Cfg::HOIST) { LRA_LAUNDER(a.win_scaled); LRA_LAUNDER(a.tw); LRA_LAUNDER(a.twr); }
-        const int gf = ta + g * FPB;
         LRA_PHASE(Cfg::NT, tid) {
-            const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = gf + slot;
-            istft_split_write<Cfg>(a, clip, frame, frame >= 0 && frame < a.n_used, tf, lds_sub(lds, slot * Cfg::FRAME_BYTES));
-        } LRA_PHASE_END
+            const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
+            const long long sid = (long long)blk * FPB + slot;
+            const long long clip = sid / a.strips_per_clip;
+            const int strip = (int)(sid % a.strips_per_clip);
+            const int t0 = strip * a.strip_frames;
+            int t1 = t0 + a.strip_frames;
+            if (t1 > a.n_used) t1 = a.n_used;
+            const int t = t0 - a.warm_frames + j;
+            const bool valid = clip < a.batch && t >= 0 && t < t1;
+            istft_split_write<Cfg>(a, clip < a.batch ? clip : 0, valid ? t : 0, valid, tf, LRA_R(rg), lds_sub(lds, slot * SB));
+        } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         // pass 0 (no twiddles) reads from LDS here, unlike the forward kernel
         if (Cfg::P > 1) {
             LRA_PHASE(Cfg::NT, tid) {
-                pass_read<Cfg, 0>(LRA_R(rg).v, lds_sub(lds, (tid / Cfg::TF) * Cfg::FRAME_BYTES), tid % Cfg::TF);
-            } LRA_PHASE_END
+                pass_read<Cfg, 0>(LRA_R(rg).v, lds_sub(lds, (tid / Cfg::TF) * SB), tid % Cfg::TF);
+            } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
             LRA_PHASE(Cfg::NT, tid) {
-                pass_twiddle_dft<Cfg, 0>(LRA_R(rg).v, tid % Cfg::TF, a.tw);
-                pass_write<Cfg, 0>(LRA_R(rg).v, lds_sub(lds, (tid / Cfg::TF) * Cfg::FRAME_BYTES), tid % Cfg::TF);
-            } LRA_PHASE_END
+                pass_dft<Cfg, 0>(LRA_R(rg), tid % Cfg::TF, a.tw);
+                pass_write<Cfg, 0>(LRA_R(rg).v, lds_sub(lds, (tid / Cfg::TF) * SB), tid % Cfg::TF);
+            } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         }
-        if (Cfg::P > 2) { LRA_MID_PASS(Cfg, 1, rg, lds, a.tw) }
-        if (Cfg::P > 3) { LRA_MID_PASS(Cfg, 2, rg, lds, a.tw) }
+        if (Cfg::P > 2) { LRA_MID_PASS(Cfg, 1, rg, lds, a.tw, SB) }
+        if (Cfg::P > 3) { LRA_MID_PASS(Cfg, 2, rg, lds, a.tw, SB) }
         LRA_PHASE(Cfg::NT, tid) {
-            pass_read<Cfg, Cfg::P - 1>(LRA_R(rg).v, lds_sub(lds, (tid / Cfg::TF) * Cfg::FRAME_BYTES), tid % Cfg::TF);
-        } LRA_PHASE_END
+            pass_read<Cfg, Cfg::P - 1>(LRA_R(rg).v, lds_sub(lds, (tid / Cfg::TF) * SB), tid % Cfg::TF);
+        } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         LRA_PHASE(Cfg::NT, tid) {
-            istft_last_write<Cfg>(a, LRA_R(rg).v, tid % Cfg::TF, lds_sub(lds, (tid / Cfg::TF) * Cfg::FRAME_BYTES));
-        } LRA_PHASE_END
-        LRA_PHASE(Cfg::NT, tid) { istft_ola<Cfg>(a, clip, gf, write_lo, write_hi, g & 1, tid, lds); } LRA_PHASE_END
+            istft_last_write<Cfg>(a, LRA_R(rg), tid % Cfg::TF, lds_sub(lds, (tid / Cfg::TF) * SB));
+        } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+        LRA_PHASE(Cfg::NT, tid) {
+            const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
+            const long long sid = (long long)blk * FPB + slot;
+            const long long clip = sid / a.strips_per_clip;
+            const int strip = (int)(sid % a.strips_per_clip);
+            const bool last = strip == a.strips_per_clip - 1;
+            const int t0 = strip * a.strip_frames;
+            int t1 = t0 + a.strip_frames;
+            if (t1 > a.n_used) t1 = a.n_used;
+            const int t = t0 - a.warm_frames + j;
+            const long long write_lo = (long long)t0 * a.hop;
+            const long long write_hi = last ? (long long)0x7fffffffffffffffLL : (long long)t1 * a.hop;
+            if (clip < a.batch) istft_ola_step<Cfg>(a, clip, t, t >= 0 && t < t1, write_lo, write_hi, j & 1, tf, lds_sub(lds, slot * SB));
+        } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
     }
 }
 

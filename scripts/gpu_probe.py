@@ -1,0 +1,69 @@
+"""Development probe (GPU box): ablation timings and variant debugging.  Not part of the product."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import torch
+
+import bench
+import librosa_amd as L
+import stft_oracle as O
+from librosa_amd import filters
+
+dev = torch.device("cuda", 0)
+ctx = L.get_context(0)
+ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+n = 22050 * 30
+batch = 256
+y = bench.make_batch(torch, batch, n, 0, dev)
+window = np.asarray(filters.get_window("hann", 2048, fftbins=True), dtype=np.float32)
+plan = ctx.stft_plan(2048, 512, window, True, "constant", np.float32)
+mel_plan = ctx.mel_plan(filters.mel(sr=22050, n_fft=2048, n_mels=128))
+T = ctx.stft_num_frames(plan, n)
+D = torch.empty((batch, T, 1025), dtype=torch.complex64, device=dev)
+M = torch.empty((batch, 128, T), dtype=torch.float32, device=dev)
+
+
+def timeit(fn, steps=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = ctx.event(), ctx.event()
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_ms(e1) / steps
+
+
+what = sys.argv[1] if len(sys.argv) > 1 else "ablate"
+if what == "ablate":
+    for variant in (0, 4):
+        ctx.set_option("variant", variant)
+        for iters in (32,):
+            ctx.set_option("stft_iters", iters)
+            for ab in (0, 1, 2, 3, 4, 5, 6, 7):
+                ctx.set_option("ablate", ab)
+                ms = timeit(lambda: ctx.stft_exec(plan, y.data_ptr(), batch, n, n, D.data_ptr()))
+                msm = timeit(lambda: ctx.melspectrogram_exec(plan, mel_plan, y.data_ptr(), batch, n, n, 2.0, M.data_ptr()))
+                print(f"variant {variant} iters {iters} ablate {ab}: stft {ms:.3f} ms ({batch * T / ms / 1e3:.1f} Mframes/s)   mel {msm:.3f} ms ({batch * T / msm / 1e3:.1f} Mframes/s)", flush=True)
+    ctx.set_option("ablate", 0)
+elif what == "variant1":
+    yh = O.config_input(1, n=44100)
+    yt = torch.from_numpy(yh).cuda()
+    ref = O.stft(yh, n_fft=2048, hop_length=512)[0]
+    for variant in (0, 1, 4):
+        ctx.set_option("variant", variant)
+        ctx.set_option("stft_iters", 1)
+        Dv = L.stft(yt, n_fft=2048, hop_length=512).cpu().numpy()[0]
+        err = np.abs(Dv - ref)
+        print("variant", variant, "max err", err.max(), "per-frame max (first 12):", np.round(err.max(axis=0)[:12], 3))
+        print("   per-bin max (bins 0..15):", np.round(err.max(axis=1)[:16], 3), " bins 1010..1024:", np.round(err.max(axis=1)[1010:], 3))
+        bad = np.argwhere(err > 1e-3 * np.abs(ref).max())
+        print("   #bad", len(bad), "of", err.size, "first bad (bin, frame):", bad[:10].tolist())

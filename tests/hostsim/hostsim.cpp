@@ -25,12 +25,15 @@ template <class T> struct StftSim {
         build_split_twiddles<Cfg>(twr.data());
         a.tw = tw.data();
         a.twr = twr.data();
-        a.frames_per_wg = a.frames_per_wg * Cfg::FPB;  // caller passes the iteration count
+        const int iters = a.frames_per_wg;  // caller passes the iteration count
+        a.frames_per_wg = iters * Cfg::FPB;
         a.wg_per_clip = (a.n_frames + a.frames_per_wg - 1) / a.frames_per_wg;
+        a.mel_tile = iters < 3 ? iters : 3;  // deliberately odd: exercises partial tiles
+        a.slot_bytes = stft_slot_bytes<Cfg>(mode, a.n_mels, a.mel_tile);
         auto& st = sim::state();
         const long long nblk = blocks * a.wg_per_clip;
         for (long long blk = 0; blk < nblk; ++blk) {
-            st.resize(stft_lds_bytes<Cfg>());
+            st.resize(Cfg::FPB * a.slot_bytes);
             Lds lds; lds.base = 0;
             if (mode == OUT_COMPLEX) stft_block<Cfg, OUT_COMPLEX>(a, (int)blk, lds);
             else if (mode == OUT_POWER) stft_block<Cfg, OUT_POWER>(a, (int)blk, lds);
@@ -38,7 +41,7 @@ template <class T> struct StftSim {
             diag[0] += st.races; diag[1] += st.uninit;
             st.races = st.uninit = 0;
         }
-        diag[2] = Cfg::NT; diag[3] = Cfg::FPB; diag[4] = Cfg::P; diag[5] = stft_lds_bytes<Cfg>();
+        diag[2] = Cfg::NT; diag[3] = Cfg::FPB; diag[4] = Cfg::P; diag[5] = Cfg::FPB * a.slot_bytes; diag[6] = Cfg::WAVE_SYNC;
     }
 };
 
@@ -54,14 +57,13 @@ template <class T> struct IstftSim {
         a.tw = tw.data();
         a.twr = twr.data();
         const int FPB = Cfg::FPB, N = Cfg::N, H = a.hop;
-        a.strip_frames = strip_groups * FPB;
+        a.strip_frames = strip_groups;  // frames per strip
         a.strips_per_clip = (a.n_used + a.strip_frames - 1) / a.strip_frames;
-        const int W = (N + H - 1) / H - 1;
-        a.warm_groups = (W + FPB - 1) / FPB;
-        const long long rem = N > H ? N - H : 0;
-        a.drain_groups = (int)((rem + (long long)FPB * H - 1) / ((long long)FPB * H));
+        a.warm_frames = (N + H - 1) / H - 1;
+        a.drain_steps = N > H ? (N - H + H - 1) / H : 0;
+        a.batch = batch;
         auto& st = sim::state();
-        const long long nblk = batch * a.strips_per_clip;
+        const long long nblk = (batch * a.strips_per_clip + FPB - 1) / FPB;
         for (long long blk = 0; blk < nblk; ++blk) {
             st.resize(istft_lds_bytes<Cfg>());
             Lds lds; lds.base = 0;
@@ -69,7 +71,7 @@ template <class T> struct IstftSim {
             diag[0] += st.races; diag[1] += st.uninit;
             st.races = st.uninit = 0;
         }
-        diag[2] = Cfg::NT; diag[3] = Cfg::FPB; diag[4] = Cfg::P; diag[5] = istft_lds_bytes<Cfg>();
+        diag[2] = Cfg::NT; diag[3] = Cfg::FPB; diag[4] = Cfg::P; diag[5] = istft_lds_bytes<Cfg>(); diag[6] = Cfg::WAVE_SYNC;
     }
 };
 

@@ -94,7 +94,7 @@ def stft(y, n_fft, hop, win, center=True, pad_mode="constant", mode=0, iters_per
             ctypes.c_int(hop), ctypes.c_int(int(center)), ctypes.c_int(PAD_MODES[pad_mode]), _p(win), ctypes.c_int(iters_per_wg), _p(out),
             ctypes.c_int(pm), ctypes.c_double(power), _p(c0), _p(ln), _p(off), _p(val), ctypes.c_int(n_mels), ctypes.c_int(variant), _p(diag))
     assert rc == 0, "unsupported n_fft for the pow2 kernels"
-    return out, dict(races=int(diag[0]), uninit=int(diag[1]), NT=int(diag[2]), FPB=int(diag[3]), P=int(diag[4]), lds=int(diag[5]))
+    return out, dict(races=int(diag[0]), uninit=int(diag[1]), NT=int(diag[2]), FPB=int(diag[3]), P=int(diag[4]), lds=int(diag[5]), wave_sync=int(diag[6]))
 
 
 def istft(D, n_fft, hop, win, wss, out_len, n_used, center=True, strip_groups=4, variant=0):
@@ -112,4 +112,4 @@ def istft(D, n_fft, hop, win, wss, out_len, n_used, center=True, strip_groups=4,
     rc = fn(ctypes.c_int(n_fft), _p(D), ctypes.c_longlong(batch), ctypes.c_int(T), ctypes.c_int(n_used), ctypes.c_int(hop), ctypes.c_int(int(center)),
             _p(ws), _p(wss), ctypes.c_double(float(np.finfo(rt).tiny)), _p(y), ctypes.c_longlong(out_len), ctypes.c_int(strip_groups), ctypes.c_int(variant), _p(diag))
     assert rc == 0
-    return y, dict(races=int(diag[0]), uninit=int(diag[1]), NT=int(diag[2]), FPB=int(diag[3]), P=int(diag[4]), lds=int(diag[5]))
+    return y, dict(races=int(diag[0]), uninit=int(diag[1]), NT=int(diag[2]), FPB=int(diag[3]), P=int(diag[4]), lds=int(diag[5]), wave_sync=int(diag[6]))

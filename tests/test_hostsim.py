@@ -38,7 +38,16 @@ def _tol(dtype):
         (2048, 512, True, "constant", 3, np.float32, 9000, 1),
         (2048, 512, True, "reflect", 1, np.float32, 9000, 2),
         (2048, 512, True, "constant", 1, np.float32, 9000, 3),
-        (2048, 511, True, "constant", 1, np.float32, 9001, 0),  # odd hop: unaligned 8-byte loads path
+        (2048, 512, True, "reflect", 5, np.float32, 9000, 4),
+        (2048, 511, True, "constant", 5, np.float32, 9001, 0),  # odd hop: unaligned sample pairs in the ring
+        (2048, 512, True, "reflect", 7, np.float32, 30000, 0),  # long slot runs: ring + prefetch, edges at both ends
+        (1024, 256, True, "edge", 6, np.float32, 9000, 0),
+        (1024, 512, True, "constant", 4, np.float32, 9000, 0),  # hop = n_fft/2: new block does not fit the prefetch registers
+        (512, 512, True, "reflect", 3, np.float32, 9000, 0),  # hop = n_fft
+        (256, 300, True, "constant", 3, np.float32, 5000, 0),  # hop > n_fft
+        (512, 100, False, "constant", 4, np.float32, 3000, 0),
+        (4096, 1000, True, "symmetric", 3, np.float32, 30000, 0),  # two waves per frame (workgroup barriers), odd-ish hop
+        (2048, 512, True, "constant", 4, np.float32, 700, 0),  # fewer frames than slots x iters
         (4096, 1024, True, "constant", 1, np.float32, 20000, 0),
         (8192, 512, True, "constant", 1, np.float32, 24687, 0),
         (16384, 4096, True, "constant", 1, np.float32, 49263, 0),
@@ -60,7 +69,7 @@ def test_stft_body(n_fft, hop, center, pad_mode, iters, dtype, n, variant):
     assert np.abs(out - ref).max() <= _tol(dtype) * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("n_fft,hop,power,n_mels,dtype,variant", [(2048, 512, 2.0, 128, np.float32, 0), (2048, 512, 2.0, 128, np.float32, 1), (1024, 256, 1.0, 40, np.float32, 0),
+@pytest.mark.parametrize("n_fft,hop,power,n_mels,dtype,variant", [(2048, 512, 2.0, 128, np.float32, 0), (2048, 512, 2.0, 128, np.float32, 1), (2048, 512, 2.0, 128, np.float32, 4), (1024, 256, 1.0, 40, np.float32, 0),
                                                           (512, 128, 1.5, 20, np.float32, 0), (2048, 512, 2.0, 64, np.float64, 0)])
 def test_power_and_mel_body(n_fft, hop, power, n_mels, dtype, variant):
     rng = np.random.default_rng(7)
@@ -106,6 +115,7 @@ def _istft_inputs(y, n_fft, hop, center, length, window="hann", win_length=None)
         (2048, 512, 22050, True, "n", np.float32, 2, "hann", None, 0),
         (2048, 512, 22050, True, None, np.float32, 3, "hann", None, 1),
         (2048, 512, 9000, True, "n", np.float32, 1, "hann", None, 3),
+        (2048, 512, 9000, True, "n", np.float32, 5, "hann", None, 4),
         (1024, 256, 9000, False, None, np.float32, 2, "hann", None, 0),
         (512, 128, 5000, True, 4000, np.float32, 2, "hann", None, 0),
         (512, 128, 5000, True, 6000, np.float32, 2, "hann", None, 0),  # length beyond the frames: zero tail
