@@ -169,7 +169,7 @@ def main():
                 print(f"[sweep] variant={variant} iters={iters:2d}  mel {fm / 1e6:8.1f} Mframes/s ({fm * BYTES_PER_FRAME_MEL / 1e9:7.0f} GB/s)   "
                       f"stft {fs / 1e6:8.1f} Mframes/s ({fs * BYTES_PER_FRAME_STFT / 1e9:7.0f} GB/s = {fs * BYTES_PER_FRAME_STFT / 1e9 / HBM_PEAK_GBS:.1%} of HBM peak)",
                       file=sys.stderr, flush=True)
-        ctx.set_option("variant", args.variant or 0)
+        ctx.set_option("variant", args.variant if args.variant is not None else -1)
         ctx.set_option("stft_iters", args.iters or 0)
 
     wall, ev = timed(step_mel, args.steps, args.warmup)

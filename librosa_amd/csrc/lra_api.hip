@@ -21,6 +21,7 @@
 
 #include "../../include/librosa_amd.h"
 #include "lra_dispatch.h"
+#include "lra_mel.h"
 
 using namespace lra;
 
@@ -59,9 +60,9 @@ struct lra_ctx {
     int n_cu = 256;
     int opt_stft_iters = 0;          // 0 = auto
     int opt_istft_strip_groups = 0;  // 0 = auto
-    int opt_variant = 0;             // kernel tuning variant (f32 n_fft = 2048 only)
+    int opt_variant = -1;            // kernel tuning variant (f32 n_fft = 2048 only); -1 = per-mode default
     int opt_mel_tile = 0;            // frames staged per mel row before a flush (0 = auto)
-    int opt_ablate = 0;              // development aid, see StftArgs::ablate
+    int opt_generic_mel = 0;         // force the generic banded mel path (tests)
     unsigned int* d_flag = nullptr;  // non-finite input flag (device)
     std::string name;
 };
@@ -143,6 +144,11 @@ struct lra_mel_plan {
     int* d_len = nullptr;
     int* d_off = nullptr;
     void* d_val = nullptr;
+    // two-slope form (lra_mel.h); two_slope == false -> only the generic banded path is available
+    bool two_slope = false;
+    void* d_wA = nullptr;
+    void* d_wB = nullptr;
+    int* d_rng = nullptr;
 };
 
 struct lra_istft_plan {
@@ -160,17 +166,33 @@ struct lra_istft_plan {
 // ------------------------------------------------------------------------------------------------
 // kernels: fused power-of-two path
 // ------------------------------------------------------------------------------------------------
-template <class Cfg, int MODE> __global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void stft_kernel(const StftArgs<typename Cfg::real> a) {
+// The PCM input and the output travel as separate __restrict__ kernel parameters (not only inside the
+// argument struct): without the noalias guarantee hipcc must assume that the next frame's sample
+// loads may read what the previous frame's spectrum stores wrote, and -- because loads may overtake
+// stores in the vector memory pipeline -- it then parks the wave on s_waitcnt vmcnt(0) at the top of
+// every frame until all of its stores have landed in L2, serialising FFT and store traffic.
+template <class Cfg, int MODE>
+__global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void stft_kernel(StftArgs<typename Cfg::real> a, const typename Cfg::real* __restrict__ y,
+                                                                     void* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char lra_smem[];
     Lds lds;
     lds.base = lra_smem;
+    a.y = y;
+    a.D = static_cast<typename Cfg::cplx*>(out);
+    a.S = static_cast<typename Cfg::real*>(out);
+    a.Mel = static_cast<typename Cfg::real*>(out);
     stft_block<Cfg, MODE>(a, (int)blockIdx.x, lds);
 }
 
-template <class Cfg> __global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void istft_kernel(const IstftArgs<typename Cfg::real> a) {
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void istft_kernel(IstftArgs<typename Cfg::real> a, const typename Cfg::cplx* __restrict__ D,
+                                                                      const typename Cfg::real* __restrict__ wss, typename Cfg::real* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) char lra_smem[];
     Lds lds;
     lds.base = lra_smem;
+    a.D = D;
+    a.wss = wss;
+    a.y = y;
     istft_block<Cfg>(a, (int)blockIdx.x, lds);
 }
 
@@ -183,34 +205,59 @@ template <class T> struct StftLaunch {
     int iters_opt = 0;  // 0 = auto
     int mel_tile_opt = 0;
     int n_cu = 256;
+    void* out = nullptr;
     hipStream_t stream = nullptr;
     hipError_t err = hipSuccess;
-    template <class Cfg> void operator()() {
+
+    template <class Cfg, int MODE> void launch(int shared_bytes) {
         static_assert(Cfg::P <= 4, "at most four Stockham passes are wired up");
-        // frames per slot: a slot pays n_fft - hop extra sample loads for its first frame, so long runs
-        // are cheap in HBM traffic; but keep >= ~4 workgroups per CU in the launch for load balance
+        // Frames per slot.  A slot pays n_fft - hop extra sample loads for its first frame, so long runs
+        // are cheap in HBM traffic; split each clip into equal shares of ~32 frames per slot, but keep
+        // a few workgroups per CU in the launch.
         int iters = iters_opt;
         if (iters <= 0) {
-            iters = 32;
-            while (iters > 4 && batch * ((a.n_frames + Cfg::FPB * iters - 1) / (Cfg::FPB * iters)) < 4LL * n_cu) iters /= 2;
-            while (iters > 1 && Cfg::FPB * (iters / 2) >= a.n_frames) iters /= 2;
+            int target = 32;
+            while (target > 4 && batch * ((a.n_frames + Cfg::FPB * target - 1) / (Cfg::FPB * target)) < 4LL * n_cu) target /= 2;
+            const int wgpc = (a.n_frames + Cfg::FPB * target - 1) / (Cfg::FPB * target);
+            iters = (a.n_frames + Cfg::FPB * wgpc - 1) / (Cfg::FPB * wgpc);
         }
+        if (iters < 1) iters = 1;
         a.mel_tile = mel_tile_opt > 0 ? mel_tile_opt : 4;
         if (a.mel_tile > iters) a.mel_tile = iters;
         a.frames_per_wg = Cfg::FPB * iters;
         a.wg_per_clip = (a.n_frames + a.frames_per_wg - 1) / a.frames_per_wg;
-        a.slot_bytes = stft_slot_bytes<Cfg>(mode, a.n_mels, a.mel_tile);
+        a.slot_bytes = stft_slot_bytes<Cfg>(MODE, a.n_mels, a.mel_tile);
+        a.shared_off = Cfg::FPB * a.slot_bytes;
         const long long grid = batch * a.wg_per_clip;
         if (grid > 0x7fffffffLL) { err = hipErrorInvalidConfiguration; return; }
-        const int lds = Cfg::FPB * a.slot_bytes;
+        const int lds = Cfg::FPB * a.slot_bytes + shared_bytes;
         if (lds > 160 * 1024) { err = hipErrorInvalidValue; return; }
-        void (*kern)(const StftArgs<T>) = mode == OUT_COMPLEX ? stft_kernel<Cfg, OUT_COMPLEX> : mode == OUT_POWER ? stft_kernel<Cfg, OUT_POWER> : stft_kernel<Cfg, OUT_MEL>;
+        void (*kern)(StftArgs<T>, const T*, void*) = stft_kernel<Cfg, MODE>;
         if (lds > 65536) {
             err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (err != hipSuccess) return;
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NT), lds, stream, a);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NT), lds, stream, a, a.y, out);
         err = hipGetLastError();
+    }
+
+    template <class Cfg> void operator()() {
+        if (mode == OUT_MEL2) {
+            // the two-slope mel kernel shares its filter tables across the slots of a larger workgroup
+            constexpr int MELNT = Cfg::TF <= 64 ? 512 : (2 * Cfg::TF <= 1024 ? 2 * Cfg::TF : Cfg::TF);
+            using MC = typename Cfg::template with_nt<MELNT>;
+            const int tile = mel_tile_opt > 0 ? mel_tile_opt : 4;
+            const int shared = mel2_shared_bytes<MC>(a.n_mels);
+            if (mel2_fits<MC>(a.n_mels) && MC::FPB * stft_slot_bytes<MC>(OUT_MEL2, a.n_mels, tile) + shared <= 160 * 1024) {
+                launch<MC, OUT_MEL2>(shared);
+                return;
+            }
+            launch<Cfg, OUT_MEL>(0);  // generic banded path
+            return;
+        }
+        if (mode == OUT_COMPLEX) launch<Cfg, OUT_COMPLEX>(0);
+        else if (mode == OUT_POWER) launch<Cfg, OUT_POWER>(0);
+        else launch<Cfg, OUT_MEL>(0);
     }
 };
 
@@ -232,12 +279,12 @@ template <class T> struct IstftLaunch {
         const long long grid = (batch * a.strips_per_clip + FPB - 1) / FPB;
         if (grid > 0x7fffffffLL) { err = hipErrorInvalidConfiguration; return; }
         constexpr int lds = istft_lds_bytes<Cfg>();
-        void (*kern)(const IstftArgs<T>) = istft_kernel<Cfg>;
+        void (*kern)(IstftArgs<T>, const cx<T>*, const T*, T*) = istft_kernel<Cfg>;
         if (lds > 65536) {
             err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (err != hipSuccess) return;
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NT), lds, stream, a);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NT), lds, stream, a, a.D, a.wss, a.y);
         err = hipGetLastError();
     }
 };
@@ -451,9 +498,7 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
         L.a.win = (const T*)p->d_win;
         L.a.tw = (const cx<T>*)p->d_tw[(ctx->opt_variant >= 0 && ctx->opt_variant < kNumVariants) ? ctx->opt_variant : 0];
         L.a.twr = (const cx<T>*)p->d_twr;
-        L.a.D = (cx<T>*)out;
-        L.a.S = (T*)out;
-        L.a.Mel = (T*)out;
+        L.out = out;
         L.a.power_mode = power_mode_of(power);
         L.a.power = (T)power;
         if (mel) {
@@ -462,16 +507,18 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
             L.a.mel_off = mel->d_off;
             L.a.mel_val = (const T*)mel->d_val;
             L.a.n_mels = mel->n_mels;
+            L.a.mel_wA = (const T*)mel->d_wA;
+            L.a.mel_wB = (const T*)mel->d_wB;
+            L.a.mel_rng = mel->d_rng;
         }
         L.a.nonfinite_flag = ctx->d_flag;
-        L.a.ablate = ctx->opt_ablate;
-        L.mode = mode;
+        L.mode = (mode == OUT_MEL && mel && mel->two_slope && !ctx->opt_generic_mel) ? OUT_MEL2 : mode;
         L.batch = batch;
         L.stream = ctx->stream;
         L.iters_opt = ctx->opt_stft_iters;
         L.n_cu = ctx->n_cu;
         L.mel_tile_opt = ctx->opt_mel_tile;
-        if (!dispatch_logm<T>(p->logm, ctx->opt_variant, L)) return fail(LRA_EINVAL, "unsupported power-of-two size");
+        if (!dispatch_logm<T>(p->logm, variant, L)) return fail(LRA_EINVAL, "unsupported power-of-two size");
         if (L.err != hipSuccess) return fail(LRA_EHIP, std::string("stft kernel launch: ") + hipGetErrorString(L.err));
         return LRA_OK;
     }
@@ -528,7 +575,8 @@ int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_s
         L.a.hop = p->hop;
         L.a.drop = p->center ? N / 2 : 0;
         L.a.win_scaled = (const T*)p->d_win_scaled;
-        L.a.tw = (const cx<T>*)p->d_tw[(ctx->opt_variant >= 0 && ctx->opt_variant < kNumVariants) ? ctx->opt_variant : 0];
+        const int variant = ctx->opt_variant >= 0 ? ctx->opt_variant : 0;
+        L.a.tw = (const cx<T>*)p->d_tw[variant];
         L.a.twr = (const cx<T>*)p->d_twr;
         L.a.wss = (const T*)wss;
         L.a.tiny = tinyv;
@@ -538,7 +586,7 @@ int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_s
         L.batch = batch;
         L.stream = ctx->stream;
         L.strip_frames = ctx->opt_istft_strip_groups > 0 ? ctx->opt_istft_strip_groups : 64;
-        if (!dispatch_logm<T>(p->logm, ctx->opt_variant, L)) return fail(LRA_EINVAL, "unsupported power-of-two size");
+        if (!dispatch_logm<T>(p->logm, variant, L)) return fail(LRA_EINVAL, "unsupported power-of-two size");
         if (L.err != hipSuccess) return fail(LRA_EHIP, std::string("istft kernel launch: ") + hipGetErrorString(L.err));
         return LRA_OK;
     }
@@ -649,8 +697,9 @@ int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value) {
     if (!std::strcmp(key, "stft_iters")) ctx->opt_stft_iters = value;
     else if (!std::strcmp(key, "istft_strip_groups")) ctx->opt_istft_strip_groups = value;
     else if (!std::strcmp(key, "mel_tile")) ctx->opt_mel_tile = value;
-    else if (!std::strcmp(key, "ablate")) ctx->opt_ablate = value;
-    else if (!std::strcmp(key, "variant")) ctx->opt_variant = (value >= 0 && value < kNumVariants) ? value : 0;
+    else if (!std::strcmp(key, "ablate")) (void)value;  // retired development knob, accepted and ignored
+    else if (!std::strcmp(key, "generic_mel")) ctx->opt_generic_mel = value;
+    else if (!std::strcmp(key, "variant")) ctx->opt_variant = (value >= 0 && value < kNumVariants) ? value : -1;
     else return fail(LRA_EINVAL, std::string("unknown option ") + key);
     return LRA_OK;
 }
@@ -853,6 +902,25 @@ int lra_mel_plan_create(lra_ctx* ctx, int n_mels, int n_bins, const void* basis_
     if (rc == LRA_OK) rc = upload((void**)&p->d_len, len.data(), len.size() * sizeof(int));
     if (rc == LRA_OK) rc = upload((void**)&p->d_off, off.data(), off.size() * sizeof(int));
     if (rc == LRA_OK) rc = upload(&p->d_val, vals.data(), vals.size());
+    if (rc == LRA_OK) {
+        if (dtype == LRA_F64) {
+            TwoSlope<double> ts = build_two_slope<double>((const double*)basis_host, n_mels, n_bins);
+            if (ts.ok) {
+                rc = upload(&p->d_wA, ts.wA.data(), ts.wA.size() * sizeof(double));
+                if (rc == LRA_OK) rc = upload(&p->d_wB, ts.wB.data(), ts.wB.size() * sizeof(double));
+                if (rc == LRA_OK) rc = upload((void**)&p->d_rng, ts.rng.data(), ts.rng.size() * sizeof(int));
+                p->two_slope = rc == LRA_OK;
+            }
+        } else {
+            TwoSlope<float> ts = build_two_slope<float>((const float*)basis_host, n_mels, n_bins);
+            if (ts.ok) {
+                rc = upload(&p->d_wA, ts.wA.data(), ts.wA.size() * sizeof(float));
+                if (rc == LRA_OK) rc = upload(&p->d_wB, ts.wB.data(), ts.wB.size() * sizeof(float));
+                if (rc == LRA_OK) rc = upload((void**)&p->d_rng, ts.rng.data(), ts.rng.size() * sizeof(int));
+                p->two_slope = rc == LRA_OK;
+            }
+        }
+    }
     if (rc != LRA_OK) {
         lra_mel_plan_destroy(p);
         return rc;
@@ -868,6 +936,9 @@ void lra_mel_plan_destroy(lra_mel_plan* p) {
     if (p->d_len) (void)hipFree(p->d_len);
     if (p->d_off) (void)hipFree(p->d_off);
     if (p->d_val) (void)hipFree(p->d_val);
+    if (p->d_wA) (void)hipFree(p->d_wA);
+    if (p->d_wB) (void)hipFree(p->d_wB);
+    if (p->d_rng) (void)hipFree(p->d_rng);
     delete p;
 }
 

@@ -67,6 +67,8 @@ template <int LOGM_, int LOGR_, class T_, int NTMIN_ = 256, int MINW_ = 0, bool 
     static constexpr int phys(int i) { return i + (i >> PADSHIFT); }
     static constexpr int MIN_WAVES = MINW_ > 0 ? MINW_ : 2;
     static constexpr bool HOIST = HOIST_;
+    // same transform, different workgroup size (the mel kernel shares its filter tables across slots)
+    template <int NT2> using with_nt = FftCfg<LOGM_, LOGR_, T_, NT2, MINW_, HOIST_>;
     // a frame slot (TF threads) never spans two waves: slot-private LDS traffic needs no s_barrier
     static constexpr bool WAVE_SYNC = TF <= 64;
 };

@@ -27,7 +27,7 @@
 
 namespace lra {
 
-enum OutMode : int { OUT_COMPLEX = 0, OUT_POWER = 1, OUT_MEL = 2 };
+enum OutMode : int { OUT_COMPLEX = 0, OUT_POWER = 1, OUT_MEL = 2, OUT_MEL2 = 3 };  // MEL2: two-slope filterbank (lra_mel.h)
 enum PowerMode : int { POW_ONE = 1, POW_TWO = 2, POW_GENERAL = 3 };
 
 template <class T> struct StftArgs {
@@ -60,13 +60,15 @@ template <class T> struct StftArgs {
     const int* mel_off;
     const T* mel_val;
     int n_mels;
+    // two-slope form (OUT_MEL2): bin-indexed weights and packed per-filter ranges, copied to a
+    // workgroup-shared LDS region at byte offset shared_off once per workgroup
+    const T* mel_wA;
+    const T* mel_wB;
+    const int* mel_rng;
+    int shared_off;
     // set to 1 when a frame's DC bin is not finite, i.e. (barring overflow) when some sample of the
     // frame is NaN/Inf: the device-side half of util.valid_audio (util/utils.py:305)
     unsigned int* nonfinite_flag;
-    // development aid (ctx option "ablate"): bit 0 = suppress the spectrum/mel stores, bit 1 = no PCM
-    // loads, bit 2 = skip the middle FFT passes.  Results are wrong when non-zero; used only to
-    // attribute time by subtraction (cdna_hip_programming.md 5.4 rule 17: values stay live).
-    int ablate;
 };
 
 template <class Cfg> struct FftRegs {
@@ -140,50 +142,62 @@ template <class T> LRA_HD T fetch_sample(const T* __restrict__ yb, long long p, 
     return idx >= 0 ? yb[idx] : (T)0;
 }
 
-// phase A: bring the ring up to date for frame `frame` (iteration `it` of the slot), then start the
-// prefetch of the following frame's new samples
-template <class Cfg> LRA_HD void stft_ring_update(const StftArgs<typename Cfg::real>& a, int clip, int frame, int it, int iters, int tf,
-                                                  FftRegs<Cfg>& rg, Lds ring) {
+// Ring maintenance is split in three so that the wave never has to wait for its own spectrum stores
+// (vmcnt completes in order: a wait for a prefetch load also waits for every older store):
+//   ring_fill      once per slot: all N samples of its first frame;
+//   ring_prefetch  at the START of frame t: issue the loads of frame t+1's new samples (registers);
+//   ring_advance   at the END of frame t, BEFORE frame t's stores are issued: wait for those loads
+//                  and write them into the ring (frame t's ring reads are long done).  The only
+//                  older stores still in flight at that wait are frame t-1's, a whole FFT old.
+template <class Cfg> LRA_HD void stft_ring_fill(const StftArgs<typename Cfg::real>& a, int clip, int frame, int tf, Lds ring) {
+    using T = typename Cfg::real;
+    constexpr int N = Cfg::N;
+    if (frame >= a.n_frames) return;
+    const T* __restrict__ yb = a.y + (long long)clip * a.y_stride;
+    const long long p0 = (long long)frame * a.hop;  // padded position of the frame's first sample
+    for (int i = tf; i < N; i += Cfg::TF) lds_st<T>(ring, (int)((p0 + i) & (N - 1)) * (int)sizeof(T), fetch_sample<T>(yb, p0 + i, a.pad, a.n, a.pad_mode));
+}
+
+// new samples of frame `next` = frame + 1: padded positions [next*H + N - Hn, next*H + N).
+// Only blocks that lie entirely inside the clip are prefetched (one simple, branch-free batch of
+// loads); the few blocks that touch the np.pad region are fetched directly in ring_advance.
+template <class Cfg> LRA_HD bool ring_block_prefetchable(const StftArgs<typename Cfg::real>& a, int next) {
+    constexpr int N = Cfg::N;
+    const int H = a.hop, Hn = H < N ? H : N;
+    if (4 * Hn > N || next >= a.n_frames) return false;
+    const long long g1 = (long long)next * H + (N - Hn) - a.pad;
+    return g1 >= 0 && g1 + Hn <= a.n;
+}
+
+template <class Cfg> LRA_HD void stft_ring_prefetch(const StftArgs<typename Cfg::real>& a, int clip, int next, int tf, FftRegs<Cfg>& rg) {
     using T = typename Cfg::real;
     constexpr int N = Cfg::N, NPF = FftRegs<Cfg>::NPF;
-    const int H = a.hop;
-    const int Hn = H < N ? H : N;          // samples that are new per frame
-    const bool use_pf = 4 * Hn <= N;       // they fit the prefetch registers
-    const bool active = frame < a.n_frames;
-    const T* __restrict__ yb = a.y + (long long)clip * a.y_stride;
-    const long long p0 = (long long)frame * H;  // padded position of the frame's first sample
-    if (active) {
-        if (it == 0) {
-            for (int i = tf; i < N; i += Cfg::TF) lds_st<T>(ring, (int)((p0 + i) & (N - 1)) * (int)sizeof(T), fetch_sample<T>(yb, p0 + i, a.pad, a.n, a.pad_mode));
-        } else if (use_pf) {
-            LRA_UNROLL
-            for (int c = 0; c < NPF; ++c) {
-                const int e = tf + c * Cfg::TF;
-                if (e < Hn) lds_st<T>(ring, (int)((p0 + (N - Hn) + e) & (N - 1)) * (int)sizeof(T), rg.pf[c]);
-            }
-        } else {
-            for (int e = tf; e < Hn; e += Cfg::TF) {
-                const long long p = p0 + (N - Hn) + e;
-                lds_st<T>(ring, (int)(p & (N - 1)) * (int)sizeof(T), fetch_sample<T>(yb, p, a.pad, a.n, a.pad_mode));
-            }
-        }
+    if (!ring_block_prefetchable<Cfg>(a, next)) return;
+    const int H = a.hop, Hn = H < N ? H : N;
+    const T* __restrict__ src = a.y + (long long)clip * a.y_stride + ((long long)next * H + (N - Hn) - a.pad);
+    LRA_UNROLL
+    for (int c = 0; c < NPF; ++c) {
+        const int e = tf + c * Cfg::TF;
+        // lanes beyond the block re-read its last sample (in bounds) instead of branching
+        rg.pf[c] = src[e < Hn ? e : Hn - 1];
     }
-    if (use_pf && it + 1 < iters && frame + 1 < a.n_frames) {
-        const long long p1 = p0 + H + (N - Hn);  // first new padded position of the next frame
-        const long long g1 = p1 - a.pad;
-        if (g1 >= 0 && g1 + Hn <= a.n) {  // uniform per slot: the whole block is inside the clip
-            LRA_UNROLL
-            for (int c = 0; c < NPF; ++c) {
-                const int e = tf + c * Cfg::TF;
-                rg.pf[c] = e < Hn ? ((a.ablate & 2) ? (T)(e & 7) : yb[g1 + e]) : (T)0;
-            }
-        } else {
-            LRA_UNROLL
-            for (int c = 0; c < NPF; ++c) {
-                const int e = tf + c * Cfg::TF;
-                rg.pf[c] = e < Hn ? fetch_sample<T>(yb, p1 + e, a.pad, a.n, a.pad_mode) : (T)0;
-            }
+}
+
+template <class Cfg> LRA_HD void stft_ring_advance(const StftArgs<typename Cfg::real>& a, int clip, int next, int tf, const FftRegs<Cfg>& rg, Lds ring) {
+    using T = typename Cfg::real;
+    constexpr int N = Cfg::N, NPF = FftRegs<Cfg>::NPF;
+    const int H = a.hop, Hn = H < N ? H : N;
+    if (next >= a.n_frames) return;
+    const long long p1 = (long long)next * H + (N - Hn);
+    if (ring_block_prefetchable<Cfg>(a, next)) {
+        LRA_UNROLL
+        for (int c = 0; c < NPF; ++c) {
+            const int e = tf + c * Cfg::TF;
+            if (e < Hn) lds_st<T>(ring, (int)((p1 + e) & (N - 1)) * (int)sizeof(T), rg.pf[c]);
         }
+    } else {
+        const T* __restrict__ yb = a.y + (long long)clip * a.y_stride;
+        for (int e = tf; e < Hn; e += Cfg::TF) lds_st<T>(ring, (int)((p1 + e) & (N - 1)) * (int)sizeof(T), fetch_sample<T>(yb, p1 + e, a.pad, a.n, a.pad_mode));
     }
 }
 
@@ -285,7 +299,7 @@ template <class Cfg, int MODE> LRA_HD void stft_split_store(const StftArgs<typen
             km = M - k;
         }
         if (MODE == OUT_COMPLEX) {
-            if (valid && (!(a.ablate & 1) || xk.x == (T)1.2345e30)) { a.D[row + k] = xk; a.D[row + km] = xm; }
+            if (valid) { a.D[row + k] = xk; a.D[row + km] = xm; }
         } else {
             const T pk = spec_power<T>(xk, a.power_mode, a.power), pm = spec_power<T>(xm, a.power_mode, a.power);
             if (MODE == OUT_POWER) {
@@ -335,6 +349,63 @@ template <class Cfg> LRA_HD void mel_flush_slot(const StftArgs<typename Cfg::rea
     }
 }
 
+// ---- OUT_MEL2: two-slope mel reduce ---------------------------------------------------------------
+// Layout of the workgroup-shared region: wA[M+1] | wB[M+1] | rng[2 n_mels].
+template <class Cfg> LRA_HD int mel2_shared_bytes(int n_mels) {
+    return ((2 * (Cfg::M + 1) * (int)sizeof(typename Cfg::real) + 2 * n_mels * (int)sizeof(int) + 15) / 16) * 16;
+}
+// byte offset of the per-filter partial sums inside a slot's frame area (after the power spectrum)
+template <class Cfg> constexpr int mel2_part_off() { return (((Cfg::M + 1) * (int)sizeof(typename Cfg::real) + 15) / 16) * 16; }
+template <class Cfg> inline bool mel2_fits(int n_mels) { return mel2_part_off<Cfg>() + 2 * n_mels * (int)sizeof(typename Cfg::real) <= Cfg::FRAME_BYTES; }
+
+template <class Cfg> LRA_HD void mel2_tables_to_lds(const StftArgs<typename Cfg::real>& a, int tid, Lds sh) {
+    using T = typename Cfg::real;
+    constexpr int NB = Cfg::M + 1;
+    for (int k = tid; k < NB; k += Cfg::NT) {
+        lds_st<T>(sh, k * (int)sizeof(T), a.mel_wA[k]);
+        lds_st<T>(sh, (NB + k) * (int)sizeof(T), a.mel_wB[k]);
+    }
+    for (int i = tid; i < 2 * a.n_mels; i += Cfg::NT) lds_st<int>(sh, 2 * NB * (int)sizeof(T) + i * (int)sizeof(int), a.mel_rng[i]);
+}
+
+// range sums: thread tf owns ranges tf, tf + TF, ...; one from each quarter of the bank, so the work
+// per thread is naturally balanced (short low-frequency ranges pair with long high-frequency ones)
+template <class Cfg> LRA_HD void mel2_ranges(const StftArgs<typename Cfg::real>& a, int tf, Lds fr, Lds sh) {
+    using T = typename Cfg::real;
+    constexpr int NB = Cfg::M + 1;
+    for (int rid = tf; rid < 2 * a.n_mels; rid += Cfg::TF) {
+        const int d = lds_ld<int>(sh, 2 * NB * (int)sizeof(T) + rid * (int)sizeof(int));
+        const int start = d & 0xfff, len = (d >> 12) & 0xfff, arr = (d >> 24) & 1;
+        const Lds w = lds_sub(sh, arr * NB * (int)sizeof(T));
+        // chunks of four with all LDS reads issued before the dependent FMA chain: the plain
+        // one-element loop was bound by LDS latency (2 dependent ds_reads per multiply-add)
+        T acc = (T)0;
+        for (int i0 = 0; i0 < len; i0 += 4) {
+            T wv[4], pv[4];
+            LRA_UNROLL
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = i0 + j < len;
+                const int idx = ok ? start + i0 + j : start;  // clamped: always inside the written spectrum
+                wv[j] = lds_ld<T>(w, idx * (int)sizeof(T));
+                pv[j] = lds_ld<T>(fr, idx * (int)sizeof(T));
+                if (!ok) wv[j] = (T)0;
+            }
+            LRA_UNROLL
+            for (int j = 0; j < 4; ++j) acc += wv[j] * pv[j];
+        }
+        lds_st<T>(fr, mel2_part_off<Cfg>() + rid * (int)sizeof(T), acc);
+    }
+}
+
+// mel[m] = rising part + falling part -> staging tile
+template <class Cfg> LRA_HD void mel2_combine(const StftArgs<typename Cfg::real>& a, int tf, int it, int tile, Lds fr, Lds stage) {
+    using T = typename Cfg::real;
+    for (int m = tf; m < a.n_mels; m += Cfg::TF) {
+        const T v = lds_ld<T>(fr, mel2_part_off<Cfg>() + (2 * m) * (int)sizeof(T)) + lds_ld<T>(fr, mel2_part_off<Cfg>() + (2 * m + 1) * (int)sizeof(T));
+        lds_st<T>(stage, (m * tile + it) * (int)sizeof(T), v);
+    }
+}
+
 #define LRA_MID_PASS(Cfg, p, rg, lds, tw, slot_bytes)                                                     \
     if (Cfg::P > p) {                                                                                     \
         LRA_PHASE(Cfg::NT, tid) {                                                                         \
@@ -352,7 +423,7 @@ template <class Cfg> constexpr int stft_ring_off() { return Cfg::FRAME_BYTES; }
 template <class Cfg> constexpr int stft_tile_off() { return Cfg::FRAME_BYTES + Cfg::N * (int)sizeof(typename Cfg::real); }
 template <class Cfg> inline int stft_slot_bytes(int mode, int n_mels, int tile) {
     int b = stft_tile_off<Cfg>();
-    if (mode == OUT_MEL) b += ((n_mels * tile * (int)sizeof(typename Cfg::real) + 15) / 16) * 16;
+    if (mode == OUT_MEL || mode == OUT_MEL2) b += ((n_mels * tile * (int)sizeof(typename Cfg::real) + 15) / 16) * 16;
     return b;
 }
 
@@ -368,36 +439,50 @@ template <class Cfg, int MODE> LRA_HD void stft_block(const StftArgs<typename Cf
     const int slot_bytes = a.slot_bytes;
     const int tile = a.mel_tile;
     LRA_REGS(FftRegs<Cfg>, rg, Cfg::NT);
-    LRA_PHASE(Cfg::NT, tid) { hoist_tables<Cfg>(LRA_R(rg), tid % Cfg::TF, a.win, a.tw, a.twr, false); } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+    LRA_PHASE(Cfg::NT, tid) {
+        hoist_tables<Cfg>(LRA_R(rg), tid % Cfg::TF, a.win, a.tw, a.twr, false);
+        if (MODE == OUT_MEL2) mel2_tables_to_lds<Cfg>(a, tid, lds_sub(lds, a.shared_off));
+    } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC && MODE != OUT_MEL2)  // the shared tables need a workgroup barrier, once
+    LRA_PHASE(Cfg::NT, tid) {
+        const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
+        stft_ring_fill<Cfg>(a, clip, f_first + slot * iters, tf, lds_sub(lds, slot * slot_bytes + stft_ring_off<Cfg>()));
+    } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
     for (int it = 0; it < iters; ++it) {
         if (f_first + it >= a.n_frames) break;  // slot 0 has the smallest frame index: uniform exit
         if (!Cfg::HOIST) { LRA_LAUNDER(a.win); LRA_LAUNDER(a.tw); LRA_LAUNDER(a.twr); }
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
-            stft_ring_update<Cfg>(a, clip, frame, it, iters, tf, LRA_R(rg), lds_sub(lds, slot * slot_bytes + stft_ring_off<Cfg>()));
+            const Lds sl = lds_sub(lds, slot * slot_bytes);
+            if (it + 1 < iters) stft_ring_prefetch<Cfg>(a, clip, frame + 1, tf, LRA_R(rg));
+            stft_ring_load_pass0<Cfg>(a, frame, tf, LRA_R(rg), lds_sub(sl, stft_ring_off<Cfg>()), sl);
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+        LRA_MID_PASS(Cfg, 1, rg, lds, a.tw, slot_bytes)
+        LRA_MID_PASS(Cfg, 2, rg, lds, a.tw, slot_bytes)
+        LRA_MID_PASS(Cfg, 3, rg, lds, a.tw, slot_bytes)
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
             const Lds sl = lds_sub(lds, slot * slot_bytes);
-            stft_ring_load_pass0<Cfg>(a, frame, tf, LRA_R(rg), lds_sub(sl, stft_ring_off<Cfg>()), sl);
-        } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
-        if (!(a.ablate & 4)) {
-            LRA_MID_PASS(Cfg, 1, rg, lds, a.tw, slot_bytes)
-            LRA_MID_PASS(Cfg, 2, rg, lds, a.tw, slot_bytes)
-            LRA_MID_PASS(Cfg, 3, rg, lds, a.tw, slot_bytes)
-        }
-        LRA_PHASE(Cfg::NT, tid) {
-            split_read<Cfg>(LRA_R(rg), lds_sub(lds, (tid / Cfg::TF) * slot_bytes), tid % Cfg::TF);
+            split_read<Cfg>(LRA_R(rg), sl, tf);
+            if (it + 1 < iters) stft_ring_advance<Cfg>(a, clip, frame + 1, tf, LRA_R(rg), lds_sub(sl, stft_ring_off<Cfg>()));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
             stft_split_store<Cfg, MODE>(a, clip, frame, frame < a.n_frames, tf, LRA_R(rg), lds_sub(lds, slot * slot_bytes));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
-        if (MODE == OUT_MEL) {
+        if (MODE == OUT_MEL2) {
+            LRA_PHASE(Cfg::NT, tid) {
+                const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
+                if (frame < a.n_frames) mel2_ranges<Cfg>(a, tf, lds_sub(lds, slot * slot_bytes), lds_sub(lds, a.shared_off));
+            } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+        }
+        if (MODE == OUT_MEL || MODE == OUT_MEL2) {
             LRA_PHASE(Cfg::NT, tid) {
                 const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
                 const Lds sl = lds_sub(lds, slot * slot_bytes);
-                if (frame < a.n_frames) mel_reduce_slot<Cfg>(a, tf, it % tile, tile, sl, lds_sub(sl, stft_tile_off<Cfg>()));
+                if (frame < a.n_frames) {
+                    if (MODE == OUT_MEL2) mel2_combine<Cfg>(a, tf, it % tile, tile, sl, lds_sub(sl, stft_tile_off<Cfg>()));
+                    else mel_reduce_slot<Cfg>(a, tf, it % tile, tile, sl, lds_sub(sl, stft_tile_off<Cfg>()));
+                }
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
             if ((it + 1) % tile == 0 || it + 1 == iters || f_first + it + 1 >= a.n_frames) {
                 LRA_PHASE(Cfg::NT, tid) {

@@ -7,6 +7,7 @@
 // linked into, imported by, or used as a fallback for the product library.
 #define LRA_HOSTSIM 1
 #include "../../librosa_amd/csrc/lra_dispatch.h"
+#include "../../librosa_amd/csrc/lra_mel.h"
 
 #include <vector>
 
@@ -19,29 +20,41 @@ template <class T> struct StftSim {
     int mode;
     long long blocks;
     long long* diag;
-    template <class Cfg> void operator()() {
+    const T* dense_basis = nullptr;  // mode 3: dense [n_mels][M+1]
+    template <class Cfg, int MODE> void run(int iters, int shared_bytes) {
         std::vector<cx<T>> tw(Cfg::TW_TOTAL), twr(Cfg::M / 2 + 1);
         build_pass_twiddles<Cfg>(tw.data());
         build_split_twiddles<Cfg>(twr.data());
         a.tw = tw.data();
         a.twr = twr.data();
-        const int iters = a.frames_per_wg;  // caller passes the iteration count
         a.frames_per_wg = iters * Cfg::FPB;
         a.wg_per_clip = (a.n_frames + a.frames_per_wg - 1) / a.frames_per_wg;
         a.mel_tile = iters < 3 ? iters : 3;  // deliberately odd: exercises partial tiles
-        a.slot_bytes = stft_slot_bytes<Cfg>(mode, a.n_mels, a.mel_tile);
+        a.slot_bytes = stft_slot_bytes<Cfg>(MODE, a.n_mels, a.mel_tile);
+        a.shared_off = Cfg::FPB * a.slot_bytes;
         auto& st = sim::state();
         const long long nblk = blocks * a.wg_per_clip;
         for (long long blk = 0; blk < nblk; ++blk) {
-            st.resize(Cfg::FPB * a.slot_bytes);
+            st.resize(Cfg::FPB * a.slot_bytes + shared_bytes);
             Lds lds; lds.base = 0;
-            if (mode == OUT_COMPLEX) stft_block<Cfg, OUT_COMPLEX>(a, (int)blk, lds);
-            else if (mode == OUT_POWER) stft_block<Cfg, OUT_POWER>(a, (int)blk, lds);
-            else stft_block<Cfg, OUT_MEL>(a, (int)blk, lds);
+            stft_block<Cfg, MODE>(a, (int)blk, lds);
             diag[0] += st.races; diag[1] += st.uninit;
             st.races = st.uninit = 0;
         }
-        diag[2] = Cfg::NT; diag[3] = Cfg::FPB; diag[4] = Cfg::P; diag[5] = Cfg::FPB * a.slot_bytes; diag[6] = Cfg::WAVE_SYNC;
+        diag[2] = Cfg::NT; diag[3] = Cfg::FPB; diag[4] = Cfg::P; diag[5] = Cfg::FPB * a.slot_bytes + shared_bytes; diag[6] = Cfg::WAVE_SYNC;
+    }
+    template <class Cfg> void operator()() {
+        const int iters = a.frames_per_wg;  // caller passes the iteration count
+        if (mode == OUT_MEL2) {
+            constexpr int MELNT = Cfg::TF <= 64 ? 512 : (2 * Cfg::TF <= 1024 ? 2 * Cfg::TF : Cfg::TF);
+            using MC = typename Cfg::template with_nt<MELNT>;
+            TwoSlope<T> ts = build_two_slope<T>(dense_basis, a.n_mels, Cfg::M + 1);
+            if (!ts.ok || !mel2_fits<MC>(a.n_mels)) { diag[7] = 1; return; }
+            a.mel_wA = ts.wA.data(); a.mel_wB = ts.wB.data(); a.mel_rng = ts.rng.data();
+            run<MC, OUT_MEL2>(iters, mel2_shared_bytes<MC>(a.n_mels));
+        } else if (mode == OUT_COMPLEX) run<Cfg, OUT_COMPLEX>(iters, 0);
+        else if (mode == OUT_POWER) run<Cfg, OUT_POWER>(iters, 0);
+        else run<Cfg, OUT_MEL>(iters, 0);
     }
 };
 
@@ -78,7 +91,7 @@ template <class T> struct IstftSim {
 template <class T>
 int run_stft(int n_fft, int mode, const T* y, long long n, long long batch, int n_frames, int hop, int center, int pad_mode, const T* win,
              int iters_per_wg, void* out, int power_mode, double power, const int* mel_c0, const int* mel_len, const int* mel_off, const T* mel_val,
-             int n_mels, int variant, long long* diag) {
+             int n_mels, int variant, const T* dense_basis, long long* diag) {
     if (!pow2_supported(n_fft, sizeof(T) == 8)) return 1;
     StftSim<T> s;
     s.a = StftArgs<T>();
@@ -87,7 +100,7 @@ int run_stft(int n_fft, int mode, const T* y, long long n, long long batch, int 
     s.a.D = (cx<T>*)out; s.a.S = (T*)out; s.a.Mel = (T*)out;
     s.a.power_mode = power_mode; s.a.power = (T)power;
     s.a.mel_c0 = mel_c0; s.a.mel_len = mel_len; s.a.mel_off = mel_off; s.a.mel_val = mel_val; s.a.n_mels = n_mels;
-    s.mode = mode; s.blocks = batch; s.diag = diag;
+    s.mode = mode; s.blocks = batch; s.diag = diag; s.dense_basis = dense_basis;
     for (int i = 0; i < 8; ++i) diag[i] = 0;
     return dispatch_logm<T>(log2_exact(n_fft) - 1, variant, s) ? 0 : 1;
 }
@@ -112,13 +125,13 @@ int run_istft(int n_fft, const T* D /* interleaved complex [batch][T][M+1] */, l
 extern "C" {
 int hostsim_stft_f32(int n_fft, int mode, const float* y, long long n, long long batch, int n_frames, int hop, int center, int pad_mode,
                      const float* win, int iters_per_wg, void* out, int power_mode, double power, const int* mel_c0, const int* mel_len,
-                     const int* mel_off, const float* mel_val, int n_mels, int variant, long long* diag) {
-    return run_stft<float>(n_fft, mode, y, n, batch, n_frames, hop, center, pad_mode, win, iters_per_wg, out, power_mode, power, mel_c0, mel_len, mel_off, mel_val, n_mels, variant, diag);
+                     const int* mel_off, const float* mel_val, int n_mels, int variant, const float* dense_basis, long long* diag) {
+    return run_stft<float>(n_fft, mode, y, n, batch, n_frames, hop, center, pad_mode, win, iters_per_wg, out, power_mode, power, mel_c0, mel_len, mel_off, mel_val, n_mels, variant, dense_basis, diag);
 }
 int hostsim_stft_f64(int n_fft, int mode, const double* y, long long n, long long batch, int n_frames, int hop, int center, int pad_mode,
                      const double* win, int iters_per_wg, void* out, int power_mode, double power, const int* mel_c0, const int* mel_len,
-                     const int* mel_off, const double* mel_val, int n_mels, int variant, long long* diag) {
-    return run_stft<double>(n_fft, mode, y, n, batch, n_frames, hop, center, pad_mode, win, iters_per_wg, out, power_mode, power, mel_c0, mel_len, mel_off, mel_val, n_mels, variant, diag);
+                     const int* mel_off, const double* mel_val, int n_mels, int variant, const double* dense_basis, long long* diag) {
+    return run_stft<double>(n_fft, mode, y, n, batch, n_frames, hop, center, pad_mode, win, iters_per_wg, out, power_mode, power, mel_c0, mel_len, mel_off, mel_val, n_mels, variant, dense_basis, diag);
 }
 int hostsim_istft_f32(int n_fft, const float* D, long long batch, int n_frames_total, int n_used, int hop, int center, const float* win_scaled,
                       const float* wss, double tiny, float* y, long long out_len, int strip_groups, int variant, long long* diag) {

@@ -66,7 +66,8 @@ def mel_band(B):
 
 
 def stft(y, n_fft, hop, win, center=True, pad_mode="constant", mode=0, iters_per_wg=1, power=2.0, mel_basis=None, variant=0):
-    """y: (batch, n) f32/f64.  mode 0 -> complex (batch, T, M+1); 1 -> power; 2 -> mel (batch, n_mels, T)."""
+    """y: (batch, n) f32/f64.  mode 0 -> complex (batch, T, M+1); 1 -> power; 2 / 3 -> mel (batch, n_mels, T)
+    through the generic banded path / the two-slope path."""
     y = np.ascontiguousarray(y)
     assert y.ndim == 2
     f64 = y.dtype == np.float64
@@ -78,22 +79,24 @@ def stft(y, n_fft, hop, win, center=True, pad_mode="constant", mode=0, iters_per
     M = n_fft // 2
     win = np.ascontiguousarray(win, dtype=y.dtype)
     pm = 2 if power == 2.0 else (1 if power == 1.0 else 3)
-    c0 = ln = off = val = None
+    c0 = ln = off = val = dense = None
     n_mels = 0
     if mode == 0:
         out = np.full((batch, n_frames, M + 1), np.nan, dtype=np.complex128 if f64 else np.complex64)
     elif mode == 1:
         out = np.full((batch, n_frames, M + 1), np.nan, dtype=y.dtype)
     else:
-        c0, ln, off, val = mel_band(np.asarray(mel_basis, dtype=y.dtype))
+        dense = np.ascontiguousarray(mel_basis, dtype=y.dtype)
+        c0, ln, off, val = mel_band(dense)
         n_mels = mel_basis.shape[0]
         out = np.full((batch, n_mels, n_frames), np.nan, dtype=y.dtype)
     diag = np.zeros(8, np.int64)
     fn = lib().hostsim_stft_f64 if f64 else lib().hostsim_stft_f32
     rc = fn(ctypes.c_int(n_fft), ctypes.c_int(mode), _p(y), ctypes.c_longlong(n), ctypes.c_longlong(batch), ctypes.c_int(n_frames),
             ctypes.c_int(hop), ctypes.c_int(int(center)), ctypes.c_int(PAD_MODES[pad_mode]), _p(win), ctypes.c_int(iters_per_wg), _p(out),
-            ctypes.c_int(pm), ctypes.c_double(power), _p(c0), _p(ln), _p(off), _p(val), ctypes.c_int(n_mels), ctypes.c_int(variant), _p(diag))
+            ctypes.c_int(pm), ctypes.c_double(power), _p(c0), _p(ln), _p(off), _p(val), ctypes.c_int(n_mels), ctypes.c_int(variant), _p(dense), _p(diag))
     assert rc == 0, "unsupported n_fft for the pow2 kernels"
+    assert diag[7] == 0, "two-slope mel form not applicable"
     return out, dict(races=int(diag[0]), uninit=int(diag[1]), NT=int(diag[2]), FPB=int(diag[3]), P=int(diag[4]), lds=int(diag[5]), wave_sync=int(diag[6]))
 
 

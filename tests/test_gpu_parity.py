@@ -297,7 +297,7 @@ def test_tuning_variants_agree(L):
                 if not np.abs(yy - yh).max() <= 2e-5:
                     bad.append((v, iters, "istft", float(np.abs(yy - yh).max())))
     finally:
-        ctx.set_option("variant", 0)
+        ctx.set_option("variant", -1)
         ctx.set_option("stft_iters", 0)
     assert not bad, bad
 

@@ -84,6 +84,10 @@ def test_power_and_mel_body(n_fft, hop, power, n_mels, dtype, variant):
     _check_diag(d)
     Mref = O.melspectrogram(y=y, sr=22050, n_fft=n_fft, hop_length=hop, power=power, n_mels=n_mels, dtype=dtype)
     assert Mo.shape == Mref.shape
+    # two-slope path (shared filter tables, larger workgroup)
+    M2, d2 = H.stft(y, n_fft, hop, win, mode=3, power=power, mel_basis=B, iters_per_wg=5, variant=variant)
+    _check_diag(d2)
+    assert np.all(np.abs(M2 - Mref) <= 1e-5 * np.abs(Mref) + 1e-5 * Mref.max())
     # mel parity bar |d| <= 1e-4 |ref| + 1e-4 max|ref|; the f32 pipeline is ~100x inside it
     assert np.all(np.abs(Mo - Mref) <= 1e-5 * np.abs(Mref) + 1e-5 * Mref.max())
 
