@@ -496,7 +496,10 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
         L.a.pad = p->center ? p->n_fft / 2 : 0;
         L.a.pad_mode = p->pad_mode;
         L.a.win = (const T*)p->d_win;
-        L.a.tw = (const cx<T>*)p->d_tw[(ctx->opt_variant >= 0 && ctx->opt_variant < kNumVariants) ? ctx->opt_variant : 0];
+        // measured on MI355X (bench.py --sweep): the two-wave-per-frame configuration wins when the mel
+        // epilogue is fused in, the one-wave-per-frame configuration for the plain spectrum
+        const int variant = ctx->opt_variant >= 0 ? ctx->opt_variant : (mode == OUT_MEL ? 4 : 0);
+        L.a.tw = (const cx<T>*)p->d_tw[variant];
         L.a.twr = (const cx<T>*)p->d_twr;
         L.out = out;
         L.a.power_mode = power_mode_of(power);
