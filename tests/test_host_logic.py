@@ -1,0 +1,150 @@
+"""Host-side logic of the drop-in (argument validation, tables, frame bookkeeping): CPU only.
+
+Mirrors the reference's own failure tests: tests/test_core.py:295-314, 2941-2963; tests/test_failures.py:18-60;
+tests/test_filters.py:120-210; tests/test_util.py (pad_center, fix_length, tiny, dtype_r2c/c2r).
+"""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+import golden_cases
+import librosa_amd as L
+import stft_oracle as O
+from librosa_amd.core import spectrum
+from librosa_amd.util import utils as U
+
+from conftest import GOLDEN_DIR
+
+
+def test_parameter_errors_are_raised_before_any_device_work():
+    y = np.zeros(1000, dtype=np.float32)
+    with pytest.raises(L.ParameterError):
+        L.stft(y, n_fft=2048, center=False)  # tests/test_core.py:295-300
+    with pytest.raises(L.ParameterError):
+        L.stft(y, n_fft=512, pad_mode="wrap")
+    for hop in (0, -1, 2.5):
+        with pytest.raises(L.ParameterError):
+            L.stft(y, n_fft=512, hop_length=hop)
+    with pytest.raises(L.ParameterError):
+        L.stft(np.zeros(1000, dtype=np.int16))  # tests/test_failures.py: non-float audio
+    with pytest.raises(L.ParameterError):
+        L.stft(np.array([0.0, np.nan] * 500, dtype=np.float32))
+    with pytest.raises(L.ParameterError):
+        L.stft([0.0] * 1000)
+    with pytest.raises(L.ParameterError):
+        L.stft(np.float32(1.0))
+    with pytest.raises(L.ParameterError):
+        L.feature.melspectrogram(y=y, n_fft=512, norm="bogus")
+    with pytest.raises(L.ParameterError):
+        L._spectrogram(y=None, S=None)
+    with pytest.raises(L.ParameterError):
+        L.istft(np.zeros((1025, 4), dtype=np.float32))  # not complex
+    with pytest.raises(L.ParameterError):
+        L.istft(np.zeros((1025, 4), dtype=np.complex64), n_fft=1024)  # bins do not match n_fft
+    with pytest.raises(L.ParameterError):
+        L.filters.get_window(np.ones(7), 8)
+
+
+def test_spectrogram_passthrough_infers_n_fft():
+    # tests/test_core.py:1726-1772 (reference): odd n_fft inference
+    S = np.ones((378, 5), dtype=np.float32)
+    S2, n_fft = L._spectrogram(S=S, n_fft=2048)
+    assert S2 is S and n_fft == 2 * (378 - 1)
+    S3, n_fft = L._spectrogram(S=np.ones((1025, 3), np.float32), n_fft=2048)
+    assert n_fft == 2048
+
+
+@pytest.mark.parametrize("name", sorted(k for k, v in golden_cases.CASES.items() if v["mel"] is not None))
+def test_mel_basis_is_bit_identical_to_the_reference(name):
+    case = golden_cases.CASES[name]
+    g = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))
+    _, fkw = golden_cases.split_mel_kwargs(case["mel"])
+    B = L.filters.mel(sr=golden_cases.SR, n_fft=case["stft"]["n_fft"], **fkw)
+    assert B.dtype == g["mel_basis"].dtype and np.array_equal(B, g["mel_basis"])
+    assert np.array_equal(L.filters.mel_cached(sr=golden_cases.SR, n_fft=case["stft"]["n_fft"], **fkw), g["mel_basis"])
+
+
+def test_mel_scale_known_answers():
+    # tests/test_filters.py:35-98 (reference)
+    assert np.allclose(L.hz_to_mel(np.array([0, 500, 1000, 2000, 3000])), [0.0, 7.5, 15.0, 25.08188016, 30.97940199])
+    assert np.allclose(L.hz_to_mel(np.array([0, 500, 1000, 2000, 3000]), htk=True), [0.0, 607.44591966, 999.98553714, 1521.35955416, 1876.45406012])
+    assert np.allclose(L.mel_to_hz(np.array([0, 5, 10, 15, 25, 30])), [0.0, 333.33333333, 666.66666667, 1000.0, 1988.77281813, 2804.64413074])
+    assert np.isclose(L.hz_to_mel(2000.0), 25.08188016) and np.isclose(L.mel_to_hz(25.0), 1988.77281813)
+    f = L.fft_frequencies(sr=22050, n_fft=2048)
+    assert f[0] == 0 and f[-1] == 11025.0 and len(f) == 1025
+
+
+def test_empty_filter_warning():
+    # tests/test_filters.py:195-210 (reference): this configuration has empty filters
+    kw = dict(sr=44100, n_fft=1024, n_mels=128, fmin=0, fmax=2000, htk=True)
+    with pytest.warns(UserWarning, match="Empty filters"):
+        L.filters.mel(**kw)
+    with pytest.warns(UserWarning, match="Empty filters"):
+        L.filters.mel_cached(**kw)
+    with pytest.warns(UserWarning, match="Empty filters"):
+        L.filters.mel_cached(**kw)  # the memoised path re-emits the warning
+
+
+def test_window_sumsquare_and_window_match_the_oracle():
+    for hop, n_fft, wl, win in ((512, 2048, None, "hann"), (100, 512, 400, "hann"), (256, 1024, None, "blackmanharris"), (300, 256, None, "hann")):
+        a = L.filters.window_sumsquare(window=win, n_frames=23, hop_length=hop, n_fft=n_fft, win_length=wl)
+        b = O.window_sumsquare(window=win, n_frames=23, hop_length=hop, n_fft=n_fft, win_length=wl)
+        assert a.dtype == b.dtype and np.array_equal(a, b)
+    assert np.array_equal(L.filters.get_window("hann", 2048), O.get_window("hann", 2048))
+    assert np.array_equal(L.filters.get_window(("kaiser", 4.0), 100), O.get_window(("kaiser", 4.0), 100))
+    assert np.array_equal(L.filters.get_window(lambda n: np.ones(n), 16), np.ones(16))
+
+
+def test_util_helpers():
+    assert np.array_equal(U.pad_center(np.ones(5), size=10), np.pad(np.ones(5), (2, 3)))
+    with pytest.raises(L.ParameterError):
+        U.pad_center(np.ones(5), size=4)
+    assert U.fix_length(np.arange(5), size=3).tolist() == [0, 1, 2] and U.fix_length(np.arange(3), size=5).tolist() == [0, 1, 2, 0, 0]
+    assert U.tiny(np.float32(1)) == np.finfo(np.float32).tiny and U.tiny(np.complex128(1)) == np.finfo(np.float64).tiny and U.tiny(5) == np.finfo(np.float32).tiny
+    assert U.dtype_r2c(np.float32) == np.complex64 and U.dtype_r2c(np.float64) == np.complex128 and U.dtype_r2c(np.float16) == np.complex64
+    assert U.dtype_c2r(np.complex64) == np.float32 and U.dtype_c2r(np.complex128) == np.float64 and U.dtype_c2r(np.float32) == np.float32
+    assert U.is_positive_int(3) and not U.is_positive_int(0) and not U.is_positive_int(2.0) and not U.is_positive_int(None)
+    assert U.valid_audio(np.zeros(4, np.float64))
+
+
+@pytest.mark.parametrize("n_fft,hop,center,T,length", [(2048, 512, True, 1292, 661500), (2048, 512, True, 1292, None), (512, 128, True, 40, 4000),
+                                                        (1024, 256, False, 32, None), (512, 100, True, 51, 5000), (256, 300, True, 17, None)])
+def test_istft_frame_bookkeeping_matches_the_oracle(n_fft, hop, center, T, length):
+    n_frames, n_used, expected = spectrum._istft_frame_counts(T, n_fft, hop, center, length)
+    D = np.zeros((1 + n_fft // 2, T), dtype=np.complex64)
+    ref = O.istft(D, hop_length=hop, n_fft=n_fft, center=center, length=length)
+    assert expected == ref.shape[-1]
+    assert n_used >= n_frames and n_used <= T
+
+
+def test_finite_check_coverage_rule():
+    """The in-kernel non-finite flag only sees samples that lie in some frame."""
+    f = spectrum._finite_check_covers_input
+
+    def brute(n, n_fft, hop, center):
+        pad = n_fft // 2 if center else 0
+        T = 1 + (n + 2 * pad - n_fft) // hop
+        seen = np.zeros(n + 2 * pad, bool)
+        for t in range(T):
+            seen[t * hop : t * hop + n_fft] = True
+        return bool(seen[pad : pad + n].all())
+
+    for args in ((661500, 2048, 512, True), (10000, 2048, 2048, True), (10000, 512, 128, False), (10000, 256, 300, True), (4096, 1024, 256, True),
+                 (5000, 512, 100, False), (5120, 512, 512, False)):
+        assert f(*args) == brute(*args), args
+
+
+def test_shard_ranges():
+    from librosa_amd.distributed import shard_range, shard_sizes
+
+    for n, w in ((4096, 8), (256, 1), (10, 3), (5, 8)):
+        covered = []
+        for r in range(w):
+            b, e = shard_range(n, r, w)
+            covered.extend(range(b, e))
+        assert covered == list(range(n))
+        assert sum(shard_sizes(n, w)) == n and max(shard_sizes(n, w)) - min(shard_sizes(n, w)) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 3, 3)
