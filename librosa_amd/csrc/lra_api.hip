@@ -146,9 +146,12 @@ struct lra_mel_plan {
     void* d_val = nullptr;
     // two-slope form (lra_mel.h); two_slope == false -> only the generic banded path is available
     bool two_slope = false;
-    void* d_wA = nullptr;
-    void* d_wB = nullptr;
-    int* d_rng = nullptr;
+    void* d_wAB = nullptr;
+    // piece tables for runs of 8 / 16 bins per thread (index 0 / 1); n_pieces == 0 -> not available
+    int* d_run[2] = {nullptr, nullptr};
+    int* d_segd[2] = {nullptr, nullptr};
+    int nyq[2] = {0, 0};
+    int n_pieces[2] = {0, 0};
 };
 
 struct lra_istft_plan {
@@ -206,6 +209,7 @@ template <class T> struct StftLaunch {
     int mel_tile_opt = 0;
     int n_cu = 256;
     void* out = nullptr;
+    const lra_mel_plan* mel = nullptr;
     hipStream_t stream = nullptr;
     hipError_t err = hipSuccess;
 
@@ -246,9 +250,17 @@ template <class T> struct StftLaunch {
             // the two-slope mel kernel shares its filter tables across the slots of a larger workgroup
             constexpr int MELNT = Cfg::TF <= 64 ? 512 : (2 * Cfg::TF <= 1024 ? 2 * Cfg::TF : Cfg::TF);
             using MC = typename Cfg::template with_nt<MELNT>;
-            const int tile = mel_tile_opt > 0 ? mel_tile_opt : 4;
             const int shared = mel2_shared_bytes<MC>(a.n_mels);
-            if (mel2_fits<MC>(a.n_mels) && MC::FPB * stft_slot_bytes<MC>(OUT_MEL2, a.n_mels, tile) + shared <= 160 * 1024) {
+            // largest staging tile (frames per flushed mel row) that still fits the 160 KiB of LDS
+            int tile = mel_tile_opt > 0 ? mel_tile_opt : 4;
+            while (tile > 1 && MC::FPB * stft_slot_bytes<MC>(OUT_MEL2, a.n_mels, tile) + shared > 160 * 1024) tile /= 2;
+            const int pi = MC::R == 16 ? 1 : 0;
+            if (mel && mel2_fits<MC>(a.n_mels) && mel->n_pieces[pi] > 0 && mel->n_pieces[pi] <= MC::TF + a.n_mels + 2 &&
+                MC::FPB * stft_slot_bytes<MC>(OUT_MEL2, a.n_mels, tile) + shared <= 160 * 1024) {
+                a.mel_run = mel->d_run[pi];
+                a.mel_segd = mel->d_segd[pi];
+                a.mel_nyq = mel->nyq[pi];
+                mel_tile_opt = tile;
                 launch<MC, OUT_MEL2>(shared);
                 return;
             }
@@ -510,9 +522,8 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
             L.a.mel_off = mel->d_off;
             L.a.mel_val = (const T*)mel->d_val;
             L.a.n_mels = mel->n_mels;
-            L.a.mel_wA = (const T*)mel->d_wA;
-            L.a.mel_wB = (const T*)mel->d_wB;
-            L.a.mel_rng = mel->d_rng;
+            L.a.mel_wAB = (const T*)mel->d_wAB;
+            L.mel = mel;
         }
         L.a.nonfinite_flag = ctx->d_flag;
         L.mode = (mode == OUT_MEL && mel && mel->two_slope && !ctx->opt_generic_mel) ? OUT_MEL2 : mode;
@@ -909,17 +920,33 @@ int lra_mel_plan_create(lra_ctx* ctx, int n_mels, int n_bins, const void* basis_
         if (dtype == LRA_F64) {
             TwoSlope<double> ts = build_two_slope<double>((const double*)basis_host, n_mels, n_bins);
             if (ts.ok) {
-                rc = upload(&p->d_wA, ts.wA.data(), ts.wA.size() * sizeof(double));
-                if (rc == LRA_OK) rc = upload(&p->d_wB, ts.wB.data(), ts.wB.size() * sizeof(double));
-                if (rc == LRA_OK) rc = upload((void**)&p->d_rng, ts.rng.data(), ts.rng.size() * sizeof(int));
+                rc = upload(&p->d_wAB, ts.wAB.data(), ts.wAB.size() * sizeof(double));
+                for (int pi = 0; pi < 2 && rc == LRA_OK; ++pi) {
+                    const int bpl = pi == 0 ? 8 : 16;
+                    if ((n_bins - 1) % bpl) continue;
+                    MelPieces mp = build_mel_pieces<double>(ts, (n_bins - 1) / bpl, bpl);
+                    if (mp.n_pieces <= 0) continue;
+                    rc = upload((void**)&p->d_run[pi], mp.run_desc.data(), mp.run_desc.size() * sizeof(int));
+                    if (rc == LRA_OK) rc = upload((void**)&p->d_segd[pi], mp.seg_desc.data(), mp.seg_desc.size() * sizeof(int));
+                    p->nyq[pi] = mp.nyquist_piece;
+                    p->n_pieces[pi] = mp.n_pieces;
+                }
                 p->two_slope = rc == LRA_OK;
             }
         } else {
             TwoSlope<float> ts = build_two_slope<float>((const float*)basis_host, n_mels, n_bins);
             if (ts.ok) {
-                rc = upload(&p->d_wA, ts.wA.data(), ts.wA.size() * sizeof(float));
-                if (rc == LRA_OK) rc = upload(&p->d_wB, ts.wB.data(), ts.wB.size() * sizeof(float));
-                if (rc == LRA_OK) rc = upload((void**)&p->d_rng, ts.rng.data(), ts.rng.size() * sizeof(int));
+                rc = upload(&p->d_wAB, ts.wAB.data(), ts.wAB.size() * sizeof(float));
+                for (int pi = 0; pi < 2 && rc == LRA_OK; ++pi) {
+                    const int bpl = pi == 0 ? 8 : 16;
+                    if ((n_bins - 1) % bpl) continue;
+                    MelPieces mp = build_mel_pieces<float>(ts, (n_bins - 1) / bpl, bpl);
+                    if (mp.n_pieces <= 0) continue;
+                    rc = upload((void**)&p->d_run[pi], mp.run_desc.data(), mp.run_desc.size() * sizeof(int));
+                    if (rc == LRA_OK) rc = upload((void**)&p->d_segd[pi], mp.seg_desc.data(), mp.seg_desc.size() * sizeof(int));
+                    p->nyq[pi] = mp.nyquist_piece;
+                    p->n_pieces[pi] = mp.n_pieces;
+                }
                 p->two_slope = rc == LRA_OK;
             }
         }
@@ -939,9 +966,11 @@ void lra_mel_plan_destroy(lra_mel_plan* p) {
     if (p->d_len) (void)hipFree(p->d_len);
     if (p->d_off) (void)hipFree(p->d_off);
     if (p->d_val) (void)hipFree(p->d_val);
-    if (p->d_wA) (void)hipFree(p->d_wA);
-    if (p->d_wB) (void)hipFree(p->d_wB);
-    if (p->d_rng) (void)hipFree(p->d_rng);
+    if (p->d_wAB) (void)hipFree(p->d_wAB);
+    for (int pi = 0; pi < 2; ++pi) {
+        if (p->d_run[pi]) (void)hipFree(p->d_run[pi]);
+        if (p->d_segd[pi]) (void)hipFree(p->d_segd[pi]);
+    }
     delete p;
 }
 

@@ -60,11 +60,12 @@ template <class T> struct StftArgs {
     const int* mel_off;
     const T* mel_val;
     int n_mels;
-    // two-slope form (OUT_MEL2): bin-indexed weights and packed per-filter ranges, copied to a
-    // workgroup-shared LDS region at byte offset shared_off once per workgroup
-    const T* mel_wA;
-    const T* mel_wB;
-    const int* mel_rng;
+    // two-slope form (OUT_MEL2, lra_mel.h): interleaved per-bin weights (wA, wB) and the packed pair
+    // segments, copied to a workgroup-shared LDS region at byte offset shared_off once per workgroup
+    const T* mel_wAB;
+    const int* mel_run;   // [TF] run descriptors (lra_mel.h)
+    const int* mel_segd;  // [n_mels + 1] segment -> pieces
+    int mel_nyq;          // piece id of the Nyquist bin
     int shared_off;
     // set to 1 when a frame's DC bin is not finite, i.e. (barring overflow) when some sample of the
     // frame is NaN/Inf: the device-side half of util.valid_audio (util/utils.py:305)
@@ -278,7 +279,7 @@ template <class T> LRA_HD void split_pair(cx<T> zk, cx<T> zm, cx<T> w, cx<T>& xk
 
 // ---- phase: split + epilogue store (complex / power) or power -> LDS (mel) --------------------
 template <class Cfg, int MODE> LRA_HD void stft_split_store(const StftArgs<typename Cfg::real>& a, int clip, int frame, bool valid, int tf,
-                                                            FftRegs<Cfg>& rg, Lds fr) {
+                                                            FftRegs<Cfg>& rg, Lds fr, Lds sh) {
     using T = typename Cfg::real;
     using C = typename Cfg::cplx;
     constexpr int M = Cfg::M;
@@ -304,6 +305,10 @@ template <class Cfg, int MODE> LRA_HD void stft_split_store(const StftArgs<typen
             const T pk = spec_power<T>(xk, a.power_mode, a.power), pm = spec_power<T>(xm, a.power_mode, a.power);
             if (MODE == OUT_POWER) {
                 if (valid) { a.S[row + k] = pk; a.S[row + km] = pm; }
+            } else if (MODE == OUT_MEL2) {
+                const C wk = lds_ld<C>(sh, k * (int)sizeof(C)), wm = lds_ld<C>(sh, km * (int)sizeof(C));
+                lds_st<C>(fr, k * (int)sizeof(C), mk<T>(wk.x * pk, wk.y * pk));
+                lds_st<C>(fr, km * (int)sizeof(C), mk<T>(wm.x * pm, wm.y * pm));
             } else {
                 lds_st<T>(fr, k * (int)sizeof(T), pk);
                 lds_st<T>(fr, km * (int)sizeof(T), pm);
@@ -318,6 +323,9 @@ template <class Cfg, int MODE> LRA_HD void stft_split_store(const StftArgs<typen
             const T pmid = spec_power<T>(xmid, a.power_mode, a.power);
             if (MODE == OUT_POWER) {
                 if (valid) a.S[row + M / 2] = pmid;
+            } else if (MODE == OUT_MEL2) {
+                const C wq = lds_ld<C>(sh, (M / 2) * (int)sizeof(C));
+                lds_st<C>(fr, (M / 2) * (int)sizeof(C), mk<T>(wq.x * pmid, wq.y * pmid));
             } else {
                 lds_st<T>(fr, (M / 2) * (int)sizeof(T), pmid);
             }
@@ -349,60 +357,80 @@ template <class Cfg> LRA_HD void mel_flush_slot(const StftArgs<typename Cfg::rea
     }
 }
 
-// ---- OUT_MEL2: two-slope mel reduce ---------------------------------------------------------------
-// Layout of the workgroup-shared region: wA[M+1] | wB[M+1] | rng[2 n_mels].
+// ---- OUT_MEL2: two-slope mel reduce (lra_mel.h) ---------------------------------------------------
+// Shared region (per workgroup): wAB[M+1] (float2) | run_desc[TF] (int) | seg_desc[n_mels+1] (int).
+// Per slot: the frame area holds AB[k] = (wA[k] P[k], wB[k] P[k]) after the split step; the piece sums
+// live in a small extra region at the end of the slot.
 template <class Cfg> LRA_HD int mel2_shared_bytes(int n_mels) {
-    return ((2 * (Cfg::M + 1) * (int)sizeof(typename Cfg::real) + 2 * n_mels * (int)sizeof(int) + 15) / 16) * 16;
+    return ((2 * (Cfg::M + 1) * (int)sizeof(typename Cfg::real) + (Cfg::TF + n_mels + 1) * (int)sizeof(int) + 15) / 16) * 16;
 }
-// byte offset of the per-filter partial sums inside a slot's frame area (after the power spectrum)
-template <class Cfg> constexpr int mel2_part_off() { return (((Cfg::M + 1) * (int)sizeof(typename Cfg::real) + 15) / 16) * 16; }
-template <class Cfg> inline bool mel2_fits(int n_mels) { return mel2_part_off<Cfg>() + 2 * n_mels * (int)sizeof(typename Cfg::real) <= Cfg::FRAME_BYTES; }
+template <class Cfg> LRA_HD int mel2_psum_bytes(int n_mels) { return ((2 * (Cfg::TF + n_mels + 2) * (int)sizeof(typename Cfg::real) + 15) / 16) * 16; }
+template <class Cfg> inline bool mel2_fits(int) { return 2 * (Cfg::M + 1) * (int)sizeof(typename Cfg::real) <= Cfg::FRAME_BYTES && (Cfg::R == 8 || Cfg::R == 16); }
 
 template <class Cfg> LRA_HD void mel2_tables_to_lds(const StftArgs<typename Cfg::real>& a, int tid, Lds sh) {
-    using T = typename Cfg::real;
+    using C = typename Cfg::cplx;
     constexpr int NB = Cfg::M + 1;
-    for (int k = tid; k < NB; k += Cfg::NT) {
-        lds_st<T>(sh, k * (int)sizeof(T), a.mel_wA[k]);
-        lds_st<T>(sh, (NB + k) * (int)sizeof(T), a.mel_wB[k]);
-    }
-    for (int i = tid; i < 2 * a.n_mels; i += Cfg::NT) lds_st<int>(sh, 2 * NB * (int)sizeof(T) + i * (int)sizeof(int), a.mel_rng[i]);
+    const C* __restrict__ w2 = reinterpret_cast<const C*>(a.mel_wAB);
+    for (int k = tid; k < NB; k += Cfg::NT) lds_st<C>(sh, k * (int)sizeof(C), w2[k]);
+    for (int i = tid; i < Cfg::TF; i += Cfg::NT) lds_st<int>(sh, NB * (int)sizeof(C) + i * (int)sizeof(int), a.mel_run[i]);
+    for (int i = tid; i <= a.n_mels; i += Cfg::NT) lds_st<int>(sh, NB * (int)sizeof(C) + (Cfg::TF + i) * (int)sizeof(int), a.mel_segd[i]);
 }
 
-// range sums: thread tf owns ranges tf, tf + TF, ...; one from each quarter of the bank, so the work
-// per thread is naturally balanced (short low-frequency ranges pair with long high-frequency ones)
-template <class Cfg> LRA_HD void mel2_ranges(const StftArgs<typename Cfg::real>& a, int tf, Lds fr, Lds sh) {
+// piece sums: thread tf reads its run of R consecutive bins (contiguous 8R bytes, all reads issued at
+// once) and emits one (sum A, sum B) pair per segment that the run touches
+template <class Cfg> LRA_HD void mel2_gather(const StftArgs<typename Cfg::real>& a, int tf, Lds fr, Lds sh, Lds psum) {
     using T = typename Cfg::real;
-    constexpr int NB = Cfg::M + 1;
-    for (int rid = tf; rid < 2 * a.n_mels; rid += Cfg::TF) {
-        const int d = lds_ld<int>(sh, 2 * NB * (int)sizeof(T) + rid * (int)sizeof(int));
-        const int start = d & 0xfff, len = (d >> 12) & 0xfff, arr = (d >> 24) & 1;
-        const Lds w = lds_sub(sh, arr * NB * (int)sizeof(T));
-        // chunks of four with all LDS reads issued before the dependent FMA chain: the plain
-        // one-element loop was bound by LDS latency (2 dependent ds_reads per multiply-add)
-        T acc = (T)0;
-        for (int i0 = 0; i0 < len; i0 += 4) {
-            T wv[4], pv[4];
-            LRA_UNROLL
-            for (int j = 0; j < 4; ++j) {
-                const bool ok = i0 + j < len;
-                const int idx = ok ? start + i0 + j : start;  // clamped: always inside the written spectrum
-                wv[j] = lds_ld<T>(w, idx * (int)sizeof(T));
-                pv[j] = lds_ld<T>(fr, idx * (int)sizeof(T));
-                if (!ok) wv[j] = (T)0;
-            }
-            LRA_UNROLL
-            for (int j = 0; j < 4; ++j) acc += wv[j] * pv[j];
+    using C = typename Cfg::cplx;
+    constexpr int NB = Cfg::M + 1, BPL = Cfg::R;
+    const int d = lds_ld<int>(sh, NB * (int)sizeof(C) + tf * (int)sizeof(int));
+    int pid = d & 0xfff;
+    const int mask = d >> 12;
+    C v[BPL];
+    LRA_UNROLL
+    for (int j = 0; j < BPL; ++j) v[j] = lds_ld<C>(fr, (tf * BPL + j) * (int)sizeof(C));
+    C acc = mk<T>((T)0, (T)0);
+    LRA_UNROLL
+    for (int j = 0; j < BPL; ++j) {
+        acc = cadd(acc, v[j]);
+        if (j == BPL - 1 || ((mask >> j) & 1)) {
+            lds_st<C>(psum, pid * (int)sizeof(C), acc);
+            ++pid;
+            acc = mk<T>((T)0, (T)0);
         }
-        lds_st<T>(fr, mel2_part_off<Cfg>() + rid * (int)sizeof(T), acc);
     }
+    if (tf == 0) lds_st<C>(psum, a.mel_nyq * (int)sizeof(C), lds_ld<C>(fr, Cfg::M * (int)sizeof(C)));
 }
 
-// mel[m] = rising part + falling part -> staging tile
-template <class Cfg> LRA_HD void mel2_combine(const StftArgs<typename Cfg::real>& a, int tf, int it, int tile, Lds fr, Lds stage) {
+// mel[m] = rising part (B over the pieces of segment m) + falling part (A over the pieces of segment
+// m+1), pieces added in ascending bin order.  tile == 1: straight to M[clip][m][frame] (the rows of
+// consecutive frames are merged by the L2); else into the staging tile.
+template <class Cfg> LRA_HD void mel2_combine(const StftArgs<typename Cfg::real>& a, int clip, int frame, int tf, int it, int tile, Lds sh, Lds psum, Lds stage) {
     using T = typename Cfg::real;
+    using C = typename Cfg::cplx;
+    constexpr int NB = Cfg::M + 1;
     for (int m = tf; m < a.n_mels; m += Cfg::TF) {
-        const T v = lds_ld<T>(fr, mel2_part_off<Cfg>() + (2 * m) * (int)sizeof(T)) + lds_ld<T>(fr, mel2_part_off<Cfg>() + (2 * m + 1) * (int)sizeof(T));
-        lds_st<T>(stage, (m * tile + it) * (int)sizeof(T), v);
+        T part[2];
+        LRA_UNROLL
+        for (int h = 0; h < 2; ++h) {  // h = 0: B over segment m; h = 1: A over segment m + 1
+            const int d = lds_ld<int>(sh, NB * (int)sizeof(C) + (Cfg::TF + m + h) * (int)sizeof(int));
+            const int first = d & 0xfff, cnt = d >> 12;
+            T acc = (T)0;
+            for (int q0 = 0; q0 < cnt; q0 += 4) {
+                T x[4];
+                LRA_UNROLL
+                for (int q = 0; q < 4; ++q) {
+                    const bool ok = q0 + q < cnt;
+                    x[q] = lds_ld<T>(psum, ((ok ? first + q0 + q : first) * 2 + (1 - h)) * (int)sizeof(T));
+                    if (!ok) x[q] = (T)0;
+                }
+                LRA_UNROLL
+                for (int q = 0; q < 4; ++q) acc += x[q];
+            }
+            part[h] = acc;
+        }
+        const T v = part[0] + part[1];
+        if (tile == 1) a.Mel[((long long)clip * a.n_mels + m) * a.n_frames + frame] = v;
+        else lds_st<T>(stage, (m * tile + it) * (int)sizeof(T), v);
     }
 }
 
@@ -423,7 +451,8 @@ template <class Cfg> constexpr int stft_ring_off() { return Cfg::FRAME_BYTES; }
 template <class Cfg> constexpr int stft_tile_off() { return Cfg::FRAME_BYTES + Cfg::N * (int)sizeof(typename Cfg::real); }
 template <class Cfg> inline int stft_slot_bytes(int mode, int n_mels, int tile) {
     int b = stft_tile_off<Cfg>();
-    if (mode == OUT_MEL || mode == OUT_MEL2) b += ((n_mels * tile * (int)sizeof(typename Cfg::real) + 15) / 16) * 16;
+    if (mode == OUT_MEL || (mode == OUT_MEL2 && tile > 1)) b += ((n_mels * tile * (int)sizeof(typename Cfg::real) + 15) / 16) * 16;
+    if (mode == OUT_MEL2) b += mel2_psum_bytes<Cfg>(n_mels);
     return b;
 }
 
@@ -467,12 +496,13 @@ template <class Cfg, int MODE> LRA_HD void stft_block(const StftArgs<typename Cf
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
-            stft_split_store<Cfg, MODE>(a, clip, frame, frame < a.n_frames, tf, LRA_R(rg), lds_sub(lds, slot * slot_bytes));
+            stft_split_store<Cfg, MODE>(a, clip, frame, frame < a.n_frames, tf, LRA_R(rg), lds_sub(lds, slot * slot_bytes), lds_sub(lds, a.shared_off));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         if (MODE == OUT_MEL2) {
             LRA_PHASE(Cfg::NT, tid) {
                 const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
-                if (frame < a.n_frames) mel2_ranges<Cfg>(a, tf, lds_sub(lds, slot * slot_bytes), lds_sub(lds, a.shared_off));
+                const Lds sl = lds_sub(lds, slot * slot_bytes);
+                if (frame < a.n_frames) mel2_gather<Cfg>(a, tf, sl, lds_sub(lds, a.shared_off), lds_sub(sl, slot_bytes - mel2_psum_bytes<Cfg>(a.n_mels)));
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         }
         if (MODE == OUT_MEL || MODE == OUT_MEL2) {
@@ -480,11 +510,11 @@ template <class Cfg, int MODE> LRA_HD void stft_block(const StftArgs<typename Cf
                 const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
                 const Lds sl = lds_sub(lds, slot * slot_bytes);
                 if (frame < a.n_frames) {
-                    if (MODE == OUT_MEL2) mel2_combine<Cfg>(a, tf, it % tile, tile, sl, lds_sub(sl, stft_tile_off<Cfg>()));
+                    if (MODE == OUT_MEL2) mel2_combine<Cfg>(a, clip, frame, tf, it % tile, tile, lds_sub(lds, a.shared_off), lds_sub(sl, slot_bytes - mel2_psum_bytes<Cfg>(a.n_mels)), lds_sub(sl, stft_tile_off<Cfg>()));
                     else mel_reduce_slot<Cfg>(a, tf, it % tile, tile, sl, lds_sub(sl, stft_tile_off<Cfg>()));
                 }
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
-            if ((it + 1) % tile == 0 || it + 1 == iters || f_first + it + 1 >= a.n_frames) {
+            if (!(MODE == OUT_MEL2 && tile == 1) && ((it + 1) % tile == 0 || it + 1 == iters || f_first + it + 1 >= a.n_frames)) {
                 LRA_PHASE(Cfg::NT, tid) {
                     const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
                     const int f0 = f_first + slot * iters + (it / tile) * tile;  // first frame of the staged tile

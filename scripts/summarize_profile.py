@@ -1,0 +1,115 @@
+"""Turn gpurun_out/prof_<tag>/ (made by scripts/profile_round.sh on the GPU box) into the committed
+profiles/<tag>_* files: kernel stats CSV, a per-kernel counter table (markdown) and <tag>_traffic.json
+(HBM bytes per launch from FETCH_SIZE / WRITE_SIZE, read back by bench.py for roofline.traffic).
+
+FETCH_SIZE / WRITE_SIZE are in KiB-like units of 1024 B? -> rocprofv3 reports them in kilobytes
+(x1024).  On gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM);
+the run contains torch's own elementwise kernels over the 677 MB input, which are used here as the
+in-situ calibration of both counters against a known byte count.
+"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def short(name):
+    if "stft_kernel" in name:
+        import re
+        m = re.search(r">, (\d)>\(", name)
+        mode = m.group(1) if m else "?"
+        cfg = re.search(r"FftCfg<(\d+), (\d), (\w+), (\d+), (\d), (\w+)>", name)
+        tag = f" [2^{cfg.group(2)} pts/thread, NT={cfg.group(4)}]" if cfg else ""
+        return {"0": "stft_kernel<complex64 out>", "1": "stft_kernel<power out>", "2": "stft_kernel<mel, generic>", "3": "stft_kernel<mel, two-slope>"}.get(mode, "stft_kernel<?>") + tag
+    if "istft_kernel" in name:
+        return "istft_kernel"
+    return name.split("(")[0][-60:]
+
+
+def counters(sub):
+    path = os.path.join(src, sub, "r_counter_collection.csv")
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    if not os.path.exists(path):
+        return agg
+    for r in csv.DictReader(open(path)):
+        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        agg[r["Kernel_Name"]]["_dur_ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+        agg[r["Kernel_Name"]]["_vgpr"].append(float(r["VGPR_Count"]) + float(r["Accum_VGPR_Count"]))
+        agg[r["Kernel_Name"]]["_lds"].append(float(r["LDS_Block_Size"]))
+    return agg
+
+
+def mean(x):
+    return sum(x) / max(len(x), 1)
+
+
+stats_csv = os.path.join(src, "stats", "r_kernel_stats.csv")
+if os.path.exists(stats_csv):
+    shutil.copy(stats_csv, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+bench_line = {}
+bl = os.path.join(src, "bench_line.json")
+if os.path.exists(bl) and os.path.getsize(bl):
+    bench_line = json.loads(open(bl).read())
+    json.dump(bench_line, open(os.path.join(dst, f"{tag}_bench_under_rocprof.json"), "w"), indent=1)
+
+fetch, write = counters("fetch"), counters("write")
+# calibration on torch's clamp_ (reads and writes the whole 256 x 661500 f32 batch once)
+calib = {}
+known = 256 * 661500 * 4
+for k, v in fetch.items():
+    if "clamp" in k.lower() and "FETCH_SIZE" in v:
+        calib["fetch_kb_per_true_byte"] = mean(v["FETCH_SIZE"]) * 1024 / known
+for k, v in write.items():
+    if "clamp" in k.lower() and "WRITE_SIZE" in v:
+        calib["write_kb_per_true_byte"] = mean(v["WRITE_SIZE"]) * 1024 / known
+traffic = {"tag": tag, "calibration": calib, "kernels": {}}
+for k in set(list(fetch) + list(write)):
+    if "stft_kernel" not in k and "istft_kernel" not in k:
+        continue
+    f_raw = mean(fetch[k]["FETCH_SIZE"]) * 1024 if "FETCH_SIZE" in fetch.get(k, {}) else None
+    w_raw = mean(write[k]["WRITE_SIZE"]) * 1024 if "WRITE_SIZE" in write.get(k, {}) else None
+    fc = calib.get("fetch_kb_per_true_byte") or 1.0
+    wc = calib.get("write_kb_per_true_byte") or 1.0
+    traffic["kernels"][short(k)] = {
+        "fetch_bytes_raw": f_raw, "write_bytes_raw": w_raw,
+        "fetch_bytes": f_raw / fc if f_raw is not None else None, "write_bytes": w_raw / wc if w_raw is not None else None,
+        "hbm_bytes": (f_raw / fc if f_raw is not None else 0) + (w_raw / wc if w_raw is not None else 0),
+    }
+json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
+
+lines = [f"# rocprofv3 summary, round tag `{tag}`", "", "Command: `scripts/profile_round.sh` (bench.py workload: 256 clips x 30 s, n_fft=2048 hop=512 n_mels=128).", ""]
+if bench_line:
+    lines += [f"bench line under `rocprofv3 --kernel-trace --stats`: value {bench_line.get('value', 0) / 1e6:.1f} Mframes/s, "
+              f"mel kernel {bench_line.get('roofline', {}).get('launch_ms')} ms/launch, stft kernel {bench_line.get('roofline_stft', {}).get('launch_ms')} ms/launch", ""]
+if os.path.exists(stats_csv):
+    lines += ["## kernel stats (top 6 by total time)", "", "| kernel | calls | avg (us) | min (us) | max (us) | % |", "|---|---|---|---|---|---|"]
+    rows = list(csv.DictReader(open(stats_csv)))[:6]
+    for r in rows:
+        lines.append(f"| {short(r['Name'])} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['MinNs']) / 1e3:.1f} | {float(r['MaxNs']) / 1e3:.1f} | {r['Percentage']} |")
+    lines.append("")
+lines += ["## HBM traffic per launch (FETCH_SIZE / WRITE_SIZE, separate passes)", "", f"calibration on torch clamp_ over the 677.4 MB batch: {calib}", "",
+          "| kernel | FETCH raw (MB) | WRITE raw (MB) | FETCH calibrated (MB) | WRITE calibrated (MB) |", "|---|---|---|---|---|"]
+for k, v in sorted(traffic["kernels"].items()):
+    fmt = lambda x: "-" if x is None else f"{x / 1e6:.1f}"
+    lines.append(f"| {k} | {fmt(v['fetch_bytes_raw'])} | {fmt(v['write_bytes_raw'])} | {fmt(v['fetch_bytes'])} | {fmt(v['write_bytes'])} |")
+lines.append("")
+for sub in ("sq1", "sq2"):
+    agg = counters(sub)
+    keys = sorted({c for k, v in agg.items() if "stft_kernel" in k for c in v})
+    if not keys:
+        continue
+    lines += [f"## SQ counters, pass `{sub}` (mean per launch)", "", "| kernel | " + " | ".join(keys) + " |", "|---|" + "---|" * len(keys)]
+    for k, v in agg.items():
+        if "stft_kernel" in k:
+            lines.append(f"| {short(k)} | " + " | ".join(f"{mean(v[c]):.4g}" if c in v else "-" for c in keys) + " |")
+    lines.append("")
+open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))

@@ -29,7 +29,7 @@ template <class T> struct StftSim {
         a.twr = twr.data();
         a.frames_per_wg = iters * Cfg::FPB;
         a.wg_per_clip = (a.n_frames + a.frames_per_wg - 1) / a.frames_per_wg;
-        a.mel_tile = iters < 3 ? iters : 3;  // deliberately odd: exercises partial tiles
+        a.mel_tile = iters < 3 ? iters : (iters == 5 ? 1 : 3);  // odd: exercises partial tiles; iters 5 -> direct stores
         a.slot_bytes = stft_slot_bytes<Cfg>(MODE, a.n_mels, a.mel_tile);
         a.shared_off = Cfg::FPB * a.slot_bytes;
         auto& st = sim::state();
@@ -50,7 +50,9 @@ template <class T> struct StftSim {
             using MC = typename Cfg::template with_nt<MELNT>;
             TwoSlope<T> ts = build_two_slope<T>(dense_basis, a.n_mels, Cfg::M + 1);
             if (!ts.ok || !mel2_fits<MC>(a.n_mels)) { diag[7] = 1; return; }
-            a.mel_wA = ts.wA.data(); a.mel_wB = ts.wB.data(); a.mel_rng = ts.rng.data();
+            MelPieces mp = build_mel_pieces<T>(ts, MC::TF, MC::R);
+            if (mp.n_pieces <= 0 || mp.n_pieces > MC::TF + a.n_mels + 2) { diag[7] = 2; return; }
+            a.mel_wAB = ts.wAB.data(); a.mel_run = mp.run_desc.data(); a.mel_segd = mp.seg_desc.data(); a.mel_nyq = mp.nyquist_piece;
             run<MC, OUT_MEL2>(iters, mel2_shared_bytes<MC>(a.n_mels));
         } else if (mode == OUT_COMPLEX) run<Cfg, OUT_COMPLEX>(iters, 0);
         else if (mode == OUT_POWER) run<Cfg, OUT_POWER>(iters, 0);
