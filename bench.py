@@ -143,6 +143,17 @@ def main():
     def step_stft():
         ctx.stft_exec(plan, yp, batch, n, n, Dp)
 
+    # ISTFT (BASELINE config 4: stft -> istft round trip); the window sum-square comes from the host
+    iplan = ctx.istft_plan(N_FFT, HOP, window, True, np.float32)
+    wss_host = filters.window_sumsquare(window="hann", n_frames=n_frames, n_fft=N_FFT, hop_length=HOP, dtype=np.float32)[N_FFT // 2 :]
+    wss_host = np.ascontiguousarray(np.pad(wss_host, (0, max(0, n - len(wss_host))))[:n], dtype=np.float32)
+    wss = torch.from_numpy(wss_host).to(device)
+    yrec = torch.empty((batch, n), dtype=torch.float32, device=device)
+    n_bins = N_FFT // 2 + 1
+
+    def step_istft():
+        ctx.istft_exec(iplan, Dp, batch, n_frames * n_bins, n_bins, n_frames, wss.data_ptr(), yrec.data_ptr(), n, n)
+
     def timed(fn, steps, warmup):
         for _ in range(warmup):
             fn()
@@ -178,6 +189,11 @@ def main():
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
     _, ev_stft = timed(step_stft, args.steps, args.warmup)
+    _, ev_istft = timed(step_istft, args.steps, args.warmup)
+    snr_db = None
+    if rank == 0:
+        err = (y[:8] - yrec[:8]).double().pow(2).sum(dim=1)
+        snr_db = float((10 * torch.log10(y[:8].double().pow(2).sum(dim=1) / err)).min().item())
 
     if rank == 0:
         total_frames = frames_per_step * args.steps * world
@@ -210,6 +226,23 @@ def main():
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_stft / HBM_PEAK_GBS, "traffic": None,
                               "bytes_per_frame": BYTES_PER_FRAME_STFT, "launch_ms": stft_launch_s * 1e3, "frames_per_s_single_gpu": frames_per_step / stft_launch_s},
         }
+        istft_launch_s = ev_istft / args.steps
+        achieved_istft = frames_per_step * BYTES_PER_FRAME_STFT / istft_launch_s / 1e9
+        line["roofline_istft"] = {"bound": "hbm", "kernel": "istft_kernel<n_fft=2048> (librosa.istft: c2r FFT + window + overlap-add + wss normalise)", "achieved": achieved_istft,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_istft / HBM_PEAK_GBS, "traffic": None, "bytes_per_frame": BYTES_PER_FRAME_STFT,
+                                  "launch_ms": istft_launch_s * 1e3, "frames_per_s_single_gpu": frames_per_step / istft_launch_s, "round_trip_snr_db_min": snr_db}
+        # HBM bytes per launch measured with rocprofv3 PMC passes (scripts/profile_round.sh), when committed
+        try:
+            prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
+            if prof:
+                tj = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))
+                for key, needle in (("roofline", "mel"), ("roofline_stft", "complex64"), ("roofline_istft", "istft")):
+                    for kname, v in tj.get("kernels", {}).items():
+                        if needle in kname and v.get("hbm_bytes"):
+                            line[key]["traffic"] = v["hbm_bytes"]
+                            line[key]["traffic_source"] = f"profiles/{prof[-1]} ({kname})"
+        except Exception:
+            pass
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -81,6 +81,10 @@ template <class Cfg> struct FftRegs {
     // HOIST configurations: this thread's table values, loaded once before the frame loop.  (hipcc
     // does not hoist them by itself across the per-phase fences; re-reading ~52 table values per
     // frame from L2 left the waves 65 % of their time in s_waitcnt.)
+    // ISTFT: next frame's spectrum bins (X[k], X[M-k] pairs and X[M/2]) in flight during the current
+    // frame, and the current hop's finished output samples held back until that prefetch has landed
+    typename Cfg::cplx xk[Cfg::R / 2 > 0 ? Cfg::R / 2 : 1], xm[Cfg::R / 2 > 0 ? Cfg::R / 2 : 1], xmid;
+    typename Cfg::real out[NPF];
     static constexpr int NH = Cfg::HOIST ? 1 : 0;
     typename Cfg::cplx win2[NH * Cfg::R + 1 - NH];       // window pairs in pass-0 register order
     typename Cfg::cplx treg[NH * Cfg::TREG_TOTAL + 1 - NH];
@@ -557,23 +561,41 @@ template <class T> struct IstftArgs {
 template <class Cfg> constexpr int istft_slot_bytes() { return Cfg::FRAME_BYTES + 2 * Cfg::N * (int)sizeof(typename Cfg::real); }
 template <class Cfg> constexpr int istft_lds_bytes() { return Cfg::FPB * istft_slot_bytes<Cfg>(); }
 
-// ---- phase: Hermitian split of X[0..M] into conj(Z'[0..M-1]) in LDS ---------------------------
-// Z'[k] = E' + i O',  E' = X[k] + conj(X[M-k]),  O' = (X[k] - conj(X[M-k])) conj(W_N^k); the
-// imaginary parts of X[0] and X[M] are ignored, as pocketfft's c2r does (SURVEY.md 3.4).
-template <class Cfg> LRA_HD void istft_split_write(const IstftArgs<typename Cfg::real>& a, long long clip, int frame, bool valid, int tf, const FftRegs<Cfg>& rg, Lds fr) {
+// ---- spectrum prefetch: X[k], X[M-k] (k = tf + i TF) and X[M/2] of one frame -> registers ------------
+template <class Cfg> LRA_HD void istft_spec_load(const IstftArgs<typename Cfg::real>& a, long long clip, int frame, bool valid, int tf, FftRegs<Cfg>& rg) {
     using T = typename Cfg::real;
     using C = typename Cfg::cplx;
     constexpr int M = Cfg::M;
-    const C* __restrict__ X = a.D + clip * a.d_batch_stride + (long long)frame * a.d_frame_stride;
     const C zero = mk<T>((T)0, (T)0);
+    if (!valid) {
+        LRA_UNROLL
+        for (int i = 0; i < Cfg::R / 2; ++i) { rg.xk[i] = zero; rg.xm[i] = zero; }
+        rg.xmid = zero;
+        return;
+    }
+    const C* __restrict__ X = a.D + clip * a.d_batch_stride + (long long)frame * a.d_frame_stride;
+    LRA_UNROLL
+    for (int i = 0; i < Cfg::R / 2; ++i) {
+        rg.xk[i] = X[tf + i * Cfg::TF];
+        rg.xm[i] = X[M - tf - i * Cfg::TF];  // tf = 0, i = 0: X[M], the Nyquist bin
+    }
+    rg.xmid = X[M / 2];
+}
+
+// ---- phase: Hermitian split of X[0..M] into conj(Z'[0..M-1]) in LDS ---------------------------
+// Z'[k] = E' + i O',  E' = X[k] + conj(X[M-k]),  O' = (X[k] - conj(X[M-k])) conj(W_N^k); the
+// imaginary parts of X[0] and X[M] are ignored, as pocketfft's c2r does (SURVEY.md 3.4).
+template <class Cfg> LRA_HD void istft_split_write(const IstftArgs<typename Cfg::real>& a, int tf, const FftRegs<Cfg>& rg, Lds fr) {
+    using T = typename Cfg::real;
+    using C = typename Cfg::cplx;
+    constexpr int M = Cfg::M;
     LRA_UNROLL
     for (int i = 0; i < Cfg::R / 2; ++i) {
         const int k = tf + i * Cfg::TF;
+        const C xk = rg.xk[i], xm = rg.xm[i];
         if (k == 0) {
-            const C x0 = valid ? X[0] : zero, xM = valid ? X[M] : zero;
-            lds_st<C>(fr, Cfg::phys(0) * (int)sizeof(C), mk<T>(x0.x + xM.x, -(x0.x - xM.x)));
+            lds_st<C>(fr, Cfg::phys(0) * (int)sizeof(C), mk<T>(xk.x + xm.x, -(xk.x - xm.x)));
         } else {
-            const C xk = valid ? X[k] : zero, xm = valid ? X[M - k] : zero;
             const C E = mk<T>(xk.x + xm.x, xk.y - xm.y);
             const C Dif = mk<T>(xk.x - xm.x, xk.y + xm.y);
             const C O = cmul(Dif, cconj(Cfg::HOIST ? rg.twr[i] : a.twr[k]));
@@ -582,10 +604,7 @@ template <class Cfg> LRA_HD void istft_split_write(const IstftArgs<typename Cfg:
             lds_st<C>(fr, Cfg::phys(M - k) * (int)sizeof(C), mk<T>(E.x + O.y, -(O.x - E.y)));
         }
     }
-    if (tf == 0) {
-        const C xh = valid ? X[M / 2] : zero;  // Z'[M/2] = 2 conj(X[M/2]); store its conjugate
-        lds_st<C>(fr, Cfg::phys(M / 2) * (int)sizeof(C), mk<T>((T)2 * xh.x, (T)2 * xh.y));
-    }
+    if (tf == 0) lds_st<C>(fr, Cfg::phys(M / 2) * (int)sizeof(C), mk<T>((T)2 * rg.xmid.x, (T)2 * rg.xmid.y));  // conj(2 conj X[M/2])
 }
 
 // ---- phase: last pass butterflies, then windowed time-domain frame -> LDS (natural order) ------
@@ -613,10 +632,22 @@ template <class Cfg> LRA_HD void istft_last_write(const IstftArgs<typename Cfg::
 // positions are final after frame t (later frames start beyond them) and are normalised and stored,
 // the rest become the carry for frame t+1.  Contributions are therefore added in increasing frame
 // order, the reference's accumulation order (core/spectrum.py:593-603, 629-643).
-template <class Cfg> LRA_HD void istft_ola_step(const IstftArgs<typename Cfg::real>& a, long long clip, int t, bool contribute, long long write_lo,
-                                                long long write_hi, int parity, int tf, Lds slot_lds) {
+template <class Cfg> LRA_HD void istft_store_sample(const IstftArgs<typename Cfg::real>& a, long long clip, long long sp, long long write_lo, long long write_hi,
+                                                    typename Cfg::real val) {
     using T = typename Cfg::real;
-    constexpr int N = Cfg::N;
+    const long long s = sp - a.drop;
+    if (sp >= write_lo && sp < write_hi && s >= 0 && s < a.out_len) {
+        const T w = a.wss[s];
+        a.y[clip * a.y_stride + s] = (w > a.tiny) ? val / w : val;
+    }
+}
+
+// DEFER: the finished samples of this hop stay in rg.out (hop <= n_fft/4) and are stored by
+// istft_flush_out after the next frame's prefetch has been consumed.
+template <class Cfg, bool DEFER> LRA_HD void istft_ola_step(const IstftArgs<typename Cfg::real>& a, long long clip, int t, bool contribute, long long write_lo,
+                                                            long long write_hi, int parity, int tf, FftRegs<Cfg>& rg, Lds slot_lds) {
+    using T = typename Cfg::real;
+    constexpr int N = Cfg::N, NPF = FftRegs<Cfg>::NPF;
     const int H = a.hop;
     const int CL = N > H ? N - H : 0;
     const int span = N > H ? N : H;
@@ -624,26 +655,90 @@ template <class Cfg> LRA_HD void istft_ola_step(const IstftArgs<typename Cfg::re
     const Lds carry_in = lds_sub(slot_lds, Cfg::FRAME_BYTES + parity * N * (int)sizeof(T));
     const Lds carry_out = lds_sub(slot_lds, Cfg::FRAME_BYTES + (1 - parity) * N * (int)sizeof(T));
     const long long pa = (long long)t * H;
-    for (int u = tf; u < span; u += Cfg::TF) {
-        T val = (T)0;
-        if (u < CL) val = lds_ld<T>(carry_in, u * (int)sizeof(T));
-        if (contribute && u < N) val += lds_ld<T>(fr, u * (int)sizeof(T));
-        if (u < H) {
-            const long long sp = pa + u;
-            const long long s = sp - a.drop;
-            if (sp >= write_lo && sp < write_hi && s >= 0 && s < a.out_len) {
-                const T w = a.wss[s];
-                a.y[clip * a.y_stride + s] = (w > a.tiny) ? val / w : val;
+    if (DEFER) {
+        // u = tf + c TF < hop: final samples -> registers
+        LRA_UNROLL
+        for (int c = 0; c < NPF; ++c) {
+            const int u = tf + c * Cfg::TF;
+            T val = (T)0;
+            if (u < H) {
+                if (u < CL) val = lds_ld<T>(carry_in, u * (int)sizeof(T));
+                if (contribute && u < N) val += lds_ld<T>(fr, u * (int)sizeof(T));
             }
-        } else if (u - H < CL) {
-            lds_st<T>(carry_out, (u - H) * (int)sizeof(T), val);
+            rg.out[c] = val;
         }
+        // the rest becomes the carry for frame t + 1; eight positions per trip with all LDS reads issued
+        // before the first dependent add/store (a one-position loop is a chain of LDS round trips)
+        for (int u0 = tf + ((H - tf + Cfg::TF - 1) / Cfg::TF) * Cfg::TF; u0 < span; u0 += 8 * Cfg::TF) {
+            T cv[8], fv[8];
+            LRA_UNROLL
+            for (int q = 0; q < 8; ++q) {
+                const int u = u0 + q * Cfg::TF;
+                cv[q] = u < CL ? lds_ld<T>(carry_in, u * (int)sizeof(T)) : (T)0;
+                fv[q] = (contribute && u < N) ? lds_ld<T>(fr, u * (int)sizeof(T)) : (T)0;
+            }
+            LRA_UNROLL
+            for (int q = 0; q < 8; ++q) {
+                const int u = u0 + q * Cfg::TF;
+                if (u < span && u - H < CL) lds_st<T>(carry_out, (u - H) * (int)sizeof(T), cv[q] + fv[q]);
+            }
+        }
+        return;
+    }
+    for (int u0 = tf; u0 < span; u0 += 8 * Cfg::TF) {
+        T cv[8], fv[8];
+        LRA_UNROLL
+        for (int q = 0; q < 8; ++q) {
+            const int u = u0 + q * Cfg::TF;
+            cv[q] = u < CL ? lds_ld<T>(carry_in, u * (int)sizeof(T)) : (T)0;
+            fv[q] = (contribute && u < N) ? lds_ld<T>(fr, u * (int)sizeof(T)) : (T)0;
+        }
+        LRA_UNROLL
+        for (int q = 0; q < 8; ++q) {
+            const int u = u0 + q * Cfg::TF;
+            if (u >= span) continue;
+            const T val = cv[q] + fv[q];
+            if (u < H) istft_store_sample<Cfg>(a, clip, pa + u, write_lo, write_hi, val);
+            else if (u - H < CL) lds_st<T>(carry_out, (u - H) * (int)sizeof(T), val);
+        }
+    }
+}
+
+template <class Cfg> LRA_HD void istft_flush_out(const IstftArgs<typename Cfg::real>& a, long long clip, int t, long long write_lo, long long write_hi, int tf,
+                                                 const FftRegs<Cfg>& rg) {
+    constexpr int NPF = FftRegs<Cfg>::NPF;
+    const long long pa = (long long)t * a.hop;
+    LRA_UNROLL
+    for (int c = 0; c < NPF; ++c) {
+        const int u = tf + c * Cfg::TF;
+        if (u < a.hop) istft_store_sample<Cfg>(a, clip, pa + u, write_lo, write_hi, rg.out[c]);
     }
 }
 
 // One workgroup = FPB slots; slot s owns strip (blk*FPB + s) of the (clip, strip) grid and walks its
 // frames one at a time: warm-up frames (their contribution to the strip's positions), the strip's
 // own frames, and -- for the last strip of a clip -- drain steps that flush the carry.
+template <class Cfg> struct IstftSlot {
+    long long clip;
+    int t0, t1;
+    long long write_lo, write_hi;
+    bool active;
+};
+template <class Cfg> LRA_HD IstftSlot<Cfg> istft_slot(const IstftArgs<typename Cfg::real>& a, int blk, int slot) {
+    IstftSlot<Cfg> s;
+    const long long sid = (long long)blk * Cfg::FPB + slot;
+    s.clip = sid / a.strips_per_clip;
+    const int strip = (int)(sid % a.strips_per_clip);
+    s.t0 = strip * a.strip_frames;
+    s.t1 = s.t0 + a.strip_frames;
+    if (s.t1 > a.n_used) s.t1 = a.n_used;
+    s.write_lo = (long long)s.t0 * a.hop;
+    s.write_hi = strip == a.strips_per_clip - 1 ? (long long)0x7fffffffffffffffLL : (long long)s.t1 * a.hop;
+    s.active = s.clip < a.batch;
+    if (!s.active) s.clip = 0;
+    return s;
+}
+
 template <class Cfg> LRA_HD void istft_block(const IstftArgs<typename Cfg::real>& a_in, const int blk, Lds lds) {
     IstftArgs<typename Cfg::real> a = a_in;
     using T = typename Cfg::real;
@@ -653,25 +748,28 @@ template <class Cfg> LRA_HD void istft_block(const IstftArgs<typename Cfg::real>
     bool has_last = false;
     for (int s = 0; s < FPB; ++s) has_last = has_last || (((long long)blk * FPB + s) % a.strips_per_clip) == a.strips_per_clip - 1;
     const int steps = a.warm_frames + a.strip_frames + (has_last ? a.drain_steps : 0);
+    const bool defer = 4 * a.hop <= Cfg::N;  // finished samples per hop fit the hold-back registers
     LRA_REGS(FftRegs<Cfg>, rg, Cfg::NT);
     LRA_PHASE(Cfg::NT, tid) {
-        hoist_tables<Cfg>(LRA_R(rg), tid % Cfg::TF, a.win_scaled, a.tw, a.twr, true);
-        const Lds c0 = lds_sub(lds, (tid / Cfg::TF) * SB + Cfg::FRAME_BYTES);
-        for (int u = tid % Cfg::TF; u < Cfg::N; u += Cfg::TF) lds_st<T>(c0, u * (int)sizeof(T), (T)0);
+        const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
+        hoist_tables<Cfg>(LRA_R(rg), tf, a.win_scaled, a.tw, a.twr, true);
+        const Lds c0 = lds_sub(lds, slot * SB + Cfg::FRAME_BYTES);
+        for (int u = tf; u < Cfg::N; u += Cfg::TF) lds_st<T>(c0, u * (int)sizeof(T), (T)0);
+        const IstftSlot<Cfg> s = istft_slot<Cfg>(a, blk, slot);
+        const int t = s.t0 - a.warm_frames;
+        istft_spec_load<Cfg>(a, s.clip, t, s.active && t >= 0 && t < s.t1, tf, LRA_R(rg));
     } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
     for (int j = 0; j < steps; ++j) {
         if (!Cfg::HOIST) { LRA_LAUNDER(a.win_scaled); LRA_LAUNDER(a.tw); LRA_LAUNDER(a.twr); }
+        // (a) split the prefetched spectrum of frame j into LDS, (b) only now issue the held-back output
+        // stores of frame j-1, (c) start the prefetch of frame j+1: the wait in (a) never covers (b)
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
-            const long long sid = (long long)blk * FPB + slot;
-            const long long clip = sid / a.strips_per_clip;
-            const int strip = (int)(sid % a.strips_per_clip);
-            const int t0 = strip * a.strip_frames;
-            int t1 = t0 + a.strip_frames;
-            if (t1 > a.n_used) t1 = a.n_used;
-            const int t = t0 - a.warm_frames + j;
-            const bool valid = clip < a.batch && t >= 0 && t < t1;
-            istft_split_write<Cfg>(a, clip < a.batch ? clip : 0, valid ? t : 0, valid, tf, LRA_R(rg), lds_sub(lds, slot * SB));
+            const IstftSlot<Cfg> s = istft_slot<Cfg>(a, blk, slot);
+            const int t = s.t0 - a.warm_frames + j;
+            istft_split_write<Cfg>(a, tf, LRA_R(rg), lds_sub(lds, slot * SB));
+            if (defer && j > 0 && s.active) istft_flush_out<Cfg>(a, s.clip, t - 1, s.write_lo, s.write_hi, tf, LRA_R(rg));
+            if (j + 1 < steps) istft_spec_load<Cfg>(a, s.clip, t + 1, s.active && t + 1 >= 0 && t + 1 < s.t1, tf, LRA_R(rg));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         // pass 0 (no twiddles) reads from LDS here, unlike the forward kernel
         if (Cfg::P > 1) {
@@ -693,17 +791,19 @@ template <class Cfg> LRA_HD void istft_block(const IstftArgs<typename Cfg::real>
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
-            const long long sid = (long long)blk * FPB + slot;
-            const long long clip = sid / a.strips_per_clip;
-            const int strip = (int)(sid % a.strips_per_clip);
-            const bool last = strip == a.strips_per_clip - 1;
-            const int t0 = strip * a.strip_frames;
-            int t1 = t0 + a.strip_frames;
-            if (t1 > a.n_used) t1 = a.n_used;
-            const int t = t0 - a.warm_frames + j;
-            const long long write_lo = (long long)t0 * a.hop;
-            const long long write_hi = last ? (long long)0x7fffffffffffffffLL : (long long)t1 * a.hop;
-            if (clip < a.batch) istft_ola_step<Cfg>(a, clip, t, t >= 0 && t < t1, write_lo, write_hi, j & 1, tf, lds_sub(lds, slot * SB));
+            const IstftSlot<Cfg> s = istft_slot<Cfg>(a, blk, slot);
+            const int t = s.t0 - a.warm_frames + j;
+            if (s.active) {
+                if (defer) istft_ola_step<Cfg, true>(a, s.clip, t, t >= 0 && t < s.t1, s.write_lo, s.write_hi, j & 1, tf, LRA_R(rg), lds_sub(lds, slot * SB));
+                else istft_ola_step<Cfg, false>(a, s.clip, t, t >= 0 && t < s.t1, s.write_lo, s.write_hi, j & 1, tf, LRA_R(rg), lds_sub(lds, slot * SB));
+            }
+        } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+    }
+    if (defer && steps > 0) {
+        LRA_PHASE(Cfg::NT, tid) {
+            const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
+            const IstftSlot<Cfg> s = istft_slot<Cfg>(a, blk, slot);
+            if (s.active) istft_flush_out<Cfg>(a, s.clip, s.t0 - a.warm_frames + steps - 1, s.write_lo, s.write_hi, tf, LRA_R(rg));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
     }
 }
