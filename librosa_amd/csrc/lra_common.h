@@ -83,7 +83,7 @@ struct State {
     void note_read(size_t off, size_t bytes) {
         if (off + bytes > mem.size()) { std::fprintf(stderr, "hostsim: LDS read out of bounds off=%zu\n", off); std::abort(); }
         for (size_t w = off / 4; w < (off + bytes + 3) / 4; ++w) {
-            if (!ever[w]) ++uninit;
+            if (!ever[w]) { if (uninit < 4 && std::getenv("LRA_SIM_DEBUG")) std::fprintf(stderr, "hostsim: uninit read word %zu tid %d epoch %d\n", w, cur_tid, epoch); ++uninit; }
             if (w_epoch[w] == epoch && w_tid[w] != cur_tid) ++races;
             // written by another wave with no workgroup barrier in between
             if (ever[w] && w_wg[w] == wg_epoch && w_tid[w] / 64 != cur_tid / 64) ++races;

@@ -133,6 +133,9 @@ template <class T> LRA_HD T spec_power(cx<T> x, int power_mode, T power) {
     return std::pow(mag, power);
 }
 
+// slot of bin k in the (wA P, wB P) array of the mel epilogue: one pad slot per thread run of R bins
+template <class Cfg> LRA_HD int ab_slot(int k) { return k + (k >> Cfg::LOGR); }
+
 // ---- PCM ring -------------------------------------------------------------------------------------
 // Each frame slot keeps the N samples of its current frame in an LDS ring indexed by the padded
 // sample position modulo N.  A slot walks CONSECUTIVE frames, so going from frame t to t+1 only the
@@ -311,8 +314,10 @@ template <class Cfg, int MODE> LRA_HD void stft_split_store(const StftArgs<typen
                 if (valid) { a.S[row + k] = pk; a.S[row + km] = pm; }
             } else if (MODE == OUT_MEL2) {
                 const C wk = lds_ld<C>(sh, k * (int)sizeof(C)), wm = lds_ld<C>(sh, km * (int)sizeof(C));
-                lds_st<C>(fr, k * (int)sizeof(C), mk<T>(wk.x * pk, wk.y * pk));
-                lds_st<C>(fr, km * (int)sizeof(C), mk<T>(wm.x * pm, wm.y * pm));
+                // AB[k] sits at the padded slot k + k/R: a thread's run of R consecutive bins then starts
+                // R+1 slots after its neighbour's, which makes the run reads of mel2_gather conflict-free
+                lds_st<C>(fr, ab_slot<Cfg>(k) * (int)sizeof(C), mk<T>(wk.x * pk, wk.y * pk));
+                lds_st<C>(fr, ab_slot<Cfg>(km) * (int)sizeof(C), mk<T>(wm.x * pm, wm.y * pm));
             } else {
                 lds_st<T>(fr, k * (int)sizeof(T), pk);
                 lds_st<T>(fr, km * (int)sizeof(T), pm);
@@ -329,7 +334,7 @@ template <class Cfg, int MODE> LRA_HD void stft_split_store(const StftArgs<typen
                 if (valid) a.S[row + M / 2] = pmid;
             } else if (MODE == OUT_MEL2) {
                 const C wq = lds_ld<C>(sh, (M / 2) * (int)sizeof(C));
-                lds_st<C>(fr, (M / 2) * (int)sizeof(C), mk<T>(wq.x * pmid, wq.y * pmid));
+                lds_st<C>(fr, ab_slot<Cfg>(M / 2) * (int)sizeof(C), mk<T>(wq.x * pmid, wq.y * pmid));
             } else {
                 lds_st<T>(fr, (M / 2) * (int)sizeof(T), pmid);
             }
@@ -369,7 +374,9 @@ template <class Cfg> LRA_HD int mel2_shared_bytes(int n_mels) {
     return ((2 * (Cfg::M + 1) * (int)sizeof(typename Cfg::real) + (Cfg::TF + n_mels + 1) * (int)sizeof(int) + 15) / 16) * 16;
 }
 template <class Cfg> LRA_HD int mel2_psum_bytes(int n_mels) { return ((2 * (Cfg::TF + n_mels + 2) * (int)sizeof(typename Cfg::real) + 15) / 16) * 16; }
-template <class Cfg> inline bool mel2_fits(int) { return 2 * (Cfg::M + 1) * (int)sizeof(typename Cfg::real) <= Cfg::FRAME_BYTES && (Cfg::R == 8 || Cfg::R == 16); }
+template <class Cfg> inline bool mel2_fits(int) {
+    return (Cfg::M + (Cfg::M >> Cfg::LOGR) + 1) * 2 * (int)sizeof(typename Cfg::real) <= Cfg::FRAME_BYTES && (Cfg::R == 8 || Cfg::R == 16);
+}
 
 template <class Cfg> LRA_HD void mel2_tables_to_lds(const StftArgs<typename Cfg::real>& a, int tid, Lds sh) {
     using C = typename Cfg::cplx;
@@ -391,7 +398,7 @@ template <class Cfg> LRA_HD void mel2_gather(const StftArgs<typename Cfg::real>&
     const int mask = d >> 12;
     C v[BPL];
     LRA_UNROLL
-    for (int j = 0; j < BPL; ++j) v[j] = lds_ld<C>(fr, (tf * BPL + j) * (int)sizeof(C));
+    for (int j = 0; j < BPL; ++j) v[j] = lds_ld<C>(fr, (tf * (BPL + 1) + j) * (int)sizeof(C));  // = ab_slot(tf*BPL + j)
     C acc = mk<T>((T)0, (T)0);
     LRA_UNROLL
     for (int j = 0; j < BPL; ++j) {
@@ -402,7 +409,7 @@ template <class Cfg> LRA_HD void mel2_gather(const StftArgs<typename Cfg::real>&
             acc = mk<T>((T)0, (T)0);
         }
     }
-    if (tf == 0) lds_st<C>(psum, a.mel_nyq * (int)sizeof(C), lds_ld<C>(fr, Cfg::M * (int)sizeof(C)));
+    if (tf == 0) lds_st<C>(psum, a.mel_nyq * (int)sizeof(C), lds_ld<C>(fr, ab_slot<Cfg>(Cfg::M) * (int)sizeof(C)));
 }
 
 // mel[m] = rising part (B over the pieces of segment m) + falling part (A over the pieces of segment

@@ -22,6 +22,8 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
+    if "istft_kernel" in name:
+        return "istft_kernel"
     if "stft_kernel" in name:
         import re
         m = re.search(r">, (\d)>\(", name)
@@ -29,8 +31,6 @@ def short(name):
         cfg = re.search(r"FftCfg<(\d+), (\d), (\w+), (\d+), (\d), (\w+)>", name)
         tag = f" [2^{cfg.group(2)} pts/thread, NT={cfg.group(4)}]" if cfg else ""
         return {"0": "stft_kernel<complex64 out>", "1": "stft_kernel<power out>", "2": "stft_kernel<mel, generic>", "3": "stft_kernel<mel, two-slope>"}.get(mode, "stft_kernel<?>") + tag
-    if "istft_kernel" in name:
-        return "istft_kernel"
     return name.split("(")[0][-60:]
 
 
