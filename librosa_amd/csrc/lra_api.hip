@@ -63,6 +63,7 @@ struct lra_ctx {
     int opt_variant = -1;            // kernel tuning variant (f32 n_fft = 2048 only); -1 = per-mode default
     int opt_mel_tile = 0;            // frames staged per mel row before a flush (0 = auto)
     int opt_generic_mel = 0;         // force the generic banded mel path (tests)
+    int opt_lds_pad = 0;             // extra dynamic LDS per workgroup (occupancy experiments)
     unsigned int* d_flag = nullptr;  // non-finite input flag (device)
     std::string name;
 };
@@ -174,7 +175,7 @@ struct lra_istft_plan {
 // loads may read what the previous frame's spectrum stores wrote, and -- because loads may overtake
 // stores in the vector memory pipeline -- it then parks the wave on s_waitcnt vmcnt(0) at the top of
 // every frame until all of its stores have landed in L2, serialising FFT and store traffic.
-template <class Cfg, int MODE>
+template <class Cfg, int MODE, int PM>
 __global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void stft_kernel(StftArgs<typename Cfg::real> a, const typename Cfg::real* __restrict__ y,
                                                                      void* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char lra_smem[];
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void stft_kernel(StftArgs<
     a.D = static_cast<typename Cfg::cplx*>(out);
     a.S = static_cast<typename Cfg::real*>(out);
     a.Mel = static_cast<typename Cfg::real*>(out);
-    stft_block<Cfg, MODE>(a, (int)blockIdx.x, lds);
+    stft_block<Cfg, MODE, PM>(a, (int)blockIdx.x, lds);
 }
 
 template <class Cfg>
@@ -209,6 +210,7 @@ template <class T> struct StftLaunch {
     int mel_tile_opt = 0;
     int n_cu = 256;
     void* out = nullptr;
+    int lds_pad = 0;
     const lra_mel_plan* mel = nullptr;
     hipStream_t stream = nullptr;
     hipError_t err = hipSuccess;
@@ -234,9 +236,11 @@ template <class T> struct StftLaunch {
         a.shared_off = Cfg::FPB * a.slot_bytes;
         const long long grid = batch * a.wg_per_clip;
         if (grid > 0x7fffffffLL) { err = hipErrorInvalidConfiguration; return; }
-        const int lds = Cfg::FPB * a.slot_bytes + shared_bytes;
+        const int lds = Cfg::FPB * a.slot_bytes + shared_bytes + lds_pad;  // lds_pad: occupancy experiments only
         if (lds > 160 * 1024) { err = hipErrorInvalidValue; return; }
-        void (*kern)(StftArgs<T>, const T*, void*) = stft_kernel<Cfg, MODE>;
+        void (*kern)(StftArgs<T>, const T*, void*) = stft_kernel<Cfg, MODE, POW_TWO>;
+        if (MODE != OUT_COMPLEX && a.power_mode == POW_ONE) kern = stft_kernel<Cfg, MODE, POW_ONE>;
+        if (MODE != OUT_COMPLEX && a.power_mode == POW_GENERAL) kern = stft_kernel<Cfg, MODE, POW_GENERAL>;
         if (lds > 65536) {
             err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (err != hipSuccess) return;
@@ -344,7 +348,10 @@ __global__ void frame_window_kernel(const T* __restrict__ y, long long y_stride,
 
 template <class T> __global__ void power_kernel(const cx<T>* __restrict__ D, T* __restrict__ S, long long count, int power_mode, T power) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) S[i] = spec_power<T>(D[i], power_mode, power);
+    if (i >= count) return;
+    if (power_mode == POW_TWO) S[i] = spec_power<T, POW_TWO>(D[i], power);
+    else if (power_mode == POW_ONE) S[i] = spec_power<T, POW_ONE>(D[i], power);
+    else S[i] = spec_power<T, POW_GENERAL>(D[i], power);
 }
 
 // M[b][m][t] = sum_i val[off[m]+i] * S[b*bs + (c0[m]+i)*fs_bin + t*fs_frame]
@@ -532,6 +539,7 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
         L.iters_opt = ctx->opt_stft_iters;
         L.n_cu = ctx->n_cu;
         L.mel_tile_opt = ctx->opt_mel_tile;
+        L.lds_pad = ctx->opt_lds_pad;
         if (!dispatch_logm<T>(p->logm, variant, L)) return fail(LRA_EINVAL, "unsupported power-of-two size");
         if (L.err != hipSuccess) return fail(LRA_EHIP, std::string("stft kernel launch: ") + hipGetErrorString(L.err));
         return LRA_OK;
@@ -713,6 +721,7 @@ int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value) {
     else if (!std::strcmp(key, "mel_tile")) ctx->opt_mel_tile = value;
     else if (!std::strcmp(key, "ablate")) (void)value;  // retired development knob, accepted and ignored
     else if (!std::strcmp(key, "generic_mel")) ctx->opt_generic_mel = value;
+    else if (!std::strcmp(key, "lds_pad")) ctx->opt_lds_pad = value;
     else if (!std::strcmp(key, "variant")) ctx->opt_variant = (value >= 0 && value < kNumVariants) ? value : -1;
     else return fail(LRA_EINVAL, std::string("unknown option ") + key);
     return LRA_OK;
@@ -828,7 +837,21 @@ int lra_stft_plan_create(lra_ctx* ctx, int n_fft, int hop_length, const void* wi
     p->pad_mode = pad_mode;
     p->dtype = dtype;
     p->pow2 = pow2_supported(n_fft, dtype == LRA_F64);
-    int rc = upload(&p->d_win, window_host, (size_t)n_fft * real_bytes(dtype));
+    int rc;
+    if (p->pow2) {
+        // the fused kernels take 0.5 * window: the 1/2 of the real-FFT split step, folded in (exact)
+        if (dtype == LRA_F64) {
+            std::vector<double> wh(n_fft);
+            for (int i = 0; i < n_fft; ++i) wh[i] = 0.5 * ((const double*)window_host)[i];
+            rc = upload(&p->d_win, wh.data(), wh.size() * sizeof(double));
+        } else {
+            std::vector<float> wh(n_fft);
+            for (int i = 0; i < n_fft; ++i) wh[i] = 0.5f * ((const float*)window_host)[i];
+            rc = upload(&p->d_win, wh.data(), wh.size() * sizeof(float));
+        }
+    } else {
+        rc = upload(&p->d_win, window_host, (size_t)n_fft * real_bytes(dtype));
+    }
     if (rc == LRA_OK && p->pow2) {
         p->logm = log2_exact(n_fft) - 1;
         rc = dtype == LRA_F64 ? build_tables<double>(p->logm, p->d_tw, &p->d_twr) : build_tables<float>(p->logm, p->d_tw, &p->d_twr);

@@ -40,7 +40,7 @@ template <class T> struct StftArgs {
     int pad;       // n_fft/2 when centred, else 0
     int pad_mode;  // PadMode
     // tables
-    const T* win;       // [N]   window padded to n_fft
+    const T* win;       // [N]   0.5 * window padded to n_fft (the 1/2 of the real-FFT split step, folded in)
     const cx<T>* tw;    // pass twiddles (FftCfg::tw_off layout)
     const cx<T>* twr;   // split twiddles W_N^k, k = 0..M/2
     // work decomposition
@@ -125,11 +125,14 @@ template <class Cfg, int p> LRA_HD void pass_dft(FftRegs<Cfg>& rg, int tf, const
     else pass_twiddle_dft<Cfg, p>(rg.v, tf, tw);
 }
 
-template <class T> LRA_HD T spec_power(cx<T> x, int power_mode, T power) {
+// The power mode is a compile-time parameter of the kernels (PM in {POW_TWO, POW_ONE, POW_GENERAL}): with a
+// run-time switch hipcc if-converts the uniform branch and executes the whole software pow() for every
+// bin even when power == 2 (it cost the fused mel kernel 25 % of its time).
+template <class T, int PM> LRA_HD T spec_power(cx<T> x, T power) {
     const T p2 = x.x * x.x + x.y * x.y;
-    if (power_mode == POW_TWO) return p2;
+    if (PM == POW_TWO) return p2;
     const T mag = std::sqrt(p2);
-    if (power_mode == POW_ONE) return mag;
+    if (PM == POW_ONE) return mag;
     return std::pow(mag, power);
 }
 
@@ -217,7 +220,7 @@ template <class Cfg> LRA_HD void stft_ring_load_pass0(const StftArgs<typename Cf
     const C* __restrict__ win2 = reinterpret_cast<const C*>(a.win);
     C* v = rg.v;
     const int base = (int)(((long long)frame * a.hop) & (N - 1));
-    if (frame >= a.n_frames) {
+    if (Cfg::FPB > 1 && frame >= a.n_frames) {  // (with one slot per workgroup the frame loop has already exited)
         LRA_UNROLL
         for (int i = 0; i < Cfg::R; ++i) v[i] = mk<T>((T)0, (T)0);
     } else if ((base & 1) == 0) {
@@ -274,18 +277,18 @@ template <class Cfg> LRA_HD void split_read(FftRegs<Cfg>& rg, Lds fr, int tf) {
 }
 
 // X[k] and X[M-k] from Z[k], Z[M-k]:  A = (Zk + conj Zm)/2, B = W_N^k (Zk - conj Zm)/(2i),
-// X[k] = A + B, X[M-k] = conj(A - B).
+// X[k] = A + B, X[M-k] = conj(A - B).  The factor 1/2 is folded into the window table of the fused
+// kernels (StftArgs::win holds 0.5 w, an exact scaling), so Z arrives pre-halved here.
 template <class T> LRA_HD void split_pair(cx<T> zk, cx<T> zm, cx<T> w, cx<T>& xk, cx<T>& xm) {
-    const T h = (T)0.5;
-    const cx<T> A = mk<T>((zk.x + zm.x) * h, (zk.y - zm.y) * h);
-    const cx<T> O = mk<T>((zk.y + zm.y) * h, (zm.x - zk.x) * h);
+    const cx<T> A = mk<T>(zk.x + zm.x, zk.y - zm.y);
+    const cx<T> O = mk<T>(zk.y + zm.y, zm.x - zk.x);
     const cx<T> B = cmul(w, O);
     xk = cadd(A, B);
     xm = cconj(csub(A, B));
 }
 
 // ---- phase: split + epilogue store (complex / power) or power -> LDS (mel) --------------------
-template <class Cfg, int MODE> LRA_HD void stft_split_store(const StftArgs<typename Cfg::real>& a, int clip, int frame, bool valid, int tf,
+template <class Cfg, int MODE, int PM> LRA_HD void stft_split_store(const StftArgs<typename Cfg::real>& a, int clip, int frame, bool valid, int tf,
                                                             FftRegs<Cfg>& rg, Lds fr, Lds sh) {
     using T = typename Cfg::real;
     using C = typename Cfg::cplx;
@@ -298,8 +301,8 @@ template <class Cfg, int MODE> LRA_HD void stft_split_store(const StftArgs<typen
         int km;
         if (k == 0) {
             const C z0 = rg.v[2 * i];
-            xk = mk<T>(z0.x + z0.y, (T)0);
-            xm = mk<T>(z0.x - z0.y, (T)0);
+            xk = mk<T>((T)2 * (z0.x + z0.y), (T)0);  // Z is pre-halved (see split_pair)
+            xm = mk<T>((T)2 * (z0.x - z0.y), (T)0);
             km = M;
             if (valid && a.nonfinite_flag && !(std::fabs(xk.x) <= std::numeric_limits<T>::max())) LRA_ATOMIC_OR(a.nonfinite_flag, 1u);
         } else {
@@ -309,7 +312,7 @@ template <class Cfg, int MODE> LRA_HD void stft_split_store(const StftArgs<typen
         if (MODE == OUT_COMPLEX) {
             if (valid) { a.D[row + k] = xk; a.D[row + km] = xm; }
         } else {
-            const T pk = spec_power<T>(xk, a.power_mode, a.power), pm = spec_power<T>(xm, a.power_mode, a.power);
+            const T pk = spec_power<T, PM>(xk, a.power), pm = spec_power<T, PM>(xm, a.power);
             if (MODE == OUT_POWER) {
                 if (valid) { a.S[row + k] = pk; a.S[row + km] = pm; }
             } else if (MODE == OUT_MEL2) {
@@ -325,11 +328,11 @@ template <class Cfg, int MODE> LRA_HD void stft_split_store(const StftArgs<typen
         }
     }
     if (tf == 0) {
-        const C xmid = cconj(rg.mid);  // X[M/2] = conj(Z[M/2])
+        const C xmid = mk<T>((T)2 * rg.mid.x, (T)-2 * rg.mid.y);  // X[M/2] = conj(Z[M/2]), Z pre-halved
         if (MODE == OUT_COMPLEX) {
             if (valid) a.D[row + M / 2] = xmid;
         } else {
-            const T pmid = spec_power<T>(xmid, a.power_mode, a.power);
+            const T pmid = spec_power<T, PM>(xmid, a.power);
             if (MODE == OUT_POWER) {
                 if (valid) a.S[row + M / 2] = pmid;
             } else if (MODE == OUT_MEL2) {
@@ -471,7 +474,7 @@ template <class Cfg> inline int stft_slot_bytes(int mode, int n_mels, int tile) 
 // f_first + s*iters + it of clip blk / wg_per_clip, as a private pipeline: all LDS traffic of a slot
 // stays inside the slot (and, when TF <= 64, inside one wave: no s_barrier anywhere).  The mel
 // epilogue stages `mel_tile` frames per row before flushing them as contiguous runs.
-template <class Cfg, int MODE> LRA_HD void stft_block(const StftArgs<typename Cfg::real>& a_in, const int blk, Lds lds) {
+template <class Cfg, int MODE, int PM = POW_TWO> LRA_HD void stft_block(const StftArgs<typename Cfg::real>& a_in, const int blk, Lds lds) {
     StftArgs<typename Cfg::real> a = a_in;
     const int clip = blk / a.wg_per_clip;
     const int f_first = (blk % a.wg_per_clip) * a.frames_per_wg;
@@ -507,7 +510,7 @@ template <class Cfg, int MODE> LRA_HD void stft_block(const StftArgs<typename Cf
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
-            stft_split_store<Cfg, MODE>(a, clip, frame, frame < a.n_frames, tf, LRA_R(rg), lds_sub(lds, slot * slot_bytes), lds_sub(lds, a.shared_off));
+            stft_split_store<Cfg, MODE, PM>(a, clip, frame, frame < a.n_frames, tf, LRA_R(rg), lds_sub(lds, slot * slot_bytes), lds_sub(lds, a.shared_off));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         if (MODE == OUT_MEL2) {
             LRA_PHASE(Cfg::NT, tid) {

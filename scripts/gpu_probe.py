@@ -54,6 +54,15 @@ if what == "ablate":
                 msm = timeit(lambda: ctx.melspectrogram_exec(plan, mel_plan, y.data_ptr(), batch, n, n, 2.0, M.data_ptr()))
                 print(f"variant {variant} iters {iters} ablate {ab}: stft {ms:.3f} ms ({batch * T / ms / 1e3:.1f} Mframes/s)   mel {msm:.3f} ms ({batch * T / msm / 1e3:.1f} Mframes/s)", flush=True)
     ctx.set_option("ablate", 0)
+elif what == "occupancy":
+    for variant in (0, 4):
+        ctx.set_option("variant", variant)
+        ctx.set_option("stft_iters", 32)
+        for pad_kb in (0, 4, 8, 12, 16, 24, 36, 64):
+            ctx.set_option("lds_pad", pad_kb * 1024)
+            ms = timeit(lambda: ctx.stft_exec(plan, y.data_ptr(), batch, n, n, D.data_ptr()))
+            print(f"variant {variant} lds_pad {pad_kb:3d} KB: stft {ms:.3f} ms ({batch * T / ms / 1e3:.1f} Mframes/s)", flush=True)
+    ctx.set_option("lds_pad", 0)
 elif what == "variant1":
     yh = O.config_input(1, n=44100)
     yt = torch.from_numpy(yh).cuda()
@@ -67,3 +76,20 @@ elif what == "variant1":
         print("   per-bin max (bins 0..15):", np.round(err.max(axis=1)[:16], 3), " bins 1010..1024:", np.round(err.max(axis=1)[1010:], 3))
         bad = np.argwhere(err > 1e-3 * np.abs(ref).max())
         print("   #bad", len(bad), "of", err.size, "first bad (bin, frame):", bad[:10].tolist())
+if what == "membw":
+    Dr = torch.view_as_real(D)
+    src = torch.empty_like(Dr)
+    for name, fn in (("fill 2.71 GB", lambda: Dr.fill_(1.0)), ("copy 2.71 GB -> 2.71 GB", lambda: Dr.copy_(src)), ("read-reduce 2.71 GB", lambda: src.sum()),
+                     ("mul_ in place 2.71 GB", lambda: Dr.mul_(1.0001)), ("fill y 0.68 GB", lambda: y.fill_(0.5))):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        for _ in range(10):
+            fn()
+        t1.record(); torch.cuda.synchronize()
+        ms = t0.elapsed_time(t1) / 10
+        nbytes = Dr.numel() * 4 if "2.71" in name else y.numel() * 4
+        mult = 2 if ("copy" in name or "mul_" in name) else 1
+        print(f"{name}: {ms:.3f} ms -> {nbytes * mult / ms / 1e6:.0f} GB/s", flush=True)

@@ -37,7 +37,9 @@ template <class T> struct StftSim {
         for (long long blk = 0; blk < nblk; ++blk) {
             st.resize(Cfg::FPB * a.slot_bytes + shared_bytes);
             Lds lds; lds.base = 0;
-            stft_block<Cfg, MODE>(a, (int)blk, lds);
+            if (a.power_mode == POW_TWO) stft_block<Cfg, MODE, POW_TWO>(a, (int)blk, lds);
+            else if (a.power_mode == POW_ONE) stft_block<Cfg, MODE, POW_ONE>(a, (int)blk, lds);
+            else stft_block<Cfg, MODE, POW_GENERAL>(a, (int)blk, lds);
             diag[0] += st.races; diag[1] += st.uninit;
             st.races = st.uninit = 0;
         }

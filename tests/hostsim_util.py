@@ -77,7 +77,7 @@ def stft(y, n_fft, hop, win, center=True, pad_mode="constant", mode=0, iters_per
     else:
         n_frames = 1 + (n - n_fft) // hop
     M = n_fft // 2
-    win = np.ascontiguousarray(win, dtype=y.dtype)
+    win = np.ascontiguousarray(0.5 * np.asarray(win, dtype=np.float64), dtype=y.dtype)  # the kernels take 0.5 * window
     pm = 2 if power == 2.0 else (1 if power == 1.0 else 3)
     c0 = ln = off = val = dense = None
     n_mels = 0
