@@ -170,7 +170,7 @@ def main():
         return wall, e0.elapsed_ms(e1) / 1e3
 
     if args.sweep and rank == 0:
-        for variant in range(5):
+        for variant in (0, 1, 4):
             for iters in (4, 8, 16, 32, 64):
                 ctx.set_option("variant", variant)
                 ctx.set_option("stft_iters", iters)

@@ -16,7 +16,8 @@ import numpy as np
 from .util.exceptions import LibrosaError, ParameterError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_liblibrosa_amd.so")
+# LIBROSA_AMD_LIBRARY: load another build of the same ABI (kernel experiments, scripts/gpu_probe.py)
+LIB_PATH = os.environ.get("LIBROSA_AMD_LIBRARY") or os.path.join(_HERE, "_liblibrosa_amd.so")
 
 LRA_OK, LRA_EINVAL, LRA_EHIP, LRA_EROCFFT, LRA_ENODEV, LRA_ENOMEM = 0, -1, -2, -3, -4, -5
 LRA_F32, LRA_F64 = 0, 1

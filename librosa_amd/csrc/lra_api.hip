@@ -175,7 +175,8 @@ struct lra_istft_plan {
 // loads may read what the previous frame's spectrum stores wrote, and -- because loads may overtake
 // stores in the vector memory pipeline -- it then parks the wave on s_waitcnt vmcnt(0) at the top of
 // every frame until all of its stores have landed in L2, serialising FFT and store traffic.
-template <class Cfg, int MODE, int PM>
+// RA: the hop is a whole number of ring rows (lra_kernels.h, ring_rows_aligned) -- the fast ring addressing.
+template <class Cfg, int MODE, int PM, bool RA>
 __global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void stft_kernel(StftArgs<typename Cfg::real> a, const typename Cfg::real* __restrict__ y,
                                                                      void* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char lra_smem[];
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void stft_kernel(StftArgs<
     a.D = static_cast<typename Cfg::cplx*>(out);
     a.S = static_cast<typename Cfg::real*>(out);
     a.Mel = static_cast<typename Cfg::real*>(out);
-    stft_block<Cfg, MODE, PM>(a, (int)blockIdx.x, lds);
+    stft_block<Cfg, MODE, PM, RA>(a, (int)blockIdx.x, lds);
 }
 
 template <class Cfg>
@@ -238,9 +239,19 @@ template <class T> struct StftLaunch {
         if (grid > 0x7fffffffLL) { err = hipErrorInvalidConfiguration; return; }
         const int lds = Cfg::FPB * a.slot_bytes + shared_bytes + lds_pad;  // lds_pad: occupancy experiments only
         if (lds > 160 * 1024) { err = hipErrorInvalidValue; return; }
-        void (*kern)(StftArgs<T>, const T*, void*) = stft_kernel<Cfg, MODE, POW_TWO>;
-        if (MODE != OUT_COMPLEX && a.power_mode == POW_ONE) kern = stft_kernel<Cfg, MODE, POW_ONE>;
-        if (MODE != OUT_COMPLEX && a.power_mode == POW_GENERAL) kern = stft_kernel<Cfg, MODE, POW_GENERAL>;
+        void (*kern)(StftArgs<T>, const T*, void*) = stft_kernel<Cfg, MODE, POW_TWO, false>;
+        if (MODE != OUT_COMPLEX && a.power_mode == POW_ONE) kern = stft_kernel<Cfg, MODE, POW_ONE, false>;
+        if (MODE != OUT_COMPLEX && a.power_mode == POW_GENERAL) kern = stft_kernel<Cfg, MODE, POW_GENERAL, false>;
+        if constexpr (sizeof(T) == 4) {  // row-aligned hops (n_fft/4, n_fft/8, ...): the fast ring addressing, f32 only
+#ifndef LRA_MEL_RA
+#define LRA_MEL_RA 1
+#endif
+            if (ring_rows_aligned<Cfg>(a.hop) && (LRA_MEL_RA || MODE == OUT_COMPLEX || MODE == OUT_POWER)) {
+                kern = stft_kernel<Cfg, MODE, POW_TWO, true>;
+                if (MODE != OUT_COMPLEX && a.power_mode == POW_ONE) kern = stft_kernel<Cfg, MODE, POW_ONE, true>;
+                if (MODE != OUT_COMPLEX && a.power_mode == POW_GENERAL) kern = stft_kernel<Cfg, MODE, POW_GENERAL, true>;
+            }
+        }
         if (lds > 65536) {
             err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (err != hipSuccess) return;

@@ -124,6 +124,9 @@ inline Lds lds_sub(Lds l, int byte_off) { Lds r; r.base = l.base + byte_off; ret
 
 #define LRA_LAUNDER(p) ((void)0)
 #define LRA_ATOMIC_OR(ptr, v) (*(ptr) |= (v))
+#define LRA_UNIFORM(x) (x)
+#define LRA_KEEP(x) ((void)0)
+template <class V> inline void stream_store(V* p, V v) { *p = v; }
 #define LRA_PHASE(NT, tid) for (int tid = 0; tid < (NT); ++tid) { ::lra::sim::state().cur_tid = tid;
 #define LRA_PHASE_END } ::lra::sim::state().barrier();
 #define LRA_PHASE_END_SYNC(WAVE) } ::lra::sim::state().barrier(WAVE);
@@ -143,6 +146,29 @@ LRA_HD Lds lds_sub(Lds l, int byte_off) { Lds r; r.base = l.base + byte_off; ret
 // hoisted out of the enclosing loop
 #define LRA_LAUNDER(p) asm volatile("" : "+s"(p))
 #define LRA_ATOMIC_OR(ptr, v) atomicOr((ptr), (v))
+// value known to be the same in every lane of the wave: keep it in an SGPR so that branches on it stay scalar
+#define LRA_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+// pins a value's computation where it is written (hipcc may not sink it into a later branch)
+#define LRA_KEEP(x) asm volatile("" : "+v"(x))
+// Output that is written once and not read again by this kernel: a non-temporal (streaming) store.
+#ifndef LRA_NT_STORE
+#define LRA_NT_STORE 0  // measured on MI355X: no gain for the spectrum rows (the L2 write-back path already streams them)
+#endif
+template <class V> __device__ __forceinline__ void stream_store(V* p, V v) {
+#if LRA_NT_STORE
+    if constexpr (sizeof(V) == 8) {
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store(__builtin_bit_cast(f2v, v), reinterpret_cast<f2v*>(p));
+    } else if constexpr (sizeof(V) == 16) {
+        typedef double d2v __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store(__builtin_bit_cast(d2v, v), reinterpret_cast<d2v*>(p));
+    } else {
+        __builtin_nontemporal_store(v, p);
+    }
+#else
+    *p = v;
+#endif
+}
 // Phase boundary.  WAVE = true: every lane that exchanges data through LDS across this boundary is
 // in the same wave64 (a wave's DS instructions execute in order), so a compiler-level fence is
 // enough and the waves of the workgroup are free to drift apart; otherwise a workgroup barrier.
@@ -152,11 +178,32 @@ template <bool WAVE> __device__ __forceinline__ void phase_sync() {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     } else {
+        // Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() is a workgroup-scope fence over
+        // every address space: hipcc then drains vmcnt to 0 in front of each s_barrier, i.e. the wave sits
+        // out the full HBM latency of its freshly issued prefetch loads (and of its output stores) at every
+        // phase boundary.  The phases exchange data through LDS and nothing else.
+        // (Spelled as asm: this hipcc still emits s_waitcnt vmcnt(0) for
+        // __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local").)  The "memory" clobber keeps the
+        // compiler from moving LDS accesses across the barrier; lgkmcnt(0) retires this wave's DS writes.
+#ifdef LRA_FULL_BARRIER  // experiments only
         __syncthreads();
+#else
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
     }
 }
-#define LRA_PHASE(NT, tid) { const int tid = (int)threadIdx.x;
-#define LRA_PHASE_END } __syncthreads();
+// The thread index is re-read through an opaque move at the top of every phase.  Without it hipcc hoists
+// every tid-derived LDS / global address of every phase out of the frame loop (dozens of VGPRs that stay
+// live for the whole kernel) and then spills the values that matter, e.g. the prefetch registers.
+__device__ __forceinline__ int phase_tid() {
+    int t = (int)threadIdx.x;
+#ifndef LRA_NO_TID_LAUNDER
+    asm volatile("" : "+v"(t));
+#endif
+    return t;
+}
+#define LRA_PHASE(NT, tid) { const int tid = ::lra::phase_tid();
+#define LRA_PHASE_END } ::lra::phase_sync<false>();
 #define LRA_PHASE_END_SYNC(WAVE) } ::lra::phase_sync<(WAVE)>();
 #define LRA_REGS(Type, name, NT) Type name
 #define LRA_R(name) name

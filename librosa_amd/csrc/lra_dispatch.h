@@ -18,7 +18,8 @@ constexpr int kNumVariants = 5; // tuning variants exist for f32 n_fft = 2048 on
 // A workgroup is ONE wave64 (several frame slots when n_fft < 2048) unless a frame needs more threads:
 // slots are private pipelines, so small workgroups only add scheduling freedom and keep the LDS
 // footprint (frame area + PCM ring + mel tile, ~17-19 KiB per slot at n_fft = 2048) granular.
-// Variants 1..3 (f32, n_fft = 2048) trade registers for occupancy; bench.py --sweep times them.
+// Variants 1 and 4 (f32, n_fft = 2048) split a frame over two waves (8 points per thread) for higher
+// occupancy; variants 2 and 3 were retired (always slower) and now alias variant 0.  bench.py --sweep times them.
 template <class T, int L, int VAR> struct CfgSel {
     using type = FftCfg<L, 4, T, 64, 2, (L <= 10)>;
 };
@@ -27,12 +28,6 @@ template <int L, int VAR> struct CfgSel<double, L, VAR> {
 };
 template <> struct CfgSel<float, 10, 1> {
     using type = FftCfg<10, 3, float, 128, 4, false>;
-};
-template <> struct CfgSel<float, 10, 2> {
-    using type = FftCfg<10, 4, float, 64, 3, false>;
-};
-template <> struct CfgSel<float, 10, 3> {
-    using type = FftCfg<10, 4, float, 64, 4, false>;
 };
 template <> struct CfgSel<float, 10, 4> {
     using type = FftCfg<10, 3, float, 128, 3, true>;  // two waves per frame, tables in registers, 3 waves/SIMD
@@ -56,23 +51,28 @@ inline int log2_exact(int v) {
 // Calls f.template operator()<Cfg>() for the configuration of (T, logm, variant); returns false if
 // unsupported.
 template <class T, class F> inline bool dispatch_logm(int logm, int variant, F&& f) {
+#ifdef LRA_PROBE_ONLY  // development builds (scripts/gpu_probe.py): n_fft = 2048 f32 only, compiles in seconds
+    if (logm != 10 || sizeof(T) != 4) return false;
+#endif
     switch (logm) {
 #define LRA_CASE(L) \
     case L: f.template operator()<typename CfgSel<T, L, 0>::type>(); return true;
+#ifndef LRA_PROBE_ONLY
         LRA_CASE(4) LRA_CASE(5) LRA_CASE(6) LRA_CASE(7) LRA_CASE(8) LRA_CASE(9) LRA_CASE(11) LRA_CASE(12)
+#endif
 #undef LRA_CASE
         case 10:
             if constexpr (sizeof(T) == 4) {
                 if (variant == 1) { f.template operator()<typename CfgSel<T, 10, 1>::type>(); return true; }
-                if (variant == 2) { f.template operator()<typename CfgSel<T, 10, 2>::type>(); return true; }
-                if (variant == 3) { f.template operator()<typename CfgSel<T, 10, 3>::type>(); return true; }
                 if (variant == 4) { f.template operator()<typename CfgSel<T, 10, 4>::type>(); return true; }
             }
             f.template operator()<typename CfgSel<T, 10, 0>::type>();
             return true;
+#ifndef LRA_PROBE_ONLY
         case 13:
             if constexpr (sizeof(T) == 4) { f.template operator()<typename CfgSel<T, 13, 0>::type>(); return true; }
             return false;
+#endif
         default: return false;
     }
 }

@@ -20,6 +20,10 @@
 // simulator used by tests (see lra_common.h).
 #pragma once
 
+#ifndef LRA_ABLATE
+#define LRA_ABLATE 0  // kernel experiments (scripts/gpu_probe.py builds), 0 in the product
+#endif
+
 #include <cmath>
 #include <limits>
 
@@ -180,12 +184,18 @@ template <class Cfg> LRA_HD bool ring_block_prefetchable(const StftArgs<typename
     return g1 >= 0 && g1 + Hn <= a.n;
 }
 
-template <class Cfg> LRA_HD void stft_ring_prefetch(const StftArgs<typename Cfg::real>& a, int clip, int next, int tf, FftRegs<Cfg>& rg) {
+template <class Cfg, bool RA> LRA_HD void stft_ring_prefetch(const StftArgs<typename Cfg::real>& a, int clip, int next, int tf, FftRegs<Cfg>& rg) {
     using T = typename Cfg::real;
     constexpr int N = Cfg::N, NPF = FftRegs<Cfg>::NPF;
     if (!ring_block_prefetchable<Cfg>(a, next)) return;
     const int H = a.hop, Hn = H < N ? H : N;
     const T* __restrict__ src = a.y + (long long)clip * a.y_stride + ((long long)next * H + (N - Hn) - a.pad);
+    if (RA) {  // hop = n_fft / 4 = NPF rows of TF samples: one per-thread base, immediate offsets
+        const T* __restrict__ st = src + tf;
+        LRA_UNROLL
+        for (int c = 0; c < NPF; ++c) rg.pf[c] = st[c * Cfg::TF];
+        return;
+    }
     LRA_UNROLL
     for (int c = 0; c < NPF; ++c) {
         const int e = tf + c * Cfg::TF;
@@ -194,13 +204,53 @@ template <class Cfg> LRA_HD void stft_ring_prefetch(const StftArgs<typename Cfg:
     }
 }
 
-template <class Cfg> LRA_HD void stft_ring_advance(const StftArgs<typename Cfg::real>& a, int clip, int next, int tf, const FftRegs<Cfg>& rg, Lds ring) {
+// Row-aligned ring addressing (RA kernels: hop = n_fft / 4, librosa's default).  View the ring as R rows
+// of TF complex (= 2 TF real) samples.  The hop is R/4 whole rows, so every frame starts on a row
+// boundary: thread tf's R sample pairs of a frame sit at byte  ((rot + row) mod R) * ROWB + 8 tf  with
+// ONE wave-uniform rotation rot in {0, R/4, R/2, 3R/4}; a scalar switch on rot turns every ring access
+// into "constant per-thread base + immediate offset" (and the pair reads into single ds_read_b64s)
+// instead of R masked address computations per frame.  Other hops use the general addressing.
+template <class Cfg> LRA_HD bool ring_rows_aligned(int hop) { return 4 * hop == Cfg::N && Cfg::R >= 4; }
+
+template <class Cfg, int ROT> LRA_HD void ring_rows_load(int rot, int tf, typename Cfg::cplx* v, Lds ring) {
+    using C = typename Cfg::cplx;
+    constexpr int lr = Cfg::logr(0), r = 1 << lr, nb = Cfg::R >> lr, ROWB = Cfg::TF * (int)sizeof(C);
+    if (rot == ROT) {
+        LRA_UNROLL
+        for (int i = 0; i < nb; ++i) {
+            LRA_UNROLL
+            for (int j = 0; j < r; ++j) v[i * r + j] = lds_ld<C>(ring, tf * (int)sizeof(C) + ((ROT + i + j * nb) & (Cfg::R - 1)) * ROWB);
+        }
+    } else if constexpr (ROT + Cfg::R / 4 < Cfg::R) {
+        ring_rows_load<Cfg, ROT + Cfg::R / 4>(rot, tf, v, ring);
+    }
+}
+
+template <class Cfg, int ROT> LRA_HD void ring_rows_store(int rot, int tf, const FftRegs<Cfg>& rg, Lds ring) {
+    using T = typename Cfg::real;
+    constexpr int NPF = FftRegs<Cfg>::NPF, ROWB = 2 * Cfg::TF * (int)sizeof(T);
+    if (rot == ROT) {
+        LRA_UNROLL
+        for (int c = 0; c < NPF; ++c)
+            lds_st<T>(ring, tf * (int)sizeof(T) + ((ROT + (c >> 1)) & (Cfg::R - 1)) * ROWB + (c & 1) * Cfg::TF * (int)sizeof(T), rg.pf[c]);
+    } else if constexpr (ROT + Cfg::R / 4 < Cfg::R) {
+        ring_rows_store<Cfg, ROT + Cfg::R / 4>(rot, tf, rg, ring);
+    }
+}
+
+template <class Cfg, bool RA> LRA_HD void stft_ring_advance(const StftArgs<typename Cfg::real>& a, int clip, int next, int tf, const FftRegs<Cfg>& rg, Lds ring) {
     using T = typename Cfg::real;
     constexpr int N = Cfg::N, NPF = FftRegs<Cfg>::NPF;
     const int H = a.hop, Hn = H < N ? H : N;
     if (next >= a.n_frames) return;
     const long long p1 = (long long)next * H + (N - Hn);
     if (ring_block_prefetchable<Cfg>(a, next)) {
+        if (RA) {
+            int rot = (int)((p1 & (N - 1)) / (2 * Cfg::TF));
+            if (Cfg::TF >= 64) rot = LRA_UNIFORM(rot);  // a wave never spans two slots: the rotation is wave-uniform
+            ring_rows_store<Cfg, 0>(rot, tf, rg, ring);
+            return;
+        }
         LRA_UNROLL
         for (int c = 0; c < NPF; ++c) {
             const int e = tf + c * Cfg::TF;
@@ -213,7 +263,7 @@ template <class Cfg> LRA_HD void stft_ring_advance(const StftArgs<typename Cfg::
 }
 
 // phase B: frame samples (ring) x window -> registers -> pass-0 butterflies -> frame area
-template <class Cfg> LRA_HD void stft_ring_load_pass0(const StftArgs<typename Cfg::real>& a, int frame, int tf, FftRegs<Cfg>& rg, Lds ring, Lds fr) {
+template <class Cfg, bool RA> LRA_HD void stft_ring_load_pass0(const StftArgs<typename Cfg::real>& a, int frame, int tf, FftRegs<Cfg>& rg, Lds ring, Lds fr) {
     using T = typename Cfg::real;
     using C = typename Cfg::cplx;
     constexpr int lr = Cfg::logr(0), r = 1 << lr, nb = Cfg::R >> lr, sin = Cfg::M >> lr, N = Cfg::N;
@@ -223,6 +273,18 @@ template <class Cfg> LRA_HD void stft_ring_load_pass0(const StftArgs<typename Cf
     if (Cfg::FPB > 1 && frame >= a.n_frames) {  // (with one slot per workgroup the frame loop has already exited)
         LRA_UNROLL
         for (int i = 0; i < Cfg::R; ++i) v[i] = mk<T>((T)0, (T)0);
+    } else if (RA) {
+        int rot = base / (2 * Cfg::TF);
+        if (Cfg::TF >= 64) rot = LRA_UNIFORM(rot);  // a wave never spans two slots: the rotation is wave-uniform
+        ring_rows_load<Cfg, 0>(rot, tf, v, ring);
+        LRA_UNROLL
+        for (int i = 0; i < nb; ++i) {
+            LRA_UNROLL
+            for (int j = 0; j < r; ++j) {
+                const C w = Cfg::HOIST ? rg.win2[i * r + j] : win2[tf + i * Cfg::TF + j * sin];
+                v[i * r + j] = mk<T>(v[i * r + j].x * w.x, v[i * r + j].y * w.y);
+            }
+        }
     } else if ((base & 1) == 0) {
         LRA_UNROLL
         for (int i = 0; i < nb; ++i) {
@@ -247,7 +309,9 @@ template <class Cfg> LRA_HD void stft_ring_load_pass0(const StftArgs<typename Cf
             }
         }
     }
+#if LRA_ABLATE != 2
     pass_dft<Cfg, 0>(rg, tf, a.tw);
+#endif
     pass_write<Cfg, 0>(v, fr, tf);
 }
 
@@ -294,6 +358,12 @@ template <class Cfg, int MODE, int PM> LRA_HD void stft_split_store(const StftAr
     using C = typename Cfg::cplx;
     constexpr int M = Cfg::M;
     const long long row = ((long long)clip * a.n_frames + frame) * (M + 1);
+    // bins k = tf + i TF ascend from one per-thread pointer, the mirrored bins M - k descend from another:
+    // two 64-bit bases per frame and immediate offsets for all R stores
+    C* __restrict__ const Dk = MODE == OUT_COMPLEX ? a.D + row + tf : nullptr;
+    C* __restrict__ const Dm = MODE == OUT_COMPLEX ? a.D + row + (M - tf) : nullptr;
+    T* __restrict__ const Sk = MODE == OUT_POWER ? a.S + row + tf : nullptr;
+    T* __restrict__ const Sm = MODE == OUT_POWER ? a.S + row + (M - tf) : nullptr;
     LRA_UNROLL
     for (int i = 0; i < Cfg::R / 2; ++i) {
         const int k = tf + i * Cfg::TF;
@@ -306,21 +376,33 @@ template <class Cfg, int MODE, int PM> LRA_HD void stft_split_store(const StftAr
             km = M;
             if (valid && a.nonfinite_flag && !(std::fabs(xk.x) <= std::numeric_limits<T>::max())) LRA_ATOMIC_OR(a.nonfinite_flag, 1u);
         } else {
+#if LRA_ABLATE == 2  // experiment: stores only
+            xk = rg.v[2 * i]; xm = rg.v[2 * i + 1];
+#else
             split_pair<T>(rg.v[2 * i], rg.v[2 * i + 1], Cfg::HOIST ? rg.twr[i] : a.twr[k], xk, xm);
+#endif
             km = M - k;
         }
         if (MODE == OUT_COMPLEX) {
-            if (valid) { a.D[row + k] = xk; a.D[row + km] = xm; }
+#if LRA_ABLATE == 1  // experiment: compute everything, store (practically) nothing
+            if (valid && xk.x == (T)12345.678) { Dk[i * Cfg::TF] = xk; Dm[-i * Cfg::TF] = xm; }
+#else
+            if (valid) { stream_store(&Dk[i * Cfg::TF], xk); stream_store(&Dm[-i * Cfg::TF], xm); }
+#endif
         } else {
             const T pk = spec_power<T, PM>(xk, a.power), pm = spec_power<T, PM>(xm, a.power);
             if (MODE == OUT_POWER) {
-                if (valid) { a.S[row + k] = pk; a.S[row + km] = pm; }
+                if (valid) { Sk[i * Cfg::TF] = pk; Sm[-i * Cfg::TF] = pm; }
             } else if (MODE == OUT_MEL2) {
                 const C wk = lds_ld<C>(sh, k * (int)sizeof(C)), wm = lds_ld<C>(sh, km * (int)sizeof(C));
                 // AB[k] sits at the padded slot k + k/R: a thread's run of R consecutive bins then starts
                 // R+1 slots after its neighbour's, which makes the run reads of mel2_gather conflict-free
+#if LRA_ABLATE == 13  // experiment: no mel epilogue at all (keep the power computation alive)
+                if (wk.x * pk + wm.x * pm == (T)12345.678) a.Mel[k] = pk;
+#else
                 lds_st<C>(fr, ab_slot<Cfg>(k) * (int)sizeof(C), mk<T>(wk.x * pk, wk.y * pk));
                 lds_st<C>(fr, ab_slot<Cfg>(km) * (int)sizeof(C), mk<T>(wm.x * pm, wm.y * pm));
+#endif
             } else {
                 lds_st<T>(fr, k * (int)sizeof(T), pk);
                 lds_st<T>(fr, km * (int)sizeof(T), pm);
@@ -367,6 +449,19 @@ template <class Cfg> LRA_HD void mel_flush_slot(const StftArgs<typename Cfg::rea
         const int m = idx / iters, i = idx - m * iters;
         if (i < nv) a.Mel[((long long)clip * a.n_mels + m) * a.n_frames + f0 + i] = lds_ld<T>(stage, idx * (int)sizeof(T));
     }
+}
+
+// flush of the staging tile that iteration `it` of a slot (first frame f_slot) belongs to: the frames
+// staged so far in that tile, clipped to the clip's frame count
+template <class Cfg> LRA_HD void mel_flush_tile(const StftArgs<typename Cfg::real>& a, int clip, int f_slot, int it, int tile, int tf, Lds stage) {
+#if LRA_ABLATE == 14
+    if (a.n_mels != 12345) return;
+#endif
+    const int f0 = f_slot + (it / tile) * tile;  // first frame of the staged tile
+    int nv = a.n_frames - f0;
+    const int staged = it % tile + 1;
+    nv = nv < 0 ? 0 : (nv > staged ? staged : nv);
+    mel_flush_slot<Cfg>(a, clip, f0, nv, tf, tile, stage);
 }
 
 // ---- OUT_MEL2: two-slope mel reduce (lra_mel.h) ---------------------------------------------------
@@ -422,24 +517,38 @@ template <class Cfg> LRA_HD void mel2_combine(const StftArgs<typename Cfg::real>
     using T = typename Cfg::real;
     using C = typename Cfg::cplx;
     constexpr int NB = Cfg::M + 1;
+#if LRA_ABLATE == 15
+    if (a.n_mels != 12345) return;
+#endif
     for (int m = tf; m < a.n_mels; m += Cfg::TF) {
-        T part[2];
+        // both descriptors, then the first UNR pieces of both halves as ONE batch of (predicated) loads: a
+        // single LDS round trip per mel band instead of one per chunk of each half; wider segments (rare:
+        // few mel bands over a large n_fft) finish in the loop
+        constexpr int UNR = 6;
+        int first[2], cnt[2];
         LRA_UNROLL
         for (int h = 0; h < 2; ++h) {  // h = 0: B over segment m; h = 1: A over segment m + 1
             const int d = lds_ld<int>(sh, NB * (int)sizeof(C) + (Cfg::TF + m + h) * (int)sizeof(int));
-            const int first = d & 0xfff, cnt = d >> 12;
-            T acc = (T)0;
-            for (int q0 = 0; q0 < cnt; q0 += 4) {
-                T x[4];
-                LRA_UNROLL
-                for (int q = 0; q < 4; ++q) {
-                    const bool ok = q0 + q < cnt;
-                    x[q] = lds_ld<T>(psum, ((ok ? first + q0 + q : first) * 2 + (1 - h)) * (int)sizeof(T));
-                    if (!ok) x[q] = (T)0;
-                }
-                LRA_UNROLL
-                for (int q = 0; q < 4; ++q) acc += x[q];
+            first[h] = d & 0xfff;
+            cnt[h] = d >> 12;
+        }
+        T x[2][UNR];
+        LRA_UNROLL
+        for (int h = 0; h < 2; ++h) {
+            LRA_UNROLL
+            for (int q = 0; q < UNR; ++q) {
+                const bool ok = q < cnt[h];
+                x[h][q] = lds_ld<T>(psum, ((ok ? first[h] + q : 0) * 2 + (1 - h)) * (int)sizeof(T));  // piece 0 always exists
+                if (!ok) x[h][q] = (T)0;
             }
+        }
+        T part[2];
+        LRA_UNROLL
+        for (int h = 0; h < 2; ++h) {
+            T acc = (T)0;
+            LRA_UNROLL
+            for (int q = 0; q < UNR; ++q) acc += x[h][q];
+            for (int q = UNR; q < cnt[h]; ++q) acc += lds_ld<T>(psum, ((first[h] + q) * 2 + (1 - h)) * (int)sizeof(T));
             part[h] = acc;
         }
         const T v = part[0] + part[1];
@@ -474,7 +583,7 @@ template <class Cfg> inline int stft_slot_bytes(int mode, int n_mels, int tile) 
 // f_first + s*iters + it of clip blk / wg_per_clip, as a private pipeline: all LDS traffic of a slot
 // stays inside the slot (and, when TF <= 64, inside one wave: no s_barrier anywhere).  The mel
 // epilogue stages `mel_tile` frames per row before flushing them as contiguous runs.
-template <class Cfg, int MODE, int PM = POW_TWO> LRA_HD void stft_block(const StftArgs<typename Cfg::real>& a_in, const int blk, Lds lds) {
+template <class Cfg, int MODE, int PM = POW_TWO, bool RA = false> LRA_HD void stft_block(const StftArgs<typename Cfg::real>& a_in, const int blk, Lds lds) {
     StftArgs<typename Cfg::real> a = a_in;
     const int clip = blk / a.wg_per_clip;
     const int f_first = (blk % a.wg_per_clip) * a.frames_per_wg;
@@ -490,54 +599,84 @@ template <class Cfg, int MODE, int PM = POW_TWO> LRA_HD void stft_block(const St
         const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
         stft_ring_fill<Cfg>(a, clip, f_first + slot * iters, tf, lds_sub(lds, slot * slot_bytes + stft_ring_off<Cfg>()));
     } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+    // OUT_MEL2 defers the last two steps of frame t's mel epilogue into frame t+1's phases (their LDS
+    // regions -- piece sums, staging tile -- are not touched by the FFT): combine(t) runs next to the ring
+    // loads / pass 0 of frame t+1 and flush(t) next to its split reads, which saves two workgroup
+    // barriers per frame and lets the loads of both overlap.  The last frame's pair runs after the loop.
+    constexpr bool DEFER = MODE == OUT_MEL2 && !(LRA_ABLATE >= 11 && LRA_ABLATE <= 13);
+    // The mel kernel has no spectrum stores to keep clear of (see the ring notes above), so it fetches the
+    // next frame's samples late -- issued with the split reads, consumed after the piece sums -- which
+    // keeps the NPF prefetch registers out of the FFT passes, where the register pressure peaks.
+#ifndef LRA_MEL_LATE_PF
+#define LRA_MEL_LATE_PF 1
+#endif
+    constexpr bool LATE_PF = DEFER && LRA_MEL_LATE_PF;
+    int done = 0;  // frames of this workgroup's slots processed so far (uniform)
     for (int it = 0; it < iters; ++it) {
         if (f_first + it >= a.n_frames) break;  // slot 0 has the smallest frame index: uniform exit
         if (!Cfg::HOIST) { LRA_LAUNDER(a.win); LRA_LAUNDER(a.tw); LRA_LAUNDER(a.twr); }
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
             const Lds sl = lds_sub(lds, slot * slot_bytes);
-            if (it + 1 < iters) stft_ring_prefetch<Cfg>(a, clip, frame + 1, tf, LRA_R(rg));
-            stft_ring_load_pass0<Cfg>(a, frame, tf, LRA_R(rg), lds_sub(sl, stft_ring_off<Cfg>()), sl);
+            if (!LATE_PF && it + 1 < iters) stft_ring_prefetch<Cfg, RA>(a, clip, frame + 1, tf, LRA_R(rg));
+            if (DEFER && it > 0 && frame - 1 < a.n_frames)
+                mel2_combine<Cfg>(a, clip, frame - 1, tf, (it - 1) % tile, tile, lds_sub(lds, a.shared_off), lds_sub(sl, slot_bytes - mel2_psum_bytes<Cfg>(a.n_mels)), lds_sub(sl, stft_tile_off<Cfg>()));
+            stft_ring_load_pass0<Cfg, RA>(a, frame, tf, LRA_R(rg), lds_sub(sl, stft_ring_off<Cfg>()), sl);
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+#if LRA_ABLATE != 2
         LRA_MID_PASS(Cfg, 1, rg, lds, a.tw, slot_bytes)
         LRA_MID_PASS(Cfg, 2, rg, lds, a.tw, slot_bytes)
         LRA_MID_PASS(Cfg, 3, rg, lds, a.tw, slot_bytes)
+#endif
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
             const Lds sl = lds_sub(lds, slot * slot_bytes);
+            if (LATE_PF && it + 1 < iters) stft_ring_prefetch<Cfg, RA>(a, clip, frame + 1, tf, LRA_R(rg));
             split_read<Cfg>(LRA_R(rg), sl, tf);
-            if (it + 1 < iters) stft_ring_advance<Cfg>(a, clip, frame + 1, tf, LRA_R(rg), lds_sub(sl, stft_ring_off<Cfg>()));
+            if (!LATE_PF && it + 1 < iters) stft_ring_advance<Cfg, RA>(a, clip, frame + 1, tf, LRA_R(rg), lds_sub(sl, stft_ring_off<Cfg>()));
+            if (DEFER && tile > 1 && it > 0 && it % tile == 0)  // the tile that frame it-1 completed
+                mel_flush_tile<Cfg>(a, clip, f_first + slot * iters, it - 1, tile, tf, lds_sub(sl, stft_tile_off<Cfg>()));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
             stft_split_store<Cfg, MODE, PM>(a, clip, frame, frame < a.n_frames, tf, LRA_R(rg), lds_sub(lds, slot * slot_bytes), lds_sub(lds, a.shared_off));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
-        if (MODE == OUT_MEL2) {
+        if (MODE == OUT_MEL2 && LRA_ABLATE != 12 && LRA_ABLATE != 13) {
             LRA_PHASE(Cfg::NT, tid) {
                 const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
                 const Lds sl = lds_sub(lds, slot * slot_bytes);
                 if (frame < a.n_frames) mel2_gather<Cfg>(a, tf, sl, lds_sub(lds, a.shared_off), lds_sub(sl, slot_bytes - mel2_psum_bytes<Cfg>(a.n_mels)));
+                if (LATE_PF && it + 1 < iters) stft_ring_advance<Cfg, RA>(a, clip, frame + 1, tf, LRA_R(rg), lds_sub(sl, stft_ring_off<Cfg>()));
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         }
-        if (MODE == OUT_MEL || MODE == OUT_MEL2) {
+        if (MODE == OUT_MEL) {
             LRA_PHASE(Cfg::NT, tid) {
                 const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
                 const Lds sl = lds_sub(lds, slot * slot_bytes);
-                if (frame < a.n_frames) {
-                    if (MODE == OUT_MEL2) mel2_combine<Cfg>(a, clip, frame, tf, it % tile, tile, lds_sub(lds, a.shared_off), lds_sub(sl, slot_bytes - mel2_psum_bytes<Cfg>(a.n_mels)), lds_sub(sl, stft_tile_off<Cfg>()));
-                    else mel_reduce_slot<Cfg>(a, tf, it % tile, tile, sl, lds_sub(sl, stft_tile_off<Cfg>()));
-                }
+                if (frame < a.n_frames) mel_reduce_slot<Cfg>(a, tf, it % tile, tile, sl, lds_sub(sl, stft_tile_off<Cfg>()));
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
-            if (!(MODE == OUT_MEL2 && tile == 1) && ((it + 1) % tile == 0 || it + 1 == iters || f_first + it + 1 >= a.n_frames)) {
+            if ((it + 1) % tile == 0 || it + 1 == iters || f_first + it + 1 >= a.n_frames) {
                 LRA_PHASE(Cfg::NT, tid) {
                     const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
-                    const int f0 = f_first + slot * iters + (it / tile) * tile;  // first frame of the staged tile
-                    int nv = a.n_frames - f0;
-                    const int staged = it % tile + 1;
-                    nv = nv < 0 ? 0 : (nv > staged ? staged : nv);
-                    mel_flush_slot<Cfg>(a, clip, f0, nv, tf, tile, lds_sub(lds, slot * slot_bytes + stft_tile_off<Cfg>()));
+                    mel_flush_tile<Cfg>(a, clip, f_first + slot * iters, it, tile, tf, lds_sub(lds, slot * slot_bytes + stft_tile_off<Cfg>()));
                 } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
             }
+        }
+        done = it + 1;
+    }
+    if (DEFER && done > 0) {  // epilogue of the last frame
+        const int it = done - 1;
+        LRA_PHASE(Cfg::NT, tid) {
+            const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
+            const Lds sl = lds_sub(lds, slot * slot_bytes);
+            if (frame < a.n_frames)
+                mel2_combine<Cfg>(a, clip, frame, tf, it % tile, tile, lds_sub(lds, a.shared_off), lds_sub(sl, slot_bytes - mel2_psum_bytes<Cfg>(a.n_mels)), lds_sub(sl, stft_tile_off<Cfg>()));
+        } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+        if (tile > 1) {
+            LRA_PHASE(Cfg::NT, tid) {
+                const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
+                mel_flush_tile<Cfg>(a, clip, f_first + slot * iters, it, tile, tf, lds_sub(lds, slot * slot_bytes + stft_tile_off<Cfg>()));
+            } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         }
     }
 }
@@ -716,13 +855,34 @@ template <class Cfg, bool DEFER> LRA_HD void istft_ola_step(const IstftArgs<type
 
 template <class Cfg> LRA_HD void istft_flush_out(const IstftArgs<typename Cfg::real>& a, long long clip, int t, long long write_lo, long long write_hi, int tf,
                                                  const FftRegs<Cfg>& rg) {
+    using T = typename Cfg::real;
     constexpr int NPF = FftRegs<Cfg>::NPF;
     const long long pa = (long long)t * a.hop;
+    // all window-sum-square loads first (clamped index for the lanes that store nothing), then the
+    // divides and stores: one memory round trip per hop instead of one per sample
+    T w[NPF];
+    long long s[NPF];
+    bool ok[NPF];
     LRA_UNROLL
     for (int c = 0; c < NPF; ++c) {
         const int u = tf + c * Cfg::TF;
-        if (u < a.hop) istft_store_sample<Cfg>(a, clip, pa + u, write_lo, write_hi, rg.out[c]);
+        const long long sp = pa + u;
+        s[c] = sp - a.drop;
+        ok[c] = u < a.hop && sp >= write_lo && sp < write_hi && s[c] >= 0 && s[c] < a.out_len;
+        w[c] = a.wss[ok[c] ? s[c] : 0];
     }
+    // normalise unconditionally (lanes that store nothing divide by wss[0]): every load is then consumed
+    // on every control path -- a load left pending behind a skipped branch makes hipcc wait for vmcnt(0),
+    // i.e. for the previous stores too, the next time its destination register is reused
+    T val[NPF];
+    LRA_UNROLL
+    for (int c = 0; c < NPF; ++c) {
+        val[c] = (w[c] > a.tiny) ? rg.out[c] / w[c] : rg.out[c];
+        LRA_KEEP(val[c]);
+    }
+    LRA_UNROLL
+    for (int c = 0; c < NPF; ++c)
+        if (ok[c]) a.y[clip * a.y_stride + s[c]] = val[c];
 }
 
 // One workgroup = FPB slots; slot s owns strip (blk*FPB + s) of the (clip, strip) grid and walks its

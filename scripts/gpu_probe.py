@@ -29,6 +29,12 @@ D = torch.empty((batch, T, 1025), dtype=torch.complex64, device=dev)
 M = torch.empty((batch, 128, T), dtype=torch.float32, device=dev)
 
 
+iplan = ctx.istft_plan(2048, 512, window, True, np.float32)
+_w = filters.window_sumsquare(window="hann", n_frames=T, n_fft=2048, hop_length=512, dtype=np.float32)[1024:]
+wss = torch.from_numpy(np.ascontiguousarray(np.pad(_w, (0, max(0, n - len(_w))))[:n], dtype=np.float32)).to(dev)
+yrec = torch.empty((batch, n), dtype=torch.float32, device=dev)
+
+
 def timeit(fn, steps=10):
     for _ in range(3):
         fn()
@@ -44,16 +50,23 @@ def timeit(fn, steps=10):
 
 what = sys.argv[1] if len(sys.argv) > 1 else "ablate"
 if what == "ablate":
-    for variant in (4, 0):
+    # run once per probe build:  LIBROSA_AMD_LIBRARY=probe/lib_abN.so python scripts/gpu_probe.py ablate
+    # (hipcc -DLRA_PROBE_ONLY -DLRA_ABLATE=N: 1 = no spectrum stores, 2 = no FFT math, stores only)
+    for variant in (0, 4):
         ctx.set_option("variant", variant)
-        for iters in (16,):
+        for iters in (16, 32):
             ctx.set_option("stft_iters", iters)
-            for ab in (0, 1, 2, 3, 7):
-                ctx.set_option("ablate", ab)
-                ms = timeit(lambda: ctx.stft_exec(plan, y.data_ptr(), batch, n, n, D.data_ptr()))
-                msm = timeit(lambda: ctx.melspectrogram_exec(plan, mel_plan, y.data_ptr(), batch, n, n, 2.0, M.data_ptr()))
-                print(f"variant {variant} iters {iters} ablate {ab}: stft {ms:.3f} ms ({batch * T / ms / 1e3:.1f} Mframes/s)   mel {msm:.3f} ms ({batch * T / msm / 1e3:.1f} Mframes/s)", flush=True)
-    ctx.set_option("ablate", 0)
+            ms = timeit(lambda: ctx.stft_exec(plan, y.data_ptr(), batch, n, n, D.data_ptr()))
+            print(f"{os.environ.get('LIBROSA_AMD_LIBRARY', 'product')}: variant {variant} iters {iters}: stft {ms:.3f} ms ({batch * T / ms / 1e3:.1f} Mframes/s)", flush=True)
+elif what == "iters":
+    for variant in (0, 4):
+        ctx.set_option("variant", variant)
+        for iters in [int(v) for v in os.environ.get("PROBE_ITERS", "16,21,27,32,41,54,62,81,108,162,324").split(",")]:
+            ctx.set_option("stft_iters", iters)
+            ms = timeit(lambda: ctx.stft_exec(plan, y.data_ptr(), batch, n, n, D.data_ptr()))
+            msm = timeit(lambda: ctx.melspectrogram_exec(plan, mel_plan, y.data_ptr(), batch, n, n, 2.0, M.data_ptr()))
+            msi = timeit(lambda: ctx.istft_exec(iplan, D.data_ptr(), batch, T * 1025, 1025, T, wss.data_ptr(), yrec.data_ptr(), n, n))
+            print(f"variant {variant} iters {iters}: stft {ms:.3f} ms ({batch * T / ms / 1e3:.1f} Mframes/s)   mel {msm:.3f} ms ({batch * T / msm / 1e3:.1f} Mframes/s)   istft {msi:.3f} ms ({batch * T / msi / 1e3:.1f} Mframes/s)", flush=True)
 elif what == "occupancy":
     for variant in (0, 4):
         ctx.set_option("variant", variant)

