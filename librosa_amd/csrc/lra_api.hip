@@ -189,7 +189,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void stft_kernel(StftArgs<
     stft_block<Cfg, MODE, PM, RA>(a, (int)blockIdx.x, lds);
 }
 
-template <class Cfg>
+template <class Cfg, int HC>
 __global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void istft_kernel(IstftArgs<typename Cfg::real> a, const typename Cfg::cplx* __restrict__ D,
                                                                       const typename Cfg::real* __restrict__ wss, typename Cfg::real* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) char lra_smem[];
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void istft_kernel(IstftArg
     a.D = D;
     a.wss = wss;
     a.y = y;
-    istft_block<Cfg>(a, (int)blockIdx.x, lds);
+    istft_block<Cfg, HC>(a, (int)blockIdx.x, lds);
 }
 
 namespace {
@@ -305,8 +305,18 @@ template <class T> struct IstftLaunch {
         a.batch = batch;
         const long long grid = (batch * a.strips_per_clip + FPB - 1) / FPB;
         if (grid > 0x7fffffffLL) { err = hipErrorInvalidConfiguration; return; }
-        constexpr int lds = istft_lds_bytes<Cfg>();
-        void (*kern)(IstftArgs<T>, const cx<T>*, const T*, T*) = istft_kernel<Cfg>;
+        int lds = istft_lds_bytes<Cfg, false>();
+        void (*kern)(IstftArgs<T>, const cx<T>*, const T*, T*) = istft_kernel<Cfg, 0>;
+        if constexpr (sizeof(T) == 4) {  // row-aligned overlap-add for hop = n_fft/4 and n_fft/8 (f32)
+            const int hc = istft_rows_hc<Cfg>(a.hop);
+            if constexpr (Cfg::R >= 4) {
+                if (hc == Cfg::R / 4) kern = istft_kernel<Cfg, Cfg::R / 4>;
+            }
+            if constexpr (Cfg::R >= 8) {
+                if (hc == Cfg::R / 8) kern = istft_kernel<Cfg, Cfg::R / 8>;
+            }
+            if (hc > 0) lds = istft_lds_bytes<Cfg, true>();
+        }
         if (lds > 65536) {
             err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (err != hipSuccess) return;
@@ -528,7 +538,7 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
         L.a.win = (const T*)p->d_win;
         // measured on MI355X (bench.py --sweep): the two-wave-per-frame configuration wins when the mel
         // epilogue is fused in, the one-wave-per-frame configuration for the plain spectrum
-        const int variant = ctx->opt_variant >= 0 ? ctx->opt_variant : (mode == OUT_MEL ? 4 : 0);
+        const int variant = ctx->opt_variant >= 0 ? ctx->opt_variant : 0;  // one wave per frame: measured best for all three epilogues
         L.a.tw = (const cx<T>*)p->d_tw[variant];
         L.a.twr = (const cx<T>*)p->d_twr;
         L.out = out;
@@ -608,7 +618,7 @@ int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_s
         L.a.hop = p->hop;
         L.a.drop = p->center ? N / 2 : 0;
         L.a.win_scaled = (const T*)p->d_win_scaled;
-        const int variant = ctx->opt_variant >= 0 ? ctx->opt_variant : 4;  // measured: two waves per frame wins for the inverse
+        const int variant = ctx->opt_variant >= 0 ? ctx->opt_variant : 0;  // measured: one wave per frame (305 vs 278 Mframes/s for the two-wave variant)
         L.a.tw = (const cx<T>*)p->d_tw[variant];
         L.a.twr = (const cx<T>*)p->d_twr;
         L.a.wss = (const T*)wss;

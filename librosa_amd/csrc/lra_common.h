@@ -41,6 +41,143 @@ template <class T> LRA_HD cx<T> cconj(cx<T> a) { return mk<T>(a.x, -a.y); }
 // multiply by -i (forward-transform quarter turn)
 template <class T> LRA_HD cx<T> cmul_mi(cx<T> a) { return mk<T>(a.y, -a.x); }
 
+// ----------------------------------------------------------------------------- packed-f32 complex arithmetic
+// A complex float lives in an aligned VGPR pair, and gfx950's packed-f32 VALU ops (v_pk_add/mul/fma_f32)
+// can read either half of each source for either half of the result (op_sel / op_sel_hi) and negate per
+// half (neg_lo / neg_hi).  Every rotation-and-add of a butterfly -- a -+ i b, conj, a + k (-i u), the
+// complex multiply -- is therefore ONE or TWO instructions on whole pairs.  hipcc only finds the
+// symmetric forms (both halves negated); for the others it computes two packed results and splices their
+// halves with v_mov (28 % of the FFT phases' VALU instructions were such moves), so the asymmetric
+// forms are spelled out here.  The plain C++ bodies are the definition (used for double, for the host
+// pass and by the CPU simulator); the asm is the same arithmetic, IEEE-identical per lane.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LRA_NO_PK_ASM)
+#define LRA_PK_ASM 1
+namespace pk {
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 v(cx<float> a) { return __builtin_bit_cast(f2, a); }
+__device__ __forceinline__ cx<float> c(f2 a) { return __builtin_bit_cast(cx<float>, a); }
+// r.lo = (+-a.lo) + (+-b[S1L]);  r.hi = (+-a.hi) + (+-b[S1H])      (N..: 1 = negate that operand half)
+template <int S1L, int S1H, int N0L, int N0H, int N1L, int N1H> __device__ __forceinline__ f2 add(f2 a, f2 b) {
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,%3] op_sel_hi:[1,%4] neg_lo:[%5,%6] neg_hi:[%7,%8]"
+        : "=v"(r) : "v"(a), "v"(b), "n"(S1L), "n"(S1H), "n"(N0L), "n"(N1L), "n"(N0H), "n"(N1H));
+    return r;
+}
+// r.lo = a[S0L] * b[S1L];  r.hi = a[S0H] * b[S1H]
+template <int S0L, int S0H, int S1L, int S1H> __device__ __forceinline__ f2 mul(f2 a, f2 b) {
+    f2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[%3,%4] op_sel_hi:[%5,%6]" : "=v"(r) : "v"(a), "v"(b), "n"(S0L), "n"(S1L), "n"(S0H), "n"(S1H));
+    return r;
+}
+// r.lo = (+-a[S0L]) * b[S1L] + c.lo;  r.hi = (+-a[S0H]) * b[S1H] + c.hi
+template <int S0L, int S0H, int S1L, int S1H, int NL, int NH> __device__ __forceinline__ f2 fma(f2 a, f2 b, f2 c) {
+    f2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[%4,%5,0] op_sel_hi:[%6,%7,1] neg_lo:[%8,0,0] neg_hi:[%9,0,0]"
+        : "=v"(r) : "v"(a), "v"(b), "v"(c), "n"(S0L), "n"(S1L), "n"(S0H), "n"(S1H), "n"(NL), "n"(NH));
+    return r;
+}
+}  // namespace pk
+#endif
+
+// a - i b  and  a + i b
+template <class T> LRA_HD cx<T> add_mi(cx<T> a, cx<T> b) {
+#ifdef LRA_PK_ASM
+    if constexpr (sizeof(T) == 4) return pk::c(pk::add<1, 0, 0, 0, 0, 1>(pk::v(a), pk::v(b)));
+#endif
+    return mk<T>(a.x + b.y, a.y - b.x);
+}
+template <class T> LRA_HD cx<T> sub_mi(cx<T> a, cx<T> b) {
+#ifdef LRA_PK_ASM
+    if constexpr (sizeof(T) == 4) return pk::c(pk::add<1, 0, 0, 0, 1, 0>(pk::v(a), pk::v(b)));
+#endif
+    return mk<T>(a.x - b.y, a.y + b.x);
+}
+// a + conj(b)  and  a - conj(b)
+template <class T> LRA_HD cx<T> add_conj(cx<T> a, cx<T> b) {
+#ifdef LRA_PK_ASM
+    if constexpr (sizeof(T) == 4) return pk::c(pk::add<0, 1, 0, 0, 0, 1>(pk::v(a), pk::v(b)));
+#endif
+    return mk<T>(a.x + b.x, a.y - b.y);
+}
+template <class T> LRA_HD cx<T> sub_conj(cx<T> a, cx<T> b) {
+#ifdef LRA_PK_ASM
+    if constexpr (sizeof(T) == 4) return pk::c(pk::add<0, 1, 0, 0, 1, 0>(pk::v(a), pk::v(b)));
+#endif
+    return mk<T>(a.x - b.x, a.y + b.y);
+}
+// conj(a - b)  and  -conj(a + i b) = (-(a.x - b.y), a.y + b.x) ... spelled by their components below
+template <class T> LRA_HD cx<T> conj_sub(cx<T> a, cx<T> b) {  // (a.x - b.x, b.y - a.y)
+#ifdef LRA_PK_ASM
+    if constexpr (sizeof(T) == 4) return pk::c(pk::add<0, 1, 0, 1, 1, 0>(pk::v(a), pk::v(b)));
+#endif
+    return mk<T>(a.x - b.x, b.y - a.y);
+}
+template <class T> LRA_HD cx<T> conj_add_mi_neg(cx<T> a, cx<T> b) {  // (a.x - b.y, -a.y - b.x) = conj(a + i b)
+#ifdef LRA_PK_ASM
+    if constexpr (sizeof(T) == 4) return pk::c(pk::add<1, 0, 0, 1, 1, 1>(pk::v(a), pk::v(b)));
+#endif
+    return mk<T>(a.x - b.y, -a.y - b.x);
+}
+// a * w  and  a * conj(w): two instructions
+template <class T> LRA_HD cx<T> cmul2(cx<T> a, cx<T> w) {
+#ifdef LRA_PK_ASM
+    if constexpr (sizeof(T) == 4) {
+        const pk::f2 p = pk::mul<0, 1, 0, 0>(pk::v(a), pk::v(w));                  // (a.x w.x, a.y w.x)
+        return pk::c(pk::fma<1, 0, 1, 1, 1, 0>(pk::v(a), pk::v(w), p));            // (-a.y w.y + ., a.x w.y + .)
+    }
+#endif
+    return cmul(a, w);
+}
+// the same product as two separately schedulable halves, p = cmul_p(a, w) then cmul_f(a, w, p): callers
+// with several independent products issue all the p's first (a packed result cannot feed the very next
+// instruction without a wait state)
+template <class T> LRA_HD cx<T> cmul_p(cx<T> a, cx<T> w) {
+#ifdef LRA_PK_ASM
+    if constexpr (sizeof(T) == 4) return pk::c(pk::mul<0, 1, 0, 0>(pk::v(a), pk::v(w)));
+#endif
+    return mk<T>(a.x * w.x, a.y * w.x);
+}
+template <class T> LRA_HD cx<T> cmul_f(cx<T> a, cx<T> w, cx<T> p) {
+#ifdef LRA_PK_ASM
+    if constexpr (sizeof(T) == 4) return pk::c(pk::fma<1, 0, 1, 1, 1, 0>(pk::v(a), pk::v(w), pk::v(p)));
+#endif
+    return mk<T>(p.x - a.y * w.y, p.y + a.x * w.y);
+}
+template <class T> LRA_HD cx<T> cmul2_conj(cx<T> a, cx<T> w) {
+#ifdef LRA_PK_ASM
+    if constexpr (sizeof(T) == 4) {
+        const pk::f2 p = pk::mul<0, 1, 0, 0>(pk::v(a), pk::v(w));                  // (a.x w.x, a.y w.x)
+        return pk::c(pk::fma<1, 0, 1, 1, 0, 1>(pk::v(a), pk::v(w), p));            // (a.y w.y + ., -a.x w.y + .)
+    }
+#endif
+    return mk<T>(a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y);
+}
+// (-i a) * w = (a.y w.x + a.x w.y, a.y w.y - a.x w.x): two instructions
+template <class T> LRA_HD cx<T> cmul2_mi(cx<T> a, cx<T> w) {
+#ifdef LRA_PK_ASM
+    if constexpr (sizeof(T) == 4) {
+        const pk::f2 p = pk::mul<0, 1, 1, 1>(pk::v(a), pk::v(w));                  // (a.x w.y, a.y w.y)
+        return pk::c(pk::fma<1, 0, 0, 0, 0, 1>(pk::v(a), pk::v(w), p));            // (a.y w.x + ., -a.x w.x + .)
+    }
+#endif
+    return mk<T>(a.y * w.x + a.x * w.y, a.y * w.y - a.x * w.x);
+}
+// acc + k (-i u) = (acc.x + k u.y, acc.y - k u.x)  and  acc - k (-i u); k real, passed as the pair (k, k)
+template <class T> LRA_HD cx<T> axpy_mi(T k, cx<T> u, cx<T> acc) {
+#ifdef LRA_PK_ASM
+    if constexpr (sizeof(T) == 4) return pk::c(pk::fma<1, 0, 0, 0, 0, 1>(pk::v(u), pk::v(mk<T>(k, k)), pk::v(acc)));
+#endif
+    return mk<T>(acc.x + k * u.y, acc.y - k * u.x);
+}
+template <class T> LRA_HD cx<T> axpy_pi(T k, cx<T> u, cx<T> acc) {
+#ifdef LRA_PK_ASM
+    if constexpr (sizeof(T) == 4) return pk::c(pk::fma<1, 0, 0, 0, 1, 0>(pk::v(u), pk::v(mk<T>(k, k)), pk::v(acc)));
+#endif
+    return mk<T>(acc.x - k * u.y, acc.y + k * u.x);
+}
+// acc + k u, k real
+template <class T> LRA_HD cx<T> axpy(T k, cx<T> u, cx<T> acc) { return mk<T>(acc.x + k * u.x, acc.y + k * u.y); }
+
 // pad modes for centred framing (np.pad modes the reference forwards, core/spectrum.py:287)
 enum PadMode : int { PAD_CONSTANT = 0, PAD_REFLECT = 1, PAD_EDGE = 2, PAD_SYMMETRIC = 3 };
 
@@ -126,6 +263,8 @@ inline Lds lds_sub(Lds l, int byte_off) { Lds r; r.base = l.base + byte_off; ret
 #define LRA_ATOMIC_OR(ptr, v) (*(ptr) |= (v))
 #define LRA_UNIFORM(x) (x)
 #define LRA_KEEP(x) ((void)0)
+#define LRA_RAW_TID(tid) (tid)
+template <class T> inline T fast_div(T x, T w) { return x / w; }
 template <class V> inline void stream_store(V* p, V v) { *p = v; }
 #define LRA_PHASE(NT, tid) for (int tid = 0; tid < (NT); ++tid) { ::lra::sim::state().cur_tid = tid;
 #define LRA_PHASE_END } ::lra::sim::state().barrier();
@@ -150,6 +289,11 @@ LRA_HD Lds lds_sub(Lds l, int byte_off) { Lds r; r.base = l.base + byte_off; ret
 #define LRA_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 // pins a value's computation where it is written (hipcc may not sink it into a later branch)
 #define LRA_KEEP(x) asm volatile("" : "+v"(x))
+// the hardware thread index without the per-phase launder (for values that SHOULD be hoisted)
+#define LRA_RAW_TID(tid) ((int)threadIdx.x)
+// x / w for normal w: v_rcp_f32 + v_mul (<= 1 ulp) instead of the ~12-instruction IEEE division sequence
+__device__ __forceinline__ float fast_div(float x, float w) { return x * __builtin_amdgcn_rcpf(w); }
+__device__ __forceinline__ double fast_div(double x, double w) { return x / w; }
 // Output that is written once and not read again by this kernel: a non-temporal (streaming) store.
 #ifndef LRA_NT_STORE
 #define LRA_NT_STORE 0  // measured on MI355X: no gain for the spectrum rows (the L2 write-back path already streams them)

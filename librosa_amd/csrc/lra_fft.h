@@ -90,20 +90,51 @@ template <class T> LRA_HD cx<T> mul_w16(cx<T> a, int idx) {
     }
 }
 
+// One radix-2 butterfly of the recursion below with the twiddle W16^idx folded in:
+// p = e + W16^idx o,  m = e - W16^idx o.  Every case is 2..4 packed instructions (lra_common.h).
+template <int idx, class T> LRA_HD void bfly_w16(cx<T> e, cx<T> o, cx<T>& p, cx<T>& m) {
+    const T h = (T)0.70710678118654752440;
+    const T c1 = (T)0.92387953251128675613, s1 = (T)0.38268343236508977173;
+    if constexpr (idx == 0) {
+        p = cadd(e, o);
+        m = csub(e, o);
+    } else if constexpr (idx == 4) {  // W = -i
+        p = add_mi(e, o);
+        m = sub_mi(e, o);
+    } else if constexpr (idx == 2) {  // W = h (1 - i):  W o = h u,  u = o - i o
+        const cx<T> u = add_mi(o, o);
+        p = axpy(h, u, e);
+        m = axpy(-h, u, e);
+    } else if constexpr (idx == 6) {  // W = -i h (1 - i):  W o = h (-i u)
+        const cx<T> u = add_mi(o, o);
+        p = axpy_mi(h, u, e);
+        m = axpy_pi(h, u, e);
+    } else if constexpr (idx == 1 || idx == 3) {  // W = c - i s:  W o = c o + s (-i o)
+        const T c = idx == 1 ? c1 : s1, s = idx == 1 ? s1 : c1;
+        p = axpy_mi(s, o, axpy(c, o, e));
+        m = axpy_pi(s, o, axpy(-c, o, e));
+    } else {  // idx 5, 7:  W = -i (c - i s):  W o = c (-i o) - s o
+        const T c = idx == 5 ? c1 : s1, s = idx == 5 ? s1 : c1;
+        p = axpy_mi(c, o, axpy(-s, o, e));
+        m = axpy_pi(c, o, axpy(s, o, e));
+    }
+}
+
 // In-place forward DFT of r points (natural order in, natural order out), r in {1,2,4,8,16}.
 template <int r, class T> struct Dft {
+    template <int k> static LRA_HD void stage(cx<T>* v, const cx<T>* e, const cx<T>* o) {
+        if constexpr (k < r / 2) {
+            bfly_w16<k * (16 / r), T>(e[k], o[k], v[k], v[k + r / 2]);
+            stage<k + 1>(v, e, o);
+        }
+    }
     static LRA_HD void run(cx<T>* v) {
         cx<T> e[r / 2], o[r / 2];
         LRA_UNROLL
         for (int k = 0; k < r / 2; ++k) { e[k] = v[2 * k]; o[k] = v[2 * k + 1]; }
         Dft<r / 2, T>::run(e);
         Dft<r / 2, T>::run(o);
-        LRA_UNROLL
-        for (int k = 0; k < r / 2; ++k) {
-            const cx<T> t = mul_w16<T>(o[k], k * (16 / r));
-            v[k] = cadd(e[k], t);
-            v[k + r / 2] = csub(e[k], t);
-        }
+        stage<0>(v, e, o);
     }
 };
 template <class T> struct Dft<1, T> {
@@ -157,14 +188,20 @@ template <class Cfg, int p> LRA_HD void pass_twiddle_dft(typename Cfg::cplx* v, 
         const int b = tf + i * Cfg::TF;
         if (p > 0) {
             const int k = b & (s - 1);
+            typename Cfg::cplx q[r];
             LRA_UNROLL
-            for (int j = 1; j < r; ++j) v[i * r + j] = cmul(v[i * r + j], tw[Cfg::tw_off(p) + (j - 1) * s + k]);
+            for (int j = 1; j < r; ++j) q[j] = cmul_p(v[i * r + j], tw[Cfg::tw_off(p) + (j - 1) * s + k]);
+            LRA_UNROLL
+            for (int j = 1; j < r; ++j) v[i * r + j] = cmul_f(v[i * r + j], tw[Cfg::tw_off(p) + (j - 1) * s + k], q[j]);
         }
         Dft<r, T>::run(v + i * r);
     }
 }
 
 // Same, with this thread's twiddles already sitting in registers (see load_pass_twiddles).
+constexpr int popcount_c(int j) { int c = 0; for (; j; j >>= 1) c += j & 1; return c; }
+constexpr int msb_c(int j) { int m = 0; for (int t = 0; t < 16; ++t) if ((j >> t) & 1) m = t; return m; }
+
 template <class Cfg, int p> LRA_HD void pass_twiddle_dft_reg(typename Cfg::cplx* v, const typename Cfg::cplx* treg) {
     using T = typename Cfg::real;
     using C = typename Cfg::cplx;
@@ -172,16 +209,26 @@ template <class Cfg, int p> LRA_HD void pass_twiddle_dft_reg(typename Cfg::cplx*
     LRA_UNROLL
     for (int i = 0; i < nb; ++i) {
         if (p > 0) {
-            C w[r];  // w[j] = W^(k j); built from the stored powers of two
+            // w[j] = W^(k j) from the stored powers of two: w^j = w^(j - msb j) * w^(msb j), level by level
+            // (number of set bits of j), each level as a batch of independent products; then the r - 1
+            // twiddle multiplies as another batch
+            C w[r], q[r];
             LRA_UNROLL
-            for (int j = 1; j < r; ++j) {
-                int msb = 0;
+            for (int j = 1; j < r; ++j)
+                if (popcount_c(j) == 1) w[j] = treg[Cfg::treg_off(p) + i * lr + msb_c(j)];
+            LRA_UNROLL
+            for (int level = 2; level <= lr; ++level) {
                 LRA_UNROLL
-                for (int t = 0; t < lr; ++t) if ((j >> t) & 1) msb = t;
-                const int rest = j - (1 << msb);
-                w[j] = rest == 0 ? treg[Cfg::treg_off(p) + i * lr + msb] : cmul(w[rest], treg[Cfg::treg_off(p) + i * lr + msb]);
-                v[i * r + j] = cmul(v[i * r + j], w[j]);
+                for (int j = 1; j < r; ++j)
+                    if (popcount_c(j) == level) q[j] = cmul_p(w[j - (1 << msb_c(j))], treg[Cfg::treg_off(p) + i * lr + msb_c(j)]);
+                LRA_UNROLL
+                for (int j = 1; j < r; ++j)
+                    if (popcount_c(j) == level) w[j] = cmul_f(w[j - (1 << msb_c(j))], treg[Cfg::treg_off(p) + i * lr + msb_c(j)], q[j]);
             }
+            LRA_UNROLL
+            for (int j = 1; j < r; ++j) q[j] = cmul_p(v[i * r + j], w[j]);
+            LRA_UNROLL
+            for (int j = 1; j < r; ++j) v[i * r + j] = cmul_f(v[i * r + j], w[j], q[j]);
         }
         Dft<r, T>::run(v + i * r);
     }

@@ -89,6 +89,7 @@ template <class Cfg> struct FftRegs {
     // frame, and the current hop's finished output samples held back until that prefetch has landed
     typename Cfg::cplx xk[Cfg::R / 2 > 0 ? Cfg::R / 2 : 1], xm[Cfg::R / 2 > 0 ? Cfg::R / 2 : 1], xmid;
     typename Cfg::real out[NPF];
+    typename Cfg::real wv[NPF];  // ISTFT (row-aligned): window sum-square values of the held-back samples, loaded a frame ahead
     static constexpr int NH = Cfg::HOIST ? 1 : 0;
     typename Cfg::cplx win2[NH * Cfg::R + 1 - NH];       // window pairs in pass-0 register order
     typename Cfg::cplx treg[NH * Cfg::TREG_TOTAL + 1 - NH];
@@ -344,11 +345,10 @@ template <class Cfg> LRA_HD void split_read(FftRegs<Cfg>& rg, Lds fr, int tf) {
 // X[k] = A + B, X[M-k] = conj(A - B).  The factor 1/2 is folded into the window table of the fused
 // kernels (StftArgs::win holds 0.5 w, an exact scaling), so Z arrives pre-halved here.
 template <class T> LRA_HD void split_pair(cx<T> zk, cx<T> zm, cx<T> w, cx<T>& xk, cx<T>& xm) {
-    const cx<T> A = mk<T>(zk.x + zm.x, zk.y - zm.y);
-    const cx<T> O = mk<T>(zk.y + zm.y, zm.x - zk.x);
-    const cx<T> B = cmul(w, O);
+    const cx<T> A = add_conj(zk, zm);
+    const cx<T> B = cmul2_mi(sub_conj(zk, zm), w);  // W (-i)(Zk - conj Zm)
     xk = cadd(A, B);
-    xm = cconj(csub(A, B));
+    xm = conj_sub(A, B);
 }
 
 // ---- phase: split + epilogue store (complex / power) or power -> LDS (mel) --------------------
@@ -707,8 +707,9 @@ template <class T> struct IstftArgs {
 };
 
 // per slot: frame area + double-buffered carry of N reals (>= N - hop for any hop >= 1)
-template <class Cfg> constexpr int istft_slot_bytes() { return Cfg::FRAME_BYTES + 2 * Cfg::N * (int)sizeof(typename Cfg::real); }
-template <class Cfg> constexpr int istft_lds_bytes() { return Cfg::FPB * istft_slot_bytes<Cfg>(); }
+// (the row-aligned overlap-add updates its carry in place: one buffer)
+template <class Cfg, bool ROWS = false> constexpr int istft_slot_bytes() { return Cfg::FRAME_BYTES + (ROWS ? 1 : 2) * Cfg::N * (int)sizeof(typename Cfg::real); }
+template <class Cfg, bool ROWS = false> constexpr int istft_lds_bytes() { return Cfg::FPB * istft_slot_bytes<Cfg, ROWS>(); }
 
 // ---- spectrum prefetch: X[k], X[M-k] (k = tf + i TF) and X[M/2] of one frame -> registers ------------
 template <class Cfg> LRA_HD void istft_spec_load(const IstftArgs<typename Cfg::real>& a, long long clip, int frame, bool valid, int tf, FftRegs<Cfg>& rg) {
@@ -723,10 +724,12 @@ template <class Cfg> LRA_HD void istft_spec_load(const IstftArgs<typename Cfg::r
         return;
     }
     const C* __restrict__ X = a.D + clip * a.d_batch_stride + (long long)frame * a.d_frame_stride;
+    const C* __restrict__ Xk = X + tf;        // ascending bins: one base, immediate offsets
+    const C* __restrict__ Xm = X + (M - tf);  // mirrored bins descend from the other
     LRA_UNROLL
     for (int i = 0; i < Cfg::R / 2; ++i) {
-        rg.xk[i] = X[tf + i * Cfg::TF];
-        rg.xm[i] = X[M - tf - i * Cfg::TF];  // tf = 0, i = 0: X[M], the Nyquist bin
+        rg.xk[i] = Xk[i * Cfg::TF];
+        rg.xm[i] = Xm[-i * Cfg::TF];  // tf = 0, i = 0: X[M], the Nyquist bin
     }
     rg.xmid = X[M / 2];
 }
@@ -745,15 +748,18 @@ template <class Cfg> LRA_HD void istft_split_write(const IstftArgs<typename Cfg:
         if (k == 0) {
             lds_st<C>(fr, Cfg::phys(0) * (int)sizeof(C), mk<T>(xk.x + xm.x, -(xk.x - xm.x)));
         } else {
-            const C E = mk<T>(xk.x + xm.x, xk.y - xm.y);
-            const C Dif = mk<T>(xk.x - xm.x, xk.y + xm.y);
-            const C O = cmul(Dif, cconj(Cfg::HOIST ? rg.twr[i] : a.twr[k]));
+            const C E = add_conj(xk, xm);
+            const C O = cmul2_conj(sub_conj(xk, xm), Cfg::HOIST ? rg.twr[i] : a.twr[k]);
             // Z'[k] = (E.x - O.y, E.y + O.x);  Z'[M-k] = (E.x + O.y, O.x - E.y); store conjugates
-            lds_st<C>(fr, Cfg::phys(k) * (int)sizeof(C), mk<T>(E.x - O.y, -(E.y + O.x)));
-            lds_st<C>(fr, Cfg::phys(M - k) * (int)sizeof(C), mk<T>(E.x + O.y, -(O.x - E.y)));
+            lds_st<C>(fr, Cfg::phys(k) * (int)sizeof(C), conj_add_mi_neg(E, O));
+            lds_st<C>(fr, Cfg::phys(M - k) * (int)sizeof(C), add_mi(E, O));
         }
     }
-    if (tf == 0) lds_st<C>(fr, Cfg::phys(M / 2) * (int)sizeof(C), mk<T>((T)2 * rg.xmid.x, (T)2 * rg.xmid.y));  // conj(2 conj X[M/2])
+    // (consumed by every lane, not only tf = 0: a load left pending behind a skipped branch costs a vmcnt(0) later)
+    C mid2 = mk<T>((T)2 * rg.xmid.x, (T)2 * rg.xmid.y);  // conj(2 conj X[M/2])
+    LRA_KEEP(mid2.x);
+    LRA_KEEP(mid2.y);
+    if (tf == 0) lds_st<C>(fr, Cfg::phys(M / 2) * (int)sizeof(C), mid2);
 }
 
 // ---- phase: last pass butterflies, then windowed time-domain frame -> LDS (natural order) ------
@@ -853,6 +859,105 @@ template <class Cfg, bool DEFER> LRA_HD void istft_ola_step(const IstftArgs<type
     }
 }
 
+// ---- row-aligned overlap-add (hop a multiple of 2 TF, hop <= n_fft/4) -----------------------------------
+// Thread tf owns the sample PAIRS p = tf + c TF (c < R) of the frame span, i.e. one residue class mod TF.
+// Because the hop is a whole number hc of such rows, (a) "final vs. carry" is a wave-uniform property of
+// c -- no per-sample bound tests --, (b) the carry shift by one hop maps a thread's pairs onto its own
+// pairs, so the carry is updated IN PLACE (reads of a chunk before its writes; chunks ascend), and
+// (c) every LDS access is one per-thread base plus an immediate, as 8-byte reads and writes.
+// The row count per hop, hc = hop / (2 TF), is a compile-time parameter HC of the kernel (all "final or
+// carry?" decisions fold away); instantiated for hop = n_fft/4 (HC = R/4) and hop = n_fft/8 (HC = R/8).
+template <class Cfg> LRA_HD int istft_rows_hc(int hop) {
+    if (Cfg::R >= 4 && 4 * hop == Cfg::N) return Cfg::R / 4;
+    if (Cfg::R >= 8 && 8 * hop == Cfg::N) return Cfg::R / 8;
+    return 0;
+}
+
+template <class Cfg, int HC> LRA_HD void istft_ola_rows(const IstftArgs<typename Cfg::real>& a, bool contribute, int tf, FftRegs<Cfg>& rg, Lds slot_lds) {
+    using T = typename Cfg::real;
+    using C = typename Cfg::cplx;
+    constexpr int R = Cfg::R, TF = Cfg::TF, CH = R < 8 ? R : 8;
+    constexpr int hc = HC;       // final pairs per thread (<= R/4)
+    constexpr int clc = R - hc;  // carry pairs per thread
+    const Lds fr = slot_lds;
+    const Lds carry = lds_sub(slot_lds, Cfg::FRAME_BYTES);
+    const C zero = mk<T>((T)0, (T)0);
+    const int rbase = tf * (int)sizeof(C);
+    const int wbase = (tf - hc * TF) * (int)sizeof(C);  // pair p lands on pair p - hc TF
+    LRA_UNROLL
+    for (int c0 = 0; c0 < R; c0 += CH) {
+        C cv[CH], fv[CH];
+        LRA_UNROLL
+        for (int q = 0; q < CH; ++q) {
+            const int c = c0 + q;
+            cv[q] = c < clc ? lds_ld<C>(carry, rbase + c * TF * (int)sizeof(C)) : zero;
+            fv[q] = contribute ? lds_ld<C>(fr, rbase + c * TF * (int)sizeof(C)) : zero;
+        }
+        LRA_UNROLL
+        for (int q = 0; q < CH; ++q) {
+            const int c = c0 + q;
+            const C val = cadd(cv[q], fv[q]);
+            if (c < hc) {
+                if (2 * c + 1 < FftRegs<Cfg>::NPF) { rg.out[2 * c] = val.x; rg.out[2 * c + 1] = val.y; }
+            } else {
+                lds_st<C>(carry, wbase + c * TF * (int)sizeof(C), val);
+            }
+        }
+    }
+}
+
+// held-back samples of frame t -> y: pair c of thread tf is padded positions t hop + 2 (tf + c TF) + {0, 1}.
+// istft_wss_rows loads their window sum-square values while frame t is still being transformed (one whole
+// frame ahead of the stores); lanes that will store nothing read wss[0].
+// A frame's held-back samples are stored iff the frame lies in the slot's strip (wave-uniform: the
+// [write_lo, write_hi) test of the general path, taken over whole hops) and the sample index falls inside
+// the output: per thread two 32-bit offset bounds, worked out once per frame.
+template <class Cfg> struct IstftRowWin {
+    long long s0;    // output index of this thread's pair 0, sample 0
+    int lo, hi;      // offsets off with lo <= off < hi are inside [0, out_len)
+};
+template <class Cfg> LRA_HD IstftRowWin<Cfg> istft_row_window(const IstftArgs<typename Cfg::real>& a, int t, bool in_strip, int tf) {
+    IstftRowWin<Cfg> w;
+    w.s0 = (long long)t * a.hop + 2 * tf - a.drop;
+    const long long big = 1 << 30;
+    long long lo = -w.s0, hi = a.out_len - w.s0;
+    lo = lo < -big ? -big : (lo > big ? big : lo);
+    hi = hi < -big ? -big : (hi > big ? big : hi);
+    w.lo = (int)lo;
+    w.hi = in_strip ? (int)hi : w.lo;  // empty window when the frame is outside the strip
+    return w;
+}
+template <class Cfg, int HC> LRA_HD void istft_wss_rows(const IstftArgs<typename Cfg::real>& a, int t, bool in_strip, int tf, FftRegs<Cfg>& rg) {
+    using T = typename Cfg::real;
+    constexpr int TF = Cfg::TF;
+    const IstftRowWin<Cfg> w = istft_row_window<Cfg>(a, t, in_strip, tf);
+    const T* __restrict__ wb = a.wss + w.s0;
+    LRA_UNROLL
+    for (int i = 0; i < 2 * HC; ++i) {
+        const int off = 2 * (i >> 1) * TF + (i & 1);
+        rg.wv[i] = (off >= w.lo && off < w.hi) ? wb[off] : a.wss[0];
+    }
+}
+template <class Cfg, int HC> LRA_HD void istft_flush_rows(const IstftArgs<typename Cfg::real>& a, long long clip, int t, bool in_strip, int tf, const FftRegs<Cfg>& rg) {
+    using T = typename Cfg::real;
+    constexpr int TF = Cfg::TF;
+    const IstftRowWin<Cfg> w = istft_row_window<Cfg>(a, t, in_strip, tf);
+    T* __restrict__ yb = a.y + clip * a.y_stride + w.s0;
+    // normalise unconditionally (every load is consumed on every control path; see istft_flush_out).  The
+    // quotient is x * rcp(w): within 1 ulp of the reference's division (core/spectrum.py:624).
+    T val[2 * HC];
+    LRA_UNROLL
+    for (int i = 0; i < 2 * HC; ++i) {
+        val[i] = (rg.wv[i] > a.tiny) ? fast_div(rg.out[i], rg.wv[i]) : rg.out[i];
+        LRA_KEEP(val[i]);
+    }
+    LRA_UNROLL
+    for (int i = 0; i < 2 * HC; ++i) {
+        const int off = 2 * (i >> 1) * TF + (i & 1);
+        if (off >= w.lo && off < w.hi) yb[off] = val[i];
+    }
+}
+
 template <class Cfg> LRA_HD void istft_flush_out(const IstftArgs<typename Cfg::real>& a, long long clip, int t, long long write_lo, long long write_hi, int tf,
                                                  const FftRegs<Cfg>& rg) {
     using T = typename Cfg::real;
@@ -893,6 +998,7 @@ template <class Cfg> struct IstftSlot {
     int t0, t1;
     long long write_lo, write_hi;
     bool active;
+    bool last;  // last strip of its clip: it also flushes the tail beyond its frames
 };
 template <class Cfg> LRA_HD IstftSlot<Cfg> istft_slot(const IstftArgs<typename Cfg::real>& a, int blk, int slot) {
     IstftSlot<Cfg> s;
@@ -904,28 +1010,35 @@ template <class Cfg> LRA_HD IstftSlot<Cfg> istft_slot(const IstftArgs<typename C
     if (s.t1 > a.n_used) s.t1 = a.n_used;
     s.write_lo = (long long)s.t0 * a.hop;
     s.write_hi = strip == a.strips_per_clip - 1 ? (long long)0x7fffffffffffffffLL : (long long)s.t1 * a.hop;
+    s.last = strip == a.strips_per_clip - 1;
     s.active = s.clip < a.batch;
     if (!s.active) s.clip = 0;
     return s;
 }
 
-template <class Cfg> LRA_HD void istft_block(const IstftArgs<typename Cfg::real>& a_in, const int blk, Lds lds) {
+// HC > 0: istft_rows_hc(hop), chosen by the host: only the row-aligned overlap-add is compiled in.
+template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typename Cfg::real>& a_in, const int blk, Lds lds) {
     IstftArgs<typename Cfg::real> a = a_in;
     using T = typename Cfg::real;
     constexpr int FPB = Cfg::FPB;
-    constexpr int SB = istft_slot_bytes<Cfg>();
+    constexpr bool ROWS = HC > 0;
+    constexpr int SB = istft_slot_bytes<Cfg, ROWS>();
     // uniform step count: drain steps only when one of this workgroup's slots owns a clip's last strip
     bool has_last = false;
     for (int s = 0; s < FPB; ++s) has_last = has_last || (((long long)blk * FPB + s) % a.strips_per_clip) == a.strips_per_clip - 1;
     const int steps = a.warm_frames + a.strip_frames + (has_last ? a.drain_steps : 0);
-    const bool defer = 4 * a.hop <= Cfg::N;  // finished samples per hop fit the hold-back registers
+    const bool defer = ROWS || 4 * a.hop <= Cfg::N;  // finished samples per hop fit the hold-back registers
+    constexpr bool rows = ROWS;
     LRA_REGS(FftRegs<Cfg>, rg, Cfg::NT);
+    // the slot's strip (64-bit divisions) is worked out once, from the un-laundered thread index
+    LRA_REGS(IstftSlot<Cfg>, sl, Cfg::NT);
     LRA_PHASE(Cfg::NT, tid) {
         const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
         hoist_tables<Cfg>(LRA_R(rg), tf, a.win_scaled, a.tw, a.twr, true);
         const Lds c0 = lds_sub(lds, slot * SB + Cfg::FRAME_BYTES);
         for (int u = tf; u < Cfg::N; u += Cfg::TF) lds_st<T>(c0, u * (int)sizeof(T), (T)0);
-        const IstftSlot<Cfg> s = istft_slot<Cfg>(a, blk, slot);
+        LRA_R(sl) = istft_slot<Cfg>(a, blk, LRA_RAW_TID(tid) / Cfg::TF);
+        const IstftSlot<Cfg> s = LRA_R(sl);
         const int t = s.t0 - a.warm_frames;
         istft_spec_load<Cfg>(a, s.clip, t, s.active && t >= 0 && t < s.t1, tf, LRA_R(rg));
     } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
@@ -935,11 +1048,17 @@ template <class Cfg> LRA_HD void istft_block(const IstftArgs<typename Cfg::real>
         // stores of frame j-1, (c) start the prefetch of frame j+1: the wait in (a) never covers (b)
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
-            const IstftSlot<Cfg> s = istft_slot<Cfg>(a, blk, slot);
+            const IstftSlot<Cfg> s = LRA_R(sl);
             const int t = s.t0 - a.warm_frames + j;
             istft_split_write<Cfg>(a, tf, LRA_R(rg), lds_sub(lds, slot * SB));
-            if (defer && j > 0 && s.active) istft_flush_out<Cfg>(a, s.clip, t - 1, s.write_lo, s.write_hi, tf, LRA_R(rg));
+            if (defer && j > 0 && s.active) {
+                if constexpr (rows) istft_flush_rows<Cfg, HC>(a, s.clip, t - 1, t - 1 >= s.t0 && (s.last || t - 1 < s.t1), tf, LRA_R(rg));
+                else istft_flush_out<Cfg>(a, s.clip, t - 1, s.write_lo, s.write_hi, tf, LRA_R(rg));
+            }
             if (j + 1 < steps) istft_spec_load<Cfg>(a, s.clip, t + 1, s.active && t + 1 >= 0 && t + 1 < s.t1, tf, LRA_R(rg));
+            if constexpr (rows) {  // for the flush of THIS frame, one iteration from now
+                if (s.active) istft_wss_rows<Cfg, HC>(a, t, t >= s.t0 && (s.last || t < s.t1), tf, LRA_R(rg));
+            }
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         // pass 0 (no twiddles) reads from LDS here, unlike the forward kernel
         if (Cfg::P > 1) {
@@ -961,10 +1080,11 @@ template <class Cfg> LRA_HD void istft_block(const IstftArgs<typename Cfg::real>
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
-            const IstftSlot<Cfg> s = istft_slot<Cfg>(a, blk, slot);
+            const IstftSlot<Cfg> s = LRA_R(sl);
             const int t = s.t0 - a.warm_frames + j;
             if (s.active) {
-                if (defer) istft_ola_step<Cfg, true>(a, s.clip, t, t >= 0 && t < s.t1, s.write_lo, s.write_hi, j & 1, tf, LRA_R(rg), lds_sub(lds, slot * SB));
+                if constexpr (rows) istft_ola_rows<Cfg, HC>(a, t >= 0 && t < s.t1, tf, LRA_R(rg), lds_sub(lds, slot * SB));
+                else if (defer) istft_ola_step<Cfg, true>(a, s.clip, t, t >= 0 && t < s.t1, s.write_lo, s.write_hi, j & 1, tf, LRA_R(rg), lds_sub(lds, slot * SB));
                 else istft_ola_step<Cfg, false>(a, s.clip, t, t >= 0 && t < s.t1, s.write_lo, s.write_hi, j & 1, tf, LRA_R(rg), lds_sub(lds, slot * SB));
             }
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
@@ -972,8 +1092,12 @@ template <class Cfg> LRA_HD void istft_block(const IstftArgs<typename Cfg::real>
     if (defer && steps > 0) {
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
-            const IstftSlot<Cfg> s = istft_slot<Cfg>(a, blk, slot);
-            if (s.active) istft_flush_out<Cfg>(a, s.clip, s.t0 - a.warm_frames + steps - 1, s.write_lo, s.write_hi, tf, LRA_R(rg));
+            const IstftSlot<Cfg> s = LRA_R(sl);
+            if (s.active) {
+                const int tl = s.t0 - a.warm_frames + steps - 1;
+                if constexpr (rows) istft_flush_rows<Cfg, HC>(a, s.clip, tl, tl >= s.t0 && (s.last || tl < s.t1), tf, LRA_R(rg));
+                else istft_flush_out<Cfg>(a, s.clip, s.t0 - a.warm_frames + steps - 1, s.write_lo, s.write_hi, tf, LRA_R(rg));
+            }
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
     }
 }
