@@ -69,7 +69,8 @@ int lra_ctx_set_stream(lra_ctx* ctx, void* hip_stream);
 /* Go back to the context's own (non-blocking) stream. */
 int lra_ctx_use_own_stream(lra_ctx* ctx);
 int lra_ctx_sync(lra_ctx* ctx);
-/* Tuning knobs: "stft_iters" (frame groups per workgroup), "istft_strip_groups", "variant". */
+/* Tuning knobs: "stft_iters" (frames per slot, 0 = auto), "istft_strip_groups" (frames per strip, 0 = auto),
+   "variant" (-1 = auto), "autotune" (1/0). */
 int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value);
 int lra_ctx_device_name(lra_ctx* ctx, char* buf, size_t buflen);
 /* Device-side half of util.valid_audio (librosa/util/utils.py:294-306): the fused power-of-two STFT
@@ -79,6 +80,11 @@ int lra_ctx_nonfinite_reset(lra_ctx* ctx);
 int lra_ctx_nonfinite_read(lra_ctx* ctx, int* flag);
 /* 1 when the plan runs the fused power-of-two kernels (and therefore feeds the flag above). */
 int lra_stft_plan_is_fused(const lra_stft_plan* plan);
+/* Kernel variant the plan settled on for an epilogue (mode 0 = stft, 1 = spectrogram, 2 = melspectrogram), after the
+   first large call timed the candidates (ctx option "autotune", default on; "variant" >= 0 pins one instead):
+   -1 = not measured (yet).  Reporting only (bench.py); the reference has no counterpart. */
+int lra_stft_plan_tuned_variant(const lra_stft_plan* plan, int mode);
+int lra_istft_plan_tuned_variant(const lra_istft_plan* plan);
 
 /* device memory helpers for hosts that do not bring their own allocator (NumPy path of the shim) */
 int lra_malloc(lra_ctx* ctx, size_t bytes, void** dptr);

@@ -43,6 +43,8 @@ SIGNATURES = {
     "lra_ctx_nonfinite_reset": (c_int, [c_void_p]),
     "lra_ctx_nonfinite_read": (c_int, [c_void_p, POINTER(c_int)]),
     "lra_stft_plan_is_fused": (c_int, [c_void_p]),
+    "lra_stft_plan_tuned_variant": (c_int, [c_void_p, c_int]),
+    "lra_istft_plan_tuned_variant": (c_int, [c_void_p]),
     "lra_malloc": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
     "lra_free": (c_int, [c_void_p, c_void_p]),
     "lra_memset": (c_int, [c_void_p, c_void_p, c_int, c_size_t]),
@@ -291,6 +293,12 @@ class Context:
 
     def stft_is_fused(self, plan):
         return bool(self.lib.lra_stft_plan_is_fused(plan))
+
+    def tuned_variant(self, plan, mode=None):
+        """Kernel variant an stft plan (mode 0/1/2) or istft plan (mode None) settled on; -1 = not measured."""
+        if mode is None:
+            return int(self.lib.lra_istft_plan_tuned_variant(plan))
+        return int(self.lib.lra_stft_plan_tuned_variant(plan, int(mode)))
 
     def stft_exec(self, plan, y_ptr, batch, n, y_stride, out_ptr):
         _check(self.lib.lra_stft_exec(plan, c_void_p(y_ptr), batch, n, y_stride, c_void_p(out_ptr)))

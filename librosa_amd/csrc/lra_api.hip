@@ -20,7 +20,8 @@
 #include <vector>
 
 #include "../../include/librosa_amd.h"
-#include "lra_dispatch.h"
+#define LRA_FUSED_EXTERN  // the fused kernels are instantiated in lra_inst.hip (parallel build), see lra_fused.h
+#include "lra_fused.h"
 #include "lra_mel.h"
 
 using namespace lra;
@@ -61,6 +62,7 @@ struct lra_ctx {
     int opt_stft_iters = 0;          // 0 = auto
     int opt_istft_strip_groups = 0;  // 0 = auto
     int opt_variant = -1;            // kernel tuning variant (f32 n_fft = 2048 only); -1 = per-mode default
+    int opt_autotune = 1;            // variant -1: time the candidate variants on the first large call of a plan and keep the faster
     int opt_mel_tile = 0;            // frames staged per mel row before a flush (0 = auto)
     int opt_generic_mel = 0;         // force the generic banded mel path (tests)
     int opt_lds_pad = 0;             // extra dynamic LDS per workgroup (occupancy experiments)
@@ -132,7 +134,8 @@ struct lra_stft_plan {
     bool pow2 = false;
     int logm = 0;
     void* d_win = nullptr;
-    void* d_tw[kNumVariants] = {};  // pass-twiddle tables; their layout depends on the kernel configuration
+    void* d_tw[kNumVariants] = {};
+    int tuned_variant[4] = {-1, -1, -1, -1};  // per epilogue mode (autotune), -1 = not measured yet  // pass-twiddle tables; their layout depends on the kernel configuration
     void* d_twr = nullptr;
     FftPlanCache fft;
     Scratch frames, spec;
@@ -162,46 +165,29 @@ struct lra_istft_plan {
     int logm = 0;
     void* d_win_scaled = nullptr;  // window / n_fft
     void* d_tw[kNumVariants] = {};
+    int tuned_variant[4] = {-1, -1, -1, -1};  // per epilogue mode (autotune), -1 = not measured yet
     void* d_twr = nullptr;
     FftPlanCache fft;
     Scratch spec, frames;
 };
 
-// ------------------------------------------------------------------------------------------------
-// kernels: fused power-of-two path
-// ------------------------------------------------------------------------------------------------
-// The PCM input and the output travel as separate __restrict__ kernel parameters (not only inside the
-// argument struct): without the noalias guarantee hipcc must assume that the next frame's sample
-// loads may read what the previous frame's spectrum stores wrote, and -- because loads may overtake
-// stores in the vector memory pipeline -- it then parks the wave on s_waitcnt vmcnt(0) at the top of
-// every frame until all of its stores have landed in L2, serialising FFT and store traffic.
-// RA: the hop is a whole number of ring rows (lra_kernels.h, ring_rows_aligned) -- the fast ring addressing.
-template <class Cfg, int MODE, int PM, bool RA>
-__global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void stft_kernel(StftArgs<typename Cfg::real> a, const typename Cfg::real* __restrict__ y,
-                                                                     void* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) char lra_smem[];
-    Lds lds;
-    lds.base = lra_smem;
-    a.y = y;
-    a.D = static_cast<typename Cfg::cplx*>(out);
-    a.S = static_cast<typename Cfg::real*>(out);
-    a.Mel = static_cast<typename Cfg::real*>(out);
-    stft_block<Cfg, MODE, PM, RA>(a, (int)blockIdx.x, lds);
-}
-
-template <class Cfg, int HC>
-__global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void istft_kernel(IstftArgs<typename Cfg::real> a, const typename Cfg::cplx* __restrict__ D,
-                                                                      const typename Cfg::real* __restrict__ wss, typename Cfg::real* __restrict__ y) {
-    extern __shared__ __attribute__((aligned(16))) char lra_smem[];
-    Lds lds;
-    lds.base = lra_smem;
-    a.D = D;
-    a.wss = wss;
-    a.y = y;
-    istft_block<Cfg, HC>(a, (int)blockIdx.x, lds);
-}
-
 namespace {
+
+// resident workgroups per CU of a kernel at a given dynamic LDS size (cached; 0 = unknown)
+static int resident_workgroups(const void* kern, int block, int lds) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, int> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    const auto key = std::make_pair(kern, lds);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    int per_cu = 0;
+    if (lds > 65536) (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, block, lds) != hipSuccess) per_cu = 0;
+    (void)hipGetLastError();
+    cache[key] = per_cu;
+    return per_cu;
+}
 
 template <class T> struct StftLaunch {
     StftArgs<T> a;
@@ -218,27 +204,7 @@ template <class T> struct StftLaunch {
 
     template <class Cfg, int MODE> void launch(int shared_bytes) {
         static_assert(Cfg::P <= 4, "at most four Stockham passes are wired up");
-        // Frames per slot.  A slot pays n_fft - hop extra sample loads for its first frame, so long runs
-        // are cheap in HBM traffic; split each clip into equal shares of ~32 frames per slot, but keep
-        // a few workgroups per CU in the launch.
-        int iters = iters_opt;
-        if (iters <= 0) {
-            int target = 32;
-            while (target > 4 && batch * ((a.n_frames + Cfg::FPB * target - 1) / (Cfg::FPB * target)) < 4LL * n_cu) target /= 2;
-            const int wgpc = (a.n_frames + Cfg::FPB * target - 1) / (Cfg::FPB * target);
-            iters = (a.n_frames + Cfg::FPB * wgpc - 1) / (Cfg::FPB * wgpc);
-        }
-        if (iters < 1) iters = 1;
-        a.mel_tile = mel_tile_opt > 0 ? mel_tile_opt : 4;
-        if (a.mel_tile > iters) a.mel_tile = iters;
-        a.frames_per_wg = Cfg::FPB * iters;
-        a.wg_per_clip = (a.n_frames + a.frames_per_wg - 1) / a.frames_per_wg;
-        a.slot_bytes = stft_slot_bytes<Cfg>(MODE, a.n_mels, a.mel_tile);
-        a.shared_off = Cfg::FPB * a.slot_bytes;
-        const long long grid = batch * a.wg_per_clip;
-        if (grid > 0x7fffffffLL) { err = hipErrorInvalidConfiguration; return; }
-        const int lds = Cfg::FPB * a.slot_bytes + shared_bytes + lds_pad;  // lds_pad: occupancy experiments only
-        if (lds > 160 * 1024) { err = hipErrorInvalidValue; return; }
+        const int lds_probe = Cfg::FPB * stft_slot_bytes<Cfg>(MODE, a.n_mels, mel_tile_opt > 0 ? mel_tile_opt : 4) + shared_bytes + lds_pad;
         void (*kern)(StftArgs<T>, const T*, void*) = stft_kernel<Cfg, MODE, POW_TWO, false>;
         if (MODE != OUT_COMPLEX && a.power_mode == POW_ONE) kern = stft_kernel<Cfg, MODE, POW_ONE, false>;
         if (MODE != OUT_COMPLEX && a.power_mode == POW_GENERAL) kern = stft_kernel<Cfg, MODE, POW_GENERAL, false>;
@@ -252,6 +218,41 @@ template <class T> struct StftLaunch {
                 if (MODE != OUT_COMPLEX && a.power_mode == POW_GENERAL) kern = stft_kernel<Cfg, MODE, POW_GENERAL, true>;
             }
         }
+        // Frames per slot (`iters`).  A slot pays n_fft - hop extra sample loads for its first frame, so long
+        // runs are cheap in HBM traffic; but the launch should also end evenly: the grid is sized to a whole
+        // number of "waves" of workgroups (CUs x resident workgroups per CU), because a last partial wave
+        // leaves most of the chip idle for one workgroup's duration (~15 % of a 0.85 ms launch at 32 frames
+        // per slot on the 256 x 30 s batch).  Among 24..128 frames per slot, take the best fill, then the
+        // longest run.
+        int iters = iters_opt;
+        if (iters <= 0) {
+            const int per_cu = lds_probe <= 160 * 1024 ? resident_workgroups(reinterpret_cast<const void*>(kern), Cfg::NT, lds_probe) : 0;
+            const long long conc = (long long)n_cu * (per_cu > 0 ? per_cu : 1);
+            const int fpb = Cfg::FPB;
+            int best_iters = 0;
+            double best_fill = -1.0;
+            for (int cand = 128; cand >= 24; --cand) {
+                const int wgpc = (a.n_frames + fpb * cand - 1) / (fpb * cand);
+                const int it = (a.n_frames + fpb * wgpc - 1) / (fpb * wgpc);  // equal shares
+                const double rounds = (double)(batch * wgpc) / (double)conc;
+                const double fill = rounds / std::ceil(rounds);
+                if (fill > best_fill + 0.02) { best_fill = fill; best_iters = it; }
+            }
+            iters = best_iters;
+            // small jobs: keep at least ~2 workgroups per CU even if that means short runs
+            while (iters > 4 && batch * ((a.n_frames + fpb * iters - 1) / (fpb * iters)) < 2LL * n_cu) iters /= 2;
+        }
+        if (iters < 1) iters = 1;
+        a.mel_tile = mel_tile_opt > 0 ? mel_tile_opt : 4;
+        if (a.mel_tile > iters) a.mel_tile = iters;
+        a.frames_per_wg = Cfg::FPB * iters;
+        a.wg_per_clip = (a.n_frames + a.frames_per_wg - 1) / a.frames_per_wg;
+        a.slot_bytes = stft_slot_bytes<Cfg>(MODE, a.n_mels, a.mel_tile);
+        a.shared_off = Cfg::FPB * a.slot_bytes;
+        const long long grid = batch * a.wg_per_clip;
+        if (grid > 0x7fffffffLL) { err = hipErrorInvalidConfiguration; return; }
+        const int lds = Cfg::FPB * a.slot_bytes + shared_bytes + lds_pad;  // lds_pad: occupancy experiments only
+        if (lds > 160 * 1024) { err = hipErrorInvalidValue; return; }
         if (lds > 65536) {
             err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (err != hipSuccess) return;
@@ -263,8 +264,7 @@ template <class T> struct StftLaunch {
     template <class Cfg> void operator()() {
         if (mode == OUT_MEL2) {
             // the two-slope mel kernel shares its filter tables across the slots of a larger workgroup
-            constexpr int MELNT = Cfg::TF <= 64 ? 512 : (2 * Cfg::TF <= 1024 ? 2 * Cfg::TF : Cfg::TF);
-            using MC = typename Cfg::template with_nt<MELNT>;
+            using MC = typename MelCfgOf<Cfg>::type;
             const int shared = mel2_shared_bytes<MC>(a.n_mels);
             // largest staging tile (frames per flushed mel row) that still fits the 160 KiB of LDS
             int tile = mel_tile_opt > 0 ? mel_tile_opt : 4;
@@ -291,20 +291,17 @@ template <class T> struct StftLaunch {
 template <class T> struct IstftLaunch {
     IstftArgs<T> a;
     long long batch = 0;
-    int strip_frames = 64;
+    int strip_frames = 0;  // 0 = auto
+    int n_cu = 256;
     hipStream_t stream = nullptr;
     hipError_t err = hipSuccess;
     template <class Cfg> void operator()() {
         static_assert(Cfg::P <= 4, "at most four Stockham passes are wired up");
         constexpr int FPB = Cfg::FPB, N = Cfg::N;
         const int H = a.hop;
-        a.strip_frames = strip_frames;
-        a.strips_per_clip = (a.n_used + a.strip_frames - 1) / a.strip_frames;
         a.warm_frames = (N + H - 1) / H - 1;
         a.drain_steps = N > H ? (N - H + H - 1) / H : 0;
         a.batch = batch;
-        const long long grid = (batch * a.strips_per_clip + FPB - 1) / FPB;
-        if (grid > 0x7fffffffLL) { err = hipErrorInvalidConfiguration; return; }
         int lds = istft_lds_bytes<Cfg, false>();
         void (*kern)(IstftArgs<T>, const cx<T>*, const T*, T*) = istft_kernel<Cfg, 0>;
         if constexpr (sizeof(T) == 4) {  // row-aligned overlap-add for hop = n_fft/4 and n_fft/8 (f32)
@@ -317,6 +314,27 @@ template <class T> struct IstftLaunch {
             }
             if (hc > 0) lds = istft_lds_bytes<Cfg, true>();
         }
+        // Frames per strip.  Each strip replays warm_frames frames before its own, so long strips are cheap;
+        // like the forward kernel, the grid should be a whole number of resident waves of workgroups.
+        int sf = strip_frames;
+        if (sf <= 0) {
+            const int per_cu = resident_workgroups(reinterpret_cast<const void*>(kern), Cfg::NT, lds);
+            const long long conc = (long long)n_cu * (per_cu > 0 ? per_cu : 1);
+            double best_fill = -1.0;
+            sf = 64;
+            for (int cand = 160; cand >= 32; --cand) {
+                const int spc = (a.n_used + cand - 1) / cand;
+                const int fr = (a.n_used + spc - 1) / spc;  // equal shares
+                const double rounds = (double)((batch * spc + FPB - 1) / FPB) / (double)conc;
+                const double fill = rounds / std::ceil(rounds);
+                if (fill > best_fill + 0.02) { best_fill = fill; sf = fr; }
+            }
+            while (sf > 8 && (batch * ((a.n_used + sf - 1) / sf) + FPB - 1) / FPB < 2LL * n_cu) sf /= 2;  // small jobs: fill the chip first
+        }
+        a.strip_frames = sf < 1 ? 1 : sf;
+        a.strips_per_clip = (a.n_used + a.strip_frames - 1) / a.strip_frames;
+        const long long grid = (batch * a.strips_per_clip + FPB - 1) / FPB;
+        if (grid > 0x7fffffffLL) { err = hipErrorInvalidConfiguration; return; }
         if (lds > 65536) {
             err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (err != hipSuccess) return;
@@ -509,6 +527,32 @@ int stft_general(lra_stft_plan* p, const T* y, long long batch, long long n, lon
     return LRA_OK;
 }
 
+// times launch(0) and launch(4) (one warm-up, then two timed launches each) on the context's stream
+template <class F> int autotune_variant(lra_ctx* ctx, F&& launch, int* tuned) {
+    hipEvent_t e0, e1;
+    LRA_HIP(hipEventCreate(&e0));
+    LRA_HIP(hipEventCreate(&e1));
+    float best = 0.f;
+    int best_v = 0, rc = LRA_OK;
+    const int cands[2] = {0, 4};
+    for (int c = 0; c < 2 && rc == LRA_OK; ++c) {
+        rc = launch(cands[c]);
+        if (rc != LRA_OK) break;
+        hipEventRecord(e0, ctx->stream);
+        rc = launch(cands[c]);
+        if (rc == LRA_OK) rc = launch(cands[c]);
+        hipEventRecord(e1, ctx->stream);
+        if (hipEventSynchronize(e1) != hipSuccess) { rc = fail(LRA_EHIP, "autotune: event synchronize failed"); break; }
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (c == 0 || ms < best) { best = ms; best_v = cands[c]; }
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (rc == LRA_OK) *tuned = best_v;
+    return rc;
+}
+
 template <class T>
 int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n, int64_t y_stride, double power, lra_mel_plan* mel, void* out) {
     LRA_TRY(ctx_bind(p->ctx));
@@ -538,8 +582,6 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
         L.a.win = (const T*)p->d_win;
         // measured on MI355X (bench.py --sweep): the two-wave-per-frame configuration wins when the mel
         // epilogue is fused in, the one-wave-per-frame configuration for the plain spectrum
-        const int variant = ctx->opt_variant >= 0 ? ctx->opt_variant : 0;  // one wave per frame: measured best for all three epilogues
-        L.a.tw = (const cx<T>*)p->d_tw[variant];
         L.a.twr = (const cx<T>*)p->d_twr;
         L.out = out;
         L.a.power_mode = power_mode_of(power);
@@ -561,9 +603,24 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
         L.n_cu = ctx->n_cu;
         L.mel_tile_opt = ctx->opt_mel_tile;
         L.lds_pad = ctx->opt_lds_pad;
-        if (!dispatch_logm<T>(p->logm, variant, L)) return fail(LRA_EINVAL, "unsupported power-of-two size");
-        if (L.err != hipSuccess) return fail(LRA_EHIP, std::string("stft kernel launch: ") + hipGetErrorString(L.err));
-        return LRA_OK;
+        // Kernel variant (f32 n_fft = 2048 only): 0 = one wave per frame, 4 = two waves per frame.  Which one
+        // is faster depends on the epilogue AND on the individual GPU (boxes of the same pool differ by +-10 %,
+        // the one-wave variant being the more sensitive one), so unless the caller pinned a variant the first
+        // large call of a plan times both on its own buffers (the kernels are idempotent) and keeps the winner.
+        int variant = ctx->opt_variant >= 0 ? ctx->opt_variant : 0;
+        auto launch = [&](int v) -> int {
+            StftLaunch<T> Lv = L;
+            Lv.a.tw = (const cx<T>*)p->d_tw[v];
+            if (!dispatch_logm<T>(p->logm, v, Lv)) return fail(LRA_EINVAL, "unsupported power-of-two size");
+            if (Lv.err != hipSuccess) return fail(LRA_EHIP, std::string("stft kernel launch: ") + hipGetErrorString(Lv.err));
+            return LRA_OK;
+        };
+        if (ctx->opt_variant < 0 && ctx->opt_autotune && sizeof(T) == 4 && p->logm == 10) {
+            int& tuned = p->tuned_variant[L.mode & 3];
+            if (tuned < 0 && batch * n_frames >= 65536) LRA_TRY(autotune_variant(ctx, launch, &tuned));
+            if (tuned >= 0) variant = tuned;
+        }
+        return launch(variant);
     }
     // general path
     if (mode == OUT_COMPLEX) return stft_general<T>(p, (const T*)y, batch, n, y_stride, n_frames, (cx<T>*)out);
@@ -618,8 +675,6 @@ int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_s
         L.a.hop = p->hop;
         L.a.drop = p->center ? N / 2 : 0;
         L.a.win_scaled = (const T*)p->d_win_scaled;
-        const int variant = ctx->opt_variant >= 0 ? ctx->opt_variant : 0;  // measured: one wave per frame (305 vs 278 Mframes/s for the two-wave variant)
-        L.a.tw = (const cx<T>*)p->d_tw[variant];
         L.a.twr = (const cx<T>*)p->d_twr;
         L.a.wss = (const T*)wss;
         L.a.tiny = tinyv;
@@ -628,10 +683,22 @@ int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_s
         L.a.out_len = out_len;
         L.batch = batch;
         L.stream = ctx->stream;
-        L.strip_frames = ctx->opt_istft_strip_groups > 0 ? ctx->opt_istft_strip_groups : 64;
-        if (!dispatch_logm<T>(p->logm, variant, L)) return fail(LRA_EINVAL, "unsupported power-of-two size");
-        if (L.err != hipSuccess) return fail(LRA_EHIP, std::string("istft kernel launch: ") + hipGetErrorString(L.err));
-        return LRA_OK;
+        L.strip_frames = ctx->opt_istft_strip_groups > 0 ? ctx->opt_istft_strip_groups : 0;
+        L.n_cu = ctx->n_cu;
+        int variant = ctx->opt_variant >= 0 ? ctx->opt_variant : 0;  // see stft_run
+        auto launch = [&](int v) -> int {
+            IstftLaunch<T> Lv = L;
+            Lv.a.tw = (const cx<T>*)p->d_tw[v];
+            if (!dispatch_logm<T>(p->logm, v, Lv)) return fail(LRA_EINVAL, "unsupported power-of-two size");
+            if (Lv.err != hipSuccess) return fail(LRA_EHIP, std::string("istft kernel launch: ") + hipGetErrorString(Lv.err));
+            return LRA_OK;
+        };
+        if (ctx->opt_variant < 0 && ctx->opt_autotune && sizeof(T) == 4 && p->logm == 10) {
+            int& tuned = p->tuned_variant[0];
+            if (tuned < 0 && batch * n_used >= 65536) LRA_TRY(autotune_variant(ctx, launch, &tuned));
+            if (tuned >= 0) variant = tuned;
+        }
+        return launch(variant);
     }
     // general path: pack -> rocFFT C2R -> gather overlap-add, one clip group at a time
     const long long group = general_clip_group(batch, n_used, N, sizeof(T));
@@ -743,6 +810,7 @@ int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value) {
     else if (!std::strcmp(key, "ablate")) (void)value;  // retired development knob, accepted and ignored
     else if (!std::strcmp(key, "generic_mel")) ctx->opt_generic_mel = value;
     else if (!std::strcmp(key, "lds_pad")) ctx->opt_lds_pad = value;
+    else if (!std::strcmp(key, "autotune")) ctx->opt_autotune = value != 0;
     else if (!std::strcmp(key, "variant")) ctx->opt_variant = (value >= 0 && value < kNumVariants) ? value : -1;
     else return fail(LRA_EINVAL, std::string("unknown option ") + key);
     return LRA_OK;
@@ -908,6 +976,13 @@ int lra_stft_num_frames(const lra_stft_plan* p, int64_t n, int64_t* n_frames) {
 }
 
 int lra_stft_plan_is_fused(const lra_stft_plan* p) { return p && p->pow2 ? 1 : 0; }
+int lra_stft_plan_tuned_variant(const lra_stft_plan* p, int mode) {
+    if (!p || mode < 0 || mode > 2) return -1;
+    // the two-slope mel kernel is mode 3 internally; the banded one mode 2
+    if (mode == 2) return p->tuned_variant[3] >= 0 ? p->tuned_variant[3] : p->tuned_variant[2];
+    return p->tuned_variant[mode];
+}
+int lra_istft_plan_tuned_variant(const lra_istft_plan* p) { return p ? p->tuned_variant[0] : -1; }
 
 int lra_stft_exec(lra_stft_plan* p, const void* y, int64_t batch, int64_t n, int64_t y_stride, void* D) {
     if (!p) return fail(LRA_EINVAL, "null plan");

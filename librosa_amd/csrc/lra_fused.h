@@ -1,0 +1,116 @@
+// lra_fused.h -- __global__ entry points of the fused power-of-two kernels and the list of their
+// instances.
+//
+// The library holds ~370 kernel instances (n_fft x dtype x epilogue x power mode x ring/row alignment); hipcc
+// compiles device code of one translation unit on one core, so the instances are explicitly instantiated in
+// lra_inst.hip, which the build compiles once per LRA_INST_GROUP in parallel, and lra_api.hip only sees
+// `extern template` declarations (LRA_FUSED_EXTERN).  Both sides expand the same X-macro list below.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "lra_dispatch.h"
+
+// The PCM input and the output travel as separate __restrict__ kernel parameters (not only inside the
+// argument struct): without the noalias guarantee hipcc must assume that the next frame's sample
+// loads may read what the previous frame's spectrum stores wrote, and -- because loads may overtake
+// stores in the vector memory pipeline -- it then parks the wave on s_waitcnt vmcnt(0) at the top of
+// every frame until all of its stores have landed in L2, serialising FFT and store traffic.
+// RA: the hop is a whole number of ring rows (lra_kernels.h, ring_rows_aligned) -- the fast ring addressing.
+template <class Cfg, int MODE, int PM, bool RA>
+__global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void stft_kernel(lra::StftArgs<typename Cfg::real> a, const typename Cfg::real* __restrict__ y,
+                                                                     void* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char lra_smem[];
+    lra::Lds lds;
+    lds.base = lra_smem;
+    a.y = y;
+    a.D = static_cast<typename Cfg::cplx*>(out);
+    a.S = static_cast<typename Cfg::real*>(out);
+    a.Mel = static_cast<typename Cfg::real*>(out);
+    lra::stft_block<Cfg, MODE, PM, RA>(a, (int)blockIdx.x, lds);
+}
+
+template <class Cfg, int HC>
+__global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void istft_kernel(lra::IstftArgs<typename Cfg::real> a, const typename Cfg::cplx* __restrict__ D,
+                                                                      const typename Cfg::real* __restrict__ wss, typename Cfg::real* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) char lra_smem[];
+    lra::Lds lds;
+    lds.base = lra_smem;
+    a.D = D;
+    a.wss = wss;
+    a.y = y;
+    lra::istft_block<Cfg, HC>(a, (int)blockIdx.x, lds);
+}
+
+
+namespace lra {
+
+// workgroup configuration of the two-slope mel kernel: its filter tables are shared across the slots of a
+// larger workgroup (512 threads when a frame fits one wave)
+template <class Cfg> struct MelCfgOf {
+    static constexpr int MELNT = Cfg::TF <= 64 ? 512 : (2 * Cfg::TF <= 1024 ? 2 * Cfg::TF : Cfg::TF);
+    using type = typename Cfg::template with_nt<MELNT>;
+};
+
+// ---- named configurations (macro arguments cannot carry the commas of template argument lists) ----------
+#define LRA_CFG_ALIAS(NAME, ...) using NAME = typename CfgSel<__VA_ARGS__>::type; using NAME##_mel = typename MelCfgOf<NAME>::type;
+LRA_CFG_ALIAS(cfg_f32_4, float, 4, 0)
+LRA_CFG_ALIAS(cfg_f32_5, float, 5, 0)
+LRA_CFG_ALIAS(cfg_f32_6, float, 6, 0)
+LRA_CFG_ALIAS(cfg_f32_7, float, 7, 0)
+LRA_CFG_ALIAS(cfg_f32_8, float, 8, 0)
+LRA_CFG_ALIAS(cfg_f32_9, float, 9, 0)
+LRA_CFG_ALIAS(cfg_f32_10, float, 10, 0)
+LRA_CFG_ALIAS(cfg_f32_10v1, float, 10, 1)
+LRA_CFG_ALIAS(cfg_f32_10v4, float, 10, 4)
+LRA_CFG_ALIAS(cfg_f32_11, float, 11, 0)
+LRA_CFG_ALIAS(cfg_f32_12, float, 12, 0)
+LRA_CFG_ALIAS(cfg_f32_13, float, 13, 0)
+LRA_CFG_ALIAS(cfg_f64_4, double, 4, 0)
+LRA_CFG_ALIAS(cfg_f64_5, double, 5, 0)
+LRA_CFG_ALIAS(cfg_f64_6, double, 6, 0)
+LRA_CFG_ALIAS(cfg_f64_7, double, 7, 0)
+LRA_CFG_ALIAS(cfg_f64_8, double, 8, 0)
+LRA_CFG_ALIAS(cfg_f64_9, double, 9, 0)
+LRA_CFG_ALIAS(cfg_f64_10, double, 10, 0)
+LRA_CFG_ALIAS(cfg_f64_11, double, 11, 0)
+LRA_CFG_ALIAS(cfg_f64_12, double, 12, 0)
+#undef LRA_CFG_ALIAS
+
+}  // namespace lra
+
+// ---- instance lists ----------------------------------------------------------------------------------------
+// S(CFG, MODE, PM, RA): one stft_kernel instance; I(CFG, HC): one istft_kernel instance.
+#define LRA_STFT_SET(S, C, RA)                                                                       \
+    S(lra::C, 0, 2, RA)                                                                              \
+    S(lra::C, 1, 1, RA) S(lra::C, 1, 2, RA) S(lra::C, 1, 3, RA)                                      \
+    S(lra::C, 2, 1, RA) S(lra::C, 2, 2, RA) S(lra::C, 2, 3, RA)                                      \
+    S(lra::C##_mel, 3, 1, RA) S(lra::C##_mel, 3, 2, RA) S(lra::C##_mel, 3, 3, RA)
+// f32: both ring addressings; all three overlap-add row counts (HC = R/4 = 4, R/8 = 2 at 16 points per thread)
+#define LRA_F32_CFG(S, I, C, HCQ, HCE) LRA_STFT_SET(S, C, false) LRA_STFT_SET(S, C, true) I(lra::C, 0) I(lra::C, HCQ) I(lra::C, HCE)
+#define LRA_F64_CFG(S, I, C) LRA_STFT_SET(S, C, false) I(lra::C, 0)
+
+#define LRA_INST_GROUP_0(S, I) LRA_F32_CFG(S, I, cfg_f32_10, 4, 2)
+#define LRA_INST_GROUP_1(S, I) LRA_F32_CFG(S, I, cfg_f32_10v4, 2, 1)
+#define LRA_INST_GROUP_2(S, I) LRA_F32_CFG(S, I, cfg_f32_10v1, 2, 1)
+#define LRA_INST_GROUP_3(S, I) LRA_F32_CFG(S, I, cfg_f32_4, 4, 2) LRA_F32_CFG(S, I, cfg_f32_5, 4, 2) LRA_F32_CFG(S, I, cfg_f32_6, 4, 2)
+#define LRA_INST_GROUP_4(S, I) LRA_F32_CFG(S, I, cfg_f32_7, 4, 2) LRA_F32_CFG(S, I, cfg_f32_8, 4, 2)
+#define LRA_INST_GROUP_5(S, I) LRA_F32_CFG(S, I, cfg_f32_9, 4, 2) LRA_F32_CFG(S, I, cfg_f32_11, 4, 2)
+#define LRA_INST_GROUP_6(S, I) LRA_F32_CFG(S, I, cfg_f32_12, 4, 2) LRA_F32_CFG(S, I, cfg_f32_13, 4, 2)
+#define LRA_INST_GROUP_7(S, I) LRA_F64_CFG(S, I, cfg_f64_4) LRA_F64_CFG(S, I, cfg_f64_5) LRA_F64_CFG(S, I, cfg_f64_6) LRA_F64_CFG(S, I, cfg_f64_7) LRA_F64_CFG(S, I, cfg_f64_8)
+#define LRA_INST_GROUP_8(S, I) LRA_F64_CFG(S, I, cfg_f64_9) LRA_F64_CFG(S, I, cfg_f64_10) LRA_F64_CFG(S, I, cfg_f64_11) LRA_F64_CFG(S, I, cfg_f64_12)
+#define LRA_INST_NUM_GROUPS 9
+#define LRA_INST_ALL(S, I)                                                                                                   \
+    LRA_INST_GROUP_0(S, I) LRA_INST_GROUP_1(S, I) LRA_INST_GROUP_2(S, I) LRA_INST_GROUP_3(S, I) LRA_INST_GROUP_4(S, I)       \
+    LRA_INST_GROUP_5(S, I) LRA_INST_GROUP_6(S, I) LRA_INST_GROUP_7(S, I) LRA_INST_GROUP_8(S, I)
+
+#define LRA_STFT_SIG(C) lra::StftArgs<typename C::real>, const typename C::real*, void*
+#define LRA_ISTFT_SIG(C) lra::IstftArgs<typename C::real>, const typename C::cplx*, const typename C::real*, typename C::real*
+#define LRA_S_EXTERN(C, MODE, PM, RA) extern template __global__ void stft_kernel<C, MODE, PM, RA>(LRA_STFT_SIG(C));
+#define LRA_I_EXTERN(C, HC) extern template __global__ void istft_kernel<C, HC>(LRA_ISTFT_SIG(C));
+#define LRA_S_DEFINE(C, MODE, PM, RA) template __global__ void stft_kernel<C, MODE, PM, RA>(LRA_STFT_SIG(C));
+#define LRA_I_DEFINE(C, HC) template __global__ void istft_kernel<C, HC>(LRA_ISTFT_SIG(C));
+
+#if defined(LRA_FUSED_EXTERN) && !defined(LRA_PROBE_ONLY)
+LRA_INST_ALL(LRA_S_EXTERN, LRA_I_EXTERN)
+#endif

@@ -1,10 +1,12 @@
 #!/bin/bash
-# Build the gfx950 library with absolute paths; prints errors and the resource summary of the headline kernels.
+# Build the gfx950 library (parallel, see librosa_amd/build.py).  With an argument: also print the register /
+# scratch summary of the kernels whose demangled name matches it (recompiles one instance group with
+# -Rpass-analysis=kernel-resource-usage; group 0 = n_fft 2048 f32 default configuration).
 R=/root/repo
-cd $R/librosa_amd/csrc || exit 1
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -o $R/librosa_amd/_liblibrosa_amd.so lra_api.hip -L/opt/rocm/lib -lrocfft -Wl,-rpath,/opt/rocm/lib -Rpass-analysis=kernel-resource-usage > /tmp/res.txt 2>&1
-n=$(grep -c " error" /tmp/res.txt)
-echo "errors: $n"
-if [ "$n" != "0" ]; then grep " error" -A3 /tmp/res.txt | head -20; exit 1; fi
-[ -f /tmp/summ2.py ] && python /tmp/summ2.py /tmp/res.txt "${1:-Cfg<10,R.,float,W.,true>}" | grep -E "${1:-true}" | head -20
+cd $R && python -m librosa_amd.build --force > /tmp/build_py.log 2>&1 || { tail -30 /tmp/build_py.log; echo "errors: 1"; exit 1; }
+echo "errors: 0"
+if [ -n "$1" ] && [ -f /tmp/summ2.py ]; then
+  cd $R/librosa_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -DLRA_INST_GROUP=${2:-0} lra_inst.hip -o /tmp/inst_res.o -Rpass-analysis=kernel-resource-usage > /tmp/res.txt 2>&1
+  python /tmp/summ2.py /tmp/res.txt "$1" | grep -E "$1" | head -40
+fi
 exit 0

@@ -26,7 +26,7 @@ def short(name):
         return "istft_kernel"
     if "stft_kernel" in name:
         import re
-        m = re.search(r">, (\d)>\(", name)
+        m = re.search(r">, (\d), (\d), (true|false)>\(", name) or re.search(r">, (\d)(?:, \d)?>\(", name)
         mode = m.group(1) if m else "?"
         cfg = re.search(r"FftCfg<(\d+), (\d), (\w+), (\d+), (\d), (\w+)>", name)
         tag = f" [2^{cfg.group(2)} pts/thread, NT={cfg.group(4)}]" if cfg else ""

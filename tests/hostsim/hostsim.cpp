@@ -148,24 +148,37 @@ int run_istft(int n_fft, const T* D /* interleaved complex [batch][T][M+1] */, l
 
 }  // namespace
 
+// The four entry points are compiled as four objects side by side (HOSTSIM_PART = 1..4, tests/hostsim_util.py):
+// each instantiates every n_fft configuration of one (transform, dtype) pair.
+#ifndef HOSTSIM_PART
+#define HOSTSIM_PART 0  // 0 = everything in one object
+#endif
 extern "C" {
+#if HOSTSIM_PART == 0 || HOSTSIM_PART == 1
 int hostsim_stft_f32(int n_fft, int mode, const float* y, long long n, long long batch, int n_frames, int hop, int center, int pad_mode,
                      const float* win, int iters_per_wg, void* out, int power_mode, double power, const int* mel_c0, const int* mel_len,
                      const int* mel_off, const float* mel_val, int n_mels, int variant, const float* dense_basis, long long* diag) {
     return run_stft<float>(n_fft, mode, y, n, batch, n_frames, hop, center, pad_mode, win, iters_per_wg, out, power_mode, power, mel_c0, mel_len, mel_off, mel_val, n_mels, variant, dense_basis, diag);
 }
+#endif
+#if HOSTSIM_PART == 0 || HOSTSIM_PART == 2
 int hostsim_stft_f64(int n_fft, int mode, const double* y, long long n, long long batch, int n_frames, int hop, int center, int pad_mode,
                      const double* win, int iters_per_wg, void* out, int power_mode, double power, const int* mel_c0, const int* mel_len,
                      const int* mel_off, const double* mel_val, int n_mels, int variant, const double* dense_basis, long long* diag) {
     return run_stft<double>(n_fft, mode, y, n, batch, n_frames, hop, center, pad_mode, win, iters_per_wg, out, power_mode, power, mel_c0, mel_len, mel_off, mel_val, n_mels, variant, dense_basis, diag);
 }
+#endif
+#if HOSTSIM_PART == 0 || HOSTSIM_PART == 3
 int hostsim_istft_f32(int n_fft, const float* D, long long batch, int n_frames_total, int n_used, int hop, int center, const float* win_scaled,
                       const float* wss, double tiny, float* y, long long out_len, int strip_groups, int variant, long long* diag) {
     return run_istft<float>(n_fft, D, batch, n_frames_total, n_used, hop, center, win_scaled, wss, tiny, y, out_len, strip_groups, variant, diag);
 }
+#endif
+#if HOSTSIM_PART == 0 || HOSTSIM_PART == 4
 int hostsim_istft_f64(int n_fft, const double* D, long long batch, int n_frames_total, int n_used, int hop, int center, const double* win_scaled,
                       const double* wss, double tiny, double* y, long long out_len, int strip_groups, int variant, long long* diag) {
     return run_istft<double>(n_fft, D, batch, n_frames_total, n_used, hop, center, win_scaled, wss, tiny, y, out_len, strip_groups, variant, diag);
 }
 long long hostsim_pad_index(long long g, long long n, int mode) { return pad_index(g, n, mode); }
+#endif
 }
