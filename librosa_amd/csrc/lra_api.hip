@@ -63,6 +63,7 @@ struct lra_ctx {
     int opt_istft_strip_groups = 0;  // 0 = auto
     int opt_variant = -1;            // kernel tuning variant (f32 n_fft = 2048 only); -1 = per-mode default
     int opt_autotune = 1;            // variant -1: time the candidate variants on the first large call of a plan and keep the faster
+    int opt_mel_runs = 1;            // use the run-ordered two-slope epilogue (OUT_MELR) where it applies
     int opt_mel_tile = 0;            // frames staged per mel row before a flush (0 = auto)
     int opt_generic_mel = 0;         // force the generic banded mel path (tests)
     int opt_lds_pad = 0;             // extra dynamic LDS per workgroup (occupancy experiments)
@@ -152,6 +153,12 @@ struct lra_mel_plan {
     bool two_slope = false;
     void* d_wAB = nullptr;
     // piece tables for runs of 8 / 16 bins per thread (index 0 / 1); n_pieces == 0 -> not available
+    // run-ordered form (OUT_MELR; 16 points per thread: TF = M/16 threads per frame, runs of 8 bins)
+    void* d_melr_w = nullptr;
+    void* d_melr_keep = nullptr;
+    int* d_melr_addr = nullptr;
+    int melr_zero = 0, melr_mid = 0, melr_pmax = 0;
+    bool melr_ok = false;
     int* d_run[2] = {nullptr, nullptr};
     int* d_segd[2] = {nullptr, nullptr};
     int nyq[2] = {0, 0};
@@ -198,6 +205,7 @@ template <class T> struct StftLaunch {
     int n_cu = 256;
     void* out = nullptr;
     int lds_pad = 0;
+    bool mel_runs = true;
     const lra_mel_plan* mel = nullptr;
     hipStream_t stream = nullptr;
     hipError_t err = hipSuccess;
@@ -265,6 +273,23 @@ template <class T> struct StftLaunch {
         if (mode == OUT_MEL2) {
             // the two-slope mel kernel shares its filter tables across the slots of a larger workgroup
             using MC = typename MelCfgOf<Cfg>::type;
+            // first choice: the run-ordered form (no per-lane control flow, no (wA P, wB P) round trip through LDS)
+            if (mel && mel->melr_ok && mel_runs && melr_fits<MC>() && MC::R == 16) {
+                const int shared_r = melr_shared_bytes<MC>(a.n_mels);
+                int tile_r = mel_tile_opt > 0 ? mel_tile_opt : 4;
+                while (tile_r > 1 && MC::FPB * stft_slot_bytes<MC>(OUT_MELR, a.n_mels, tile_r) + shared_r > 160 * 1024) tile_r /= 2;
+                if (MC::FPB * stft_slot_bytes<MC>(OUT_MELR, a.n_mels, tile_r) + shared_r <= 160 * 1024) {
+                    a.melr_w = (const T*)mel->d_melr_w;
+                    a.melr_keep = (const T*)mel->d_melr_keep;
+                    a.melr_addr = mel->d_melr_addr;
+                    a.melr_zero = mel->melr_zero;
+                    a.melr_mid = mel->melr_mid;
+                    a.melr_pmax = mel->melr_pmax;
+                    mel_tile_opt = tile_r;
+                    launch<MC, OUT_MELR>(shared_r);
+                    return;
+                }
+            }
             const int shared = mel2_shared_bytes<MC>(a.n_mels);
             // largest staging tile (frames per flushed mel row) that still fits the 160 KiB of LDS
             int tile = mel_tile_opt > 0 ? mel_tile_opt : 4;
@@ -603,6 +628,7 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
         L.n_cu = ctx->n_cu;
         L.mel_tile_opt = ctx->opt_mel_tile;
         L.lds_pad = ctx->opt_lds_pad;
+        L.mel_runs = ctx->opt_mel_runs != 0;
         // Kernel variant (f32 n_fft = 2048 only): 0 = one wave per frame, 4 = two waves per frame.  Which one
         // is faster depends on the epilogue AND on the individual GPU (boxes of the same pool differ by +-10 %,
         // the one-wave variant being the more sensitive one), so unless the caller pinned a variant the first
@@ -811,6 +837,7 @@ int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value) {
     else if (!std::strcmp(key, "generic_mel")) ctx->opt_generic_mel = value;
     else if (!std::strcmp(key, "lds_pad")) ctx->opt_lds_pad = value;
     else if (!std::strcmp(key, "autotune")) ctx->opt_autotune = value != 0;
+    else if (!std::strcmp(key, "mel_runs")) ctx->opt_mel_runs = value != 0;
     else if (!std::strcmp(key, "variant")) ctx->opt_variant = (value >= 0 && value < kNumVariants) ? value : -1;
     else return fail(LRA_EINVAL, std::string("unknown option ") + key);
     return LRA_OK;
@@ -1050,6 +1077,18 @@ int lra_mel_plan_create(lra_ctx* ctx, int n_mels, int n_bins, const void* basis_
                     p->nyq[pi] = mp.nyquist_piece;
                     p->n_pieces[pi] = mp.n_pieces;
                 }
+                if (rc == LRA_OK && (n_bins - 1) % 16 == 0) {
+                    MelRuns<double> mr = build_mel_runs<double>(ts, (n_bins - 1) / 16, 8, MELR_PMAX);
+                    if (mr.ok) {
+                        rc = upload(&p->d_melr_w, mr.w.data(), mr.w.size() * sizeof(double));
+                        if (rc == LRA_OK) rc = upload(&p->d_melr_keep, mr.keep.data(), mr.keep.size() * sizeof(double));
+                        if (rc == LRA_OK) rc = upload((void**)&p->d_melr_addr, mr.addr.data(), mr.addr.size() * sizeof(int));
+                        p->melr_zero = mr.zero_addr;
+                        p->melr_mid = mr.mid_addr;
+                        p->melr_pmax = mr.max_pieces;
+                        p->melr_ok = rc == LRA_OK;
+                    }
+                }
                 p->two_slope = rc == LRA_OK;
             }
         } else {
@@ -1065,6 +1104,18 @@ int lra_mel_plan_create(lra_ctx* ctx, int n_mels, int n_bins, const void* basis_
                     if (rc == LRA_OK) rc = upload((void**)&p->d_segd[pi], mp.seg_desc.data(), mp.seg_desc.size() * sizeof(int));
                     p->nyq[pi] = mp.nyquist_piece;
                     p->n_pieces[pi] = mp.n_pieces;
+                }
+                if (rc == LRA_OK && (n_bins - 1) % 16 == 0) {
+                    MelRuns<float> mr = build_mel_runs<float>(ts, (n_bins - 1) / 16, 8, MELR_PMAX);
+                    if (mr.ok) {
+                        rc = upload(&p->d_melr_w, mr.w.data(), mr.w.size() * sizeof(float));
+                        if (rc == LRA_OK) rc = upload(&p->d_melr_keep, mr.keep.data(), mr.keep.size() * sizeof(float));
+                        if (rc == LRA_OK) rc = upload((void**)&p->d_melr_addr, mr.addr.data(), mr.addr.size() * sizeof(int));
+                        p->melr_zero = mr.zero_addr;
+                        p->melr_mid = mr.mid_addr;
+                        p->melr_pmax = mr.max_pieces;
+                        p->melr_ok = rc == LRA_OK;
+                    }
                 }
                 p->two_slope = rc == LRA_OK;
             }
@@ -1086,6 +1137,9 @@ void lra_mel_plan_destroy(lra_mel_plan* p) {
     if (p->d_off) (void)hipFree(p->d_off);
     if (p->d_val) (void)hipFree(p->d_val);
     if (p->d_wAB) (void)hipFree(p->d_wAB);
+    if (p->d_melr_w) (void)hipFree(p->d_melr_w);
+    if (p->d_melr_keep) (void)hipFree(p->d_melr_keep);
+    if (p->d_melr_addr) (void)hipFree(p->d_melr_addr);
     for (int pi = 0; pi < 2; ++pi) {
         if (p->d_run[pi]) (void)hipFree(p->d_run[pi]);
         if (p->d_segd[pi]) (void)hipFree(p->d_segd[pi]);

@@ -85,7 +85,8 @@ LRA_CFG_ALIAS(cfg_f64_12, double, 12, 0)
     S(lra::C, 0, 2, RA)                                                                              \
     S(lra::C, 1, 1, RA) S(lra::C, 1, 2, RA) S(lra::C, 1, 3, RA)                                      \
     S(lra::C, 2, 1, RA) S(lra::C, 2, 2, RA) S(lra::C, 2, 3, RA)                                      \
-    S(lra::C##_mel, 3, 1, RA) S(lra::C##_mel, 3, 2, RA) S(lra::C##_mel, 3, 3, RA)
+    S(lra::C##_mel, 3, 1, RA) S(lra::C##_mel, 3, 2, RA) S(lra::C##_mel, 3, 3, RA)                   \
+    S(lra::C##_mel, 4, 1, RA) S(lra::C##_mel, 4, 2, RA) S(lra::C##_mel, 4, 3, RA)
 // f32: both ring addressings; all three overlap-add row counts (HC = R/4 = 4, R/8 = 2 at 16 points per thread)
 #define LRA_F32_CFG(S, I, C, HCQ, HCE) LRA_STFT_SET(S, C, false) LRA_STFT_SET(S, C, true) I(lra::C, 0) I(lra::C, HCQ) I(lra::C, HCE)
 #define LRA_F64_CFG(S, I, C) LRA_STFT_SET(S, C, false) I(lra::C, 0)

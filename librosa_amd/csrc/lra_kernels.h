@@ -31,7 +31,7 @@
 
 namespace lra {
 
-enum OutMode : int { OUT_COMPLEX = 0, OUT_POWER = 1, OUT_MEL = 2, OUT_MEL2 = 3 };  // MEL2: two-slope filterbank (lra_mel.h)
+enum OutMode : int { OUT_COMPLEX = 0, OUT_POWER = 1, OUT_MEL = 2, OUT_MEL2 = 3, OUT_MELR = 4 };  // MEL2: two-slope filterbank, MELR: its run-ordered form (lra_mel.h)
 enum PowerMode : int { POW_ONE = 1, POW_TWO = 2, POW_GENERAL = 3 };
 
 template <class T> struct StftArgs {
@@ -70,6 +70,12 @@ template <class T> struct StftArgs {
     const int* mel_run;   // [TF] run descriptors (lra_mel.h)
     const int* mel_segd;  // [n_mels + 1] segment -> pieces
     int mel_nyq;          // piece id of the Nyquist bin
+    // run-ordered two-slope form (OUT_MELR, lra_mel.h MelRuns): also copied to the shared LDS region
+    const T* melr_w;        // [(M + 1)] (wA, wB) pairs: bins 0..M/2-1, then M, M-1, .., M/2+1, then M/2
+    const T* melr_keep;     // [R][TF]: 0 where a thread's running sum restarts
+    const int* melr_addr;   // [2 MELR_PMAX][n_mels] LDS byte addresses of the piece totals (entries 0..PMAX-1: B list, then the A list)
+    int melr_pmax;            // longest piece list actually used (<= MELR_PMAX)
+    int melr_zero, melr_mid;  // byte addresses (inside the slot's running-sum area) of the zero slot and of bin M/2's slot
     int shared_off;
     // set to 1 when a frame's DC bin is not finite, i.e. (barring overflow) when some sample of the
     // frame is NaN/Inf: the device-side half of util.valid_audio (util/utils.py:305)
@@ -89,6 +95,10 @@ template <class Cfg> struct FftRegs {
     // frame, and the current hop's finished output samples held back until that prefetch has landed
     typename Cfg::cplx xk[Cfg::R / 2 > 0 ? Cfg::R / 2 : 1], xm[Cfg::R / 2 > 0 ? Cfg::R / 2 : 1], xmid;
     typename Cfg::real out[NPF];
+    // OUT_MELR: this thread's restart factors and the first MELR_PHOIST entries of the piece lists of its (up to two) mel bands
+    static constexpr int MELR_PHOIST = 4;
+    typename Cfg::real keep[Cfg::R];
+    int mad[2][2 * MELR_PHOIST];
     typename Cfg::real wv[NPF];  // ISTFT (row-aligned): window sum-square values of the held-back samples, loaded a frame ahead
     static constexpr int NH = Cfg::HOIST ? 1 : 0;
     typename Cfg::cplx win2[NH * Cfg::R + 1 - NH];       // window pairs in pass-0 register order
@@ -98,7 +108,7 @@ template <class Cfg> struct FftRegs {
 
 // prologue of HOIST kernels: window, pass twiddles and split twiddles -> registers
 template <class Cfg> LRA_HD void hoist_tables(FftRegs<Cfg>& rg, int tf, const typename Cfg::real* __restrict__ win, const typename Cfg::cplx* __restrict__ tw,
-                                              const typename Cfg::cplx* __restrict__ twr, bool window_in_last_pass_order) {
+                                              const typename Cfg::cplx* __restrict__ twr, bool window_in_last_pass_order, bool split_run_order = false) {
     using C = typename Cfg::cplx;
     if (!Cfg::HOIST) return;
     const C* __restrict__ win2 = reinterpret_cast<const C*>(win);
@@ -121,7 +131,7 @@ template <class Cfg> LRA_HD void hoist_tables(FftRegs<Cfg>& rg, int tf, const ty
     if (Cfg::P > 2) load_pass_twiddles<Cfg, (2 < Cfg::P ? 2 : 0)>(rg.treg, tf, tw);
     if (Cfg::P > 3) load_pass_twiddles<Cfg, (3 < Cfg::P ? 3 : 0)>(rg.treg, tf, tw);
     LRA_UNROLL
-    for (int i = 0; i < Cfg::R / 2; ++i) rg.twr[i] = twr[tf + i * Cfg::TF];
+    for (int i = 0; i < Cfg::R / 2; ++i) rg.twr[i] = split_run_order ? twr[(Cfg::R / 2) * tf + i] : twr[tf + i * Cfg::TF];
 }
 
 // twiddle + butterflies of pass p from whichever source the configuration uses
@@ -557,6 +567,156 @@ template <class Cfg> LRA_HD void mel2_combine(const StftArgs<typename Cfg::real>
     }
 }
 
+// ---- OUT_MELR: run-ordered two-slope mel epilogue (lra_mel.h, MelRuns) -------------------------------------
+// Shared region (per workgroup): w[(M+1)] pairs | keep[R][TF] reals | addr[n_mels][2 PMAX] ints.
+// Per slot: the frame area is reused as the running-sum area rs[R][TF] pairs (+ zero slot, + bin M/2's slot).
+constexpr int MELR_PMAX = 6;  // pieces per pair segment the address lists can hold (host falls back to OUT_MEL2 beyond)
+// the weight pairs are stored with one pad pair per run of R/2 (index i -> i + i / (R/2)): a thread reads ITS run, so
+// lanes are R/2 + 1 pairs apart -- an odd number of 8-byte slots, i.e. conflict-free instead of 16 lanes per bank
+template <class Cfg> LRA_HD int melr_w_slot(int i) { return i + i / (Cfg::R / 2); }
+template <class Cfg> LRA_HD int melr_keep_off() { return ((melr_w_slot<Cfg>(Cfg::M) + 1) * 2 * (int)sizeof(typename Cfg::real) + 15) / 16 * 16; }
+template <class Cfg> LRA_HD int melr_addr_off() { return melr_keep_off<Cfg>() + ((Cfg::R * Cfg::TF * (int)sizeof(typename Cfg::real) + 15) / 16) * 16; }
+template <class Cfg> LRA_HD int melr_shared_bytes(int n_mels) { return ((melr_addr_off<Cfg>() + n_mels * 2 * MELR_PMAX * (int)sizeof(int) + 15) / 16) * 16; }
+template <class Cfg> inline bool melr_fits() {
+    return Cfg::R == 16 && (1 << Cfg::PADSHIFT) % (Cfg::R / 2) == 0 && (Cfg::R * Cfg::TF + 2) * 2 * (int)sizeof(typename Cfg::real) <= Cfg::FRAME_BYTES;
+}
+
+template <class Cfg> LRA_HD void melr_tables_to_lds(const StftArgs<typename Cfg::real>& a, int tid, Lds sh) {
+    using T = typename Cfg::real;
+    using C = typename Cfg::cplx;
+    const C* __restrict__ w2 = reinterpret_cast<const C*>(a.melr_w);
+    for (int k = tid; k < Cfg::M + 1; k += Cfg::NT) lds_st<C>(sh, melr_w_slot<Cfg>(k) * (int)sizeof(C), w2[k]);
+    for (int i = tid; i < Cfg::R * Cfg::TF; i += Cfg::NT) lds_st<T>(sh, melr_keep_off<Cfg>() + i * (int)sizeof(T), a.melr_keep[i]);
+    for (int i = tid; i < a.n_mels * 2 * MELR_PMAX; i += Cfg::NT) lds_st<int>(sh, melr_addr_off<Cfg>() + i * (int)sizeof(int), a.melr_addr[i]);
+}
+
+// phase: Z[k], Z[M-k] for this thread's RUN of R/2 consecutive bins k = (R/2) tf + j  (v[2j], v[2j+1])
+template <class Cfg> LRA_HD void split_read_runs(FftRegs<Cfg>& rg, Lds fr, int tf) {
+    using C = typename Cfg::cplx;
+    constexpr int BPL = Cfg::R / 2, M = Cfg::M;
+    // a run of BPL <= 16 consecutive elements never straddles a pad slot (phys(i) = i + i/16): base + immediates
+    const int ba = Cfg::phys(BPL * tf) * (int)sizeof(C);
+    const int bm = Cfg::phys(M - BPL * tf - 1) * (int)sizeof(C);                 // j = 1 .. BPL-1 descend from here
+    const int b0 = Cfg::phys((M - BPL * tf) & (M - 1)) * (int)sizeof(C);         // j = 0 (wraps to Z[0] for tf = 0)
+    LRA_UNROLL
+    for (int j = 0; j < BPL; ++j) {
+        rg.v[2 * j] = lds_ld<C>(fr, ba + j * (int)sizeof(C));
+        rg.v[2 * j + 1] = lds_ld<C>(fr, j == 0 ? b0 : bm - (j - 1) * (int)sizeof(C));
+    }
+    if (tf == 0) rg.mid = lds_ld<C>(fr, Cfg::phys(M / 2) * (int)sizeof(C));
+}
+
+// phase: split + power + (wA, wB) + running sums along both runs -> rs[jj][tf]
+template <class Cfg, int PM> LRA_HD void melr_split_accumulate(const StftArgs<typename Cfg::real>& a, bool valid, int tf, FftRegs<Cfg>& rg, Lds rs, Lds sh) {
+    using T = typename Cfg::real;
+    using C = typename Cfg::cplx;
+    constexpr int BPL = Cfg::R / 2, M = Cfg::M, TF = Cfg::TF;
+    C ab[2 * BPL];
+    LRA_UNROLL
+    for (int j = 0; j < BPL; ++j) {
+        const int k = BPL * tf + j;
+        C xk, xm;
+        if (k == 0) {
+            const C z0 = rg.v[0];
+            xk = mk<T>((T)2 * (z0.x + z0.y), (T)0);  // Z is pre-halved (see split_pair)
+            xm = mk<T>((T)2 * (z0.x - z0.y), (T)0);
+            if (valid && a.nonfinite_flag && !(std::fabs(xk.x) <= std::numeric_limits<T>::max())) LRA_ATOMIC_OR(a.nonfinite_flag, 1u);
+        } else {
+            split_pair<T>(rg.v[2 * j], rg.v[2 * j + 1], Cfg::HOIST ? rg.twr[j] : a.twr[k], xk, xm);
+        }
+        const T pk = spec_power<T, PM>(xk, a.power), pm = spec_power<T, PM>(xm, a.power);
+        // (slot of pair i: i + i / BPL; both halves start on a run boundary, so the thread's pairs are base + j)
+        const C wk = lds_ld<C>(sh, ((BPL + 1) * tf + j) * (int)sizeof(C)), wm = lds_ld<C>(sh, ((BPL + 1) * (TF + tf) + j) * (int)sizeof(C));
+        ab[j] = mk<T>(wk.x * pk, wk.y * pk);
+        ab[BPL + j] = mk<T>(wm.x * pm, wm.y * pm);
+    }
+    // running sums: acc = keep * acc + ab (keep = 0 restarts the sum at the first bin of a pair segment / of the run)
+    LRA_UNROLL
+    for (int run = 0; run < 2; ++run) {
+        C acc = mk<T>((T)0, (T)0);
+        LRA_UNROLL
+        for (int j = 0; j < BPL; ++j) {
+            const int jj = run * BPL + j;
+            const T keep = rg.keep[jj];
+            acc = mk<T>(acc.x * keep + ab[jj].x, acc.y * keep + ab[jj].y);
+            lds_st<C>(rs, (jj * TF + tf) * (int)sizeof(C), acc);
+        }
+    }
+    if (tf == 0) {
+        const C xmid = mk<T>((T)2 * rg.mid.x, (T)-2 * rg.mid.y);  // X[M/2] = conj(Z[M/2]), Z pre-halved
+        const T pmid = spec_power<T, PM>(xmid, a.power);
+        const C wq = lds_ld<C>(sh, melr_w_slot<Cfg>(M) * (int)sizeof(C));
+        lds_st<C>(rs, a.melr_mid, mk<T>(wq.x * pmid, wq.y * pmid));
+        lds_st<C>(rs, a.melr_zero, mk<T>((T)0, (T)0));
+    }
+}
+
+// prologue: per-thread constants of the run-ordered epilogue -> registers (restart factors; the first MELR_PHOIST
+// entries of both piece lists of mel bands tf and tf + TF)
+template <class Cfg> LRA_HD void melr_hoist(const StftArgs<typename Cfg::real>& a, int tf, FftRegs<Cfg>& rg) {
+    constexpr int PH = FftRegs<Cfg>::MELR_PHOIST;
+    LRA_UNROLL
+    for (int jj = 0; jj < Cfg::R; ++jj) rg.keep[jj] = a.melr_keep[jj * Cfg::TF + tf];
+    LRA_UNROLL
+    for (int b = 0; b < 2; ++b) {
+        const int m = tf + b * Cfg::TF;
+        LRA_UNROLL
+        for (int h = 0; h < 2; ++h) {
+            LRA_UNROLL
+            for (int q = 0; q < PH; ++q) rg.mad[b][h * PH + q] = m < a.n_mels ? a.melr_addr[(h * MELR_PMAX + q) * a.n_mels + m] : a.melr_zero;
+        }
+    }
+}
+
+// phase: mel[m] = sum of the B totals of segment m's pieces + sum of the A totals of segment m+1's pieces
+// (ascending bins).  Bands tf and tf + TF use the hoisted address lists; longer lists / further bands read
+// theirs from the shared table.
+template <class Cfg> LRA_HD void melr_combine(const StftArgs<typename Cfg::real>& a, int clip, int frame, int tf, int it, int tile, const FftRegs<Cfg>& rg, Lds sh, Lds rs,
+                                              Lds stage) {
+    using T = typename Cfg::real;
+    constexpr int PH = FftRegs<Cfg>::MELR_PHOIST, TF = Cfg::TF;
+    const bool more = a.melr_pmax > PH;  // uniform
+    T x[2][2 * PH];
+    LRA_UNROLL
+    for (int b = 0; b < 2; ++b) {
+        LRA_UNROLL
+        for (int q = 0; q < 2 * PH; ++q) x[b][q] = lds_ld<T>(rs, rg.mad[b][q]);
+    }
+    LRA_UNROLL
+    for (int b = 0; b < 2; ++b) {
+        const int m = tf + b * TF;
+        if (m >= a.n_mels) break;
+        T part[2];
+        LRA_UNROLL
+        for (int h = 0; h < 2; ++h) {
+            T acc = (T)0;
+            LRA_UNROLL
+            for (int q = 0; q < PH; ++q) acc += x[b][h * PH + q];
+            if (more) {
+                for (int q = PH; q < MELR_PMAX; ++q)
+                    acc += lds_ld<T>(rs, lds_ld<int>(sh, melr_addr_off<Cfg>() + ((h * MELR_PMAX + q) * a.n_mels + m) * (int)sizeof(int)));
+            }
+            part[h] = acc;
+        }
+        const T v = part[0] + part[1];
+        if (tile == 1) a.Mel[((long long)clip * a.n_mels + m) * a.n_frames + frame] = v;
+        else lds_st<T>(stage, (m * tile + it) * (int)sizeof(T), v);
+    }
+    for (int m = tf + 2 * TF; m < a.n_mels; m += TF) {  // more than two bands per thread: everything from the table
+        T part[2];
+        LRA_UNROLL
+        for (int h = 0; h < 2; ++h) {
+            T acc = (T)0;
+            for (int q = 0; q < MELR_PMAX; ++q)
+                acc += lds_ld<T>(rs, lds_ld<int>(sh, melr_addr_off<Cfg>() + ((h * MELR_PMAX + q) * a.n_mels + m) * (int)sizeof(int)));
+            part[h] = acc;
+        }
+        const T v = part[0] + part[1];
+        if (tile == 1) a.Mel[((long long)clip * a.n_mels + m) * a.n_frames + frame] = v;
+        else lds_st<T>(stage, (m * tile + it) * (int)sizeof(T), v);
+    }
+}
+
 #define LRA_MID_PASS(Cfg, p, rg, lds, tw, slot_bytes)                                                     \
     if (Cfg::P > p) {                                                                                     \
         LRA_PHASE(Cfg::NT, tid) {                                                                         \
@@ -574,7 +734,7 @@ template <class Cfg> constexpr int stft_ring_off() { return Cfg::FRAME_BYTES; }
 template <class Cfg> constexpr int stft_tile_off() { return Cfg::FRAME_BYTES + Cfg::N * (int)sizeof(typename Cfg::real); }
 template <class Cfg> inline int stft_slot_bytes(int mode, int n_mels, int tile) {
     int b = stft_tile_off<Cfg>();
-    if (mode == OUT_MEL || (mode == OUT_MEL2 && tile > 1)) b += ((n_mels * tile * (int)sizeof(typename Cfg::real) + 15) / 16) * 16;
+    if (mode == OUT_MEL || ((mode == OUT_MEL2 || mode == OUT_MELR) && tile > 1)) b += ((n_mels * tile * (int)sizeof(typename Cfg::real) + 15) / 16) * 16;
     if (mode == OUT_MEL2) b += mel2_psum_bytes<Cfg>(n_mels);
     return b;
 }
@@ -592,9 +752,13 @@ template <class Cfg, int MODE, int PM = POW_TWO, bool RA = false> LRA_HD void st
     const int tile = a.mel_tile;
     LRA_REGS(FftRegs<Cfg>, rg, Cfg::NT);
     LRA_PHASE(Cfg::NT, tid) {
-        hoist_tables<Cfg>(LRA_R(rg), tid % Cfg::TF, a.win, a.tw, a.twr, false);
+        hoist_tables<Cfg>(LRA_R(rg), tid % Cfg::TF, a.win, a.tw, a.twr, false, MODE == OUT_MELR);
         if (MODE == OUT_MEL2) mel2_tables_to_lds<Cfg>(a, tid, lds_sub(lds, a.shared_off));
-    } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC && MODE != OUT_MEL2)  // the shared tables need a workgroup barrier, once
+        if (MODE == OUT_MELR) {
+            melr_tables_to_lds<Cfg>(a, tid, lds_sub(lds, a.shared_off));
+            melr_hoist<Cfg>(a, tid % Cfg::TF, LRA_R(rg));
+        }
+    } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC && MODE != OUT_MEL2 && MODE != OUT_MELR)  // the shared tables need a workgroup barrier, once
     LRA_PHASE(Cfg::NT, tid) {
         const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
         stft_ring_fill<Cfg>(a, clip, f_first + slot * iters, tf, lds_sub(lds, slot * slot_bytes + stft_ring_off<Cfg>()));
@@ -632,14 +796,16 @@ template <class Cfg, int MODE, int PM = POW_TWO, bool RA = false> LRA_HD void st
             const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
             const Lds sl = lds_sub(lds, slot * slot_bytes);
             if (LATE_PF && it + 1 < iters) stft_ring_prefetch<Cfg, RA>(a, clip, frame + 1, tf, LRA_R(rg));
-            split_read<Cfg>(LRA_R(rg), sl, tf);
+            if constexpr (MODE == OUT_MELR) split_read_runs<Cfg>(LRA_R(rg), sl, tf);
+            else split_read<Cfg>(LRA_R(rg), sl, tf);
             if (!LATE_PF && it + 1 < iters) stft_ring_advance<Cfg, RA>(a, clip, frame + 1, tf, LRA_R(rg), lds_sub(sl, stft_ring_off<Cfg>()));
             if (DEFER && tile > 1 && it > 0 && it % tile == 0)  // the tile that frame it-1 completed
                 mel_flush_tile<Cfg>(a, clip, f_first + slot * iters, it - 1, tile, tf, lds_sub(sl, stft_tile_off<Cfg>()));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
-            stft_split_store<Cfg, MODE, PM>(a, clip, frame, frame < a.n_frames, tf, LRA_R(rg), lds_sub(lds, slot * slot_bytes), lds_sub(lds, a.shared_off));
+            if constexpr (MODE == OUT_MELR) melr_split_accumulate<Cfg, PM>(a, frame < a.n_frames, tf, LRA_R(rg), lds_sub(lds, slot * slot_bytes), lds_sub(lds, a.shared_off));
+            else stft_split_store<Cfg, MODE, PM>(a, clip, frame, frame < a.n_frames, tf, LRA_R(rg), lds_sub(lds, slot * slot_bytes), lds_sub(lds, a.shared_off));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         if (MODE == OUT_MEL2 && LRA_ABLATE != 12 && LRA_ABLATE != 13) {
             LRA_PHASE(Cfg::NT, tid) {
@@ -649,13 +815,16 @@ template <class Cfg, int MODE, int PM = POW_TWO, bool RA = false> LRA_HD void st
                 if (LATE_PF && it + 1 < iters) stft_ring_advance<Cfg, RA>(a, clip, frame + 1, tf, LRA_R(rg), lds_sub(sl, stft_ring_off<Cfg>()));
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         }
-        if (MODE == OUT_MEL) {
+        if (MODE == OUT_MEL || MODE == OUT_MELR) {
             LRA_PHASE(Cfg::NT, tid) {
                 const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
                 const Lds sl = lds_sub(lds, slot * slot_bytes);
-                if (frame < a.n_frames) mel_reduce_slot<Cfg>(a, tf, it % tile, tile, sl, lds_sub(sl, stft_tile_off<Cfg>()));
+                if (frame < a.n_frames) {
+                    if constexpr (MODE == OUT_MELR) melr_combine<Cfg>(a, clip, frame, tf, it % tile, tile, LRA_R(rg), lds_sub(lds, a.shared_off), sl, lds_sub(sl, stft_tile_off<Cfg>()));
+                    else mel_reduce_slot<Cfg>(a, tf, it % tile, tile, sl, lds_sub(sl, stft_tile_off<Cfg>()));
+                }
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
-            if ((it + 1) % tile == 0 || it + 1 == iters || f_first + it + 1 >= a.n_frames) {
+            if (!(MODE == OUT_MELR && tile == 1) && ((it + 1) % tile == 0 || it + 1 == iters || f_first + it + 1 >= a.n_frames)) {
                 LRA_PHASE(Cfg::NT, tid) {
                     const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
                     mel_flush_tile<Cfg>(a, clip, f_first + slot * iters, it, tile, tf, lds_sub(lds, slot * slot_bytes + stft_tile_off<Cfg>()));

@@ -17,6 +17,7 @@
 // order: ascending bins).
 #pragma once
 
+#include <algorithm>
 #include <vector>
 
 namespace lra {
@@ -133,6 +134,100 @@ template <class T> inline MelPieces build_mel_pieces(const TwoSlope<T>& ts, int 
         if (seg_count[p] > mp.max_per_seg) mp.max_per_seg = seg_count[p];
     }
     return mp;
+}
+
+// ---- run-ordered epilogue (OUT_MELR) ------------------------------------------------------------------------
+// With `bpl` = R/2 and TF threads per frame, thread tf owns, in REGISTERS right after the Hermitian split,
+//     run A: bins  bpl tf + j           (ascending,  j = 0 .. bpl-1)   -- register slot jj = j
+//     run B: bins  M - bpl tf - j       (descending, j = 0 .. bpl-1)   -- register slot jj = bpl + j
+// (M = n_bins - 1; bin M/2 is an extra bin of thread 0).  It multiplies by (wA, wB), keeps a running sum
+// along each run that restarts where the run enters another pair segment, and writes ALL 2 bpl running sums
+// to LDS slot (jj TF + tf); a piece's total is the running sum at the piece's last slot.  mel[m] then adds
+// the B components of the pieces of segment m and the A components of the pieces of segment m+1: two fixed
+// lists of at most PMAX LDS addresses per mel band (unused entries point at a slot that holds zero).
+// Nothing in the device code depends on per-lane control flow.
+template <class T> struct MelRuns {
+    bool ok = false;
+    int tf = 0, bpl = 0, pmax = 0, max_pieces = 0;
+    std::vector<T> w;        // [2][M/2] pairs: (wA, wB)[i] for i < M/2, then (wA, wB)[M - i] for i < M/2; then the pair of bin M/2
+    std::vector<T> keep;     // [2 bpl][TF]: 0 where the running sum restarts, 1 elsewhere
+    std::vector<int> addr;   // [2 pmax][n_mels]: byte addresses (entries 0..pmax-1: B components, then the A components)
+    int zero_addr = 0, mid_addr = 0;  // byte addresses of the always-zero slot and of bin M/2's (A, B) slot
+};
+
+template <class T> inline MelRuns<T> build_mel_runs(const TwoSlope<T>& ts, int tf_count, int bpl, int pmax) {
+    MelRuns<T> mr;
+    mr.tf = tf_count;
+    mr.bpl = bpl;
+    mr.pmax = pmax;
+    const int M = ts.n_bins - 1;
+    if (!ts.ok || bpl < 1 || 2 * bpl * tf_count != M || pmax < 1) return mr;
+    const int half = M / 2, slots = 2 * bpl * tf_count, pair_bytes = 2 * (int)sizeof(T);
+    mr.zero_addr = slots * pair_bytes;
+    mr.mid_addr = (slots + 1) * pair_bytes;
+    if (mr.mid_addr + pair_bytes > 65535) return mr;
+    mr.w.assign(2 * (size_t)(2 * half + 1), (T)0);
+    for (int i = 0; i < half; ++i) {
+        mr.w[2 * (size_t)i] = ts.wAB[2 * (size_t)i];
+        mr.w[2 * (size_t)i + 1] = ts.wAB[2 * (size_t)i + 1];
+        mr.w[2 * (size_t)(half + i)] = ts.wAB[2 * (size_t)(M - i)];
+        mr.w[2 * (size_t)(half + i) + 1] = ts.wAB[2 * (size_t)(M - i) + 1];
+    }
+    mr.w[2 * (size_t)(2 * half)] = ts.wAB[2 * (size_t)half];
+    mr.w[2 * (size_t)(2 * half) + 1] = ts.wAB[2 * (size_t)half + 1];
+    // bin -> register slot; effective segment of a bin (bins outside every filter carry zero weights and simply
+    // extend the neighbouring stretch)
+    auto bin_of = [&](int t, int jj) { return jj < bpl ? bpl * t + jj : M - bpl * t - (jj - bpl); };
+    mr.keep.assign((size_t)2 * bpl * tf_count, (T)1);
+    // pieces: (segment, byte address of the slot that holds the piece's total, lowest bin) in bin order per segment
+    struct Piece { int seg, addr, lowbin; };
+    std::vector<Piece> pieces;
+    for (int t = 0; t < tf_count; ++t) {
+        for (int run = 0; run < 2; ++run) {
+            int cur = -2;  // segment of the current stretch (-2: none yet)
+            for (int j = 0; j < bpl; ++j) {
+                const int jj = run * bpl + j, k = bin_of(t, jj);
+                const int seg = ts.owner[k];
+                const bool restart = j == 0 || (seg >= 0 && cur >= 0 && seg != cur);
+                if (restart) {
+                    mr.keep[(size_t)jj * tf_count + t] = (T)0;
+                    if (j > 0 && cur >= 0) {  // the previous slot closed a piece of segment cur
+                        const int pj = jj - 1;
+                        int lo = bin_of(t, pj), hi = lo;
+                        pieces.push_back({cur, (pj * tf_count + t) * pair_bytes, 0});
+                        (void)lo; (void)hi;
+                    }
+                    cur = seg >= 0 ? seg : -2;
+                } else if (seg >= 0 && cur < 0) {
+                    cur = seg;  // first weighted bin of a stretch that began with unweighted bins
+                }
+            }
+            if (cur >= 0) pieces.push_back({cur, ((run * bpl + bpl - 1) * tf_count + t) * pair_bytes, 0});
+        }
+    }
+    if (ts.owner[half] >= 0) pieces.push_back({ts.owner[half], mr.mid_addr, 0});
+    // lowest bin of each piece (for ordering): recompute from the address
+    for (auto& pc : pieces) {
+        if (pc.addr == mr.mid_addr) { pc.lowbin = half; continue; }
+        const int slot = pc.addr / pair_bytes, jj = slot / tf_count, t = slot % tf_count;
+        pc.lowbin = bin_of(t, jj);  // run A: the last (highest) bin; run B: the last slot is the LOWEST bin -- either orders pieces consistently
+    }
+    std::vector<std::vector<Piece>> by_seg((size_t)ts.n_mels + 1);
+    for (const auto& pc : pieces) by_seg[(size_t)pc.seg].push_back(pc);
+    for (auto& v : by_seg) {
+        std::sort(v.begin(), v.end(), [](const Piece& a, const Piece& b) { return a.lowbin < b.lowbin; });
+        if ((int)v.size() > mr.max_pieces) mr.max_pieces = (int)v.size();
+    }
+    if (mr.max_pieces > pmax) return mr;
+    mr.addr.assign((size_t)ts.n_mels * 2 * pmax, mr.zero_addr);  // [entry][mel]
+    for (int m = 0; m < ts.n_mels; ++m) {
+        int q = 0;
+        for (const auto& pc : by_seg[(size_t)m]) mr.addr[(size_t)(q++) * ts.n_mels + m] = pc.addr + (int)sizeof(T);              // B component
+        q = 0;
+        for (const auto& pc : by_seg[(size_t)m + 1]) mr.addr[(size_t)(pmax + q++) * ts.n_mels + m] = pc.addr;                    // A component
+    }
+    mr.ok = true;
+    return mr;
 }
 
 }  // namespace lra

@@ -59,6 +59,8 @@ if what == "ablate":
             ms = timeit(lambda: ctx.stft_exec(plan, y.data_ptr(), batch, n, n, D.data_ptr()))
             print(f"{os.environ.get('LIBROSA_AMD_LIBRARY', 'product')}: variant {variant} iters {iters}: stft {ms:.3f} ms ({batch * T / ms / 1e3:.1f} Mframes/s)", flush=True)
 elif what == "iters":
+    ctx.set_option("mel_runs", int(os.environ.get("PROBE_MEL_RUNS", "1")))
+    ctx.set_option("autotune", 0)
     for variant in (0, 1, 4):
         ctx.set_option("variant", variant)
         for iters in [int(v) for v in os.environ.get("PROBE_ITERS", "16,21,27,32,41,54,62,81,108,162,324").split(",")]:

@@ -76,8 +76,8 @@ def mel_band(B):
 
 
 def stft(y, n_fft, hop, win, center=True, pad_mode="constant", mode=0, iters_per_wg=1, power=2.0, mel_basis=None, variant=0):
-    """y: (batch, n) f32/f64.  mode 0 -> complex (batch, T, M+1); 1 -> power; 2 / 3 -> mel (batch, n_mels, T)
-    through the generic banded path / the two-slope path."""
+    """y: (batch, n) f32/f64.  mode 0 -> complex (batch, T, M+1); 1 -> power; 2 / 3 / 4 -> mel (batch, n_mels, T)
+    through the generic banded path / the two-slope path / its run-ordered form."""
     y = np.ascontiguousarray(y)
     assert y.ndim == 2
     f64 = y.dtype == np.float64
@@ -106,8 +106,10 @@ def stft(y, n_fft, hop, win, center=True, pad_mode="constant", mode=0, iters_per
             ctypes.c_int(hop), ctypes.c_int(int(center)), ctypes.c_int(PAD_MODES[pad_mode]), _p(win), ctypes.c_int(iters_per_wg), _p(out),
             ctypes.c_int(pm), ctypes.c_double(power), _p(c0), _p(ln), _p(off), _p(val), ctypes.c_int(n_mels), ctypes.c_int(variant), _p(dense), _p(diag))
     assert rc == 0, "unsupported n_fft for the pow2 kernels"
+    if mode == 4 and diag[7] != 0:
+        return None, dict(unavailable=int(diag[7]))  # run-ordered form not applicable to this configuration (the library falls back too)
     assert diag[7] == 0, "two-slope mel form not applicable"
-    return out, dict(races=int(diag[0]), uninit=int(diag[1]), NT=int(diag[2]), FPB=int(diag[3]), P=int(diag[4]), lds=int(diag[5]), wave_sync=int(diag[6]), ring_aligned=int(diag[8]))
+    return out, dict(races=int(diag[0]), uninit=int(diag[1]), NT=int(diag[2]), FPB=int(diag[3]), P=int(diag[4]), lds=int(diag[5]), wave_sync=int(diag[6]), ring_aligned=int(diag[8]), max_pieces=int(diag[9]))
 
 
 def istft(D, n_fft, hop, win, wss, out_len, n_used, center=True, strip_groups=4, variant=0):

@@ -90,6 +90,13 @@ def test_power_and_mel_body(n_fft, hop, power, n_mels, dtype, variant):
     assert np.all(np.abs(M2 - Mref) <= 1e-5 * np.abs(Mref) + 1e-5 * Mref.max())
     # mel parity bar |d| <= 1e-4 |ref| + 1e-4 max|ref|; the f32 pipeline is ~100x inside it
     assert np.all(np.abs(Mo - Mref) <= 1e-5 * np.abs(Mref) + 1e-5 * Mref.max())
+    # run-ordered two-slope path (16 points per thread only; falls back when a segment needs too many pieces)
+    M4, d4 = H.stft(y, n_fft, hop, win, mode=4, power=power, mel_basis=B, iters_per_wg=3, variant=variant)
+    if M4 is None:
+        assert not (n_fft == 2048 and n_mels == 128 and dtype == np.float32 and variant == 0), d4  # the headline configuration must have it
+    else:
+        _check_diag(d4)
+        assert np.all(np.abs(M4 - Mref) <= 1e-5 * np.abs(Mref) + 1e-5 * Mref.max())
 
 
 def _istft_inputs(y, n_fft, hop, center, length, window="hann", win_length=None):
