@@ -699,7 +699,11 @@ template <class Cfg> LRA_HD void melr_combine(const StftArgs<typename Cfg::real>
             part[h] = acc;
         }
         const T v = part[0] + part[1];
+#if LRA_ABLATE == 21  // experiment: no mel stores
+        if (tile == 1 && v == (T)12345.678) a.Mel[((long long)clip * a.n_mels + m) * a.n_frames + frame] = v;
+#else
         if (tile == 1) a.Mel[((long long)clip * a.n_mels + m) * a.n_frames + frame] = v;
+#endif
         else lds_st<T>(stage, (m * tile + it) * (int)sizeof(T), v);
     }
     for (int m = tf + 2 * TF; m < a.n_mels; m += TF) {  // more than two bands per thread: everything from the table

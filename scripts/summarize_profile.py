@@ -23,14 +23,17 @@ os.makedirs(dst, exist_ok=True)
 
 def short(name):
     if "istft_kernel" in name:
-        return "istft_kernel"
+        import re
+        cfg = re.search(r"FftCfg<(\d+), (\d), (\w+), (\d+), (\d), (\w+)>", name)
+        return "istft_kernel" + (f" [n_fft={2 ** (int(cfg.group(1)) + 1)}, 2^{cfg.group(2)} pts/thread, NT={cfg.group(4)}]" if cfg else "")
     if "stft_kernel" in name:
         import re
         m = re.search(r">, (\d), (\d), (true|false)>\(", name) or re.search(r">, (\d)(?:, \d)?>\(", name)
         mode = m.group(1) if m else "?"
         cfg = re.search(r"FftCfg<(\d+), (\d), (\w+), (\d+), (\d), (\w+)>", name)
-        tag = f" [2^{cfg.group(2)} pts/thread, NT={cfg.group(4)}]" if cfg else ""
-        return {"0": "stft_kernel<complex64 out>", "1": "stft_kernel<power out>", "2": "stft_kernel<mel, generic>", "3": "stft_kernel<mel, two-slope>"}.get(mode, "stft_kernel<?>") + tag
+        tag = f" [n_fft={2 ** (int(cfg.group(1)) + 1)}, 2^{cfg.group(2)} pts/thread, NT={cfg.group(4)}]" if cfg else ""
+        return {"0": "stft_kernel<complex64 out>", "1": "stft_kernel<power out>", "2": "stft_kernel<mel, generic>", "3": "stft_kernel<mel, two-slope>",
+                "4": "stft_kernel<mel, run-ordered two-slope>"}.get(mode, "stft_kernel<?>") + tag
     return name.split("(")[0][-60:]
 
 
@@ -82,6 +85,7 @@ for k in set(list(fetch) + list(write)):
         "fetch_bytes_raw": f_raw, "write_bytes_raw": w_raw,
         "fetch_bytes": f_raw / fc if f_raw is not None else None, "write_bytes": w_raw / wc if w_raw is not None else None,
         "hbm_bytes": (f_raw / fc if f_raw is not None else 0) + (w_raw / wc if w_raw is not None else 0),
+        "launches": max(len(fetch.get(k, {}).get("FETCH_SIZE", [])), len(write.get(k, {}).get("WRITE_SIZE", []))),
     }
 json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1)
 
