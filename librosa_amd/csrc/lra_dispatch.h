@@ -21,7 +21,7 @@ constexpr int kNumVariants = 5; // tuning variants exist for f32 n_fft = 2048 on
 // Variants 1 and 4 (f32, n_fft = 2048) split a frame over two waves (8 points per thread) for higher
 // occupancy; variants 2 and 3 were retired (always slower) and now alias variant 0.  bench.py --sweep times them.
 template <class T, int L, int VAR> struct CfgSel {
-    using type = FftCfg<L, 4, T, 64, 2, (L <= 10)>;
+    using type = FftCfg<L, 4, T, 64, 2, true>;
 };
 template <int L, int VAR> struct CfgSel<double, L, VAR> {
     using type = FftCfg<L, 3, double, 64, 2, false>;

@@ -67,6 +67,51 @@ def _wss_for(skw, n_total_frames, out_len, length, dtype):
     return O.fix_length(wss[(n_fft // 2 if center else 0) :], size=out_len)
 
 
+def test_mel_epilogue_forms_agree(L):
+    """The run-ordered two-slope epilogue (default where it applies), the masked two-slope fallback and the generic
+    banded path must all match the oracle: 128 / 80 mels (run-ordered), 40 mels (too many pieces: falls back)."""
+    import torch
+
+    yh = O.config_input(3, n=30000)
+    y = torch.from_numpy(yh).cuda()
+    ctx = L.get_context(0)
+    bad = []
+    try:
+        for n_fft, hop, n_mels, power in ((2048, 512, 128, 2.0), (2048, 512, 80, 1.0), (2048, 256, 40, 2.0), (1024, 256, 80, 2.0), (1024, 256, 64, 1.5)):
+            Mref = O.melspectrogram(y=yh, n_fft=n_fft, hop_length=hop, n_mels=n_mels, power=power)
+            for runs, generic in ((1, 0), (0, 0), (0, 1)):
+                ctx.set_option("mel_runs", runs)
+                ctx.set_option("generic_mel", generic)
+                M = L.feature.melspectrogram(y=y, n_fft=n_fft, hop_length=hop, n_mels=n_mels, power=power).cpu().numpy()
+                if not _mel_close(M, Mref):
+                    bad.append((n_fft, hop, n_mels, power, runs, generic, float(np.abs(M - Mref).max() / Mref.max())))
+    finally:
+        ctx.set_option("mel_runs", 1)
+        ctx.set_option("generic_mel", 0)
+    assert not bad, bad
+
+
+def test_autotune_picks_a_variant_and_stays_correct(L):
+    """A large first call times the kernel variants on its own buffers; the result must be unaffected."""
+    import torch
+
+    yh = O.config_input(130, n=22050 * 12)  # 130 x 517 = 67 210 frames: above the autotune threshold (65 536)
+    y = torch.from_numpy(yh).cuda()
+    ctx = L.get_context(0)
+    window = np.asarray(L.filters.get_window("hann", 2048, fftbins=True), dtype=np.float32)
+    ctx.set_option("autotune", 1)
+    D = L.stft(y, n_fft=2048, hop_length=512)
+    M = L.feature.melspectrogram(y=y, n_fft=2048, hop_length=512)
+    yy = L.istft(D, hop_length=512, length=yh.shape[-1])
+    torch.cuda.synchronize()
+    plan = ctx.stft_plan(2048, 512, window, True, "constant", np.float32)
+    assert ctx.tuned_variant(plan, 0) in (0, 4) and ctx.tuned_variant(plan, 2) in (0, 4)
+    k = 5  # spot-check a clip against the oracle
+    assert _stft_close(D[k].cpu().numpy(), O.stft(yh[k], n_fft=2048, hop_length=512))
+    assert _mel_close(M[k].cpu().numpy(), O.melspectrogram(y=yh[k], n_fft=2048, hop_length=512))
+    assert np.abs(yy[k].cpu().numpy() - yh[k]).max() <= 2e-5
+
+
 # ---------------------------------------------------------------------------------------------------
 # 1. committed reference outputs
 # ---------------------------------------------------------------------------------------------------
