@@ -82,6 +82,16 @@ template <class T> struct StftArgs {
     unsigned int* nonfinite_flag;
 };
 
+// Thread -> (frame slot, thread within the slot).  The slot index is wave-uniform whenever a slot is one or more
+// whole waves (TF >= 64): fetching it through readfirstlane keeps everything derived from it -- frame number,
+// row bases of the stores, prefetch pointers and their 64-bit bound checks -- in SGPRs and on the scalar unit.
+template <class Cfg> LRA_HD int slot_of(int tid) {
+    if (Cfg::FPB == 1) return 0;
+    if (Cfg::TF >= 64) return LRA_UNIFORM((int)((unsigned)tid / (unsigned)Cfg::TF));
+    return (int)((unsigned)tid / (unsigned)Cfg::TF);
+}
+template <class Cfg> LRA_HD int lane_of(int tid) { return (int)((unsigned)tid % (unsigned)Cfg::TF); }
+
 template <class Cfg> struct FftRegs {
     typename Cfg::cplx v[Cfg::R];
     typename Cfg::cplx mid;
@@ -724,11 +734,11 @@ template <class Cfg> LRA_HD void melr_combine(const StftArgs<typename Cfg::real>
 #define LRA_MID_PASS(Cfg, p, rg, lds, tw, slot_bytes)                                                     \
     if (Cfg::P > p) {                                                                                     \
         LRA_PHASE(Cfg::NT, tid) {                                                                         \
-            pass_read<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(rg).v, lds_sub(lds, (tid / Cfg::TF) * (slot_bytes)), tid % Cfg::TF); \
+            pass_read<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(rg).v, lds_sub(lds, (slot_of<Cfg>(tid)) * (slot_bytes)), lane_of<Cfg>(tid)); \
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)                                                              \
         LRA_PHASE(Cfg::NT, tid) {                                                                         \
-            pass_dft<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(rg), tid % Cfg::TF, tw);                          \
-            pass_write<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(rg).v, lds_sub(lds, (tid / Cfg::TF) * (slot_bytes)), tid % Cfg::TF); \
+            pass_dft<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(rg), lane_of<Cfg>(tid), tw);                          \
+            pass_write<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(rg).v, lds_sub(lds, (slot_of<Cfg>(tid)) * (slot_bytes)), lane_of<Cfg>(tid)); \
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)                                                              \
     }
 
@@ -756,15 +766,15 @@ template <class Cfg, int MODE, int PM = POW_TWO, bool RA = false> LRA_HD void st
     const int tile = a.mel_tile;
     LRA_REGS(FftRegs<Cfg>, rg, Cfg::NT);
     LRA_PHASE(Cfg::NT, tid) {
-        hoist_tables<Cfg>(LRA_R(rg), tid % Cfg::TF, a.win, a.tw, a.twr, false, MODE == OUT_MELR);
+        hoist_tables<Cfg>(LRA_R(rg), lane_of<Cfg>(tid), a.win, a.tw, a.twr, false, MODE == OUT_MELR);
         if (MODE == OUT_MEL2) mel2_tables_to_lds<Cfg>(a, tid, lds_sub(lds, a.shared_off));
         if (MODE == OUT_MELR) {
             melr_tables_to_lds<Cfg>(a, tid, lds_sub(lds, a.shared_off));
-            melr_hoist<Cfg>(a, tid % Cfg::TF, LRA_R(rg));
+            melr_hoist<Cfg>(a, lane_of<Cfg>(tid), LRA_R(rg));
         }
     } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC && MODE != OUT_MEL2 && MODE != OUT_MELR)  // the shared tables need a workgroup barrier, once
     LRA_PHASE(Cfg::NT, tid) {
-        const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
+        const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
         stft_ring_fill<Cfg>(a, clip, f_first + slot * iters, tf, lds_sub(lds, slot * slot_bytes + stft_ring_off<Cfg>()));
     } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
     // OUT_MEL2 defers the last two steps of frame t's mel epilogue into frame t+1's phases (their LDS
@@ -784,7 +794,7 @@ template <class Cfg, int MODE, int PM = POW_TWO, bool RA = false> LRA_HD void st
         if (f_first + it >= a.n_frames) break;  // slot 0 has the smallest frame index: uniform exit
         if (!Cfg::HOIST) { LRA_LAUNDER(a.win); LRA_LAUNDER(a.tw); LRA_LAUNDER(a.twr); }
         LRA_PHASE(Cfg::NT, tid) {
-            const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
+            const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
             const Lds sl = lds_sub(lds, slot * slot_bytes);
             if (!LATE_PF && it + 1 < iters) stft_ring_prefetch<Cfg, RA>(a, clip, frame + 1, tf, LRA_R(rg));
             if (DEFER && it > 0 && frame - 1 < a.n_frames)
@@ -797,7 +807,7 @@ template <class Cfg, int MODE, int PM = POW_TWO, bool RA = false> LRA_HD void st
         LRA_MID_PASS(Cfg, 3, rg, lds, a.tw, slot_bytes)
 #endif
         LRA_PHASE(Cfg::NT, tid) {
-            const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
+            const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
             const Lds sl = lds_sub(lds, slot * slot_bytes);
             if (LATE_PF && it + 1 < iters) stft_ring_prefetch<Cfg, RA>(a, clip, frame + 1, tf, LRA_R(rg));
             if constexpr (MODE == OUT_MELR) split_read_runs<Cfg>(LRA_R(rg), sl, tf);
@@ -807,13 +817,13 @@ template <class Cfg, int MODE, int PM = POW_TWO, bool RA = false> LRA_HD void st
                 mel_flush_tile<Cfg>(a, clip, f_first + slot * iters, it - 1, tile, tf, lds_sub(sl, stft_tile_off<Cfg>()));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         LRA_PHASE(Cfg::NT, tid) {
-            const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
+            const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
             if constexpr (MODE == OUT_MELR) melr_split_accumulate<Cfg, PM>(a, frame < a.n_frames, tf, LRA_R(rg), lds_sub(lds, slot * slot_bytes), lds_sub(lds, a.shared_off));
             else stft_split_store<Cfg, MODE, PM>(a, clip, frame, frame < a.n_frames, tf, LRA_R(rg), lds_sub(lds, slot * slot_bytes), lds_sub(lds, a.shared_off));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         if (MODE == OUT_MEL2 && LRA_ABLATE != 12 && LRA_ABLATE != 13) {
             LRA_PHASE(Cfg::NT, tid) {
-                const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
+                const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
                 const Lds sl = lds_sub(lds, slot * slot_bytes);
                 if (frame < a.n_frames) mel2_gather<Cfg>(a, tf, sl, lds_sub(lds, a.shared_off), lds_sub(sl, slot_bytes - mel2_psum_bytes<Cfg>(a.n_mels)));
                 if (LATE_PF && it + 1 < iters) stft_ring_advance<Cfg, RA>(a, clip, frame + 1, tf, LRA_R(rg), lds_sub(sl, stft_ring_off<Cfg>()));
@@ -821,7 +831,7 @@ template <class Cfg, int MODE, int PM = POW_TWO, bool RA = false> LRA_HD void st
         }
         if (MODE == OUT_MEL || MODE == OUT_MELR) {
             LRA_PHASE(Cfg::NT, tid) {
-                const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
+                const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
                 const Lds sl = lds_sub(lds, slot * slot_bytes);
                 if (frame < a.n_frames) {
                     if constexpr (MODE == OUT_MELR) melr_combine<Cfg>(a, clip, frame, tf, it % tile, tile, LRA_R(rg), lds_sub(lds, a.shared_off), sl, lds_sub(sl, stft_tile_off<Cfg>()));
@@ -830,7 +840,7 @@ template <class Cfg, int MODE, int PM = POW_TWO, bool RA = false> LRA_HD void st
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
             if (!(MODE == OUT_MELR && tile == 1) && ((it + 1) % tile == 0 || it + 1 == iters || f_first + it + 1 >= a.n_frames)) {
                 LRA_PHASE(Cfg::NT, tid) {
-                    const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
+                    const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
                     mel_flush_tile<Cfg>(a, clip, f_first + slot * iters, it, tile, tf, lds_sub(lds, slot * slot_bytes + stft_tile_off<Cfg>()));
                 } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
             }
@@ -840,14 +850,14 @@ template <class Cfg, int MODE, int PM = POW_TWO, bool RA = false> LRA_HD void st
     if (DEFER && done > 0) {  // epilogue of the last frame
         const int it = done - 1;
         LRA_PHASE(Cfg::NT, tid) {
-            const int slot = tid / Cfg::TF, tf = tid % Cfg::TF, frame = f_first + slot * iters + it;
+            const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
             const Lds sl = lds_sub(lds, slot * slot_bytes);
             if (frame < a.n_frames)
                 mel2_combine<Cfg>(a, clip, frame, tf, it % tile, tile, lds_sub(lds, a.shared_off), lds_sub(sl, slot_bytes - mel2_psum_bytes<Cfg>(a.n_mels)), lds_sub(sl, stft_tile_off<Cfg>()));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         if (tile > 1) {
             LRA_PHASE(Cfg::NT, tid) {
-                const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
+                const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
                 mel_flush_tile<Cfg>(a, clip, f_first + slot * iters, it, tile, tf, lds_sub(lds, slot * slot_bytes + stft_tile_off<Cfg>()));
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         }
@@ -1206,11 +1216,11 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
     // the slot's strip (64-bit divisions) is worked out once, from the un-laundered thread index
     LRA_REGS(IstftSlot<Cfg>, sl, Cfg::NT);
     LRA_PHASE(Cfg::NT, tid) {
-        const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
+        const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
         hoist_tables<Cfg>(LRA_R(rg), tf, a.win_scaled, a.tw, a.twr, true);
         const Lds c0 = lds_sub(lds, slot * SB + Cfg::FRAME_BYTES);
         for (int u = tf; u < Cfg::N; u += Cfg::TF) lds_st<T>(c0, u * (int)sizeof(T), (T)0);
-        LRA_R(sl) = istft_slot<Cfg>(a, blk, LRA_RAW_TID(tid) / Cfg::TF);
+        LRA_R(sl) = istft_slot<Cfg>(a, blk, slot_of<Cfg>(LRA_RAW_TID(tid)));
         const IstftSlot<Cfg> s = LRA_R(sl);
         const int t = s.t0 - a.warm_frames;
         istft_spec_load<Cfg>(a, s.clip, t, s.active && t >= 0 && t < s.t1, tf, LRA_R(rg));
@@ -1220,7 +1230,7 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
         // (a) split the prefetched spectrum of frame j into LDS, (b) only now issue the held-back output
         // stores of frame j-1, (c) start the prefetch of frame j+1: the wait in (a) never covers (b)
         LRA_PHASE(Cfg::NT, tid) {
-            const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
+            const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
             const IstftSlot<Cfg> s = LRA_R(sl);
             const int t = s.t0 - a.warm_frames + j;
             istft_split_write<Cfg>(a, tf, LRA_R(rg), lds_sub(lds, slot * SB));
@@ -1236,23 +1246,23 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
         // pass 0 (no twiddles) reads from LDS here, unlike the forward kernel
         if (Cfg::P > 1) {
             LRA_PHASE(Cfg::NT, tid) {
-                pass_read<Cfg, 0>(LRA_R(rg).v, lds_sub(lds, (tid / Cfg::TF) * SB), tid % Cfg::TF);
+                pass_read<Cfg, 0>(LRA_R(rg).v, lds_sub(lds, (slot_of<Cfg>(tid)) * SB), lane_of<Cfg>(tid));
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
             LRA_PHASE(Cfg::NT, tid) {
-                pass_dft<Cfg, 0>(LRA_R(rg), tid % Cfg::TF, a.tw);
-                pass_write<Cfg, 0>(LRA_R(rg).v, lds_sub(lds, (tid / Cfg::TF) * SB), tid % Cfg::TF);
+                pass_dft<Cfg, 0>(LRA_R(rg), lane_of<Cfg>(tid), a.tw);
+                pass_write<Cfg, 0>(LRA_R(rg).v, lds_sub(lds, (slot_of<Cfg>(tid)) * SB), lane_of<Cfg>(tid));
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         }
         if (Cfg::P > 2) { LRA_MID_PASS(Cfg, 1, rg, lds, a.tw, SB) }
         if (Cfg::P > 3) { LRA_MID_PASS(Cfg, 2, rg, lds, a.tw, SB) }
         LRA_PHASE(Cfg::NT, tid) {
-            pass_read<Cfg, Cfg::P - 1>(LRA_R(rg).v, lds_sub(lds, (tid / Cfg::TF) * SB), tid % Cfg::TF);
+            pass_read<Cfg, Cfg::P - 1>(LRA_R(rg).v, lds_sub(lds, (slot_of<Cfg>(tid)) * SB), lane_of<Cfg>(tid));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         LRA_PHASE(Cfg::NT, tid) {
-            istft_last_write<Cfg>(a, LRA_R(rg), tid % Cfg::TF, lds_sub(lds, (tid / Cfg::TF) * SB));
+            istft_last_write<Cfg>(a, LRA_R(rg), lane_of<Cfg>(tid), lds_sub(lds, (slot_of<Cfg>(tid)) * SB));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         LRA_PHASE(Cfg::NT, tid) {
-            const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
+            const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
             const IstftSlot<Cfg> s = LRA_R(sl);
             const int t = s.t0 - a.warm_frames + j;
             if (s.active) {
@@ -1264,7 +1274,7 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
     }
     if (defer && steps > 0) {
         LRA_PHASE(Cfg::NT, tid) {
-            const int slot = tid / Cfg::TF, tf = tid % Cfg::TF;
+            const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
             const IstftSlot<Cfg> s = LRA_R(sl);
             if (s.active) {
                 const int tl = s.t0 - a.warm_frames + steps - 1;
