@@ -329,9 +329,10 @@ template <class T> struct IstftLaunch {
         a.batch = batch;
         int lds = istft_lds_bytes<Cfg, false>();
         void (*kern)(IstftArgs<T>, const cx<T>*, const T*, T*) = istft_kernel<Cfg, 0>;
-        if constexpr (sizeof(T) == 4) {  // row-aligned overlap-add for hop = n_fft/4 and n_fft/8 (f32)
+        if constexpr (sizeof(T) == 4) {  // row-aligned overlap-add for hop = n_fft/2, n_fft/4 and n_fft/8 (f32)
             const int hc = istft_rows_hc<Cfg>(a.hop);
             if constexpr (Cfg::R >= 4) {
+                if (hc == Cfg::R / 2) kern = istft_kernel<Cfg, Cfg::R / 2>;
                 if (hc == Cfg::R / 4) kern = istft_kernel<Cfg, Cfg::R / 4>;
             }
             if constexpr (Cfg::R >= 8) {

@@ -87,8 +87,8 @@ LRA_CFG_ALIAS(cfg_f64_12, double, 12, 0)
     S(lra::C, 2, 1, RA) S(lra::C, 2, 2, RA) S(lra::C, 2, 3, RA)                                      \
     S(lra::C##_mel, 3, 1, RA) S(lra::C##_mel, 3, 2, RA) S(lra::C##_mel, 3, 3, RA)                   \
     S(lra::C##_mel, 4, 1, RA) S(lra::C##_mel, 4, 2, RA) S(lra::C##_mel, 4, 3, RA)
-// f32: both ring addressings; all three overlap-add row counts (HC = R/4 = 4, R/8 = 2 at 16 points per thread)
-#define LRA_F32_CFG(S, I, C, HCQ, HCE) LRA_STFT_SET(S, C, false) LRA_STFT_SET(S, C, true) I(lra::C, 0) I(lra::C, HCQ) I(lra::C, HCE)
+// f32: both ring addressings; the overlap-add row counts HC = R/2, R/4, R/8 (8, 4, 2 at 16 points per thread)
+#define LRA_F32_CFG(S, I, C, HCQ, HCE) LRA_STFT_SET(S, C, false) LRA_STFT_SET(S, C, true) I(lra::C, 0) I(lra::C, (2 * HCQ)) I(lra::C, HCQ) I(lra::C, HCE)
 #define LRA_F64_CFG(S, I, C) LRA_STFT_SET(S, C, false) I(lra::C, 0)
 
 #define LRA_INST_GROUP_0(S, I) LRA_F32_CFG(S, I, cfg_f32_10, 4, 2)

@@ -95,21 +95,23 @@ template <class Cfg> LRA_HD int lane_of(int tid) { return (int)((unsigned)tid % 
 template <class Cfg> struct FftRegs {
     typename Cfg::cplx v[Cfg::R];
     typename Cfg::cplx mid;
-    // next frame's new hop samples, in flight while the current frame is transformed (hop <= n_fft/4)
+    // next frame's new hop samples, in flight while the current frame is transformed (hop <= n_fft/4 ...
     static constexpr int NPF = (Cfg::N / 4) / Cfg::TF > 0 ? (Cfg::N / 4) / Cfg::TF : 1;
-    typename Cfg::real pf[NPF];
+    // ... up to hop = n_fft/2 in the kernels with general ring addressing (the row-aligned ones use the first NPF only)
+    static constexpr int NPFX = 2 * NPF;
+    typename Cfg::real pf[NPFX];
     // HOIST configurations: this thread's table values, loaded once before the frame loop.  (hipcc
     // does not hoist them by itself across the per-phase fences; re-reading ~52 table values per
     // frame from L2 left the waves 65 % of their time in s_waitcnt.)
     // ISTFT: next frame's spectrum bins (X[k], X[M-k] pairs and X[M/2]) in flight during the current
     // frame, and the current hop's finished output samples held back until that prefetch has landed
     typename Cfg::cplx xk[Cfg::R / 2 > 0 ? Cfg::R / 2 : 1], xm[Cfg::R / 2 > 0 ? Cfg::R / 2 : 1], xmid;
-    typename Cfg::real out[NPF];
+    typename Cfg::real out[NPFX];  // ISTFT hold-back (hop <= n_fft/2 in the row-aligned kernels, <= n_fft/4 otherwise)
     // OUT_MELR: this thread's restart factors and the first MELR_PHOIST entries of the piece lists of its (up to two) mel bands
     static constexpr int MELR_PHOIST = 4;
     typename Cfg::real keep[Cfg::R];
     int mad[2][2 * MELR_PHOIST];
-    typename Cfg::real wv[NPF];  // ISTFT (row-aligned): window sum-square values of the held-back samples, loaded a frame ahead
+    typename Cfg::real wv[NPFX];  // ISTFT (row-aligned): window sum-square values of the held-back samples, loaded a frame ahead
     static constexpr int NH = Cfg::HOIST ? 1 : 0;
     typename Cfg::cplx win2[NH * Cfg::R + 1 - NH];       // window pairs in pass-0 register order
     typename Cfg::cplx treg[NH * Cfg::TREG_TOTAL + 1 - NH];
@@ -200,7 +202,7 @@ template <class Cfg> LRA_HD void stft_ring_fill(const StftArgs<typename Cfg::rea
 template <class Cfg> LRA_HD bool ring_block_prefetchable(const StftArgs<typename Cfg::real>& a, int next) {
     constexpr int N = Cfg::N;
     const int H = a.hop, Hn = H < N ? H : N;
-    if (4 * Hn > N || next >= a.n_frames) return false;
+    if (2 * Hn > N || next >= a.n_frames) return false;
     const long long g1 = (long long)next * H + (N - Hn) - a.pad;
     return g1 >= 0 && g1 + Hn <= a.n;
 }
@@ -218,7 +220,7 @@ template <class Cfg, bool RA> LRA_HD void stft_ring_prefetch(const StftArgs<type
         return;
     }
     LRA_UNROLL
-    for (int c = 0; c < NPF; ++c) {
+    for (int c = 0; c < FftRegs<Cfg>::NPFX; ++c) {
         const int e = tf + c * Cfg::TF;
         // lanes beyond the block re-read its last sample (in bounds) instead of branching
         rg.pf[c] = src[e < Hn ? e : Hn - 1];
@@ -273,7 +275,7 @@ template <class Cfg, bool RA> LRA_HD void stft_ring_advance(const StftArgs<typen
             return;
         }
         LRA_UNROLL
-        for (int c = 0; c < NPF; ++c) {
+        for (int c = 0; c < FftRegs<Cfg>::NPFX; ++c) {
             const int e = tf + c * Cfg::TF;
             if (e < Hn) lds_st<T>(ring, (int)((p1 + e) & (N - 1)) * (int)sizeof(T), rg.pf[c]);
         }
@@ -1049,8 +1051,9 @@ template <class Cfg, bool DEFER> LRA_HD void istft_ola_step(const IstftArgs<type
 // pairs, so the carry is updated IN PLACE (reads of a chunk before its writes; chunks ascend), and
 // (c) every LDS access is one per-thread base plus an immediate, as 8-byte reads and writes.
 // The row count per hop, hc = hop / (2 TF), is a compile-time parameter HC of the kernel (all "final or
-// carry?" decisions fold away); instantiated for hop = n_fft/4 (HC = R/4) and hop = n_fft/8 (HC = R/8).
+// carry?" decisions fold away); instantiated for hop = n_fft/2, n_fft/4 and n_fft/8 (HC = R/2, R/4, R/8).
 template <class Cfg> LRA_HD int istft_rows_hc(int hop) {
+    if (Cfg::R >= 2 && 2 * hop == Cfg::N) return Cfg::R / 2;
     if (Cfg::R >= 4 && 4 * hop == Cfg::N) return Cfg::R / 4;
     if (Cfg::R >= 8 && 8 * hop == Cfg::N) return Cfg::R / 8;
     return 0;
@@ -1081,7 +1084,7 @@ template <class Cfg, int HC> LRA_HD void istft_ola_rows(const IstftArgs<typename
             const int c = c0 + q;
             const C val = cadd(cv[q], fv[q]);
             if (c < hc) {
-                if (2 * c + 1 < FftRegs<Cfg>::NPF) { rg.out[2 * c] = val.x; rg.out[2 * c + 1] = val.y; }
+                if (2 * c + 1 < FftRegs<Cfg>::NPFX) { rg.out[2 * c] = val.x; rg.out[2 * c + 1] = val.y; }
             } else {
                 lds_st<C>(carry, wbase + c * TF * (int)sizeof(C), val);
             }

@@ -69,6 +69,33 @@ elif what == "iters":
             msm = timeit(lambda: ctx.melspectrogram_exec(plan, mel_plan, y.data_ptr(), batch, n, n, 2.0, M.data_ptr()))
             msi = timeit(lambda: ctx.istft_exec(iplan, D.data_ptr(), batch, T * 1025, 1025, T, wss.data_ptr(), yrec.data_ptr(), n, n))
             print(f"variant {variant} iters {iters}: stft {ms:.3f} ms ({batch * T / ms / 1e3:.1f} Mframes/s)   mel {msm:.3f} ms ({batch * T / msm / 1e3:.1f} Mframes/s)   istft {msi:.3f} ms ({batch * T / msi / 1e3:.1f} Mframes/s)", flush=True)
+elif what == "survey":
+    # other common configurations: ms and algorithmic GB/s for stft / melspectrogram / istft
+    ctx.set_option("variant", -1)
+    for n_fft, hop, dt in ((2048, 512, np.float32), (1024, 256, np.float32), (512, 128, np.float32), (4096, 1024, np.float32), (2048, 1024, np.float32), (2048, 256, np.float32),
+                           (1024, 512, np.float32), (400, 160, np.float32), (2048, 512, np.float64)):
+        tdt = torch.float32 if dt == np.float32 else torch.float64
+        es = 4 if dt == np.float32 else 8
+        b = batch if dt == np.float32 else batch // 2
+        yy = y[:b].to(tdt)
+        w = np.asarray(filters.get_window("hann", n_fft, fftbins=True), dtype=dt)
+        pl = ctx.stft_plan(n_fft, hop, w, True, "constant", dt)
+        Tn = ctx.stft_num_frames(pl, n)
+        bins = n_fft // 2 + 1
+        Dn = torch.empty((b, Tn, bins), dtype=torch.complex64 if dt == np.float32 else torch.complex128, device=dev)
+        Mn = torch.empty((b, 128, Tn), dtype=tdt, device=dev)
+        mp = ctx.mel_plan(filters.mel(sr=22050, n_fft=n_fft, n_mels=128, dtype=dt))
+        ip = ctx.istft_plan(n_fft, hop, w, True, dt)
+        ww = filters.window_sumsquare(window="hann", n_frames=Tn, n_fft=n_fft, hop_length=hop, dtype=dt)[n_fft // 2:]
+        ww = torch.from_numpy(np.ascontiguousarray(np.pad(ww, (0, max(0, n - len(ww))))[:n], dtype=dt)).to(dev)
+        yr = torch.empty((b, n), dtype=tdt, device=dev)
+        ms = timeit(lambda: ctx.stft_exec(pl, yy.data_ptr(), b, n, n, Dn.data_ptr()), 5)
+        mm = timeit(lambda: ctx.melspectrogram_exec(pl, mp, yy.data_ptr(), b, n, n, 2.0, Mn.data_ptr()), 5)
+        mi = timeit(lambda: ctx.istft_exec(ip, Dn.data_ptr(), b, Tn * bins, bins, Tn, ww.data_ptr(), yr.data_ptr(), n, n), 5)
+        by = b * Tn * (bins * 2 * es + hop * es)
+        print(f"n_fft {n_fft:5d} hop {hop:5d} {np.dtype(dt).name}: frames {b * Tn:8d}  stft {ms:7.3f} ms ({by / ms / 1e6:6.0f} GB/s)  mel {mm:7.3f} ms ({b * Tn / mm / 1e3:6.1f} Mfr/s)  "
+              f"istft {mi:7.3f} ms ({by / mi / 1e6:6.0f} GB/s)", flush=True)
+        del Dn, Mn, yr
 elif what == "occupancy":
     for variant in (0, 4):
         ctx.set_option("variant", variant)

@@ -110,7 +110,8 @@ template <class T> struct IstftSim {
             Lds lds; lds.base = 0;
             bool ran = false;
             if constexpr (sizeof(typename Cfg::real) == 4 && Cfg::R >= 4) {
-                if (hc == Cfg::R / 4) { istft_block<Cfg, Cfg::R / 4>(a, (int)blk, lds); ran = true; }
+                if (hc == Cfg::R / 2) { istft_block<Cfg, Cfg::R / 2>(a, (int)blk, lds); ran = true; }
+                if (!ran && hc == Cfg::R / 4) { istft_block<Cfg, Cfg::R / 4>(a, (int)blk, lds); ran = true; }
             }
             if constexpr (sizeof(typename Cfg::real) == 4 && Cfg::R >= 8) {
                 if (!ran && hc == Cfg::R / 8) { istft_block<Cfg, Cfg::R / 8>(a, (int)blk, lds); ran = true; }

@@ -41,6 +41,9 @@ def _tol(dtype):
         (2048, 512, True, "reflect", 5, np.float32, 9000, 4),
         (2048, 511, True, "constant", 5, np.float32, 9001, 0),  # odd hop: unaligned sample pairs in the ring
         (2048, 512, True, "reflect", 7, np.float32, 30000, 0),  # long slot runs: ring + prefetch, edges at both ends
+        (2048, 1024, True, "reflect", 5, np.float32, 30000, 0),  # hop = n_fft/2: the widest prefetch
+        (1024, 512, True, "constant", 4, np.float32, 12000, 0),
+        (1024, 700, True, "constant", 4, np.float32, 12000, 0),  # hop > n_fft/2: no prefetch, direct fetches
         (1024, 256, True, "edge", 6, np.float32, 9000, 0),
         (1024, 512, True, "constant", 4, np.float32, 9000, 0),  # hop = n_fft/2: new block does not fit the prefetch registers
         (512, 512, True, "reflect", 3, np.float32, 9000, 0),  # hop = n_fft
@@ -127,6 +130,8 @@ def _istft_inputs(y, n_fft, hop, center, length, window="hann", win_length=None)
         (2048, 512, 22050, True, None, np.float32, 3, "hann", None, 1),
         (2048, 512, 9000, True, "n", np.float32, 1, "hann", None, 3),
         (2048, 512, 9000, True, "n", np.float32, 5, "hann", None, 4),
+        (2048, 1024, 20000, True, "n", np.float32, 3, "hann", None, 0),  # hop = n_fft/2: row-aligned overlap-add with HC = R/2
+        (1024, 512, 9000, True, "n", np.float32, 2, "hann", None, 0),
         (1024, 256, 9000, False, None, np.float32, 2, "hann", None, 0),
         (512, 128, 5000, True, 4000, np.float32, 2, "hann", None, 0),
         (512, 128, 5000, True, 6000, np.float32, 2, "hann", None, 0),  # length beyond the frames: zero tail
