@@ -253,6 +253,11 @@ def main():
         line["roofline_istft"] = {"bound": "hbm", "kernel": "istft_kernel<n_fft=2048> (librosa.istft: c2r FFT + window + overlap-add + wss normalise)", "achieved": achieved_istft,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_istft / HBM_PEAK_GBS, "traffic": None, "bytes_per_frame": BYTES_PER_FRAME_STFT,
                                   "launch_ms": istft_launch_s * 1e3, "frames_per_s_single_gpu": frames_per_step / istft_launch_s, "round_trip_snr_db_min": snr_db}
+        # the fused mel kernel sits on the VALU side of the ridge: the same launch against the f32 vector peak
+        # (~65 kFLOP per frame by the 5 N log2 N convention; 157.3 TFLOP/s = 256 CUs x 256 flop/clk x 2.4 GHz,
+        # reachable only with packed FMAs -- an FFT is mostly packed adds, 2 flop per lane-instruction instead of 4)
+        line["roofline_valu"] = {"bound": "valu", "kernel": line["roofline"]["kernel"], "achieved": frames_per_step * 65e3 / launch_s / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                                 "frac": frames_per_step * 65e3 / launch_s / 1e12 / 157.3, "flop_per_frame": 65e3}
         line["kernel_variants"] = {"stft": ctx.tuned_variant(plan, 0), "melspectrogram": ctx.tuned_variant(plan, 2), "istft": ctx.tuned_variant(iplan),
                                    "note": "n_fft=2048 f32: 0 = one wave64 per frame (16 points/thread), 4 = two waves per frame (8 points/thread); chosen by timing both on the first call (ctx option autotune), -1 = pinned or default"}
         line["roofline_stft"]["achievable_note"] = ("scripts/storepat.hip (same 2 048 B read + 8 200 B write per row, no arithmetic, no LDS) reaches 4.6-4.8 TB/s on this "
