@@ -219,11 +219,19 @@ template <class Cfg, bool RA> LRA_HD void stft_ring_prefetch(const StftArgs<type
         for (int c = 0; c < NPF; ++c) rg.pf[c] = st[c * Cfg::TF];
         return;
     }
+    // two batches of NPF loads: the second only for hops above n_fft/4 (uniform branch)
     LRA_UNROLL
-    for (int c = 0; c < FftRegs<Cfg>::NPFX; ++c) {
+    for (int c = 0; c < NPF; ++c) {
         const int e = tf + c * Cfg::TF;
         // lanes beyond the block re-read its last sample (in bounds) instead of branching
         rg.pf[c] = src[e < Hn ? e : Hn - 1];
+    }
+    if (Hn > NPF * Cfg::TF) {
+        LRA_UNROLL
+        for (int c = NPF; c < FftRegs<Cfg>::NPFX; ++c) {
+            const int e = tf + c * Cfg::TF;
+            rg.pf[c] = src[e < Hn ? e : Hn - 1];
+        }
     }
 }
 
@@ -1092,6 +1100,42 @@ template <class Cfg, int HC> LRA_HD void istft_ola_rows(const IstftArgs<typename
     }
 }
 
+// Last FFT pass fused with the row-aligned overlap-add: the last pass leaves thread tf with exactly the sample
+// pairs it owns in the overlap-add (output position tf + i TF + j s = pair c = i + nb j of its residue class), so
+// the windowed frame never goes through LDS: sum = carry[c] + frame[c] straight from the butterfly registers.
+template <class Cfg, int HC> LRA_HD void istft_last_ola_rows(const IstftArgs<typename Cfg::real>& a, bool contribute, int tf, FftRegs<Cfg>& rg, Lds slot_lds) {
+    using T = typename Cfg::real;
+    using C = typename Cfg::cplx;
+    constexpr int p = Cfg::P - 1, lr = Cfg::logr(p), r = 1 << lr, nb = Cfg::R >> lr;
+    constexpr int R = Cfg::R, TF = Cfg::TF, CH = R < 8 ? R : 8;
+    constexpr int hc = HC, clc = R - hc;
+    static_assert((1 << Cfg::logs(p)) == nb * TF, "last-pass output stride must be nb rows");
+    const C* __restrict__ ws2 = reinterpret_cast<const C*>(a.win_scaled);
+    const Lds carry = lds_sub(slot_lds, Cfg::FRAME_BYTES);
+    const C zero = mk<T>((T)0, (T)0);
+    const int rbase = tf * (int)sizeof(C);
+    const int wbase = (tf - hc * TF) * (int)sizeof(C);  // pair c lands on pair c - hc
+    pass_dft<Cfg, p>(rg, tf, a.tw);
+    LRA_UNROLL
+    for (int c0 = 0; c0 < R; c0 += CH) {
+        C cv[CH];
+        LRA_UNROLL
+        for (int q = 0; q < CH; ++q) cv[q] = (c0 + q) < clc ? lds_ld<C>(carry, rbase + (c0 + q) * TF * (int)sizeof(C)) : zero;
+        LRA_UNROLL
+        for (int q = 0; q < CH; ++q) {
+            const int c = c0 + q, i = c % nb, j = c / nb;
+            const C z = rg.v[i * r + j];  // = conj(z'[pos]); x[2 pos] = Re z', x[2 pos + 1] = Im z'
+            const C w = Cfg::HOIST ? rg.win2[i * r + j] : ws2[last_pass_pos<Cfg>(tf, i, j)];
+            const C val = contribute ? mk<T>(cv[q].x + z.x * w.x, cv[q].y - z.y * w.y) : cv[q];
+            if (c < hc) {
+                if (2 * c + 1 < FftRegs<Cfg>::NPFX) { rg.out[2 * c] = val.x; rg.out[2 * c + 1] = val.y; }
+            } else {
+                lds_st<C>(carry, wbase + c * TF * (int)sizeof(C), val);
+            }
+        }
+    }
+}
+
 // held-back samples of frame t -> y: pair c of thread tf is padded positions t hop + 2 (tf + c TF) + {0, 1}.
 // istft_wss_rows loads their window sum-square values while frame t is still being transformed (one whole
 // frame ahead of the stores); lanes that will store nothing read wss[0].
@@ -1261,6 +1305,15 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
         LRA_PHASE(Cfg::NT, tid) {
             pass_read<Cfg, Cfg::P - 1>(LRA_R(rg).v, lds_sub(lds, (slot_of<Cfg>(tid)) * SB), lane_of<Cfg>(tid));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+        if constexpr (rows) {  // last pass + window + overlap-add in one phase (an inactive slot still runs the butterflies: harmless)
+            LRA_PHASE(Cfg::NT, tid) {
+                const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
+                const IstftSlot<Cfg> s = LRA_R(sl);
+                const int t = s.t0 - a.warm_frames + j;
+                if (s.active) istft_last_ola_rows<Cfg, HC>(a, t >= 0 && t < s.t1, tf, LRA_R(rg), lds_sub(lds, slot * SB));
+            } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+            continue;
+        }
         LRA_PHASE(Cfg::NT, tid) {
             istft_last_write<Cfg>(a, LRA_R(rg), lane_of<Cfg>(tid), lds_sub(lds, (slot_of<Cfg>(tid)) * SB));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
