@@ -4,9 +4,10 @@
 //                           + real FFT, then one of three epilogues:
 //       OUT_COMPLEX  D[b][t][k] complex          (librosa.stft,           core/spectrum.py:380-390)
 //       OUT_POWER    S[b][t][k] = |X|^power      (_spectrogram,           core/spectrum.py:3000-3013)
-//       OUT_MEL      M[b][m][t] = sum_k B[m,k] |X[k]|^power, the 1025-bin spectrum never leaves
-//                    the CU (feature.melspectrogram, feature/spectral.py:2145-2161)
-//   istft_block<Cfg>        Hermitian split + inverse FFT + window, overlap-add in LDS with a
+//       OUT_MEL*     M[b][m][t] = sum_k B[m,k] |X[k]|^power, the 1025-bin spectrum never leaves
+//                    the CU (feature.melspectrogram, feature/spectral.py:2145-2161): OUT_MELR / OUT_MEL2 for
+//                    triangular banks (run-ordered / masked two-slope forms, lra_mel.h), OUT_MEL for any banded basis
+//   istft_block<Cfg, HC>    Hermitian split + inverse FFT + window, overlap-add in LDS with a
 //                           carry between frame groups (frame order = the reference's
 //                           accumulation order, core/spectrum.py:593-603, 629-643), divide by the
 //                           window sum-square where it exceeds tiny (:606-624).
