@@ -276,7 +276,8 @@ template <class T> struct StftLaunch {
             // first choice: the run-ordered form (no per-lane control flow, no (wA P, wB P) round trip through LDS)
             if (mel && mel->melr_ok && mel_runs && melr_fits<MC>() && MC::R == 16) {
                 const int shared_r = melr_shared_bytes<MC>(a.n_mels);
-                int tile_r = mel_tile_opt > 0 ? mel_tile_opt : 4;
+                // no LDS staging tile by default: the kernel keeps the last 8 frames of each band in registers and stores them as one burst
+                int tile_r = mel_tile_opt > 0 ? mel_tile_opt : 1;
                 while (tile_r > 1 && MC::FPB * stft_slot_bytes<MC>(OUT_MELR, a.n_mels, tile_r) + shared_r > 160 * 1024) tile_r /= 2;
                 if (MC::FPB * stft_slot_bytes<MC>(OUT_MELR, a.n_mels, tile_r) + shared_r <= 160 * 1024) {
                     a.melr_w = (const T*)mel->d_melr_w;

@@ -112,6 +112,11 @@ template <class Cfg> struct FftRegs {
     static constexpr int MELR_PHOIST = 4;
     typename Cfg::real keep[Cfg::R];
     int mad[2][2 * MELR_PHOIST];
+    // ... and the last MELR_TILE frames' values of those two bands: stored as one burst per band every MELR_TILE
+    // frames, so that the L2 merges them into whole 32-byte sectors (single 4-byte stores 5 us apart do not merge:
+    // 865 MB of HBM writes per launch for 169 MB of output)
+    static constexpr int MELR_TILE = 8;
+    typename Cfg::real mt[2][MELR_TILE];
     typename Cfg::real wv[NPFX];  // ISTFT (row-aligned): window sum-square values of the held-back samples, loaded a frame ahead
     static constexpr int NH = Cfg::HOIST ? 1 : 0;
     typename Cfg::cplx win2[NH * Cfg::R + 1 - NH];       // window pairs in pass-0 register order
@@ -584,7 +589,7 @@ template <class Cfg> LRA_HD void mel2_combine(const StftArgs<typename Cfg::real>
         }
         const T v = part[0] + part[1];
         if (tile == 1) a.Mel[((long long)clip * a.n_mels + m) * a.n_frames + frame] = v;
-        else lds_st<T>(stage, (m * tile + it) * (int)sizeof(T), v);
+        else lds_st<T>(stage, (m * tile + (it % tile)) * (int)sizeof(T), v);
     }
 }
 
@@ -692,8 +697,8 @@ template <class Cfg> LRA_HD void melr_hoist(const StftArgs<typename Cfg::real>& 
 // phase: mel[m] = sum of the B totals of segment m's pieces + sum of the A totals of segment m+1's pieces
 // (ascending bins).  Bands tf and tf + TF use the hoisted address lists; longer lists / further bands read
 // theirs from the shared table.
-template <class Cfg> LRA_HD void melr_combine(const StftArgs<typename Cfg::real>& a, int clip, int frame, int tf, int it, int tile, const FftRegs<Cfg>& rg, Lds sh, Lds rs,
-                                              Lds stage) {
+template <class Cfg> LRA_HD void melr_combine(const StftArgs<typename Cfg::real>& a, int clip, int frame, int tf, int it, int tile, bool last_of_slot, FftRegs<Cfg>& rg, Lds sh,
+                                              Lds rs, Lds stage) {
     using T = typename Cfg::real;
     constexpr int PH = FftRegs<Cfg>::MELR_PHOIST, TF = Cfg::TF;
     const bool more = a.melr_pmax > PH;  // uniform
@@ -720,12 +725,21 @@ template <class Cfg> LRA_HD void melr_combine(const StftArgs<typename Cfg::real>
             part[h] = acc;
         }
         const T v = part[0] + part[1];
-#if LRA_ABLATE == 21  // experiment: no mel stores
-        if (tile == 1 && v == (T)12345.678) a.Mel[((long long)clip * a.n_mels + m) * a.n_frames + frame] = v;
-#else
-        if (tile == 1) a.Mel[((long long)clip * a.n_mels + m) * a.n_frames + frame] = v;
-#endif
-        else lds_st<T>(stage, (m * tile + it) * (int)sizeof(T), v);
+        if (tile == 1) {  // register tile: slot it & 7 of this band's row; burst when the tile is full or the slot ends
+            constexpr int MT = FftRegs<Cfg>::MELR_TILE;
+            const int s8 = it & (MT - 1);
+            LRA_UNROLL
+            for (int k = 0; k < MT; ++k)
+                if (k == s8) rg.mt[b][k] = v;
+            if (s8 == MT - 1 || last_of_slot) {
+                T* __restrict__ row = a.Mel + ((long long)clip * a.n_mels + m) * a.n_frames + (frame - s8);
+                LRA_UNROLL
+                for (int k = 0; k < MT; ++k)
+                    if (k <= s8) row[k] = rg.mt[b][k];
+            }
+        } else {
+            lds_st<T>(stage, (m * tile + (it % tile)) * (int)sizeof(T), v);
+        }
     }
     for (int m = tf + 2 * TF; m < a.n_mels; m += TF) {  // more than two bands per thread: everything from the table
         T part[2];
@@ -738,7 +752,7 @@ template <class Cfg> LRA_HD void melr_combine(const StftArgs<typename Cfg::real>
         }
         const T v = part[0] + part[1];
         if (tile == 1) a.Mel[((long long)clip * a.n_mels + m) * a.n_frames + frame] = v;
-        else lds_st<T>(stage, (m * tile + it) * (int)sizeof(T), v);
+        else lds_st<T>(stage, (m * tile + (it % tile)) * (int)sizeof(T), v);
     }
 }
 
@@ -845,7 +859,7 @@ template <class Cfg, int MODE, int PM = POW_TWO, bool RA = false> LRA_HD void st
                 const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
                 const Lds sl = lds_sub(lds, slot * slot_bytes);
                 if (frame < a.n_frames) {
-                    if constexpr (MODE == OUT_MELR) melr_combine<Cfg>(a, clip, frame, tf, it % tile, tile, LRA_R(rg), lds_sub(lds, a.shared_off), sl, lds_sub(sl, stft_tile_off<Cfg>()));
+                    if constexpr (MODE == OUT_MELR) melr_combine<Cfg>(a, clip, frame, tf, it, tile, it + 1 == iters || frame + 1 >= a.n_frames, LRA_R(rg), lds_sub(lds, a.shared_off), sl, lds_sub(sl, stft_tile_off<Cfg>()));
                     else mel_reduce_slot<Cfg>(a, tf, it % tile, tile, sl, lds_sub(sl, stft_tile_off<Cfg>()));
                 }
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
