@@ -275,7 +275,7 @@ template <class T> struct StftLaunch {
             using MC = typename MelCfgOf<Cfg>::type;
             // first choice: the run-ordered form (no per-lane control flow, no (wA P, wB P) round trip through LDS)
             if (mel && mel->melr_ok && mel_runs && melr_fits<MC>() && MC::R == 16) {
-                const int shared_r = melr_shared_bytes<MC>(a.n_mels);
+                const int shared_r = melr_shared_bytes<MC>(a.n_mels, mel->melr_pmax);
                 // no LDS staging tile by default: the kernel keeps the last 8 frames of each band in registers and stores them as one burst
                 int tile_r = mel_tile_opt > 0 ? mel_tile_opt : 1;
                 while (tile_r > 1 && MC::FPB * stft_slot_bytes<MC>(OUT_MELR, a.n_mels, tile_r) + shared_r > 160 * 1024) tile_r /= 2;
@@ -1080,14 +1080,14 @@ int lra_mel_plan_create(lra_ctx* ctx, int n_mels, int n_bins, const void* basis_
                     p->n_pieces[pi] = mp.n_pieces;
                 }
                 if (rc == LRA_OK && (n_bins - 1) % 16 == 0) {
-                    MelRuns<double> mr = build_mel_runs<double>(ts, (n_bins - 1) / 16, 8, MELR_PMAX);
+                    MelRuns<double> mr = build_mel_runs<double>(ts, (n_bins - 1) / 16, 8, MELR_PMAX, 4);
                     if (mr.ok) {
                         rc = upload(&p->d_melr_w, mr.w.data(), mr.w.size() * sizeof(double));
                         if (rc == LRA_OK) rc = upload(&p->d_melr_keep, mr.keep.data(), mr.keep.size() * sizeof(double));
                         if (rc == LRA_OK) rc = upload((void**)&p->d_melr_addr, mr.addr.data(), mr.addr.size() * sizeof(int));
                         p->melr_zero = mr.zero_addr;
                         p->melr_mid = mr.mid_addr;
-                        p->melr_pmax = mr.max_pieces;
+                        p->melr_pmax = mr.pmax;
                         p->melr_ok = rc == LRA_OK;
                     }
                 }
@@ -1108,14 +1108,14 @@ int lra_mel_plan_create(lra_ctx* ctx, int n_mels, int n_bins, const void* basis_
                     p->n_pieces[pi] = mp.n_pieces;
                 }
                 if (rc == LRA_OK && (n_bins - 1) % 16 == 0) {
-                    MelRuns<float> mr = build_mel_runs<float>(ts, (n_bins - 1) / 16, 8, MELR_PMAX);
+                    MelRuns<float> mr = build_mel_runs<float>(ts, (n_bins - 1) / 16, 8, MELR_PMAX, 4);
                     if (mr.ok) {
                         rc = upload(&p->d_melr_w, mr.w.data(), mr.w.size() * sizeof(float));
                         if (rc == LRA_OK) rc = upload(&p->d_melr_keep, mr.keep.data(), mr.keep.size() * sizeof(float));
                         if (rc == LRA_OK) rc = upload((void**)&p->d_melr_addr, mr.addr.data(), mr.addr.size() * sizeof(int));
                         p->melr_zero = mr.zero_addr;
                         p->melr_mid = mr.mid_addr;
-                        p->melr_pmax = mr.max_pieces;
+                        p->melr_pmax = mr.pmax;
                         p->melr_ok = rc == LRA_OK;
                     }
                 }

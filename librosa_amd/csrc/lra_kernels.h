@@ -74,8 +74,8 @@ template <class T> struct StftArgs {
     // run-ordered two-slope form (OUT_MELR, lra_mel.h MelRuns): also copied to the shared LDS region
     const T* melr_w;        // [(M + 1)] (wA, wB) pairs: bins 0..M/2-1, then M, M-1, .., M/2+1, then M/2
     const T* melr_keep;     // [R][TF]: 0 where a thread's running sum restarts
-    const int* melr_addr;   // [2 MELR_PMAX][n_mels] LDS byte addresses of the piece totals (entries 0..PMAX-1: B list, then the A list)
-    int melr_pmax;            // longest piece list actually used (<= MELR_PMAX)
+    const int* melr_addr;   // [2 pmax][n_mels] LDS byte addresses of the piece totals (entries 0..pmax-1: B list, then the A list)
+    int melr_pmax;            // list length = pieces of the widest pair segment, at least MELR_PHOIST (<= MELR_PMAX)
     int melr_zero, melr_mid;  // byte addresses (inside the slot's running-sum area) of the zero slot and of bin M/2's slot
     int shared_off;
     // set to 1 when a frame's DC bin is not finite, i.e. (barring overflow) when some sample of the
@@ -596,13 +596,13 @@ template <class Cfg> LRA_HD void mel2_combine(const StftArgs<typename Cfg::real>
 // ---- OUT_MELR: run-ordered two-slope mel epilogue (lra_mel.h, MelRuns) -------------------------------------
 // Shared region (per workgroup): w[(M+1)] pairs | keep[R][TF] reals | addr[n_mels][2 PMAX] ints.
 // Per slot: the frame area is reused as the running-sum area rs[R][TF] pairs (+ zero slot, + bin M/2's slot).
-constexpr int MELR_PMAX = 6;  // pieces per pair segment the address lists can hold (host falls back to OUT_MEL2 beyond)
+constexpr int MELR_PMAX = 16;  // longest piece list supported (the host falls back to OUT_MEL2 beyond); the lists are stored with their actual length
 // the weight pairs are stored with one pad pair per run of R/2 (index i -> i + i / (R/2)): a thread reads ITS run, so
 // lanes are R/2 + 1 pairs apart -- an odd number of 8-byte slots, i.e. conflict-free instead of 16 lanes per bank
 template <class Cfg> LRA_HD int melr_w_slot(int i) { return i + i / (Cfg::R / 2); }
 template <class Cfg> LRA_HD int melr_keep_off() { return ((melr_w_slot<Cfg>(Cfg::M) + 1) * 2 * (int)sizeof(typename Cfg::real) + 15) / 16 * 16; }
 template <class Cfg> LRA_HD int melr_addr_off() { return melr_keep_off<Cfg>() + ((Cfg::R * Cfg::TF * (int)sizeof(typename Cfg::real) + 15) / 16) * 16; }
-template <class Cfg> LRA_HD int melr_shared_bytes(int n_mels) { return ((melr_addr_off<Cfg>() + n_mels * 2 * MELR_PMAX * (int)sizeof(int) + 15) / 16) * 16; }
+template <class Cfg> LRA_HD int melr_shared_bytes(int n_mels, int pmax) { return ((melr_addr_off<Cfg>() + n_mels * 2 * pmax * (int)sizeof(int) + 15) / 16) * 16; }
 template <class Cfg> inline bool melr_fits() {
     return Cfg::R == 16 && (1 << Cfg::PADSHIFT) % (Cfg::R / 2) == 0 && (Cfg::R * Cfg::TF + 2) * 2 * (int)sizeof(typename Cfg::real) <= Cfg::FRAME_BYTES;
 }
@@ -613,7 +613,7 @@ template <class Cfg> LRA_HD void melr_tables_to_lds(const StftArgs<typename Cfg:
     const C* __restrict__ w2 = reinterpret_cast<const C*>(a.melr_w);
     for (int k = tid; k < Cfg::M + 1; k += Cfg::NT) lds_st<C>(sh, melr_w_slot<Cfg>(k) * (int)sizeof(C), w2[k]);
     for (int i = tid; i < Cfg::R * Cfg::TF; i += Cfg::NT) lds_st<T>(sh, melr_keep_off<Cfg>() + i * (int)sizeof(T), a.melr_keep[i]);
-    for (int i = tid; i < a.n_mels * 2 * MELR_PMAX; i += Cfg::NT) lds_st<int>(sh, melr_addr_off<Cfg>() + i * (int)sizeof(int), a.melr_addr[i]);
+    for (int i = tid; i < a.n_mels * 2 * a.melr_pmax; i += Cfg::NT) lds_st<int>(sh, melr_addr_off<Cfg>() + i * (int)sizeof(int), a.melr_addr[i]);
 }
 
 // phase: Z[k], Z[M-k] for this thread's RUN of R/2 consecutive bins k = (R/2) tf + j  (v[2j], v[2j+1])
@@ -689,7 +689,7 @@ template <class Cfg> LRA_HD void melr_hoist(const StftArgs<typename Cfg::real>& 
         LRA_UNROLL
         for (int h = 0; h < 2; ++h) {
             LRA_UNROLL
-            for (int q = 0; q < PH; ++q) rg.mad[b][h * PH + q] = m < a.n_mels ? a.melr_addr[(h * MELR_PMAX + q) * a.n_mels + m] : a.melr_zero;
+            for (int q = 0; q < PH; ++q) rg.mad[b][h * PH + q] = m < a.n_mels ? a.melr_addr[(h * a.melr_pmax + q) * a.n_mels + m] : a.melr_zero;
         }
     }
 }
@@ -719,8 +719,8 @@ template <class Cfg> LRA_HD void melr_combine(const StftArgs<typename Cfg::real>
             LRA_UNROLL
             for (int q = 0; q < PH; ++q) acc += x[b][h * PH + q];
             if (more) {
-                for (int q = PH; q < MELR_PMAX; ++q)
-                    acc += lds_ld<T>(rs, lds_ld<int>(sh, melr_addr_off<Cfg>() + ((h * MELR_PMAX + q) * a.n_mels + m) * (int)sizeof(int)));
+                for (int q = PH; q < a.melr_pmax; ++q)
+                    acc += lds_ld<T>(rs, lds_ld<int>(sh, melr_addr_off<Cfg>() + ((h * a.melr_pmax + q) * a.n_mels + m) * (int)sizeof(int)));
             }
             part[h] = acc;
         }
@@ -746,8 +746,8 @@ template <class Cfg> LRA_HD void melr_combine(const StftArgs<typename Cfg::real>
         LRA_UNROLL
         for (int h = 0; h < 2; ++h) {
             T acc = (T)0;
-            for (int q = 0; q < MELR_PMAX; ++q)
-                acc += lds_ld<T>(rs, lds_ld<int>(sh, melr_addr_off<Cfg>() + ((h * MELR_PMAX + q) * a.n_mels + m) * (int)sizeof(int)));
+            for (int q = 0; q < a.melr_pmax; ++q)
+                acc += lds_ld<T>(rs, lds_ld<int>(sh, melr_addr_off<Cfg>() + ((h * a.melr_pmax + q) * a.n_mels + m) * (int)sizeof(int)));
             part[h] = acc;
         }
         const T v = part[0] + part[1];

@@ -155,7 +155,7 @@ template <class T> struct MelRuns {
     int zero_addr = 0, mid_addr = 0;  // byte addresses of the always-zero slot and of bin M/2's (A, B) slot
 };
 
-template <class T> inline MelRuns<T> build_mel_runs(const TwoSlope<T>& ts, int tf_count, int bpl, int pmax) {
+template <class T> inline MelRuns<T> build_mel_runs(const TwoSlope<T>& ts, int tf_count, int bpl, int pmax, int min_len) {
     MelRuns<T> mr;
     mr.tf = tf_count;
     mr.bpl = bpl;
@@ -219,6 +219,8 @@ template <class T> inline MelRuns<T> build_mel_runs(const TwoSlope<T>& ts, int t
         if ((int)v.size() > mr.max_pieces) mr.max_pieces = (int)v.size();
     }
     if (mr.max_pieces > pmax) return mr;
+    pmax = mr.max_pieces < min_len ? min_len : mr.max_pieces;  // lists are stored with their actual length (>= the hoisted prefix)
+    mr.pmax = pmax;
     mr.addr.assign((size_t)ts.n_mels * 2 * pmax, mr.zero_addr);  // [entry][mel]
     for (int m = 0; m < ts.n_mels; ++m) {
         int q = 0;

@@ -72,11 +72,11 @@ template <class T> struct StftSim {
             using MC = typename Cfg::template with_nt<MELNT>;
             TwoSlope<T> ts = build_two_slope<T>(dense_basis, a.n_mels, Cfg::M + 1);
             if (!ts.ok || !melr_fits<MC>()) { diag[7] = 1; return; }
-            MelRuns<T> mr = build_mel_runs<T>(ts, MC::TF, MC::R / 2, MELR_PMAX);
+            MelRuns<T> mr = build_mel_runs<T>(ts, MC::TF, MC::R / 2, MELR_PMAX, FftRegs<MC>::MELR_PHOIST);
             if (!mr.ok) { diag[7] = 2; return; }
-            a.melr_w = mr.w.data(); a.melr_keep = mr.keep.data(); a.melr_addr = mr.addr.data(); a.melr_zero = mr.zero_addr; a.melr_mid = mr.mid_addr; a.melr_pmax = mr.max_pieces;
+            a.melr_w = mr.w.data(); a.melr_keep = mr.keep.data(); a.melr_addr = mr.addr.data(); a.melr_zero = mr.zero_addr; a.melr_mid = mr.mid_addr; a.melr_pmax = mr.pmax;
             diag[9] = mr.max_pieces;
-            run<MC, OUT_MELR>(iters, melr_shared_bytes<MC>(a.n_mels));
+            run<MC, OUT_MELR>(iters, melr_shared_bytes<MC>(a.n_mels, mr.pmax));
         } else if (mode == OUT_COMPLEX) run<Cfg, OUT_COMPLEX>(iters, 0);
         else if (mode == OUT_POWER) run<Cfg, OUT_POWER>(iters, 0);
         else run<Cfg, OUT_MEL>(iters, 0);
