@@ -106,14 +106,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU fallback)"
+    # LRA_BENCH_BACKEND=gloo: control-flow check of the N > 1 path on a box with fewer GPUs than ranks (ranks then share devices)
+    backend = os.environ.get("LRA_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")
-    assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend)  # nccl = RCCL; used for the barriers and the max-over-ranks of the timing only
 
     def barrier():
         if world > 1:
@@ -123,7 +126,7 @@ def main():
     n = SR * CLIP_SECONDS
     batch = args.batch
     y = make_batch(torch, batch, n, rank * batch, device)
-    ctx = L.get_context(local_rank)
+    ctx = L.get_context(dev_index)
     ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
     if args.variant is not None:
         ctx.set_option("variant", args.variant)
@@ -170,7 +173,7 @@ def main():
         barrier()
         return wall, e0.elapsed_ms(e1) / 1e3
 
-    if args.sweep and rank == 0:
+    if args.sweep and world == 1:
         for variant in (0, 1, 4):
             for iters in (4, 8, 16, 32, 64):
                 ctx.set_option("variant", variant)
@@ -186,14 +189,14 @@ def main():
 
     wall, ev = timed(step_mel, args.steps, args.warmup)
     if world > 1:
-        tw = torch.tensor([wall], dtype=torch.float64, device=device)
+        tw = torch.tensor([wall], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
     _, ev_stft = timed(step_stft, args.steps, args.warmup)
     _, ev_istft = timed(step_istft, args.steps, args.warmup)
     # BASELINE config 5 (CQT-lite): three STFTs at n_fft = 512 / 2048 / 8192 over the same batch, shared hop 512
     cqt = None
-    if rank == 0 and not args.no_cqt:
+    if world == 1 and not args.no_cqt:  # single-GPU runs only: timed() contains collective barriers
         try:
             parts = {}
             total_s = 0.0
