@@ -16,6 +16,10 @@ Extra keys on the JSON line:
   roofline       dominant kernel of the step (the fused mel kernel): algorithmic bytes / HIP-event time
   roofline_stft  the complex64-out STFT kernel on the same input (the north star's >=70 %-of-HBM bar
                  is attached to this kernel: 10 248 B/frame), timed in the same process
+  roofline_istft the inverse on the STFT's output (BASELINE configs[3]; round-trip SNR included)
+  roofline_valu  the fused mel kernel against the f32 vector peak (it sits on the compute side of the ridge)
+  cqt_lite       BASELINE configs[4]: STFTs at n_fft 512 / 2048 / 8192 over the same batch (N=1 only)
+  kernel_variants  which n_fft=2048 tuning the plans settled on (first-call autotune)
   cpu_baseline   the NumPy/scipy.fft oracle (a port of the reference path) on this box's host cores,
                  rank 0 at N=1 only, on a bounded sample of the same workload
 """
@@ -34,7 +38,7 @@ sys.path.insert(0, ROOT)
 
 SR, N_FFT, HOP, N_MELS = 22050, 2048, 512, 128
 CLIP_SECONDS = 30
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured on the chip: plain copy 4.8 TB/s, this kernel's store stream 4.7
 BYTES_PER_FRAME_MEL = HOP * 4 + N_MELS * 4            # 2 560 B: PCM read once + mel written once
 BYTES_PER_FRAME_STFT = HOP * 4 + (N_FFT // 2 + 1) * 8  # 10 248 B: PCM read once + complex64 spectrum written once
 
