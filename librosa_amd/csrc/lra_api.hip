@@ -251,6 +251,13 @@ template <class T> struct StftLaunch {
             while (iters > 4 && batch * ((a.n_frames + fpb * iters - 1) / (fpb * iters)) < 2LL * n_cu) iters /= 2;
         }
         if (iters < 1) iters = 1;
+        // several slots per wave (n_fft < 2048) with the row-aligned ring: keep the slots in step (frames per slot a
+        // multiple of n_fft / hop = 4) so that the ring rotation is one scalar per wave
+        a.rot_uniform = 0;
+        if (Cfg::FPB > 1 && Cfg::TF < 64 && ring_rows_aligned<Cfg>(a.hop)) {
+            if (iters_opt <= 0 && iters >= 4) iters = (iters + 3) / 4 * 4;
+            a.rot_uniform = iters % 4 == 0;
+        }
         a.mel_tile = mel_tile_opt > 0 ? mel_tile_opt : 4;
         if (a.mel_tile > iters) a.mel_tile = iters;
         a.frames_per_wg = Cfg::FPB * iters;

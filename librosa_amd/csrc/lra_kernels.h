@@ -75,6 +75,7 @@ template <class T> struct StftArgs {
     const T* melr_w;        // [(M + 1)] (wA, wB) pairs: bins 0..M/2-1, then M, M-1, .., M/2+1, then M/2
     const T* melr_keep;     // [R][TF]: 0 where a thread's running sum restarts
     const int* melr_addr;   // [2 pmax][n_mels] LDS byte addresses of the piece totals (entries 0..pmax-1: B list, then the A list)
+    int rot_uniform;          // row-aligned ring, several slots per wave: frames per slot is a multiple of n_fft/hop, so all slots of a wave share the ring rotation
     int melr_pmax;            // list length = pieces of the widest pair segment, at least MELR_PHOIST (<= MELR_PMAX)
     int melr_zero, melr_mid;  // byte addresses (inside the slot's running-sum area) of the zero slot and of bin M/2's slot
     int shared_off;
@@ -284,7 +285,7 @@ template <class Cfg, bool RA> LRA_HD void stft_ring_advance(const StftArgs<typen
     if (ring_block_prefetchable<Cfg>(a, next)) {
         if (RA) {
             int rot = (int)((p1 & (N - 1)) / (2 * Cfg::TF));
-            if (Cfg::TF >= 64) rot = LRA_UNIFORM(rot);  // a wave never spans two slots: the rotation is wave-uniform
+            if (Cfg::TF >= 64 || a.rot_uniform) rot = LRA_UNIFORM(rot);  // wave-uniform: a wave never spans two slots, or all its slots are in step
             ring_rows_store<Cfg, 0>(rot, tf, rg, ring);
             return;
         }
@@ -312,7 +313,7 @@ template <class Cfg, bool RA> LRA_HD void stft_ring_load_pass0(const StftArgs<ty
         for (int i = 0; i < Cfg::R; ++i) v[i] = mk<T>((T)0, (T)0);
     } else if (RA) {
         int rot = base / (2 * Cfg::TF);
-        if (Cfg::TF >= 64) rot = LRA_UNIFORM(rot);  // a wave never spans two slots: the rotation is wave-uniform
+        if (Cfg::TF >= 64 || a.rot_uniform) rot = LRA_UNIFORM(rot);  // wave-uniform: a wave never spans two slots, or all its slots are in step
         ring_rows_load<Cfg, 0>(rot, tf, v, ring);
         LRA_UNROLL
         for (int i = 0; i < nb; ++i) {

@@ -29,6 +29,7 @@ template <class T> struct StftSim {
         a.tw = tw.data();
         a.twr = twr.data();
         a.frames_per_wg = iters * Cfg::FPB;
+        a.rot_uniform = (Cfg::FPB > 1 && Cfg::TF < 64 && iters % 4 == 0) ? 1 : 0;  // as StftLaunch::launch (no effect on the simulator: LRA_UNIFORM is the identity)
         a.wg_per_clip = (a.n_frames + a.frames_per_wg - 1) / a.frames_per_wg;
         a.mel_tile = iters < 3 ? iters : (iters == 5 ? 1 : 3);  // odd: exercises partial tiles; iters 5 -> direct stores
         a.slot_bytes = stft_slot_bytes<Cfg>(MODE, a.n_mels, a.mel_tile);
