@@ -77,4 +77,16 @@ template <class T, class F> inline bool dispatch_logm(int logm, int variant, F&&
     }
 }
 
+// workgroup configuration of the two-slope mel kernel: its filter tables are shared across the slots of a
+// larger workgroup.  When a frame fits one wave: 256 threads = 4 slots (two such workgroups share a CU and
+// drift apart; measured +2 % over one 512-thread workgroup whose 8 waves start every phase together)
+template <class Cfg> struct MelCfgOf {
+#ifndef LRA_MELNT
+#define LRA_MELNT 256
+#endif
+    static constexpr int MELNT = Cfg::TF <= 64 ? LRA_MELNT : (2 * Cfg::TF <= 1024 ? 2 * Cfg::TF : Cfg::TF);
+    using type = typename Cfg::template with_nt<MELNT>;
+};
+
+
 }  // namespace lra

@@ -45,13 +45,6 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void istft_kernel(lra::Ist
 
 namespace lra {
 
-// workgroup configuration of the two-slope mel kernel: its filter tables are shared across the slots of a
-// larger workgroup (512 threads when a frame fits one wave)
-template <class Cfg> struct MelCfgOf {
-    static constexpr int MELNT = Cfg::TF <= 64 ? 512 : (2 * Cfg::TF <= 1024 ? 2 * Cfg::TF : Cfg::TF);
-    using type = typename Cfg::template with_nt<MELNT>;
-};
-
 // ---- named configurations (macro arguments cannot carry the commas of template argument lists) ----------
 #define LRA_CFG_ALIAS(NAME, ...) using NAME = typename CfgSel<__VA_ARGS__>::type; using NAME##_mel = typename MelCfgOf<NAME>::type;
 LRA_CFG_ALIAS(cfg_f32_4, float, 4, 0)

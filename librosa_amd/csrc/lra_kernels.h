@@ -595,15 +595,19 @@ template <class Cfg> LRA_HD void mel2_combine(const StftArgs<typename Cfg::real>
 }
 
 // ---- OUT_MELR: run-ordered two-slope mel epilogue (lra_mel.h, MelRuns) -------------------------------------
-// Shared region (per workgroup): w[(M+1)] pairs | keep[R][TF] reals | addr[n_mels][2 PMAX] ints.
+// Shared region (per workgroup): w[(M+1) + pads] pairs | addr[2 pmax][n_mels] ints.
 // Per slot: the frame area is reused as the running-sum area rs[R][TF] pairs (+ zero slot, + bin M/2's slot).
 constexpr int MELR_PMAX = 16;  // longest piece list supported (the host falls back to OUT_MEL2 beyond); the lists are stored with their actual length
 // the weight pairs are stored with one pad pair per run of R/2 (index i -> i + i / (R/2)): a thread reads ITS run, so
 // lanes are R/2 + 1 pairs apart -- an odd number of 8-byte slots, i.e. conflict-free instead of 16 lanes per bank
 template <class Cfg> LRA_HD int melr_w_slot(int i) { return i + i / (Cfg::R / 2); }
 template <class Cfg> LRA_HD int melr_keep_off() { return ((melr_w_slot<Cfg>(Cfg::M) + 1) * 2 * (int)sizeof(typename Cfg::real) + 15) / 16 * 16; }
-template <class Cfg> LRA_HD int melr_addr_off() { return melr_keep_off<Cfg>() + ((Cfg::R * Cfg::TF * (int)sizeof(typename Cfg::real) + 15) / 16) * 16; }
-template <class Cfg> LRA_HD int melr_shared_bytes(int n_mels, int pmax) { return ((melr_addr_off<Cfg>() + n_mels * 2 * pmax * (int)sizeof(int) + 15) / 16) * 16; }
+template <class Cfg> LRA_HD int melr_addr_off() { return melr_keep_off<Cfg>(); }  // (the restart factors live in registers only, melr_hoist)
+// the address table is needed in LDS only for lists longer than the hoisted prefix or more than two bands per thread
+template <class Cfg> LRA_HD bool melr_needs_table(int n_mels, int pmax) { return pmax > FftRegs<Cfg>::MELR_PHOIST || n_mels > 2 * Cfg::TF; }
+template <class Cfg> LRA_HD int melr_shared_bytes(int n_mels, int pmax) {
+    return ((melr_addr_off<Cfg>() + (melr_needs_table<Cfg>(n_mels, pmax) ? n_mels * 2 * pmax * (int)sizeof(int) : 0) + 15) / 16) * 16;
+}
 template <class Cfg> inline bool melr_fits() {
     return Cfg::R == 16 && (1 << Cfg::PADSHIFT) % (Cfg::R / 2) == 0 && (Cfg::R * Cfg::TF + 2) * 2 * (int)sizeof(typename Cfg::real) <= Cfg::FRAME_BYTES;
 }
@@ -613,8 +617,8 @@ template <class Cfg> LRA_HD void melr_tables_to_lds(const StftArgs<typename Cfg:
     using C = typename Cfg::cplx;
     const C* __restrict__ w2 = reinterpret_cast<const C*>(a.melr_w);
     for (int k = tid; k < Cfg::M + 1; k += Cfg::NT) lds_st<C>(sh, melr_w_slot<Cfg>(k) * (int)sizeof(C), w2[k]);
-    for (int i = tid; i < Cfg::R * Cfg::TF; i += Cfg::NT) lds_st<T>(sh, melr_keep_off<Cfg>() + i * (int)sizeof(T), a.melr_keep[i]);
-    for (int i = tid; i < a.n_mels * 2 * a.melr_pmax; i += Cfg::NT) lds_st<int>(sh, melr_addr_off<Cfg>() + i * (int)sizeof(int), a.melr_addr[i]);
+    if (melr_needs_table<Cfg>(a.n_mels, a.melr_pmax))
+        for (int i = tid; i < a.n_mels * 2 * a.melr_pmax; i += Cfg::NT) lds_st<int>(sh, melr_addr_off<Cfg>() + i * (int)sizeof(int), a.melr_addr[i]);
 }
 
 // phase: Z[k], Z[M-k] for this thread's RUN of R/2 consecutive bins k = (R/2) tf + j  (v[2j], v[2j+1])

@@ -60,8 +60,7 @@ template <class T> struct StftSim {
     template <class Cfg> void operator()() {
         const int iters = a.frames_per_wg;  // caller passes the iteration count
         if (mode == OUT_MEL2) {
-            constexpr int MELNT = Cfg::TF <= 64 ? 512 : (2 * Cfg::TF <= 1024 ? 2 * Cfg::TF : Cfg::TF);
-            using MC = typename Cfg::template with_nt<MELNT>;
+            using MC = typename MelCfgOf<Cfg>::type;
             TwoSlope<T> ts = build_two_slope<T>(dense_basis, a.n_mels, Cfg::M + 1);
             if (!ts.ok || !mel2_fits<MC>(a.n_mels)) { diag[7] = 1; return; }
             MelPieces mp = build_mel_pieces<T>(ts, MC::TF, MC::R);
@@ -69,8 +68,7 @@ template <class T> struct StftSim {
             a.mel_wAB = ts.wAB.data(); a.mel_run = mp.run_desc.data(); a.mel_segd = mp.seg_desc.data(); a.mel_nyq = mp.nyquist_piece;
             run<MC, OUT_MEL2>(iters, mel2_shared_bytes<MC>(a.n_mels));
         } else if (mode == OUT_MELR) {
-            constexpr int MELNT = Cfg::TF <= 64 ? 512 : (2 * Cfg::TF <= 1024 ? 2 * Cfg::TF : Cfg::TF);
-            using MC = typename Cfg::template with_nt<MELNT>;
+            using MC = typename MelCfgOf<Cfg>::type;
             TwoSlope<T> ts = build_two_slope<T>(dense_basis, a.n_mels, Cfg::M + 1);
             if (!ts.ok || !melr_fits<MC>()) { diag[7] = 1; return; }
             MelRuns<T> mr = build_mel_runs<T>(ts, MC::TF, MC::R / 2, MELR_PMAX, FftRegs<MC>::MELR_PHOIST);
