@@ -5,8 +5,8 @@
 R=/root/repo
 cd $R && python -m librosa_amd.build --force > /tmp/build_py.log 2>&1 || { tail -30 /tmp/build_py.log; echo "errors: 1"; exit 1; }
 echo "errors: 0"
-if [ -n "$1" ] && [ -f /tmp/summ2.py ]; then
+if [ -n "$1" ] && [ -f $R/scripts/kernel_resources.py ]; then
   cd $R/librosa_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -DLRA_INST_GROUP=${2:-0} lra_inst.hip -o /tmp/inst_res.o -Rpass-analysis=kernel-resource-usage > /tmp/res.txt 2>&1
-  python /tmp/summ2.py /tmp/res.txt "$1" | grep -E "$1" | head -40
+  python $R/scripts/kernel_resources.py /tmp/res.txt "$1" | grep -E "$1" | head -40
 fi
 exit 0
