@@ -335,18 +335,17 @@ template <class T> struct IstftLaunch {
         a.warm_frames = (N + H - 1) / H - 1;
         a.drain_steps = N > H ? (N - H + H - 1) / H : 0;
         a.batch = batch;
-        int lds = istft_lds_bytes<Cfg, false>();
+        int lds = istft_lds_bytes<Cfg, 0>();
         void (*kern)(IstftArgs<T>, const cx<T>*, const T*, T*) = istft_kernel<Cfg, 0>;
         if constexpr (sizeof(T) == 4) {  // row-aligned overlap-add for hop = n_fft/2, n_fft/4 and n_fft/8 (f32)
             const int hc = istft_rows_hc<Cfg>(a.hop);
             if constexpr (Cfg::R >= 4) {
-                if (hc == Cfg::R / 2) kern = istft_kernel<Cfg, Cfg::R / 2>;
-                if (hc == Cfg::R / 4) kern = istft_kernel<Cfg, Cfg::R / 4>;
+                if (hc == Cfg::R / 2) { kern = istft_kernel<Cfg, Cfg::R / 2>; lds = istft_lds_bytes<Cfg, Cfg::R / 2>(); }
+                if (hc == Cfg::R / 4) { kern = istft_kernel<Cfg, Cfg::R / 4>; lds = istft_lds_bytes<Cfg, Cfg::R / 4>(); }
             }
             if constexpr (Cfg::R >= 8) {
-                if (hc == Cfg::R / 8) kern = istft_kernel<Cfg, Cfg::R / 8>;
+                if (hc == Cfg::R / 8) { kern = istft_kernel<Cfg, Cfg::R / 8>; lds = istft_lds_bytes<Cfg, Cfg::R / 8>(); }
             }
-            if (hc > 0) lds = istft_lds_bytes<Cfg, true>();
         }
         // Frames per strip.  Each strip replays warm_frames frames before its own, so long strips are cheap;
         // like the forward kernel, the grid should be a whole number of resident waves of workgroups.

@@ -920,9 +920,10 @@ template <class T> struct IstftArgs {
 };
 
 // per slot: frame area + double-buffered carry of N reals (>= N - hop for any hop >= 1)
-// (the row-aligned overlap-add updates its carry in place: one buffer)
-template <class Cfg, bool ROWS = false> constexpr int istft_slot_bytes() { return Cfg::FRAME_BYTES + (ROWS ? 1 : 2) * Cfg::N * (int)sizeof(typename Cfg::real); }
-template <class Cfg, bool ROWS = false> constexpr int istft_lds_bytes() { return Cfg::FPB * istft_slot_bytes<Cfg, ROWS>(); }
+// HC > 0 (row-aligned): one in-place carry of the R - HC rows that outlive a frame, (R - HC) TF sample pairs
+template <class Cfg, int HC = 0> constexpr int istft_carry_reals() { return HC > 0 ? (Cfg::R - HC) * Cfg::TF * 2 : 2 * Cfg::N; }
+template <class Cfg, int HC = 0> constexpr int istft_slot_bytes() { return Cfg::FRAME_BYTES + ((istft_carry_reals<Cfg, HC>() * (int)sizeof(typename Cfg::real) + 15) / 16) * 16; }
+template <class Cfg, int HC = 0> constexpr int istft_lds_bytes() { return Cfg::FPB * istft_slot_bytes<Cfg, HC>(); }
 
 // ---- spectrum prefetch: X[k], X[M-k] (k = tf + i TF) and X[M/2] of one frame -> registers ------------
 template <class Cfg> LRA_HD void istft_spec_load(const IstftArgs<typename Cfg::real>& a, long long clip, int frame, bool valid, int tf, FftRegs<Cfg>& rg) {
@@ -1272,7 +1273,7 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
     using T = typename Cfg::real;
     constexpr int FPB = Cfg::FPB;
     constexpr bool ROWS = HC > 0;
-    constexpr int SB = istft_slot_bytes<Cfg, ROWS>();
+    constexpr int SB = istft_slot_bytes<Cfg, HC>();
     // uniform step count: drain steps only when one of this workgroup's slots owns a clip's last strip
     bool has_last = false;
     for (int s = 0; s < FPB; ++s) has_last = has_last || (((long long)blk * FPB + s) % a.strips_per_clip) == a.strips_per_clip - 1;
@@ -1286,7 +1287,7 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
         const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
         hoist_tables<Cfg>(LRA_R(rg), tf, a.win_scaled, a.tw, a.twr, true);
         const Lds c0 = lds_sub(lds, slot * SB + Cfg::FRAME_BYTES);
-        for (int u = tf; u < Cfg::N; u += Cfg::TF) lds_st<T>(c0, u * (int)sizeof(T), (T)0);
+        for (int u = tf; u < (HC > 0 ? istft_carry_reals<Cfg, HC>() : Cfg::N); u += Cfg::TF) lds_st<T>(c0, u * (int)sizeof(T), (T)0);
         LRA_R(sl) = istft_slot<Cfg>(a, blk, slot_of<Cfg>(LRA_RAW_TID(tid)));
         const IstftSlot<Cfg> s = LRA_R(sl);
         const int t = s.t0 - a.warm_frames;

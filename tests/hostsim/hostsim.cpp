@@ -105,22 +105,22 @@ template <class T> struct IstftSim {
             int hc = 0;  // same kernel selection as IstftLaunch (lra_api.hip)
             if constexpr (sizeof(typename Cfg::real) == 4) hc = std::getenv("LRA_SIM_NO_RA") ? 0 : istft_rows_hc<Cfg>(a.hop);
             const bool rows = hc > 0;
-            st.resize(rows ? istft_lds_bytes<Cfg, true>() : istft_lds_bytes<Cfg, false>());
             Lds lds; lds.base = 0;
             bool ran = false;
             if constexpr (sizeof(typename Cfg::real) == 4 && Cfg::R >= 4) {
-                if (hc == Cfg::R / 2) { istft_block<Cfg, Cfg::R / 2>(a, (int)blk, lds); ran = true; }
-                if (!ran && hc == Cfg::R / 4) { istft_block<Cfg, Cfg::R / 4>(a, (int)blk, lds); ran = true; }
+                if (hc == Cfg::R / 2) { st.resize(istft_lds_bytes<Cfg, Cfg::R / 2>()); istft_block<Cfg, Cfg::R / 2>(a, (int)blk, lds); ran = true; }
+                if (!ran && hc == Cfg::R / 4) { st.resize(istft_lds_bytes<Cfg, Cfg::R / 4>()); istft_block<Cfg, Cfg::R / 4>(a, (int)blk, lds); ran = true; }
             }
             if constexpr (sizeof(typename Cfg::real) == 4 && Cfg::R >= 8) {
-                if (!ran && hc == Cfg::R / 8) { istft_block<Cfg, Cfg::R / 8>(a, (int)blk, lds); ran = true; }
+                if (!ran && hc == Cfg::R / 8) { st.resize(istft_lds_bytes<Cfg, Cfg::R / 8>()); istft_block<Cfg, Cfg::R / 8>(a, (int)blk, lds); ran = true; }
             }
+            if (!ran) st.resize(istft_lds_bytes<Cfg, 0>());
             if (!ran) istft_block<Cfg, 0>(a, (int)blk, lds);
             diag[8] = rows;
             diag[0] += st.races; diag[1] += st.uninit;
             st.races = st.uninit = 0;
         }
-        diag[2] = Cfg::NT; diag[3] = Cfg::FPB; diag[4] = Cfg::P; diag[5] = istft_lds_bytes<Cfg, false>(); diag[6] = Cfg::WAVE_SYNC;
+        diag[2] = Cfg::NT; diag[3] = Cfg::FPB; diag[4] = Cfg::P; diag[5] = istft_lds_bytes<Cfg, 0>(); diag[6] = Cfg::WAVE_SYNC;
     }
 };
 
