@@ -1073,7 +1073,7 @@ template <class Cfg, bool DEFER> LRA_HD void istft_ola_step(const IstftArgs<type
     }
 }
 
-// ---- row-aligned overlap-add (hop a multiple of 2 TF, hop <= n_fft/4) -----------------------------------
+// ---- row-aligned overlap-add (hop = n_fft/2, n_fft/4 or n_fft/8) ------------------------------------------
 // Thread tf owns the sample PAIRS p = tf + c TF (c < R) of the frame span, i.e. one residue class mod TF.
 // Because the hop is a whole number hc of such rows, (a) "final vs. carry" is a wave-uniform property of
 // c -- no per-sample bound tests --, (b) the carry shift by one hop maps a thread's pairs onto its own
@@ -1086,39 +1086,6 @@ template <class Cfg> LRA_HD int istft_rows_hc(int hop) {
     if (Cfg::R >= 4 && 4 * hop == Cfg::N) return Cfg::R / 4;
     if (Cfg::R >= 8 && 8 * hop == Cfg::N) return Cfg::R / 8;
     return 0;
-}
-
-template <class Cfg, int HC> LRA_HD void istft_ola_rows(const IstftArgs<typename Cfg::real>& a, bool contribute, int tf, FftRegs<Cfg>& rg, Lds slot_lds) {
-    using T = typename Cfg::real;
-    using C = typename Cfg::cplx;
-    constexpr int R = Cfg::R, TF = Cfg::TF, CH = R < 8 ? R : 8;
-    constexpr int hc = HC;       // final pairs per thread (<= R/4)
-    constexpr int clc = R - hc;  // carry pairs per thread
-    const Lds fr = slot_lds;
-    const Lds carry = lds_sub(slot_lds, Cfg::FRAME_BYTES);
-    const C zero = mk<T>((T)0, (T)0);
-    const int rbase = tf * (int)sizeof(C);
-    const int wbase = (tf - hc * TF) * (int)sizeof(C);  // pair p lands on pair p - hc TF
-    LRA_UNROLL
-    for (int c0 = 0; c0 < R; c0 += CH) {
-        C cv[CH], fv[CH];
-        LRA_UNROLL
-        for (int q = 0; q < CH; ++q) {
-            const int c = c0 + q;
-            cv[q] = c < clc ? lds_ld<C>(carry, rbase + c * TF * (int)sizeof(C)) : zero;
-            fv[q] = contribute ? lds_ld<C>(fr, rbase + c * TF * (int)sizeof(C)) : zero;
-        }
-        LRA_UNROLL
-        for (int q = 0; q < CH; ++q) {
-            const int c = c0 + q;
-            const C val = cadd(cv[q], fv[q]);
-            if (c < hc) {
-                if (2 * c + 1 < FftRegs<Cfg>::NPFX) { rg.out[2 * c] = val.x; rg.out[2 * c + 1] = val.y; }
-            } else {
-                lds_st<C>(carry, wbase + c * TF * (int)sizeof(C), val);
-            }
-        }
-    }
 }
 
 // Last FFT pass fused with the row-aligned overlap-add: the last pass leaves thread tf with exactly the sample
@@ -1343,8 +1310,7 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
             const IstftSlot<Cfg> s = LRA_R(sl);
             const int t = s.t0 - a.warm_frames + j;
             if (s.active) {
-                if constexpr (rows) istft_ola_rows<Cfg, HC>(a, t >= 0 && t < s.t1, tf, LRA_R(rg), lds_sub(lds, slot * SB));
-                else if (defer) istft_ola_step<Cfg, true>(a, s.clip, t, t >= 0 && t < s.t1, s.write_lo, s.write_hi, j & 1, tf, LRA_R(rg), lds_sub(lds, slot * SB));
+                if (defer) istft_ola_step<Cfg, true>(a, s.clip, t, t >= 0 && t < s.t1, s.write_lo, s.write_hi, j & 1, tf, LRA_R(rg), lds_sub(lds, slot * SB));
                 else istft_ola_step<Cfg, false>(a, s.clip, t, t >= 0 && t < s.t1, s.write_lo, s.write_hi, j & 1, tf, LRA_R(rg), lds_sub(lds, slot * SB));
             }
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
