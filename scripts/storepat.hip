@@ -68,6 +68,11 @@ __global__ __launch_bounds__(256) void fillk_blocked(f4* __restrict__ out, size_
     const size_t b0 = (size_t)blockIdx.x * per_wg;
     for (size_t i = threadIdx.x; i < per_wg && b0 + i < n4; i += 256) out[b0 + i] = w;
 }
+__global__ __launch_bounds__(256) void readk(const f4* __restrict__ in, float* __restrict__ out, size_t n4) {
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) acc += in[i];
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = acc.x;
+}
 int main() {
     const int batch = 256, rows = 1292;
     f2* out; float* in;
@@ -105,6 +110,14 @@ int main() {
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             printf("fill blocked %zu KB per WG: %.0f GB/s\n", per * 16 / 1024, n4 * 16.0 / (ms / 10) / 1e6);
+        }
+        for (int grid : {2048, 16384, 65536}) {
+            for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(readk, dim3(grid), dim3(256), 0, 0, (const f4*)out, in, n4);
+            hipEventRecord(e0);
+            for (int w = 0; w < 10; ++w) hipLaunchKernelGGL(readk, dim3(grid), dim3(256), 0, 0, (const f4*)out, in, n4);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float msr; hipEventElapsedTime(&msr, e0, e1);
+            printf("read-only grid-stride grid %d: %.0f GB/s\n", grid, n4 * 16.0 / (msr / 10) / 1e6);
         }
         hipEventRecord(e0);
         for (int w = 0; w < 10; ++w) hipMemsetAsync(out, 0, n4 * 16, 0);
