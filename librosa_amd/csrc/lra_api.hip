@@ -326,6 +326,7 @@ template <class T> struct IstftLaunch {
     long long batch = 0;
     int strip_frames = 0;  // 0 = auto
     int n_cu = 256;
+    bool too_big = false;  // the slot does not fit the 160 KiB of LDS (n_fft = 16384 with a hop outside n_fft/2, /4, /8): caller takes the rocFFT path
     hipStream_t stream = nullptr;
     hipError_t err = hipSuccess;
     template <class Cfg> void operator()() {
@@ -347,6 +348,7 @@ template <class T> struct IstftLaunch {
                 if (hc == Cfg::R / 8) { kern = istft_kernel<Cfg, Cfg::R / 8>; lds = istft_lds_bytes<Cfg, Cfg::R / 8>(); }
             }
         }
+        if (lds > 160 * 1024) { too_big = true; return; }
         // Frames per strip.  Each strip replays warm_frames frames before its own, so long strips are cheap;
         // like the forward kernel, the grid should be a whole number of resident waves of workgroups.
         int sf = strip_frames;
@@ -720,10 +722,12 @@ int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_s
         L.strip_frames = ctx->opt_istft_strip_groups > 0 ? ctx->opt_istft_strip_groups : 0;
         L.n_cu = ctx->n_cu;
         int variant = ctx->opt_variant >= 0 ? ctx->opt_variant : 0;  // see stft_run
+        bool too_big = false;
         auto launch = [&](int v) -> int {
             IstftLaunch<T> Lv = L;
             Lv.a.tw = (const cx<T>*)p->d_tw[v];
             if (!dispatch_logm<T>(p->logm, v, Lv)) return fail(LRA_EINVAL, "unsupported power-of-two size");
+            if (Lv.too_big) { too_big = true; return LRA_OK; }
             if (Lv.err != hipSuccess) return fail(LRA_EHIP, std::string("istft kernel launch: ") + hipGetErrorString(Lv.err));
             return LRA_OK;
         };
@@ -732,7 +736,8 @@ int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_s
             if (tuned < 0 && batch * n_used >= 65536) LRA_TRY(autotune_variant(ctx, launch, &tuned));
             if (tuned >= 0) variant = tuned;
         }
-        return launch(variant);
+        LRA_TRY(launch(variant));
+        if (!too_big) return LRA_OK;
     }
     // general path: pack -> rocFFT C2R -> gather overlap-add, one clip group at a time
     const long long group = general_clip_group(batch, n_used, N, sizeof(T));

@@ -67,6 +67,22 @@ def _wss_for(skw, n_total_frames, out_len, length, dtype):
     return O.fix_length(wss[(n_fft // 2 if center else 0) :], size=out_len)
 
 
+@pytest.mark.parametrize("n_fft,hop", [(16384, 4096), (16384, 1000), (8192, 3000), (32, 8), (32, 5), (64, 32), (4096, 2048)])
+def test_extreme_sizes(L, n_fft, hop):
+    """Smallest and largest fused sizes, aligned and unaligned hops (n_fft = 16384 with a general hop does not fit the
+    inverse kernel's LDS budget and must fall back to the rocFFT path transparently)."""
+    rng = np.random.default_rng(n_fft + hop)
+    y = rng.standard_normal((2, 70000)).astype(np.float32)
+    D = L.stft(y, n_fft=n_fft, hop_length=hop)
+    ref = O.stft(y, n_fft=n_fft, hop_length=hop)
+    assert _stft_close(D, ref)
+    yy = L.istft(D, hop_length=hop, length=y.shape[-1])
+    assert np.abs(yy - O.istft(ref, hop_length=hop, length=y.shape[-1])).max() <= 2e-5
+    if n_fft >= 512:
+        M = L.feature.melspectrogram(y=y, n_fft=n_fft, hop_length=hop, n_mels=32)
+        assert _mel_close(M, O.melspectrogram(y=y, n_fft=n_fft, hop_length=hop, n_mels=32))
+
+
 def test_mel_epilogue_forms_agree(L):
     """The run-ordered two-slope epilogue (default where it applies), the masked two-slope fallback and the generic
     banded path must all match the oracle: 128 / 80 mels (run-ordered), 40 mels (too many pieces: falls back)."""
