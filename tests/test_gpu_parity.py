@@ -83,6 +83,55 @@ def test_extreme_sizes(L, n_fft, hop):
         assert _mel_close(M, O.melspectrogram(y=y, n_fft=n_fft, hop_length=hop, n_mels=32))
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_configurations(L, seed):
+    """Seeded sweep over (n_fft power of two or not, hop aligned or not or beyond n_fft, dtype, center, pad mode,
+    win_length, 1-D / 2-D input): stft, istft and melspectrogram against the oracle.  The inverse is compared where
+    the window sum-square is at least 1 % of its maximum: elsewhere y = acc / wss amplifies rounding noise by 1 / wss
+    in the reference as much as here."""
+    import warnings
+
+    rng = np.random.default_rng(seed)
+    bad = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(24):
+            n_fft = int(rng.choice([64, 128, 256, 400, 512, 1000, 1024, 2048, 2049, 4096, 8192]))
+            hop = int(rng.choice([max(1, n_fft // 8), n_fft // 4, n_fft // 2, n_fft // 3, n_fft, 160, 100, 441]))
+            dtype = np.float64 if rng.random() < 0.25 else np.float32
+            center = bool(rng.random() < 0.8)
+            pad_mode = str(rng.choice(["constant", "reflect", "edge", "symmetric"]))
+            n = int(rng.integers(max(n_fft, 2 * hop) + 3, 6 * n_fft + 4000))
+            shape = (2, n) if rng.random() < 0.7 else (n,)
+            win_length = None if rng.random() < 0.7 else int(n_fft * 3 // 4)
+            y = rng.standard_normal(shape).astype(dtype)
+            kw = dict(n_fft=n_fft, hop_length=hop, center=center, pad_mode=pad_mode, win_length=win_length)
+            tag = (n_fft, hop, np.dtype(dtype).name, center, pad_mode, n, win_length, shape)
+            f32 = dtype == np.float32
+            D, ref = L.stft(y, **kw), O.stft(y, **kw)
+            if not np.abs(D - ref).max() <= (4e-6 if f32 else 1e-12) * np.abs(ref).max():
+                bad.append(("stft",) + tag)
+            ikw = dict(hop_length=hop, center=center, win_length=win_length, n_fft=n_fft)
+            try:
+                yr = O.istft(ref, **ikw)
+            except Exception:
+                yr = None  # the reference rejects this combination (e.g. no frame fits): nothing to compare
+            if yr is not None:
+                yy = L.istft(D, **ikw)
+                wss = O.window_sumsquare(window="hann", n_frames=ref.shape[-1], win_length=win_length, n_fft=n_fft, hop_length=hop, dtype=np.float64)
+                wss = wss[(n_fft // 2 if center else 0):]
+                wss = np.pad(wss, (0, max(0, yr.shape[-1] - len(wss))))[: yr.shape[-1]]
+                good = wss > 1e-2 * wss.max()
+                if yy.shape != yr.shape or (good.any() and not np.abs(yy - yr)[..., good].max() <= (3e-5 if f32 else 1e-11) * max(np.abs(yr[..., good]).max(), 1e-30)):
+                    bad.append(("istft",) + tag)
+            if n_fft >= 256:
+                mk = dict(kw, n_mels=int(rng.choice([20, 40, 64, 128])), power=float(rng.choice([1.0, 2.0, 1.5])))
+                M, Mr = L.feature.melspectrogram(y=y, **mk), O.melspectrogram(y=y, **mk)
+                if not np.abs(M - Mr).max() <= (2e-5 if f32 else 1e-11) * Mr.max():
+                    bad.append(("mel",) + tag)
+    assert not bad, bad
+
+
 def test_mel_epilogue_forms_agree(L):
     """The run-ordered two-slope epilogue (default where it applies), the masked two-slope fallback and the generic
     banded path must all match the oracle: 128 / 80 mels (run-ordered), 40 mels (too many pieces: falls back)."""
