@@ -573,17 +573,17 @@ template <class F> int autotune_variant(lra_ctx* ctx, F&& launch, int* tuned) {
     for (int c = 0; c < 2 && rc == LRA_OK; ++c) {
         rc = launch(cands[c]);
         if (rc != LRA_OK) break;
-        hipEventRecord(e0, ctx->stream);
+        (void)hipEventRecord(e0, ctx->stream);
         rc = launch(cands[c]);
         if (rc == LRA_OK) rc = launch(cands[c]);
-        hipEventRecord(e1, ctx->stream);
+        (void)hipEventRecord(e1, ctx->stream);
         if (hipEventSynchronize(e1) != hipSuccess) { rc = fail(LRA_EHIP, "autotune: event synchronize failed"); break; }
         float ms = 0.f;
-        hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventElapsedTime(&ms, e0, e1);
         if (c == 0 || ms < best) { best = ms; best_v = cands[c]; }
     }
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     if (rc == LRA_OK) *tuned = best_v;
     return rc;
 }
