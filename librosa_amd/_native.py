@@ -6,6 +6,7 @@ in-tree by ``__graft_entry__.build()`` / ``python -m librosa_amd.build``.
 """
 from __future__ import annotations
 
+import collections
 import ctypes
 import os
 import threading
@@ -197,9 +198,10 @@ class Context:
         _check(self.lib.lra_ctx_create(int(device), byref(h)))
         self.handle = h
         self.device = int(device)
-        self._stft_plans = {}
-        self._istft_plans = {}
-        self._mel_plans = {}
+        # least-recently-used caches, bounded: a plan owns device tables (and, on the rocFFT path, scratch buffers)
+        self._stft_plans = collections.OrderedDict()
+        self._istft_plans = collections.OrderedDict()
+        self._mel_plans = collections.OrderedDict()
         self._wss_cache = {}
         self._lock = threading.RLock()
 
@@ -236,43 +238,55 @@ class Context:
     def event(self):
         return Event(self)
 
+    PLAN_CACHE_SIZE = 48
+
+    def _cached_plan(self, cache, key, create, destroy):
+        """LRU lookup; on overflow the oldest plan is destroyed (hipFree synchronises with the device first)."""
+        with self._lock:
+            plan = cache.get(key)
+            if plan is not None:
+                cache.move_to_end(key)
+                return plan
+            plan = create()
+            cache[key] = plan
+            while len(cache) > self.PLAN_CACHE_SIZE:
+                _, old = cache.popitem(last=False)
+                destroy(old)
+            return plan
+
     # -- plans (cached; keyed by the bytes of the host tables so any window spec works) -----------
     def stft_plan(self, n_fft, hop, window, center, pad_mode, dtype):
         window = np.ascontiguousarray(window, dtype=dtype)
         key = (int(n_fft), int(hop), window.tobytes(), bool(center), pad_mode, np.dtype(dtype).str)
-        with self._lock:
-            plan = self._stft_plans.get(key)
-            if plan is None:
-                h = c_void_p()
-                _check(self.lib.lra_stft_plan_create(self.handle, int(n_fft), int(hop), window.ctypes.data, int(bool(center)), PAD_MODES[pad_mode],
-                                                     dtype_code(dtype), byref(h)))
-                plan = h
-                self._stft_plans[key] = plan
-        return plan
+
+        def create():
+            h = c_void_p()
+            _check(self.lib.lra_stft_plan_create(self.handle, int(n_fft), int(hop), window.ctypes.data, int(bool(center)), PAD_MODES[pad_mode], dtype_code(dtype), byref(h)))
+            return h
+
+        return self._cached_plan(self._stft_plans, key, create, self.lib.lra_stft_plan_destroy)
 
     def istft_plan(self, n_fft, hop, window, center, dtype):
         window = np.ascontiguousarray(window, dtype=dtype)
         key = (int(n_fft), int(hop), window.tobytes(), bool(center), np.dtype(dtype).str)
-        with self._lock:
-            plan = self._istft_plans.get(key)
-            if plan is None:
-                h = c_void_p()
-                _check(self.lib.lra_istft_plan_create(self.handle, int(n_fft), int(hop), window.ctypes.data, int(bool(center)), dtype_code(dtype), byref(h)))
-                plan = h
-                self._istft_plans[key] = plan
-        return plan
+
+        def create():
+            h = c_void_p()
+            _check(self.lib.lra_istft_plan_create(self.handle, int(n_fft), int(hop), window.ctypes.data, int(bool(center)), dtype_code(dtype), byref(h)))
+            return h
+
+        return self._cached_plan(self._istft_plans, key, create, self.lib.lra_istft_plan_destroy)
 
     def mel_plan(self, basis):
         basis = np.ascontiguousarray(basis)
         key = (basis.shape, basis.dtype.str, basis.tobytes())
-        with self._lock:
-            plan = self._mel_plans.get(key)
-            if plan is None:
-                h = c_void_p()
-                _check(self.lib.lra_mel_plan_create(self.handle, int(basis.shape[0]), int(basis.shape[1]), basis.ctypes.data, dtype_code(basis.dtype), byref(h)))
-                plan = h
-                self._mel_plans[key] = plan
-        return plan
+
+        def create():
+            h = c_void_p()
+            _check(self.lib.lra_mel_plan_create(self.handle, int(basis.shape[0]), int(basis.shape[1]), basis.ctypes.data, dtype_code(basis.dtype), byref(h)))
+            return h
+
+        return self._cached_plan(self._mel_plans, key, create, self.lib.lra_mel_plan_destroy)
 
     def device_table(self, key, host_array):
         """Small read-only device table (e.g. a window sum-square), cached by key."""
