@@ -51,18 +51,30 @@ class Session:
 
     def __init__(self, like):
         self.is_torch = is_torch_tensor(like)
+        self._keep = []
+        self._locked = False
         if self.is_torch:
             torch = _torch()
             if like.device.type != "cuda":
                 raise ParameterError("torch inputs must live on a ROCm device (tensor.device.type == 'cuda'); pass a numpy array for host data")
             self.device = like.device
             self.ctx = _native.get_context(like.device.index if like.device.index is not None else torch.cuda.current_device())
-            self.ctx.set_stream(torch.cuda.current_stream(like.device).cuda_stream)
         else:
             self.device = None
             self.ctx = _native.get_context()
-            self.ctx.use_own_stream()
-        self._keep = []
+        # One call at a time per context: the stream selection below, the sticky non-finite flag, the plans' scratch
+        # buffers and rocFFT work areas are per-context state, and ctypes releases the GIL during native calls.  The
+        # lock is held until close(); the device work of different threads is serialised on one stream anyway.
+        self.ctx.call_lock.acquire()
+        self._locked = True
+        try:
+            if self.is_torch:
+                self.ctx.set_stream(_torch().cuda.current_stream(like.device).cuda_stream)
+            else:
+                self.ctx.use_own_stream()
+        except Exception:
+            self.close()
+            raise
 
     # ---- inputs ---------------------------------------------------------------------------------
     def input_2d(self, x, dtype):
@@ -118,10 +130,15 @@ class Session:
         return buf.ptr
 
     def close(self):
-        for k in self._keep:
-            if isinstance(k, _native.DeviceBuffer):
-                k.free()
-        self._keep = []
+        try:
+            for k in self._keep:
+                if isinstance(k, _native.DeviceBuffer):
+                    k.free()
+            self._keep = []
+        finally:
+            if self._locked:
+                self._locked = False
+                self.ctx.call_lock.release()
 
 
 def swap_last_two(x):

@@ -204,6 +204,7 @@ class Context:
         self._mel_plans = collections.OrderedDict()
         self._wss_cache = {}
         self._lock = threading.RLock()
+        self.call_lock = threading.RLock()  # held by _arrays.Session for the duration of one public call
 
     # -- context ------------------------------------------------------------------------------
     def device_name(self):

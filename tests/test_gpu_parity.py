@@ -132,6 +132,42 @@ def test_random_configurations(L, seed):
     assert not bad, bad
 
 
+def test_threads_share_a_context(L):
+    """Several Python threads calling the drop-in concurrently (ctypes releases the GIL): public calls serialise on a
+    per-context lock, so stream selection, the sticky non-finite flag and plan scratch buffers cannot interleave."""
+    import threading
+    import warnings
+
+    errs = []
+
+    def work(seed):
+        rng = np.random.default_rng(seed)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for it in range(8):
+                n_fft = int(rng.choice([400, 512, 1024, 2048]))
+                hop = n_fft // 4
+                y = rng.standard_normal((3, int(rng.integers(6000, 30000)))).astype(np.float32)
+                try:
+                    D = L.stft(y, n_fft=n_fft, hop_length=hop)
+                    if not _stft_close(D, O.stft(y, n_fft=n_fft, hop_length=hop)):
+                        errs.append(("stft", seed, it))
+                    M = L.feature.melspectrogram(y=y, n_fft=n_fft, hop_length=hop, n_mels=64)
+                    if not _mel_close(M, O.melspectrogram(y=y, n_fft=n_fft, hop_length=hop, n_mels=64)):
+                        errs.append(("mel", seed, it))
+                    if not np.abs(L.istft(D, hop_length=hop, length=y.shape[-1]) - y).max() <= 2e-5:
+                        errs.append(("istft", seed, it))
+                except Exception as exc:  # noqa: BLE001 -- collected and reported by the main thread
+                    errs.append(("exception", seed, it, repr(exc)[:120]))
+
+    threads = [threading.Thread(target=work, args=(s,)) for s in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs[:5]
+
+
 def test_mel_epilogue_forms_agree(L):
     """The run-ordered two-slope epilogue (default where it applies), the masked two-slope fallback and the generic
     banded path must all match the oracle: 128 / 80 mels (run-ordered), 40 mels (too many pieces: falls back)."""
