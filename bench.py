@@ -21,7 +21,8 @@ Extra keys on the JSON line:
   cqt_lite       BASELINE configs[4]: STFTs at n_fft 512 / 2048 / 8192 over the same batch (N=1 only)
   kernel_variants  which n_fft=2048 tuning the plans settled on (first-call autotune)
   cpu_baseline   the NumPy/scipy.fft oracle (a port of the reference path) on this box's host cores,
-                 rank 0 at N=1 only, on a bounded sample of the same workload
+                 rank 0 at N=1 only, on a bounded sample of the same workload (one core); cpu_baseline_all_cores
+                 = the same with one independent process per core (up to 64)
 """
 from __future__ import annotations
 
@@ -87,6 +88,39 @@ def cpu_baseline(seconds=12.0):
         "sample": f"{clips} clips x {CLIP_SECONDS} s melspectrogram (n_fft={N_FFT} hop={HOP} n_mels={N_MELS}) in {dt:.1f} s, "
                   f"1 process, BLAS limited to 1 thread; host has {os.cpu_count()} logical cores",
     }
+
+
+def _cpu_worker(seconds):
+    """One host process of the all-cores baseline (spawned: no torch / HIP state in the child)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import stft_oracle as O
+
+    try:
+        from threadpoolctl import threadpool_limits
+
+        threadpool_limits(limits=1)
+    except Exception:  # pragma: no cover
+        pass
+    y = O.config_input(2, n=SR * CLIP_SECONDS)
+    O.melspectrogram(y=y[0], sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS)
+    frames, clips, t0 = 0, 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        frames += O.melspectrogram(y=y[clips % 2], sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS).shape[-1]
+        clips += 1
+    return frames, time.perf_counter() - t0
+
+
+def cpu_baseline_all_cores(seconds=8.0, max_procs=64):
+    """The reference has no internal parallelism: its fair multi-core mode is one independent process per core
+    (SURVEY.md 8d).  P = min(cores, max_procs) spawned processes, each looping over clips for `seconds`."""
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+
+    procs = max(1, min(os.cpu_count() or 1, max_procs))
+    with ProcessPoolExecutor(max_workers=procs, mp_context=mp.get_context("spawn")) as pool:
+        res = list(pool.map(_cpu_worker, [seconds] * procs))
+    return {"value": sum(f / dt for f, dt in res), "unit": "frames/s", "cores": procs, "kind": "port",
+            "sample": f"{procs} independent processes x {seconds:.0f} s of 30 s-clip melspectrograms (n_fft={N_FFT} hop={HOP} n_mels={N_MELS}), 1 BLAS thread each; host has {os.cpu_count()} logical cores"}
 
 
 def main():
@@ -287,6 +321,10 @@ def main():
             pass
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+            try:
+                line["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
+            except Exception as exc:  # the single-core object above is the contract; this one is informative
+                line["cpu_baseline_all_cores"] = {"error": repr(exc)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
