@@ -322,13 +322,11 @@ template <bool WAVE> __device__ __forceinline__ void phase_sync() {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     } else {
-        // Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() is a workgroup-scope fence over
-        // every address space: hipcc then drains vmcnt to 0 in front of each s_barrier, i.e. the wave sits
-        // out the full HBM latency of its freshly issued prefetch loads (and of its output stores) at every
-        // phase boundary.  The phases exchange data through LDS and nothing else.
-        // (Spelled as asm: this hipcc still emits s_waitcnt vmcnt(0) for
-        // __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local").)  The "memory" clobber keeps the
-        // compiler from moving LDS accesses across the barrier; lgkmcnt(0) retires this wave's DS writes.
+        // Workgroup barrier: the phases exchange data through LDS and nothing else, so all that is needed is
+        // "my DS writes have retired" + s_barrier.  That is also what __syncthreads() compiles to on gfx950 today
+        // (s_waitcnt lgkmcnt(0); s_barrier -- no vmcnt drain, checked in the ISA); it is spelled out so that the
+        // in-flight prefetch loads and output stores can never be made to wait here by a stronger fence.  The
+        // "memory" clobber keeps the compiler from moving LDS accesses across the barrier.
 #ifdef LRA_FULL_BARRIER  // experiments only
         __syncthreads();
 #else
