@@ -202,7 +202,6 @@ class Context:
         self._stft_plans = collections.OrderedDict()
         self._istft_plans = collections.OrderedDict()
         self._mel_plans = collections.OrderedDict()
-        self._wss_cache = {}
         self._lock = threading.RLock()
         self.call_lock = threading.RLock()  # held by _arrays.Session for the duration of one public call
 
@@ -288,17 +287,6 @@ class Context:
             return h
 
         return self._cached_plan(self._mel_plans, key, create, self.lib.lra_mel_plan_destroy)
-
-    def device_table(self, key, host_array):
-        """Small read-only device table (e.g. a window sum-square), cached by key."""
-        with self._lock:
-            buf = self._wss_cache.get(key)
-            if buf is None:
-                if len(self._wss_cache) > 64:
-                    self._wss_cache.clear()
-                buf = self.alloc(max(host_array.nbytes, 16)).upload(host_array)
-                self._wss_cache[key] = buf
-        return buf
 
     # -- execution ----------------------------------------------------------------------------------
     def stft_num_frames(self, plan, n):

@@ -51,7 +51,7 @@ def _validate_audio(y, check_finite):
     return False
 
 
-def _prepare_stft(y, n_fft, hop_length, win_length, window, center, pad_mode):
+def _prepare_stft(y, n_fft, hop_length, win_length, window, center, pad_mode, _warn_level=4):
     """Shared front end of stft/_spectrogram/melspectrogram: defaults, checks, window, padding.
 
     Returns (y, hop_length, fft_window (float64, length n_fft), center, pad_mode)."""
@@ -70,7 +70,7 @@ def _prepare_stft(y, n_fft, hop_length, win_length, window, center, pad_mode):
         if pad_mode in _REJECTED_PAD_MODES:
             raise ParameterError(f"pad_mode='{pad_mode}' is not supported by librosa.stft")
         if n_fft > n:
-            warnings.warn(f"n_fft={n_fft} is too large for input signal of length={n}", stacklevel=3)
+            warnings.warn(f"n_fft={n_fft} is too large for input signal of length={n}", stacklevel=_warn_level)
         if not (isinstance(pad_mode, str) and pad_mode in _DEVICE_PAD_MODES):
             # exotic np.pad modes (linear_ramp, empty, callables, ...): pad on the host, then run uncentred
             if is_torch_tensor(y):
@@ -139,7 +139,10 @@ def _run_stft_family(kind, y, *, n_fft, hop_length, win_length, window, center, 
             ptr, handle = sess.output((batch, n_mels, n_frames), real)
             ctx.melspectrogram_exec(plan, mel_plan, y_ptr, batch, n, y_stride, power, ptr)
         if need_device_check and ctx.nonfinite_read():
-            raise ParameterError("Audio buffer is not finite everywhere")
+            # the flag says "some frame's DC bin is not finite"; finite samples of enormous magnitude overflow it
+            # too, so the samples themselves decide (util.valid_audio tests np.isfinite(y), util/utils.py:305)
+            if not bool(_arrays._torch().isfinite(y).all()):
+                raise ParameterError("Audio buffer is not finite everywhere")
         res = sess.result(handle)
     finally:
         sess.close()
@@ -234,7 +237,9 @@ def istft(stft_matrix, *, hop_length=None, win_length=None, n_fft=None, window="
     if n_fft is None:
         n_fft = 2 * (D.shape[-2] - 1)
     if D.shape[-2] != 1 + n_fft // 2:
-        raise ParameterError(f"stft_matrix has {D.shape[-2]} frequency bins, expected {1 + n_fft // 2} for n_fft={n_fft}")
+        # an explicit n_fft that disagrees with the matrix: scipy's irfft(n=n_fft) (core/spectrum.py:566,598) crops
+        # the bin axis to 1 + n_fft//2 or zero-pads it, and so does the drop-in
+        D = _fit_bins(D, 1 + n_fft // 2)
     if win_length is None:
         win_length = n_fft
     if hop_length is None:
@@ -296,6 +301,18 @@ def istft(stft_matrix, *, hop_length=None, win_length=None, n_fft=None, window="
         out[...] = y
         return out
     return y
+
+
+def _fit_bins(D, n_bins):
+    """Crop or zero-pad axis -2 to ``n_bins`` (what ``irfft(..., n=n_fft, axis=-2)`` does to its input)."""
+    have = D.shape[-2]
+    if have > n_bins:
+        return D[..., :n_bins, :]
+    if is_torch_tensor(D):
+        return _arrays._torch().nn.functional.pad(D, (0, 0, 0, n_bins - have))
+    widths = [(0, 0)] * D.ndim
+    widths[-2] = (0, n_bins - have)
+    return np.pad(D, widths)
 
 
 def _as_like(sess, host_array):

@@ -67,6 +67,7 @@ struct lra_ctx {
     int opt_mel_tile = 0;            // frames staged per mel row before a flush (0 = auto)
     int opt_generic_mel = 0;         // force the generic banded mel path (tests)
     int opt_lds_pad = 0;             // extra dynamic LDS per workgroup (occupancy experiments)
+    int opt_xcd_remap = 1;           // workgroup -> work item map that keeps neighbouring strips on one XCD (lra_kernels.h, xcd_block)
     unsigned int* d_flag = nullptr;  // non-finite input flag (device)
     std::string name;
 };
@@ -78,15 +79,26 @@ struct lra_event {
 
 namespace {
 
+// rocFFT plans of the general (non-power-of-two) path.  A batched plan is specific to its transform count, which is
+// clips x frames of the call; so that variable-length inputs neither create a plan per call nor grow device memory
+// without bound, a call runs as full chunks of kFftChunk transforms (one canonical plan) plus one remainder, and the
+// cache keeps at most kMaxFftPlans plans (least recently used evicted and destroyed).
+constexpr long long kFftChunk = 8192;
+constexpr size_t kMaxFftPlans = 8;
 struct FftPlanCache {
-    std::map<long long, rocfft_plan> plans;  // key = number of transforms
+    std::vector<std::pair<long long, rocfft_plan>> plans;  // most recently used last; key = number of transforms
     rocfft_execution_info info = nullptr;
     void* work = nullptr;
     size_t work_bytes = 0;
+    // The frame / spectrum scratch and the work buffer belong to the plan, not to a stream: a call on another stream
+    // first waits for the previous user's last kernel (event recorded at the end of every general-path call).
+    hipEvent_t last_use = nullptr;
+    hipStream_t last_stream = nullptr;
     ~FftPlanCache() {
         for (auto& kv : plans) rocfft_plan_destroy(kv.second);
         if (info) rocfft_execution_info_destroy(info);
         if (work) (void)hipFree(work);
+        if (last_use) (void)hipEventDestroy(last_use);
     }
 };
 
@@ -119,11 +131,30 @@ int upload(void** dptr, const void* host, size_t bytes) {
     return LRA_OK;
 }
 
-int ctx_bind(lra_ctx* ctx) {
-    if (!ctx) return fail(LRA_EINVAL, "null context");
-    LRA_HIP(hipSetDevice(ctx->device));
-    return LRA_OK;
-}
+// Every entry point runs with the context's device current and puts the caller's device back on exit: a torch
+// process that calls in with cuda:0 current and a tensor on cuda:1 (or a NumPy call that defaults to LOCAL_RANK's
+// device) must not find its own current device changed behind its back.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) {
+            err = hipSetDevice(device);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define LRA_BIND(ctxptr)                                                                                       \
+    if (!(ctxptr)) return fail(LRA_EINVAL, "null context");                                                    \
+    DeviceGuard device_guard__((ctxptr)->device);                                                              \
+    if (device_guard__.err != hipSuccess) return fail(LRA_EHIP, std::string("selecting the context's device: ") + hipGetErrorString(device_guard__.err))
 
 inline size_t real_bytes(int dtype) { return dtype == LRA_F64 ? 8 : 4; }
 
@@ -205,6 +236,7 @@ template <class T> struct StftLaunch {
     int n_cu = 256;
     void* out = nullptr;
     int lds_pad = 0;
+    bool xcd_remap = true;
     bool mel_runs = true;
     const lra_mel_plan* mel = nullptr;
     hipStream_t stream = nullptr;
@@ -265,14 +297,17 @@ template <class T> struct StftLaunch {
         a.slot_bytes = stft_slot_bytes<Cfg>(MODE, a.n_mels, a.mel_tile);
         a.shared_off = Cfg::FPB * a.slot_bytes;
         const long long grid = batch * a.wg_per_clip;
-        if (grid > 0x7fffffffLL) { err = hipErrorInvalidConfiguration; return; }
+        if (grid > 0x7ffffff0LL) { err = hipErrorInvalidConfiguration; return; }
         const int lds = Cfg::FPB * a.slot_bytes + shared_bytes + lds_pad;  // lds_pad: occupancy experiments only
         if (lds > 160 * 1024) { err = hipErrorInvalidValue; return; }
         if (lds > 65536) {
             err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (err != hipSuccess) return;
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NT), lds, stream, a, a.y, out);
+        a.n_blocks = (int)grid;
+        a.xcd_chunk = (xcd_remap && grid >= 64) ? (int)((grid + 7) / 8) : 0;
+        const long long launch_grid = a.xcd_chunk ? 8LL * a.xcd_chunk : grid;
+        hipLaunchKernelGGL(kern, dim3((unsigned)launch_grid), dim3(Cfg::NT), lds, stream, a, a.y, out);
         err = hipGetLastError();
     }
 
@@ -326,6 +361,7 @@ template <class T> struct IstftLaunch {
     long long batch = 0;
     int strip_frames = 0;  // 0 = auto
     int n_cu = 256;
+    bool xcd_remap = true;
     bool too_big = false;  // the slot does not fit the 160 KiB of LDS (n_fft = 16384 with a hop outside n_fft/2, /4, /8): caller takes the rocFFT path
     hipStream_t stream = nullptr;
     hipError_t err = hipSuccess;
@@ -369,12 +405,15 @@ template <class T> struct IstftLaunch {
         a.strip_frames = sf < 1 ? 1 : sf;
         a.strips_per_clip = (a.n_used + a.strip_frames - 1) / a.strip_frames;
         const long long grid = (batch * a.strips_per_clip + FPB - 1) / FPB;
-        if (grid > 0x7fffffffLL) { err = hipErrorInvalidConfiguration; return; }
+        if (grid > 0x7ffffff0LL) { err = hipErrorInvalidConfiguration; return; }
         if (lds > 65536) {
             err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (err != hipSuccess) return;
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(Cfg::NT), lds, stream, a, a.D, a.wss, a.y);
+        a.n_blocks = (int)grid;
+        a.xcd_chunk = (xcd_remap && grid >= 64) ? (int)((grid + 7) / 8) : 0;
+        const long long launch_grid = a.xcd_chunk ? 8LL * a.xcd_chunk : grid;
+        hipLaunchKernelGGL(kern, dim3((unsigned)launch_grid), dim3(Cfg::NT), lds, stream, a, a.D, a.wss, a.y);
         err = hipGetLastError();
     }
 };
@@ -506,26 +545,66 @@ namespace {
 
 int get_rocfft_plan(FftPlanCache& cache, lra_ctx* ctx, rocfft_transform_type type, int dtype, int n_fft, long long count, rocfft_plan* out) {
     rocfft_setup_once();
-    auto it = cache.plans.find(count);
-    if (it == cache.plans.end()) {
-        rocfft_plan plan = nullptr;
+    rocfft_plan plan = nullptr;
+    for (size_t i = 0; i < cache.plans.size(); ++i)
+        if (cache.plans[i].first == count) {
+            plan = cache.plans[i].second;
+            cache.plans.erase(cache.plans.begin() + (long)i);
+            break;
+        }
+    if (!plan) {
         size_t lengths[1] = {(size_t)n_fft};
         LRA_FFT(rocfft_plan_create(&plan, rocfft_placement_notinplace, type, dtype == LRA_F64 ? rocfft_precision_double : rocfft_precision_single, 1,
                                    lengths, (size_t)count, nullptr));
-        it = cache.plans.emplace(count, plan).first;
+        if (cache.plans.size() >= kMaxFftPlans) {
+            // the evicted plan may still have work in flight on the stream that used it last
+            if (cache.last_use) (void)hipEventSynchronize(cache.last_use);
+            rocfft_plan_destroy(cache.plans.front().second);
+            cache.plans.erase(cache.plans.begin());
+        }
     }
+    cache.plans.emplace_back(count, plan);
     size_t wb = 0;
-    LRA_FFT(rocfft_plan_get_work_buffer_size(it->second, &wb));
+    LRA_FFT(rocfft_plan_get_work_buffer_size(plan, &wb));
     if (!cache.info) LRA_FFT(rocfft_execution_info_create(&cache.info));
     if (wb > cache.work_bytes) {
-        if (cache.work) (void)hipFree(cache.work);
+        if (cache.work) (void)hipFree(cache.work);  // hipFree synchronises with the device first
         cache.work = nullptr;
+        cache.work_bytes = 0;
         LRA_HIP(hipMalloc(&cache.work, wb));
         cache.work_bytes = wb;
     }
     if (wb) LRA_FFT(rocfft_execution_info_set_work_buffer(cache.info, cache.work, cache.work_bytes));
     LRA_FFT(rocfft_execution_info_set_stream(cache.info, ctx->stream));
-    *out = it->second;
+    *out = plan;
+    return LRA_OK;
+}
+
+// `total` transforms of length n_fft, input stride in_stride / output stride out_stride (elements of in_elem / out_elem
+// bytes), as full chunks of kFftChunk transforms + one remainder
+int run_rocfft_chunked(FftPlanCache& cache, lra_ctx* ctx, rocfft_transform_type type, int dtype, int n_fft, long long total, char* in, size_t in_bytes_per_transform,
+                       char* out, size_t out_bytes_per_transform) {
+    for (long long t0 = 0; t0 < total;) {
+        const long long cnt = total - t0 >= kFftChunk ? kFftChunk : total - t0;
+        rocfft_plan plan;
+        LRA_TRY(get_rocfft_plan(cache, ctx, type, dtype, n_fft, cnt, &plan));
+        void* ib[1] = {in + (size_t)t0 * in_bytes_per_transform};
+        void* ob[1] = {out + (size_t)t0 * out_bytes_per_transform};
+        LRA_FFT(rocfft_execute(plan, ib, ob, cache.info));
+        t0 += cnt;
+    }
+    return LRA_OK;
+}
+
+// scratch ordering across streams (see FftPlanCache): call before the first and after the last kernel of a general-path call
+int scratch_acquire(FftPlanCache& cache, hipStream_t stream) {
+    if (cache.last_use && cache.last_stream != stream) LRA_HIP(hipStreamWaitEvent(stream, cache.last_use, 0));
+    return LRA_OK;
+}
+int scratch_release(FftPlanCache& cache, hipStream_t stream) {
+    if (!cache.last_use) LRA_HIP(hipEventCreateWithFlags(&cache.last_use, hipEventDisableTiming));
+    LRA_HIP(hipEventRecord(cache.last_use, stream));
+    cache.last_stream = stream;
     return LRA_OK;
 }
 
@@ -553,11 +632,8 @@ int stft_general(lra_stft_plan* p, const T* y, long long batch, long long n, lon
         hipLaunchKernelGGL(frame_window_kernel<T>, dim3((unsigned)(total * chunks)), dim3(256), 0, ctx->stream, y, y_stride, n, (int)n_frames, p->hop,
                            p->center ? N / 2 : 0, p->pad_mode, (const T*)p->d_win, N, c0, total, (T*)p->frames.p);
         LRA_HIP(hipGetLastError());
-        rocfft_plan plan;
-        LRA_TRY(get_rocfft_plan(p->fft, ctx, rocfft_transform_type_real_forward, p->dtype, N, total, &plan));
-        void* in[1] = {p->frames.p};
-        void* out[1] = {(void*)(D + c0 * n_frames * bins)};
-        LRA_FFT(rocfft_execute(plan, in, out, p->fft.info));
+        LRA_TRY(run_rocfft_chunked(p->fft, ctx, rocfft_transform_type_real_forward, p->dtype, N, total, (char*)p->frames.p, (size_t)N * sizeof(T),
+                                   (char*)(D + c0 * n_frames * bins), (size_t)bins * sizeof(cx<T>)));
     }
     return LRA_OK;
 }
@@ -590,7 +666,7 @@ template <class F> int autotune_variant(lra_ctx* ctx, F&& launch, int* tuned) {
 
 template <class T>
 int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n, int64_t y_stride, double power, lra_mel_plan* mel, void* out) {
-    LRA_TRY(ctx_bind(p->ctx));
+    LRA_BIND(p->ctx);
     int64_t n_frames = 0;
     LRA_TRY(lra_stft_num_frames(p, n, &n_frames));
     if (batch <= 0) return LRA_OK;
@@ -638,6 +714,7 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
         L.n_cu = ctx->n_cu;
         L.mel_tile_opt = ctx->opt_mel_tile;
         L.lds_pad = ctx->opt_lds_pad;
+        L.xcd_remap = ctx->opt_xcd_remap != 0;
         L.mel_runs = ctx->opt_mel_runs != 0;
         // Kernel variant (f32 n_fft = 2048 only): 0 = one wave per frame, 4 = two waves per frame.  Which one
         // is faster depends on the epilogue AND on the individual GPU (boxes of the same pool differ by +-10 %,
@@ -659,7 +736,11 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
         return launch(variant);
     }
     // general path
-    if (mode == OUT_COMPLEX) return stft_general<T>(p, (const T*)y, batch, n, y_stride, n_frames, (cx<T>*)out);
+    LRA_TRY(scratch_acquire(p->fft, ctx->stream));
+    if (mode == OUT_COMPLEX) {
+        LRA_TRY(stft_general<T>(p, (const T*)y, batch, n, y_stride, n_frames, (cx<T>*)out));
+        return scratch_release(p->fft, ctx->stream);
+    }
     // power / mel need the complex spectrum in scratch, one clip group at a time
     const long long group = general_clip_group(batch, n_frames, p->n_fft, sizeof(T));
     LRA_TRY(p->spec.ensure((size_t)group * n_frames * bins * sizeof(cx<T>) + (mode == OUT_MEL ? (size_t)group * n_frames * bins * sizeof(T) : 0)));
@@ -680,13 +761,13 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
             LRA_HIP(hipGetLastError());
         }
     }
-    return LRA_OK;
+    return scratch_release(p->fft, ctx->stream);
 }
 
 template <class T>
 int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_stride, int64_t d_frame_stride, int64_t n_used, const void* wss, void* y,
               int64_t out_len, int64_t y_stride) {
-    LRA_TRY(ctx_bind(p->ctx));
+    LRA_BIND(p->ctx);
     lra_ctx* ctx = p->ctx;
     const int N = p->n_fft, bins = N / 2 + 1;
     if (batch <= 0 || out_len <= 0) return LRA_OK;
@@ -721,6 +802,7 @@ int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_s
         L.stream = ctx->stream;
         L.strip_frames = ctx->opt_istft_strip_groups > 0 ? ctx->opt_istft_strip_groups : 0;
         L.n_cu = ctx->n_cu;
+        L.xcd_remap = ctx->opt_xcd_remap != 0;
         int variant = ctx->opt_variant >= 0 ? ctx->opt_variant : 0;  // see stft_run
         bool too_big = false;
         auto launch = [&](int v) -> int {
@@ -740,6 +822,7 @@ int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_s
         if (!too_big) return LRA_OK;
     }
     // general path: pack -> rocFFT C2R -> gather overlap-add, one clip group at a time
+    LRA_TRY(scratch_acquire(p->fft, ctx->stream));
     const long long group = general_clip_group(batch, n_used, N, sizeof(T));
     LRA_TRY(p->spec.ensure((size_t)group * n_used * bins * sizeof(cx<T>)));
     LRA_TRY(p->frames.ensure((size_t)group * n_used * N * sizeof(T)));
@@ -750,17 +833,14 @@ int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_s
         hipLaunchKernelGGL(spec_pack_kernel<T>, dim3((unsigned)(total * chunks)), dim3(256), 0, ctx->stream, (const cx<T>*)D, (long long)d_batch_stride,
                            (long long)d_frame_stride, (int)n_used, bins, (N % 2) == 0 ? 1 : 0, c0, total, (cx<T>*)p->spec.p);
         LRA_HIP(hipGetLastError());
-        rocfft_plan plan;
-        LRA_TRY(get_rocfft_plan(p->fft, ctx, rocfft_transform_type_real_inverse, p->dtype, N, total, &plan));
-        void* in[1] = {p->spec.p};
-        void* outb[1] = {p->frames.p};
-        LRA_FFT(rocfft_execute(plan, in, outb, p->fft.info));
+        LRA_TRY(run_rocfft_chunked(p->fft, ctx, rocfft_transform_type_real_inverse, p->dtype, N, total, (char*)p->spec.p, (size_t)bins * sizeof(cx<T>),
+                                   (char*)p->frames.p, (size_t)N * sizeof(T)));
         const long long ochunks = (out_len + 255) / 256;
         hipLaunchKernelGGL(ola_gather_kernel<T>, dim3((unsigned)(clips * ochunks)), dim3(256), 0, ctx->stream, (const T*)p->frames.p, N, p->hop, (int)n_used,
                            p->center ? N / 2 : 0, (const T*)p->d_win_scaled, (const T*)wss, tinyv, c0, clips, (T*)y, (long long)y_stride, (long long)out_len);
         LRA_HIP(hipGetLastError());
     }
-    return LRA_OK;
+    return scratch_release(p->fft, ctx->stream);
 }
 
 }  // namespace
@@ -791,7 +871,8 @@ int lra_ctx_create(int device, lra_ctx** out) {
     int n = 0;
     if (lra_device_count(&n) != LRA_OK || n <= 0) return fail(LRA_ENODEV, "no HIP device available: librosa_amd has no CPU fallback");
     if (device < 0 || device >= n) return fail(LRA_EINVAL, "device index out of range");
-    LRA_HIP(hipSetDevice(device));
+    DeviceGuard device_guard__(device);
+    if (device_guard__.err != hipSuccess) return fail(LRA_EHIP, std::string("selecting device: ") + hipGetErrorString(device_guard__.err));
     hipDeviceProp_t prop;
     LRA_HIP(hipGetDeviceProperties(&prop, device));
     lra_ctx* c = new lra_ctx();
@@ -817,7 +898,7 @@ int lra_ctx_create(int device, lra_ctx** out) {
 
 void lra_ctx_destroy(lra_ctx* ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard device_guard__(ctx->device);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
     delete ctx;
@@ -836,7 +917,7 @@ int lra_ctx_use_own_stream(lra_ctx* ctx) {
 }
 
 int lra_ctx_sync(lra_ctx* ctx) {
-    LRA_TRY(ctx_bind(ctx));
+    LRA_BIND(ctx);
     LRA_HIP(hipStreamSynchronize(ctx->stream));
     return LRA_OK;
 }
@@ -849,6 +930,7 @@ int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value) {
     else if (!std::strcmp(key, "ablate")) (void)value;  // retired development knob, accepted and ignored
     else if (!std::strcmp(key, "generic_mel")) ctx->opt_generic_mel = value;
     else if (!std::strcmp(key, "lds_pad")) ctx->opt_lds_pad = value;
+    else if (!std::strcmp(key, "xcd_remap")) ctx->opt_xcd_remap = value != 0;
     else if (!std::strcmp(key, "autotune")) ctx->opt_autotune = value != 0;
     else if (!std::strcmp(key, "mel_runs")) ctx->opt_mel_runs = value != 0;
     else if (!std::strcmp(key, "variant")) ctx->opt_variant = (value >= 0 && value < kNumVariants) ? value : -1;
@@ -857,13 +939,13 @@ int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value) {
 }
 
 int lra_ctx_nonfinite_reset(lra_ctx* ctx) {
-    LRA_TRY(ctx_bind(ctx));
+    LRA_BIND(ctx);
     LRA_HIP(hipMemsetAsync(ctx->d_flag, 0, sizeof(unsigned int), ctx->stream));
     return LRA_OK;
 }
 
 int lra_ctx_nonfinite_read(lra_ctx* ctx, int* flag) {
-    LRA_TRY(ctx_bind(ctx));
+    LRA_BIND(ctx);
     if (!flag) return fail(LRA_EINVAL, "null flag");
     unsigned int h = 0;
     LRA_HIP(hipMemcpyAsync(&h, ctx->d_flag, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
@@ -879,7 +961,7 @@ int lra_ctx_device_name(lra_ctx* ctx, char* buf, size_t buflen) {
 }
 
 int lra_malloc(lra_ctx* ctx, size_t bytes, void** dptr) {
-    LRA_TRY(ctx_bind(ctx));
+    LRA_BIND(ctx);
     if (!dptr) return fail(LRA_EINVAL, "null dptr");
     *dptr = nullptr;
     hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
@@ -888,33 +970,33 @@ int lra_malloc(lra_ctx* ctx, size_t bytes, void** dptr) {
 }
 
 int lra_free(lra_ctx* ctx, void* dptr) {
-    LRA_TRY(ctx_bind(ctx));
+    LRA_BIND(ctx);
     if (dptr) LRA_HIP(hipFree(dptr));
     return LRA_OK;
 }
 
 int lra_memset(lra_ctx* ctx, void* dptr, int value, size_t bytes) {
-    LRA_TRY(ctx_bind(ctx));
+    LRA_BIND(ctx);
     LRA_HIP(hipMemsetAsync(dptr, value, bytes, ctx->stream));
     return LRA_OK;
 }
 
 int lra_memcpy_h2d(lra_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
-    LRA_TRY(ctx_bind(ctx));
+    LRA_BIND(ctx);
     LRA_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
     LRA_HIP(hipStreamSynchronize(ctx->stream));
     return LRA_OK;
 }
 
 int lra_memcpy_d2h(lra_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
-    LRA_TRY(ctx_bind(ctx));
+    LRA_BIND(ctx);
     LRA_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     LRA_HIP(hipStreamSynchronize(ctx->stream));
     return LRA_OK;
 }
 
 int lra_event_create(lra_ctx* ctx, lra_event** out) {
-    LRA_TRY(ctx_bind(ctx));
+    LRA_BIND(ctx);
     if (!out) return fail(LRA_EINVAL, "null out");
     lra_event* e = new lra_event();
     e->ctx = ctx;
@@ -935,14 +1017,14 @@ void lra_event_destroy(lra_event* ev) {
 
 int lra_event_record(lra_event* ev) {
     if (!ev) return fail(LRA_EINVAL, "null event");
-    LRA_TRY(ctx_bind(ev->ctx));
+    LRA_BIND(ev->ctx);
     LRA_HIP(hipEventRecord(ev->ev, ev->ctx->stream));
     return LRA_OK;
 }
 
 int lra_event_elapsed_ms(lra_event* start, lra_event* stop, float* ms) {
     if (!start || !stop || !ms) return fail(LRA_EINVAL, "null argument");
-    LRA_TRY(ctx_bind(stop->ctx));
+    LRA_BIND(stop->ctx);
     LRA_HIP(hipEventSynchronize(stop->ev));
     LRA_HIP(hipEventElapsedTime(ms, start->ev, stop->ev));
     return LRA_OK;
@@ -950,7 +1032,7 @@ int lra_event_elapsed_ms(lra_event* start, lra_event* stop, float* ms) {
 
 // ---- STFT ---------------------------------------------------------------------------------------
 int lra_stft_plan_create(lra_ctx* ctx, int n_fft, int hop_length, const void* window_host, int center, int pad_mode, int dtype, lra_stft_plan** out) {
-    LRA_TRY(ctx_bind(ctx));
+    LRA_BIND(ctx);
     if (!out) return fail(LRA_EINVAL, "null out");
     *out = nullptr;
     if (n_fft < 1) return fail(LRA_EINVAL, "n_fft must be positive");
@@ -995,7 +1077,7 @@ int lra_stft_plan_create(lra_ctx* ctx, int n_fft, int hop_length, const void* wi
 
 void lra_stft_plan_destroy(lra_stft_plan* p) {
     if (!p) return;
-    (void)hipSetDevice(p->ctx->device);
+    DeviceGuard device_guard__(p->ctx->device);
     if (p->d_win) (void)hipFree(p->d_win);
     for (int v = 0; v < kNumVariants; ++v)
         if (p->d_tw[v]) (void)hipFree(p->d_tw[v]);
@@ -1038,7 +1120,7 @@ int lra_spectrogram_exec(lra_stft_plan* p, const void* y, int64_t batch, int64_t
 
 // ---- mel ----------------------------------------------------------------------------------------
 int lra_mel_plan_create(lra_ctx* ctx, int n_mels, int n_bins, const void* basis_host, int dtype, lra_mel_plan** out) {
-    LRA_TRY(ctx_bind(ctx));
+    LRA_BIND(ctx);
     if (!out) return fail(LRA_EINVAL, "null out");
     *out = nullptr;
     if (n_mels < 1 || n_bins < 1 || !basis_host) return fail(LRA_EINVAL, "bad mel basis");
@@ -1144,7 +1226,7 @@ int lra_mel_plan_create(lra_ctx* ctx, int n_mels, int n_bins, const void* basis_
 
 void lra_mel_plan_destroy(lra_mel_plan* p) {
     if (!p) return;
-    (void)hipSetDevice(p->ctx->device);
+    DeviceGuard device_guard__(p->ctx->device);
     if (p->d_c0) (void)hipFree(p->d_c0);
     if (p->d_len) (void)hipFree(p->d_len);
     if (p->d_off) (void)hipFree(p->d_off);
@@ -1169,7 +1251,7 @@ int lra_melspectrogram_exec(lra_stft_plan* stft, lra_mel_plan* mel, const void* 
 int lra_mel_apply_exec(lra_mel_plan* mel, const void* S, int64_t batch, int64_t n_frames, int64_t batch_stride, int64_t bin_stride, int64_t frame_stride,
                        void* M) {
     if (!mel) return fail(LRA_EINVAL, "null plan");
-    LRA_TRY(ctx_bind(mel->ctx));
+    LRA_BIND(mel->ctx);
     if (batch <= 0 || n_frames <= 0) return LRA_OK;
     if (!S || !M) return fail(LRA_EINVAL, "null data pointer");
     const long long tblocks = (n_frames + 255) / 256;
@@ -1189,7 +1271,7 @@ int lra_mel_apply_exec(lra_mel_plan* mel, const void* S, int64_t batch, int64_t 
 
 // ---- ISTFT --------------------------------------------------------------------------------------
 int lra_istft_plan_create(lra_ctx* ctx, int n_fft, int hop_length, const void* window_host, int center, int dtype, lra_istft_plan** out) {
-    LRA_TRY(ctx_bind(ctx));
+    LRA_BIND(ctx);
     if (!out) return fail(LRA_EINVAL, "null out");
     *out = nullptr;
     if (n_fft < 1) return fail(LRA_EINVAL, "n_fft must be positive");
@@ -1227,7 +1309,7 @@ int lra_istft_plan_create(lra_ctx* ctx, int n_fft, int hop_length, const void* w
 
 void lra_istft_plan_destroy(lra_istft_plan* p) {
     if (!p) return;
-    (void)hipSetDevice(p->ctx->device);
+    DeviceGuard device_guard__(p->ctx->device);
     if (p->d_win_scaled) (void)hipFree(p->d_win_scaled);
     for (int v = 0; v < kNumVariants; ++v)
         if (p->d_tw[v]) (void)hipFree(p->d_tw[v]);
@@ -1242,9 +1324,21 @@ int lra_istft_exec(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_ba
                                : istft_run<float>(p, D, batch, d_batch_stride, d_frame_stride, n_used, wss, y, out_len, y_stride);
 }
 
+#ifdef LRA_PHASE_TIMER
+// experiments only (probe builds): read and clear the phase timer of lra_kernels.h
+int lra_debug_phase_ticks(lra_ctx* ctx, unsigned long long* out16) {
+    LRA_BIND(ctx);
+    LRA_HIP(hipStreamSynchronize(ctx->stream));
+    LRA_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(lra_phase_ticks), 16 * sizeof(unsigned long long)));
+    unsigned long long zero[16] = {};
+    LRA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(lra_phase_ticks), zero, sizeof(zero)));
+    return LRA_OK;
+}
+#endif
+
 // ---- transpose ----------------------------------------------------------------------------------
 int lra_transpose(lra_ctx* ctx, const void* src, void* dst, int64_t batch, int64_t rows, int64_t cols, int elem_bytes) {
-    LRA_TRY(ctx_bind(ctx));
+    LRA_BIND(ctx);
     if (batch <= 0 || rows <= 0 || cols <= 0) return LRA_OK;
     if (!src || !dst) return fail(LRA_EINVAL, "null data pointer");
     if (batch > 65535) return fail(LRA_EINVAL, "transpose batch too large");

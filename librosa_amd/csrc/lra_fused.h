@@ -27,7 +27,9 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void stft_kernel(lra::Stft
     a.D = static_cast<typename Cfg::cplx*>(out);
     a.S = static_cast<typename Cfg::real*>(out);
     a.Mel = static_cast<typename Cfg::real*>(out);
-    lra::stft_block<Cfg, MODE, PM, RA>(a, (int)blockIdx.x, lds);
+    const int blk = lra::xcd_block((int)blockIdx.x, a.xcd_chunk);
+    if (blk >= a.n_blocks) return;  // grid padded to a multiple of 8 (uniform exit, before any barrier)
+    lra::stft_block<Cfg, MODE, PM, RA>(a, blk, lds);
 }
 
 template <class Cfg, int HC>
@@ -39,7 +41,9 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void istft_kernel(lra::Ist
     a.D = D;
     a.wss = wss;
     a.y = y;
-    lra::istft_block<Cfg, HC>(a, (int)blockIdx.x, lds);
+    const int blk = lra::xcd_block((int)blockIdx.x, a.xcd_chunk);
+    if (blk >= a.n_blocks) return;
+    lra::istft_block<Cfg, HC>(a, blk, lds);
 }
 
 

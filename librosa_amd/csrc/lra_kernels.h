@@ -30,6 +30,30 @@
 
 #include "lra_fft.h"
 
+// Phase timer (experiments only, -DLRA_PHASE_TIMER in a single-TU probe build): every wave adds the shader-clock
+// ticks it spends between consecutive LRA_TICK points of the forward kernel's frame loop to lra_phase_ticks[i].
+// s_memtime needs its own lgkmcnt(0) wait, which also drains the wave's LDS queue at that point: the numbers show
+// where the time goes, at ~10 % overhead.
+#if defined(LRA_PHASE_TIMER) && !defined(LRA_HOSTSIM)
+__device__ unsigned long long lra_phase_ticks[16];
+#define LRA_TICK(i)                                                    \
+    do {                                                               \
+        const unsigned long long now__ = __builtin_amdgcn_s_memtime(); \
+        tick_acc[i] += now__ - tick_prev;                              \
+        tick_prev = now__;                                             \
+    } while (0)
+#define LRA_TICK_DECL unsigned long long tick_acc[16] = {}, tick_prev = __builtin_amdgcn_s_memtime()
+#define LRA_TICK_FLUSH                                                                    \
+    do {                                                                                  \
+        if ((threadIdx.x & 63) == 0)                                                      \
+            for (int i__ = 0; i__ < 16; ++i__) atomicAdd(&lra_phase_ticks[i__], tick_acc[i__]); \
+    } while (0)
+#else
+#define LRA_TICK(i) ((void)0)
+#define LRA_TICK_DECL ((void)0)
+#define LRA_TICK_FLUSH ((void)0)
+#endif
+
 namespace lra {
 
 enum OutMode : int { OUT_COMPLEX = 0, OUT_POWER = 1, OUT_MEL = 2, OUT_MEL2 = 3, OUT_MELR = 4 };  // MEL2: two-slope filterbank, MELR: its run-ordered form (lra_mel.h)
@@ -79,10 +103,19 @@ template <class T> struct StftArgs {
     int melr_pmax;            // list length = pieces of the widest pair segment, at least MELR_PHOIST (<= MELR_PMAX)
     int melr_zero, melr_mid;  // byte addresses (inside the slot's running-sum area) of the zero slot and of bin M/2's slot
     int shared_off;
+    // launch geometry: the grid is n_blocks rounded up to 8 * xcd_chunk workgroups (xcd_chunk = 0: no remap), see xcd_block
+    int n_blocks, xcd_chunk;
     // set to 1 when a frame's DC bin is not finite, i.e. (barring overflow) when some sample of the
     // frame is NaN/Inf: the device-side half of util.valid_audio (util/utils.py:305)
     unsigned int* nonfinite_flag;
 };
+
+// Workgroup -> work item, XCD-aware.  The hardware deals workgroups round-robin to the 8 XCDs (workgroup b runs on XCD
+// b mod 8, MI355X_MICROARCH.md), so with the identity map the consecutive strips of a clip -- neighbours in the output
+// and sharing their PCM halo -- land on 8 different L2s.  Mapping b -> (b mod 8) * chunk + b / 8 gives every XCD one
+// contiguous eighth of the (clip, strip) list instead: measured on the store stream of the STFT (scripts/storepat2.hip)
+// +6 % on its own and +15 % together with aligned non-temporal stores.  chunk = ceil(n_blocks / 8); 0 = identity.
+LRA_HD int xcd_block(int b, int chunk) { return chunk > 0 ? (b & 7) * chunk + (b >> 3) : b; }
 
 // Thread -> (frame slot, thread within the slot).  The slot index is wave-uniform whenever a slot is one or more
 // whole waves (TF >= 64): fetching it through readfirstlane keeps everything derived from it -- frame number,
@@ -766,10 +799,12 @@ template <class Cfg> LRA_HD void melr_combine(const StftArgs<typename Cfg::real>
         LRA_PHASE(Cfg::NT, tid) {                                                                         \
             pass_read<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(rg).v, lds_sub(lds, (slot_of<Cfg>(tid)) * (slot_bytes)), lane_of<Cfg>(tid)); \
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)                                                              \
+        LRA_TICK(2 * p);                                                                                  \
         LRA_PHASE(Cfg::NT, tid) {                                                                         \
             pass_dft<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(rg), lane_of<Cfg>(tid), tw);                          \
             pass_write<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(rg).v, lds_sub(lds, (slot_of<Cfg>(tid)) * (slot_bytes)), lane_of<Cfg>(tid)); \
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)                                                              \
+        LRA_TICK(2 * p + 1);                                                                              \
     }
 
 // bytes of LDS one frame slot needs (frame area + mel staging tile), multiple of 16
@@ -820,8 +855,10 @@ template <class Cfg, int MODE, int PM = POW_TWO, bool RA = false> LRA_HD void st
 #endif
     constexpr bool LATE_PF = DEFER && LRA_MEL_LATE_PF;
     int done = 0;  // frames of this workgroup's slots processed so far (uniform)
+    LRA_TICK_DECL;
     for (int it = 0; it < iters; ++it) {
         if (f_first + it >= a.n_frames) break;  // slot 0 has the smallest frame index: uniform exit
+        LRA_TICK(0);
         if (!Cfg::HOIST) { LRA_LAUNDER(a.win); LRA_LAUNDER(a.tw); LRA_LAUNDER(a.twr); }
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
@@ -831,6 +868,7 @@ template <class Cfg, int MODE, int PM = POW_TWO, bool RA = false> LRA_HD void st
                 mel2_combine<Cfg>(a, clip, frame - 1, tf, (it - 1) % tile, tile, lds_sub(lds, a.shared_off), lds_sub(sl, slot_bytes - mel2_psum_bytes<Cfg>(a.n_mels)), lds_sub(sl, stft_tile_off<Cfg>()));
             stft_ring_load_pass0<Cfg, RA>(a, frame, tf, LRA_R(rg), lds_sub(sl, stft_ring_off<Cfg>()), sl);
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+        LRA_TICK(1);
 #if LRA_ABLATE != 2
         LRA_MID_PASS(Cfg, 1, rg, lds, a.tw, slot_bytes)
         LRA_MID_PASS(Cfg, 2, rg, lds, a.tw, slot_bytes)
@@ -846,11 +884,13 @@ template <class Cfg, int MODE, int PM = POW_TWO, bool RA = false> LRA_HD void st
             if (DEFER && tile > 1 && it > 0 && it % tile == 0)  // the tile that frame it-1 completed
                 mel_flush_tile<Cfg>(a, clip, f_first + slot * iters, it - 1, tile, tf, lds_sub(sl, stft_tile_off<Cfg>()));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+        LRA_TICK(8);
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
             if constexpr (MODE == OUT_MELR) melr_split_accumulate<Cfg, PM>(a, frame < a.n_frames, tf, LRA_R(rg), lds_sub(lds, slot * slot_bytes), lds_sub(lds, a.shared_off));
             else stft_split_store<Cfg, MODE, PM>(a, clip, frame, frame < a.n_frames, tf, LRA_R(rg), lds_sub(lds, slot * slot_bytes), lds_sub(lds, a.shared_off));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+        LRA_TICK(9);
         if (MODE == OUT_MEL2 && LRA_ABLATE != 12 && LRA_ABLATE != 13) {
             LRA_PHASE(Cfg::NT, tid) {
                 const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
@@ -875,8 +915,10 @@ template <class Cfg, int MODE, int PM = POW_TWO, bool RA = false> LRA_HD void st
                 } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
             }
         }
+        LRA_TICK(10);
         done = it + 1;
     }
+    LRA_TICK_FLUSH;
     if (DEFER && done > 0) {  // epilogue of the last frame
         const int it = done - 1;
         LRA_PHASE(Cfg::NT, tid) {
@@ -917,6 +959,7 @@ template <class T> struct IstftArgs {
     int strips_per_clip;
     int warm_frames;            // frames replayed before the strip: ceil(N/hop) - 1
     int drain_steps;            // extra steps the last strip of a clip runs to flush the carry
+    int n_blocks, xcd_chunk;    // launch geometry, see xcd_block
 };
 
 // per slot: frame area + double-buffered carry of N reals (>= N - hop for any hop >= 1)
@@ -1247,6 +1290,7 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
     const int steps = a.warm_frames + a.strip_frames + (has_last ? a.drain_steps : 0);
     const bool defer = ROWS || 4 * a.hop <= Cfg::N;  // finished samples per hop fit the hold-back registers
     constexpr bool rows = ROWS;
+    LRA_TICK_DECL;  // (the pass macro shared with the forward kernel ticks; the inverse kernel does not report)
     LRA_REGS(FftRegs<Cfg>, rg, Cfg::NT);
     // the slot's strip (64-bit divisions) is worked out once, from the un-laundered thread index
     LRA_REGS(IstftSlot<Cfg>, sl, Cfg::NT);

@@ -93,43 +93,36 @@ def dtype_c2r(d, *, default=np.float32):
     return np.dtype(table.get(dt, default))
 
 
-def normalize(S, *, norm=np.inf, axis=0, threshold=None, fill=None):
-    """``librosa/util/utils.py:796-1025`` (host tables only: window and filterbank normalisation)."""
+def normalize(S, *, norm=np.inf, axis=0, threshold=None):
+    """Scale ``S`` to unit ``norm`` along ``axis`` -- the part of ``librosa.util.normalize``
+    (``librosa/util/utils.py:796-1025``) this path reaches: ``filters.mel(norm=<number>)`` (``filters.py:238-239``)
+    and ``window_sumsquare(norm=...)`` (``filters.py:1325-1327``), both with the default ``fill=None``.
+
+    ``norm``: ``None`` (no scaling), ``+-inf`` (max / min magnitude), ``0`` (number of non-zeros) or ``p > 0``
+    (the l_p norm).  Slices whose norm is below ``threshold`` (default: ``tiny`` of the dtype) are left unscaled.
+    """
+    if norm is None:
+        return S
     if threshold is None:
         threshold = tiny(S)
     elif threshold <= 0:
         raise ParameterError(f"threshold={threshold} must be strictly positive")
-    if fill not in [None, False, True]:
-        raise ParameterError(f"fill={fill} must be None or boolean")
-    if not np.all(np.isfinite(S)):
+    S = np.asarray(S)
+    if not np.isfinite(S).all():
         raise ParameterError("Input must be finite")
-    mag = np.abs(S).astype(float)
-    fill_norm = 1
-    if norm is None:
-        return S
-    if norm == np.inf:
-        length = np.max(mag, axis=axis, keepdims=True)
-    elif norm == -np.inf:
-        length = np.min(mag, axis=axis, keepdims=True)
-    elif norm == 0:
-        if fill is True:
-            raise ParameterError("Cannot normalize with norm=0 and fill=True")
-        length = np.sum(mag > 0, axis=axis, keepdims=True, dtype=mag.dtype)
-    elif np.issubdtype(type(norm), np.number) and norm > 0:
-        length = np.sum(mag**norm, axis=axis, keepdims=True) ** (1.0 / norm)
-        fill_norm = (mag.size if axis is None else mag.shape[axis]) ** (-1.0 / norm)
+    magnitude = np.abs(S).astype(float)
+    reduce_kw = dict(axis=axis, keepdims=True)
+    if isinstance(norm, (int, float, np.number)) and np.isposinf(norm):
+        scale = magnitude.max(**reduce_kw)
+    elif isinstance(norm, (int, float, np.number)) and np.isneginf(norm):
+        scale = magnitude.min(**reduce_kw)
+    elif isinstance(norm, (int, float, np.number)) and norm == 0:
+        scale = np.count_nonzero(magnitude, **reduce_kw).astype(magnitude.dtype)
+    elif isinstance(norm, (int, float, np.number)) and norm > 0:
+        scale = np.sum(magnitude**norm, **reduce_kw) ** (1.0 / norm)
     else:
         raise ParameterError(f"Unsupported norm: {norm!r}")
-    small = length < threshold
+    scale = np.where(scale < threshold, 1.0, scale)
     out = np.empty_like(S)
-    if fill is None:
-        length[small] = 1.0
-        out[:] = S / length
-    elif fill:
-        length[small] = np.nan
-        out[:] = S / length
-        out[np.isnan(out)] = fill_norm
-    else:
-        length[small] = np.inf
-        out[:] = S / length
+    out[...] = S / scale
     return out

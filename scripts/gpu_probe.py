@@ -69,6 +69,20 @@ elif what == "iters":
             msm = timeit(lambda: ctx.melspectrogram_exec(plan, mel_plan, y.data_ptr(), batch, n, n, 2.0, M.data_ptr()))
             msi = timeit(lambda: ctx.istft_exec(iplan, D.data_ptr(), batch, T * 1025, 1025, T, wss.data_ptr(), yrec.data_ptr(), n, n))
             print(f"variant {variant} iters {iters}: stft {ms:.3f} ms ({batch * T / ms / 1e3:.1f} Mframes/s)   mel {msm:.3f} ms ({batch * T / msm / 1e3:.1f} Mframes/s)   istft {msi:.3f} ms ({batch * T / msi / 1e3:.1f} Mframes/s)", flush=True)
+elif what == "remap":
+    # XCD-aware workgroup map on/off x frames per slot, all three kernels (run once per library build)
+    ctx.set_option("autotune", 0)
+    ctx.set_option("variant", 0)
+    for remap in (0, 1):
+        ctx.set_option("xcd_remap", remap)
+        for iters in (0, 54, 81, 108, 162, 324):
+            ctx.set_option("stft_iters", iters)
+            ctx.set_option("istft_strip_groups", iters)
+            ms = min(timeit(lambda: ctx.stft_exec(plan, y.data_ptr(), batch, n, n, D.data_ptr())) for _ in range(3))
+            msm = min(timeit(lambda: ctx.melspectrogram_exec(plan, mel_plan, y.data_ptr(), batch, n, n, 2.0, M.data_ptr())) for _ in range(3))
+            msi = min(timeit(lambda: ctx.istft_exec(iplan, D.data_ptr(), batch, T * 1025, 1025, T, wss.data_ptr(), yrec.data_ptr(), n, n)) for _ in range(3))
+            print(f"{os.environ.get('LIBROSA_AMD_LIBRARY', 'product')}: remap {remap} iters {iters:3d}: stft {ms:.3f} ms ({batch * T * 10248 / ms / 1e6:5.0f} GB/s)   mel {msm:.3f} ms ({batch * T / msm / 1e3:.1f} Mframes/s)   "
+                  f"istft {msi:.3f} ms ({batch * T * 10248 / msi / 1e6:5.0f} GB/s)", flush=True)
 elif what == "survey":
     # other common configurations: ms and algorithmic GB/s for stft / melspectrogram / istft
     ctx.set_option("variant", -1)

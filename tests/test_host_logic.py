@@ -42,8 +42,6 @@ def test_parameter_errors_are_raised_before_any_device_work():
     with pytest.raises(L.ParameterError):
         L.istft(np.zeros((1025, 4), dtype=np.float32))  # not complex
     with pytest.raises(L.ParameterError):
-        L.istft(np.zeros((1025, 4), dtype=np.complex64), n_fft=1024)  # bins do not match n_fft
-    with pytest.raises(L.ParameterError):
         L.filters.get_window(np.ones(7), 8)
 
 
