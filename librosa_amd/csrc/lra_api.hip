@@ -67,6 +67,7 @@ struct lra_ctx {
     int opt_mel_tile = 0;            // frames staged per mel row before a flush (0 = auto)
     int opt_generic_mel = 0;         // force the generic banded mel path (tests)
     int opt_lds_pad = 0;             // extra dynamic LDS per workgroup (occupancy experiments)
+    int opt_v2 = 1;                  // second-generation forward kernel where it applies (lra_kernels2.h)
     int opt_xcd_remap = 1;           // workgroup -> work item map that keeps neighbouring strips on one XCD (lra_kernels.h, xcd_block)
     unsigned int* d_flag = nullptr;  // non-finite input flag (device)
     std::string name;
@@ -237,6 +238,7 @@ template <class T> struct StftLaunch {
     void* out = nullptr;
     int lds_pad = 0;
     bool xcd_remap = true;
+    bool use_v2 = true;
     bool mel_runs = true;
     const lra_mel_plan* mel = nullptr;
     hipStream_t stream = nullptr;
@@ -244,7 +246,7 @@ template <class T> struct StftLaunch {
 
     template <class Cfg, int MODE> void launch(int shared_bytes) {
         static_assert(Cfg::P <= 4, "at most four Stockham passes are wired up");
-        const int lds_probe = Cfg::FPB * stft_slot_bytes<Cfg>(MODE, a.n_mels, mel_tile_opt > 0 ? mel_tile_opt : 4) + shared_bytes + lds_pad;
+        const int lds_probe_v1 = Cfg::FPB * stft_slot_bytes<Cfg>(MODE, a.n_mels, mel_tile_opt > 0 ? mel_tile_opt : 4) + shared_bytes + lds_pad;
         void (*kern)(StftArgs<T>, const T*, void*) = stft_kernel<Cfg, MODE, POW_TWO, false>;
         if (MODE != OUT_COMPLEX && a.power_mode == POW_ONE) kern = stft_kernel<Cfg, MODE, POW_ONE, false>;
         if (MODE != OUT_COMPLEX && a.power_mode == POW_GENERAL) kern = stft_kernel<Cfg, MODE, POW_GENERAL, false>;
@@ -258,6 +260,22 @@ template <class T> struct StftLaunch {
                 if (MODE != OUT_COMPLEX && a.power_mode == POW_GENERAL) kern = stft_kernel<Cfg, MODE, POW_GENERAL, true>;
             }
         }
+        // Second-generation kernel (lra_kernels2.h) where it applies: complex / power epilogues, 16 points per thread with
+        // a two-butterfly last pass (n_fft 1024 / 2048 / 4096), hop = n_fft / {1, 2, 4, 8}.
+        bool v2 = false;
+        if constexpr (v2_cfg_ok<Cfg>() && (MODE == OUT_COMPLEX || MODE == OUT_POWER)) {
+            const int hd = use_v2 ? v2_hop_divisor<Cfg>(a.hop) : 0;
+            if (hd) {
+                v2 = true;
+#define LRA_PICK2(HD)                                                                                        \
+    kern = stft2_kernel<Cfg, HD, MODE, POW_TWO>;                                                            \
+    if (MODE != OUT_COMPLEX && a.power_mode == POW_ONE) kern = stft2_kernel<Cfg, HD, MODE, POW_ONE>;        \
+    if (MODE != OUT_COMPLEX && a.power_mode == POW_GENERAL) kern = stft2_kernel<Cfg, HD, MODE, POW_GENERAL>;
+                if (hd == 1) { LRA_PICK2(1) } else if (hd == 2) { LRA_PICK2(2) } else if (hd == 4) { LRA_PICK2(4) } else { LRA_PICK2(8) }
+#undef LRA_PICK2
+            }
+        }
+        const int lds_probe = v2 ? Cfg::FPB * stft2_slot_bytes<Cfg>() + lds_pad : lds_probe_v1;
         // Frames per slot (`iters`).  A slot pays n_fft - hop extra sample loads for its first frame, so long
         // runs are cheap in HBM traffic; but the launch should also end evenly: the grid is sized to a whole
         // number of "waves" of workgroups (CUs x resident workgroups per CU), because a last partial wave
@@ -294,7 +312,7 @@ template <class T> struct StftLaunch {
         if (a.mel_tile > iters) a.mel_tile = iters;
         a.frames_per_wg = Cfg::FPB * iters;
         a.wg_per_clip = (a.n_frames + a.frames_per_wg - 1) / a.frames_per_wg;
-        a.slot_bytes = stft_slot_bytes<Cfg>(MODE, a.n_mels, a.mel_tile);
+        a.slot_bytes = v2 ? stft2_slot_bytes<Cfg>() : stft_slot_bytes<Cfg>(MODE, a.n_mels, a.mel_tile);
         a.shared_off = Cfg::FPB * a.slot_bytes;
         const long long grid = batch * a.wg_per_clip;
         if (grid > 0x7ffffff0LL) { err = hipErrorInvalidConfiguration; return; }
@@ -422,7 +440,7 @@ template <class T> struct TableBuild {
     std::vector<cx<T>> tw, twr;
     template <class Cfg> void operator()() {
         tw.assign(Cfg::TW_TOTAL, mk<T>((T)1, (T)0));
-        twr.assign(Cfg::M / 2 + 1, mk<T>((T)1, (T)0));
+        twr.assign(split_tw_count<Cfg>(), mk<T>((T)1, (T)0));
         build_pass_twiddles<Cfg>(tw.data());
         build_split_twiddles<Cfg>(twr.data());
     }
@@ -715,6 +733,7 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
         L.mel_tile_opt = ctx->opt_mel_tile;
         L.lds_pad = ctx->opt_lds_pad;
         L.xcd_remap = ctx->opt_xcd_remap != 0;
+        L.use_v2 = ctx->opt_v2 != 0;
         L.mel_runs = ctx->opt_mel_runs != 0;
         // Kernel variant (f32 n_fft = 2048 only): 0 = one wave per frame, 4 = two waves per frame.  Which one
         // is faster depends on the epilogue AND on the individual GPU (boxes of the same pool differ by +-10 %,
@@ -728,7 +747,11 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
             if (Lv.err != hipSuccess) return fail(LRA_EHIP, std::string("stft kernel launch: ") + hipGetErrorString(Lv.err));
             return LRA_OK;
         };
-        if (ctx->opt_variant < 0 && ctx->opt_autotune && sizeof(T) == 4 && p->logm == 10) {
+        // (the second-generation kernel replaces both tunings for the complex / power epilogues)
+        bool v2_applies = false;
+        if constexpr (sizeof(T) == 4)
+            v2_applies = ctx->opt_v2 && (L.mode == OUT_COMPLEX || L.mode == OUT_POWER) && p->logm == 10 && v2_hop_divisor<typename CfgSel<float, 10, 0>::type>(p->hop) > 0;
+        if (ctx->opt_variant < 0 && ctx->opt_autotune && sizeof(T) == 4 && p->logm == 10 && !v2_applies) {
             int& tuned = p->tuned_variant[L.mode & 3];
             if (tuned < 0 && batch * n_frames >= 65536) LRA_TRY(autotune_variant(ctx, launch, &tuned));
             if (tuned >= 0) variant = tuned;
@@ -931,6 +954,7 @@ int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value) {
     else if (!std::strcmp(key, "generic_mel")) ctx->opt_generic_mel = value;
     else if (!std::strcmp(key, "lds_pad")) ctx->opt_lds_pad = value;
     else if (!std::strcmp(key, "xcd_remap")) ctx->opt_xcd_remap = value != 0;
+    else if (!std::strcmp(key, "v2")) ctx->opt_v2 = value != 0;
     else if (!std::strcmp(key, "autotune")) ctx->opt_autotune = value != 0;
     else if (!std::strcmp(key, "mel_runs")) ctx->opt_mel_runs = value != 0;
     else if (!std::strcmp(key, "variant")) ctx->opt_variant = (value >= 0 && value < kNumVariants) ? value : -1;

@@ -3,6 +3,7 @@
 #pragma once
 
 #include "lra_kernels.h"
+#include "lra_kernels2.h"
 
 namespace lra {
 

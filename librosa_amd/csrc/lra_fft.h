@@ -302,10 +302,11 @@ template <class Cfg> inline void build_pass_twiddles(typename Cfg::cplx* out) {
             }
     }
 }
-// W_N^k = exp(-2 pi i k / N), k = 0 .. M/2
+// W_N^k = exp(-2 pi i k / N), k = 0 .. M  (SPLIT_TW_COUNT entries; the first-generation kernels read k <= M/2 only)
+template <class Cfg> constexpr int split_tw_count() { return Cfg::M + 1; }
 template <class Cfg> inline void build_split_twiddles(typename Cfg::cplx* out) {
     const double two_pi = 6.283185307179586476925286766559;
-    for (int k = 0; k <= Cfg::M / 2; ++k) {
+    for (int k = 0; k <= Cfg::M; ++k) {
         const double ang = -two_pi * (double)k / (double)Cfg::N;
         out[k] = mk<typename Cfg::real>((typename Cfg::real)std::cos(ang), (typename Cfg::real)std::sin(ang));
     }

@@ -32,6 +32,24 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void stft_kernel(lra::Stft
     lra::stft_block<Cfg, MODE, PM, RA>(a, blk, lds);
 }
 
+// Second-generation forward kernel (lra_kernels2.h): PCM ring in registers, mirrored last pass with the split step in
+// registers.  HD = n_fft / hop.  The register budget is sized for 3 waves per SIMD (12 slots of 8.7 KB per CU) where the
+// kernel fits it without spilling (hop <= n_fft/4, i.e. at most 4 sample pairs in flight per thread).
+template <class Cfg, int HD, int MODE, int PM>
+__global__ __launch_bounds__(Cfg::NT, (Cfg::NT >= 256 ? 1 : (HD >= 4 && PM != lra::POW_GENERAL ? 3 : 2))) void stft2_kernel(lra::StftArgs<typename Cfg::real> a, const typename Cfg::real* __restrict__ y,
+                                                                                  void* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char lra_smem[];
+    lra::Lds lds;
+    lds.base = lra_smem;
+    a.y = y;
+    a.D = static_cast<typename Cfg::cplx*>(out);
+    a.S = static_cast<typename Cfg::real*>(out);
+    a.Mel = static_cast<typename Cfg::real*>(out);
+    const int blk = lra::xcd_block((int)blockIdx.x, a.xcd_chunk);
+    if (blk >= a.n_blocks) return;
+    lra::stft_block2<Cfg, HD, MODE, PM>(a, blk, lds);
+}
+
 template <class Cfg, int HC>
 __global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void istft_kernel(lra::IstftArgs<typename Cfg::real> a, const typename Cfg::cplx* __restrict__ D,
                                                                       const typename Cfg::real* __restrict__ wss, typename Cfg::real* __restrict__ y) {
@@ -97,7 +115,13 @@ LRA_CFG_ALIAS(cfg_f64_12, double, 12, 0)
 #define LRA_INST_GROUP_6(S, I) LRA_F32_CFG(S, I, cfg_f32_12, 4, 2) LRA_F32_CFG(S, I, cfg_f32_13, 4, 2)
 #define LRA_INST_GROUP_7(S, I) LRA_F64_CFG(S, I, cfg_f64_4) LRA_F64_CFG(S, I, cfg_f64_5) LRA_F64_CFG(S, I, cfg_f64_6) LRA_F64_CFG(S, I, cfg_f64_7) LRA_F64_CFG(S, I, cfg_f64_8)
 #define LRA_INST_GROUP_8(S, I) LRA_F64_CFG(S, I, cfg_f64_9) LRA_F64_CFG(S, I, cfg_f64_10) LRA_F64_CFG(S, I, cfg_f64_11) LRA_F64_CFG(S, I, cfg_f64_12)
-#define LRA_INST_NUM_GROUPS 9
+// second-generation forward kernels: T(CFG, HD, MODE, PM)
+#define LRA_STFT2_HD(T, C, HD) T(lra::C, HD, 0, 2) T(lra::C, HD, 1, 1) T(lra::C, HD, 1, 2) T(lra::C, HD, 1, 3)
+#define LRA_STFT2_CFG(T, C) LRA_STFT2_HD(T, C, 1) LRA_STFT2_HD(T, C, 2) LRA_STFT2_HD(T, C, 4) LRA_STFT2_HD(T, C, 8)
+#define LRA_INST2_GROUP_9(T) LRA_STFT2_CFG(T, cfg_f32_10)
+#define LRA_INST2_GROUP_10(T) LRA_STFT2_CFG(T, cfg_f32_9) LRA_STFT2_CFG(T, cfg_f32_11)
+#define LRA_INST2_ALL(T) LRA_INST2_GROUP_9(T) LRA_INST2_GROUP_10(T)
+#define LRA_INST_NUM_GROUPS 11
 #define LRA_INST_ALL(S, I)                                                                                                   \
     LRA_INST_GROUP_0(S, I) LRA_INST_GROUP_1(S, I) LRA_INST_GROUP_2(S, I) LRA_INST_GROUP_3(S, I) LRA_INST_GROUP_4(S, I)       \
     LRA_INST_GROUP_5(S, I) LRA_INST_GROUP_6(S, I) LRA_INST_GROUP_7(S, I) LRA_INST_GROUP_8(S, I)
@@ -109,6 +133,10 @@ LRA_CFG_ALIAS(cfg_f64_12, double, 12, 0)
 #define LRA_S_DEFINE(C, MODE, PM, RA) template __global__ void stft_kernel<C, MODE, PM, RA>(LRA_STFT_SIG(C));
 #define LRA_I_DEFINE(C, HC) template __global__ void istft_kernel<C, HC>(LRA_ISTFT_SIG(C));
 
+#define LRA_T_EXTERN(C, HD, MODE, PM) extern template __global__ void stft2_kernel<C, HD, MODE, PM>(LRA_STFT_SIG(C));
+#define LRA_T_DEFINE(C, HD, MODE, PM) template __global__ void stft2_kernel<C, HD, MODE, PM>(LRA_STFT_SIG(C));
+
 #if defined(LRA_FUSED_EXTERN) && !defined(LRA_PROBE_ONLY)
 LRA_INST_ALL(LRA_S_EXTERN, LRA_I_EXTERN)
+LRA_INST2_ALL(LRA_T_EXTERN)
 #endif

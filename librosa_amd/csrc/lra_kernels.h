@@ -454,7 +454,7 @@ template <class Cfg, int MODE, int PM> LRA_HD void stft_split_store(const StftAr
             km = M - k;
         }
         if (MODE == OUT_COMPLEX) {
-#if LRA_ABLATE == 1  // experiment: compute everything, store (practically) nothing
+#if LRA_ABLATE == 1 || LRA_ABLATE == 4  // experiment: compute everything, store (practically) nothing
             if (valid && xk.x == (T)12345.678) { Dk[i * Cfg::TF] = xk; Dm[-i * Cfg::TF] = xm; }
 #else
             if (valid) { stream_store(&Dk[i * Cfg::TF], xk); stream_store(&Dm[-i * Cfg::TF], xm); }
@@ -829,19 +829,6 @@ template <class Cfg, int MODE, int PM = POW_TWO, bool RA = false> LRA_HD void st
     const int iters = a.frames_per_wg / Cfg::FPB;
     const int slot_bytes = a.slot_bytes;
     const int tile = a.mel_tile;
-    LRA_REGS(FftRegs<Cfg>, rg, Cfg::NT);
-    LRA_PHASE(Cfg::NT, tid) {
-        hoist_tables<Cfg>(LRA_R(rg), lane_of<Cfg>(tid), a.win, a.tw, a.twr, false, MODE == OUT_MELR);
-        if (MODE == OUT_MEL2) mel2_tables_to_lds<Cfg>(a, tid, lds_sub(lds, a.shared_off));
-        if (MODE == OUT_MELR) {
-            melr_tables_to_lds<Cfg>(a, tid, lds_sub(lds, a.shared_off));
-            melr_hoist<Cfg>(a, lane_of<Cfg>(tid), LRA_R(rg));
-        }
-    } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC && MODE != OUT_MEL2 && MODE != OUT_MELR)  // the shared tables need a workgroup barrier, once
-    LRA_PHASE(Cfg::NT, tid) {
-        const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
-        stft_ring_fill<Cfg>(a, clip, f_first + slot * iters, tf, lds_sub(lds, slot * slot_bytes + stft_ring_off<Cfg>()));
-    } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
     // OUT_MEL2 defers the last two steps of frame t's mel epilogue into frame t+1's phases (their LDS
     // regions -- piece sums, staging tile -- are not touched by the FFT): combine(t) runs next to the ring
     // loads / pass 0 of frame t+1 and flush(t) next to its split reads, which saves two workgroup
@@ -854,6 +841,29 @@ template <class Cfg, int MODE, int PM = POW_TWO, bool RA = false> LRA_HD void st
 #define LRA_MEL_LATE_PF 1
 #endif
     constexpr bool LATE_PF = DEFER && LRA_MEL_LATE_PF;
+    // Vector memory operations of a wave complete IN ORDER (one vmcnt for loads and stores): a wait for the prefetched
+    // samples also waits for every store issued before those loads, and a spectrum store is acknowledged only ~1.5 us
+    // after issue (a lone wave loses 1 400 of 5 200 cycles per frame to that wait).  So the loads of frame t+2 are issued
+    // at the END of frame t, right after the ring took frame t+1's samples and BEFORE frame t's stores: the wait one
+    // frame later is then s_waitcnt vmcnt(<stores of frame t+1>) and only covers stores that are two frames old.
+#ifndef LRA_PF_EARLY
+#define LRA_PF_EARLY 1
+#endif
+    constexpr bool PF_EARLY = !LATE_PF && LRA_PF_EARLY;
+    LRA_REGS(FftRegs<Cfg>, rg, Cfg::NT);
+    LRA_PHASE(Cfg::NT, tid) {
+        hoist_tables<Cfg>(LRA_R(rg), lane_of<Cfg>(tid), a.win, a.tw, a.twr, false, MODE == OUT_MELR);
+        if (MODE == OUT_MEL2) mel2_tables_to_lds<Cfg>(a, tid, lds_sub(lds, a.shared_off));
+        if (MODE == OUT_MELR) {
+            melr_tables_to_lds<Cfg>(a, tid, lds_sub(lds, a.shared_off));
+            melr_hoist<Cfg>(a, lane_of<Cfg>(tid), LRA_R(rg));
+        }
+    } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC && MODE != OUT_MEL2 && MODE != OUT_MELR)  // the shared tables need a workgroup barrier, once
+    LRA_PHASE(Cfg::NT, tid) {
+        const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
+        stft_ring_fill<Cfg>(a, clip, f_first + slot * iters, tf, lds_sub(lds, slot * slot_bytes + stft_ring_off<Cfg>()));
+        if (PF_EARLY && iters > 1) stft_ring_prefetch<Cfg, RA>(a, clip, f_first + slot * iters + 1, tf, LRA_R(rg));
+    } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
     int done = 0;  // frames of this workgroup's slots processed so far (uniform)
     LRA_TICK_DECL;
     for (int it = 0; it < iters; ++it) {
@@ -863,7 +873,9 @@ template <class Cfg, int MODE, int PM = POW_TWO, bool RA = false> LRA_HD void st
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
             const Lds sl = lds_sub(lds, slot * slot_bytes);
-            if (!LATE_PF && it + 1 < iters) stft_ring_prefetch<Cfg, RA>(a, clip, frame + 1, tf, LRA_R(rg));
+#if LRA_ABLATE != 3 && LRA_ABLATE != 4  // experiments 3 / 4: no PCM loads in the frame loop (4: and no spectrum stores)
+            if (!LATE_PF && !PF_EARLY && it + 1 < iters) stft_ring_prefetch<Cfg, RA>(a, clip, frame + 1, tf, LRA_R(rg));
+#endif
             if (DEFER && it > 0 && frame - 1 < a.n_frames)
                 mel2_combine<Cfg>(a, clip, frame - 1, tf, (it - 1) % tile, tile, lds_sub(lds, a.shared_off), lds_sub(sl, slot_bytes - mel2_psum_bytes<Cfg>(a.n_mels)), lds_sub(sl, stft_tile_off<Cfg>()));
             stft_ring_load_pass0<Cfg, RA>(a, frame, tf, LRA_R(rg), lds_sub(sl, stft_ring_off<Cfg>()), sl);
@@ -880,7 +892,10 @@ template <class Cfg, int MODE, int PM = POW_TWO, bool RA = false> LRA_HD void st
             if (LATE_PF && it + 1 < iters) stft_ring_prefetch<Cfg, RA>(a, clip, frame + 1, tf, LRA_R(rg));
             if constexpr (MODE == OUT_MELR) split_read_runs<Cfg>(LRA_R(rg), sl, tf);
             else split_read<Cfg>(LRA_R(rg), sl, tf);
+#if LRA_ABLATE != 3 && LRA_ABLATE != 4
             if (!LATE_PF && it + 1 < iters) stft_ring_advance<Cfg, RA>(a, clip, frame + 1, tf, LRA_R(rg), lds_sub(sl, stft_ring_off<Cfg>()));
+            if (PF_EARLY && it + 2 < iters) stft_ring_prefetch<Cfg, RA>(a, clip, frame + 2, tf, LRA_R(rg));
+#endif
             if (DEFER && tile > 1 && it > 0 && it % tile == 0)  // the tile that frame it-1 completed
                 mel_flush_tile<Cfg>(a, clip, f_first + slot * iters, it - 1, tile, tf, lds_sub(sl, stft_tile_off<Cfg>()));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)

@@ -1,0 +1,352 @@
+// lra_kernels2.h -- second-generation forward kernel body (stft_block2): same results as stft_block (lra_kernels.h),
+// half of its LDS traffic.  Reference semantics: librosa/core/spectrum.py:380-390 (rfft of the windowed frames),
+// :3000-3013 (|X|^power).
+//
+// Measured on MI355X (profiles/r02_*): the first-generation kernel is bound by the LDS -- 470 LDS-array cycles per
+// frame against one frame per ~930 cycles per CU with every store and load removed -- not by the VALU (23 % busy)
+// and not by HBM.  Two of its four LDS round trips per frame are not arithmetic at all:
+//
+//   * the PCM ring.  A slot walks CONSECUTIVE frames, and with the hop a whole number of pass-0 rows (hop = n_fft/HD,
+//     HD in {1, 2, 4, 8}) frame t+1's pass-0 input element (tf, j) IS frame t's element (tf, j + r0/HD): the samples a
+//     thread needs next time are already in ITS OWN registers.  The ring therefore lives in 2 R registers per thread
+//     (`raw`), shifted by register moves; only the R/HD new sample pairs per frame are loaded (8-byte loads, one frame
+//     ahead, issued before the frame's stores so that the wait for them never covers those stores).  No ring in LDS:
+//     16 reads + 8 writes per frame gone, and the slot shrinks from 17 KB to 8.7 KB (12 instead of 9 waves per CU).
+//
+//   * the last pass's write + the split step's read.  The split needs Z[k] and Z[M-k] in one thread.  In the last
+//     Stockham pass (radix r, s = M/r butterflies, output of butterfly b at b + j s) the mirror of an output of
+//     butterfly b belongs to butterfly s - b.  Nothing ties butterfly b to thread b: thread tf takes butterflies tf and
+//     s - tf (thread 0: 0 and s/2, the two self-mirrored ones), and after the pass every mirrored pair sits in ONE
+//     thread's registers: X[k], X[M-k] come straight out of the butterflies and go to HBM (or to |X|^p) without the
+//     16 ds_write_b64 + 16 ds_read_b64 of a third round trip.  Lane 0's pairs are arranged differently (both of its
+//     butterflies are self-mirrored); a handful of lane-0 selects and a second pair of store bases absorb that.
+//
+// Applies to configurations whose last pass has two butterflies per thread (R / r_last == 2): n_fft 1024, 2048, 4096
+// at 16 points per thread.  Everything else keeps stft_block.
+#pragma once
+
+#include "lra_kernels.h"
+
+namespace lra {
+
+template <class Cfg> constexpr bool v2_cfg_ok() {
+    constexpr int pl = Cfg::P - 1;
+    return Cfg::P >= 2 && Cfg::R == 16 && Cfg::HOIST && sizeof(typename Cfg::real) == 4 && affine_tf<Cfg>() && (Cfg::R >> Cfg::logr(pl)) == 2 &&
+           2 * Cfg::TF == (Cfg::M >> Cfg::logr(pl)) && (Cfg::M >> Cfg::logr(pl)) % (1 << Cfg::PADSHIFT) == 0;
+}
+// hop = n_fft / HD with the hop a whole number of pass-0 rows
+template <class Cfg> constexpr bool v2_hd_ok(int hd) { return (hd == 1 || hd == 2 || hd == 4 || hd == 8) && (1 << Cfg::logr(0)) % hd == 0; }
+template <class Cfg> LRA_HD int v2_hop_divisor(int hop) {
+    for (int hd = 1; hd <= 8; hd *= 2)
+        if (hop * hd == Cfg::N && v2_hd_ok<Cfg>(hd)) return hd;
+    return 0;
+}
+
+template <class Cfg, int HD> struct Regs2 {
+    using C = typename Cfg::cplx;
+    static constexpr int R = Cfg::R;
+    static constexpr int r0 = 1 << Cfg::logr(0), nb0 = R >> Cfg::logr(0), sin0 = Cfg::M >> Cfg::logr(0);
+    static constexpr int SJ = r0 / HD;   // pass-0 rows a frame advances by
+    static constexpr int NEW = R / HD;   // new sample pairs per thread and frame
+    static constexpr int rl = 1 << Cfg::logr(Cfg::P - 1);  // last-pass radix
+    C v[R];            // butterfly registers
+    C raw[R];          // this frame's sample pairs in pass-0 register order: element e = i r0 + j is complex index tf + i TF + j sin0
+    C pf[NEW];         // next frame's new sample pairs, in flight during the current frame
+    C win2[R];         // window pairs (x 1/2, see split_pair), pass-0 order
+    C treg[Cfg::TREG_TOTAL];
+    C twr[rl];         // split twiddles W_N^k of this thread's rl pair slots
+    // complex index (within a frame) of pass-0 register element e
+    static LRA_HD int q_of(int tf, int e) { return tf + (e / r0) * Cfg::TF + (e % r0) * sin0; }
+    // pass-0 register element of new pair n
+    static LRA_HD int elem_of_new(int n) { return (n / SJ) * r0 + (r0 - SJ) + (n % SJ); }
+};
+
+// second butterfly of thread tf in the last pass (the first is tf): the mirror s - tf; thread 0 takes s/2
+template <class Cfg> LRA_HD int v2_mirror_bfly(int tf) { return tf == 0 ? Cfg::TF : 2 * Cfg::TF - tf; }
+// "virtual thread index" of the store / twiddle addressing of pair slots q >= rl/2: tf, except for lane 0 whose slots
+// there hold the pairs of butterfly s/2: bins s/2 + (q - rl/2) s = q s + (s/2)(1 - rl)
+template <class Cfg> LRA_HD int v2_tf_hi(int tf) {
+    constexpr int rl = 1 << Cfg::logr(Cfg::P - 1), s = 2 * Cfg::TF;
+    return tf == 0 ? (s / 2) * (1 - rl) : tf;
+}
+
+template <class Cfg, int HD> LRA_HD void v2_hoist(Regs2<Cfg, HD>& rg, int tf, const typename Cfg::real* __restrict__ win, const typename Cfg::cplx* __restrict__ tw,
+                                                   const typename Cfg::cplx* __restrict__ twr_full) {
+    using C = typename Cfg::cplx;
+    using RG = Regs2<Cfg, HD>;
+    const C* __restrict__ win2 = reinterpret_cast<const C*>(win);
+    LRA_UNROLL
+    for (int e = 0; e < Cfg::R; ++e) rg.win2[e] = win2[RG::q_of(tf, e)];
+    // middle passes: the usual butterflies tf + i TF
+    if (Cfg::P > 2) load_pass_twiddles<Cfg, (1 < Cfg::P - 1 ? 1 : 0)>(rg.treg, tf, tw);
+    if (Cfg::P > 3) load_pass_twiddles<Cfg, (2 < Cfg::P - 1 ? 2 : 0)>(rg.treg, tf, tw);
+    // last pass: butterflies tf and its mirror
+    {
+        constexpr int p = Cfg::P - 1, lr = Cfg::logr(p), s = 1 << Cfg::logs(p);
+        LRA_UNROLL
+        for (int i = 0; i < 2; ++i) {
+            const int k = i == 0 ? tf : v2_mirror_bfly<Cfg>(tf);
+            LRA_UNROLL
+            for (int t = 0; t < lr; ++t) rg.treg[Cfg::treg_off(p) + i * lr + t] = tw[Cfg::tw_off(p) + ((1 << t) - 1) * s + k];
+        }
+    }
+    // split twiddles of the pair slots: slot q pairs bin k_q = tfo + q s with bin M - k_q
+    {
+        constexpr int rl = RG::rl, s = 2 * Cfg::TF;
+        const int tfh = v2_tf_hi<Cfg>(tf);
+        LRA_UNROLL
+        for (int q = 0; q < rl; ++q) rg.twr[q] = twr_full[(q < rl / 2 ? tf : tfh) + q * s];
+    }
+}
+
+// new sample pairs of frame `next` -> rg.pf (issued one frame ahead).  Blocks that lie inside the clip take plain
+// 8-byte loads (4-byte loads when the clip is not 8-byte aligned); the few that touch the np.pad region
+// (core/spectrum.py:287) go through the index fold.
+template <class Cfg, int HD> LRA_HD void v2_issue_loads(const StftArgs<typename Cfg::real>& a, int clip, int next, int tf, Regs2<Cfg, HD>& rg) {
+    using T = typename Cfg::real;
+    using C = typename Cfg::cplx;
+    using RG = Regs2<Cfg, HD>;
+    if (next >= a.n_frames) return;
+    const T* __restrict__ yb = a.y + (long long)clip * a.y_stride;
+    const long long p0 = (long long)next * a.hop;               // padded position of the frame's first sample
+    const long long g0 = p0 + (Cfg::N - a.hop) - a.pad;         // clip position of the first NEW sample
+    if (g0 >= 0 && g0 + a.hop <= a.n) {
+        const T* __restrict__ src = yb + (p0 - a.pad) + 2 * tf;  // this thread's pair 0 of the frame (only the new pairs are dereferenced)
+        if ((reinterpret_cast<size_t>(src) & (2 * sizeof(T) - 1)) == 0) {
+            LRA_UNROLL
+            for (int n = 0; n < RG::NEW; ++n) {
+                const int e = RG::elem_of_new(n);
+                rg.pf[n] = *reinterpret_cast<const C*>(src + 2 * ((e / RG::r0) * Cfg::TF + (e % RG::r0) * RG::sin0));
+            }
+        } else {
+            LRA_UNROLL
+            for (int n = 0; n < RG::NEW; ++n) {
+                const int e = RG::elem_of_new(n);
+                const T* __restrict__ s2 = src + 2 * ((e / RG::r0) * Cfg::TF + (e % RG::r0) * RG::sin0);
+                rg.pf[n] = mk<T>(s2[0], s2[1]);
+            }
+        }
+    } else {
+        LRA_UNROLL
+        for (int n = 0; n < RG::NEW; ++n) {
+            const long long p = p0 + 2 * RG::q_of(tf, RG::elem_of_new(n));
+            rg.pf[n] = mk<T>(fetch_sample<T>(yb, p, a.pad, a.n, a.pad_mode), fetch_sample<T>(yb, p + 1, a.pad, a.n, a.pad_mode));
+        }
+    }
+}
+
+// all R sample pairs of a slot's first frame
+template <class Cfg, int HD> LRA_HD void v2_fill(const StftArgs<typename Cfg::real>& a, int clip, int frame, int tf, Regs2<Cfg, HD>& rg) {
+    using T = typename Cfg::real;
+    using RG = Regs2<Cfg, HD>;
+    const T* __restrict__ yb = a.y + (long long)clip * a.y_stride;
+    const long long p0 = (long long)frame * a.hop;
+    LRA_UNROLL
+    for (int e = 0; e < Cfg::R; ++e) {
+        const long long p = p0 + 2 * RG::q_of(tf, e);
+        const bool live = frame < a.n_frames;
+        rg.raw[e] = live ? mk<T>(fetch_sample<T>(yb, p, a.pad, a.n, a.pad_mode), fetch_sample<T>(yb, p + 1, a.pad, a.n, a.pad_mode)) : mk<T>((T)0, (T)0);
+    }
+}
+
+// frame t -> t + 1: rows move down by SJ, the prefetched pairs become the last SJ rows
+template <class Cfg, int HD> LRA_HD void v2_shift(Regs2<Cfg, HD>& rg) {
+    using RG = Regs2<Cfg, HD>;
+    LRA_UNROLL
+    for (int i = 0; i < RG::nb0; ++i) {
+        LRA_UNROLL
+        for (int j = 0; j < RG::r0; ++j) rg.raw[i * RG::r0 + j] = j + RG::SJ < RG::r0 ? rg.raw[i * RG::r0 + j + RG::SJ] : rg.pf[i * RG::SJ + (j + RG::SJ - RG::r0)];
+    }
+}
+
+// phase: window, pass-0 butterflies, first LDS write of the frame
+template <class Cfg, int HD> LRA_HD void v2_pass0(bool live, int tf, Regs2<Cfg, HD>& rg, Lds fr) {
+    using T = typename Cfg::real;
+    constexpr int r0 = Regs2<Cfg, HD>::r0, nb0 = Regs2<Cfg, HD>::nb0;
+    LRA_UNROLL
+    for (int e = 0; e < Cfg::R; ++e) rg.v[e] = live ? mk<T>(rg.raw[e].x * rg.win2[e].x, rg.raw[e].y * rg.win2[e].y) : mk<T>((T)0, (T)0);
+    LRA_UNROLL
+    for (int i = 0; i < nb0; ++i) Dft<r0, T>::run(rg.v + i * r0);
+    pass_write<Cfg, 0>(rg.v, fr, tf);
+}
+
+// phase: inputs of the last pass for butterflies tf (v[0 .. rl)) and its mirror (v[rl .. 2 rl))
+template <class Cfg, int HD> LRA_HD void v2_last_read(Regs2<Cfg, HD>& rg, Lds fr, int tf) {
+    using C = typename Cfg::cplx;
+    constexpr int p = Cfg::P - 1, lr = Cfg::logr(p), r = 1 << lr, sin = Cfg::M >> lr;
+    const int bA = Cfg::phys(tf) * (int)sizeof(C);
+    const int bB = Cfg::phys(v2_mirror_bfly<Cfg>(tf)) * (int)sizeof(C);
+    LRA_UNROLL
+    for (int j = 0; j < r; ++j) {
+        rg.v[j] = lds_ld<C>(fr, bA + j * pstride<Cfg>(sin) * (int)sizeof(C));
+        rg.v[r + j] = lds_ld<C>(fr, bB + j * pstride<Cfg>(sin) * (int)sizeof(C));
+    }
+}
+
+template <class C> LRA_HD C v2_sel(bool c, C a, C b) { return c ? a : b; }
+
+// staged complex epilogue (v2_store_row below): 16-byte pieces, and where a row starts relative to them
+template <class T> struct alignas(16) V4 {
+    T a, b, c, d;
+};
+template <class Cfg> LRA_HD int v2_row_shift(const StftArgs<typename Cfg::real>& a, int clip, int frame) {
+    const long long row = ((long long)clip * a.n_frames + frame) * (Cfg::M + 1);
+    return (int)(reinterpret_cast<size_t>(a.D + row) & (2 * sizeof(typename Cfg::real)));  // 0 or sizeof(cplx): the row starts on / half-way into a 16-byte piece
+}
+
+// phase: last-pass butterflies, Hermitian split in registers, epilogue (complex spectrum or |X|^power) to HBM
+template <class Cfg, int HD, int MODE, int PM, bool STAGED>
+LRA_HD void v2_last_split_store(const StftArgs<typename Cfg::real>& a, int clip, int frame, bool valid, int tf, Regs2<Cfg, HD>& rg, Lds stage) {
+    using T = typename Cfg::real;
+    using C = typename Cfg::cplx;
+    constexpr int p = Cfg::P - 1, r = 1 << Cfg::logr(p), s = 2 * Cfg::TF, M = Cfg::M;
+    static_assert(r * s == M, "last pass: r butterfly outputs s apart");
+    pass_twiddle_dft_reg<Cfg, p>(rg.v, rg.treg);
+    const C* A = rg.v;       // A[j] = Z[tf + j s]          (lane 0: Z[j s])
+    const C* B = rg.v + r;   // B[j] = Z[(s - tf) + j s]    (lane 0: Z[s/2 + j s])
+    const bool l0 = tf == 0;
+    const int tfh = v2_tf_hi<Cfg>(tf);
+    const long long row = ((long long)clip * a.n_frames + frame) * (M + 1);
+    C* __restrict__ const D = MODE == OUT_COMPLEX ? a.D + row : nullptr;
+    T* __restrict__ const S = MODE == OUT_POWER ? a.S + row : nullptr;
+    const int sh = (MODE == OUT_COMPLEX && STAGED) ? v2_row_shift<Cfg>(a, clip, frame) : 0;
+    LRA_UNROLL
+    for (int q = 0; q < r; ++q) {
+        // pair slot q.  Lanes 1..: (A[q], B[r-1-q]) = (Z[k], Z[M-k]), k = tf + q s.  Lane 0: q < r/2: (A[q], A[r-q]), k = q s;
+        // q >= r/2: (B[q - r/2], B[3r/2 - 1 - q]), k = s/2 + (q - r/2) s; slot 0 of lane 0 is the DC / Nyquist pair.
+        const C zk = q >= r / 2 ? v2_sel(l0, B[q - r / 2], A[q]) : A[q];
+        C zm;
+        if (q == 0) zm = B[r - 1];
+        else if (q < r / 2) zm = v2_sel(l0, A[r - q], B[r - 1 - q]);
+        else zm = v2_sel(l0, B[3 * r / 2 - 1 - q], B[r - 1 - q]);
+        C xk, xm;
+        split_pair<T>(zk, zm, rg.twr[q], xk, xm);
+        if (q == 0) {
+            const C z0 = A[0];  // Z is pre-halved (see split_pair)
+            const C dc = mk<T>((T)2 * (z0.x + z0.y), (T)0), ny = mk<T>((T)2 * (z0.x - z0.y), (T)0);
+            xk = v2_sel(l0, dc, xk);
+            xm = v2_sel(l0, ny, xm);
+            if (l0 && valid && a.nonfinite_flag && !(std::fabs(dc.x) <= std::numeric_limits<T>::max())) LRA_ATOMIC_OR(a.nonfinite_flag, 1u);
+        }
+        const int k = (q < r / 2 ? tf : tfh) + q * s;
+        if (MODE == OUT_COMPLEX && STAGED) {
+            // the row goes to LDS in bin order (the frame area is free: every Z is in registers), shifted so that LDS and
+            // global addresses agree modulo 16; v2_store_row then writes it as aligned 16-byte pieces.  Of the two bins that
+            // a row of 1025 has in excess of whole 16-byte pieces one is stored here: bin 0 or bin M, both lane 0's slot 0.
+            lds_st<C>(stage, sh + k * (int)sizeof(C), xk);
+            lds_st<C>(stage, sh + (M - k) * (int)sizeof(C), xm);
+            if (q == 0 && l0 && valid) D[sh ? 0 : M] = sh ? xk : xm;
+        } else if (MODE == OUT_COMPLEX) {
+#if LRA_ABLATE == 1
+            if (valid && xk.x == (T)12345.678) { stream_store(&D[k], xk); stream_store(&D[M - k], xm); }
+#else
+            if (valid) { stream_store(&D[k], xk); stream_store(&D[M - k], xm); }
+#endif
+        } else {
+            const T pk = spec_power<T, PM>(xk, a.power), pm = spec_power<T, PM>(xm, a.power);
+            if (valid) { S[k] = pk; S[M - k] = pm; }
+        }
+    }
+    // X[M/2] = conj(Z[M/2]) (Z pre-halved): lane 0's A[r/2]
+    const C zmid = A[r / 2];
+    const C xmid = mk<T>((T)2 * zmid.x, (T)-2 * zmid.y);
+    if (MODE == OUT_COMPLEX && STAGED) {
+        if (l0) lds_st<C>(stage, sh + (M / 2) * (int)sizeof(C), xmid);
+    } else if (l0 && valid) {
+        if (MODE == OUT_COMPLEX) D[M / 2] = xmid;
+        else S[M / 2] = spec_power<T, PM>(xmid, a.power);
+    }
+}
+
+// Staged complex epilogue, second half: the row sits in LDS (v2_last_split_store) and leaves as whole 16-byte pieces:
+// 8 M bytes = M / (2 TF) store instructions of TF x 16 contiguous bytes each, starting at the row's first 16-byte
+// boundary.  Measured on the bare store stream (scripts/storepat2.hip): 8-byte pieces in butterfly order 5.0 TB/s,
+// aligned 16-byte pieces 5.4, and only these take non-temporal stores and the XCD-aware workgroup map well (6.2).
+template <class Cfg> LRA_HD void v2_store_row(const StftArgs<typename Cfg::real>& a, int clip, int frame, bool valid, int tf, Lds stage) {
+    using T = typename Cfg::real;
+    using C = typename Cfg::cplx;
+    constexpr int M = Cfg::M, PIECES = M / (2 * Cfg::TF);
+    static_assert(sizeof(T) == 4, "16-byte pieces of complex64");
+    if (!valid) return;
+    const long long row = ((long long)clip * a.n_frames + frame) * (M + 1);
+    const int sh = v2_row_shift<Cfg>(a, clip, frame);
+    char* __restrict__ const g = reinterpret_cast<char*>(a.D + row) + sh + 16 * tf;  // first aligned piece of this thread
+    V4<T> w[PIECES];
+    LRA_UNROLL
+    for (int c = 0; c < PIECES; ++c) w[c] = lds_ld<V4<T>>(stage, 2 * sh + c * 16 * Cfg::TF + 16 * tf);
+    LRA_UNROLL
+    for (int c = 0; c < PIECES; ++c) {
+#if LRA_ABLATE == 1  // experiment: everything but the spectrum stores
+        if (w[c].a != (T)12345.678) continue;
+#endif
+        stream_store16(reinterpret_cast<V4<T>*>(g + c * 16 * Cfg::TF), w[c]);
+    }
+}
+
+// bytes of LDS one frame slot needs: the frame area only
+template <class Cfg> constexpr int stft2_slot_bytes() { return Cfg::FRAME_BYTES; }
+
+// One workgroup = FPB frame slots, slot s transforms frames f_first + s iters + it, it = 0 .. iters-1 (as stft_block).
+template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2(const StftArgs<typename Cfg::real>& a_in, const int blk, Lds lds) {
+    static_assert(v2_cfg_ok<Cfg>(), "configuration has no mirrored last pass");
+    static_assert(MODE == OUT_COMPLEX || MODE == OUT_POWER, "epilogues of the second-generation kernel");
+    StftArgs<typename Cfg::real> a = a_in;
+    using RG = Regs2<Cfg, HD>;
+    const int clip = blk / a.wg_per_clip;
+    const int f_first = (blk % a.wg_per_clip) * a.frames_per_wg;
+    const int iters = a.frames_per_wg / Cfg::FPB;
+    constexpr int SB = stft2_slot_bytes<Cfg>();
+    // Complex epilogue form.  0 (product): 8-byte stores straight from the butterfly registers.  1 (experiment): the row is
+    // staged in LDS and leaves as aligned 16-byte pieces (v2_store_row).  On the bare store stream aligned pieces are up to
+    // 6 % faster, but a kernel with 12 resident waves per CU is bound by the bytes it keeps in flight, not by the piece
+    // size: measured 0.66 ms direct vs 0.72-0.74 ms staged (with or without non-temporal stores) for the 256 x 30 s batch,
+    // the staging round trip costing more LDS time than the wider stores save (profiles/r02_store_stream.md).
+#ifndef LRA_V2_STAGED
+#define LRA_V2_STAGED 0
+#endif
+    constexpr bool STAGED = MODE == OUT_COMPLEX && LRA_V2_STAGED && sizeof(typename Cfg::real) == 4 && (Cfg::M + 3) * (int)sizeof(typename Cfg::cplx) <= SB;
+    LRA_REGS(RG, rg, Cfg::NT);
+    LRA_PHASE(Cfg::NT, tid) {
+        const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
+        v2_hoist<Cfg, HD>(LRA_R(rg), tf, a.win, a.tw, a.twr);
+        v2_fill<Cfg, HD>(a, clip, f_first + slot * iters, tf, LRA_R(rg));
+    } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+    for (int it = 0; it < iters; ++it) {
+        if (f_first + it >= a.n_frames) break;  // slot 0 has the smallest frame index: uniform exit
+        LRA_PHASE(Cfg::NT, tid) {
+            const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
+            RG& r = LRA_R(rg);
+            if (it > 0) v2_shift<Cfg, HD>(r);                                       // consumes the pairs loaded during the previous frame
+            if (it + 1 < iters) v2_issue_loads<Cfg, HD>(a, clip, frame + 1, tf, r);  // ... and starts the next batch, BEFORE this frame's stores
+            v2_pass0<Cfg, HD>(frame < a.n_frames, tf, r, lds_sub(lds, slot * SB));
+        } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+#define LRA_MID_PASS2(p)                                                                                                  \
+        if (Cfg::P - 1 > p) {                                                                                             \
+            LRA_PHASE(Cfg::NT, tid) {                                                                                     \
+                pass_read<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(rg).v, lds_sub(lds, slot_of<Cfg>(tid) * SB), lane_of<Cfg>(tid)); \
+            } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)                                                                          \
+            LRA_PHASE(Cfg::NT, tid) {                                                                                     \
+                pass_twiddle_dft_reg<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(rg).v, LRA_R(rg).treg);                             \
+                pass_write<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(rg).v, lds_sub(lds, slot_of<Cfg>(tid) * SB), lane_of<Cfg>(tid)); \
+            } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)                                                                          \
+        }
+        LRA_MID_PASS2(1)
+        LRA_MID_PASS2(2)
+#undef LRA_MID_PASS2
+        LRA_PHASE(Cfg::NT, tid) {
+            v2_last_read<Cfg, HD>(LRA_R(rg), lds_sub(lds, slot_of<Cfg>(tid) * SB), lane_of<Cfg>(tid));
+        } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+        LRA_PHASE(Cfg::NT, tid) {
+            const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
+            v2_last_split_store<Cfg, HD, MODE, PM, STAGED>(a, clip, frame, frame < a.n_frames, tf, LRA_R(rg), lds_sub(lds, slot * SB));
+        } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+        if (STAGED) {
+            LRA_PHASE(Cfg::NT, tid) {
+                const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
+                v2_store_row<Cfg>(a, clip, frame, frame < a.n_frames, tf, lds_sub(lds, slot * SB));
+            } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+        }
+    }
+}
+
+}  // namespace lra

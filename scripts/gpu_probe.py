@@ -83,6 +83,32 @@ elif what == "remap":
             msi = min(timeit(lambda: ctx.istft_exec(iplan, D.data_ptr(), batch, T * 1025, 1025, T, wss.data_ptr(), yrec.data_ptr(), n, n)) for _ in range(3))
             print(f"{os.environ.get('LIBROSA_AMD_LIBRARY', 'product')}: remap {remap} iters {iters:3d}: stft {ms:.3f} ms ({batch * T * 10248 / ms / 1e6:5.0f} GB/s)   mel {msm:.3f} ms ({batch * T / msm / 1e3:.1f} Mframes/s)   "
                   f"istft {msi:.3f} ms ({batch * T * 10248 / msi / 1e6:5.0f} GB/s)", flush=True)
+elif what == "v2":
+    # second-generation forward kernel on / off x XCD map x frames per slot (run once per library build)
+    ctx.set_option("autotune", 0)
+    ctx.set_option("variant", 0)
+    Sp = torch.empty((batch, T, 1025), dtype=torch.float32, device=dev)
+    for v2 in (0, 1):
+        ctx.set_option("v2", v2)
+        for remap in (0, 1):
+            ctx.set_option("xcd_remap", remap)
+            for iters in (0, 41, 54, 81, 108, 162, 324):
+                ctx.set_option("stft_iters", iters)
+                ms = min(timeit(lambda: ctx.stft_exec(plan, y.data_ptr(), batch, n, n, D.data_ptr())) for _ in range(3))
+                msp = min(timeit(lambda: ctx.spectrogram_exec(plan, y.data_ptr(), batch, n, n, 2.0, Sp.data_ptr())) for _ in range(3))
+                print(f"{os.environ.get('LIBROSA_AMD_LIBRARY', 'product')}: v2 {v2} remap {remap} iters {iters:3d}: stft {ms:.3f} ms ({batch * T * 10248 / ms / 1e6:5.0f} GB/s = {batch * T * 10248 / ms / 8e7:4.1f} %)   "
+                      f"power {msp:.3f} ms ({batch * T * 6148 / msp / 1e6:5.0f} GB/s)", flush=True)
+elif what == "v2b":
+    # second-generation kernel only: XCD map x frames per slot (store-form / ablation variants are separate builds)
+    ctx.set_option("autotune", 0)
+    ctx.set_option("variant", 0)
+    ctx.set_option("v2", 1)
+    for remap in (0, 1):
+        ctx.set_option("xcd_remap", remap)
+        for iters in (0, 54, 81, 108, 162, 324):
+            ctx.set_option("stft_iters", iters)
+            ms = min(timeit(lambda: ctx.stft_exec(plan, y.data_ptr(), batch, n, n, D.data_ptr())) for _ in range(3))
+            print(f"{os.environ.get('LIBROSA_AMD_LIBRARY', 'product')}: remap {remap} iters {iters:3d}: stft {ms:.3f} ms ({batch * T * 10248 / ms / 1e6:5.0f} GB/s = {batch * T * 10248 / ms / 8e7:4.1f} %)", flush=True)
 elif what == "survey":
     # other common configurations: ms and algorithmic GB/s for stft / melspectrogram / istft
     ctx.set_option("variant", -1)
@@ -111,13 +137,14 @@ elif what == "survey":
               f"istft {mi:7.3f} ms ({by / mi / 1e6:6.0f} GB/s)", flush=True)
         del Dn, Mn, yr
 elif what == "occupancy":
-    for variant in (0, 4):
-        ctx.set_option("variant", variant)
-        ctx.set_option("stft_iters", 32)
-        for pad_kb in (0, 4, 8, 12, 16, 24, 36, 64):
-            ctx.set_option("lds_pad", pad_kb * 1024)
-            ms = timeit(lambda: ctx.stft_exec(plan, y.data_ptr(), batch, n, n, D.data_ptr()))
-            print(f"variant {variant} lds_pad {pad_kb:3d} KB: stft {ms:.3f} ms ({batch * T / ms / 1e3:.1f} Mframes/s)", flush=True)
+    # stft kernel time vs resident waves per CU (one wave64 per workgroup, 17 KB of LDS per slot + pad); run once per (ablation) build
+    ctx.set_option("autotune", 0)
+    ctx.set_option("variant", 0)
+    for waves in (9, 8, 6, 4, 3, 2, 1):
+        pad = max(0, int(160 * 1024 / waves) - 17 * 1024 - 512) & ~255 if waves < 9 else 0
+        ctx.set_option("lds_pad", pad)
+        ms = min(timeit(lambda: ctx.stft_exec(plan, y.data_ptr(), batch, n, n, D.data_ptr()), 5) for _ in range(2))
+        print(f"{os.environ.get('LIBROSA_AMD_LIBRARY', 'product')}: {waves} waves/CU (lds_pad {pad // 1024:3d} KB): stft {ms:.3f} ms  -> {ms * 1e-3 * 2.2e9 * 256 * waves / (batch * T):7.0f} cycles per frame per wave @2.2GHz", flush=True)
     ctx.set_option("lds_pad", 0)
 elif what == "variant1":
     yh = O.config_input(1, n=44100)

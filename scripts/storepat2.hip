@@ -27,7 +27,7 @@ template <bool NT, class V> __device__ __forceinline__ void st(V* p, V v) {
     else *p = v;
 }
 
-template <int MODE, bool NT, bool READ> __global__ __launch_bounds__(256) void k(char* __restrict__ out, const float* __restrict__ in, int rows_per_clip, int iters, int n_clips, int xcd_remap) {
+template <int MODE, bool NT, bool READ> __global__ __launch_bounds__(256) void k(char* __restrict__ out, const float* __restrict__ in, int rows_per_clip, int iters, int n_clips, int xcd_remap, int delay) {
     extern __shared__ char pad_lds[];
     const int W = blockDim.x / 64, wave = threadIdx.x / 64, lane = threadIdx.x % 64;
     int b = blockIdx.x;
@@ -92,6 +92,8 @@ template <int MODE, bool NT, bool READ> __global__ __launch_bounds__(256) void k
             for (int c = 0; c < 8; ++c) nx[c] = src[c * 64];
         }
         v.x += cur[0] + cur[7];
+        // stand-in for the FFT of the frame: `delay` dependent FMAs (~4 cycles each for a lone wave)
+        for (int d = 0; d < delay; ++d) v.y = __builtin_fmaf(v.y, 1.0000001f, 1e-9f);
         char* rb = out + ((size_t)clip * rows_per_clip + row) * ROWB;
         f2* rp = reinterpret_cast<f2*>(rb);
         if (MODE == 0) {
@@ -117,7 +119,7 @@ template <int MODE, bool NT, bool READ> __global__ __launch_bounds__(256) void k
 }
 
 struct Cfg {
-    int mode, W, iters, lds_pad, remap, nt, read;
+    int mode, W, iters, lds_pad, remap, nt, read, delay;
 };
 
 template <int MODE, bool NT, bool READ> float run_t(char* out, const float* in, const Cfg& c, int batch, int rows) {
@@ -134,10 +136,10 @@ template <int MODE, bool NT, bool READ> float run_t(char* out, const float* in, 
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k<MODE, NT, READ>), dim3(grid), dim3(64 * c.W), c.lds_pad, 0, out, in, rows, c.iters, batch, c.remap);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((k<MODE, NT, READ>), dim3(grid), dim3(64 * c.W), c.lds_pad, 0, out, in, rows, c.iters, batch, c.remap, c.delay);
     hipEventRecord(e0);
     const int reps = 8;
-    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL((k<MODE, NT, READ>), dim3(grid), dim3(64 * c.W), c.lds_pad, 0, out, in, rows, c.iters, batch, c.remap);
+    for (int w = 0; w < reps; ++w) hipLaunchKernelGGL((k<MODE, NT, READ>), dim3(grid), dim3(64 * c.W), c.lds_pad, 0, out, in, rows, c.iters, batch, c.remap, c.delay);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -163,7 +165,7 @@ float run(char* out, const float* in, const Cfg& c, int batch, int rows) {
     }
 }
 
-int main() {
+int main(int argc, char** argv) {
     const int batch = 256, rows = 1292;
     char* out;
     float* in;
@@ -175,9 +177,21 @@ int main() {
     auto report = [&](const Cfg& c) {
         const float ms = run(out, in, c, batch, rows);
         const double by = c.read ? bytes_rw : bytes_w;
-        printf("%-9s W=%d iters=%3d ldspad=%3dK remap=%d nt=%d read=%d : %.4f ms  %.0f GB/s\n", names[c.mode], c.W, c.iters, c.lds_pad / 1024, c.remap, c.nt, c.read, ms, by / ms / 1e6);
+        printf("%-9s W=%d iters=%3d ldspad=%3dK remap=%d nt=%d read=%d delay=%4d : %.4f ms  %.0f GB/s\n", names[c.mode], c.W, c.iters, c.lds_pad / 1024, c.remap, c.nt, c.read, c.delay, ms, by / ms / 1e6);
         fflush(stdout);
     };
+    if (argc > 1) {  // "conc": the two store forms against resident waves per CU, rows per strip and a little compute between rows
+        for (int mode : {0, 3})
+            for (int nt : {0, 1}) {
+                if (mode == 0 && nt) continue;
+                for (int remap : {0, 1})
+                    for (int wpc : {8, 12, 16, 24, 32})
+                        for (int iters : {81, 162}) report({mode, 1, iters, wpc >= 32 ? 0 : ((160 * 1024 / wpc) & ~255), remap, nt, 1, 0});
+            }
+        for (int mode : {0, 3})
+            for (int delay : {10, 30, 60, 100}) report({mode, 1, 108, (160 * 1024 / 12) & ~255, 1, mode == 3, 1, delay});
+        return 0;
+    }
     // 1. decomposition x rows per strip, default residency
     for (int read : {1, 0})
         for (int mode : {0, 3, 4}) {

@@ -22,8 +22,9 @@ template <class T> struct StftSim {
     long long blocks;
     long long* diag;
     const T* dense_basis = nullptr;  // mode 3: dense [n_mels][M+1]
+    bool use_v2 = true;
     template <class Cfg, int MODE> void run(int iters, int shared_bytes) {
-        std::vector<cx<T>> tw(Cfg::TW_TOTAL), twr(Cfg::M / 2 + 1);
+        std::vector<cx<T>> tw(Cfg::TW_TOTAL), twr(split_tw_count<Cfg>());
         build_pass_twiddles<Cfg>(tw.data());
         build_split_twiddles<Cfg>(twr.data());
         a.tw = tw.data();
@@ -42,7 +43,24 @@ template <class T> struct StftSim {
             // same kernel selection as StftLaunch::launch (lra_api.hip): row-aligned hops take the fast ring path
             bool ra = false;
             if constexpr (sizeof(typename Cfg::real) == 4) ra = ring_rows_aligned<Cfg>(a.hop) && !std::getenv("LRA_SIM_NO_RA");
-            if (ra) {
+            // second-generation kernel body (lra_kernels2.h), same selection as StftLaunch::launch
+            bool v2 = false;
+            if constexpr (v2_cfg_ok<Cfg>() && (MODE == OUT_COMPLEX || MODE == OUT_POWER)) {
+                const int hd = use_v2 ? v2_hop_divisor<Cfg>(a.hop) : 0;
+                if (hd) {
+                    v2 = true;
+                    st.resize(Cfg::FPB * stft2_slot_bytes<Cfg>());
+#define SIM_V2(HD)                                                                                             \
+    if (a.power_mode == POW_TWO) stft_block2<Cfg, HD, MODE, POW_TWO>(a, (int)blk, lds);                        \
+    else if (a.power_mode == POW_ONE) stft_block2<Cfg, HD, MODE, POW_ONE>(a, (int)blk, lds);                   \
+    else stft_block2<Cfg, HD, MODE, POW_GENERAL>(a, (int)blk, lds);
+                    if (hd == 1) { SIM_V2(1) } else if (hd == 2) { SIM_V2(2) } else if (hd == 4) { SIM_V2(4) } else { SIM_V2(8) }
+#undef SIM_V2
+                }
+            }
+            diag[10] = v2;
+            if (v2) {
+            } else if (ra) {
                 if constexpr (sizeof(typename Cfg::real) == 4) {
                     if (a.power_mode == POW_TWO) stft_block<Cfg, MODE, POW_TWO, true>(a, (int)blk, lds);
                     else if (a.power_mode == POW_ONE) stft_block<Cfg, MODE, POW_ONE, true>(a, (int)blk, lds);
@@ -88,7 +106,7 @@ template <class T> struct IstftSim {
     long long* diag;
     int strip_groups;
     template <class Cfg> void operator()() {
-        std::vector<cx<T>> tw(Cfg::TW_TOTAL), twr(Cfg::M / 2 + 1);
+        std::vector<cx<T>> tw(Cfg::TW_TOTAL), twr(split_tw_count<Cfg>());
         build_pass_twiddles<Cfg>(tw.data());
         build_split_twiddles<Cfg>(twr.data());
         a.tw = tw.data();
@@ -137,6 +155,7 @@ int run_stft(int n_fft, int mode, const T* y, long long n, long long batch, int 
     s.a.power_mode = power_mode; s.a.power = (T)power;
     s.a.mel_c0 = mel_c0; s.a.mel_len = mel_len; s.a.mel_off = mel_off; s.a.mel_val = mel_val; s.a.n_mels = n_mels;
     s.mode = mode; s.blocks = batch; s.diag = diag; s.dense_basis = dense_basis;
+    s.use_v2 = !std::getenv("LRA_SIM_NO_V2");
     for (int i = 0; i < 12; ++i) diag[i] = 0;
     return dispatch_logm<T>(log2_exact(n_fft) - 1, variant, s) ? 0 : 1;
 }

@@ -206,7 +206,8 @@ def test_autotune_picks_a_variant_and_stays_correct(L):
     yy = L.istft(D, hop_length=512, length=yh.shape[-1])
     torch.cuda.synchronize()
     plan = ctx.stft_plan(2048, 512, window, True, "constant", np.float32)
-    assert ctx.tuned_variant(plan, 0) in (0, 4) and ctx.tuned_variant(plan, 2) in (0, 4)
+    # (the complex-out epilogue runs the second-generation kernel, which has no variants: nothing to tune there)
+    assert ctx.tuned_variant(plan, 0) == -1 and ctx.tuned_variant(plan, 2) in (0, 4)
     k = 5  # spot-check a clip against the oracle
     assert _stft_close(D[k].cpu().numpy(), O.stft(yh[k], n_fft=2048, hop_length=512))
     assert _mel_close(M[k].cpu().numpy(), O.melspectrogram(y=yh[k], n_fft=2048, hop_length=512))

@@ -60,7 +60,8 @@ def _tol(dtype):
         (8192, 2048, False, "constant", 1, np.float64, 30000, 0),
     ],
 )
-def test_stft_body(n_fft, hop, center, pad_mode, iters, dtype, n, variant):
+def test_stft_body(n_fft, hop, center, pad_mode, iters, dtype, n, variant, monkeypatch):
+    monkeypatch.setenv("LRA_SIM_NO_V2", "1")  # the first-generation bodies (the second generation has its own cases below)
     rng = np.random.default_rng(n_fft + hop + n)
     y = rng.standard_normal((2, n)).astype(dtype)
     win = O.get_window("hann", n_fft)
@@ -70,6 +71,47 @@ def test_stft_body(n_fft, hop, center, pad_mode, iters, dtype, n, variant):
     assert out.shape == ref.shape and out.dtype == ref.dtype
     assert np.isfinite(out.view(dtype)).all()
     assert np.abs(out - ref).max() <= _tol(dtype) * np.abs(ref).max()
+
+
+@pytest.mark.parametrize(
+    "n_fft,hop,center,pad_mode,iters,n,power",
+    [
+        (2048, 512, True, "constant", 2, 22050, None),
+        (2048, 512, True, "reflect", 7, 30000, None),   # long runs: register ring shifts, edge blocks at both ends
+        (2048, 512, True, "constant", 4, 700, None),    # fewer frames than slots x iters
+        (2048, 512, False, "constant", 3, 9001, None),  # uncentred, odd length
+        (2048, 512, True, "edge", 5, 9001, None),
+        (2048, 1024, True, "reflect", 5, 30000, None),  # HD = 2
+        (2048, 2048, True, "symmetric", 3, 30000, None),  # HD = 1: every pair is new
+        (2048, 256, True, "constant", 6, 9000, None),   # HD = 8
+        (1024, 256, True, "edge", 6, 9000, None),       # two frame slots per wave, radix 8 / 8 / 8
+        (1024, 512, True, "constant", 4, 12000, None),
+        (1024, 128, False, "constant", 5, 5000, None),
+        (4096, 1024, True, "constant", 2, 20000, None),  # two waves per frame: workgroup barriers
+        (4096, 512, True, "reflect", 3, 30000, None),
+        (2048, 512, True, "constant", 3, 9000, 2.0),    # |X|^power epilogues
+        (2048, 512, True, "constant", 3, 9000, 1.0),
+        (1024, 256, True, "reflect", 3, 9000, 1.7),
+    ],
+)
+def test_stft_body_second_generation(n_fft, hop, center, pad_mode, iters, n, power):
+    """lra_kernels2.h: PCM ring in registers, mirrored last pass, split in registers."""
+    rng = np.random.default_rng(n_fft + hop + n)
+    y = rng.standard_normal((2, n)).astype(np.float32)
+    win = O.get_window("hann", n_fft)
+    ref = np.moveaxis(O.stft(y, n_fft=n_fft, hop_length=hop, center=center, pad_mode=pad_mode), -1, -2)
+    if power is None:
+        out, d = H.stft(y, n_fft, hop, win, center=center, pad_mode=pad_mode, iters_per_wg=iters)
+        assert d["v2"] == 1
+        _check_diag(d)
+        assert out.shape == ref.shape and out.dtype == ref.dtype
+        assert np.abs(out - ref).max() <= 2e-6 * np.abs(ref).max()
+    else:
+        out, d = H.stft(y, n_fft, hop, win, center=center, pad_mode=pad_mode, iters_per_wg=iters, mode=1, power=power)
+        assert d["v2"] == 1
+        _check_diag(d)
+        S = np.abs(ref) ** power
+        assert np.abs(out - S).max() <= 4e-6 * S.max()
 
 
 @pytest.mark.parametrize("n_fft,hop,power,n_mels,dtype,variant", [(2048, 512, 2.0, 128, np.float32, 0), (2048, 512, 2.0, 128, np.float32, 1), (2048, 512, 2.0, 128, np.float32, 4), (1024, 256, 1.0, 40, np.float32, 0),
