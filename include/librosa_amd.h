@@ -141,6 +141,26 @@ void lra_istft_plan_destroy(lra_istft_plan* plan);
 int lra_istft_exec(lra_istft_plan* plan, const void* D, int64_t batch, int64_t d_batch_stride, int64_t d_frame_stride, int64_t n_used,
                    const void* wss, void* y, int64_t out_len, int64_t y_stride);
 
+/* ---- decibel scaling: librosa.power_to_db / amplitude_to_db, librosa/core/spectrum.py:1735-1883, 1946-2038 ---- */
+/* Arrays are [batch][per_item] (the shim flattens the reduced axes -- "auto" = the last two -- into per_item).
+ * out_max[b] = max_i |x[b][i]|: the reduction behind ref=np.max and top_db (log_spec.max(axes), :1877-1881). */
+int lra_item_absmax_exec(lra_ctx* ctx, const void* x, int64_t batch, int64_t per_item, int dtype, void* out_max);
+/* out = 10 log10(max(amin, mag)) - 10 log10(max(amin, ref)), floored at its per-item maximum - top_db (:1873-1881).
+ * amplitude != 0: mag = x**2, ref -> ref**2 (amplitude_to_db, :2030-2037; pass amin already squared), else mag = |x|.
+ * ref_items (device, [batch]) overrides ref_scalar; item_max (device, [batch], input domain) is read when use_top_db. */
+int lra_to_db_exec(lra_ctx* ctx, const void* x, void* out, int64_t batch, int64_t per_item, int dtype, int amplitude, double amin, double ref_scalar,
+                   const void* ref_items, const void* item_max, int use_top_db, double top_db);
+/* db_to_power: ref * 10**(0.1 x) (:1925); amplitude != 0: db_to_amplitude = db_to_power(x, ref**2)**0.5 (:2082). */
+int lra_from_db_exec(lra_ctx* ctx, const void* x, void* out, int64_t count, int dtype, int amplitude, double ref);
+
+/* ---- MFCC: librosa.feature.mfcc, librosa/feature/spectral.py:1843-2019 --------------------------------------------- */
+/* out[b][k][t] = lift[k] * sum_m basis[k][m] * f(S[b][m][t]), k < n_out.  basis (device): the rows of
+ * scipy.fft.dct(eye(n_in), axis=0, type, norm) (:2005), n_out rows rounded up to a multiple of 128 with zero rows;
+ * lift (device, [n_out]): 1 + (lifter/2) sin(pi (k+1) / lifter) or ones (:2008-2015).  fuse_db != 0: f is the decibel
+ * scaling of lra_to_db_exec (power domain), so that mfcc(y=...) reads the mel power spectrogram once (:2001). */
+int lra_dct_exec(lra_ctx* ctx, const void* S, void* out, int64_t batch, int n_in, int n_out, int64_t n_frames, int dtype, const void* basis, const void* lift,
+                 int fuse_db, double amin, double ref_scalar, const void* ref_items, const void* item_max, int use_top_db, double top_db);
+
 /* ---- layout helper: dst[b][c][r] = src[b][r][c], elem_bytes in {4, 8, 16} ------------------ */
 int lra_transpose(lra_ctx* ctx, const void* src, void* dst, int64_t batch, int64_t rows, int64_t cols, int elem_bytes);
 

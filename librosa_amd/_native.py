@@ -68,6 +68,10 @@ SIGNATURES = {
     "lra_istft_plan_destroy": (None, [c_void_p]),
     "lra_istft_exec": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64]),
     "lra_transpose": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int]),
+    "lra_item_absmax_exec": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "lra_to_db_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_int, c_double]),
+    "lra_from_db_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_double]),
+    "lra_dct_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_int, c_double, c_double, c_void_p, c_void_p, c_int, c_double]),
 }
 
 _lib = None
@@ -317,6 +321,21 @@ class Context:
 
     def istft_exec(self, plan, d_ptr, batch, d_batch_stride, d_frame_stride, n_used, wss_ptr, y_ptr, out_len, y_stride):
         _check(self.lib.lra_istft_exec(plan, c_void_p(d_ptr), batch, d_batch_stride, d_frame_stride, n_used, c_void_p(wss_ptr), c_void_p(y_ptr), out_len, y_stride))
+
+    def item_absmax_exec(self, x_ptr, batch, per_item, dtype, out_ptr):
+        _check(self.lib.lra_item_absmax_exec(self.handle, c_void_p(x_ptr), batch, per_item, dtype_code(dtype), c_void_p(out_ptr)))
+
+    def to_db_exec(self, x_ptr, out_ptr, batch, per_item, dtype, amplitude, amin, ref_scalar, ref_items_ptr, item_max_ptr, top_db):
+        _check(self.lib.lra_to_db_exec(self.handle, c_void_p(x_ptr), c_void_p(out_ptr), batch, per_item, dtype_code(dtype), int(bool(amplitude)), float(amin), float(ref_scalar),
+                                       c_void_p(ref_items_ptr or None), c_void_p(item_max_ptr or None), int(top_db is not None), float(top_db if top_db is not None else 0.0)))
+
+    def from_db_exec(self, x_ptr, out_ptr, count, dtype, amplitude, ref):
+        _check(self.lib.lra_from_db_exec(self.handle, c_void_p(x_ptr), c_void_p(out_ptr), count, dtype_code(dtype), int(bool(amplitude)), float(ref)))
+
+    def dct_exec(self, s_ptr, out_ptr, batch, n_in, n_out, n_frames, dtype, basis_ptr, lift_ptr, fuse_db=False, amin=1e-10, ref_scalar=1.0, ref_items_ptr=None, item_max_ptr=None, top_db=None):
+        _check(self.lib.lra_dct_exec(self.handle, c_void_p(s_ptr), c_void_p(out_ptr), batch, n_in, n_out, n_frames, dtype_code(dtype), c_void_p(basis_ptr), c_void_p(lift_ptr),
+                                     int(bool(fuse_db)), float(amin), float(ref_scalar), c_void_p(ref_items_ptr or None), c_void_p(item_max_ptr or None), int(top_db is not None),
+                                     float(top_db if top_db is not None else 0.0)))
 
     def transpose(self, src_ptr, dst_ptr, batch, rows, cols, elem_bytes):
         _check(self.lib.lra_transpose(self.handle, c_void_p(src_ptr), c_void_p(dst_ptr), batch, rows, cols, elem_bytes))

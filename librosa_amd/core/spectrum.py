@@ -22,7 +22,7 @@ from ..util import utils as util
 from ..util.exceptions import ParameterError
 from ..util.utils import is_torch_tensor
 
-__all__ = ["stft", "istft", "_spectrogram"]
+__all__ = ["stft", "istft", "_spectrogram", "power_to_db", "amplitude_to_db", "db_to_power", "db_to_amplitude"]
 
 # np.pad modes that do not depend only on edge values: rejected exactly as the reference does
 _REJECTED_PAD_MODES = ("wrap", "maximum", "mean", "median", "minimum")
@@ -96,8 +96,11 @@ def _finite_check_covers_input(n, n_fft, hop, center):
     return covered_hi >= (n + (n_fft // 2 if center else 0))
 
 
-def _run_stft_family(kind, y, *, n_fft, hop_length, win_length, window, center, pad_mode, dtype=None, power=1.0, mel_basis=None, check_finite=True):
-    """kind in {"stft", "power", "mel"}.  Returns the result laid out like the reference's."""
+def _run_stft_family(kind, y, *, n_fft, hop_length, win_length, window, center, pad_mode, dtype=None, power=1.0, mel_basis=None, check_finite=True, post=None):
+    """kind in {"stft", "power", "mel"}.  Returns the result laid out like the reference's.
+
+    ``post(sess, mel_ptr, batch, n_mels, n_frames, real) -> (handle, rows)`` (mel only) chains further device work on the mel
+    spectrogram before anything is downloaded (``feature.mfcc``); the result then has ``rows`` rows instead of ``n_mels``."""
     need_device_check = _validate_audio(y, check_finite)
     y, hop, fft_window, center, pad_mode = _prepare_stft(y, n_fft, hop_length, win_length, window, center, pad_mode)
     in_dtype = _arrays.numpy_dtype_of(y)
@@ -138,6 +141,8 @@ def _run_stft_family(kind, y, *, n_fft, hop_length, win_length, window, center, 
             mel_plan = ctx.mel_plan(np.ascontiguousarray(mel_basis, dtype=real))
             ptr, handle = sess.output((batch, n_mels, n_frames), real)
             ctx.melspectrogram_exec(plan, mel_plan, y_ptr, batch, n, y_stride, power, ptr)
+            if post is not None:
+                handle, n_mels = post(sess, ptr, batch, n_mels, n_frames, real)
         if need_device_check and ctx.nonfinite_read():
             # the flag says "some frame's DC bin is not finite"; finite samples of enormous magnitude overflow it
             # too, so the samples themselves decide (util.valid_audio tests np.isfinite(y), util/utils.py:305)
@@ -328,3 +333,153 @@ def _transpose_batched(ctx, src_ptr, dst_ptr, batch, rows, cols, elem_bytes):
         nb = min(step, batch - b0)
         off = b0 * rows * cols * elem_bytes
         ctx.transpose(src_ptr + off, dst_ptr + off, nb, rows, cols, elem_bytes)
+
+
+# ---------------------------------------------------------------------------------------------------
+# decibel scaling: librosa/core/spectrum.py:1735-1883, 1898-1925, 1946-2038, 2054-2082
+# ---------------------------------------------------------------------------------------------------
+def _db_axes(ndim, axes):
+    """``axes="auto"`` -> the last two axes (``core/spectrum.py:1853-1859``); returns a sorted tuple of non-negative axes (empty: reduce nothing ... of a 0-d input)."""
+    if isinstance(axes, str):
+        if axes != "auto":
+            raise ParameterError(f"axes={axes!r} must be 'auto', None, an int or a tuple of ints")
+        axes = (-2, -1) if ndim >= 2 else ((-1,) if ndim == 1 else None)
+    if axes is None:
+        return tuple(range(ndim))
+    if isinstance(axes, (int, np.integer)):
+        axes = (int(axes),)
+    out = sorted({int(a) % ndim for a in axes}) if ndim else []
+    return tuple(out)
+
+
+def _as_items(x, red_axes):
+    """Move the reduced axes last and flatten: (array of shape (batch, per_item), restore) with restore(flat) -> original layout."""
+    ndim = x.ndim
+    keep = [a for a in range(ndim) if a not in red_axes]
+    perm = keep + list(red_axes)
+    moved = perm != list(range(ndim))
+    xp = (x.permute(*perm) if is_torch_tensor(x) else np.transpose(x, perm)) if moved else x
+    shape_p = tuple(xp.shape)
+    batch = int(np.prod([shape_p[i] for i in range(len(keep))], dtype=np.int64)) if keep else 1
+    per_item = int(np.prod(shape_p[len(keep):], dtype=np.int64)) if red_axes else 1
+
+    def restore(flat):
+        r = flat.reshape(shape_p)
+        if moved:
+            inv = np.argsort(perm)
+            r = r.permute(*[int(i) for i in inv]) if is_torch_tensor(r) else np.transpose(r, inv)
+        return r
+
+    return xp, batch, per_item, restore
+
+
+def _magnitude_and_dtype(S, name):
+    """abs() of complex input with the reference's warning; the real dtype the device computes in (f32 stays f32, everything else f64)."""
+    if is_torch_tensor(S):
+        if S.is_complex():
+            warnings.warn(f"{name} was called on complex input so phase information will be discarded. To suppress this warning, "
+                          f"call {name}(np.abs(D){'**2' if name == 'power_to_db' else ''}) instead.", stacklevel=3)
+            S = S.abs()
+        real = np.dtype(np.float32) if _arrays.numpy_dtype_of(S) == np.float32 else np.dtype(np.float64)
+        return S, real
+    S = np.asarray(S)
+    if np.issubdtype(S.dtype, np.complexfloating):
+        warnings.warn(f"{name} was called on complex input so phase information will be discarded. To suppress this warning, "
+                      f"call {name}(np.abs(D){'**2' if name == 'power_to_db' else ''}) instead.", stacklevel=3)
+        S = np.abs(S)
+    real = np.dtype(np.float32) if S.dtype == np.float32 else np.dtype(np.float64)
+    return S, real
+
+
+_MAX_CALLABLES = (np.max, np.amax)
+
+
+def _to_db(S, ref, amin, top_db, axes, amplitude, name):
+    if amin <= 0:
+        raise ParameterError("amin must be strictly positive")
+    if top_db is not None and top_db < 0:
+        raise ParameterError("top_db must be non-negative")
+    S, real = _magnitude_and_dtype(S, name)
+    scalar_in = S.ndim == 0
+    red = _db_axes(S.ndim, axes)
+    xp, batch, per_item, restore = _as_items(S, red)
+    if batch * per_item == 0:
+        return restore(xp.to(_arrays.torch_dtype(real)).reshape(batch, per_item) if is_torch_tensor(xp) else np.asarray(xp, dtype=real).reshape(batch, per_item))
+    ref_items_host = None
+    ref_scalar = 1.0
+    device_max_as_ref = False
+    if callable(ref):
+        if any(ref is f for f in _MAX_CALLABLES):
+            device_max_as_ref = True  # the per-item maximum is reduced on the device (the common ref=np.max)
+        else:
+            # any other reduction runs on the host exactly as the reference calls it (core/spectrum.py:1861-1869); device
+            # tensors are copied down for it (a slow path: prefer ref=np.max or a number)
+            host = np.abs(S.detach().cpu().numpy()) if is_torch_tensor(S) else np.abs(S)
+            try:
+                rv = ref(host, axis=(red if S.ndim else None), keepdims=True)
+            except TypeError as exc:
+                raise ParameterError("The provided reference function must support 'axis' and 'keepdims' arguments for proper multichannel processing.") from exc
+            rv = np.broadcast_to(np.asarray(rv), tuple(1 if a in red else S.shape[a] for a in range(S.ndim)))
+            ref_items_host = np.ascontiguousarray(rv, dtype=real).reshape(-1)
+    else:
+        ref_scalar = float(np.abs(ref))
+    sess = _arrays.Session(S if is_torch_tensor(S) else np.empty(0))
+    try:
+        ctx = sess.ctx
+        x_ptr = sess.input_raw(xp.reshape(batch, per_item) if not is_torch_tensor(xp) else xp.reshape(batch, per_item), real)
+        out_ptr, handle = sess.output((batch, per_item), real)
+        max_ptr = None
+        if device_max_as_ref or top_db is not None:
+            max_ptr = sess.scratch(batch * real.itemsize)
+            ctx.item_absmax_exec(x_ptr, batch, per_item, real, max_ptr)
+        ref_ptr = max_ptr if device_max_as_ref else (sess.input_raw(_as_like(sess, ref_items_host), real) if ref_items_host is not None else None)
+        ctx.to_db_exec(x_ptr, out_ptr, batch, per_item, real, amplitude, amin * amin if amplitude else amin, ref_scalar, ref_ptr, max_ptr, top_db)
+        out = sess.result(handle)
+    finally:
+        sess.close()
+    out = restore(out)
+    return out[()] if scalar_in and not is_torch_tensor(out) else out
+
+
+def power_to_db(S, *, ref=1.0, amin=1e-10, top_db=80.0, axes="auto"):
+    """``10 * log10(S / ref)``, numerically stable; drop-in for ``librosa.power_to_db`` (``librosa/core/spectrum.py:1735-1883``).
+
+    ``log_spec = 10 log10(max(amin, S)) - 10 log10(max(amin, ref))`` and, unless ``top_db`` is None,
+    ``max(log_spec, log_spec.max(axes) - top_db)``; with ``axes="auto"`` the maximum (and a callable ``ref``) is taken per
+    item over the last two axes.  One device reduction (the per-item maximum, shared by ``ref=np.max`` and ``top_db``) and one
+    elementwise pass; accepts NumPy arrays (result downloaded) or device tensors."""
+    return _to_db(S, ref, amin, top_db, axes, False, "power_to_db")
+
+
+def amplitude_to_db(S, *, ref=1.0, amin=1e-5, top_db=80.0, axes="auto"):
+    """``power_to_db(S**2, ref=ref**2, amin=amin**2, top_db=top_db)`` as the reference defines it (``core/spectrum.py:1946-2038``)."""
+    return _to_db(S, ref, amin, top_db, axes, True, "amplitude_to_db")
+
+
+def _from_db(S_db, ref, amplitude):
+    x = S_db if is_torch_tensor(S_db) else np.asarray(S_db)
+    scalar_in = x.ndim == 0
+    real = np.dtype(np.float32) if _arrays.numpy_dtype_of(x) == np.float32 else np.dtype(np.float64)
+    count = int(np.prod(x.shape, dtype=np.int64)) if x.ndim else 1
+    if count == 0:
+        return x
+    sess = _arrays.Session(x if is_torch_tensor(x) else np.empty(0))
+    try:
+        x_ptr = sess.input_raw(x.reshape(-1), real)
+        out_ptr, handle = sess.output((count,), real)
+        sess.ctx.from_db_exec(x_ptr, out_ptr, count, real, amplitude, float(ref))
+        out = sess.result(handle)
+    finally:
+        sess.close()
+    out = out.reshape(tuple(x.shape))
+    return out[()] if scalar_in and not is_torch_tensor(out) else out
+
+
+def db_to_power(S_db, *, ref=1.0):
+    """``ref * 10**(S_db / 10)``: inverse of ``power_to_db`` (``librosa/core/spectrum.py:1898-1925``)."""
+    return _from_db(S_db, ref, False)
+
+
+def db_to_amplitude(S_db, *, ref=1.0):
+    """``db_to_power(S_db, ref=ref**2) ** 0.5`` (``librosa/core/spectrum.py:2054-2082``)."""
+    return _from_db(S_db, ref, True)

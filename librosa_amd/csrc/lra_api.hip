@@ -23,6 +23,7 @@
 #define LRA_FUSED_EXTERN  // the fused kernels are instantiated in lra_inst.hip (parallel build), see lra_fused.h
 #include "lra_fused.h"
 #include "lra_mel.h"
+#include "lra_post.h"
 
 using namespace lra;
 
@@ -191,6 +192,12 @@ struct lra_mel_plan {
     int* d_melr_addr = nullptr;
     int melr_zero = 0, melr_mid = 0, melr_pmax = 0;
     bool melr_ok = false;
+    // the same for the second-generation kernel (lra_mel.h layout 1: both runs ascending, extra bin M)
+    void* d_melr2_w = nullptr;
+    void* d_melr2_keep = nullptr;
+    int* d_melr2_addr = nullptr;
+    int melr2_zero = 0, melr2_mid = 0, melr2_pmax = 0;
+    bool melr2_ok = false;
     int* d_run[2] = {nullptr, nullptr};
     int* d_segd[2] = {nullptr, nullptr};
     int nyq[2] = {0, 0};
@@ -239,6 +246,7 @@ template <class T> struct StftLaunch {
     int lds_pad = 0;
     bool xcd_remap = true;
     bool use_v2 = true;
+    bool mel_v2 = false;  // OUT_MELR: the plan's layout-1 tables are bound, run the second-generation kernel
     bool mel_runs = true;
     const lra_mel_plan* mel = nullptr;
     hipStream_t stream = nullptr;
@@ -263,8 +271,8 @@ template <class T> struct StftLaunch {
         // Second-generation kernel (lra_kernels2.h) where it applies: complex / power epilogues, 16 points per thread with
         // a two-butterfly last pass (n_fft 1024 / 2048 / 4096), hop = n_fft / {1, 2, 4, 8}.
         bool v2 = false;
-        if constexpr (v2_cfg_ok<Cfg>() && (MODE == OUT_COMPLEX || MODE == OUT_POWER)) {
-            const int hd = use_v2 ? v2_hop_divisor<Cfg>(a.hop) : 0;
+        if constexpr (v2_cfg_ok<Cfg>() && (MODE == OUT_COMPLEX || MODE == OUT_POWER || MODE == OUT_MELR)) {
+            const int hd = (use_v2 && (MODE != OUT_MELR || mel_v2)) ? v2_hop_divisor<Cfg>(a.hop) : 0;
             if (hd) {
                 v2 = true;
 #define LRA_PICK2(HD)                                                                                        \
@@ -275,12 +283,12 @@ template <class T> struct StftLaunch {
 #undef LRA_PICK2
             }
         }
-        const int lds_probe = v2 ? Cfg::FPB * stft2_slot_bytes<Cfg>() + lds_pad : lds_probe_v1;
+        const int lds_probe = v2 ? Cfg::FPB * stft2_slot_bytes<Cfg>() + shared_bytes + lds_pad : lds_probe_v1;
         // Frames per slot (`iters`).  A slot pays n_fft - hop extra sample loads for its first frame, so long
         // runs are cheap in HBM traffic; but the launch should also end evenly: the grid is sized to a whole
         // number of "waves" of workgroups (CUs x resident workgroups per CU), because a last partial wave
         // leaves most of the chip idle for one workgroup's duration (~15 % of a 0.85 ms launch at 32 frames
-        // per slot on the 256 x 30 s batch).  Among 24..128 frames per slot, take the best fill, then the
+        // per slot on the 256 x 30 s batch).  Among 24..176 frames per slot, take the best fill, then the
         // longest run.
         int iters = iters_opt;
         if (iters <= 0) {
@@ -289,11 +297,13 @@ template <class T> struct StftLaunch {
             const int fpb = Cfg::FPB;
             int best_iters = 0;
             double best_fill = -1.0;
-            for (int cand = 128; cand >= 24; --cand) {
+            for (int cand = 176; cand >= 24; --cand) {
                 const int wgpc = (a.n_frames + fpb * cand - 1) / (fpb * cand);
                 const int it = (a.n_frames + fpb * wgpc - 1) / (fpb * wgpc);  // equal shares
                 const double rounds = (double)(batch * wgpc) / (double)conc;
-                const double fill = rounds / std::ceil(rounds);
+                // a single round that occupies at least 60 % of the slots has no tail to speak of, and long runs beat full
+                // residency there (measured on the 256 x 30 s batch: 162 frames per slot 0.657 ms, 108 0.674, 324 0.674)
+                const double fill = (rounds <= 1.0 && rounds >= 0.6) ? 1.0 : rounds / std::ceil(rounds);
                 if (fill > best_fill + 0.02) { best_fill = fill; best_iters = it; }
             }
             iters = best_iters;
@@ -334,6 +344,23 @@ template <class T> struct StftLaunch {
             // the two-slope mel kernel shares its filter tables across the slots of a larger workgroup
             using MC = typename MelCfgOf<Cfg>::type;
             // first choice: the run-ordered form (no per-lane control flow, no (wA P, wB P) round trip through LDS)
+            if constexpr (v2_cfg_ok<MC>()) {
+                if (mel && mel->melr2_ok && mel_runs && use_v2 && melr_fits<MC>() && v2_hop_divisor<MC>(a.hop) > 0) {
+                    const int shared_r = melr_shared_bytes<MC>(a.n_mels, mel->melr2_pmax);
+                    if (MC::FPB * stft2_slot_bytes<MC>() + shared_r <= 160 * 1024) {
+                        a.melr_w = (const T*)mel->d_melr2_w;
+                        a.melr_keep = (const T*)mel->d_melr2_keep;
+                        a.melr_addr = mel->d_melr2_addr;
+                        a.melr_zero = mel->melr2_zero;
+                        a.melr_mid = mel->melr2_mid;
+                        a.melr_pmax = mel->melr2_pmax;
+                        mel_v2 = true;
+                        mel_tile_opt = 1;
+                        launch<MC, OUT_MELR>(shared_r);
+                        return;
+                    }
+                }
+            }
             if (mel && mel->melr_ok && mel_runs && melr_fits<MC>() && MC::R == 16) {
                 const int shared_r = melr_shared_bytes<MC>(a.n_mels, mel->melr_pmax);
                 // no LDS staging tile by default: the kernel keeps the last 8 frames of each band in registers and stores them as one burst
@@ -868,6 +895,55 @@ int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_s
 
 }  // namespace
 
+// launch helpers of the decibel / MFCC entry points (lra_post.h)
+namespace {
+int post_chunks(long long batch, long long per_item, int n_cu) {
+    // enough workgroups to fill the chip even for one big item, at least ~16 K elements each
+    long long want = (8LL * n_cu + batch - 1) / (batch > 0 ? batch : 1);
+    const long long most = (per_item + 16383) / 16384;
+    if (want > most) want = most;
+    return (int)(want < 1 ? 1 : want);
+}
+template <class T>
+int to_db_run(lra_ctx* ctx, const void* x, void* out, long long batch, long long per_item, int amplitude, double amin, double ref_scalar, const void* ref_items, const void* item_max,
+              int use_top_db, double top_db) {
+    DbArgs<T> d;
+    d.amin = (T)amin;
+    d.ref_scalar = (T)ref_scalar;
+    d.ref_items = (const T*)ref_items;
+    d.item_max = use_top_db ? (const T*)item_max : nullptr;
+    d.top_db = (T)top_db;
+    const int chunks = post_chunks(batch, per_item, ctx->n_cu);
+    const long long grid = batch * chunks;
+    if (grid > 0x7fffffffLL) return fail(LRA_EINVAL, "too many items");
+    if (amplitude) hipLaunchKernelGGL((to_db_kernel<T, true>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const T*)x, (T*)out, per_item, chunks, d);
+    else hipLaunchKernelGGL((to_db_kernel<T, false>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const T*)x, (T*)out, per_item, chunks, d);
+    LRA_HIP(hipGetLastError());
+    return LRA_OK;
+}
+template <class T, bool DB>
+int dct_run(lra_ctx* ctx, const T* S, T* out, long long batch, int n_in, int n_out, long long n_frames, const T* C, const T* lift, const DbArgs<T>& d) {
+    const long long tblocks = (n_frames + 255) / 256;
+    const long long grid = tblocks * batch;
+    if (grid > 0x7fffffffLL) return fail(LRA_EINVAL, "grid too large");
+    // the basis arrives padded to whole groups of 128 rows of zeros beyond n_out (lra_dct_exec's contract); every group is one launch
+    for (int k0 = 0; k0 < n_out; k0 += 128) {
+        const int rows = n_out - k0 < 128 ? n_out - k0 : 128;
+        const T* Ck = C + (size_t)k0 * n_in;
+        T* ok = out + (size_t)k0 * n_frames;
+#define LRA_DCT(N) hipLaunchKernelGGL((dct_rows_kernel<T, N, DB>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, S, ok, n_frames, n_in, rows, n_out, Ck, lift + k0, d)
+        if (rows <= 16) LRA_DCT(16);
+        else if (rows <= 32) LRA_DCT(32);
+        else if (rows <= 64) LRA_DCT(64);
+        else LRA_DCT(128);
+#undef LRA_DCT
+        LRA_HIP(hipGetLastError());
+    }
+    return LRA_OK;
+}
+}  // namespace
+
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
@@ -1207,6 +1283,16 @@ int lra_mel_plan_create(lra_ctx* ctx, int n_mels, int n_bins, const void* basis_
                         p->melr_pmax = mr.pmax;
                         p->melr_ok = rc == LRA_OK;
                     }
+                    MelRuns<double> mr2 = build_mel_runs<double>(ts, (n_bins - 1) / 16, 8, MELR_PMAX, 4, 1);
+                    if (rc == LRA_OK && mr2.ok) {
+                        rc = upload(&p->d_melr2_w, mr2.w.data(), mr2.w.size() * sizeof(double));
+                        if (rc == LRA_OK) rc = upload(&p->d_melr2_keep, mr2.keep.data(), mr2.keep.size() * sizeof(double));
+                        if (rc == LRA_OK) rc = upload((void**)&p->d_melr2_addr, mr2.addr.data(), mr2.addr.size() * sizeof(int));
+                        p->melr2_zero = mr2.zero_addr;
+                        p->melr2_mid = mr2.mid_addr;
+                        p->melr2_pmax = mr2.pmax;
+                        p->melr2_ok = rc == LRA_OK;
+                    }
                 }
                 p->two_slope = rc == LRA_OK;
             }
@@ -1235,6 +1321,16 @@ int lra_mel_plan_create(lra_ctx* ctx, int n_mels, int n_bins, const void* basis_
                         p->melr_pmax = mr.pmax;
                         p->melr_ok = rc == LRA_OK;
                     }
+                    MelRuns<float> mr2 = build_mel_runs<float>(ts, (n_bins - 1) / 16, 8, MELR_PMAX, 4, 1);
+                    if (rc == LRA_OK && mr2.ok) {
+                        rc = upload(&p->d_melr2_w, mr2.w.data(), mr2.w.size() * sizeof(float));
+                        if (rc == LRA_OK) rc = upload(&p->d_melr2_keep, mr2.keep.data(), mr2.keep.size() * sizeof(float));
+                        if (rc == LRA_OK) rc = upload((void**)&p->d_melr2_addr, mr2.addr.data(), mr2.addr.size() * sizeof(int));
+                        p->melr2_zero = mr2.zero_addr;
+                        p->melr2_mid = mr2.mid_addr;
+                        p->melr2_pmax = mr2.pmax;
+                        p->melr2_ok = rc == LRA_OK;
+                    }
                 }
                 p->two_slope = rc == LRA_OK;
             }
@@ -1259,6 +1355,9 @@ void lra_mel_plan_destroy(lra_mel_plan* p) {
     if (p->d_melr_w) (void)hipFree(p->d_melr_w);
     if (p->d_melr_keep) (void)hipFree(p->d_melr_keep);
     if (p->d_melr_addr) (void)hipFree(p->d_melr_addr);
+    if (p->d_melr2_w) (void)hipFree(p->d_melr2_w);
+    if (p->d_melr2_keep) (void)hipFree(p->d_melr2_keep);
+    if (p->d_melr2_addr) (void)hipFree(p->d_melr2_addr);
     for (int pi = 0; pi < 2; ++pi) {
         if (p->d_run[pi]) (void)hipFree(p->d_run[pi]);
         if (p->d_segd[pi]) (void)hipFree(p->d_segd[pi]);
@@ -1346,6 +1445,67 @@ int lra_istft_exec(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_ba
     if (!p) return fail(LRA_EINVAL, "null plan");
     return p->dtype == LRA_F64 ? istft_run<double>(p, D, batch, d_batch_stride, d_frame_stride, n_used, wss, y, out_len, y_stride)
                                : istft_run<float>(p, D, batch, d_batch_stride, d_frame_stride, n_used, wss, y, out_len, y_stride);
+}
+
+// ---- decibel scaling and MFCC (lra_post.h) -------------------------------------------------------------------------
+int lra_item_absmax_exec(lra_ctx* ctx, const void* x, int64_t batch, int64_t per_item, int dtype, void* out_max) {
+    LRA_BIND(ctx);
+    if (batch <= 0) return LRA_OK;
+    if (!x || !out_max) return fail(LRA_EINVAL, "null data pointer");
+    if (per_item <= 0) return fail(LRA_EINVAL, "empty items have no maximum");
+    const int chunks = post_chunks(batch, per_item, ctx->n_cu);
+    if (batch * chunks > 0x7fffffffLL) return fail(LRA_EINVAL, "too many items");
+    LRA_HIP(hipMemsetAsync(out_max, 0, (size_t)batch * real_bytes(dtype), ctx->stream));
+    if (dtype == LRA_F64)
+        hipLaunchKernelGGL(item_absmax_kernel<double>, dim3((unsigned)(batch * chunks)), dim3(256), 0, ctx->stream, (const double*)x, (long long)per_item, chunks, (unsigned long long*)out_max);
+    else
+        hipLaunchKernelGGL(item_absmax_kernel<float>, dim3((unsigned)(batch * chunks)), dim3(256), 0, ctx->stream, (const float*)x, (long long)per_item, chunks, (unsigned int*)out_max);
+    LRA_HIP(hipGetLastError());
+    return LRA_OK;
+}
+
+int lra_to_db_exec(lra_ctx* ctx, const void* x, void* out, int64_t batch, int64_t per_item, int dtype, int amplitude, double amin, double ref_scalar, const void* ref_items,
+                   const void* item_max, int use_top_db, double top_db) {
+    LRA_BIND(ctx);
+    if (batch <= 0 || per_item <= 0) return LRA_OK;
+    if (!x || !out) return fail(LRA_EINVAL, "null data pointer");
+    if (!(amin > 0)) return fail(LRA_EINVAL, "amin must be strictly positive");
+    if (use_top_db && top_db < 0) return fail(LRA_EINVAL, "top_db must be non-negative");
+    if (use_top_db && !item_max) return fail(LRA_EINVAL, "top_db needs the per-item maxima");
+    return dtype == LRA_F64 ? to_db_run<double>(ctx, x, out, batch, per_item, amplitude, amin, ref_scalar, ref_items, item_max, use_top_db, top_db)
+                            : to_db_run<float>(ctx, x, out, batch, per_item, amplitude, amin, ref_scalar, ref_items, item_max, use_top_db, top_db);
+}
+
+int lra_from_db_exec(lra_ctx* ctx, const void* x, void* out, int64_t count, int dtype, int amplitude, double ref) {
+    LRA_BIND(ctx);
+    if (count <= 0) return LRA_OK;
+    if (!x || !out) return fail(LRA_EINVAL, "null data pointer");
+    long long grid = (count + 255) / 256;
+    if (grid > 64LL * ctx->n_cu) grid = 64LL * ctx->n_cu;
+#define LRA_FROM(T, AMP) hipLaunchKernelGGL((from_db_kernel<T, AMP>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const T*)x, (T*)out, (long long)count, (T)ref)
+    if (dtype == LRA_F64) { if (amplitude) LRA_FROM(double, true); else LRA_FROM(double, false); }
+    else { if (amplitude) LRA_FROM(float, true); else LRA_FROM(float, false); }
+#undef LRA_FROM
+    LRA_HIP(hipGetLastError());
+    return LRA_OK;
+}
+
+int lra_dct_exec(lra_ctx* ctx, const void* S, void* out, int64_t batch, int n_in, int n_out, int64_t n_frames, int dtype, const void* basis, const void* lift, int fuse_db, double amin,
+                 double ref_scalar, const void* ref_items, const void* item_max, int use_top_db, double top_db) {
+    LRA_BIND(ctx);
+    if (batch <= 0 || n_frames <= 0 || n_out <= 0) return LRA_OK;
+    if (!S || !out || !basis || !lift) return fail(LRA_EINVAL, "null data pointer");
+    if (n_in <= 0) return fail(LRA_EINVAL, "empty band axis");
+    if (fuse_db && !(amin > 0)) return fail(LRA_EINVAL, "amin must be strictly positive");
+    if (fuse_db && use_top_db && (top_db < 0 || !item_max)) return fail(LRA_EINVAL, "top_db must be non-negative and needs the per-item maxima");
+    if (dtype == LRA_F64) {
+        DbArgs<double> d{amin, ref_scalar, (const double*)ref_items, use_top_db ? (const double*)item_max : nullptr, top_db};
+        return fuse_db ? dct_run<double, true>(ctx, (const double*)S, (double*)out, batch, n_in, n_out, n_frames, (const double*)basis, (const double*)lift, d)
+                       : dct_run<double, false>(ctx, (const double*)S, (double*)out, batch, n_in, n_out, n_frames, (const double*)basis, (const double*)lift, d);
+    }
+    DbArgs<float> d{(float)amin, (float)ref_scalar, (const float*)ref_items, use_top_db ? (const float*)item_max : nullptr, (float)top_db};
+    return fuse_db ? dct_run<float, true>(ctx, (const float*)S, (float*)out, batch, n_in, n_out, n_frames, (const float*)basis, (const float*)lift, d)
+                   : dct_run<float, false>(ctx, (const float*)S, (float*)out, batch, n_in, n_out, n_frames, (const float*)basis, (const float*)lift, d);
 }
 
 #ifdef LRA_PHASE_TIMER

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void stft_kernel(lra::Stft
 // registers.  HD = n_fft / hop.  The register budget is sized for 3 waves per SIMD (12 slots of 8.7 KB per CU) where the
 // kernel fits it without spilling (hop <= n_fft/4, i.e. at most 4 sample pairs in flight per thread).
 template <class Cfg, int HD, int MODE, int PM>
-__global__ __launch_bounds__(Cfg::NT, (Cfg::NT >= 256 ? 1 : (HD >= 4 && PM != lra::POW_GENERAL ? 3 : 2))) void stft2_kernel(lra::StftArgs<typename Cfg::real> a, const typename Cfg::real* __restrict__ y,
+__global__ __launch_bounds__(Cfg::NT, (Cfg::NT > 256 ? 1 : (HD >= 4 && PM != lra::POW_GENERAL && MODE != lra::OUT_MELR ? 3 : 2))) void stft2_kernel(lra::StftArgs<typename Cfg::real> a, const typename Cfg::real* __restrict__ y,
                                                                                   void* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char lra_smem[];
     lra::Lds lds;
@@ -118,7 +118,9 @@ LRA_CFG_ALIAS(cfg_f64_12, double, 12, 0)
 // second-generation forward kernels: T(CFG, HD, MODE, PM)
 #define LRA_STFT2_HD(T, C, HD) T(lra::C, HD, 0, 2) T(lra::C, HD, 1, 1) T(lra::C, HD, 1, 2) T(lra::C, HD, 1, 3)
 #define LRA_STFT2_CFG(T, C) LRA_STFT2_HD(T, C, 1) LRA_STFT2_HD(T, C, 2) LRA_STFT2_HD(T, C, 4) LRA_STFT2_HD(T, C, 8)
-#define LRA_INST2_GROUP_9(T) LRA_STFT2_CFG(T, cfg_f32_10)
+#define LRA_STFT2_MEL_HD(T, C, HD) T(lra::C, HD, 4, 1) T(lra::C, HD, 4, 2) T(lra::C, HD, 4, 3)
+#define LRA_STFT2_MEL(T, C) LRA_STFT2_MEL_HD(T, C, 1) LRA_STFT2_MEL_HD(T, C, 2) LRA_STFT2_MEL_HD(T, C, 4) LRA_STFT2_MEL_HD(T, C, 8)
+#define LRA_INST2_GROUP_9(T) LRA_STFT2_CFG(T, cfg_f32_10) LRA_STFT2_MEL(T, cfg_f32_10_mel)
 #define LRA_INST2_GROUP_10(T) LRA_STFT2_CFG(T, cfg_f32_9) LRA_STFT2_CFG(T, cfg_f32_11)
 #define LRA_INST2_ALL(T) LRA_INST2_GROUP_9(T) LRA_INST2_GROUP_10(T)
 #define LRA_INST_NUM_GROUPS 11

@@ -637,11 +637,12 @@ template <class Cfg> LRA_HD int melr_w_slot(int i) { return i + i / (Cfg::R / 2)
 template <class Cfg> LRA_HD int melr_keep_off() { return ((melr_w_slot<Cfg>(Cfg::M) + 1) * 2 * (int)sizeof(typename Cfg::real) + 15) / 16 * 16; }
 template <class Cfg> LRA_HD int melr_addr_off() { return melr_keep_off<Cfg>(); }  // (the restart factors live in registers only, melr_hoist)
 // the address table is needed in LDS only for lists longer than the hoisted prefix or more than two bands per thread
-template <class Cfg> LRA_HD bool melr_needs_table(int n_mels, int pmax) { return pmax > FftRegs<Cfg>::MELR_PHOIST || n_mels > 2 * Cfg::TF; }
+constexpr int MELR_PHOIST_N = 4;  // piece-list entries per band kept in registers (FftRegs / Regs2 ::MELR_PHOIST)
+template <class Cfg> LRA_HD bool melr_needs_table(int n_mels, int pmax) { return pmax > MELR_PHOIST_N || n_mels > 2 * Cfg::TF; }
 template <class Cfg> LRA_HD int melr_shared_bytes(int n_mels, int pmax) {
     return ((melr_addr_off<Cfg>() + (melr_needs_table<Cfg>(n_mels, pmax) ? n_mels * 2 * pmax * (int)sizeof(int) : 0) + 15) / 16) * 16;
 }
-template <class Cfg> inline bool melr_fits() {
+template <class Cfg> constexpr bool melr_fits() {
     return Cfg::R == 16 && (1 << Cfg::PADSHIFT) % (Cfg::R / 2) == 0 && (Cfg::R * Cfg::TF + 2) * 2 * (int)sizeof(typename Cfg::real) <= Cfg::FRAME_BYTES;
 }
 
@@ -717,8 +718,8 @@ template <class Cfg, int PM> LRA_HD void melr_split_accumulate(const StftArgs<ty
 
 // prologue: per-thread constants of the run-ordered epilogue -> registers (restart factors; the first MELR_PHOIST
 // entries of both piece lists of mel bands tf and tf + TF)
-template <class Cfg> LRA_HD void melr_hoist(const StftArgs<typename Cfg::real>& a, int tf, FftRegs<Cfg>& rg) {
-    constexpr int PH = FftRegs<Cfg>::MELR_PHOIST;
+template <class Cfg, class RG> LRA_HD void melr_hoist(const StftArgs<typename Cfg::real>& a, int tf, RG& rg) {
+    constexpr int PH = RG::MELR_PHOIST;
     LRA_UNROLL
     for (int jj = 0; jj < Cfg::R; ++jj) rg.keep[jj] = a.melr_keep[jj * Cfg::TF + tf];
     LRA_UNROLL
@@ -735,10 +736,10 @@ template <class Cfg> LRA_HD void melr_hoist(const StftArgs<typename Cfg::real>& 
 // phase: mel[m] = sum of the B totals of segment m's pieces + sum of the A totals of segment m+1's pieces
 // (ascending bins).  Bands tf and tf + TF use the hoisted address lists; longer lists / further bands read
 // theirs from the shared table.
-template <class Cfg> LRA_HD void melr_combine(const StftArgs<typename Cfg::real>& a, int clip, int frame, int tf, int it, int tile, bool last_of_slot, FftRegs<Cfg>& rg, Lds sh,
-                                              Lds rs, Lds stage) {
+template <class Cfg, class RG> LRA_HD void melr_combine(const StftArgs<typename Cfg::real>& a, int clip, int frame, int tf, int it, int tile, bool last_of_slot, RG& rg, Lds sh,
+                                                        Lds rs, Lds stage) {
     using T = typename Cfg::real;
-    constexpr int PH = FftRegs<Cfg>::MELR_PHOIST, TF = Cfg::TF;
+    constexpr int PH = RG::MELR_PHOIST, TF = Cfg::TF;
     const bool more = a.melr_pmax > PH;  // uniform
     T x[2][2 * PH];
     LRA_UNROLL
@@ -764,7 +765,7 @@ template <class Cfg> LRA_HD void melr_combine(const StftArgs<typename Cfg::real>
         }
         const T v = part[0] + part[1];
         if (tile == 1) {  // register tile: slot it & 7 of this band's row; burst when the tile is full or the slot ends
-            constexpr int MT = FftRegs<Cfg>::MELR_TILE;
+            constexpr int MT = RG::MELR_TILE;
             const int s8 = it & (MT - 1);
             LRA_UNROLL
             for (int k = 0; k < MT; ++k)

@@ -55,6 +55,14 @@ template <class Cfg, int HD> struct Regs2 {
     C win2[R];         // window pairs (x 1/2, see split_pair), pass-0 order
     C treg[Cfg::TREG_TOTAL];
     C twr[rl];         // split twiddles W_N^k of this thread's rl pair slots
+    // OUT_MELR (run-ordered two-slope mel epilogue, lra_mel.h layout 1): this thread's two runs of R/2 power values, the
+    // restart factors of its running sums, the first MELR_PHOIST piece addresses of its two mel bands and the last
+    // MELR_TILE frames' values of those bands (stored as one burst per band, see FftRegs)
+    static constexpr int MELR_PHOIST = MELR_PHOIST_N, MELR_TILE = 8;
+    typename Cfg::real pw[R], pw_extra;
+    typename Cfg::real keep[R];
+    int mad[2][2 * MELR_PHOIST];
+    typename Cfg::real mt[2][MELR_TILE];
     // complex index (within a frame) of pass-0 register element e
     static LRA_HD int q_of(int tf, int e) { return tf + (e / r0) * Cfg::TF + (e % r0) * sin0; }
     // pass-0 register element of new pair n
@@ -194,6 +202,10 @@ template <class Cfg> LRA_HD int v2_row_shift(const StftArgs<typename Cfg::real>&
     return (int)(reinterpret_cast<size_t>(a.D + row) & (2 * sizeof(typename Cfg::real)));  // 0 or sizeof(cplx): the row starts on / half-way into a 16-byte piece
 }
 
+// OUT_MELR: float index of bin k in the power row: runs of 8 bins, 12 floats (48 bytes) apart
+LRA_HD int v2_pw_index(int k) { return (k >> 3) * 12 + (k & 7); }
+template <class Cfg> constexpr int v2_pw_bytes() { return ((Cfg::M >> 3) * 12 + 4) * (int)sizeof(typename Cfg::real); }
+
 // phase: last-pass butterflies, Hermitian split in registers, epilogue (complex spectrum or |X|^power) to HBM
 template <class Cfg, int HD, int MODE, int PM, bool STAGED>
 LRA_HD void v2_last_split_store(const StftArgs<typename Cfg::real>& a, int clip, int frame, bool valid, int tf, Regs2<Cfg, HD>& rg, Lds stage) {
@@ -229,7 +241,13 @@ LRA_HD void v2_last_split_store(const StftArgs<typename Cfg::real>& a, int clip,
             if (l0 && valid && a.nonfinite_flag && !(std::fabs(dc.x) <= std::numeric_limits<T>::max())) LRA_ATOMIC_OR(a.nonfinite_flag, 1u);
         }
         const int k = (q < r / 2 ? tf : tfh) + q * s;
-        if (MODE == OUT_COMPLEX && STAGED) {
+        if (MODE == OUT_MELR) {
+            // power row -> LDS (the frame area is free: every Z is in registers), bin k at float (k / 8) 12 + k % 8: runs of 8
+            // bins 48 bytes apart, so that the 16-byte run reads of v2_mel_runs_read hit disjoint banks.  Per-thread bases + immediates.
+            const int tfo = q < r / 2 ? tf : tfh;
+            lds_st<T>(stage, (v2_pw_index(tfo) + 24 * q * (s / 16)) * (int)sizeof(T), spec_power<T, PM>(xk, a.power));
+            lds_st<T>(stage, (v2_pw_index(M - tfo) - 24 * q * (s / 16)) * (int)sizeof(T), spec_power<T, PM>(xm, a.power));
+        } else if (MODE == OUT_COMPLEX && STAGED) {
             // the row goes to LDS in bin order (the frame area is free: every Z is in registers), shifted so that LDS and
             // global addresses agree modulo 16; v2_store_row then writes it as aligned 16-byte pieces.  Of the two bins that
             // a row of 1025 has in excess of whole 16-byte pieces one is stored here: bin 0 or bin M, both lane 0's slot 0.
@@ -250,7 +268,9 @@ LRA_HD void v2_last_split_store(const StftArgs<typename Cfg::real>& a, int clip,
     // X[M/2] = conj(Z[M/2]) (Z pre-halved): lane 0's A[r/2]
     const C zmid = A[r / 2];
     const C xmid = mk<T>((T)2 * zmid.x, (T)-2 * zmid.y);
-    if (MODE == OUT_COMPLEX && STAGED) {
+    if (MODE == OUT_MELR) {
+        if (l0) lds_st<T>(stage, v2_pw_index(M / 2) * (int)sizeof(T), spec_power<T, PM>(xmid, a.power));
+    } else if (MODE == OUT_COMPLEX && STAGED) {
         if (l0) lds_st<C>(stage, sh + (M / 2) * (int)sizeof(C), xmid);
     } else if (l0 && valid) {
         if (MODE == OUT_COMPLEX) D[M / 2] = xmid;
@@ -283,13 +303,55 @@ template <class Cfg> LRA_HD void v2_store_row(const StftArgs<typename Cfg::real>
     }
 }
 
+// ---- OUT_MELR on the second-generation core ------------------------------------------------------------------------
+
+// phase: this thread's runs (bins 8 tf .. 8 tf + 7 and M/2 + 8 tf ..) from the power row; thread 0 also takes bin M
+template <class Cfg, int HD> LRA_HD void v2_mel_runs_read(Regs2<Cfg, HD>& rg, Lds pwr, int tf) {
+    using T = typename Cfg::real;
+    constexpr int BPL = Cfg::R / 2;
+    static_assert(BPL == 8, "runs of 8 bins");
+    LRA_UNROLL
+    for (int run = 0; run < 2; ++run) {
+        const int base = 12 * (run * Cfg::TF + tf) * (int)sizeof(T);
+        const V4<T> lo = lds_ld<V4<T>>(pwr, base), hi = lds_ld<V4<T>>(pwr, base + 16);
+        T* d = rg.pw + run * BPL;
+        d[0] = lo.a; d[1] = lo.b; d[2] = lo.c; d[3] = lo.d; d[4] = hi.a; d[5] = hi.b; d[6] = hi.c; d[7] = hi.d;
+    }
+    rg.pw_extra = lds_ld<T>(pwr, (tf == 0 ? v2_pw_index(Cfg::M) : 0) * (int)sizeof(T));  // consumed by thread 0 only
+}
+
+// phase: (wA, wB) x power, running sums along both runs (restart factors in registers) -> rs[jj][tf] (as melr_split_accumulate)
+template <class Cfg, int HD> LRA_HD void v2_mel_accumulate(const StftArgs<typename Cfg::real>& a, int tf, Regs2<Cfg, HD>& rg, Lds rs, Lds sh) {
+    using T = typename Cfg::real;
+    using C = typename Cfg::cplx;
+    constexpr int BPL = Cfg::R / 2, TF = Cfg::TF;
+    LRA_UNROLL
+    for (int run = 0; run < 2; ++run) {
+        C acc = mk<T>((T)0, (T)0);
+        LRA_UNROLL
+        for (int j = 0; j < BPL; ++j) {
+            const int jj = run * BPL + j;
+            const C w = lds_ld<C>(sh, ((BPL + 1) * (run * TF + tf) + j) * (int)sizeof(C));
+            const T p = rg.pw[jj], keep = rg.keep[jj];
+            acc = mk<T>(acc.x * keep + w.x * p, acc.y * keep + w.y * p);
+            lds_st<C>(rs, (jj * TF + tf) * (int)sizeof(C), acc);
+        }
+    }
+    if (tf == 0) {
+        const C wq = lds_ld<C>(sh, melr_w_slot<Cfg>(Cfg::M) * (int)sizeof(C));
+        lds_st<C>(rs, a.melr_mid, mk<T>(wq.x * rg.pw_extra, wq.y * rg.pw_extra));
+        lds_st<C>(rs, a.melr_zero, mk<T>((T)0, (T)0));
+    }
+}
+
 // bytes of LDS one frame slot needs: the frame area only
 template <class Cfg> constexpr int stft2_slot_bytes() { return Cfg::FRAME_BYTES; }
 
 // One workgroup = FPB frame slots, slot s transforms frames f_first + s iters + it, it = 0 .. iters-1 (as stft_block).
 template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2(const StftArgs<typename Cfg::real>& a_in, const int blk, Lds lds) {
     static_assert(v2_cfg_ok<Cfg>(), "configuration has no mirrored last pass");
-    static_assert(MODE == OUT_COMPLEX || MODE == OUT_POWER, "epilogues of the second-generation kernel");
+    static_assert(MODE == OUT_COMPLEX || MODE == OUT_POWER || MODE == OUT_MELR, "epilogues of the second-generation kernel");
+    static_assert(MODE != OUT_MELR || (melr_fits<Cfg>() && v2_pw_bytes<Cfg>() <= Cfg::FRAME_BYTES), "mel epilogue: running sums and power row live in the frame area");
     StftArgs<typename Cfg::real> a = a_in;
     using RG = Regs2<Cfg, HD>;
     const int clip = blk / a.wg_per_clip;
@@ -310,7 +372,11 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
         const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
         v2_hoist<Cfg, HD>(LRA_R(rg), tf, a.win, a.tw, a.twr);
         v2_fill<Cfg, HD>(a, clip, f_first + slot * iters, tf, LRA_R(rg));
-    } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+        if (MODE == OUT_MELR) {
+            melr_tables_to_lds<Cfg>(a, tid, lds_sub(lds, a.shared_off));
+            melr_hoist<Cfg>(a, tf, LRA_R(rg));
+        }
+    } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC && MODE != OUT_MELR)  // the shared mel tables need a workgroup barrier, once
     for (int it = 0; it < iters; ++it) {
         if (f_first + it >= a.n_frames) break;  // slot 0 has the smallest frame index: uniform exit
         LRA_PHASE(Cfg::NT, tid) {
@@ -344,6 +410,22 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
             LRA_PHASE(Cfg::NT, tid) {
                 const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
                 v2_store_row<Cfg>(a, clip, frame, frame < a.n_frames, tf, lds_sub(lds, slot * SB));
+            } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+        }
+        if (MODE == OUT_MELR) {
+            // power row -> runs in registers; then (only then: the running sums reuse the row's bytes) weights, running sums
+            // -> rs; then every band adds its piece totals (melr_combine, shared with the first-generation kernel)
+            LRA_PHASE(Cfg::NT, tid) {
+                v2_mel_runs_read<Cfg, HD>(LRA_R(rg), lds_sub(lds, slot_of<Cfg>(tid) * SB), lane_of<Cfg>(tid));
+            } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+            LRA_PHASE(Cfg::NT, tid) {
+                v2_mel_accumulate<Cfg, HD>(a, lane_of<Cfg>(tid), LRA_R(rg), lds_sub(lds, slot_of<Cfg>(tid) * SB), lds_sub(lds, a.shared_off));
+            } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+            LRA_PHASE(Cfg::NT, tid) {
+                const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
+                const Lds sl = lds_sub(lds, slot * SB);
+                if (frame < a.n_frames)
+                    melr_combine<Cfg>(a, clip, frame, tf, it, 1, it + 1 == iters || frame + 1 >= a.n_frames, LRA_R(rg), lds_sub(lds, a.shared_off), sl, sl);
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         }
     }

@@ -155,7 +155,10 @@ template <class T> struct MelRuns {
     int zero_addr = 0, mid_addr = 0;  // byte addresses of the always-zero slot and of bin M/2's (A, B) slot
 };
 
-template <class T> inline MelRuns<T> build_mel_runs(const TwoSlope<T>& ts, int tf_count, int bpl, int pmax, int min_len) {
+// layout 0 (first-generation kernels): run A = bins bpl t + j, run B = bins M - bpl t - j (mirrored), extra bin M/2;
+// layout 1 (second-generation kernel, which reads its runs from a power row in LDS): run A = bins bpl t + j, run B = bins
+// M/2 + bpl t + j (both ascending), extra bin M; the weight table is then in plain bin order.
+template <class T> inline MelRuns<T> build_mel_runs(const TwoSlope<T>& ts, int tf_count, int bpl, int pmax, int min_len, int layout = 0) {
     MelRuns<T> mr;
     mr.tf = tf_count;
     mr.bpl = bpl;
@@ -167,17 +170,22 @@ template <class T> inline MelRuns<T> build_mel_runs(const TwoSlope<T>& ts, int t
     mr.mid_addr = (slots + 1) * pair_bytes;
     if (mr.mid_addr + pair_bytes > 65535) return mr;
     mr.w.assign(2 * (size_t)(2 * half + 1), (T)0);
+    const int extra_bin = layout == 0 ? half : M;
     for (int i = 0; i < half; ++i) {
+        const int hi = layout == 0 ? M - i : half + i;  // bin behind weight-table entry half + i
         mr.w[2 * (size_t)i] = ts.wAB[2 * (size_t)i];
         mr.w[2 * (size_t)i + 1] = ts.wAB[2 * (size_t)i + 1];
-        mr.w[2 * (size_t)(half + i)] = ts.wAB[2 * (size_t)(M - i)];
-        mr.w[2 * (size_t)(half + i) + 1] = ts.wAB[2 * (size_t)(M - i) + 1];
+        mr.w[2 * (size_t)(half + i)] = ts.wAB[2 * (size_t)hi];
+        mr.w[2 * (size_t)(half + i) + 1] = ts.wAB[2 * (size_t)hi + 1];
     }
-    mr.w[2 * (size_t)(2 * half)] = ts.wAB[2 * (size_t)half];
-    mr.w[2 * (size_t)(2 * half) + 1] = ts.wAB[2 * (size_t)half + 1];
+    mr.w[2 * (size_t)(2 * half)] = ts.wAB[2 * (size_t)extra_bin];
+    mr.w[2 * (size_t)(2 * half) + 1] = ts.wAB[2 * (size_t)extra_bin + 1];
     // bin -> register slot; effective segment of a bin (bins outside every filter carry zero weights and simply
     // extend the neighbouring stretch)
-    auto bin_of = [&](int t, int jj) { return jj < bpl ? bpl * t + jj : M - bpl * t - (jj - bpl); };
+    auto bin_of = [&](int t, int jj) {
+        if (jj < bpl) return bpl * t + jj;
+        return layout == 0 ? M - bpl * t - (jj - bpl) : half + bpl * t + (jj - bpl);
+    };
     mr.keep.assign((size_t)2 * bpl * tf_count, (T)1);
     // pieces: (segment, byte address of the slot that holds the piece's total, lowest bin) in bin order per segment
     struct Piece { int seg, addr, lowbin; };
@@ -205,10 +213,10 @@ template <class T> inline MelRuns<T> build_mel_runs(const TwoSlope<T>& ts, int t
             if (cur >= 0) pieces.push_back({cur, ((run * bpl + bpl - 1) * tf_count + t) * pair_bytes, 0});
         }
     }
-    if (ts.owner[half] >= 0) pieces.push_back({ts.owner[half], mr.mid_addr, 0});
+    if (ts.owner[extra_bin] >= 0) pieces.push_back({ts.owner[extra_bin], mr.mid_addr, 0});
     // lowest bin of each piece (for ordering): recompute from the address
     for (auto& pc : pieces) {
-        if (pc.addr == mr.mid_addr) { pc.lowbin = half; continue; }
+        if (pc.addr == mr.mid_addr) { pc.lowbin = extra_bin; continue; }
         const int slot = pc.addr / pair_bytes, jj = slot / tf_count, t = slot % tf_count;
         pc.lowbin = bin_of(t, jj);  // run A: the last (highest) bin; run B: the last slot is the LOWEST bin -- either orders pieces consistently
     }

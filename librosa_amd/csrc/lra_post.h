@@ -1,0 +1,138 @@
+// lra_post.h -- the consumers right after the mel reduce: decibel scaling and MFCC.
+//
+//   power_to_db / amplitude_to_db   librosa/core/spectrum.py:1735-1883, 1946-2038
+//       log_spec = 10 log10(max(amin, S)) - 10 log10(max(amin, ref)),  then  max(log_spec, log_spec.max(axes) - top_db)
+//   db_to_power / db_to_amplitude   librosa/core/spectrum.py:1898-1925, 2054-2082
+//   mfcc                            librosa/feature/spectral.py:1843-2019:  scipy.fft.dct(S_db, axis=-2, type, norm)[..., :n_mfcc, :] (+ lifter)
+//
+// All of them are HBM-bound elementwise / small-contraction work over [batch][per_item] or [batch][n_in][n_frames] arrays:
+// lanes run along the contiguous axis (16-byte accesses where the layout allows), reductions are per item (the
+// reference's axes="auto": the last two axes), the DCT basis is a host-built table (float64 recipe, exactly scipy's
+// transform applied to the identity) that every lane reads through the scalar cache.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace lra {
+
+// ---- per-item maximum of |x| (the reduction behind ref=np.max and top_db) --------------------------------------------
+// Non-negative IEEE values order like their bit patterns, so the cross-workgroup combine is an integer atomicMax.
+template <class T> struct MaxBits;
+template <> struct MaxBits<float> {
+    using type = unsigned int;
+    static __device__ type bits(float v) { return __float_as_uint(v); }
+};
+template <> struct MaxBits<double> {
+    using type = unsigned long long;
+    static __device__ type bits(double v) { return (unsigned long long)__double_as_longlong(v); }
+};
+
+template <class T> __global__ __launch_bounds__(256) void item_absmax_kernel(const T* __restrict__ x, long long per_item, int chunks_per_item, typename MaxBits<T>::type* __restrict__ out) {
+    const long long item = blockIdx.x / chunks_per_item;
+    const int chunk = blockIdx.x % chunks_per_item;
+    const T* __restrict__ xi = x + item * per_item;
+    const long long per_chunk = (per_item + chunks_per_item - 1) / chunks_per_item;
+    const long long lo = chunk * per_chunk, hi = lo + per_chunk < per_item ? lo + per_chunk : per_item;
+    T m = (T)0;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+        const T v = xi[i] < (T)0 ? -xi[i] : xi[i];
+        m = v > m ? v : m;  // NaN never wins: the reference's np.max would propagate it, but NaN power is rejected upstream
+    }
+    __shared__ T red[256];
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = red[threadIdx.x + s] > red[threadIdx.x] ? red[threadIdx.x + s] : red[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicMax(&out[item], MaxBits<T>::bits(red[0]));
+}
+
+// ---- decibel scaling ---------------------------------------------------------------------------------------------------
+// AMP: the input is an amplitude (amplitude_to_db squares it first, in the input precision, exactly as the reference does:
+// power_to_db(S**2, ref=ref**2, amin=amin**2), core/spectrum.py:2030-2037)
+template <class T> __device__ __forceinline__ T ten_log10(T v) { return (T)10 * log10(v); }
+template <> __device__ __forceinline__ float ten_log10<float>(float v) { return 10.0f * log10f(v); }
+
+template <class T> struct DbArgs {
+    T amin;               // power domain (the host squares amplitude_to_db's amin)
+    T ref_scalar;         // |ref| when ref_items == nullptr (input domain: squared here for amplitudes)
+    const T* ref_items;   // per-item |reference| values (input domain), or nullptr
+    const T* item_max;    // per-item max of |x| (input domain), or nullptr when top_db is None
+    T top_db;
+};
+
+template <class T> __device__ __forceinline__ T db_of(T mag, T amin, T ref_db) { return ten_log10<T>(mag > amin ? mag : amin) - ref_db; }
+
+template <class T> __device__ __forceinline__ void db_item_constants(const DbArgs<T>& d, long long item, bool amp, T& ref_db, T& floor_db) {
+    T ref = d.ref_items ? d.ref_items[item] : d.ref_scalar;
+    if (amp) ref = ref * ref;
+    ref_db = ten_log10<T>(ref > d.amin ? ref : d.amin);
+    floor_db = -INFINITY;
+    if (d.item_max) {
+        T mx = d.item_max[item];
+        if (amp) mx = mx * mx;
+        floor_db = db_of<T>(mx, d.amin, ref_db) - d.top_db;  // log10 is monotone: max of the logs = log of the max
+    }
+}
+
+template <class T, bool AMP> __global__ __launch_bounds__(256) void to_db_kernel(const T* __restrict__ x, T* __restrict__ out, long long per_item, int chunks_per_item, DbArgs<T> d) {
+    const long long item = blockIdx.x / chunks_per_item;
+    const int chunk = blockIdx.x % chunks_per_item;
+    T ref_db, floor_db;
+    db_item_constants<T>(d, item, AMP, ref_db, floor_db);
+    const long long per_chunk = (per_item + chunks_per_item - 1) / chunks_per_item;
+    const long long lo = chunk * per_chunk, hi = lo + per_chunk < per_item ? lo + per_chunk : per_item;
+    const T* __restrict__ xi = x + item * per_item;
+    T* __restrict__ oi = out + item * per_item;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+        T v = xi[i];
+        v = AMP ? v * v : (v < (T)0 ? -v : v);
+        const T db = db_of<T>(v, d.amin, ref_db);
+        oi[i] = db > floor_db ? db : floor_db;
+    }
+}
+
+// db_to_power: ref * 10^(0.1 x); db_to_amplitude: db_to_power(x, ref = ref^2) ^ 0.5 (core/spectrum.py:1925, 2082)
+template <class T, bool AMP> __global__ __launch_bounds__(256) void from_db_kernel(const T* __restrict__ x, T* __restrict__ out, long long count, T ref) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+        const T p = (AMP ? ref * ref : ref) * pow((T)10, x[i] * (T)0.1);
+        out[i] = AMP ? sqrt(p) : p;
+    }
+}
+
+// ---- DCT over the band axis (MFCC) -------------------------------------------------------------------------------------
+// out[b][k][t] = lift[k] * sum_m C[k][m] * f(S[b][m][t]),  k < n_out <= NOUT,  f = identity or the decibel scaling above
+// (DB: the fused mfcc(y=...) path reads the mel POWER spectrogram once and never materialises power_to_db's output).
+// One thread per frame t (lanes along the contiguous axis: every S row access is a 256-byte coalesced wave load), NOUT
+// accumulators in registers, the basis C through uniform (scalar-cache) loads: 2 n_in NOUT flops per 4 n_in bytes read.
+template <class T, int NOUT, bool DB>
+__global__ __launch_bounds__(256) void dct_rows_kernel(const T* __restrict__ S, T* __restrict__ out, long long n_frames, int n_in, int n_out /* rows of this launch */, int out_rows /* rows of `out` per item */,
+                                                       const T* __restrict__ C /* [NOUT][n_in], zero rows beyond n_out */, const T* __restrict__ lift /* [n_out] */, DbArgs<T> d) {
+    const long long tblocks = (n_frames + 255) / 256;
+    const long long b = blockIdx.x / tblocks;
+    const long long t = (blockIdx.x % tblocks) * 256 + threadIdx.x;
+    T ref_db = (T)0, floor_db = -INFINITY;
+    if (DB) db_item_constants<T>(d, b, false, ref_db, floor_db);
+    if (t >= n_frames) return;
+    const T* __restrict__ s = S + b * (long long)n_in * n_frames + t;
+    T acc[NOUT];
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k) acc[k] = (T)0;
+    for (int m = 0; m < n_in; ++m) {
+        T v = s[(long long)m * n_frames];
+        if (DB) {
+            v = v < (T)0 ? -v : v;
+            const T db = db_of<T>(v, d.amin, ref_db);
+            v = db > floor_db ? db : floor_db;
+        }
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) acc[k] += C[k * n_in + m] * v;
+    }
+    T* __restrict__ o = out + b * (long long)out_rows * n_frames + t;
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k)
+        if (k < n_out) o[(long long)k * n_frames] = acc[k] * lift[k];
+}
+
+}  // namespace lra

@@ -9,7 +9,7 @@ from ..core import spectrum as _spectrum
 from ..util.exceptions import ParameterError
 from ..util.utils import is_torch_tensor
 
-__all__ = ["melspectrogram"]
+__all__ = ["melspectrogram", "mfcc"]
 
 
 def melspectrogram(*, y=None, sr=22050, S=None, n_fft=2048, hop_length=512, win_length=None, window="hann", center=True, pad_mode="constant",
@@ -33,6 +33,93 @@ def melspectrogram(*, y=None, sr=22050, S=None, n_fft=2048, hop_length=512, win_
     mel_basis = filters.mel_cached(sr=sr, n_fft=n_fft, **kwargs)
     return _spectrum._run_stft_family("mel", y, n_fft=n_fft, hop_length=hop_length, win_length=win_length, window=window, center=center,
                                       pad_mode=pad_mode, power=float(power), mel_basis=mel_basis, check_finite=check_finite)
+
+
+def _dct_tables(n_in, n_mfcc, dct_type, norm, lifter, real):
+    """Host tables of the MFCC contraction: the first ``n_mfcc`` rows of scipy's DCT applied to the identity (float64 recipe,
+    rounded once to the compute dtype; zero rows up to a multiple of 128, the C ABI's contract) and the lifter weights
+    ``1 + (lifter / 2) sin(pi (k + 1) / lifter)`` in the result dtype (``feature/spectral.py:2005-2015``)."""
+    import scipy.fft
+
+    if lifter < 0:
+        raise ParameterError(f"MFCC lifter={lifter} must be a non-negative number")
+    full = scipy.fft.dct(np.eye(n_in, dtype=np.float64), axis=0, type=dct_type, norm=norm)
+    n_out = min(int(n_mfcc), n_in)
+    rows = -(-n_out // 128) * 128
+    basis = np.zeros((rows, n_in), dtype=real)
+    basis[:n_out] = full[:n_out]
+    if lifter > 0:
+        if n_out != int(n_mfcc):
+            raise ParameterError(f"n_mfcc={n_mfcc} exceeds the {n_in} bands of the input: the lifter cannot be applied")
+        li = np.sin(np.pi * np.arange(1, 1 + n_out, dtype=real) / lifter)
+        lift = np.asarray(1 + (lifter / 2) * li, dtype=real)
+    else:
+        lift = np.ones(n_out, dtype=real)
+    return basis, lift, n_out
+
+
+def mfcc(*, y=None, sr=22050, S=None, n_mfcc=20, dct_type=2, norm="ortho", lifter=0, mel_norm="slaney", check_finite=True, **kwargs):
+    """Mel-frequency cepstral coefficients; drop-in for ``librosa.feature.mfcc`` (``librosa/feature/spectral.py:1843-2019``).
+
+    ``S`` (a log-power mel spectrogram) given: ``scipy.fft.dct(S, axis=-2, type=dct_type, norm=norm)[..., :n_mfcc, :]`` times
+    the lifter, as one device contraction.  ``y`` given: ``S = power_to_db(melspectrogram(y=y, sr=sr, norm=mel_norm,
+    **kwargs))`` (``:2001``) -- here the fused mel kernel, one per-clip maximum reduction (``top_db``) and the DCT kernel, which
+    applies the decibel scaling while it reads the mel power spectrogram: nothing but the ``n_mfcc`` rows returns to the host."""
+    if lifter < 0:
+        raise ParameterError(f"MFCC lifter={lifter} must be a non-negative number")
+    if S is not None:
+        return _mfcc_of(S, n_mfcc, dct_type, norm, lifter)
+    n_fft = kwargs.pop("n_fft", 2048)
+    hop_length = kwargs.pop("hop_length", 512)
+    win_length = kwargs.pop("win_length", None)
+    window = kwargs.pop("window", "hann")
+    center = kwargs.pop("center", True)
+    pad_mode = kwargs.pop("pad_mode", "constant")
+    power = kwargs.pop("power", 2.0)
+    if n_fft is None:
+        raise ParameterError(f"Unable to compute spectrogram with n_fft={n_fft}")
+    if y is None:
+        raise ParameterError("Input signal must be provided to compute a spectrogram")
+    mel_basis = filters.mel_cached(sr=sr, n_fft=n_fft, norm=mel_norm, **kwargs)
+    tables = {}
+
+    def post(sess, mel_ptr, batch, n_mels, n_frames, real):
+        basis, lift, n_out = _dct_tables(n_mels, n_mfcc, dct_type, norm, lifter, real)
+        tables["n_out"] = n_out
+        ctx = sess.ctx
+        max_ptr = sess.scratch(batch * real.itemsize)
+        ctx.item_absmax_exec(mel_ptr, batch, n_mels * n_frames, real, max_ptr)  # power_to_db's top_db = 80 (defaults, :2001)
+        out_ptr, handle = sess.output((batch, n_out, n_frames), real)
+        ctx.dct_exec(mel_ptr, out_ptr, batch, n_mels, n_out, n_frames, real, sess.input_raw(_spectrum._as_like(sess, basis), real),
+                     sess.input_raw(_spectrum._as_like(sess, lift), real), fuse_db=True, amin=1e-10, ref_scalar=1.0, item_max_ptr=max_ptr, top_db=80.0)
+        return handle, n_out
+
+    return _spectrum._run_stft_family("mel", y, n_fft=n_fft, hop_length=hop_length, win_length=win_length, window=window, center=center, pad_mode=pad_mode,
+                                      power=float(power), mel_basis=mel_basis, check_finite=check_finite, post=post)
+
+
+def _mfcc_of(S, n_mfcc, dct_type, norm, lifter):
+    """DCT over axis -2 of a (log-)mel spectrogram (``feature/spectral.py:2005-2015``)."""
+    s_dtype = _arrays.numpy_dtype_of(S)
+    if s_dtype.kind == "c":
+        raise ParameterError("S must be a real-valued (log-power) mel spectrogram")
+    if S.ndim < 2:
+        raise ParameterError(f"S must have at least 2 dimensions, given shape={tuple(S.shape)}")
+    real = np.dtype(np.float32) if s_dtype == np.float32 else np.dtype(np.float64)
+    lead = tuple(S.shape[:-2])
+    n_in, n_frames = int(S.shape[-2]), int(S.shape[-1])
+    batch = int(np.prod(lead, dtype=np.int64)) if lead else 1
+    basis, lift, n_out = _dct_tables(n_in, n_mfcc, dct_type, norm, lifter, real)
+    sess = _arrays.Session(S)
+    try:
+        s_ptr = sess.input_raw(S, real)
+        out_ptr, handle = sess.output((batch, n_out, n_frames), real)
+        sess.ctx.dct_exec(s_ptr, out_ptr, batch, n_in, n_out, n_frames, real, sess.input_raw(_spectrum._as_like(sess, basis), real),
+                          sess.input_raw(_spectrum._as_like(sess, lift), real))
+        M = sess.result(handle)
+    finally:
+        sess.close()
+    return M.reshape(lead + (n_out, n_frames))
 
 
 def _apply_mel(S, mel_basis):

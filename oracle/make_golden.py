@@ -87,6 +87,36 @@ def main():
             store[f"mel_absmax_{i}"] = M.max()
     np.savez_compressed(os.path.join(OUT, "config2_clips.npz"), params=json.dumps(dict(case="config2", **meta)), **store)
     print("config2 done")
+    make_db_mfcc(librosa, meta)
+
+
+def make_db_mfcc(librosa, meta):
+    """power_to_db / amplitude_to_db / db_to_power and mfcc outputs of the reference."""
+    rng = np.random.default_rng(2718)
+    y = golden_cases.make_signal("mix", 16000, 21, (2,), "float32")
+    M = librosa.feature.melspectrogram(y=y, sr=golden_cases.SR, n_fft=1024, hop_length=256, n_mels=40)  # (2, 40, 63)
+    A = np.abs(librosa.stft(y[0], n_fft=512, hop_length=128))  # amplitudes (257, 126)
+    store = dict(y=y, M=M, A=A)
+    store["db_default"] = librosa.power_to_db(M)
+    store["db_refmax"] = librosa.power_to_db(M, ref=np.max)
+    store["db_notop"] = librosa.power_to_db(M, top_db=None, amin=1e-6, ref=2.5)
+    store["db_median_top30"] = librosa.power_to_db(M, ref=np.median, top_db=30.0)
+    store["db_axes_last"] = librosa.power_to_db(M, ref=np.max, axes=-1, top_db=40.0)
+    store["db_axes_none"] = librosa.power_to_db(M, ref=np.max, axes=None)
+    store["adb_default"] = librosa.amplitude_to_db(A)
+    store["adb_refmax"] = librosa.amplitude_to_db(A, ref=np.max, top_db=60.0)
+    store["pow_back"] = librosa.db_to_power(store["db_notop"], ref=2.5)
+    store["amp_back"] = librosa.db_to_amplitude(librosa.amplitude_to_db(A, top_db=None), ref=1.0)
+    store["mfcc_S"] = librosa.feature.mfcc(S=store["db_default"], n_mfcc=13)
+    store["mfcc_S_t3_lift"] = librosa.feature.mfcc(S=store["db_default"], n_mfcc=20, dct_type=3, lifter=22)
+    store["mfcc_S_t1_none"] = librosa.feature.mfcc(S=store["db_default"], n_mfcc=12, dct_type=1, norm=None)
+    store["mfcc_y"] = librosa.feature.mfcc(y=y, sr=golden_cases.SR, n_mfcc=20, n_fft=1024, hop_length=256, n_mels=40)
+    y2 = stft_oracle.config_input(1, n=22050 * 2)[0]
+    store["y2"] = y2
+    store["mfcc_y2_default"] = librosa.feature.mfcc(y=y2, sr=22050)  # n_fft 2048, hop 512, 128 mels, 20 coefficients
+    store["mfcc_y2_htk_lift"] = librosa.feature.mfcc(y=y2, sr=22050, n_mfcc=13, lifter=2 * 13, htk=True, n_mels=64, fmax=8000.0)
+    np.savez_compressed(os.path.join(OUT, "db_mfcc.npz"), params=json.dumps(dict(case="db_mfcc", **meta)), **store)
+    print("db_mfcc done")
 
 
 if __name__ == "__main__":

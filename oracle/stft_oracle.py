@@ -357,6 +357,65 @@ def melspectrogram(*, y=None, sr=22050, S=None, n_fft=2048, hop_length=512, win_
     return np.einsum("...ft,mf->...mt", S, mel_basis, optimize=True)
 
 
+# ----------------------------------------------------------------------------- L5: decibel scaling and MFCC
+def _db_axes(ndim, axes):
+    """``librosa/core/spectrum.py:1853-1859``: axes="auto" -> the last two axes (one for 1-d input, None for scalars)."""
+    if isinstance(axes, str) and axes == "auto":
+        return (-2, -1) if ndim >= 2 else ((-1,) if ndim == 1 else None)
+    return axes
+
+
+def power_to_db(S, *, ref=1.0, amin=1e-10, top_db=80.0, axes="auto"):
+    """``librosa/core/spectrum.py:1838-1883``."""
+    S = np.asarray(S)
+    if amin <= 0:
+        raise ParameterError("amin must be strictly positive")
+    magnitude = np.abs(S) if np.issubdtype(S.dtype, np.complexfloating) else S
+    axes = _db_axes(magnitude.ndim, axes)
+    ref_value = ref(magnitude, axis=axes, keepdims=True) if callable(ref) else np.abs(ref)
+    log_spec = 10.0 * np.log10(np.maximum(amin, magnitude))
+    log_spec -= 10.0 * np.log10(np.maximum(amin, ref_value))
+    if top_db is not None:
+        if top_db < 0:
+            raise ParameterError("top_db must be non-negative")
+        log_spec = np.maximum(log_spec, log_spec.max(axis=axes, keepdims=True) - top_db)
+    return log_spec[()]
+
+
+def amplitude_to_db(S, *, ref=1.0, amin=1e-5, top_db=80.0, axes="auto"):
+    """``librosa/core/spectrum.py:2000-2038``: power_to_db(|S|**2, ref=ref**2, amin=amin**2)."""
+    magnitude = np.abs(np.asarray(S))
+    axes = _db_axes(magnitude.ndim, axes)
+    ref_value = ref(magnitude, axis=axes, keepdims=True) if callable(ref) else np.abs(ref)
+    power = np.square(magnitude)
+    return power_to_db(power, ref=ref_value**2, amin=amin**2, top_db=top_db, axes=axes)
+
+
+def db_to_power(S_db, *, ref=1.0):
+    """``librosa/core/spectrum.py:1925``."""
+    return ref * np.power(10.0, np.asarray(S_db) * 0.1)
+
+
+def db_to_amplitude(S_db, *, ref=1.0):
+    """``librosa/core/spectrum.py:2082``."""
+    return db_to_power(S_db, ref=ref**2) ** 0.5
+
+
+def mfcc(*, y=None, sr=22050, S=None, n_mfcc=20, dct_type=2, norm="ortho", lifter=0, mel_norm="slaney", **kwargs):
+    """``librosa/feature/spectral.py:1999-2019``: DCT over the mel axis of the log-power mel spectrogram (+ lifter)."""
+    if S is None:
+        S = power_to_db(melspectrogram(y=y, sr=sr, norm=mel_norm, **kwargs))
+    M = scipy.fft.dct(S, axis=-2, type=dct_type, norm=norm)[..., :n_mfcc, :]
+    if lifter > 0:
+        LI = np.sin(np.pi * np.arange(1, 1 + n_mfcc, dtype=M.dtype) / lifter)
+        LI = LI.reshape((1,) * (S.ndim - 2) + (-1, 1))
+        M *= 1 + (lifter / 2) * LI
+        return M
+    if lifter == 0:
+        return M
+    raise ParameterError(f"MFCC lifter={lifter} must be a non-negative number")
+
+
 # ----------------------------------------------------------------------------- synthetic inputs
 def config_input(batch, n=661500, sr=22050, seed=440, first_clip=0):
     """SURVEY.md 8(d) config-2/3 generator: 0.1*noise + 0.5*sin(2 pi f_i t), f_i = 110*2^((i%72)/12).

@@ -109,6 +109,16 @@ elif what == "v2b":
             ctx.set_option("stft_iters", iters)
             ms = min(timeit(lambda: ctx.stft_exec(plan, y.data_ptr(), batch, n, n, D.data_ptr())) for _ in range(3))
             print(f"{os.environ.get('LIBROSA_AMD_LIBRARY', 'product')}: remap {remap} iters {iters:3d}: stft {ms:.3f} ms ({batch * T * 10248 / ms / 1e6:5.0f} GB/s = {batch * T * 10248 / ms / 8e7:4.1f} %)", flush=True)
+elif what == "mel2":
+    # fused melspectrogram: second-generation core on / off x frames per slot
+    ctx.set_option("autotune", 0)
+    ctx.set_option("variant", 0)
+    for v2 in (0, 1):
+        ctx.set_option("v2", v2)
+        for iters in (0, 27, 41, 54, 81, 108, 162):
+            ctx.set_option("stft_iters", iters)
+            msm = min(timeit(lambda: ctx.melspectrogram_exec(plan, mel_plan, y.data_ptr(), batch, n, n, 2.0, M.data_ptr())) for _ in range(3))
+            print(f"{os.environ.get('LIBROSA_AMD_LIBRARY', 'product')}: v2 {v2} iters {iters:3d}: mel {msm:.3f} ms ({batch * T / msm / 1e3:.1f} Mframes/s)", flush=True)
 elif what == "survey":
     # other common configurations: ms and algorithmic GB/s for stft / melspectrogram / istft
     ctx.set_option("variant", -1)

@@ -23,6 +23,7 @@ template <class T> struct StftSim {
     long long* diag;
     const T* dense_basis = nullptr;  // mode 3: dense [n_mels][M+1]
     bool use_v2 = true;
+    bool mel_v2 = false;
     template <class Cfg, int MODE> void run(int iters, int shared_bytes) {
         std::vector<cx<T>> tw(Cfg::TW_TOTAL), twr(split_tw_count<Cfg>());
         build_pass_twiddles<Cfg>(tw.data());
@@ -45,11 +46,13 @@ template <class T> struct StftSim {
             if constexpr (sizeof(typename Cfg::real) == 4) ra = ring_rows_aligned<Cfg>(a.hop) && !std::getenv("LRA_SIM_NO_RA");
             // second-generation kernel body (lra_kernels2.h), same selection as StftLaunch::launch
             bool v2 = false;
-            if constexpr (v2_cfg_ok<Cfg>() && (MODE == OUT_COMPLEX || MODE == OUT_POWER)) {
-                const int hd = use_v2 ? v2_hop_divisor<Cfg>(a.hop) : 0;
+            if constexpr (v2_cfg_ok<Cfg>() && (MODE == OUT_COMPLEX || MODE == OUT_POWER || MODE == OUT_MELR)) {
+                const int hd = (use_v2 && (MODE != OUT_MELR || mel_v2)) ? v2_hop_divisor<Cfg>(a.hop) : 0;
                 if (hd) {
                     v2 = true;
-                    st.resize(Cfg::FPB * stft2_slot_bytes<Cfg>());
+                    a.slot_bytes = stft2_slot_bytes<Cfg>();
+                    a.shared_off = Cfg::FPB * a.slot_bytes;
+                    st.resize(Cfg::FPB * stft2_slot_bytes<Cfg>() + shared_bytes);
 #define SIM_V2(HD)                                                                                             \
     if (a.power_mode == POW_TWO) stft_block2<Cfg, HD, MODE, POW_TWO>(a, (int)blk, lds);                        \
     else if (a.power_mode == POW_ONE) stft_block2<Cfg, HD, MODE, POW_ONE>(a, (int)blk, lds);                   \
@@ -89,7 +92,10 @@ template <class T> struct StftSim {
             using MC = typename MelCfgOf<Cfg>::type;
             TwoSlope<T> ts = build_two_slope<T>(dense_basis, a.n_mels, Cfg::M + 1);
             if (!ts.ok || !melr_fits<MC>()) { diag[7] = 1; return; }
-            MelRuns<T> mr = build_mel_runs<T>(ts, MC::TF, MC::R / 2, MELR_PMAX, FftRegs<MC>::MELR_PHOIST);
+            bool v2m = false;
+            if constexpr (v2_cfg_ok<MC>()) v2m = use_v2 && v2_hop_divisor<MC>(a.hop) > 0;
+            mel_v2 = v2m;
+            MelRuns<T> mr = build_mel_runs<T>(ts, MC::TF, MC::R / 2, MELR_PMAX, FftRegs<MC>::MELR_PHOIST, v2m ? 1 : 0);
             if (!mr.ok) { diag[7] = 2; return; }
             a.melr_w = mr.w.data(); a.melr_keep = mr.keep.data(); a.melr_addr = mr.addr.data(); a.melr_zero = mr.zero_addr; a.melr_mid = mr.mid_addr; a.melr_pmax = mr.pmax;
             diag[9] = mr.max_pieces;

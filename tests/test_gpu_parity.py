@@ -516,3 +516,89 @@ def test_multi_resolution_stack(L, full_batch):
     yi = y[3].cpu().numpy()
     for n, o in zip((512, 2048, 8192), outs):
         assert _stft_close(o[3].cpu().numpy(), O.stft(yi, n_fft=n, hop_length=512))
+
+
+# ---------------------------------------------------------------------------------------------------
+# 5. decibel scaling and MFCC
+# ---------------------------------------------------------------------------------------------------
+# Tolerances: dB values are 10 log10 of float32 powers: one ulp of the logarithm's argument moves the result by 4e-7 dB and
+# the device's log10f differs from NumPy's by a few ulp of the RESULT (|dB| <= 150): |d| <= 5e-5 dB.  MFCC sums 40..128
+# such values with O(1) weights: |d| <= 2e-4 + 1e-5 |ref|.
+DB_TOL = 5e-5
+
+
+def _mfcc_close(a, ref):
+    return np.all(np.abs(a - ref) <= 2e-4 + 1e-5 * np.abs(ref))
+
+
+def test_db_golden(L):
+    g = np.load(os.path.join(GOLDEN_DIR, "db_mfcc.npz"))
+    M, A = g["M"], g["A"]
+    cases = [
+        (L.power_to_db(M), "db_default"),
+        (L.power_to_db(M, ref=np.max), "db_refmax"),
+        (L.power_to_db(M, top_db=None, amin=1e-6, ref=2.5), "db_notop"),
+        (L.power_to_db(M, ref=np.median, top_db=30.0), "db_median_top30"),
+        (L.power_to_db(M, ref=np.max, axes=-1, top_db=40.0), "db_axes_last"),
+        (L.power_to_db(M, ref=np.max, axes=None), "db_axes_none"),
+        (L.amplitude_to_db(A), "adb_default"),
+        (L.amplitude_to_db(A, ref=np.max, top_db=60.0), "adb_refmax"),
+    ]
+    for out, key in cases:
+        assert out.shape == g[key].shape and out.dtype == g[key].dtype, key
+        assert np.abs(out - g[key]).max() <= DB_TOL, (key, np.abs(out - g[key]).max())
+    P = L.db_to_power(g["db_notop"], ref=2.5)
+    assert np.all(np.abs(P - g["pow_back"]) <= 2e-6 * np.abs(g["pow_back"]))
+    Ab = L.db_to_amplitude(O.amplitude_to_db(A, top_db=None), ref=1.0)
+    assert np.all(np.abs(Ab - g["amp_back"]) <= 2e-6 * np.abs(g["amp_back"]) + 1e-12)
+    # scalars, 1-d input, float64
+    assert abs(float(L.power_to_db(np.float32(0.5))) - float(O.power_to_db(np.float32(0.5)))) <= DB_TOL
+    v = np.abs(np.random.default_rng(0).standard_normal(1000)) ** 2
+    assert np.abs(L.power_to_db(v, ref=np.max) - O.power_to_db(v, ref=np.max)).max() <= 1e-10
+    with pytest.raises(L.ParameterError):
+        L.power_to_db(M, amin=0)
+    with pytest.raises(L.ParameterError):
+        L.power_to_db(M, top_db=-1)
+    with pytest.warns(UserWarning, match="phase"):
+        L.power_to_db((M + 1j * M).astype(np.complex64))
+
+
+def test_mfcc_golden(L):
+    g = np.load(os.path.join(GOLDEN_DIR, "db_mfcc.npz"))
+    S = g["db_default"]
+    for out, key in [
+        (L.feature.mfcc(S=S, n_mfcc=13), "mfcc_S"),
+        (L.feature.mfcc(S=S, n_mfcc=20, dct_type=3, lifter=22), "mfcc_S_t3_lift"),
+        (L.feature.mfcc(S=S, n_mfcc=12, dct_type=1, norm=None), "mfcc_S_t1_none"),
+        (L.feature.mfcc(y=g["y"], sr=22050, n_mfcc=20, n_fft=1024, hop_length=256, n_mels=40), "mfcc_y"),
+        (L.feature.mfcc(y=g["y2"], sr=22050), "mfcc_y2_default"),
+        (L.feature.mfcc(y=g["y2"], sr=22050, n_mfcc=13, lifter=26, htk=True, n_mels=64, fmax=8000.0), "mfcc_y2_htk_lift"),
+    ]:
+        assert out.shape == g[key].shape and out.dtype == g[key].dtype, key
+        assert _mfcc_close(out, g[key]), (key, np.abs(out - g[key]).max())
+    with pytest.raises(L.ParameterError):
+        L.feature.mfcc(S=S, lifter=-2)
+
+
+def test_db_mfcc_device_tensors_and_batches(L):
+    """Device tensors stay on the device; a batch is scaled per clip (axes="auto"), exactly like clip-by-clip calls."""
+    import torch
+
+    yh = O.config_input(3, n=22050 * 2)
+    y = torch.from_numpy(yh).cuda()
+    M = L.feature.melspectrogram(y=y, sr=22050)
+    Mdb = L.power_to_db(M, ref=np.max)
+    assert isinstance(Mdb, torch.Tensor) and Mdb.is_cuda and tuple(Mdb.shape) == tuple(M.shape)
+    ref = O.power_to_db(O.melspectrogram(y=yh, sr=22050), ref=np.max)
+    assert np.abs(Mdb.cpu().numpy() - ref).max() <= 2e-4  # includes the mel kernel's own 1e-6 relative error near the -80 dB floor
+    C = L.feature.mfcc(y=y, sr=22050)
+    assert isinstance(C, torch.Tensor) and tuple(C.shape) == (3, 20, M.shape[-1])
+    Cref = O.mfcc(y=yh, sr=22050)
+    assert np.all(np.abs(C.cpu().numpy() - Cref) <= 5e-4 + 1e-5 * np.abs(Cref))
+    for i in range(3):
+        Ci = L.feature.mfcc(y=yh[i], sr=22050)
+        assert np.array_equal(Ci, C[i].cpu().numpy())
+    # many coefficients: more than one group of 128 basis rows
+    S = torch.randn(2, 200, 50, device="cuda")
+    big = L.feature.mfcc(S=S, n_mfcc=150)
+    assert _mfcc_close(big.cpu().numpy(), O.mfcc(S=S.cpu().numpy(), n_mfcc=150))

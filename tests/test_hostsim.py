@@ -144,6 +144,24 @@ def test_power_and_mel_body(n_fft, hop, power, n_mels, dtype, variant):
         assert np.all(np.abs(M4 - Mref) <= 1e-5 * np.abs(Mref) + 1e-5 * Mref.max())
 
 
+@pytest.mark.parametrize("n_fft,hop,power,n_mels,iters,n,v2", [(2048, 512, 2.0, 128, 3, 9000, 1), (2048, 512, 1.0, 128, 9, 30000, 1), (2048, 512, 2.0, 40, 4, 9000, 1), (2048, 1024, 2.0, 128, 3, 9000, 1),
+                                                               (2048, 256, 1.6, 64, 5, 9000, 1), (1024, 256, 2.0, 40, 6, 9000, 1), (2048, 512, 2.0, 128, 3, 9000, 0), (1024, 256, 1.0, 40, 3, 9000, 0)])
+def test_mel_body_run_ordered_both_generations(n_fft, hop, power, n_mels, iters, n, v2, monkeypatch):
+    """OUT_MELR on the second-generation core (power row in LDS, lra_kernels2.h) and on the first-generation one."""
+    if not v2:
+        monkeypatch.setenv("LRA_SIM_NO_V2", "1")
+    rng = np.random.default_rng(n_fft + n_mels)
+    y = rng.standard_normal((3, n)).astype(np.float32)
+    win = O.get_window("hann", n_fft)
+    B = O.mel(sr=22050, n_fft=n_fft, n_mels=n_mels)
+    M4, d4 = H.stft(y, n_fft, hop, win, mode=4, power=power, mel_basis=B, iters_per_wg=iters)
+    assert M4 is not None, d4
+    assert d4["v2"] == v2
+    _check_diag(d4)
+    Mref = O.melspectrogram(y=y, sr=22050, n_fft=n_fft, hop_length=hop, power=power, n_mels=n_mels)
+    assert np.all(np.abs(M4 - Mref) <= 1e-5 * np.abs(Mref) + 1e-5 * Mref.max())
+
+
 def _istft_inputs(y, n_fft, hop, center, length, window="hann", win_length=None):
     D = O.stft(y, n_fft=n_fft, hop_length=hop, center=center, window=window, win_length=win_length)
     ref = O.istft(D, hop_length=hop, n_fft=n_fft, center=center, length=length, window=window, win_length=win_length)

@@ -220,3 +220,28 @@ def test_oracle_vs_live_reference(seed):
     np.testing.assert_allclose(M0, M1, rtol=1e-5, atol=1e-6 * M0.max())
     wss0 = librosa.filters.window_sumsquare(window="hann", n_frames=17, hop_length=hop, n_fft=n_fft)
     assert np.array_equal(wss0, O.window_sumsquare(window="hann", n_frames=17, hop_length=hop, n_fft=n_fft))
+
+
+def test_db_and_mfcc_oracle_matches_reference_goldens():
+    """the restated power_to_db / amplitude_to_db / db_to_* / mfcc against outputs of the unmodified
+    reference (tests/golden/db_mfcc.npz, oracle/make_golden.py::make_db_mfcc)."""
+    g = np.load(os.path.join(GOLDEN_DIR, "db_mfcc.npz"))
+    M, A, y, y2 = g["M"], g["A"], g["y"], g["y2"]
+    assert np.array_equal(O.power_to_db(M), g["db_default"])
+    assert np.array_equal(O.power_to_db(M, ref=np.max), g["db_refmax"])
+    assert np.array_equal(O.power_to_db(M, top_db=None, amin=1e-6, ref=2.5), g["db_notop"])
+    assert np.array_equal(O.power_to_db(M, ref=np.median, top_db=30.0), g["db_median_top30"])
+    assert np.array_equal(O.power_to_db(M, ref=np.max, axes=-1, top_db=40.0), g["db_axes_last"])
+    assert np.array_equal(O.power_to_db(M, ref=np.max, axes=None), g["db_axes_none"])
+    assert np.array_equal(O.amplitude_to_db(A), g["adb_default"])
+    assert np.array_equal(O.amplitude_to_db(A, ref=np.max, top_db=60.0), g["adb_refmax"])
+    assert np.array_equal(O.db_to_power(g["db_notop"], ref=2.5), g["pow_back"])
+    assert np.array_equal(O.mfcc(S=g["db_default"], n_mfcc=13), g["mfcc_S"])
+    assert np.array_equal(O.mfcc(S=g["db_default"], n_mfcc=20, dct_type=3, lifter=22), g["mfcc_S_t3_lift"])
+    assert np.array_equal(O.mfcc(S=g["db_default"], n_mfcc=12, dct_type=1, norm=None), g["mfcc_S_t1_none"])
+    assert np.array_equal(O.mfcc(y=y, sr=22050, n_mfcc=20, n_fft=1024, hop_length=256, n_mels=40), g["mfcc_y"])
+    assert np.array_equal(O.mfcc(y=y2, sr=22050), g["mfcc_y2_default"])
+    with pytest.raises(O.ParameterError):
+        O.power_to_db(M, amin=0)
+    with pytest.raises(O.ParameterError):
+        O.mfcc(S=g["db_default"], lifter=-1)
