@@ -1,34 +1,41 @@
 #!/usr/bin/env python
 """bench.py -- STFT+mel frames/sec on MI355X (BASELINE.json metric), one process per GPU.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path -- feature.melspectrogram (fused framing + window + FFT +
-|X|^2 + banded mel, one kernel launch) -- over one batch of synthetic 22.05 kHz clips already
-resident in HBM: BASELINE.json configs[1], batch=256 clips x 30 s, n_fft=2048 hop=512 n_mels=128,
-per GPU (weak scaling: clips are independent, every rank gets its own 256, no data-path collective).
-Plans/tables are created outside the timed region.  The timed region is bracketed by a
+A "step" is one pass of the hot path -- feature.melspectrogram (fused framing + window + FFT + |X|^2 + two-slope mel,
+one kernel launch) -- over one batch of synthetic 22.05 kHz clips already resident in HBM.  Workload:
+  N = 1   BASELINE.json configs[1]: 256 clips x 30 s, n_fft=2048 hop=512 n_mels=128;
+  N > 1   BASELINE.json configs[2]'s split: 512 clips per GPU (4096 clips at N = 8), clip i on GPU i // 512, no collective
+          on the data path; `value` is the sharded-output rate, `gathered` the rate with every rank holding the full
+          (N x 512, 128, 1292) result, the gather (RCCL over xGMI) travelling in chunks of clips behind the compute.
+Plans/tables are created outside the timed region.  The timed region is EXACTLY --steps steps bracketed by a
 barrier + device synchronize on both sides; the max over ranks is reported.
 
-Extra keys on the JSON line:
-  roofline       dominant kernel of the step (the fused mel kernel): algorithmic bytes / HIP-event time
-  roofline_stft  the complex64-out STFT kernel on the same input (the north star's >=70 %-of-HBM bar
-                 is attached to this kernel: 10 248 B/frame), timed in the same process
-  roofline_istft the inverse on the STFT's output (BASELINE configs[3]; round-trip SNR included)
-  roofline_valu  the fused mel kernel against the f32 vector peak (it sits on the compute side of the ridge)
-  cqt_lite       BASELINE configs[4]: STFTs at n_fft 512 / 2048 / 8192 over the same batch (N=1 only)
-  kernel_variants  which n_fft=2048 tuning the plans settled on (first-call autotune)
-  cpu_baseline   the NumPy/scipy.fft oracle (a port of the reference path) on this box's host cores,
-                 rank 0 at N=1 only, on a bounded sample of the same workload (one core); cpu_baseline_all_cores
-                 = the same with one independent process per core (up to 64)
+Extra keys on the JSON line (rank 0):
+  roofline        dominant kernel of the step (the fused mel kernel): algorithmic bytes / HIP-event time, + HBM traffic from
+                  the newest profiles/*_traffic.json (rocprofv3 PMC passes, scripts/profile_round.sh)
+  roofline_stft   the complex64-out STFT kernel on the same input (north-star bar: >= 70 % of HBM, 10 248 B/frame)
+  roofline_istft  the inverse on the STFT's output (BASELINE configs[3]; round-trip SNR included)
+  roofline_valu   the fused mel kernel against the f32 vector peak (it sits on the compute side of the ridge)
+  repeats         min / median ms per step over 5 more repeats of the timed region (box-to-box and run-to-run spread)
+  parity          max relative error of a sampled clip's mel spectrogram against the CPU oracle (same input, downloaded)
+  dropin_torch    the PUBLIC drop-in (librosa_amd.feature.melspectrogram on a device tensor: validation, plan cache, lock)
+  end_to_end_numpy  the public drop-in on NumPy input: H2D + kernel + D2H (PCIe-bound; informative, never `value`)
+  power_to_db / mfcc  the SURVEY 8(f) consumers on the same batch (device tensors)
+  cqt_lite        BASELINE configs[4]: STFTs at n_fft 512 / 2048 / 8192 over the same batch (N=1 only)
+  cpu_baseline    the NumPy/scipy.fft oracle (a port of the reference path) on this box's host cores, rank 0 at N=1 only, on
+                  a bounded sample of the same workload (one core); cpu_baseline_all_cores = one independent process per core
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import platform
+import statistics
 import sys
 import time
 
@@ -39,7 +46,7 @@ sys.path.insert(0, ROOT)
 
 SR, N_FFT, HOP, N_MELS = 22050, 2048, 512, 128
 CLIP_SECONDS = 30
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured on the chip: plain copy 4.8 TB/s, this kernel's store stream 4.7
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); what this access mix reaches without arithmetic: profiles/r02_store_stream.md
 BYTES_PER_FRAME_MEL = HOP * 4 + N_MELS * 4            # 2 560 B: PCM read once + mel written once
 BYTES_PER_FRAME_STFT = HOP * 4 + (N_FFT // 2 + 1) * 8  # 10 248 B: PCM read once + complex64 spectrum written once
 
@@ -56,8 +63,34 @@ def make_batch(torch, batch, n, first_clip, device):
     return y.clamp_(-1.0, 1.0).contiguous()
 
 
-def cpu_baseline(seconds=12.0):
-    """Oracle (NumPy restatement of the reference path, oracle/stft_oracle.py) timed on this host, 1 core."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or platform.machine()
+
+
+def _host_versions():
+    import scipy
+
+    v = {"numpy": np.__version__, "scipy": scipy.__version__, "python": platform.python_version(), "cpu_model": _cpu_model(), "logical_cores": os.cpu_count()}
+    try:
+        from threadpoolctl import threadpool_info
+
+        v["blas"] = sorted({f"{i.get('internal_api')} {i.get('version')}" for i in threadpool_info() if i.get("user_api") == "blas"})
+    except Exception:  # pragma: no cover
+        pass
+    return v
+
+
+def cpu_baseline(seconds=12.0, parity_clip=None):
+    """Oracle (NumPy restatement of the reference path, oracle/stft_oracle.py) timed on this host, 1 core.
+
+    ``parity_clip = (y_host, M_gpu_host)``: the same leg also checks the timed kernel's output for that clip."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import stft_oracle as O
 
@@ -80,14 +113,29 @@ def cpu_baseline(seconds=12.0):
             frames += M.shape[-1]
             clips += 1
     dt = time.perf_counter() - t0
-    return {
+    out = {
         "value": frames / dt,
         "unit": "frames/s",
         "cores": 1,
         "kind": "port",
         "sample": f"{clips} clips x {CLIP_SECONDS} s melspectrogram (n_fft={N_FFT} hop={HOP} n_mels={N_MELS}) in {dt:.1f} s, "
-                  f"1 process, BLAS limited to 1 thread; host has {os.cpu_count()} logical cores",
+                  f"1 process, BLAS limited to 1 thread",
+        "host": _host_versions(),
     }
+    # the port against the reference itself, measured where the reference tree exists (the build container), committed
+    try:
+        ratio = json.load(open(os.path.join(ROOT, "profiles", "cpu_port_vs_reference.json")))
+        out["port_vs_reference"] = ratio
+    except Exception:
+        pass
+    parity = None
+    if parity_clip is not None:
+        yh, Mg = parity_clip
+        Mref = O.melspectrogram(y=yh, sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS)
+        rel = np.abs(Mg - Mref) / np.abs(Mref)
+        parity = {"mel_max_rel_err": float(rel.max()), "mel_max_abs_err_over_max": float(np.abs(Mg - Mref).max() / Mref.max()), "bar": 1e-4,
+                  "sample": "clip 0 of the timed batch (downloaded), all 128 x 1292 values, pure relative error |d| / |ref|"}
+    return out, parity
 
 
 def _cpu_worker(seconds):
@@ -128,10 +176,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=256, help="clips per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: 256 at N=1 = configs[1], 512 at N>1 = configs[2]'s split)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cqt", action="store_true", help="skip the CQT-lite (config 5) side measurement")
-    ap.add_argument("--sweep", action="store_true", help="time kernel tuning variants (development aid), prints extra lines to stderr")
+    ap.add_argument("--no-side", action="store_true", help="skip every side measurement (profiling runs)")
+    ap.add_argument("--gather-chunks", type=int, default=4, help="pieces the shard travels in during the `gathered` measurement (N>1)")
     ap.add_argument("--variant", type=int, default=None)
     ap.add_argument("--iters", type=int, default=None)
     args = ap.parse_args()
@@ -140,6 +189,7 @@ def main():
 
     import librosa_amd as L
     from librosa_amd import filters
+    from librosa_amd.distributed import ShardedGather, chunk_ranges
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -154,7 +204,7 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=backend)  # nccl = RCCL; used for the barriers and the max-over-ranks of the timing only
+        dist.init_process_group(backend=backend)  # nccl = RCCL: barriers, the max-over-ranks of the timing, and the `gathered` measurement
 
     def barrier():
         if world > 1:
@@ -162,8 +212,8 @@ def main():
         torch.cuda.synchronize(device)
 
     n = SR * CLIP_SECONDS
-    batch = args.batch
-    y = make_batch(torch, batch, n, rank * batch, device)
+    batch = args.batch if args.batch else (256 if world == 1 else 512)
+    total_clips = batch * world
     ctx = L.get_context(dev_index)
     ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
     if args.variant is not None:
@@ -176,30 +226,18 @@ def main():
     n_frames = ctx.stft_num_frames(plan, n)
     frames_per_step = batch * n_frames
     M = torch.empty((batch, N_MELS, n_frames), dtype=torch.float32, device=device)
-    D = torch.empty((batch, n_frames, N_FFT // 2 + 1), dtype=torch.complex64, device=device)
-    yp, Mp, Dp = y.data_ptr(), M.data_ptr(), D.data_ptr()
+    # the synthetic input is generated LAST, right before the warm-up: plan / table construction above is host work during
+    # which an idle GPU drops to its low power state, and the first few milliseconds after that run ~10 % slow
+    y = make_batch(torch, batch, n, rank * batch, device)  # clip i of the job lives on rank i // batch
+    yp, Mp = y.data_ptr(), M.data_ptr()
 
     def step_mel():
         ctx.melspectrogram_exec(plan, mel_plan, yp, batch, n, n, 2.0, Mp)
 
-    def step_stft():
-        ctx.stft_exec(plan, yp, batch, n, n, Dp)
-
-    # ISTFT (BASELINE config 4: stft -> istft round trip); the window sum-square comes from the host
-    iplan = ctx.istft_plan(N_FFT, HOP, window, True, np.float32)
-    wss_host = filters.window_sumsquare(window="hann", n_frames=n_frames, n_fft=N_FFT, hop_length=HOP, dtype=np.float32)[N_FFT // 2 :]
-    wss_host = np.ascontiguousarray(np.pad(wss_host, (0, max(0, n - len(wss_host))))[:n], dtype=np.float32)
-    wss = torch.from_numpy(wss_host).to(device)
-    yrec = torch.empty((batch, n), dtype=torch.float32, device=device)
-    n_bins = N_FFT // 2 + 1
-
-    def step_istft():
-        ctx.istft_exec(iplan, Dp, batch, n_frames * n_bins, n_bins, n_frames, wss.data_ptr(), yrec.data_ptr(), n, n)
-
-    def timed(fn, steps, warmup):
+    def timed(fn, steps, warmup, collective=True):
         for _ in range(warmup):
             fn()
-        barrier()
+        barrier() if collective else torch.cuda.synchronize(device)
         e0, e1 = ctx.event(), ctx.event()
         t0 = time.perf_counter()
         e0.record()
@@ -208,63 +246,150 @@ def main():
         e1.record()
         torch.cuda.synchronize(device)
         wall = time.perf_counter() - t0
-        barrier()
+        if collective:
+            barrier()
         return wall, e0.elapsed_ms(e1) / 1e3
 
-    if args.sweep and world == 1:
-        for variant in (0, 1, 4):
-            for iters in (4, 8, 16, 32, 64):
-                ctx.set_option("variant", variant)
-                ctx.set_option("stft_iters", iters)
-                _, ev_m = timed(step_mel, args.steps, 3)
-                _, ev_s = timed(step_stft, args.steps, 3)
-                fm, fs = frames_per_step * args.steps / ev_m, frames_per_step * args.steps / ev_s
-                print(f"[sweep] variant={variant} iters={iters:2d}  mel {fm / 1e6:8.1f} Mframes/s ({fm * BYTES_PER_FRAME_MEL / 1e9:7.0f} GB/s)   "
-                      f"stft {fs / 1e6:8.1f} Mframes/s ({fs * BYTES_PER_FRAME_STFT / 1e9:7.0f} GB/s = {fs * BYTES_PER_FRAME_STFT / 1e9 / HBM_PEAK_GBS:.1%} of HBM peak)",
-                      file=sys.stderr, flush=True)
-        ctx.set_option("variant", args.variant if args.variant is not None else -1)
-        ctx.set_option("stft_iters", args.iters or 0)
-
+    # ---- the timed region of the contract: exactly --steps steps, barrier + synchronize on both sides, max over ranks -------
     wall, ev = timed(step_mel, args.steps, args.warmup)
     if world > 1:
         tw = torch.tensor([wall], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
-    _, ev_stft = timed(step_stft, args.steps, args.warmup)
-    _, ev_istft = timed(step_istft, args.steps, args.warmup)
-    # BASELINE config 5 (CQT-lite): three STFTs at n_fft = 512 / 2048 / 8192 over the same batch, shared hop 512
-    cqt = None
-    if world == 1 and not args.no_cqt:  # single-GPU runs only: timed() contains collective barriers
+    # five more repeats of the same region (no collectives): run-to-run spread
+    rep = [timed(step_mel, args.steps, 0, collective=False)[1] / args.steps * 1e3 for _ in range(5)]
+
+    side = {}
+
+    def measure(name, fn):
+        """A side measurement never breaks the contract line."""
+        if args.no_side:
+            return
         try:
-            parts = {}
-            total_s = 0.0
-            for nf in (512, 2048, 8192):
-                w = np.asarray(filters.get_window("hann", nf, fftbins=True), dtype=np.float32)
-                pl = plan if nf == N_FFT else ctx.stft_plan(nf, HOP, w, True, "constant", np.float32)
-                T_nf = ctx.stft_num_frames(pl, n)
-                Dn = D if nf == N_FFT else torch.empty((batch, T_nf, nf // 2 + 1), dtype=torch.complex64, device=device)
-                _, ev_n = timed(lambda: ctx.stft_exec(pl, yp, batch, n, n, Dn.data_ptr()), max(3, args.steps // 2), 2)
-                per = ev_n / max(3, args.steps // 2)
-                bytes_n = batch * T_nf * ((nf // 2 + 1) * 8 + HOP * 4)
-                parts[str(nf)] = {"ms": per * 1e3, "GBps": bytes_n / per / 1e9}
-                total_s += per
-                del Dn
-            cqt = {"workload": f"3 STFTs n_fft=512/2048/8192, hop=512, batch={batch} x {CLIP_SECONDS} s (BASELINE config 5)", "per_n_fft": parts, "ms_total": total_s * 1e3,
-                   "frame_triples_per_s": frames_per_step / total_s}
-        except Exception as exc:  # never let the side measurement break the contract line
-            cqt = {"error": repr(exc)}
+            side[name] = fn()
+        except Exception as exc:  # pragma: no cover
+            side[name] = {"error": repr(exc)}
+
+    # ---- N > 1: the same step with every rank ending up with the full result (chunked gather behind the compute) --------------
+    if world > 1 and not args.no_side:
+        pieces = chunk_ranges(batch, args.gather_chunks)
+
+        def step_gathered():
+            g = ShardedGather(M, total_clips)
+            for lo, hi in pieces:
+                ctx.melspectrogram_exec(plan, mel_plan, yp + lo * n * 4, hi - lo, n, n, 2.0, Mp + lo * N_MELS * n_frames * 4)
+                g.push(lo, hi, M[lo:hi])  # async: travels while the next piece is computed
+            return g.wait()
+
+        g_steps = max(3, min(10, args.steps // 5))
+        g_wall, _ = timed(step_gathered, g_steps, 2)
+        tw = torch.tensor([g_wall], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        g_wall = float(tw.item())
+        full = step_gathered()
+        ok = bool(torch.equal(full[rank * batch : (rank + 1) * batch], M))
+        side["gathered"] = {"value": frames_per_step * world * g_steps / g_wall, "unit": "frames/s", "ms_per_step": g_wall / g_steps * 1e3, "steps": g_steps, "chunks": len(pieces),
+                            "bytes_per_rank": batch * N_MELS * n_frames * 4, "backend": backend, "own_rows_match": ok,
+                            "what": "every rank holds the full (N x clips, 128, frames) mel tensor; the shard is computed and all-gathered in chunks of clips (librosa_amd.distributed.ShardedGather)"}
+        del full
+
+    # ---- single-GPU side measurements (their timing helpers contain no collectives) -------------------------------------------
     snr_db = None
-    if rank == 0:
-        err = (y[:8] - yrec[:8]).double().pow(2).sum(dim=1)
-        snr_db = float((10 * torch.log10(y[:8].double().pow(2).sum(dim=1) / err)).min().item())
+    if world == 1 and not args.no_side:
+        D = torch.empty((batch, n_frames, N_FFT // 2 + 1), dtype=torch.complex64, device=device)
+        Dp = D.data_ptr()
+        n_bins = N_FFT // 2 + 1
+        iplan = ctx.istft_plan(N_FFT, HOP, window, True, np.float32)
+        wss_host = filters.window_sumsquare(window="hann", n_frames=n_frames, n_fft=N_FFT, hop_length=HOP, dtype=np.float32)[N_FFT // 2 :]
+        wss_host = np.ascontiguousarray(np.pad(wss_host, (0, max(0, n - len(wss_host))))[:n], dtype=np.float32)
+        wss = torch.from_numpy(wss_host).to(device)
+        yrec = torch.empty((batch, n), dtype=torch.float32, device=device)
+
+        def roof(fn, bytes_per_frame, kernel):
+            _, e = timed(fn, args.steps, args.warmup, collective=False)
+            s = e / args.steps
+            ach = frames_per_step * bytes_per_frame / s / 1e9
+            return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "bytes_per_frame": bytes_per_frame, "launch_ms": s * 1e3, "frames_per_s_single_gpu": frames_per_step / s}
+
+        measure("roofline_stft", lambda: roof(lambda: ctx.stft_exec(plan, yp, batch, n, n, Dp), BYTES_PER_FRAME_STFT,
+                                              "stft2_kernel<n_fft=2048, OUT_COMPLEX> (librosa.stft, complex64 out)"))
+        measure("roofline_istft", lambda: roof(lambda: ctx.istft_exec(iplan, Dp, batch, n_frames * n_bins, n_bins, n_frames, wss.data_ptr(), yrec.data_ptr(), n, n), BYTES_PER_FRAME_STFT,
+                                               "istft_kernel<n_fft=2048> (librosa.istft: c2r FFT + window + overlap-add + wss normalise)"))
+        try:
+            err = (y[:8] - yrec[:8]).double().pow(2).sum(dim=1)
+            snr_db = float((10 * torch.log10(y[:8].double().pow(2).sum(dim=1) / err)).min().item())
+            side["roofline_istft"]["round_trip_snr_db_min"] = snr_db
+        except Exception:
+            pass
+        del yrec
+
+        def public_torch():
+            fn = lambda: L.feature.melspectrogram(y=y, sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS, check_finite=False)
+            _, e = timed(fn, 10, 3, collective=False)
+            fn2 = lambda: L.feature.melspectrogram(y=y, sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS)
+            _, e2 = timed(fn2, 10, 3, collective=False)
+            return {"ms_per_call": e / 10 * 1e3, "frames_per_s": frames_per_step / (e / 10), "ms_per_call_with_finite_check": e2 / 10 * 1e3,
+                    "what": "librosa_amd.feature.melspectrogram(y=<device tensor>): argument validation, plan-cache lookup, per-context lock, output allocation + the kernel"}
+
+        measure("dropin_torch", public_torch)
+
+        def public_numpy():
+            nb = 64  # a quarter of the batch: 169 MB up, 42 MB down
+            yh = y[:nb].cpu().numpy()
+            L.feature.melspectrogram(y=yh[:2], sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS)
+            t0 = time.perf_counter()
+            Mh = L.feature.melspectrogram(y=yh, sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS)
+            dt = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            Dh = L.stft(yh, n_fft=N_FFT, hop_length=HOP)
+            dts = time.perf_counter() - t0
+            return {"melspectrogram": {"clips": nb, "ms": dt * 1e3, "frames_per_s": nb * n_frames / dt, "host_bytes": int(yh.nbytes + Mh.nbytes)},
+                    "stft": {"clips": nb, "ms": dts * 1e3, "frames_per_s": nb * n_frames / dts, "host_bytes": int(yh.nbytes + Dh.nbytes)},
+                    "what": "public drop-in on np.ndarray: host finite scan + H2D + kernel + D2H over PCIe; informative only"}
+
+        measure("end_to_end_numpy", public_numpy)
+
+        def db_and_mfcc():
+            out = {}
+            fn = lambda: L.power_to_db(M, ref=np.max)
+            _, e = timed(fn, 10, 3, collective=False)
+            out["power_to_db"] = {"ms_per_call": e / 10 * 1e3, "GBps": 2 * M.numel() * 4 / (e / 10) / 1e9, "what": "power_to_db(M, ref=np.max) on the mel batch: per-clip max reduction + one elementwise pass (reads M twice, writes once)"}
+            fn = lambda: L.feature.mfcc(y=y, sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS, check_finite=False)
+            _, e = timed(fn, 10, 3, collective=False)
+            out["mfcc"] = {"ms_per_call": e / 10 * 1e3, "frames_per_s": frames_per_step / (e / 10), "what": "feature.mfcc(y=<device tensor>): fused mel kernel + per-clip max + DCT kernel with the dB scaling fused into its read (20 coefficients)"}
+            return out
+
+        measure("post", db_and_mfcc)
+        # BASELINE config 5 (CQT-lite): three STFTs at n_fft = 512 / 2048 / 8192 over the same batch, shared hop 512
+        if not args.no_cqt:
+            def cqt_lite():
+                parts = {}
+                total_s = 0.0
+                for nf in (512, 2048, 8192):
+                    w = np.asarray(filters.get_window("hann", nf, fftbins=True), dtype=np.float32)
+                    pl = plan if nf == N_FFT else ctx.stft_plan(nf, HOP, w, True, "constant", np.float32)
+                    T_nf = ctx.stft_num_frames(pl, n)
+                    Dn = D if nf == N_FFT else torch.empty((batch, T_nf, nf // 2 + 1), dtype=torch.complex64, device=device)
+                    _, ev_n = timed(lambda: ctx.stft_exec(pl, yp, batch, n, n, Dn.data_ptr()), max(3, args.steps // 2), 2, collective=False)
+                    per = ev_n / max(3, args.steps // 2)
+                    bytes_n = batch * T_nf * ((nf // 2 + 1) * 8 + HOP * 4)
+                    parts[str(nf)] = {"ms": per * 1e3, "GBps": bytes_n / per / 1e9}
+                    total_s += per
+                    del Dn
+                return {"workload": f"3 STFTs n_fft=512/2048/8192, hop=512, batch={batch} x {CLIP_SECONDS} s (BASELINE config 5)", "per_n_fft": parts, "ms_total": total_s * 1e3,
+                        "frame_triples_per_s": frames_per_step / total_s}
+
+            measure("cqt_lite", cqt_lite)
+        del D
 
     if rank == 0:
         total_frames = frames_per_step * args.steps * world
         value = total_frames / wall
         launch_s = ev / args.steps
         achieved = frames_per_step * BYTES_PER_FRAME_MEL / launch_s / 1e9
-        stft_launch_s = ev_stft / args.steps
-        achieved_stft = frames_per_step * BYTES_PER_FRAME_STFT / stft_launch_s / 1e9
+        split = (f"BASELINE configs[1]: batch={batch} clips x {CLIP_SECONDS} s on 1 GPU" if world == 1 else
+                 f"BASELINE configs[2]'s split: {batch} clips x {CLIP_SECONDS} s per GPU, {total_clips} clips on {world} GPUs (clip i on GPU i // {batch})")
         line = {
             "metric": "STFT+mel frames/sec (n_fft=2048 hop=512)",
             "value": value,
@@ -278,39 +403,37 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"feature.melspectrogram: batch={batch} clips x {CLIP_SECONDS} s @ 22.05 kHz per GPU, n_fft={N_FFT} hop={HOP} n_mels={N_MELS}, "
-                                   f"inputs resident in HBM, outputs left sharded (no gather)", "frames_per_step_per_gpu": frames_per_step,
+            "config": {"workload": f"feature.melspectrogram, {split}, @ 22.05 kHz, n_fft={N_FFT} hop={HOP} n_mels={N_MELS}, inputs resident in HBM, outputs left sharded "
+                                   f"(`gathered`: all-gathered)", "frames_per_step_per_gpu": frames_per_step, "clips_per_gpu": batch,
                        "parallelism": f"clips sharded over {world} GPU(s), no collective on the data path", "device": ctx.device_name()},
-            "roofline": {"bound": "hbm", "kernel": "stft_kernel<n_fft=2048, OUT_MEL> (fused melspectrogram)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "stft2_kernel<n_fft=2048, OUT_MELR> (fused melspectrogram)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_frame": BYTES_PER_FRAME_MEL,
                          "launch_ms": launch_s * 1e3, "frames_per_s_single_gpu": frames_per_step / launch_s,
-                         "note": "this kernel sits on the VALU side of the ridge (~65 kFLOP per 2 560 B); see roofline_stft for the HBM-bound kernel"},
-            "roofline_stft": {"bound": "hbm", "kernel": "stft_kernel<n_fft=2048, OUT_COMPLEX> (librosa.stft, complex64 out)", "achieved": achieved_stft,
-                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_stft / HBM_PEAK_GBS, "traffic": None,
-                              "bytes_per_frame": BYTES_PER_FRAME_STFT, "launch_ms": stft_launch_s * 1e3, "frames_per_s_single_gpu": frames_per_step / stft_launch_s},
+                         "note": "this kernel sits on the LDS / VALU side of the ridge (~65 kFLOP and ~500 LDS cycles per 2 560 B); see roofline_stft for the HBM-bound kernel"},
+            "repeats": {"ms_per_step_min": min(rep), "ms_per_step_median": statistics.median(rep), "ms_per_step_all": rep, "what": "5 more repeats of the timed region (HIP events, no collectives)"},
         }
-        istft_launch_s = ev_istft / args.steps
-        achieved_istft = frames_per_step * BYTES_PER_FRAME_STFT / istft_launch_s / 1e9
-        line["roofline_istft"] = {"bound": "hbm", "kernel": "istft_kernel<n_fft=2048> (librosa.istft: c2r FFT + window + overlap-add + wss normalise)", "achieved": achieved_istft,
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_istft / HBM_PEAK_GBS, "traffic": None, "bytes_per_frame": BYTES_PER_FRAME_STFT,
-                                  "launch_ms": istft_launch_s * 1e3, "frames_per_s_single_gpu": frames_per_step / istft_launch_s, "round_trip_snr_db_min": snr_db}
-        # the fused mel kernel sits on the VALU side of the ridge: the same launch against the f32 vector peak
-        # (~65 kFLOP per frame by the 5 N log2 N convention; 157.3 TFLOP/s = 256 CUs x 256 flop/clk x 2.4 GHz,
-        # reachable only with packed FMAs -- an FFT is mostly packed adds, 2 flop per lane-instruction instead of 4)
+        # the fused mel kernel against the f32 vector peak (~65 kFLOP per frame by the 5 N log2 N convention)
         line["roofline_valu"] = {"bound": "valu", "kernel": line["roofline"]["kernel"], "achieved": frames_per_step * 65e3 / launch_s / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                                  "frac": frames_per_step * 65e3 / launch_s / 1e12 / 157.3, "flop_per_frame": 65e3}
-        line["kernel_variants"] = {"stft": ctx.tuned_variant(plan, 0), "melspectrogram": ctx.tuned_variant(plan, 2), "istft": ctx.tuned_variant(iplan),
-                                   "note": "n_fft=2048 f32: 0 = one wave64 per frame (16 points/thread), 4 = two waves per frame (8 points/thread); chosen by timing both on the first call (ctx option autotune), -1 = pinned or default"}
-        line["roofline_stft"]["achievable_note"] = ("scripts/storepat.hip (same 2 048 B read + 8 200 B write per row, no arithmetic, no LDS) reaches 4.6-4.8 TB/s on this "
-                                                    "chip, a plain copy 4.8 TB/s: that, not the 8 TB/s pin rate, is what this store stream can reach")
-        if cqt is not None:
-            line["cqt_lite"] = cqt
+        for k, v in side.items():
+            if k == "post" and isinstance(v, dict) and "error" not in v:
+                line.update(v)
+            else:
+                line[k] = v
+        line["kernel_variants"] = {"melspectrogram": ctx.tuned_variant(plan, 2),
+                                   "note": "n_fft=2048 f32 fused mel: 0 = second-generation core, one wave64 per frame; 4 = first generation, two waves per frame; chosen by timing both on the first call "
+                                           "(ctx option autotune); stft / |X|^p always run the second-generation kernel"}
+        if "roofline_stft" in line and "error" not in line["roofline_stft"]:
+            line["roofline_stft"]["achievable_note"] = ("the same stream without arithmetic (scripts/storepat2.hip: 2 048 B read + 8 200 B written per row) reaches 5.0-5.5 TB/s at the kernel's "
+                                                        "residency on this chip (profiles/r02_store_stream.md)")
         # HBM bytes per launch measured with rocprofv3 PMC passes (scripts/profile_round.sh), when committed
         try:
             prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
             if prof:
                 tj = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))
                 for key, needle in (("roofline", "mel"), ("roofline_stft", "complex64"), ("roofline_istft", "istft")):
+                    if key not in line or "error" in line[key]:
+                        continue
                     # several variants of a kernel may appear (autotune candidates): the one launched most is the one timed here
                     cands = [(v.get("launches", 0), kname, v) for kname, v in tj.get("kernels", {}).items() if needle in kname and "n_fft=2048" in kname and v.get("hbm_bytes")]
                     if cands:
@@ -320,7 +443,13 @@ def main():
         except Exception:
             pass
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            try:
+                clip = (y[0].cpu().numpy(), M[0].cpu().numpy())
+            except Exception:
+                clip = None
+            line["cpu_baseline"], parity = cpu_baseline(parity_clip=clip)
+            if parity is not None:
+                line["parity"] = parity
             try:
                 line["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
             except Exception as exc:  # the single-core object above is the contract; this one is informative

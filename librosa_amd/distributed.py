@@ -5,6 +5,12 @@ Clips (leading axes) are independent (the reference asserts batch == per-item,
 exchange during compute.  The only collective is the optional final gather of the (small) mel
 output -- RCCL over xGMI when the process group uses the ``nccl`` backend (which is RCCL on ROCm),
 ``gloo`` on CPU for tests.
+
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): the gather of one 338.7 MB mel shard per rank
+(BASELINE configs[2]: 512 clips x 128 x 1292 f32) is bound by the per-link rate, ~2.2 ms direct against
+~1 ms of compute per shard, so ``ShardedGather`` overlaps it with the compute: the shard is produced and
+shipped in chunks of clips, chunk c travelling (on the communication stream RCCL owns) while chunk c+1
+is being computed.
 """
 from __future__ import annotations
 
@@ -22,25 +28,81 @@ def shard_sizes(n_items: int, world_size: int):
     return [shard_range(n_items, r, world_size)[1] - shard_range(n_items, r, world_size)[0] for r in range(world_size)]
 
 
-def gather_shards(local, n_items: int, group=None):
+def chunk_ranges(n: int, n_chunks: int):
+    """[begin, end) of ``n_chunks`` near-equal consecutive pieces of range(n) (empty pieces dropped)."""
+    n_chunks = max(1, min(int(n_chunks), max(1, n)))
+    out = []
+    for c in range(n_chunks):
+        b, e = shard_range(n, c, n_chunks)
+        if e > b:
+            out.append((b, e))
+    return out
+
+
+class ShardedGather:
+    """Gathers per-rank shards (clips on axis 0) into the full batch on every rank, piece by piece.
+
+    ``full`` is allocated once; ``rank r``'s shard occupies rows ``shard_range(n_items, r, world)``, i.e. the layout of
+    the unsharded result: no padding, no concatenation.  ``push(lo, hi, piece)`` ships rows ``[lo, hi)`` of the LOCAL
+    shard as soon as they exist and returns immediately (``async_op``); ``wait()`` completes everything.
+
+    * equal shards: one ``all_gather`` per piece straight into views of ``full`` (RCCL: every rank's piece crosses each
+      xGMI link once);
+    * unequal shards (``n_items % world != 0``): every rank broadcasts its own piece into its rows -- still no padding
+      and no extra copy, at the price of ``world`` smaller collectives per piece.
+    """
+
+    def __init__(self, like, n_items: int, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.sizes = shard_sizes(n_items, self.world)
+        self.offsets = [shard_range(n_items, r, self.world)[0] for r in range(self.world)]
+        self.equal = len(set(self.sizes)) == 1
+        self.full = torch.empty((int(n_items),) + tuple(like.shape[1:]), dtype=like.dtype, device=like.device)
+        self.pending = []
+
+    def push(self, lo: int, hi: int, piece):
+        """Ship rows [lo, hi) of this rank's shard (``piece`` holds exactly those rows)."""
+        dist = self.dist
+        if hi <= lo:
+            return
+        piece = piece.contiguous()
+        if self.equal:
+            views = [self.full[self.offsets[r] + lo : self.offsets[r] + hi] for r in range(self.world)]
+            self.pending.append(dist.all_gather(views, piece, group=self.group, async_op=True))
+            return
+        # unequal shards: rows [lo, hi) exist on a rank only as far as its shard reaches
+        for r in range(self.world):
+            r_hi = min(hi, self.sizes[r])
+            if r_hi <= lo:
+                continue
+            view = self.full[self.offsets[r] + lo : self.offsets[r] + r_hi]
+            if r == self.rank:
+                view.copy_(piece[: r_hi - lo])
+            src = dist.get_global_rank(self.group, r) if self.group is not None else r
+            self.pending.append(dist.broadcast(view, src=src, group=self.group, async_op=True))
+
+    def wait(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+        return self.full
+
+
+def gather_shards(local, n_items: int, group=None, n_chunks: int = 1):
     """All-gather per-rank results (clips on axis 0, possibly unequal shard sizes) into the full batch.
 
-    ``local`` is a torch tensor holding this rank's shard.  Every rank returns the full
-    ``(n_items, ...)`` tensor.  Uses one padded ``all_gather_into_tensor`` (a direct exchange over
-    xGMI under RCCL; each rank's shard crosses each link once).
-    """
-    import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size(group)
-    sizes = shard_sizes(n_items, world)
-    biggest = max(sizes)
-    pad = local
-    if local.shape[0] < biggest:
-        pad = torch.zeros((biggest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        pad[: local.shape[0]] = local
-    out = torch.empty((world * biggest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad.contiguous(), group=group)
-    if all(s == biggest for s in sizes):
-        return out
-    return torch.cat([out[r * biggest : r * biggest + sizes[r]] for r in range(world)], dim=0)
+    ``local`` is a torch tensor holding this rank's whole shard; every rank returns the full ``(n_items, ...)`` tensor.
+    For a gather that overlaps the compute, produce the shard in pieces and use :class:`ShardedGather` directly
+    (``bench.py``'s ``gathered`` measurement does)."""
+    g = ShardedGather(local, n_items, group)
+    mine = g.sizes[g.rank]
+    biggest = max(g.sizes)
+    for lo, hi in chunk_ranges(biggest, n_chunks):
+        g.push(lo, hi, local[lo : min(hi, mine)])
+    return g.wait()

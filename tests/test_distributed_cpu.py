@@ -35,6 +35,15 @@ def _worker(rank, world, port, n_clips, out_dir):
     y = O.config_input(e - b, n=8000, first_clip=b)  # clip i depends only on (seed, i)
     M = O.melspectrogram(y=y, sr=22050, n_fft=512, hop_length=128, n_mels=20)
     full = gather_shards(torch.from_numpy(M), n_clips)
+    chunked = gather_shards(torch.from_numpy(M), n_clips, n_chunks=2)  # the overlapped form: the shard travels in pieces
+    # pieces pushed as they are "computed" (what bench.py's gathered measurement does)
+    from librosa_amd.distributed import ShardedGather, chunk_ranges
+
+    g = ShardedGather(torch.from_numpy(M), n_clips)
+    for lo, hi in chunk_ranges(max(g.sizes), 3):
+        g.push(lo, hi, torch.from_numpy(M[lo : min(hi, e - b)]))
+    piecewise = g.wait()
+    assert torch.equal(full, chunked) and torch.equal(full, piecewise)
     if rank == 0:
         np.save(os.path.join(out_dir, "gathered.npy"), full.numpy())
     dist.barrier()
