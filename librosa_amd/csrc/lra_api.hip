@@ -340,6 +340,14 @@ template <class T> struct StftLaunch {
     }
 
     template <class Cfg> void operator()() {
+        if constexpr (Cfg::REV) {  // the ascending-radix configurations exist for the inverse kernel only
+            err = hipErrorInvalidValue;
+            return;
+        } else {
+            run<Cfg>();
+        }
+    }
+    template <class Cfg> void run() {
         if (mode == OUT_MEL2) {
             // the two-slope mel kernel shares its filter tables across the slots of a larger workgroup
             using MC = typename MelCfgOf<Cfg>::type;
@@ -854,6 +862,12 @@ int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_s
         L.n_cu = ctx->n_cu;
         L.xcd_remap = ctx->opt_xcd_remap != 0;
         int variant = ctx->opt_variant >= 0 ? ctx->opt_variant : 0;  // see stft_run
+        // f32 n_fft = 2048 with hop = n_fft / {2, 4, 8}: the ascending-radix configuration (variant 5), whose Hermitian step is
+        // fused into the first pass, replaces both tunings
+        bool fused_first_pass = false;
+        if constexpr (sizeof(T) == 4)
+            fused_first_pass = ctx->opt_v2 && ctx->opt_variant < 0 && p->logm == 10 && istft_rows_hc<typename CfgSel<float, 10, 5>::type>(p->hop) > 0;
+        if (fused_first_pass) variant = 5;
         bool too_big = false;
         auto launch = [&](int v) -> int {
             IstftLaunch<T> Lv = L;
@@ -863,7 +877,7 @@ int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_s
             if (Lv.err != hipSuccess) return fail(LRA_EHIP, std::string("istft kernel launch: ") + hipGetErrorString(Lv.err));
             return LRA_OK;
         };
-        if (ctx->opt_variant < 0 && ctx->opt_autotune && sizeof(T) == 4 && p->logm == 10) {
+        if (ctx->opt_variant < 0 && ctx->opt_autotune && sizeof(T) == 4 && p->logm == 10 && !fused_first_pass) {
             int& tuned = p->tuned_variant[0];
             if (tuned < 0 && batch * n_used >= 65536) LRA_TRY(autotune_variant(ctx, launch, &tuned));
             if (tuned >= 0) variant = tuned;

@@ -10,7 +10,7 @@ namespace lra {
 constexpr int kMinLogM = 4;     // n_fft = 32
 constexpr int kMaxLogM = 13;    // n_fft = 16384 (M = 8192 complex: 68 KiB of LDS per frame in f32)
 constexpr int kMaxLogM64 = 12;  // f64: n_fft <= 8192
-constexpr int kNumVariants = 5; // tuning variants exist for f32 n_fft = 2048 only
+constexpr int kNumVariants = 6; // tuning variants exist for f32 n_fft = 2048 only
 
 // Compile-time configuration per (dtype, log2 M, variant).  Variant 0 is the default:
 //   f32: 16 complex points per thread, 256-VGPR budget (2 waves/SIMD), window/twiddle values kept
@@ -20,7 +20,8 @@ constexpr int kNumVariants = 5; // tuning variants exist for f32 n_fft = 2048 on
 // slots are private pipelines, so small workgroups only add scheduling freedom and keep the LDS
 // footprint (frame area + PCM ring + mel tile, ~17-19 KiB per slot at n_fft = 2048) granular.
 // Variants 1 and 4 (f32, n_fft = 2048) split a frame over two waves (8 points per thread) for higher
-// occupancy; variants 2 and 3 were retired (always slower) and now alias variant 0.  bench.py --sweep times them.
+// occupancy; variants 2 and 3 were retired (always slower) and now alias variant 0; variant 5 is the inverse kernel's
+// ascending-radix configuration (the forward launchers reject it).
 template <class T, int L, int VAR> struct CfgSel {
     using type = FftCfg<L, 4, T, 64, 2, true>;
 };
@@ -32,6 +33,9 @@ template <> struct CfgSel<float, 10, 1> {
 };
 template <> struct CfgSel<float, 10, 4> {
     using type = FftCfg<10, 3, float, 128, 3, true>;  // two waves per frame, tables in registers, 3 waves/SIMD
+};
+template <> struct CfgSel<float, 10, 5> {
+    using type = FftCfg<10, 4, float, 64, 2, true, true>;  // inverse kernel only: radices 8, 8, 16 (Hermitian step fused into the first pass)
 };
 
 // true when n_fft is a power of two handled by the fused LDS kernels
@@ -66,6 +70,7 @@ template <class T, class F> inline bool dispatch_logm(int logm, int variant, F&&
             if constexpr (sizeof(T) == 4) {
                 if (variant == 1) { f.template operator()<typename CfgSel<T, 10, 1>::type>(); return true; }
                 if (variant == 4) { f.template operator()<typename CfgSel<T, 10, 4>::type>(); return true; }
+                if (variant == 5) { f.template operator()<typename CfgSel<T, 10, 5>::type>(); return true; }
             }
             f.template operator()<typename CfgSel<T, 10, 0>::type>();
             return true;

@@ -27,7 +27,10 @@ namespace lra {
 // the compiler keep the per-thread window/twiddle values in registers across the frame loop (they
 // are loop-invariant); when false the table pointers are laundered every iteration so the tables
 // are re-read from L1/L2 and the register budget stays small.
-template <int LOGM_, int LOGR_, class T_, int NTMIN_ = 256, int MINW_ = 0, bool HOIST_ = true> struct FftCfg {
+// REV_: the radices in ascending order (8, 8, 16 instead of 16, 8, 8 at M = 1024): the inverse kernel wants the
+// two-butterfly pass FIRST (its Hermitian step is fused into the first pass, see istft_unsplit_pass0) and the one-butterfly
+// radix-16 pass last (fused with the overlap-add).
+template <int LOGM_, int LOGR_, class T_, int NTMIN_ = 256, int MINW_ = 0, bool HOIST_ = true, bool REV_ = false> struct FftCfg {
     using real = T_;
     using cplx = cx<T_>;
     static constexpr int LOGM = LOGM_;
@@ -39,7 +42,8 @@ template <int LOGM_, int LOGR_, class T_, int NTMIN_ = 256, int MINW_ = 0, bool 
     static constexpr int NT = TF > NTMIN_ ? TF : NTMIN_;
     static constexpr int FPB = NT / TF;  // frames per workgroup iteration
     static constexpr int P = (LOGM + LOGR - 1) / LOGR;
-    static constexpr int logr(int p) { return LOGM / P + (p < LOGM % P ? 1 : 0); }
+    static constexpr bool REV = REV_;
+    static constexpr int logr(int p) { return LOGM / P + ((REV_ ? p >= P - LOGM % P : p < LOGM % P) ? 1 : 0); }
     static constexpr int logs(int p) {
         int s = 0;
         for (int q = 0; q < p; ++q) s += logr(q);
@@ -68,7 +72,7 @@ template <int LOGM_, int LOGR_, class T_, int NTMIN_ = 256, int MINW_ = 0, bool 
     static constexpr int MIN_WAVES = MINW_ > 0 ? MINW_ : 2;
     static constexpr bool HOIST = HOIST_;
     // same transform, different workgroup size (the mel kernel shares its filter tables across slots)
-    template <int NT2> using with_nt = FftCfg<LOGM_, LOGR_, T_, NT2, MINW_, HOIST_>;
+    template <int NT2> using with_nt = FftCfg<LOGM_, LOGR_, T_, NT2, MINW_, HOIST_, REV_>;
     // a frame slot (TF threads) never spans two waves: slot-private LDS traffic needs no s_barrier
     static constexpr bool WAVE_SYNC = TF <= 64;
 };

@@ -34,9 +34,9 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void stft_kernel(lra::Stft
 
 // Second-generation forward kernel (lra_kernels2.h): PCM ring in registers, mirrored last pass with the split step in
 // registers.  HD = n_fft / hop.  The register budget is sized for 3 waves per SIMD (12 slots of 8.7 KB per CU) where the
-// kernel fits it without spilling (hop <= n_fft/4, i.e. at most 4 sample pairs in flight per thread).
+// kernel fits it without spilling (n_fft = 2048 with hop <= n_fft/4, i.e. at most 4 sample pairs in flight per thread).
 template <class Cfg, int HD, int MODE, int PM>
-__global__ __launch_bounds__(Cfg::NT, (Cfg::NT > 256 ? 1 : (HD >= 4 && PM != lra::POW_GENERAL && MODE != lra::OUT_MELR ? 3 : 2))) void stft2_kernel(lra::StftArgs<typename Cfg::real> a, const typename Cfg::real* __restrict__ y,
+__global__ __launch_bounds__(Cfg::NT, (Cfg::NT > 256 ? 1 : (Cfg::TF == 64 && HD >= 4 && PM != lra::POW_GENERAL && MODE != lra::OUT_MELR ? 3 : 2))) void stft2_kernel(lra::StftArgs<typename Cfg::real> a, const typename Cfg::real* __restrict__ y,
                                                                                   void* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char lra_smem[];
     lra::Lds lds;
@@ -78,6 +78,7 @@ LRA_CFG_ALIAS(cfg_f32_9, float, 9, 0)
 LRA_CFG_ALIAS(cfg_f32_10, float, 10, 0)
 LRA_CFG_ALIAS(cfg_f32_10v1, float, 10, 1)
 LRA_CFG_ALIAS(cfg_f32_10v4, float, 10, 4)
+LRA_CFG_ALIAS(cfg_f32_10r, float, 10, 5)
 LRA_CFG_ALIAS(cfg_f32_11, float, 11, 0)
 LRA_CFG_ALIAS(cfg_f32_12, float, 12, 0)
 LRA_CFG_ALIAS(cfg_f32_13, float, 13, 0)
@@ -120,9 +121,10 @@ LRA_CFG_ALIAS(cfg_f64_12, double, 12, 0)
 #define LRA_STFT2_CFG(T, C) LRA_STFT2_HD(T, C, 1) LRA_STFT2_HD(T, C, 2) LRA_STFT2_HD(T, C, 4) LRA_STFT2_HD(T, C, 8)
 #define LRA_STFT2_MEL_HD(T, C, HD) T(lra::C, HD, 4, 1) T(lra::C, HD, 4, 2) T(lra::C, HD, 4, 3)
 #define LRA_STFT2_MEL(T, C) LRA_STFT2_MEL_HD(T, C, 1) LRA_STFT2_MEL_HD(T, C, 2) LRA_STFT2_MEL_HD(T, C, 4) LRA_STFT2_MEL_HD(T, C, 8)
-#define LRA_INST2_GROUP_9(T) LRA_STFT2_CFG(T, cfg_f32_10) LRA_STFT2_MEL(T, cfg_f32_10_mel)
-#define LRA_INST2_GROUP_10(T) LRA_STFT2_CFG(T, cfg_f32_9) LRA_STFT2_CFG(T, cfg_f32_11)
-#define LRA_INST2_ALL(T) LRA_INST2_GROUP_9(T) LRA_INST2_GROUP_10(T)
+#define LRA_INST2_GROUP_9(T, I) LRA_STFT2_CFG(T, cfg_f32_10) LRA_STFT2_MEL(T, cfg_f32_10_mel)
+// ... and the inverse kernel on the ascending-radix configuration (Hermitian step fused into the first pass)
+#define LRA_INST2_GROUP_10(T, I) LRA_STFT2_CFG(T, cfg_f32_9) LRA_STFT2_CFG(T, cfg_f32_11) I(lra::cfg_f32_10r, 8) I(lra::cfg_f32_10r, 4) I(lra::cfg_f32_10r, 2)
+#define LRA_INST2_ALL(T, I) LRA_INST2_GROUP_9(T, I) LRA_INST2_GROUP_10(T, I)
 #define LRA_INST_NUM_GROUPS 11
 #define LRA_INST_ALL(S, I)                                                                                                   \
     LRA_INST_GROUP_0(S, I) LRA_INST_GROUP_1(S, I) LRA_INST_GROUP_2(S, I) LRA_INST_GROUP_3(S, I) LRA_INST_GROUP_4(S, I)       \
@@ -140,5 +142,5 @@ LRA_CFG_ALIAS(cfg_f64_12, double, 12, 0)
 
 #if defined(LRA_FUSED_EXTERN) && !defined(LRA_PROBE_ONLY)
 LRA_INST_ALL(LRA_S_EXTERN, LRA_I_EXTERN)
-LRA_INST2_ALL(LRA_T_EXTERN)
+LRA_INST2_ALL(LRA_T_EXTERN, LRA_I_EXTERN)
 #endif

@@ -8,7 +8,7 @@
 #define LRA_CAT2(a, b) a##b
 #define LRA_CAT(a, b) LRA_CAT2(a, b)
 #if LRA_INST_GROUP >= 9  // second-generation forward kernels
-LRA_CAT(LRA_INST2_GROUP_, LRA_INST_GROUP)(LRA_T_DEFINE)
+LRA_CAT(LRA_INST2_GROUP_, LRA_INST_GROUP)(LRA_T_DEFINE, LRA_I_DEFINE)
 #else
 LRA_CAT(LRA_INST_GROUP_, LRA_INST_GROUP)(LRA_S_DEFINE, LRA_I_DEFINE)
 #endif

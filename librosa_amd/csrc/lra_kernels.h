@@ -1035,6 +1035,93 @@ template <class Cfg> LRA_HD void istft_split_write(const IstftArgs<typename Cfg:
     if (tf == 0) lds_st<C>(fr, Cfg::phys(M / 2) * (int)sizeof(C), mid2);
 }
 
+// ---- ascending-radix configurations (FftCfg REV): Hermitian step fused into the first pass --------------------------------
+// The first pass (radix r0, butterfly b reads Z'[b + j s], s = M / r0) then has two butterflies per thread, and as in the
+// second-generation forward kernel (lra_kernels2.h) thread tf takes butterflies tf and s - tf (thread 0: 0 and s/2): both
+// members of every pair (Z'[k], Z'[M-k]) are inputs of ONE thread.  X[k], X[M-k] are loaded in that order (pair slot q:
+// k = tf + q s), turned into the pair in registers and fed straight to the butterflies: the split phase's LDS write and the
+// first pass's LDS read (32 of the frame's 80 LDS instructions) disappear.
+template <class Cfg> constexpr bool istft_mir_ok() {
+    return Cfg::REV && Cfg::HOIST && sizeof(typename Cfg::real) == 4 && Cfg::R == 16 && Cfg::P >= 2 && (Cfg::R >> Cfg::logr(0)) == 2 && 2 * Cfg::TF == (Cfg::M >> Cfg::logr(0)) &&
+           affine_tf<Cfg>();
+}
+template <class Cfg> LRA_HD int mir_bfly(int tf) { return tf == 0 ? Cfg::TF : 2 * Cfg::TF - tf; }
+// bins of pair slots q >= r0/2 are tf + q s, except for lane 0 (whose second butterfly is s/2): s/2 + (q - r0/2) s
+template <class Cfg> LRA_HD int mir_tf_hi(int tf) {
+    constexpr int r0 = 1 << Cfg::logr(0), s = 2 * Cfg::TF;
+    return tf == 0 ? (s / 2) * (1 - r0) : tf;
+}
+template <class Cfg> LRA_HD int mir_slot_bin(int tf, int q) {
+    constexpr int r0 = 1 << Cfg::logr(0), s = 2 * Cfg::TF;
+    return (q < r0 / 2 ? tf : mir_tf_hi<Cfg>(tf)) + q * s;
+}
+
+template <class Cfg> LRA_HD void istft_spec_load_mir(const IstftArgs<typename Cfg::real>& a, long long clip, int frame, bool valid, int tf, FftRegs<Cfg>& rg) {
+    using T = typename Cfg::real;
+    using C = typename Cfg::cplx;
+    constexpr int M = Cfg::M, r0 = 1 << Cfg::logr(0), s = 2 * Cfg::TF;
+    static_assert(r0 == Cfg::R / 2, "one pair slot per first-pass input");
+    const C zero = mk<T>((T)0, (T)0);
+    if (!valid) {
+        LRA_UNROLL
+        for (int q = 0; q < r0; ++q) { rg.xk[q] = zero; rg.xm[q] = zero; }
+        rg.xmid = zero;
+        return;
+    }
+    const C* __restrict__ X = a.D + clip * a.d_batch_stride + (long long)frame * a.d_frame_stride;
+    const C* __restrict__ Xlo = X + tf;                     // slots q < r0/2: ascending from tf, mirrored from M - tf
+    const C* __restrict__ Xhi = X + mir_tf_hi<Cfg>(tf);
+    LRA_UNROLL
+    for (int q = 0; q < r0; ++q) {
+        const C* __restrict__ Xq = q < r0 / 2 ? Xlo : Xhi;
+        rg.xk[q] = Xq[q * s];
+        rg.xm[q] = X[M - (q < r0 / 2 ? tf : mir_tf_hi<Cfg>(tf)) - q * s];
+    }
+    rg.xmid = X[M / 2];
+}
+
+// phase: pairs -> conj Z' in first-pass order, first-pass butterflies, first LDS write of the frame
+template <class Cfg> LRA_HD void istft_unsplit_pass0(int tf, FftRegs<Cfg>& rg, Lds fr) {
+    using T = typename Cfg::real;
+    using C = typename Cfg::cplx;
+    constexpr int r0 = 1 << Cfg::logr(0);
+    const bool l0 = tf == 0;
+    C zk[r0], zm[r0];
+    LRA_UNROLL
+    for (int q = 0; q < r0; ++q) {
+        const C xk = rg.xk[q], xm = rg.xm[q];
+        const C E = add_conj(xk, xm);
+        const C O = cmul2_conj(sub_conj(xk, xm), rg.twr[q]);
+        zk[q] = conj_add_mi_neg(E, O);  // conj Z'[k]
+        zm[q] = add_mi(E, O);           // conj Z'[M - k]
+    }
+    // lane 0, slot 0: (X[0], X[M]) -> conj Z'[0] (their imaginary parts are ignored, as pocketfft's c2r does); bin M/2 -> conj Z'[M/2]
+    const C z0 = mk<T>(rg.xk[0].x + rg.xm[0].x, -(rg.xk[0].x - rg.xm[0].x));
+    const C mid2 = mk<T>((T)2 * rg.xmid.x, (T)2 * rg.xmid.y);
+    C* A = rg.v;        // butterfly tf:      inputs Z'[tf + j s]        lanes 1..: zk[j];            lane 0: Z'[j s]
+    C* B = rg.v + r0;   // butterfly s - tf:  inputs Z'[(s - tf) + j s]  lanes 1..: zm[r0 - 1 - j];   lane 0: Z'[s/2 + j s]
+    LRA_UNROLL
+    for (int j = 0; j < r0; ++j) {
+        C a0;  // lane 0's A[j]
+        if (j == 0) a0 = z0;
+        else if (j < r0 / 2) a0 = zk[j];
+        else if (j == r0 / 2) a0 = mid2;
+        else a0 = zm[r0 - j];
+        const C b0 = j < r0 / 2 ? zk[r0 / 2 + j] : zm[3 * r0 / 2 - 1 - j];  // lane 0's B[j]
+        A[j] = l0 ? a0 : zk[j];
+        B[j] = l0 ? b0 : zm[r0 - 1 - j];
+    }
+    Dft<r0, T>::run(A);
+    Dft<r0, T>::run(B);
+    // pass 0 (s = 1): output j of butterfly b at position b r0 + j, i.e. padded slot b (r0 + 1) + j
+    const int baseA = tf * (r0 + 1) * (int)sizeof(C), baseB = mir_bfly<Cfg>(tf) * (r0 + 1) * (int)sizeof(C);
+    LRA_UNROLL
+    for (int j = 0; j < r0; ++j) {
+        lds_st<C>(fr, baseA + j * (int)sizeof(C), A[j]);
+        lds_st<C>(fr, baseB + j * (int)sizeof(C), B[j]);
+    }
+}
+
 // ---- phase: last pass butterflies, then windowed time-domain frame -> LDS (natural order) ------
 template <class Cfg> LRA_HD void istft_last_write(const IstftArgs<typename Cfg::real>& a, FftRegs<Cfg>& rg, int tf, Lds fr) {
     using T = typename Cfg::real;
@@ -1299,6 +1386,7 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
     using T = typename Cfg::real;
     constexpr int FPB = Cfg::FPB;
     constexpr bool ROWS = HC > 0;
+    constexpr bool MIR = ROWS && istft_mir_ok<Cfg>();  // Hermitian step in registers, fused into the first pass
     constexpr int SB = istft_slot_bytes<Cfg, HC>();
     // uniform step count: drain steps only when one of this workgroup's slots owns a clip's last strip
     bool has_last = false;
@@ -1313,12 +1401,17 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
     LRA_PHASE(Cfg::NT, tid) {
         const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
         hoist_tables<Cfg>(LRA_R(rg), tf, a.win_scaled, a.tw, a.twr, true);
+        if constexpr (MIR) {
+            LRA_UNROLL
+            for (int q = 0; q < Cfg::R / 2; ++q) LRA_R(rg).twr[q] = a.twr[mir_slot_bin<Cfg>(tf, q)];
+        }
         const Lds c0 = lds_sub(lds, slot * SB + Cfg::FRAME_BYTES);
         for (int u = tf; u < (HC > 0 ? istft_carry_reals<Cfg, HC>() : Cfg::N); u += Cfg::TF) lds_st<T>(c0, u * (int)sizeof(T), (T)0);
         LRA_R(sl) = istft_slot<Cfg>(a, blk, slot_of<Cfg>(LRA_RAW_TID(tid)));
         const IstftSlot<Cfg> s = LRA_R(sl);
         const int t = s.t0 - a.warm_frames;
-        istft_spec_load<Cfg>(a, s.clip, t, s.active && t >= 0 && t < s.t1, tf, LRA_R(rg));
+        if constexpr (MIR) istft_spec_load_mir<Cfg>(a, s.clip, t, s.active && t >= 0 && t < s.t1, tf, LRA_R(rg));
+        else istft_spec_load<Cfg>(a, s.clip, t, s.active && t >= 0 && t < s.t1, tf, LRA_R(rg));
     } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
     for (int j = 0; j < steps; ++j) {
         if (!Cfg::HOIST) { LRA_LAUNDER(a.win_scaled); LRA_LAUNDER(a.tw); LRA_LAUNDER(a.twr); }
@@ -1328,18 +1421,22 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
             const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
             const IstftSlot<Cfg> s = LRA_R(sl);
             const int t = s.t0 - a.warm_frames + j;
-            istft_split_write<Cfg>(a, tf, LRA_R(rg), lds_sub(lds, slot * SB));
+            if constexpr (MIR) istft_unsplit_pass0<Cfg>(tf, LRA_R(rg), lds_sub(lds, slot * SB));
+            else istft_split_write<Cfg>(a, tf, LRA_R(rg), lds_sub(lds, slot * SB));
             if (defer && j > 0 && s.active) {
                 if constexpr (rows) istft_flush_rows<Cfg, HC>(a, s.clip, t - 1, t - 1 >= s.t0 && (s.last || t - 1 < s.t1), tf, LRA_R(rg));
                 else istft_flush_out<Cfg>(a, s.clip, t - 1, s.write_lo, s.write_hi, tf, LRA_R(rg));
             }
-            if (j + 1 < steps) istft_spec_load<Cfg>(a, s.clip, t + 1, s.active && t + 1 >= 0 && t + 1 < s.t1, tf, LRA_R(rg));
+            if (j + 1 < steps) {
+                if constexpr (MIR) istft_spec_load_mir<Cfg>(a, s.clip, t + 1, s.active && t + 1 >= 0 && t + 1 < s.t1, tf, LRA_R(rg));
+                else istft_spec_load<Cfg>(a, s.clip, t + 1, s.active && t + 1 >= 0 && t + 1 < s.t1, tf, LRA_R(rg));
+            }
             if constexpr (rows) {  // for the flush of THIS frame, one iteration from now
                 if (s.active) istft_wss_rows<Cfg, HC>(a, t, t >= s.t0 && (s.last || t < s.t1), tf, LRA_R(rg));
             }
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
-        // pass 0 (no twiddles) reads from LDS here, unlike the forward kernel
-        if (Cfg::P > 1) {
+        // pass 0 (no twiddles) reads from LDS here, unlike the forward kernel (unless it was fused into the Hermitian step)
+        if (Cfg::P > 1 && !MIR) {
             LRA_PHASE(Cfg::NT, tid) {
                 pass_read<Cfg, 0>(LRA_R(rg).v, lds_sub(lds, (slot_of<Cfg>(tid)) * SB), lane_of<Cfg>(tid));
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)

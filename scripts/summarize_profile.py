@@ -22,18 +22,18 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
+    import re
+    cfg = re.search(r"FftCfg<(\d+), (\d), (\w+), (\d+), (\d), (\w+)(?:, (\w+))?>", name)
+    tag = f" [n_fft={2 ** (int(cfg.group(1)) + 1)}, 2^{cfg.group(2)} pts/thread, NT={cfg.group(4)}{', ascending radices' if cfg.group(7) == 'true' else ''}]" if cfg else ""
+    modes = {"0": "complex64 out", "1": "power out", "2": "mel, generic", "3": "mel, two-slope", "4": "mel, run-ordered two-slope"}
     if "istft_kernel" in name:
-        import re
-        cfg = re.search(r"FftCfg<(\d+), (\d), (\w+), (\d+), (\d), (\w+)>", name)
-        return "istft_kernel" + (f" [n_fft={2 ** (int(cfg.group(1)) + 1)}, 2^{cfg.group(2)} pts/thread, NT={cfg.group(4)}]" if cfg else "")
+        return "istft_kernel" + tag
+    if "stft2_kernel" in name:  # second generation: <Cfg, n_fft / hop, MODE, PM>
+        m = re.search(r">, (\d+), (\d), (\d)>\(", name)
+        return f"stft2_kernel<{modes.get(m.group(2), '?') if m else '?'}>" + tag
     if "stft_kernel" in name:
-        import re
         m = re.search(r">, (\d), (\d), (true|false)>\(", name) or re.search(r">, (\d)(?:, \d)?>\(", name)
-        mode = m.group(1) if m else "?"
-        cfg = re.search(r"FftCfg<(\d+), (\d), (\w+), (\d+), (\d), (\w+)>", name)
-        tag = f" [n_fft={2 ** (int(cfg.group(1)) + 1)}, 2^{cfg.group(2)} pts/thread, NT={cfg.group(4)}]" if cfg else ""
-        return {"0": "stft_kernel<complex64 out>", "1": "stft_kernel<power out>", "2": "stft_kernel<mel, generic>", "3": "stft_kernel<mel, two-slope>",
-                "4": "stft_kernel<mel, run-ordered two-slope>"}.get(mode, "stft_kernel<?>") + tag
+        return f"stft_kernel<{modes.get(m.group(1) if m else '?', '?')}>" + tag
     return name.split("(")[0][-60:]
 
 
@@ -42,7 +42,15 @@ def counters(sub):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     if not os.path.exists(path):
         return agg
-    for r in csv.DictReader(open(path)):
+    rows = list(csv.DictReader(open(path)))
+    # a kernel is also launched on other batches (autotune probes, the 64-clip NumPy end-to-end key): keep the launches
+    # with the most frequent grid only, i.e. the 256-clip batch of the timed step every per-launch figure refers to
+    grids = collections.defaultdict(collections.Counter)
+    for r in rows:
+        grids[r["Kernel_Name"]][int(r["Grid_Size"])] += 1
+    for r in rows:
+        if int(r["Grid_Size"]) != grids[r["Kernel_Name"]].most_common(1)[0][0]:
+            continue
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         agg[r["Kernel_Name"]]["_dur_ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
         agg[r["Kernel_Name"]]["_vgpr"].append(float(r["VGPR_Count"]) + float(r["Accum_VGPR_Count"]))
@@ -75,7 +83,7 @@ for k, v in write.items():
         calib["write_kb_per_true_byte"] = mean(v["WRITE_SIZE"]) * 1024 / known
 traffic = {"tag": tag, "calibration": calib, "kernels": {}}
 for k in set(list(fetch) + list(write)):
-    if "stft_kernel" not in k and "istft_kernel" not in k:
+    if "stft_kernel" not in k and "stft2_kernel" not in k:
         continue
     f_raw = mean(fetch[k]["FETCH_SIZE"]) * 1024 if "FETCH_SIZE" in fetch.get(k, {}) else None
     w_raw = mean(write[k]["WRITE_SIZE"]) * 1024 if "WRITE_SIZE" in write.get(k, {}) else None
@@ -107,12 +115,12 @@ for k, v in sorted(traffic["kernels"].items()):
 lines.append("")
 for sub in ("sq1", "sq2"):
     agg = counters(sub)
-    keys = sorted({c for k, v in agg.items() if "stft_kernel" in k for c in v})
+    keys = sorted({c for k, v in agg.items() if ("stft_kernel" in k or "stft2_kernel" in k) for c in v})
     if not keys:
         continue
     lines += [f"## SQ counters, pass `{sub}` (mean per launch)", "", "| kernel | " + " | ".join(keys) + " |", "|---|" + "---|" * len(keys)]
     for k, v in agg.items():
-        if "stft_kernel" in k:
+        if "stft_kernel" in k or "stft2_kernel" in k:
             lines.append(f"| {short(k)} | " + " | ".join(f"{mean(v[c]):.4g}" if c in v else "-" for c in keys) + " |")
     lines.append("")
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
