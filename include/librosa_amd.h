@@ -161,6 +161,15 @@ int lra_from_db_exec(lra_ctx* ctx, const void* x, void* out, int64_t count, int 
 int lra_dct_exec(lra_ctx* ctx, const void* S, void* out, int64_t batch, int n_in, int n_out, int64_t n_frames, int dtype, const void* basis, const void* lift,
                  int fuse_db, double amin, double ref_scalar, const void* ref_items, const void* item_max, int use_top_db, double top_db);
 
+/* ---- Griffin-Lim: librosa.griffinlim, librosa/core/spectrum.py:2669-2917 ------------------------------------------- */
+/* One phase update over `count` complex values (:2896-2902):
+ *   angles = rebuilt - coef * tprev (tprev may be NULL: first iteration);  angles /= |angles| + eps;  angles *= S
+ * coef = momentum / (1 + momentum), eps = tiny(angles) (:2830).  normalize == 0: angles = rebuilt * S only (:2847).
+ * rebuilt / tprev / angles: complex of `dtype`'s precision, S: real, all in the same element order ([batch][frame][bin] in
+ * the shim's loop: lra_istft_exec -> lra_stft_exec -> this, device-resident across iterations); angles may alias rebuilt. */
+int lra_griffinlim_update(lra_ctx* ctx, const void* rebuilt, const void* tprev, const void* S, void* angles, int64_t count, int dtype, double coef, double eps,
+                          int normalize);
+
 /* ---- layout helper: dst[b][c][r] = src[b][r][c], elem_bytes in {4, 8, 16} ------------------ */
 int lra_transpose(lra_ctx* ctx, const void* src, void* dst, int64_t batch, int64_t rows, int64_t cols, int elem_bytes);
 

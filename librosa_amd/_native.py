@@ -71,6 +71,7 @@ SIGNATURES = {
     "lra_item_absmax_exec": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "lra_to_db_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_int, c_double]),
     "lra_from_db_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_double]),
+    "lra_griffinlim_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_double, c_double, c_int]),
     "lra_dct_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_int, c_double, c_double, c_void_p, c_void_p, c_int, c_double]),
 }
 
@@ -336,6 +337,10 @@ class Context:
         _check(self.lib.lra_dct_exec(self.handle, c_void_p(s_ptr), c_void_p(out_ptr), batch, n_in, n_out, n_frames, dtype_code(dtype), c_void_p(basis_ptr), c_void_p(lift_ptr),
                                      int(bool(fuse_db)), float(amin), float(ref_scalar), c_void_p(ref_items_ptr or None), c_void_p(item_max_ptr or None), int(top_db is not None),
                                      float(top_db if top_db is not None else 0.0)))
+
+    def griffinlim_update(self, rebuilt_ptr, tprev_ptr, s_ptr, angles_ptr, count, dtype, coef, eps, normalize=True):
+        _check(self.lib.lra_griffinlim_update(self.handle, c_void_p(rebuilt_ptr), c_void_p(tprev_ptr) if tprev_ptr else None, c_void_p(s_ptr), c_void_p(angles_ptr), count, dtype_code(dtype),
+                                              float(coef), float(eps), int(bool(normalize))))
 
     def transpose(self, src_ptr, dst_ptr, batch, rows, cols, elem_bytes):
         _check(self.lib.lra_transpose(self.handle, c_void_p(src_ptr), c_void_p(dst_ptr), batch, rows, cols, elem_bytes))

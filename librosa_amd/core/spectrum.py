@@ -22,7 +22,7 @@ from ..util import utils as util
 from ..util.exceptions import ParameterError
 from ..util.utils import is_torch_tensor
 
-__all__ = ["stft", "istft", "_spectrogram", "power_to_db", "amplitude_to_db", "db_to_power", "db_to_amplitude"]
+__all__ = ["stft", "istft", "_spectrogram", "griffinlim", "power_to_db", "amplitude_to_db", "db_to_power", "db_to_amplitude"]
 
 # np.pad modes that do not depend only on edge values: rejected exactly as the reference does
 _REJECTED_PAD_MODES = ("wrap", "maximum", "mean", "median", "minimum")
@@ -333,6 +333,142 @@ def _transpose_batched(ctx, src_ptr, dst_ptr, batch, rows, cols, elem_bytes):
         nb = min(step, batch - b0)
         off = b0 * rows * cols * elem_bytes
         ctx.transpose(src_ptr + off, dst_ptr + off, nb, rows, cols, elem_bytes)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Griffin-Lim: librosa/core/spectrum.py:2669-2917
+# ---------------------------------------------------------------------------------------------------
+class _Deprecated:
+    """Sentinel for the reference's deprecated ``random_state`` keyword (``util/deprecation.py``)."""
+
+    def __repr__(self):
+        return "<DEPRECATED parameter>"
+
+
+_DEPRECATED = _Deprecated()
+
+
+def _to_frame_major(sess, x, batch, rows, cols, dtype):
+    """(..., rows, cols) array/tensor -> device pointer of its [batch][cols][rows] transpose in ``dtype``."""
+    dtype = np.dtype(dtype)
+    if sess.is_torch:
+        xt = _arrays.swap_last_two(x)
+        if xt.is_contiguous() and xt.dtype == _arrays.torch_dtype(dtype):
+            sess._keep.append(xt)
+            return xt.data_ptr()
+        src = x.to(_arrays.torch_dtype(dtype)).contiguous()
+        sess._keep.append(src)
+        src_ptr = src.data_ptr()
+    else:
+        src_ptr = sess.input_raw(np.ascontiguousarray(x, dtype=dtype), dtype)
+    dst = sess.scratch(batch * rows * cols * dtype.itemsize)
+    _transpose_batched(sess.ctx, src_ptr, dst, batch, rows, cols, dtype.itemsize)
+    return dst
+
+
+def griffinlim(S, *, n_iter=32, hop_length=None, win_length=None, n_fft=None, window="hann", center=True, dtype=None, length=None, pad_mode="constant",
+               momentum=0.99, init="random", rng=None, random_state=_DEPRECATED):
+    """"Fast" Griffin-Lim magnitude inversion; drop-in for ``librosa.griffinlim`` (``librosa/core/spectrum.py:2669-2917``).
+
+    The whole fixed-point iteration -- ``istft`` (:2850), ``stft`` (:2863), the phase update with momentum (:2875-2880) --
+    runs on the device: the phase estimate, the two rebuilt spectra and the signal stay in HBM for all ``n_iter``
+    rounds and only ``S`` (and the host-drawn initial phases, so that ``rng`` reproduces the reference's stream) go up
+    and the final signal comes down.  ``S`` may be a device tensor; a device tensor is then returned.
+
+    Differences from the reference: the loop always runs in the precision of ``S`` (``dtype`` is honoured by the final
+    ``istft`` only), and ``util.valid_audio`` is checked once after the loop instead of inside every ``stft``.
+    """
+    if random_state is not _DEPRECATED:
+        if rng is not None:
+            raise ParameterError(f"Both random_state={random_state!r} and rng={rng!r} were provided. Please use only the rng parameter.")
+        warnings.warn("griffinlim() keyword argument 'random_state' has been renamed to 'rng' in version 1.0.0.\n\tThis alias will be removed in version 1.2.0.",
+                      category=FutureWarning, stacklevel=2)
+        rng = random_state
+    if not isinstance(rng, np.random.RandomState):
+        rng = np.random.default_rng(rng)
+    if momentum > 1:
+        warnings.warn(f"Griffin-Lim with momentum={momentum} > 1 can be unstable. Proceed with caution!", stacklevel=2)
+    elif momentum < 0:
+        raise ParameterError(f"griffinlim() called with momentum={momentum} < 0")
+    if init not in ("random", None):
+        raise ParameterError(f"init={init} must either None or 'random'")
+    if S.ndim < 2:
+        raise ParameterError(f"S must have at least 2 dimensions, given shape={tuple(S.shape)}")
+    if n_fft is None:
+        n_fft = 2 * (S.shape[-2] - 1)
+    n_bins, n_total = int(S.shape[-2]), int(S.shape[-1])
+    if n_bins != 1 + n_fft // 2:
+        # the reference fails at ``angles[:] = rebuilt`` (:2875) with a broadcasting error
+        raise ParameterError(f"S has {n_bins} frequency bins, which does not match n_fft={n_fft}")
+    if win_length is None:
+        win_length = n_fft
+    if hop_length is None:
+        hop_length = int(win_length // 4)
+    elif not util.is_positive_int(hop_length):
+        raise ParameterError(f"hop_length={hop_length} must be a positive integer")
+    hop = int(hop_length)
+    center = bool(center)
+    if center and not (isinstance(pad_mode, str) and pad_mode in _DEVICE_PAD_MODES):
+        raise ParameterError(f"pad_mode={pad_mode!r} is not supported by librosa_amd.griffinlim")
+    s_dtype = _arrays.numpy_dtype_of(S)
+    cplx = np.dtype(util.dtype_r2c(s_dtype))
+    real = np.dtype(np.float64) if cplx == np.complex128 else np.dtype(np.float32)
+    out_dtype = np.dtype(util.dtype_c2r(cplx)) if dtype is None else np.dtype(dtype)
+    eps = float(util.tiny(np.empty(0, dtype=cplx)))
+    fft_window = util.pad_center(np.asarray(filters.get_window(window, win_length, fftbins=True), dtype=np.float64), size=n_fft)
+    n_frames, n_used, expected = _istft_frame_counts(n_total, n_fft, hop, center, length)
+    expected = int(expected)
+    if not center and n_fft > expected:
+        raise ParameterError(f"n_fft={n_fft} is too large for uncentered analysis of input signal of length={expected}")
+    rebuilt_frames = 1 + (expected + (2 * (n_fft // 2) if center else 0) - n_fft) // hop
+    if rebuilt_frames != n_total:
+        raise ParameterError(f"the signal of length {expected} rebuilt from S has {rebuilt_frames} frames, S has {n_total}: could not iterate")
+    wss = filters.window_sumsquare(window=window, n_frames=n_frames, win_length=win_length, n_fft=n_fft, hop_length=hop, dtype=out_dtype)
+    wss = np.ascontiguousarray(util.fix_length(wss[(n_fft // 2 if center else 0) :], size=expected), dtype=real)
+    lead = tuple(S.shape[:-2])
+    batch = int(np.prod(lead, dtype=np.int64)) if lead else 1
+    # initial phases on the host: the reference's draw order (S.shape, C order) and its float64 phasor (:2834)
+    if init == "random":
+        ang = 2 * np.pi * rng.random(size=tuple(S.shape))
+        angles0 = (np.cos(ang) + 1j * np.sin(ang)).astype(cplx)
+    else:
+        angles0 = np.ones(tuple(S.shape), dtype=cplx)
+    sess = _arrays.Session(S)
+    try:
+        ctx = sess.ctx
+        iplan = ctx.istft_plan(n_fft, hop, fft_window.astype(real), center, real)
+        splan = ctx.stft_plan(n_fft, hop, fft_window.astype(real), center, pad_mode if center else "constant", real)
+        if ctx.stft_num_frames(splan, expected) != n_total:
+            raise ParameterError("internal frame-count mismatch")
+        count = batch * n_total * n_bins
+        s_ptr = _to_frame_major(sess, S, batch, n_bins, n_total, real)
+        # phases travel in S's own layout and are transposed on the device
+        up = sess.input_raw(_as_like(sess, angles0.reshape(batch, n_bins, n_total)), cplx)
+        angles = sess.scratch(count * cplx.itemsize)
+        _transpose_batched(ctx, up, angles, batch, n_bins, n_total, cplx.itemsize)
+        rebuilt = sess.scratch(count * cplx.itemsize)
+        tprev = sess.scratch(count * cplx.itemsize)
+        wss_ptr = sess.input_raw(_as_like(sess, wss), real)
+        y_ptr, handle = sess.output((batch, expected), real)
+        coef = momentum / (1 + momentum)
+        check = ctx.stft_is_fused(splan) and _finite_check_covers_input(expected, n_fft, hop, center)
+        if check:
+            ctx.nonfinite_reset()
+        ctx.griffinlim_update(angles, None, s_ptr, angles, count, real, 0.0, eps, normalize=False)       # angles *= S  (:2847)
+        have_prev = False
+        for _ in range(int(n_iter)):
+            ctx.istft_exec(iplan, angles, batch, n_total * n_bins, n_bins, n_used, wss_ptr, y_ptr, expected, expected)   # :2850
+            ctx.stft_exec(splan, y_ptr, batch, expected, expected, rebuilt)                                                # :2863
+            ctx.griffinlim_update(rebuilt, tprev if have_prev else None, s_ptr, angles, count, real, coef, eps)            # :2875-2880
+            rebuilt, tprev = tprev, rebuilt                                                                                # :2882
+            have_prev = True
+        ctx.istft_exec(iplan, angles, batch, n_total * n_bins, n_bins, n_used, wss_ptr, y_ptr, expected, expected)       # :2885
+        if check and ctx.nonfinite_read():
+            raise ParameterError("Audio buffer is not finite everywhere")
+        y = sess.result(handle)
+    finally:
+        sess.close()
+    return _arrays.cast(y.reshape(lead + (expected,)), out_dtype)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -1504,6 +1504,20 @@ int lra_from_db_exec(lra_ctx* ctx, const void* x, void* out, int64_t count, int 
     return LRA_OK;
 }
 
+int lra_griffinlim_update(lra_ctx* ctx, const void* rebuilt, const void* tprev, const void* S, void* angles, int64_t count, int dtype, double coef, double eps, int normalize) {
+    LRA_BIND(ctx);
+    if (count <= 0) return LRA_OK;
+    if (!rebuilt || !S || !angles) return fail(LRA_EINVAL, "null data pointer");
+    long long grid = (count + 255) / 256;
+    if (grid > 64LL * ctx->n_cu) grid = 64LL * ctx->n_cu;
+#define LRA_GL(T, N) hipLaunchKernelGGL((griffinlim_update_kernel<T, N>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const Cplx2<T>*)rebuilt, (const Cplx2<T>*)tprev, (const T*)S, (Cplx2<T>*)angles, (long long)count, (T)coef, (T)eps)
+    if (dtype == LRA_F64) { if (normalize) LRA_GL(double, true); else LRA_GL(double, false); }
+    else { if (normalize) LRA_GL(float, true); else LRA_GL(float, false); }
+#undef LRA_GL
+    LRA_HIP(hipGetLastError());
+    return LRA_OK;
+}
+
 int lra_dct_exec(lra_ctx* ctx, const void* S, void* out, int64_t batch, int n_in, int n_out, int64_t n_frames, int dtype, const void* basis, const void* lift, int fuse_db, double amin,
                  double ref_scalar, const void* ref_items, const void* item_max, int use_top_db, double top_db) {
     LRA_BIND(ctx);

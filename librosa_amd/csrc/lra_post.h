@@ -135,4 +135,53 @@ __global__ __launch_bounds__(256) void dct_rows_kernel(const T* __restrict__ S, 
         if (k < n_out) o[(long long)k * n_frames] = acc[k] * lift[k];
 }
 
+// ---- Griffin-Lim phase update -----------------------------------------------------------------------
+//   librosa/core/spectrum.py:2896-2902:  angles = rebuilt - momentum/(1+momentum) tprev;  angles /= |angles| + eps;  angles *= S
+// Elementwise over `count` complex values in any common layout (the arrays here are [batch][frame][bin]); 28 bytes per value.
+// The arithmetic follows NumPy's complex64 / complex128 loops operation by operation (no contraction into fma, which would
+// change the rounding): coef * tprev per component, the subtraction, |.| as the correctly rounded hypot (double-width square
+// root for f32; NumPy's own float32 hypot differs from it in the last bit depending on the host's SIMD dispatch), complex /
+// real as multiplication by the reciprocal 1 / (|.| + eps) (NumPy's Smith division with a zero imaginary divisor), then the
+// two products with S.
+// hipcc contracts a * b - c into fma by default (-ffp-contract=fast): the operations below are emitted with contraction off,
+// and only they.
+#pragma clang fp contract(off)
+template <class T> struct Cplx2 { T x, y; };
+template <class T> __device__ __forceinline__ T gl_hypot(T a, T b);
+template <> __device__ __forceinline__ float gl_hypot<float>(float a, float b) { return (float)sqrt((double)a * (double)a + (double)b * (double)b); }  // exact products, one rounding in the sum
+template <> __device__ __forceinline__ double gl_hypot<double>(double a, double b) { return hypot(a, b); }
+// one rounding per operation: plain operators compiled with contraction off (ROCm's __fmul_rn / __fsub_rn are plain operators
+// in a header compiled with contraction ON, so they fuse)
+template <class T> struct RnOps {
+    static __device__ __forceinline__ T mul(T a, T b) { return a * b; }
+    static __device__ __forceinline__ T sub(T a, T b) { return a - b; }
+    static __device__ __forceinline__ T add(T a, T b) { return a + b; }
+    static __device__ __forceinline__ T div(T a, T b) { return a / b; }
+};
+#pragma clang fp contract(fast)
+
+// NORMALIZE = false: angles = rebuilt * S only (the initial "absorb magnitudes into angles", :2847)
+template <class T, bool NORMALIZE>
+__global__ __launch_bounds__(256) void griffinlim_update_kernel(const Cplx2<T>* __restrict__ rebuilt, const Cplx2<T>* __restrict__ tprev /* or nullptr */, const T* __restrict__ S,
+                                                                Cplx2<T>* angles /* may alias rebuilt */, long long count, T coef, T eps) {
+    using R = RnOps<T>;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+        Cplx2<T> a = rebuilt[i];
+        if (NORMALIZE) {
+            if (tprev) {
+                const Cplx2<T> t = tprev[i];
+                a.x = R::sub(a.x, R::mul(coef, t.x));
+                a.y = R::sub(a.y, R::mul(coef, t.y));
+            }
+            const T scl = R::div((T)1, R::add(gl_hypot<T>(a.x, a.y), eps));
+            a.x = R::mul(a.x, scl);
+            a.y = R::mul(a.y, scl);
+        }
+        const T s = S[i];
+        a.x = R::mul(a.x, s);
+        a.y = R::mul(a.y, s);
+        angles[i] = a;
+    }
+}
+
 }  // namespace lra

@@ -67,6 +67,20 @@ CASES = {
 }
 
 
+# SURVEY.md 8f rank 3 -- griffinlim (reference tests: tests/test_core.py:2583-2711: win_length < n_fft, n_fft = 2049,
+# pad_mode="reflect", length=, momentum 0 / 0.99, init None / "random").  name -> dict(signal, stft kwargs that produce the
+# magnitude, griffinlim kwargs)
+GRIFFINLIM_CASES = {
+    "gl_n512_h128_rand": dict(signal=("chirp", 6000, 31, None, "float32"), stft=dict(n_fft=512, hop_length=128), gl=dict(n_iter=4, hop_length=128, rng=0)),
+    "gl_n512_win400_reflect_len": dict(signal=("chirp", 6000, 32, None, "float32"), stft=dict(n_fft=512, hop_length=128, win_length=400, pad_mode="reflect"),
+                                       gl=dict(n_iter=8, hop_length=128, win_length=400, n_fft=512, pad_mode="reflect", length=6000, rng=3)),
+    "gl_n1024_init_none_mom0": dict(signal=("mix", 9000, 33, None, "float32"), stft=dict(n_fft=1024), gl=dict(n_iter=3, init=None, momentum=0.0)),
+    "gl_n2049_odd": dict(signal=("chirp", 12000, 34, None, "float32"), stft=dict(n_fft=2049, hop_length=512), gl=dict(n_iter=2, n_fft=2049, hop_length=512, rng=5)),
+    "gl_stereo_n2048_32iter": dict(signal=("mix", 22050, 35, (2,), "float32"), stft=dict(n_fft=2048, hop_length=512), gl=dict(n_iter=32, hop_length=512, rng=7)),
+    "gl_f64_n512": dict(signal=("chirp", 5000, 36, None, "float64"), stft=dict(n_fft=512, hop_length=128), gl=dict(n_iter=3, hop_length=128, rng=11)),
+}
+
+
 def split_mel_kwargs(mel_kwargs):
     """melspectrogram kwargs -> (power, filter kwargs)."""
     kw = dict(mel_kwargs)

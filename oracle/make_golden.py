@@ -88,6 +88,20 @@ def main():
     np.savez_compressed(os.path.join(OUT, "config2_clips.npz"), params=json.dumps(dict(case="config2", **meta)), **store)
     print("config2 done")
     make_db_mfcc(librosa, meta)
+    make_griffinlim(librosa, meta)
+
+
+def make_griffinlim(librosa, meta):
+    """librosa.griffinlim outputs of the reference on |stft| of seeded signals."""
+    store = {}
+    for name, case in golden_cases.GRIFFINLIM_CASES.items():
+        kind, n, seed, channels, dtype = case["signal"]
+        y = golden_cases.make_signal(kind, n, seed, channels, dtype)
+        S = np.abs(librosa.stft(y, **case["stft"]))
+        store[f"{name}__S"] = S
+        store[f"{name}__y"] = librosa.griffinlim(S, **case["gl"])
+    np.savez_compressed(os.path.join(OUT, "griffinlim.npz"), params=json.dumps(dict(case="griffinlim", **meta)), **store)
+    print("griffinlim done")
 
 
 def make_db_mfcc(librosa, meta):
@@ -120,4 +134,10 @@ def make_db_mfcc(librosa, meta):
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "griffinlim":  # only this fixture (the others are unchanged)
+        _librosa = ref_shim.load_reference()
+        import scipy as _scipy
+
+        make_griffinlim(_librosa, dict(numpy=np.__version__, scipy=_scipy.__version__, reference_version=str(_librosa.__version__)))
+    else:
+        main()

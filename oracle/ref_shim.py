@@ -67,13 +67,36 @@ def _raising_decorator(name):
     return factory
 
 
+def _array_vectorize(*dargs, **dkwargs):
+    """numba.vectorize for scalar kernels whose bodies are plain NumPy expressions (``util/utils.py:2580-2637``:
+    ``_cabs2``, ``_phasor_angles``): the undecorated function already works elementwise on arrays; a trailing extra
+    positional argument is the ufunc's ``out``."""
+
+    def deco(fn):
+        nin = fn.__code__.co_argcount
+
+        @functools.wraps(fn)
+        def ufunc(*args):
+            res = fn(*args[:nin])
+            if len(args) > nin and args[nin] is not None:
+                args[nin][...] = res
+                return args[nin]
+            return res
+
+        return ufunc
+
+    if len(dargs) == 1 and callable(dargs[0]) and not dkwargs:
+        return deco(dargs[0])
+    return deco
+
+
 def _make_numba():
     m = types.ModuleType("numba")
     m.jit = _identity_decorator
     m.njit = _identity_decorator
     m.stencil = _raising_decorator("stencil")
     m.guvectorize = _raising_decorator("guvectorize")
-    m.vectorize = _raising_decorator("vectorize")
+    m.vectorize = _array_vectorize
     m.__version__ = "0.0-stub"
     return m
 

@@ -416,6 +416,58 @@ def mfcc(*, y=None, sr=22050, S=None, n_mfcc=20, dct_type=2, norm="ortho", lifte
     raise ParameterError(f"MFCC lifter={lifter} must be a non-negative number")
 
 
+# ----------------------------------------------------------------------------- Griffin-Lim
+def phasor(angles, mag=None):
+    """``librosa/util/utils.py:2629-2637, 2700-2706``: cos + i sin in the precision of ``angles``, times ``mag``."""
+    angles = np.asarray(angles)
+    z = np.empty_like(angles, dtype=dtype_r2c(angles.dtype))
+    z[...] = np.cos(angles) + 1j * np.sin(angles)
+    if mag is not None:
+        z *= mag
+    return z
+
+
+def griffinlim_update(rebuilt, tprev, S, momentum, eps):
+    """One phase update, ``librosa/core/spectrum.py:2896-2902`` (in the precision of ``rebuilt``):
+    ``angles = rebuilt - momentum/(1+momentum) tprev; angles /= |angles| + eps; angles *= S``."""
+    angles = np.array(rebuilt, copy=True)
+    if tprev is not None:
+        angles -= (momentum / (1 + momentum)) * tprev
+    angles /= np.abs(angles) + eps
+    angles *= S
+    return angles
+
+
+def griffinlim(S, *, n_iter=32, hop_length=None, win_length=None, n_fft=None, window="hann", center=True, dtype=None, length=None, pad_mode="constant",
+               momentum=0.99, init="random", rng=None):
+    """``librosa/core/spectrum.py:2816-2917``: istft <-> stft fixed-point iteration with momentum ("fast" Griffin-Lim)."""
+    if not isinstance(rng, np.random.RandomState):
+        rng = np.random.default_rng(rng)                                            # :2812-2813
+    if momentum > 1:
+        warnings.warn(f"Griffin-Lim with momentum={momentum} > 1 can be unstable. Proceed with caution!", stacklevel=2)
+    elif momentum < 0:
+        raise ParameterError(f"griffinlim() called with momentum={momentum} < 0")
+    if n_fft is None:
+        n_fft = 2 * (S.shape[-2] - 1)                                               # :2825-2826
+    angles = np.empty(S.shape, dtype=dtype_r2c(S.dtype))                            # :2829
+    eps = tiny(angles)
+    if init == "random":
+        angles[:] = phasor(2 * np.pi * rng.random(size=S.shape))                    # :2834
+    elif init is None:
+        angles[:] = 1.0
+    else:
+        raise ParameterError(f"init={init} must either None or 'random'")
+    tprev = None
+    angles *= S                                                                     # :2847
+    kw_i = dict(hop_length=hop_length, win_length=win_length, n_fft=n_fft, window=window, center=center, dtype=dtype, length=length)
+    for _ in range(n_iter):
+        inverse = istft(angles, **kw_i)                                             # :2850-2860
+        rebuilt = stft(inverse, n_fft=n_fft, hop_length=hop_length, win_length=win_length, window=window, center=center, pad_mode=pad_mode)  # :2863-2872
+        angles[:] = griffinlim_update(rebuilt, tprev, S, momentum, eps)             # :2875-2880
+        tprev = rebuilt                                                             # :2882
+    return istft(angles, **kw_i)                                                    # :2885-2895
+
+
 # ----------------------------------------------------------------------------- synthetic inputs
 def config_input(batch, n=661500, sr=22050, seed=440, first_clip=0):
     """SURVEY.md 8(d) config-2/3 generator: 0.1*noise + 0.5*sin(2 pi f_i t), f_i = 110*2^((i%72)/12).

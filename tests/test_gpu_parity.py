@@ -708,3 +708,123 @@ def test_istft_bins_follow_n_fft_like_irfft(L):
         ref = O.istft(D, n_fft=n_fft, hop_length=256)
         assert got.shape == ref.shape
         assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
+# ---- Griffin-Lim (librosa/core/spectrum.py:2669-2917) ------------------------------------------------
+def _spectral_convergence(y, S, skw):
+    """|| |stft(y)| - S || / || S ||  (the quantity Griffin-Lim descends on), evaluated with the oracle."""
+    R = np.abs(O.stft(y, **skw))
+    return float(np.linalg.norm(R - S) / np.linalg.norm(S))
+
+
+def test_griffinlim_update_kernel(L):
+    """The phase update follows NumPy's complex64 loops operation by operation (lra_post.h)."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    ctx = L.get_context(0)
+    for real, cplx in ((np.float32, np.complex64), (np.float64, np.complex128)):
+        n = 100003
+        rebuilt = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(cplx)
+        tprev = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(cplx)
+        rebuilt[:7] = 0  # |angles| = 0: the eps in the denominator decides
+        tprev[:3] = 0
+        S = np.abs(rng.standard_normal(n)).astype(real)
+        eps = float(np.finfo(real).tiny)
+        for mom, prev in ((0.99, tprev), (0.3, tprev), (0.99, None)):
+            ref = O.griffinlim_update(rebuilt, prev, S, mom, np.finfo(real).tiny)
+            r, s = torch.from_numpy(rebuilt).cuda(), torch.from_numpy(S).cuda()
+            t = torch.from_numpy(prev).cuda() if prev is not None else None
+            out = torch.empty_like(r)
+            ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+            ctx.griffinlim_update(r.data_ptr(), t.data_ptr() if t is not None else None, s.data_ptr(), out.data_ptr(), n, real, mom / (1 + mom), eps)
+            got = out.cpu().numpy()
+            # NumPy's |complex64| is a float32 hypot whose last bit depends on the host's SIMD dispatch; the kernel's is the
+            # correctly rounded one, everything else follows NumPy's operation order (the last-bit difference of |.| passes through
+            # a reciprocal and two products)
+            assert np.all(np.abs(got.real - ref.real) <= 4 * np.finfo(real).eps * np.abs(ref.real)), (mom, prev is None)
+            assert np.all(np.abs(got.imag - ref.imag) <= 4 * np.finfo(real).eps * np.abs(ref.imag)), (mom, prev is None)
+
+
+@pytest.mark.parametrize("name", list(golden_cases.GRIFFINLIM_CASES))
+def test_griffinlim_golden(L, name):
+    """Against the reference's own output for the same seed.  The iteration is a fixed-point map, not a contraction: a
+    float32 FFT's 1e-7 differences grow by a small factor per round where |angles| is tiny, so the sample-wise bar is
+    loose and scaled by the iteration count; the quantity the algorithm minimises must match the reference's closely."""
+    g = np.load(os.path.join(GOLDEN_DIR, "griffinlim.npz"))
+    case = golden_cases.GRIFFINLIM_CASES[name]
+    S, ref = g[f"{name}__S"], g[f"{name}__y"]
+    y = L.griffinlim(S, **case["gl"])
+    assert y.shape == ref.shape and y.dtype == ref.dtype
+    n_iter = case["gl"]["n_iter"]
+    err = np.abs(y - ref).max() / np.abs(ref).max()
+    if y.dtype == np.float64:
+        assert err <= 1e-9, err
+    else:
+        assert err <= (2e-4 if n_iter <= 8 else 5e-2), err
+    skw = dict(case["stft"])
+    c_ref, c_got = _spectral_convergence(ref, S, skw), _spectral_convergence(y, S, skw)
+    assert abs(c_got - c_ref) <= 0.02 * c_ref + 1e-6, (c_got, c_ref)
+
+
+@pytest.mark.parametrize("n_fft", [2048, 2049])
+@pytest.mark.parametrize("center", [False, True])
+@pytest.mark.parametrize("use_length", [False, True])
+@pytest.mark.parametrize("pad_mode", ["constant", "reflect"])
+@pytest.mark.parametrize("init", [None, "random"])
+def test_griffinlim_reference_matrix(L, n_fft, center, use_length, pad_mode, init):
+    """tests/test_core.py:2583-2640 (hop / win_length / window folded into two combinations per case)."""
+    y = golden_cases.make_signal("chirp", 22050, 41, None, "float32")
+    for hop_length, win_length, window in ((None, None, "hann"), (1024, 1024, "boxcar")):
+        S = np.abs(O.stft(y, hop_length=hop_length, win_length=win_length, n_fft=n_fft, window=window, center=center, pad_mode=pad_mode))
+        kw = dict(hop_length=hop_length, win_length=win_length, n_fft=n_fft, window=window, center=center, length=len(y) if use_length else None, pad_mode=pad_mode, n_iter=1, init=init)
+        y_rec = L.griffinlim(S, rng=0, **kw)
+        if use_length:
+            assert len(y_rec) == len(y)
+        assert np.isrealobj(y_rec) and np.all(np.isfinite(y_rec))
+        ref = O.griffinlim(S, rng=0, **kw)
+        assert y_rec.shape == ref.shape
+        well = _wss_for(dict(n_fft=n_fft, hop_length=hop_length, win_length=win_length, window=window, center=center), S.shape[-1], ref.shape[-1], kw["length"], np.float32)
+        well = well > 1e-2 * well.max()
+        # init=None starts from zero phases: the first rebuilt spectrum is full of near-cancellations, whose normalisation
+        # (angles / |angles|) amplifies float32 rounding
+        assert np.abs(y_rec - ref)[well].max() <= (1e-4 if init == "random" else 2e-3) * np.abs(ref).max()
+
+
+def test_griffinlim_arguments(L):
+    """tests/test_core.py:2643-2711: dtype, momentum, rng state, deprecated random_state, error paths."""
+    import torch
+
+    y = golden_cases.make_signal("chirp", 22050, 42, None, "float32")
+    S = np.abs(O.stft(y))
+    for dt in (np.float32, np.float64):
+        assert L.griffinlim(S, dtype=dt, n_iter=1).dtype == dt
+    for momentum in (0, 0.99):
+        L.griffinlim(S, momentum=momentum, n_iter=1)
+    a, b = L.griffinlim(S, rng=0, n_iter=1), L.griffinlim(S, rng=0, n_iter=1)
+    assert np.array_equal(a, b)
+    L.griffinlim(S, rng=np.random.RandomState(), n_iter=1)
+    with pytest.warns(FutureWarning, match="renamed to 'rng'"):
+        y1 = L.griffinlim(S, n_iter=2, random_state=5)
+    assert np.array_equal(y1, L.griffinlim(S, n_iter=2, rng=5))
+    x = np.zeros((33, 3))
+    with pytest.raises(L.ParameterError):
+        L.griffinlim(x, init="garbage")
+    with pytest.raises(TypeError):
+        L.griffinlim(x, rng="garbage")
+    with pytest.raises(L.ParameterError):
+        L.griffinlim(x, rng=0, random_state=0)
+    with pytest.raises(L.ParameterError):
+        L.griffinlim(x, momentum=-1)
+    with pytest.warns(UserWarning):
+        z = L.griffinlim(x, momentum=2)
+    assert z.shape == (32,) and z.dtype == np.float64 and np.all(z == 0)
+    # device tensors: same numbers, nothing leaves the device
+    St = torch.from_numpy(S).cuda()
+    yt = L.griffinlim(St, rng=3, n_iter=4)
+    assert isinstance(yt, torch.Tensor) and yt.is_cuda
+    assert np.array_equal(yt.cpu().numpy(), L.griffinlim(S, rng=3, n_iter=4))
+    # a batch is processed clip by clip with one stream of random phases, exactly like the reference
+    Sb = np.stack([S, 0.5 * S])
+    yb = L.griffinlim(Sb, rng=1, n_iter=3)
+    assert np.abs(yb - O.griffinlim(Sb, rng=1, n_iter=3)).max() <= 2e-4 * np.abs(yb).max()

@@ -245,3 +245,26 @@ def test_db_and_mfcc_oracle_matches_reference_goldens():
         O.power_to_db(M, amin=0)
     with pytest.raises(O.ParameterError):
         O.mfcc(S=g["db_default"], lifter=-1)
+
+
+# ---- Griffin-Lim -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(golden_cases.GRIFFINLIM_CASES))
+def test_griffinlim_oracle_matches_reference_golden(name):
+    """The restatement of librosa/core/spectrum.py:2816-2917 reproduces the reference's output bit for bit (same rng
+    stream, same operation order) on the committed fixtures (oracle/make_golden.py::make_griffinlim)."""
+    g = np.load(os.path.join(GOLDEN_DIR, "griffinlim.npz"))
+    case = golden_cases.GRIFFINLIM_CASES[name]
+    y = O.griffinlim(g[f"{name}__S"], **case["gl"])
+    ref = g[f"{name}__y"]
+    assert y.dtype == ref.dtype and np.array_equal(y, ref)
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="/root/reference not present (GPU box)")
+def test_griffinlim_oracle_live_reference():
+    librosa = ref_shim.load_reference()
+    y = golden_cases.make_signal("mix", 7000, 51, None, "float32")
+    for skw, gkw in ((dict(n_fft=512, hop_length=160), dict(hop_length=160, n_iter=5, rng=9, momentum=0.5)),
+                     (dict(n_fft=400, hop_length=100, center=False), dict(hop_length=100, n_fft=400, center=False, n_iter=2, init=None))):
+        S = np.abs(librosa.stft(y, **skw))
+        assert np.array_equal(O.griffinlim(S, **gkw), librosa.griffinlim(S, **gkw))
+    assert np.array_equal(O.phasor(np.linspace(-7, 7, 101)), librosa.util.phasor(np.linspace(-7, 7, 101)))
