@@ -116,6 +116,20 @@ int lra_stft_exec(lra_stft_plan* plan, const void* y, int64_t batch, int64_t n, 
 /* S[batch][n_frames][n_bins] = |stft|**power  (_spectrogram, core/spectrum.py:3000-3013). */
 int lra_spectrogram_exec(lra_stft_plan* plan, const void* y, int64_t batch, int64_t n, int64_t y_stride, double power, void* S);
 
+/* Host-buffer form of the three forward calls (what librosa.stft / _spectrogram / feature.melspectrogram take: NumPy arrays,
+ * core/spectrum.py:57-391, :2920-3015, feature/spectral.py:2145-2160).  y_host: [batch] rows of n reals, y_stride elements
+ * apart, pageable host memory; out_host: [batch] items of [n_frames][n_bins] complex (kind 0), [n_frames][n_bins] reals
+ * (kind 1, |X|**power) or [n_mels][n_frames] reals (kind 2; mel required), out_item_stride reals apart (0 = packed).
+ * Clips are moved in stages of ~pipe_chunk_mb (ctx option): host threads copy to / from pinned staging while the previous
+ * stage's upload, kernel and download run on their own streams, so the call runs at link rate instead of at the rate of
+ * a pageable copy.  Staging and device buffers persist in the context: a streaming caller (librosa.stream blocks ->
+ * stft(center=False, out=D), docs/examples/plot_pcen_stream.py:72-74) allocates nothing after its first block.
+ * nonfinite (optional): the staging threads also apply util.valid_audio's test (util/utils.py:305: every sample finite) to
+ * the samples they copy; *nonfinite != 0 when it failed (the caller raises, the output is then meaningless).
+ * Synchronous: out_host is complete on return. */
+int lra_stft_exec_host(lra_stft_plan* plan, lra_mel_plan* mel, int kind, const void* y_host, int64_t batch, int64_t n, int64_t y_stride, double power,
+                       void* out_host, int64_t out_item_stride, int* nonfinite);
+
 /* ---- mel: librosa.filters.mel (filters.py:116-251) applied as in feature/spectral.py:2158-2160 */
 /* basis: host pointer, dense [n_mels][n_bins] reals of `dtype`, built by the shim on the host with
  * the reference's float64 recipe (so it is bit-identical to filters.mel); stored on the device in

@@ -71,6 +71,7 @@ SIGNATURES = {
     "lra_item_absmax_exec": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "lra_to_db_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_int, c_double]),
     "lra_from_db_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_double]),
+    "lra_stft_exec_host": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p, c_int64, POINTER(c_int)]),
     "lra_griffinlim_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_double, c_double, c_int]),
     "lra_dct_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_int, c_double, c_double, c_void_p, c_void_p, c_int, c_double]),
 }
@@ -316,6 +317,12 @@ class Context:
 
     def melspectrogram_exec(self, plan, mel_plan, y_ptr, batch, n, y_stride, power, out_ptr):
         _check(self.lib.lra_melspectrogram_exec(plan, mel_plan, c_void_p(y_ptr), batch, n, y_stride, float(power), c_void_p(out_ptr)))
+
+    def stft_exec_host(self, plan, mel_plan, kind, y_host_ptr, batch, n, y_stride, power, out_host_ptr, out_item_stride=0):
+        """Host buffers in, host buffers out (chunked, overlapped staging); returns the non-finite flag."""
+        flag = c_int(0)
+        _check(self.lib.lra_stft_exec_host(plan, mel_plan, int(kind), c_void_p(y_host_ptr), batch, n, y_stride, float(power), c_void_p(out_host_ptr), int(out_item_stride), ctypes.byref(flag)))
+        return bool(flag.value)
 
     def mel_apply_exec(self, mel_plan, s_ptr, batch, n_frames, batch_stride, bin_stride, frame_stride, out_ptr):
         _check(self.lib.lra_mel_apply_exec(mel_plan, c_void_p(s_ptr), batch, n_frames, batch_stride, bin_stride, frame_stride, c_void_p(out_ptr)))

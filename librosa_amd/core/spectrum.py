@@ -47,8 +47,22 @@ def _validate_audio(y, check_finite):
         if y.ndim == 0:
             raise ParameterError(f"Audio data must be at least one-dimensional, given y.shape={tuple(y.shape)}")
         return bool(check_finite)
-    util.valid_audio(y)
-    return False
+    util.valid_audio(y, scan=False)  # type / rank checks now; the finite scan rides on the staging copy (lra_stft_exec_host)
+    return True
+
+
+def _all_finite(y):
+    return bool(_arrays._torch().isfinite(y).all()) if is_torch_tensor(y) else bool(np.isfinite(y).all())
+
+
+def _direct_out(out, n_frames, n_bins, dtype):
+    """``out=`` of ``stft``: (target, pointer-able base, item stride in reals) when the kernels' [frame][bin] layout can be
+    written into ``out`` in place -- i.e. ``out`` is laid out like the array ``stft`` itself returns (each frame's
+    spectrum contiguous, ``core/spectrum.py:356``), possibly with more columns than needed -- else (target, None, 0)."""
+    target = out if out.shape[-1] == n_frames else out[..., :n_frames]
+    if out.dtype == np.dtype(dtype) and np.swapaxes(out, -1, -2).flags["C_CONTIGUOUS"] and out.flags["WRITEABLE"]:
+        return target, out, int(out.shape[-1]) * n_bins * 2
+    return target, None, 0
 
 
 def _prepare_stft(y, n_fft, hop_length, win_length, window, center, pad_mode, _warn_level=4):
@@ -96,7 +110,7 @@ def _finite_check_covers_input(n, n_fft, hop, center):
     return covered_hi >= (n + (n_fft // 2 if center else 0))
 
 
-def _run_stft_family(kind, y, *, n_fft, hop_length, win_length, window, center, pad_mode, dtype=None, power=1.0, mel_basis=None, check_finite=True, post=None):
+def _run_stft_family(kind, y, *, n_fft, hop_length, win_length, window, center, pad_mode, dtype=None, power=1.0, mel_basis=None, check_finite=True, post=None, out=None):
     """kind in {"stft", "power", "mel"}.  Returns the result laid out like the reference's.
 
     ``post(sess, mel_ptr, batch, n_mels, n_frames, real) -> (handle, rows)`` (mel only) chains further device work on the mel
@@ -122,13 +136,49 @@ def _run_stft_family(kind, y, *, n_fft, hop_length, win_length, window, center, 
         plan = ctx.stft_plan(n_fft, hop, fft_window.astype(real), center, pad_mode, real)
         n_frames = ctx.stft_num_frames(plan, n)
         fused = ctx.stft_is_fused(plan)
-        if need_device_check:
+        if out is not None:  # shape / dtype checks of core/spectrum.py:357-367, before any work
+            shape = list(lead) + [n_bins, n_frames]
+            if not (np.allclose(out.shape[:-1], shape[:-1]) and out.shape[-1] >= shape[-1]):
+                raise ParameterError(f"Shape mismatch for provided output array out.shape={out.shape} and target shape={shape}")
+            if not np.iscomplexobj(out):
+                raise ParameterError(f"output with dtype={out.dtype} is not of complex type")
+        host_pipeline = not sess.is_torch and post is None
+        if need_device_check and not host_pipeline:
             if fused and _finite_check_covers_input(n, n_fft, hop, center):
                 ctx.nonfinite_reset()
             else:
                 need_device_check = False
-                if not bool(_arrays._torch().isfinite(y).all()):
+                if not _all_finite(y):
                     raise ParameterError("Audio buffer is not finite everywhere")
+        if host_pipeline:
+            # NumPy in, NumPy out: the native host pipeline (chunked, overlapped staging; include/librosa_amd.h)
+            a = np.ascontiguousarray(y, dtype=real).reshape(-1, n)
+            batch = a.shape[0]
+            mel_plan, target, stride = None, None, 0
+            if kind == "stft":
+                cdt = np.dtype(util.dtype_r2c(real))
+                if out is not None:
+                    target, base, stride = _direct_out(out, n_frames, n_bins, cdt)
+                    host = base
+                if out is None or base is None:
+                    host, stride = np.empty((batch, n_frames, n_bins), dtype=cdt), 0
+            elif kind == "power":
+                host = np.empty((batch, n_frames, n_bins), dtype=real)
+            else:
+                n_mels = int(mel_basis.shape[0])
+                mel_plan = ctx.mel_plan(np.ascontiguousarray(mel_basis, dtype=real))
+                host = np.empty((batch, n_mels, n_frames), dtype=real)
+            flagged = ctx.stft_exec_host(plan, mel_plan, {"stft": 0, "power": 1, "mel": 2}[kind], a.ctypes.data, batch, n, n, power, host.ctypes.data, stride)
+            if flagged:  # util.valid_audio's scan (util/utils.py:305), done by the staging threads on the samples they copy
+                raise ParameterError("Audio buffer is not finite everywhere")
+            if kind == "mel":
+                return host.reshape(lead + (n_mels, n_frames))
+            if target is not None:
+                if host is not out:
+                    target[...] = _arrays.swap_last_two(host.reshape(lead + (n_frames, n_bins)))
+                return target
+            res = _arrays.swap_last_two(host.reshape(lead + (n_frames, n_bins)))
+            return _arrays.cast(res, out_dtype) if kind == "stft" else res
         y_ptr, batch, _, y_stride = sess.input_2d(y, real)
         if kind == "stft":
             ptr, handle = sess.output((batch, n_frames, n_bins), util.dtype_r2c(real))
@@ -146,7 +196,7 @@ def _run_stft_family(kind, y, *, n_fft, hop_length, win_length, window, center, 
         if need_device_check and ctx.nonfinite_read():
             # the flag says "some frame's DC bin is not finite"; finite samples of enormous magnitude overflow it
             # too, so the samples themselves decide (util.valid_audio tests np.isfinite(y), util/utils.py:305)
-            if not bool(_arrays._torch().isfinite(y).all()):
+            if not _all_finite(y):
                 raise ParameterError("Audio buffer is not finite everywhere")
         res = sess.result(handle)
     finally:
@@ -173,18 +223,8 @@ def stft(y, *, n_fft=2048, hop_length=None, win_length=None, window="hann", cent
     """
     if out is not None and is_torch_tensor(y):
         raise ParameterError("out= is only supported for numpy inputs")
-    D = _run_stft_family("stft", y, n_fft=n_fft, hop_length=hop_length, win_length=win_length, window=window, center=center, pad_mode=pad_mode,
-                         dtype=dtype if out is None else (dtype or util.dtype_r2c(_arrays.numpy_dtype_of(y))), check_finite=check_finite)
-    if out is None:
-        return D
-    shape = list(D.shape)
-    if not (np.allclose(out.shape[:-1], shape[:-1]) and out.shape[-1] >= shape[-1]):
-        raise ParameterError(f"Shape mismatch for provided output array out.shape={out.shape} and target shape={shape}")
-    if not np.iscomplexobj(out):
-        raise ParameterError(f"output with dtype={out.dtype} is not of complex type")
-    target = out if np.allclose(shape, out.shape) else out[..., : shape[-1]]
-    target[...] = D
-    return target
+    return _run_stft_family("stft", y, n_fft=n_fft, hop_length=hop_length, win_length=win_length, window=window, center=center, pad_mode=pad_mode,
+                            dtype=dtype if out is None else (dtype or util.dtype_r2c(_arrays.numpy_dtype_of(y))), check_finite=check_finite, out=out)
 
 
 def _spectrogram(*, y=None, S=None, n_fft=2048, hop_length=512, power=1, win_length=None, window="hann", center=True, pad_mode="constant"):

@@ -11,12 +11,14 @@
 #include <rocfft/rocfft.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/librosa_amd.h"
@@ -72,6 +74,48 @@ struct lra_ctx {
     int opt_xcd_remap = 1;           // workgroup -> work item map that keeps neighbouring strips on one XCD (lra_kernels.h, xcd_block)
     unsigned int* d_flag = nullptr;  // non-finite input flag (device)
     std::string name;
+    struct HostPipe* pipe = nullptr;  // staging of the host-buffer entry points (lra_stft_exec_host), created on first use
+    int opt_pipe_chunk_mb = 128;      // bytes (in + out) one pipeline stage moves
+    int opt_pipe_threads = 8;         // host threads per staging copy
+};
+
+// Two-slot staging between pageable host buffers and the device for the host-buffer entry points: pinned buffers the DMA
+// engines read / write at link rate, device buffers that persist across calls (a streaming caller -- stft(center=False,
+// out=D) per block -- allocates nothing after its first block), one stream per direction next to the compute stream.
+struct HostPipe {
+    size_t in_cap = 0, out_cap = 0;  // bytes per slot
+    void* pin_in[2] = {nullptr, nullptr};
+    void* pin_out[2] = {nullptr, nullptr};
+    void* dev_in[2] = {nullptr, nullptr};
+    void* dev_out[2] = {nullptr, nullptr};
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+    void release_buffers(bool in, bool out) {
+        for (int i = 0; i < 2; ++i) {
+            if (in) {
+                if (pin_in[i]) (void)hipHostFree(pin_in[i]);
+                if (dev_in[i]) (void)hipFree(dev_in[i]);
+                pin_in[i] = dev_in[i] = nullptr;
+            }
+            if (out) {
+                if (pin_out[i]) (void)hipHostFree(pin_out[i]);
+                if (dev_out[i]) (void)hipFree(dev_out[i]);
+                pin_out[i] = dev_out[i] = nullptr;
+            }
+        }
+        if (in) in_cap = 0;
+        if (out) out_cap = 0;
+    }
+    ~HostPipe() {
+        release_buffers(true, true);
+        for (int i = 0; i < 2; ++i) {
+            if (ev_in[i]) (void)hipEventDestroy(ev_in[i]);
+            if (ev_comp[i]) (void)hipEventDestroy(ev_comp[i]);
+            if (ev_out[i]) (void)hipEventDestroy(ev_out[i]);
+        }
+        if (s_in) (void)hipStreamDestroy(s_in);
+        if (s_out) (void)hipStreamDestroy(s_out);
+    }
 };
 
 struct lra_event {
@@ -961,6 +1005,89 @@ int dct_run(lra_ctx* ctx, const T* S, T* out, long long batch, int n_in, int n_o
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
+// ---- host-buffer entry point: chunked, overlapped H2D / kernel / D2H ---------------------------------------------------------
+namespace {
+
+// util.valid_audio's finite test (util/utils.py:305) on a span of IEEE words: exponent field all ones
+template <class W, W MASK> bool span_has_nonfinite(const void* p, size_t bytes) {
+    const W* w = (const W*)p;
+    const size_t count = bytes / sizeof(W);
+    W bad = 0;
+    for (size_t i = 0; i < count; ++i) bad |= (W)((w[i] & MASK) == MASK);
+    return bad != 0;
+}
+
+// rows x row_bytes between a strided and a packed buffer, split over a few host threads (one core copies ~10 GB/s, the
+// link moves ~50).  scan_elem = 4 / 8: the copied samples (f32 / f64) are also tested for NaN / Inf while they are in
+// cache; returns true when one was seen.
+bool staged_copy(char* dst, size_t dst_stride, const char* src, size_t src_stride, size_t rows, size_t row_bytes, int threads, int scan_elem = 0) {
+    const size_t total = rows * row_bytes;
+    if (!total) return false;
+    std::atomic<int> bad{0};
+    auto span = [&bad, dst, dst_stride, src, src_stride, row_bytes, scan_elem](size_t lo, size_t hi) {
+        size_t pos = lo;
+        bool b = false;
+        while (pos < hi) {
+            const size_t r = pos / row_bytes, off = pos % row_bytes;
+            const size_t len = std::min(row_bytes - off, hi - pos);
+            char* d = dst + r * dst_stride + off;
+            std::memcpy(d, src + r * src_stride + off, len);
+            if (scan_elem == 4) b |= span_has_nonfinite<uint32_t, 0x7f800000u>(d, len);
+            else if (scan_elem == 8) b |= span_has_nonfinite<uint64_t, 0x7ff0000000000000ull>(d, len);
+            pos += len;
+        }
+        if (b) bad.store(1);
+    };
+    if (threads < 2 || total < (size_t)4 << 20) {
+        span(0, total);
+        return bad.load() != 0;
+    }
+    // byte spans (multiples of 8, so element boundaries are kept), not row ranges: one long row (a single clip) is shared too
+    std::vector<std::thread> pool;
+    const size_t per = (((total + threads - 1) / threads) + 7) & ~(size_t)7;
+    for (int t = 0; t < threads; ++t) {
+        const size_t lo = (size_t)t * per, hi = std::min(total, lo + per);
+        if (lo >= hi) break;
+        pool.emplace_back(span, lo, hi);
+    }
+    for (auto& th : pool) th.join();
+    return bad.load() != 0;
+}
+
+int pipe_ensure(lra_ctx* ctx, size_t in_bytes, size_t out_bytes) {
+    if (!ctx->pipe) {
+        ctx->pipe = new HostPipe();
+        HostPipe* hp = ctx->pipe;
+        LRA_HIP(hipStreamCreateWithFlags(&hp->s_in, hipStreamNonBlocking));
+        LRA_HIP(hipStreamCreateWithFlags(&hp->s_out, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            LRA_HIP(hipEventCreateWithFlags(&hp->ev_in[i], hipEventDisableTiming));
+            LRA_HIP(hipEventCreateWithFlags(&hp->ev_comp[i], hipEventDisableTiming));
+            LRA_HIP(hipEventCreateWithFlags(&hp->ev_out[i], hipEventDisableTiming));
+        }
+    }
+    HostPipe* hp = ctx->pipe;
+    if (in_bytes > hp->in_cap) {
+        hp->release_buffers(true, false);
+        for (int i = 0; i < 2; ++i) {
+            LRA_HIP(hipHostMalloc(&hp->pin_in[i], in_bytes, hipHostMallocDefault));
+            LRA_HIP(hipMalloc(&hp->dev_in[i], in_bytes));
+        }
+        hp->in_cap = in_bytes;
+    }
+    if (out_bytes > hp->out_cap) {
+        hp->release_buffers(false, true);
+        for (int i = 0; i < 2; ++i) {
+            LRA_HIP(hipHostMalloc(&hp->pin_out[i], out_bytes, hipHostMallocDefault));
+            LRA_HIP(hipMalloc(&hp->dev_out[i], out_bytes));
+        }
+        hp->out_cap = out_bytes;
+    }
+    return LRA_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 const char* lra_last_error(void) { return g_err.c_str(); }
@@ -1012,6 +1139,7 @@ int lra_ctx_create(int device, lra_ctx** out) {
 void lra_ctx_destroy(lra_ctx* ctx) {
     if (!ctx) return;
     DeviceGuard device_guard__(ctx->device);
+    delete ctx->pipe;
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
     delete ctx;
@@ -1042,6 +1170,8 @@ int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value) {
     else if (!std::strcmp(key, "mel_tile")) ctx->opt_mel_tile = value;
     else if (!std::strcmp(key, "ablate")) (void)value;  // retired development knob, accepted and ignored
     else if (!std::strcmp(key, "generic_mel")) ctx->opt_generic_mel = value;
+    else if (!std::strcmp(key, "pipe_chunk_mb")) ctx->opt_pipe_chunk_mb = value > 0 ? value : 128;
+    else if (!std::strcmp(key, "pipe_threads")) ctx->opt_pipe_threads = value > 0 ? value : 1;
     else if (!std::strcmp(key, "lds_pad")) ctx->opt_lds_pad = value;
     else if (!std::strcmp(key, "xcd_remap")) ctx->opt_xcd_remap = value != 0;
     else if (!std::strcmp(key, "v2")) ctx->opt_v2 = value != 0;
@@ -1383,6 +1513,77 @@ int lra_melspectrogram_exec(lra_stft_plan* stft, lra_mel_plan* mel, const void* 
     if (!stft || !mel) return fail(LRA_EINVAL, "null plan");
     return stft->dtype == LRA_F64 ? stft_run<double>(stft, OUT_MEL, y, batch, n, y_stride, power, mel, M)
                                   : stft_run<float>(stft, OUT_MEL, y, batch, n, y_stride, power, mel, M);
+}
+
+int lra_stft_exec_host(lra_stft_plan* p, lra_mel_plan* mel, int kind, const void* y_host, int64_t batch, int64_t n, int64_t y_stride, double power, void* out_host,
+                       int64_t out_item_stride, int* nonfinite) {
+    if (!p) return fail(LRA_EINVAL, "null plan");
+    lra_ctx* ctx = p->ctx;
+    LRA_BIND(ctx);
+    if (nonfinite) *nonfinite = 0;
+    if (kind < 0 || kind > 2) return fail(LRA_EINVAL, "kind must be 0 (complex), 1 (|X|^power) or 2 (mel)");
+    if (kind == 2 && !mel) return fail(LRA_EINVAL, "null mel plan");
+    if (batch <= 0) return LRA_OK;
+    if (!y_host || !out_host) return fail(LRA_EINVAL, "null data pointer");
+    int64_t T = 0;
+    LRA_TRY(lra_stft_num_frames(p, n, &T));
+    const size_t es = real_bytes(p->dtype);
+    const int64_t n_bins = p->n_fft / 2 + 1;
+    const size_t in_item = (size_t)n * es;
+    const size_t out_item = kind == 0 ? (size_t)T * n_bins * 2 * es : kind == 1 ? (size_t)T * n_bins * es : (size_t)T * mel->n_mels * es;
+    if (out_item_stride <= 0) out_item_stride = (int64_t)(out_item / es);
+    if ((size_t)out_item_stride * es < out_item) return fail(LRA_EINVAL, "out_item_stride smaller than one item");
+    // clips per stage: ~pipe_chunk_mb of traffic, at least one clip, at least two stages when there are two clips
+    int64_t per = (int64_t)(((size_t)ctx->opt_pipe_chunk_mb << 20) / (in_item + out_item));
+    per = std::max<int64_t>(1, std::min<int64_t>(per, (batch + 1) / 2));
+    LRA_TRY(pipe_ensure(ctx, (size_t)per * in_item, (size_t)per * out_item));
+    HostPipe* hp = ctx->pipe;
+    hipStream_t compute = ctx->stream;
+    const int64_t chunks = (batch + per - 1) / per;
+    const char* yh = (const char*)y_host;
+    char* oh = (char*)out_host;
+    auto drain = [&](int64_t c) -> int {  // pinned_out[slot of c] -> the caller's buffer
+        const int s = (int)(c & 1);
+        const int64_t b0 = c * per, nb = std::min(per, batch - b0);
+        LRA_HIP(hipEventSynchronize(hp->ev_out[s]));
+        staged_copy(oh + (size_t)b0 * out_item_stride * es, (size_t)out_item_stride * es, (const char*)hp->pin_out[s], out_item, (size_t)nb, out_item, ctx->opt_pipe_threads);
+        return LRA_OK;
+    };
+    int rc = LRA_OK;
+    bool bad_samples = false;
+    for (int64_t c = 0; c < chunks && rc == LRA_OK; ++c) {
+        const int s = (int)(c & 1);
+        const int64_t b0 = c * per, nb = std::min(per, batch - b0);
+        // slot s: its previous upload (chunk c - 2) must have left the pinned buffer before the host overwrites it
+        if (c >= 2) LRA_HIP(hipEventSynchronize(hp->ev_in[s]));
+        if (staged_copy((char*)hp->pin_in[s], in_item, yh + (size_t)b0 * y_stride * es, (size_t)y_stride * es, (size_t)nb, in_item, ctx->opt_pipe_threads, nonfinite ? (int)es : 0))
+            bad_samples = true;
+        if (c >= 2) LRA_HIP(hipStreamWaitEvent(hp->s_in, hp->ev_comp[s], 0));  // dev_in[s] is still read by chunk c - 2's kernel
+        LRA_HIP(hipMemcpyAsync(hp->dev_in[s], hp->pin_in[s], (size_t)nb * in_item, hipMemcpyHostToDevice, hp->s_in));
+        LRA_HIP(hipEventRecord(hp->ev_in[s], hp->s_in));
+        LRA_HIP(hipStreamWaitEvent(compute, hp->ev_in[s], 0));
+        if (c >= 2) LRA_HIP(hipStreamWaitEvent(compute, hp->ev_out[s], 0));  // dev_out[s] still being downloaded (chunk c - 2)
+        const int mode = kind == 0 ? OUT_COMPLEX : kind == 1 ? OUT_POWER : OUT_MEL;
+        rc = p->dtype == LRA_F64 ? stft_run<double>(p, mode, hp->dev_in[s], nb, n, n, power, kind == 2 ? mel : nullptr, hp->dev_out[s])
+                                 : stft_run<float>(p, mode, hp->dev_in[s], nb, n, n, power, kind == 2 ? mel : nullptr, hp->dev_out[s]);
+        if (rc != LRA_OK) break;
+        LRA_HIP(hipEventRecord(hp->ev_comp[s], compute));
+        // the previous chunk's download has been running meanwhile: hand it to the caller before its pinned slot is reused
+        if (c >= 1) rc = drain(c - 1);
+        if (rc != LRA_OK) break;
+        LRA_HIP(hipStreamWaitEvent(hp->s_out, hp->ev_comp[s], 0));
+        LRA_HIP(hipMemcpyAsync(hp->pin_out[s], hp->dev_out[s], (size_t)nb * out_item, hipMemcpyDeviceToHost, hp->s_out));
+        LRA_HIP(hipEventRecord(hp->ev_out[s], hp->s_out));
+    }
+    if (rc == LRA_OK) rc = drain(chunks - 1);
+    if (rc != LRA_OK) {  // leave no work in flight on buffers the next call reuses
+        (void)hipStreamSynchronize(hp->s_in);
+        (void)hipStreamSynchronize(compute);
+        (void)hipStreamSynchronize(hp->s_out);
+        return rc;
+    }
+    if (nonfinite) *nonfinite = bad_samples ? 1 : 0;
+    return LRA_OK;
 }
 
 int lra_mel_apply_exec(lra_mel_plan* mel, const void* S, int64_t batch, int64_t n_frames, int64_t batch_stride, int64_t bin_stride, int64_t frame_stride,

@@ -20,15 +20,18 @@ def is_torch_tensor(x) -> bool:
     return mod == "torch" or mod.startswith("torch.")
 
 
-def valid_audio(y) -> bool:
-    """``librosa/util/utils.py:294-306``: ndarray, floating, >= 1-d, finite everywhere."""
+def valid_audio(y, *, scan=True) -> bool:
+    """``librosa/util/utils.py:294-306``: ndarray, floating, >= 1-d, finite everywhere.
+
+    ``scan=False`` skips the pass over the samples (the fused kernels then report non-finite frames themselves and the
+    caller confirms on the samples only when they do)."""
     if not isinstance(y, np.ndarray):
         raise ParameterError("Audio data must be of type numpy.ndarray")
     if not np.issubdtype(y.dtype, np.floating):
         raise ParameterError("Audio data must be floating-point")
     if y.ndim == 0:
         raise ParameterError(f"Audio data must be at least one-dimensional, given y.shape={y.shape}")
-    if not np.isfinite(y).all():
+    if scan and not np.isfinite(y).all():
         raise ParameterError("Audio buffer is not finite everywhere")
     return True
 

@@ -468,6 +468,25 @@ def griffinlim(S, *, n_iter=32, hop_length=None, win_length=None, n_fft=None, wi
     return istft(angles, **kw_i)                                                    # :2885-2895
 
 
+# ----------------------------------------------------------------------------- block feeder
+def stream_blocks(y, *, block_length, frame_length, hop_length, fill_value=None):
+    """Blocks ``librosa.stream`` yields for an already decoded signal ``y`` ((n,) or (channels, n)), stated directly from
+    its two constants (``librosa/core/audio.py:409-410``): blocks of ``(block_length-1)*hop + frame_length`` samples,
+    ``block_length*hop`` apart, starting at every multiple of the advance below ``n`` (full blocks ``:488-491``, then the
+    remainder ``:507-520``, short unless ``fill_value`` pads it)."""
+    size = (block_length - 1) * hop_length + frame_length
+    advance = block_length * hop_length
+    n = y.shape[-1]
+    out = []
+    for lo in range(0, n, advance):
+        blk = y[..., lo : lo + size]
+        if blk.shape[-1] < size and fill_value is not None:
+            width = [(0, 0)] * (y.ndim - 1) + [(0, size - blk.shape[-1])]
+            blk = np.pad(blk, width, mode="constant", constant_values=fill_value)
+        out.append(np.array(blk, copy=True))
+    return out
+
+
 # ----------------------------------------------------------------------------- synthetic inputs
 def config_input(batch, n=661500, sr=22050, seed=440, first_clip=0):
     """SURVEY.md 8(d) config-2/3 generator: 0.1*noise + 0.5*sin(2 pi f_i t), f_i = 110*2^((i%72)/12).

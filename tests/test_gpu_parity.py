@@ -828,3 +828,80 @@ def test_griffinlim_arguments(L):
     Sb = np.stack([S, 0.5 * S])
     yb = L.griffinlim(Sb, rng=1, n_iter=3)
     assert np.abs(yb - O.griffinlim(Sb, rng=1, n_iter=3)).max() <= 2e-4 * np.abs(yb).max()
+
+
+# ---- NumPy drop-in through the native host pipeline; streaming ----------------------------------------
+def test_host_pipeline_chunking_and_finite_scan(L):
+    """lra_stft_exec_host: any staging granularity gives the same numbers as one device-resident call; the staging threads'
+    finite scan finds a single bad sample anywhere (util.valid_audio, util/utils.py:305)."""
+    import torch
+
+    ctx = L.get_context(0)
+    y = O.config_input(11, n=40000)
+    y64 = y.astype(np.float64)
+    try:
+        for mb in (1, 2, 128):
+            ctx.set_option("pipe_chunk_mb", mb)
+            D = L.stft(y, n_fft=1024, hop_length=256)
+            assert np.array_equal(D, L.stft(torch.from_numpy(y).cuda(), n_fft=1024, hop_length=256).cpu().numpy())
+            M = L.feature.melspectrogram(y=y, sr=22050, n_fft=1024, hop_length=256, n_mels=40)
+            assert np.array_equal(M, L.feature.melspectrogram(y=torch.from_numpy(y).cuda(), sr=22050, n_fft=1024, hop_length=256, n_mels=40).cpu().numpy())
+            S, _ = L._spectrogram(y=y, n_fft=1024, hop_length=256, power=1)
+            assert _stft_close(S.astype(np.complex64), np.abs(O.stft(y, n_fft=1024, hop_length=256)).astype(np.complex64))
+            D64 = L.stft(y64, n_fft=1000, hop_length=250)  # rocFFT path, float64
+            assert _stft_close(D64, O.stft(y64, n_fft=1000, hop_length=250))
+        ctx.set_option("pipe_chunk_mb", 1)
+        for b, i in ((0, 0), (10, 39999), (5, 20001)):
+            for v in (np.nan, np.inf, -np.inf):
+                bad = y.copy()
+                bad[b, i] = v
+                with pytest.raises(L.ParameterError, match="not finite"):
+                    L.stft(bad, n_fft=1024, hop_length=256)
+                with pytest.raises(L.ParameterError, match="not finite"):
+                    L.feature.melspectrogram(y=bad.astype(np.float64), sr=22050, n_fft=512, hop_length=2000)  # hop > n_fft: no frame sees every sample
+        big = y.copy()
+        big[3, 7] = 3e38  # finite: overflows the DC bin, but valid_audio looks at the samples
+        assert L.stft(big, n_fft=1024, hop_length=256).shape == D.shape
+    finally:
+        ctx.set_option("pipe_chunk_mb", 128)
+    # non-contiguous / strided input
+    ys = np.asfortranarray(y)
+    assert np.array_equal(L.stft(ys, n_fft=1024, hop_length=256), D)
+
+
+def test_streaming_stft_out_reuse(L):
+    """docs/examples/plot_pcen_stream.py:72-74: D = stft(block, center=False, out=D) over librosa.stream blocks; the output
+    array and every staging / device buffer are reused from the second block on, and the tiled frames are the STFT of the
+    whole signal."""
+    n_fft, hop, block_length = 2048, 512, 16
+    y = O.config_input(1, n=22050 * 4)[0]
+    whole = O.stft(y, n_fft=n_fft, hop_length=hop, center=False)
+    D, cols, ident = None, [], []
+    for blk in L.stream(y, block_length=block_length, frame_length=n_fft, hop_length=hop, fill_value=0.0):
+        D2 = L.stft(blk, n_fft=n_fft, hop_length=hop, center=False, out=D)
+        ident.append(D is None or D2 is D)
+        D = D2
+        cols.append(D.copy())
+    assert all(ident) and D.shape == (1025, block_length)
+    tiled = np.concatenate(cols, axis=-1)[:, : whole.shape[1]]
+    assert _stft_close(tiled, whole)
+    # the reference's preallocation matrix: wider out, C-ordered out, wrong shapes (tests/test_core.py:317-371)
+    blk = y[: (block_length - 1) * hop + n_fft]
+    ref = O.stft(blk, n_fft=n_fft, hop_length=hop, center=False)
+    wide_f = np.zeros((1025, block_length + 5), dtype=np.complex64, order="F")
+    r = L.stft(blk, n_fft=n_fft, hop_length=hop, center=False, out=wide_f)
+    assert r.shape == ref.shape and np.shares_memory(r, wide_f) and _stft_close(r, ref) and np.all(wide_f[:, block_length:] == 0)
+    wide_c = np.zeros((1025, block_length + 5), dtype=np.complex64)
+    r = L.stft(blk, n_fft=n_fft, hop_length=hop, center=False, out=wide_c)
+    assert np.shares_memory(r, wide_c) and _stft_close(r, ref)
+    out128 = np.zeros((1025, block_length), dtype=np.complex128)
+    r = L.stft(blk, n_fft=n_fft, hop_length=hop, center=False, out=out128)
+    assert r is out128 and _stft_close(r.astype(np.complex64), ref)
+    stereo = np.stack([blk, -blk])
+    outs = np.zeros((2, 1025, block_length + 1), dtype=np.complex64)
+    r = L.stft(stereo, n_fft=n_fft, hop_length=hop, center=False, out=outs)
+    assert np.shares_memory(r, outs) and _stft_close(r[0], ref) and _stft_close(r[1], -ref)
+    with pytest.raises(L.ParameterError):
+        L.stft(blk, n_fft=n_fft, hop_length=hop, center=False, out=np.zeros((1025, block_length - 1), dtype=np.complex64))
+    with pytest.raises(L.ParameterError):
+        L.stft(blk, n_fft=n_fft, hop_length=hop, center=False, out=np.zeros((1025, block_length), dtype=np.float32))

