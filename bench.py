@@ -176,6 +176,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--prewarm-ms", type=float, default=400.0, help="untimed run of the timed launch before the warm-up steps (clock ramp)")
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: 256 at N=1 = configs[1], 512 at N>1 = configs[2]'s split)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cqt", action="store_true", help="skip the CQT-lite (config 5) side measurement")
@@ -234,7 +235,12 @@ def main():
     def step_mel():
         ctx.melspectrogram_exec(plan, mel_plan, yp, batch, n, n, 2.0, Mp)
 
-    def timed(fn, steps, warmup, collective=True):
+    def timed(fn, steps, warmup, collective=True, ramp_ms=0.0):
+        # side measurements start after host-side set-up during which the GPU clocked down: same untimed ramp as the headline
+        t_ramp = time.perf_counter()
+        while ramp_ms and time.perf_counter() - t_ramp < ramp_ms / 1e3:
+            fn()
+            torch.cuda.synchronize(device)
         for _ in range(warmup):
             fn()
         barrier() if collective else torch.cuda.synchronize(device)
@@ -250,6 +256,14 @@ def main():
             barrier()
         return wall, e0.elapsed_ms(e1) / 1e3
 
+    # An idle MI355X sits in a low power state and its first ~0.2 s of work run up to 10 % slow (the driver's default
+    # --warmup 5 is 4 ms of work): bring the clocks up with the same launch, untimed and reported as `prewarm_ms`, before the
+    # contract's own --warmup steps.
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < args.prewarm_ms / 1e3:
+        for _ in range(20):
+            step_mel()
+        torch.cuda.synchronize(device)
     # ---- the timed region of the contract: exactly --steps steps, barrier + synchronize on both sides, max over ranks -------
     wall, ev = timed(step_mel, args.steps, args.warmup)
     if world > 1:
@@ -306,7 +320,7 @@ def main():
         yrec = torch.empty((batch, n), dtype=torch.float32, device=device)
 
         def roof(fn, bytes_per_frame, kernel):
-            _, e = timed(fn, args.steps, args.warmup, collective=False)
+            _, e = timed(fn, args.steps, args.warmup, collective=False, ramp_ms=args.prewarm_ms / 2)
             s = e / args.steps
             ach = frames_per_step * bytes_per_frame / s / 1e9
             return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
@@ -337,7 +351,11 @@ def main():
         def public_numpy():
             nb = 64  # a quarter of the batch: 169 MB up, 42 MB down
             yh = y[:nb].cpu().numpy()
-            L.feature.melspectrogram(y=yh[:2], sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS)
+            # first calls (untimed): the context sizes its pinned staging / device buffers for this batch; they persist
+            t0 = time.perf_counter()
+            L.feature.melspectrogram(y=yh, sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS)
+            L.stft(yh, n_fft=N_FFT, hop_length=HOP)
+            first = time.perf_counter() - t0
             t0 = time.perf_counter()
             Mh = L.feature.melspectrogram(y=yh, sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS)
             dt = time.perf_counter() - t0
@@ -346,7 +364,9 @@ def main():
             dts = time.perf_counter() - t0
             return {"melspectrogram": {"clips": nb, "ms": dt * 1e3, "frames_per_s": nb * n_frames / dt, "host_bytes": int(yh.nbytes + Mh.nbytes)},
                     "stft": {"clips": nb, "ms": dts * 1e3, "frames_per_s": nb * n_frames / dts, "host_bytes": int(yh.nbytes + Dh.nbytes)},
-                    "what": "public drop-in on np.ndarray: host finite scan + H2D + kernel + D2H over PCIe; informative only"}
+                    "first_calls_ms": first * 1e3,
+                    "what": "public drop-in on np.ndarray through the native host pipeline (lra_stft_exec_host: pinned two-slot staging, finite scan fused into the staging copy, "
+                            "upload / kernel / download overlapped); steady state, `first_calls_ms` = the two calls that sized the staging buffers; informative only"}
 
         measure("end_to_end_numpy", public_numpy)
 
@@ -361,6 +381,26 @@ def main():
             return out
 
         measure("post", db_and_mfcc)
+
+        def griffinlim_key():
+            nb, iters = 32, 8
+            S = torch.abs(L.stft(y[:nb], n_fft=N_FFT, hop_length=HOP))
+            L.griffinlim(S, n_iter=1, hop_length=HOP, rng=0)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            yr = L.griffinlim(S, n_iter=iters, hop_length=HOP, rng=0)
+            torch.cuda.synchronize(device)
+            dt = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            L.griffinlim(S, n_iter=0, hop_length=HOP, rng=0)
+            torch.cuda.synchronize(device)
+            dt0 = time.perf_counter() - t0
+            per_iter = (dt - dt0) / iters
+            return {"clips": nb, "n_iter": iters, "ms_total": dt * 1e3, "ms_per_iteration": per_iter * 1e3, "frames_per_s_per_iteration": nb * n_frames / per_iter,
+                    "ms_setup": dt0 * 1e3, "finite": bool(torch.isfinite(yr).all()),
+                    "what": "librosa_amd.griffinlim(<device |stft|>): per iteration istft + stft + phase update, all device-resident; ms_setup = host-drawn random phases (the reference's rng stream) + upload + the final istft"}
+
+        measure("griffinlim", griffinlim_key)
         # BASELINE config 5 (CQT-lite): three STFTs at n_fft = 512 / 2048 / 8192 over the same batch, shared hop 512
         if not args.no_cqt:
             def cqt_lite():
@@ -404,7 +444,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"feature.melspectrogram, {split}, @ 22.05 kHz, n_fft={N_FFT} hop={HOP} n_mels={N_MELS}, inputs resident in HBM, outputs left sharded "
-                                   f"(`gathered`: all-gathered)", "frames_per_step_per_gpu": frames_per_step, "clips_per_gpu": batch,
+                                   f"(`gathered`: all-gathered)", "frames_per_step_per_gpu": frames_per_step, "clips_per_gpu": batch, "prewarm_ms": args.prewarm_ms,
                        "parallelism": f"clips sharded over {world} GPU(s), no collective on the data path", "device": ctx.device_name()},
             "roofline": {"bound": "hbm", "kernel": "stft2_kernel<n_fft=2048, OUT_MELR> (fused melspectrogram)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_frame": BYTES_PER_FRAME_MEL,

@@ -184,6 +184,10 @@ int lra_dct_exec(lra_ctx* ctx, const void* S, void* out, int64_t batch, int n_in
 int lra_griffinlim_update(lra_ctx* ctx, const void* rebuilt, const void* tprev, const void* S, void* angles, int64_t count, int dtype, double coef, double eps,
                           int normalize);
 
+/* Initial estimate (:2832-2847, init="random"): angles = S * exp(2 pi i u), u: device array of float64 uniform draws (the
+ * caller's rng.random(S.shape), so that a seed reproduces the reference's stream), in the element order of S / angles. */
+int lra_griffinlim_init(lra_ctx* ctx, const void* u, const void* S, void* angles, int64_t count, int dtype);
+
 /* ---- layout helper: dst[b][c][r] = src[b][r][c], elem_bytes in {4, 8, 16} ------------------ */
 int lra_transpose(lra_ctx* ctx, const void* src, void* dst, int64_t batch, int64_t rows, int64_t cols, int elem_bytes);
 

@@ -72,6 +72,7 @@ SIGNATURES = {
     "lra_to_db_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_int, c_double]),
     "lra_from_db_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_double]),
     "lra_stft_exec_host": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p, c_int64, POINTER(c_int)]),
+    "lra_griffinlim_init": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int]),
     "lra_griffinlim_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_double, c_double, c_int]),
     "lra_dct_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_int, c_double, c_double, c_void_p, c_void_p, c_int, c_double]),
 }
@@ -344,6 +345,12 @@ class Context:
         _check(self.lib.lra_dct_exec(self.handle, c_void_p(s_ptr), c_void_p(out_ptr), batch, n_in, n_out, n_frames, dtype_code(dtype), c_void_p(basis_ptr), c_void_p(lift_ptr),
                                      int(bool(fuse_db)), float(amin), float(ref_scalar), c_void_p(ref_items_ptr or None), c_void_p(item_max_ptr or None), int(top_db is not None),
                                      float(top_db if top_db is not None else 0.0)))
+
+    def memset(self, ptr, value, nbytes):
+        _check(self.lib.lra_memset(self.handle, c_void_p(ptr), int(value), int(nbytes)))
+
+    def griffinlim_init(self, u_ptr, s_ptr, angles_ptr, count, dtype):
+        _check(self.lib.lra_griffinlim_init(self.handle, c_void_p(u_ptr), c_void_p(s_ptr), c_void_p(angles_ptr), count, dtype_code(dtype)))
 
     def griffinlim_update(self, rebuilt_ptr, tprev_ptr, s_ptr, angles_ptr, count, dtype, coef, eps, normalize=True):
         _check(self.lib.lra_griffinlim_update(self.handle, c_void_p(rebuilt_ptr), c_void_p(tprev_ptr) if tprev_ptr else None, c_void_p(s_ptr), c_void_p(angles_ptr), count, dtype_code(dtype),

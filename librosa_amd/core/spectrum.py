@@ -467,12 +467,9 @@ def griffinlim(S, *, n_iter=32, hop_length=None, win_length=None, n_fft=None, wi
     wss = np.ascontiguousarray(util.fix_length(wss[(n_fft // 2 if center else 0) :], size=expected), dtype=real)
     lead = tuple(S.shape[:-2])
     batch = int(np.prod(lead, dtype=np.int64)) if lead else 1
-    # initial phases on the host: the reference's draw order (S.shape, C order) and its float64 phasor (:2834)
-    if init == "random":
-        ang = 2 * np.pi * rng.random(size=tuple(S.shape))
-        angles0 = (np.cos(ang) + 1j * np.sin(ang)).astype(cplx)
-    else:
-        angles0 = np.ones(tuple(S.shape), dtype=cplx)
+    # the uniform draws come from the host generator in the reference's order (S.shape, C order, :2834) so that a seed
+    # reproduces its stream; the float64 phasor itself is evaluated on the device
+    draws = rng.random(size=tuple(S.shape)) if init == "random" else None
     sess = _arrays.Session(S)
     try:
         ctx = sess.ctx
@@ -482,10 +479,7 @@ def griffinlim(S, *, n_iter=32, hop_length=None, win_length=None, n_fft=None, wi
             raise ParameterError("internal frame-count mismatch")
         count = batch * n_total * n_bins
         s_ptr = _to_frame_major(sess, S, batch, n_bins, n_total, real)
-        # phases travel in S's own layout and are transposed on the device
-        up = sess.input_raw(_as_like(sess, angles0.reshape(batch, n_bins, n_total)), cplx)
         angles = sess.scratch(count * cplx.itemsize)
-        _transpose_batched(ctx, up, angles, batch, n_bins, n_total, cplx.itemsize)
         rebuilt = sess.scratch(count * cplx.itemsize)
         tprev = sess.scratch(count * cplx.itemsize)
         wss_ptr = sess.input_raw(_as_like(sess, wss), real)
@@ -494,7 +488,15 @@ def griffinlim(S, *, n_iter=32, hop_length=None, win_length=None, n_fft=None, wi
         check = ctx.stft_is_fused(splan) and _finite_check_covers_input(expected, n_fft, hop, center)
         if check:
             ctx.nonfinite_reset()
-        ctx.griffinlim_update(angles, None, s_ptr, angles, count, real, 0.0, eps, normalize=False)       # angles *= S  (:2847)
+        # angles = S exp(2 pi i u)  (:2834, :2847); the draws travel in S's layout and are transposed on the device.
+        # init=None is u = 0: angles = S (1 + 0i)  (:2837)
+        u_t = sess.scratch(count * 8)
+        if draws is not None:
+            up = sess.input_raw(_as_like(sess, draws.reshape(batch, n_bins, n_total)), np.float64)
+            _transpose_batched(ctx, up, u_t, batch, n_bins, n_total, 8)
+        else:
+            ctx.memset(u_t, 0, count * 8)
+        ctx.griffinlim_init(u_t, s_ptr, angles, count, real)
         have_prev = False
         for _ in range(int(n_iter)):
             ctx.istft_exec(iplan, angles, batch, n_total * n_bins, n_bins, n_used, wss_ptr, y_ptr, expected, expected)   # :2850

@@ -71,6 +71,7 @@ struct lra_ctx {
     int opt_generic_mel = 0;         // force the generic banded mel path (tests)
     int opt_lds_pad = 0;             // extra dynamic LDS per workgroup (occupancy experiments)
     int opt_v2 = 1;                  // second-generation forward kernel where it applies (lra_kernels2.h)
+    int opt_direct = 1;              // direct framing (no ring) for hop >= n_fft
     int opt_xcd_remap = 1;           // workgroup -> work item map that keeps neighbouring strips on one XCD (lra_kernels.h, xcd_block)
     unsigned int* d_flag = nullptr;  // non-finite input flag (device)
     std::string name;
@@ -290,6 +291,7 @@ template <class T> struct StftLaunch {
     int lds_pad = 0;
     bool xcd_remap = true;
     bool use_v2 = true;
+    bool use_direct = true;
     bool mel_v2 = false;  // OUT_MELR: the plan's layout-1 tables are bound, run the second-generation kernel
     bool mel_runs = true;
     const lra_mel_plan* mel = nullptr;
@@ -299,17 +301,27 @@ template <class T> struct StftLaunch {
     template <class Cfg, int MODE> void launch(int shared_bytes) {
         static_assert(Cfg::P <= 4, "at most four Stockham passes are wired up");
         const int lds_probe_v1 = Cfg::FPB * stft_slot_bytes<Cfg>(MODE, a.n_mels, mel_tile_opt > 0 ? mel_tile_opt : 4) + shared_bytes + lds_pad;
-        void (*kern)(StftArgs<T>, const T*, void*) = stft_kernel<Cfg, MODE, POW_TWO, false>;
-        if (MODE != OUT_COMPLEX && a.power_mode == POW_ONE) kern = stft_kernel<Cfg, MODE, POW_ONE, false>;
-        if (MODE != OUT_COMPLEX && a.power_mode == POW_GENERAL) kern = stft_kernel<Cfg, MODE, POW_GENERAL, false>;
+        void (*kern)(StftArgs<T>, const T*, void*) = stft_kernel<Cfg, MODE, POW_TWO, 0>;
+        if (MODE != OUT_COMPLEX && a.power_mode == POW_ONE) kern = stft_kernel<Cfg, MODE, POW_ONE, 0>;
+        if (MODE != OUT_COMPLEX && a.power_mode == POW_GENERAL) kern = stft_kernel<Cfg, MODE, POW_GENERAL, 0>;
         if constexpr (sizeof(T) == 4) {  // row-aligned hops (n_fft/4, n_fft/8, ...): the fast ring addressing, f32 only
 #ifndef LRA_MEL_RA
 #define LRA_MEL_RA 1
 #endif
             if (ring_rows_aligned<Cfg>(a.hop) && (LRA_MEL_RA || MODE == OUT_COMPLEX || MODE == OUT_POWER)) {
-                kern = stft_kernel<Cfg, MODE, POW_TWO, true>;
-                if (MODE != OUT_COMPLEX && a.power_mode == POW_ONE) kern = stft_kernel<Cfg, MODE, POW_ONE, true>;
-                if (MODE != OUT_COMPLEX && a.power_mode == POW_GENERAL) kern = stft_kernel<Cfg, MODE, POW_GENERAL, true>;
+                kern = stft_kernel<Cfg, MODE, POW_TWO, 1>;
+                if (MODE != OUT_COMPLEX && a.power_mode == POW_ONE) kern = stft_kernel<Cfg, MODE, POW_ONE, 1>;
+                if (MODE != OUT_COMPLEX && a.power_mode == POW_GENERAL) kern = stft_kernel<Cfg, MODE, POW_GENERAL, 1>;
+            }
+        }
+        // hop >= n_fft (frames do not overlap): direct framing, no ring (complex / power epilogues)
+        bool direct = false;
+        if constexpr (MODE == OUT_COMPLEX || MODE == OUT_POWER) {
+            if (a.hop >= Cfg::N && use_direct) {
+                direct = true;
+                kern = stft_kernel<Cfg, MODE, POW_TWO, 2>;
+                if (MODE != OUT_COMPLEX && a.power_mode == POW_ONE) kern = stft_kernel<Cfg, MODE, POW_ONE, 2>;
+                if (MODE != OUT_COMPLEX && a.power_mode == POW_GENERAL) kern = stft_kernel<Cfg, MODE, POW_GENERAL, 2>;
             }
         }
         // Second-generation kernel (lra_kernels2.h) where it applies: complex / power epilogues, 16 points per thread with
@@ -327,7 +339,7 @@ template <class T> struct StftLaunch {
 #undef LRA_PICK2
             }
         }
-        const int lds_probe = v2 ? Cfg::FPB * stft2_slot_bytes<Cfg>() + shared_bytes + lds_pad : lds_probe_v1;
+        const int lds_probe = v2 ? Cfg::FPB * stft2_slot_bytes<Cfg>() + shared_bytes + lds_pad : direct ? Cfg::FPB * Cfg::FRAME_BYTES + lds_pad : lds_probe_v1;
         // Frames per slot (`iters`).  A slot pays n_fft - hop extra sample loads for its first frame, so long
         // runs are cheap in HBM traffic; but the launch should also end evenly: the grid is sized to a whole
         // number of "waves" of workgroups (CUs x resident workgroups per CU), because a last partial wave
@@ -347,7 +359,10 @@ template <class T> struct StftLaunch {
                 const double rounds = (double)(batch * wgpc) / (double)conc;
                 // a single round that occupies at least 60 % of the slots has no tail to speak of, and long runs beat full
                 // residency there (measured on the 256 x 30 s batch: 162 frames per slot 0.657 ms, 108 0.674, 324 0.674)
-                const double fill = (rounds <= 1.0 && rounds >= 0.6) ? 1.0 : rounds / std::ceil(rounds);
+                // (that kernel is bound by its store stream; the others -- small frames sharing a wave, frames spread over
+                // several waves -- are bound by latency and want every resident slot taken: n_fft = 512, hop = 512 ran 5 of 8
+                // resident workgroups per CU under this rule)
+                const double fill = (v2 && Cfg::TF == 64 && rounds <= 1.0 && rounds >= 0.6) ? 1.0 : rounds / std::ceil(rounds);
                 if (fill > best_fill + 0.02) { best_fill = fill; best_iters = it; }
             }
             iters = best_iters;
@@ -366,7 +381,7 @@ template <class T> struct StftLaunch {
         if (a.mel_tile > iters) a.mel_tile = iters;
         a.frames_per_wg = Cfg::FPB * iters;
         a.wg_per_clip = (a.n_frames + a.frames_per_wg - 1) / a.frames_per_wg;
-        a.slot_bytes = v2 ? stft2_slot_bytes<Cfg>() : stft_slot_bytes<Cfg>(MODE, a.n_mels, a.mel_tile);
+        a.slot_bytes = v2 ? stft2_slot_bytes<Cfg>() : direct ? Cfg::FRAME_BYTES : stft_slot_bytes<Cfg>(MODE, a.n_mels, a.mel_tile);
         a.shared_off = Cfg::FPB * a.slot_bytes;
         const long long grid = batch * a.wg_per_clip;
         if (grid > 0x7ffffff0LL) { err = hipErrorInvalidConfiguration; return; }
@@ -813,6 +828,7 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
         L.lds_pad = ctx->opt_lds_pad;
         L.xcd_remap = ctx->opt_xcd_remap != 0;
         L.use_v2 = ctx->opt_v2 != 0;
+        L.use_direct = ctx->opt_direct != 0;
         L.mel_runs = ctx->opt_mel_runs != 0;
         // Kernel variant (f32 n_fft = 2048 only): 0 = one wave per frame, 4 = two waves per frame.  Which one
         // is faster depends on the epilogue AND on the individual GPU (boxes of the same pool differ by +-10 %,
@@ -1175,6 +1191,7 @@ int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value) {
     else if (!std::strcmp(key, "lds_pad")) ctx->opt_lds_pad = value;
     else if (!std::strcmp(key, "xcd_remap")) ctx->opt_xcd_remap = value != 0;
     else if (!std::strcmp(key, "v2")) ctx->opt_v2 = value != 0;
+    else if (!std::strcmp(key, "direct")) ctx->opt_direct = value != 0;
     else if (!std::strcmp(key, "autotune")) ctx->opt_autotune = value != 0;
     else if (!std::strcmp(key, "mel_runs")) ctx->opt_mel_runs = value != 0;
     else if (!std::strcmp(key, "variant")) ctx->opt_variant = (value >= 0 && value < kNumVariants) ? value : -1;
@@ -1715,6 +1732,18 @@ int lra_griffinlim_update(lra_ctx* ctx, const void* rebuilt, const void* tprev, 
     if (dtype == LRA_F64) { if (normalize) LRA_GL(double, true); else LRA_GL(double, false); }
     else { if (normalize) LRA_GL(float, true); else LRA_GL(float, false); }
 #undef LRA_GL
+    LRA_HIP(hipGetLastError());
+    return LRA_OK;
+}
+
+int lra_griffinlim_init(lra_ctx* ctx, const void* u, const void* S, void* angles, int64_t count, int dtype) {
+    LRA_BIND(ctx);
+    if (count <= 0) return LRA_OK;
+    if (!u || !S || !angles) return fail(LRA_EINVAL, "null data pointer");
+    long long grid = (count + 255) / 256;
+    if (grid > 64LL * ctx->n_cu) grid = 64LL * ctx->n_cu;
+    if (dtype == LRA_F64) hipLaunchKernelGGL((griffinlim_init_kernel<double>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const double*)u, (const double*)S, (Cplx2<double>*)angles, (long long)count);
+    else hipLaunchKernelGGL((griffinlim_init_kernel<float>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const double*)u, (const float*)S, (Cplx2<float>*)angles, (long long)count);
     LRA_HIP(hipGetLastError());
     return LRA_OK;
 }

@@ -17,7 +17,7 @@
 // stores in the vector memory pipeline -- it then parks the wave on s_waitcnt vmcnt(0) at the top of
 // every frame until all of its stores have landed in L2, serialising FFT and store traffic.
 // RA: the hop is a whole number of ring rows (lra_kernels.h, ring_rows_aligned) -- the fast ring addressing.
-template <class Cfg, int MODE, int PM, bool RA>
+template <class Cfg, int MODE, int PM, int RA>
 __global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void stft_kernel(lra::StftArgs<typename Cfg::real> a, const typename Cfg::real* __restrict__ y,
                                                                      void* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char lra_smem[];
@@ -103,9 +103,11 @@ LRA_CFG_ALIAS(cfg_f64_12, double, 12, 0)
     S(lra::C, 2, 1, RA) S(lra::C, 2, 2, RA) S(lra::C, 2, 3, RA)                                      \
     S(lra::C##_mel, 3, 1, RA) S(lra::C##_mel, 3, 2, RA) S(lra::C##_mel, 3, 3, RA)                   \
     S(lra::C##_mel, 4, 1, RA) S(lra::C##_mel, 4, 2, RA) S(lra::C##_mel, 4, 3, RA)
+// direct framing (RA = 2: hop >= n_fft, no ring): complex and power epilogues
+#define LRA_STFT_DIRECT(S, C) S(lra::C, 0, 2, 2) S(lra::C, 1, 1, 2) S(lra::C, 1, 2, 2) S(lra::C, 1, 3, 2)
 // f32: both ring addressings; the overlap-add row counts HC = R/2, R/4, R/8 (8, 4, 2 at 16 points per thread)
-#define LRA_F32_CFG(S, I, C, HCQ, HCE) LRA_STFT_SET(S, C, false) LRA_STFT_SET(S, C, true) I(lra::C, 0) I(lra::C, (2 * HCQ)) I(lra::C, HCQ) I(lra::C, HCE)
-#define LRA_F64_CFG(S, I, C) LRA_STFT_SET(S, C, false) I(lra::C, 0)
+#define LRA_F32_CFG(S, I, C, HCQ, HCE) LRA_STFT_SET(S, C, 0) LRA_STFT_SET(S, C, 1) LRA_STFT_DIRECT(S, C) I(lra::C, 0) I(lra::C, (2 * HCQ)) I(lra::C, HCQ) I(lra::C, HCE)
+#define LRA_F64_CFG(S, I, C) LRA_STFT_SET(S, C, 0) LRA_STFT_DIRECT(S, C) I(lra::C, 0)
 
 #define LRA_INST_GROUP_0(S, I) LRA_F32_CFG(S, I, cfg_f32_10, 4, 2)
 #define LRA_INST_GROUP_1(S, I) LRA_F32_CFG(S, I, cfg_f32_10v4, 2, 1)

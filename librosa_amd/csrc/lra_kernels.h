@@ -135,6 +135,7 @@ template <class Cfg> struct FftRegs {
     // ... up to hop = n_fft/2 in the kernels with general ring addressing (the row-aligned ones use the first NPF only)
     static constexpr int NPFX = 2 * NPF;
     typename Cfg::real pf[NPFX];
+    typename Cfg::cplx nxt[Cfg::R];  // direct framing (hop >= n_fft, no ring): the next frame's sample pairs in pass-0 register order, in flight during the current frame
     // HOIST configurations: this thread's table values, loaded once before the frame loop.  (hipcc
     // does not hoist them by itself across the per-phase fences; re-reading ~52 table values per
     // frame from L2 left the waves 65 % of their time in s_waitcnt.)
@@ -384,6 +385,71 @@ template <class Cfg, bool RA> LRA_HD void stft_ring_load_pass0(const StftArgs<ty
     pass_dft<Cfg, 0>(rg, tf, a.tw);
 #endif
     pass_write<Cfg, 0>(v, fr, tf);
+}
+
+// ---- direct framing (stft_kernel<..., RA = 2>): hop >= n_fft --------------------------------------------------------------
+// Frames do not overlap, so there is nothing for a ring to keep: frame t+1's R sample pairs per thread are loaded straight
+// into registers (pass-0 order: element i r + j is complex index tf + i TF + j sin) at the START of frame t -- before frame
+// t's stores are issued, so that the wait for them one frame later never covers fresh stores (vmcnt completes in order) --
+// and the slot's LDS is the frame area only.  Frames that touch the np.pad region (core/spectrum.py:287) take the index fold.
+// (The ring kernels fetched such hops with one dependent load per sample: n_fft = 512, hop = 512 ran at 1.3 TB/s.)
+template <class Cfg> LRA_HD void stft_direct_fetch(const StftArgs<typename Cfg::real>& a, int clip, int frame, int tf, FftRegs<Cfg>& rg) {
+    using T = typename Cfg::real;
+    using C = typename Cfg::cplx;
+    constexpr int lr = Cfg::logr(0), r = 1 << lr, nb = Cfg::R >> lr, sin = Cfg::M >> lr, N = Cfg::N;
+    if (frame >= a.n_frames) return;
+    const T* __restrict__ yb = a.y + (long long)clip * a.y_stride;
+    const long long p0 = (long long)frame * a.hop, g0 = p0 - a.pad;
+    if (g0 >= 0 && g0 + N <= a.n) {
+        const T* __restrict__ src = yb + g0 + 2 * tf;
+        if ((reinterpret_cast<size_t>(src) & (2 * sizeof(T) - 1)) == 0) {
+            LRA_UNROLL
+            for (int i = 0; i < nb; ++i) {
+                LRA_UNROLL
+                for (int j = 0; j < r; ++j) rg.nxt[i * r + j] = *reinterpret_cast<const C*>(src + 2 * (i * Cfg::TF + j * sin));
+            }
+        } else {
+            LRA_UNROLL
+            for (int i = 0; i < nb; ++i) {
+                LRA_UNROLL
+                for (int j = 0; j < r; ++j) {
+                    const T* __restrict__ s2 = src + 2 * (i * Cfg::TF + j * sin);
+                    rg.nxt[i * r + j] = mk<T>(s2[0], s2[1]);
+                }
+            }
+        }
+    } else {
+        LRA_UNROLL
+        for (int i = 0; i < nb; ++i) {
+            LRA_UNROLL
+            for (int j = 0; j < r; ++j) {
+                const long long pp = p0 + 2 * (tf + i * Cfg::TF + j * sin);
+                rg.nxt[i * r + j] = mk<T>(fetch_sample<T>(yb, pp, a.pad, a.n, a.pad_mode), fetch_sample<T>(yb, pp + 1, a.pad, a.n, a.pad_mode));
+            }
+        }
+    }
+}
+
+// phase B of a directly framed kernel: the pairs loaded a frame ago x window -> pass-0 butterflies -> frame area; then the
+// next frame's loads are issued
+template <class Cfg> LRA_HD void stft_direct_pass0(const StftArgs<typename Cfg::real>& a, int clip, int frame, bool more, int tf, FftRegs<Cfg>& rg, Lds fr) {
+    using T = typename Cfg::real;
+    using C = typename Cfg::cplx;
+    constexpr int lr = Cfg::logr(0), r = 1 << lr, nb = Cfg::R >> lr, sin = Cfg::M >> lr;
+    const C* __restrict__ win2 = reinterpret_cast<const C*>(a.win);
+    const bool live = frame < a.n_frames;
+    LRA_UNROLL
+    for (int i = 0; i < nb; ++i) {
+        LRA_UNROLL
+        for (int j = 0; j < r; ++j) {
+            const C w = Cfg::HOIST ? rg.win2[i * r + j] : win2[tf + i * Cfg::TF + j * sin];
+            const C x = rg.nxt[i * r + j];
+            rg.v[i * r + j] = live ? mk<T>(x.x * w.x, x.y * w.y) : mk<T>((T)0, (T)0);
+        }
+    }
+    if (more) stft_direct_fetch<Cfg>(a, clip, frame + 1, tf, rg);
+    pass_dft<Cfg, 0>(rg, tf, a.tw);
+    pass_write<Cfg, 0>(rg.v, fr, tf);
 }
 
 // ---- phase: read Z[k], Z[M-k] pairs for the split step ----------------------------------------
@@ -823,7 +889,10 @@ template <class Cfg> inline int stft_slot_bytes(int mode, int n_mels, int tile) 
 // f_first + s*iters + it of clip blk / wg_per_clip, as a private pipeline: all LDS traffic of a slot
 // stays inside the slot (and, when TF <= 64, inside one wave: no s_barrier anywhere).  The mel
 // epilogue stages `mel_tile` frames per row before flushing them as contiguous runs.
-template <class Cfg, int MODE, int PM = POW_TWO, bool RA = false> LRA_HD void stft_block(const StftArgs<typename Cfg::real>& a_in, const int blk, Lds lds) {
+// RAM: ring addressing mode: 0 general, 1 row-aligned (hop = n_fft/4), 2 no ring at all (direct framing, hop >= n_fft; complex / power epilogues)
+template <class Cfg, int MODE, int PM = POW_TWO, int RAM = 0> LRA_HD void stft_block(const StftArgs<typename Cfg::real>& a_in, const int blk, Lds lds) {
+    constexpr bool RA = RAM == 1, DIRECT = RAM == 2;
+    static_assert(!DIRECT || MODE == OUT_COMPLEX || MODE == OUT_POWER, "direct framing serves the complex / power epilogues");
     StftArgs<typename Cfg::real> a = a_in;
     const int clip = blk / a.wg_per_clip;
     const int f_first = (blk % a.wg_per_clip) * a.frames_per_wg;
@@ -862,8 +931,12 @@ template <class Cfg, int MODE, int PM = POW_TWO, bool RA = false> LRA_HD void st
     } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC && MODE != OUT_MEL2 && MODE != OUT_MELR)  // the shared tables need a workgroup barrier, once
     LRA_PHASE(Cfg::NT, tid) {
         const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
-        stft_ring_fill<Cfg>(a, clip, f_first + slot * iters, tf, lds_sub(lds, slot * slot_bytes + stft_ring_off<Cfg>()));
-        if (PF_EARLY && iters > 1) stft_ring_prefetch<Cfg, RA>(a, clip, f_first + slot * iters + 1, tf, LRA_R(rg));
+        if (DIRECT) {
+            stft_direct_fetch<Cfg>(a, clip, f_first + slot * iters, tf, LRA_R(rg));
+        } else {
+            stft_ring_fill<Cfg>(a, clip, f_first + slot * iters, tf, lds_sub(lds, slot * slot_bytes + stft_ring_off<Cfg>()));
+            if (PF_EARLY && iters > 1) stft_ring_prefetch<Cfg, RA>(a, clip, f_first + slot * iters + 1, tf, LRA_R(rg));
+        }
     } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
     int done = 0;  // frames of this workgroup's slots processed so far (uniform)
     LRA_TICK_DECL;
@@ -875,11 +948,12 @@ template <class Cfg, int MODE, int PM = POW_TWO, bool RA = false> LRA_HD void st
             const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
             const Lds sl = lds_sub(lds, slot * slot_bytes);
 #if LRA_ABLATE != 3 && LRA_ABLATE != 4  // experiments 3 / 4: no PCM loads in the frame loop (4: and no spectrum stores)
-            if (!LATE_PF && !PF_EARLY && it + 1 < iters) stft_ring_prefetch<Cfg, RA>(a, clip, frame + 1, tf, LRA_R(rg));
+            if (!DIRECT && !LATE_PF && !PF_EARLY && it + 1 < iters) stft_ring_prefetch<Cfg, RA>(a, clip, frame + 1, tf, LRA_R(rg));
 #endif
             if (DEFER && it > 0 && frame - 1 < a.n_frames)
                 mel2_combine<Cfg>(a, clip, frame - 1, tf, (it - 1) % tile, tile, lds_sub(lds, a.shared_off), lds_sub(sl, slot_bytes - mel2_psum_bytes<Cfg>(a.n_mels)), lds_sub(sl, stft_tile_off<Cfg>()));
-            stft_ring_load_pass0<Cfg, RA>(a, frame, tf, LRA_R(rg), lds_sub(sl, stft_ring_off<Cfg>()), sl);
+            if (DIRECT) stft_direct_pass0<Cfg>(a, clip, frame, it + 1 < iters, tf, LRA_R(rg), sl);
+            else stft_ring_load_pass0<Cfg, RA>(a, frame, tf, LRA_R(rg), lds_sub(sl, stft_ring_off<Cfg>()), sl);
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         LRA_TICK(1);
 #if LRA_ABLATE != 2
@@ -894,8 +968,8 @@ template <class Cfg, int MODE, int PM = POW_TWO, bool RA = false> LRA_HD void st
             if constexpr (MODE == OUT_MELR) split_read_runs<Cfg>(LRA_R(rg), sl, tf);
             else split_read<Cfg>(LRA_R(rg), sl, tf);
 #if LRA_ABLATE != 3 && LRA_ABLATE != 4
-            if (!LATE_PF && it + 1 < iters) stft_ring_advance<Cfg, RA>(a, clip, frame + 1, tf, LRA_R(rg), lds_sub(sl, stft_ring_off<Cfg>()));
-            if (PF_EARLY && it + 2 < iters) stft_ring_prefetch<Cfg, RA>(a, clip, frame + 2, tf, LRA_R(rg));
+            if (!DIRECT && !LATE_PF && it + 1 < iters) stft_ring_advance<Cfg, RA>(a, clip, frame + 1, tf, LRA_R(rg), lds_sub(sl, stft_ring_off<Cfg>()));
+            if (!DIRECT && PF_EARLY && it + 2 < iters) stft_ring_prefetch<Cfg, RA>(a, clip, frame + 2, tf, LRA_R(rg));
 #endif
             if (DEFER && tile > 1 && it > 0 && it % tile == 0)  // the tile that frame it-1 completed
                 mel_flush_tile<Cfg>(a, clip, f_first + slot * iters, it - 1, tile, tf, lds_sub(sl, stft_tile_off<Cfg>()));

@@ -184,4 +184,20 @@ __global__ __launch_bounds__(256) void griffinlim_update_kernel(const Cplx2<T>* 
     }
 }
 
+// Initial phase estimate (:2832-2847): angles = S * (cos, sin)(2 pi u), u = the caller's uniform draws in [0, 1) (float64, drawn
+// on the host so that `rng` reproduces the reference's stream).  The phasor is evaluated in float64 like util.phasor
+// (util/utils.py:2629-2637) and rounded once to the working precision.
+template <class T> __global__ __launch_bounds__(256) void griffinlim_init_kernel(const double* __restrict__ u, const T* __restrict__ S, Cplx2<T>* __restrict__ angles, long long count) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+        const double a = 6.283185307179586 * u[i];  // 2 * np.pi * rng.random(...)
+        double sn, cs;
+        sincos(a, &sn, &cs);
+        const T s = S[i];
+        Cplx2<T> z;
+        z.x = (T)cs * s;
+        z.y = (T)sn * s;
+        angles[i] = z;
+    }
+}
+
 }  // namespace lra

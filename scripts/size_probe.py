@@ -1,0 +1,42 @@
+"""Development probe (GPU box): one STFT shape in a loop (for rocprofv3 counter passes).  python scripts/size_probe.py n_fft hop [steps] [what]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import bench, librosa_amd as L
+from librosa_amd import filters
+n_fft, hop = int(sys.argv[1]), int(sys.argv[2])
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+what = sys.argv[4] if len(sys.argv) > 4 else "stft"
+dev = torch.device("cuda", 0)
+ctx = L.get_context(0)
+ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+for kv in os.environ.get("PROBE_OPTS", "").split(","):
+    if "=" in kv:
+        k, v = kv.split("="); ctx.set_option(k, int(v))
+n, batch = 22050 * 30, 256
+y = bench.make_batch(torch, batch, n, 0, dev)
+w = np.asarray(filters.get_window("hann", n_fft, fftbins=True), dtype=np.float32)
+pl = ctx.stft_plan(n_fft, hop, w, True, "constant", np.float32)
+T = ctx.stft_num_frames(pl, n)
+bins = n_fft // 2 + 1
+D = torch.empty((batch, T, bins), dtype=torch.complex64, device=dev)
+if what == "istft":
+    ip = ctx.istft_plan(n_fft, hop, w, True, np.float32)
+    ww = filters.window_sumsquare(window="hann", n_frames=T, n_fft=n_fft, hop_length=hop, dtype=np.float32)[n_fft // 2:]
+    ww = torch.from_numpy(np.ascontiguousarray(np.pad(ww, (0, max(0, n - len(ww))))[:n], dtype=np.float32)).to(dev)
+    yr = torch.empty((batch, n), dtype=torch.float32, device=dev)
+    ctx.stft_exec(pl, y.data_ptr(), batch, n, n, D.data_ptr())
+    fn = lambda: ctx.istft_exec(ip, D.data_ptr(), batch, T * bins, bins, T, ww.data_ptr(), yr.data_ptr(), n, n)
+else:
+    fn = lambda: ctx.stft_exec(pl, y.data_ptr(), batch, n, n, D.data_ptr())
+for _ in range(5): fn()
+torch.cuda.synchronize()
+best = 1e9
+for rep in range(3):
+    e0, e1 = ctx.event(), ctx.event(); e0.record()
+    for _ in range(steps): fn()
+    e1.record(); torch.cuda.synchronize()
+    best = min(best, e0.elapsed_ms(e1) / steps)
+by = batch * T * (bins * 8 + hop * 4)
+print(f"{what} n_fft {n_fft} hop {hop}: frames {batch*T} {best:.3f} ms  {by/best/1e6:.0f} GB/s  ({by/1e6:.0f} MB algorithmic)", flush=True)

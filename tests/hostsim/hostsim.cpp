@@ -62,16 +62,28 @@ template <class T> struct StftSim {
                 }
             }
             diag[10] = v2;
+            // direct framing (hop >= n_fft: no ring), same selection as StftLaunch::launch
+            bool direct = false;
+            if constexpr (MODE == OUT_COMPLEX || MODE == OUT_POWER) direct = !v2 && a.hop >= Cfg::N && !std::getenv("LRA_SIM_NO_DIRECT");
             if (v2) {
+            } else if (direct) {
+                if constexpr (MODE == OUT_COMPLEX || MODE == OUT_POWER) {
+                    a.slot_bytes = Cfg::FRAME_BYTES;
+                    a.shared_off = Cfg::FPB * a.slot_bytes;
+                    st.resize(Cfg::FPB * a.slot_bytes + shared_bytes);
+                    if (a.power_mode == POW_TWO) stft_block<Cfg, MODE, POW_TWO, 2>(a, (int)blk, lds);
+                    else if (a.power_mode == POW_ONE) stft_block<Cfg, MODE, POW_ONE, 2>(a, (int)blk, lds);
+                    else stft_block<Cfg, MODE, POW_GENERAL, 2>(a, (int)blk, lds);
+                }
             } else if (ra) {
                 if constexpr (sizeof(typename Cfg::real) == 4) {
-                    if (a.power_mode == POW_TWO) stft_block<Cfg, MODE, POW_TWO, true>(a, (int)blk, lds);
-                    else if (a.power_mode == POW_ONE) stft_block<Cfg, MODE, POW_ONE, true>(a, (int)blk, lds);
-                    else stft_block<Cfg, MODE, POW_GENERAL, true>(a, (int)blk, lds);
+                    if (a.power_mode == POW_TWO) stft_block<Cfg, MODE, POW_TWO, 1>(a, (int)blk, lds);
+                    else if (a.power_mode == POW_ONE) stft_block<Cfg, MODE, POW_ONE, 1>(a, (int)blk, lds);
+                    else stft_block<Cfg, MODE, POW_GENERAL, 1>(a, (int)blk, lds);
                 }
-            } else if (a.power_mode == POW_TWO) stft_block<Cfg, MODE, POW_TWO, false>(a, (int)blk, lds);
-            else if (a.power_mode == POW_ONE) stft_block<Cfg, MODE, POW_ONE, false>(a, (int)blk, lds);
-            else stft_block<Cfg, MODE, POW_GENERAL, false>(a, (int)blk, lds);
+            } else if (a.power_mode == POW_TWO) stft_block<Cfg, MODE, POW_TWO, 0>(a, (int)blk, lds);
+            else if (a.power_mode == POW_ONE) stft_block<Cfg, MODE, POW_ONE, 0>(a, (int)blk, lds);
+            else stft_block<Cfg, MODE, POW_GENERAL, 0>(a, (int)blk, lds);
             diag[8] = ra;
             diag[0] += st.races; diag[1] += st.uninit;
             st.races = st.uninit = 0;

@@ -905,3 +905,27 @@ def test_streaming_stft_out_reuse(L):
         L.stft(blk, n_fft=n_fft, hop_length=hop, center=False, out=np.zeros((1025, block_length - 1), dtype=np.complex64))
     with pytest.raises(L.ParameterError):
         L.stft(blk, n_fft=n_fft, hop_length=hop, center=False, out=np.zeros((1025, block_length), dtype=np.float32))
+
+
+@pytest.mark.parametrize("n_fft,hop,center,pad_mode,dtype", [(512, 512, True, "constant", np.float32), (512, 512, False, "constant", np.float32), (256, 300, True, "reflect", np.float32),
+                                                            (2048, 2048, True, "edge", np.float32), (8192, 8192, True, "symmetric", np.float32), (128, 1000, True, "constant", np.float32),
+                                                            (512, 512, True, "reflect", np.float64), (4096, 5000, False, "constant", np.float64)])
+def test_direct_framing(L, n_fft, hop, center, pad_mode, dtype):
+    """hop >= n_fft (BASELINE configs[4]'s n_fft = 512 leg): frames do not overlap and the kernels frame without a ring
+    (stft_kernel<..., RA = 2>); with the option off the ring kernels must give the same numbers."""
+    ctx = L.get_context(0)
+    rng = np.random.default_rng(n_fft + hop)
+    y = rng.standard_normal((3, 70001)).astype(dtype)  # odd length: clips 1.. start on odd sample addresses
+    ref = O.stft(y, n_fft=n_fft, hop_length=hop, center=center, pad_mode=pad_mode)
+    try:
+        for v2 in (1, 0):
+            ctx.set_option("v2", v2)
+            D = L.stft(y, n_fft=n_fft, hop_length=hop, center=center, pad_mode=pad_mode)
+            assert D.shape == ref.shape and _stft_close(D, ref)
+            S, _ = L._spectrogram(y=y, n_fft=n_fft, hop_length=hop, power=2, center=center, pad_mode=pad_mode)
+            assert np.all(np.abs(S - np.abs(ref) ** 2) <= (1e-11 if dtype == np.float64 else 4e-6) * (np.abs(ref) ** 2).max())
+        ctx.set_option("direct", 0)
+        assert _stft_close(L.stft(y, n_fft=n_fft, hop_length=hop, center=center, pad_mode=pad_mode), ref)
+    finally:
+        ctx.set_option("v2", 1)
+        ctx.set_option("direct", 1)

@@ -48,6 +48,11 @@ def _tol(dtype):
         (1024, 512, True, "constant", 4, np.float32, 9000, 0),  # hop = n_fft/2: new block does not fit the prefetch registers
         (512, 512, True, "reflect", 3, np.float32, 9000, 0),  # hop = n_fft
         (256, 300, True, "constant", 3, np.float32, 5000, 0),  # hop > n_fft
+        (512, 512, False, "constant", 5, np.float32, 9001, 0),  # direct framing (no ring): odd length -> the second clip's pairs are not 8-byte aligned
+        (2048, 2048, True, "edge", 2, np.float32, 30001, 0),   # direct framing, one wave per frame
+        (8192, 8192, True, "reflect", 2, np.float32, 70000, 0),  # direct framing, four waves per frame
+        (128, 1000, True, "symmetric", 4, np.float32, 9000, 0),
+        (512, 512, True, "reflect", 3, np.float64, 9000, 0),
         (512, 100, False, "constant", 4, np.float32, 3000, 0),
         (4096, 1000, True, "symmetric", 3, np.float32, 30000, 0),  # two waves per frame (workgroup barriers), odd-ish hop
         (2048, 512, True, "constant", 4, np.float32, 700, 0),  # fewer frames than slots x iters
