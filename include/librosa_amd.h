@@ -188,6 +188,12 @@ int lra_griffinlim_update(lra_ctx* ctx, const void* rebuilt, const void* tprev, 
  * caller's rng.random(S.shape), so that a seed reproduces the reference's stream), in the element order of S / angles. */
 int lra_griffinlim_init(lra_ctx* ctx, const void* u, const void* S, void* angles, int64_t count, int dtype);
 
+/* ---- phase vocoder: librosa.phase_vocoder, librosa/core/spectrum.py:1364-1519 (effects.time_stretch, effects.py:464-484) ---- */
+/* D: [batch][n_frames][n_bins] complex (device), out: [batch][n_out][n_bins]; t_out_host: n_out fractional input frame times in
+ * [0, n_frames) (np.arange(0, n_frames, rate) for a constant rate, :1488).  Phase: running sum of the phase differences of the
+ * two input frames around each time (:1491-1507); magnitude: scipy interp1d(kind="linear") of |D| (:1507-1515). */
+int lra_phase_vocoder_exec(lra_ctx* ctx, const void* D, void* out, int64_t batch, int64_t n_frames, int n_bins, const double* t_out_host, int64_t n_out, int dtype);
+
 /* ---- layout helper: dst[b][c][r] = src[b][r][c], elem_bytes in {4, 8, 16} ------------------ */
 int lra_transpose(lra_ctx* ctx, const void* src, void* dst, int64_t batch, int64_t rows, int64_t cols, int elem_bytes);
 

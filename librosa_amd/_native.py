@@ -72,6 +72,7 @@ SIGNATURES = {
     "lra_to_db_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_int, c_double]),
     "lra_from_db_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_double]),
     "lra_stft_exec_host": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p, c_int64, POINTER(c_int)]),
+    "lra_phase_vocoder_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_int]),
     "lra_griffinlim_init": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int]),
     "lra_griffinlim_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_double, c_double, c_int]),
     "lra_dct_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_int, c_double, c_double, c_void_p, c_void_p, c_int, c_double]),
@@ -345,6 +346,10 @@ class Context:
         _check(self.lib.lra_dct_exec(self.handle, c_void_p(s_ptr), c_void_p(out_ptr), batch, n_in, n_out, n_frames, dtype_code(dtype), c_void_p(basis_ptr), c_void_p(lift_ptr),
                                      int(bool(fuse_db)), float(amin), float(ref_scalar), c_void_p(ref_items_ptr or None), c_void_p(item_max_ptr or None), int(top_db is not None),
                                      float(top_db if top_db is not None else 0.0)))
+
+    def phase_vocoder_exec(self, d_ptr, out_ptr, batch, n_frames, n_bins, t_out, dtype):
+        t = np.ascontiguousarray(t_out, dtype=np.float64)
+        _check(self.lib.lra_phase_vocoder_exec(self.handle, c_void_p(d_ptr), c_void_p(out_ptr), batch, n_frames, n_bins, c_void_p(t.ctypes.data), len(t), dtype_code(dtype)))
 
     def memset(self, ptr, value, nbytes):
         _check(self.lib.lra_memset(self.handle, c_void_p(ptr), int(value), int(nbytes)))

@@ -22,7 +22,7 @@ from ..util import utils as util
 from ..util.exceptions import ParameterError
 from ..util.utils import is_torch_tensor
 
-__all__ = ["stft", "istft", "_spectrogram", "griffinlim", "power_to_db", "amplitude_to_db", "db_to_power", "db_to_amplitude"]
+__all__ = ["stft", "istft", "_spectrogram", "griffinlim", "phase_vocoder", "power_to_db", "amplitude_to_db", "db_to_power", "db_to_amplitude"]
 
 # np.pad modes that do not depend only on edge values: rejected exactly as the reference does
 _REJECTED_PAD_MODES = ("wrap", "maximum", "mean", "median", "minimum")
@@ -511,6 +511,57 @@ def griffinlim(S, *, n_iter=32, hop_length=None, win_length=None, n_fft=None, wi
     finally:
         sess.close()
     return _arrays.cast(y.reshape(lead + (expected,)), out_dtype)
+
+
+# ---------------------------------------------------------------------------------------------------
+# phase vocoder: librosa/core/spectrum.py:1364-1519
+# ---------------------------------------------------------------------------------------------------
+def phase_vocoder(D, *, rate=None, t_out=None, kind="linear", hop_length=_DEPRECATED, n_fft=_DEPRECATED):
+    """Phase vocoder; drop-in for ``librosa.phase_vocoder`` (``librosa/core/spectrum.py:1364-1519``).
+
+    One device kernel: a thread per (clip, bin) accumulates the phase along the output frames and interpolates the
+    magnitude (``csrc/lra_post.h``).  ``D`` may be a device tensor (a device tensor is returned).  Only
+    ``kind="linear"`` (the default) is provided.
+    """
+    if D.ndim < 2:
+        raise ParameterError(f"D must have at least 2 dimensions, given shape={tuple(D.shape)}")
+    n_frames = int(D.shape[-1])
+    for name, val in (("hop_length", hop_length), ("n_fft", n_fft)):
+        if val is not _DEPRECATED:
+            warnings.warn(f"The `{name}` parameter is deprecated as of 1.0 and will be removed in 1.1. It is unused in the current implementation.", FutureWarning, stacklevel=2)
+    if (rate is None) == (t_out is None):
+        raise ParameterError("Must specify exactly one of `rate` or `t_out`")
+    if (rate is not None) and (rate <= 0):
+        raise ParameterError(f"rate={rate} must be a positive number")
+    if kind != "linear":
+        raise ParameterError(f"kind={kind!r}: librosa_amd.phase_vocoder provides linear magnitude interpolation only")
+    if t_out is None:
+        t_out = np.arange(0.0, n_frames, rate)
+    t_out = np.asarray(t_out, dtype=float)
+    if np.any(t_out < 0) or np.any(t_out >= n_frames):
+        raise ParameterError("t_out values must be in the range [0, D.shape[-1])")
+    if np.any(np.diff(t_out) < 0):
+        warnings.warn("t_out is not monotonic; phase estimation may be unstable", stacklevel=2)
+    in_dtype = _arrays.numpy_dtype_of(D)
+    if in_dtype.kind != "c":
+        raise ParameterError(f"D with dtype={in_dtype} is not of complex type")
+    cplx = np.dtype(in_dtype)
+    real = np.dtype(np.float64) if cplx == np.complex128 else np.dtype(np.float32)
+    n_bins, n_out = int(D.shape[-2]), int(len(t_out))
+    lead = tuple(D.shape[:-2])
+    batch = int(np.prod(lead, dtype=np.int64)) if lead else 1
+    if n_frames < 2:
+        raise ParameterError("phase_vocoder needs at least two frames")
+    sess = _arrays.Session(D)
+    try:
+        ctx = sess.ctx
+        d_ptr = _to_frame_major(sess, D, batch, n_bins, n_frames, cplx)
+        ptr, handle = sess.output((batch, n_out, n_bins), cplx)
+        ctx.phase_vocoder_exec(d_ptr, ptr, batch, n_frames, n_bins, t_out, real)
+        res = sess.result(handle)
+    finally:
+        sess.close()
+    return _arrays.swap_last_two(res.reshape(lead + (n_out, n_bins)))
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -1748,6 +1748,41 @@ int lra_griffinlim_init(lra_ctx* ctx, const void* u, const void* S, void* angles
     return LRA_OK;
 }
 
+int lra_phase_vocoder_exec(lra_ctx* ctx, const void* D, void* out, int64_t batch, int64_t n_frames, int n_bins, const double* t_out_host, int64_t n_out, int dtype) {
+    LRA_BIND(ctx);
+    if (batch <= 0 || n_out <= 0 || n_bins <= 0) return LRA_OK;
+    if (!D || !out || !t_out_host) return fail(LRA_EINVAL, "null data pointer");
+    if (n_frames < 2) return fail(LRA_EINVAL, "phase_vocoder needs at least two frames");
+    // per output frame: the two phase frames and scipy interp1d's bracket (searchsorted left, clipped to [1, n - 1]; interpolate.py _call_linear)
+    std::vector<VocoderStep<float>> steps((size_t)n_out);
+    for (int64_t t = 0; t < n_out; ++t) {
+        const double x = t_out_host[t];
+        if (!(x >= 0) || !(x < (double)n_frames)) return fail(LRA_EINVAL, "t_out values must be in the range [0, D.shape[-1])");
+        const int64_t i0 = (int64_t)std::floor(x);
+        int64_t idx = (int64_t)std::ceil(x);  // first frame index >= x
+        idx = std::min<int64_t>(std::max<int64_t>(idx, 1), n_frames - 1);
+        steps[(size_t)t] = {(int)i0, (int)std::min<int64_t>(i0 + 1, n_frames - 1), (int)(idx - 1), x - (double)(idx - 1)};
+    }
+    void* d_steps = nullptr;
+    LRA_HIP(hipMallocAsync(&d_steps, steps.size() * sizeof(steps[0]), ctx->stream));
+    hipError_t e = hipMemcpyAsync(d_steps, steps.data(), steps.size() * sizeof(steps[0]), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // `steps` is pageable host memory that dies with this call
+    if (e == hipSuccess) {
+        const long long threads = (long long)batch * n_bins;
+        const unsigned grid = (unsigned)((threads + 255) / 256);
+        if (dtype == LRA_F64)
+            hipLaunchKernelGGL(phase_vocoder_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream, (const Cplx2<double>*)D, (Cplx2<double>*)out, (const VocoderStep<double>*)d_steps,
+                               (long long)n_frames, (long long)n_out, n_bins, (long long)batch);
+        else
+            hipLaunchKernelGGL(phase_vocoder_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, (const Cplx2<float>*)D, (Cplx2<float>*)out, (const VocoderStep<float>*)d_steps,
+                               (long long)n_frames, (long long)n_out, n_bins, (long long)batch);
+        e = hipGetLastError();
+    }
+    (void)hipFreeAsync(d_steps, ctx->stream);
+    if (e != hipSuccess) return fail(LRA_EHIP, std::string("phase_vocoder: ") + hipGetErrorString(e));
+    return LRA_OK;
+}
+
 int lra_dct_exec(lra_ctx* ctx, const void* S, void* out, int64_t batch, int n_in, int n_out, int64_t n_frames, int dtype, const void* basis, const void* lift, int fuse_db, double amin,
                  double ref_scalar, const void* ref_items, const void* item_max, int use_top_db, double top_db) {
     LRA_BIND(ctx);

@@ -200,4 +200,43 @@ template <class T> __global__ __launch_bounds__(256) void griffinlim_init_kernel
     }
 }
 
+// ---- phase vocoder (librosa/core/spectrum.py:1459-1519) ----------------------------------------------
+// One thread per (clip, bin), lanes along the contiguous bin axis of the [batch][frame][bin] layout: every frame access is a
+// coalesced wave load / store.  The thread walks the output frames in order, because the phase is a running sum along time
+// (np.cumsum in the spectrum's real precision, :1507): phase_0 = angle(D[i0_0]); phase_t = phase_{t-1} + angle(D[i1_{t-1}]) -
+// angle(D[i0_{t-1}]) with i0 = floor(t_out), i1 = min(i0 + 1, n - 1) (:1491-1504).  The magnitude is scipy's linear interp1d of
+// |D| (:1507-1515): between the frames lo = clip(searchsorted(t), 1, n - 1) - 1 and lo + 1, evaluated in float64 as
+// slope * (t - lo) + |D[lo]|, and the phasor multiply is NumPy's complex64 *= float64 (in double, rounded once).
+template <class T> struct VocoderStep {
+    int i0, i1, lo;    // phase frames; lower interpolation frame
+    double frac;       // t - lo
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void phase_vocoder_kernel(const Cplx2<T>* __restrict__ D, Cplx2<T>* __restrict__ out, const VocoderStep<T>* __restrict__ steps, long long n_in, long long n_out,
+                                                            int n_bins, long long batch) {
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= batch * n_bins) return;
+    const long long b = id / n_bins;
+    const int k = (int)(id % n_bins);
+    const Cplx2<T>* __restrict__ d = D + b * n_in * n_bins + k;
+    Cplx2<T>* __restrict__ o = out + b * n_out * n_bins + k;
+    T phase = (T)0;
+    for (long long t = 0; t < n_out; ++t) {
+        const VocoderStep<T> st = steps[t];  // uniform: scalar loads
+        const Cplx2<T> a = d[(long long)st.i0 * n_bins], c = d[(long long)st.i1 * n_bins];
+        const T pa = atan2(a.y, a.x), pc = atan2(c.y, c.x);
+        if (t == 0) phase = pa;
+        const Cplx2<T> l = d[(long long)st.lo * n_bins], h = d[(long long)(st.lo + 1) * n_bins];
+        const double ml = (double)gl_hypot<T>(l.x, l.y), mh = (double)gl_hypot<T>(h.x, h.y);
+        const double mag = (mh - ml) * st.frac + ml;
+        const T sn = sin(phase), cs = cos(phase);
+        Cplx2<T> z;
+        z.x = (T)((double)cs * mag);
+        z.y = (T)((double)sn * mag);
+        o[t * n_bins] = z;
+        phase += pc - pa;  // consumed by the next frame (phase[1:] = diff[:-1], :1504)
+    }
+}
+
 }  // namespace lra

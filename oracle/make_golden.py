@@ -89,6 +89,32 @@ def main():
     print("config2 done")
     make_db_mfcc(librosa, meta)
     make_griffinlim(librosa, meta)
+    make_vocoder(librosa, meta)
+
+
+def make_vocoder(librosa, meta):
+    """librosa.phase_vocoder / effects.time_stretch outputs of the reference."""
+    import warnings
+
+    warnings.simplefilter("ignore", FutureWarning)  # time_stretch hands phase_vocoder its deprecated keywords (effects.py:471-476)
+    y = golden_cases.make_signal("mix", 12000, 61, None, "float32")
+    # broadband-floored signals: where a bin is below the float32 leakage floor its phase is rounding noise, and the vocoder
+    # ACCUMULATES phase -- on a clean chirp two correct STFT implementations give different outputs once the chirp reaches
+    # a bin that was quiet before (SURVEY.md 7, "precision")
+    ys = np.stack([y, golden_cases.make_signal("mix", 12000, 62, None, "float32")])
+    D = librosa.stft(y, n_fft=1024, hop_length=256)
+    t_out = np.array([0.0, 0.5, 3.25, 3.25, 10.9, 20.0, 46.999])
+    store = dict(y=y, ys=ys, D=np.ascontiguousarray(D), t_out=t_out)
+    store["pv_rate2"] = librosa.phase_vocoder(D, rate=2.0)
+    store["pv_rate06"] = librosa.phase_vocoder(D, rate=0.6)
+    store["pv_tout"] = librosa.phase_vocoder(D, t_out=t_out)
+    store["ts_15"] = librosa.effects.time_stretch(y, rate=1.5, n_fft=1024, hop_length=256)
+    store["ts_stereo_07_default"] = librosa.effects.time_stretch(ys, rate=0.7)
+    D64 = librosa.stft(ys.astype(np.float64), n_fft=512)
+    store["D64"] = np.ascontiguousarray(D64)
+    store["pv64_rate08"] = librosa.phase_vocoder(D64, rate=0.8)
+    np.savez_compressed(os.path.join(OUT, "vocoder.npz"), params=json.dumps(dict(case="vocoder", **meta)), **store)
+    print("vocoder done")
 
 
 def make_griffinlim(librosa, meta):
@@ -134,10 +160,11 @@ def make_db_mfcc(librosa, meta):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "griffinlim":  # only this fixture (the others are unchanged)
+    if len(sys.argv) > 1 and sys.argv[1] in ("griffinlim", "vocoder"):  # only this fixture (the others are unchanged)
         _librosa = ref_shim.load_reference()
         import scipy as _scipy
 
-        make_griffinlim(_librosa, dict(numpy=np.__version__, scipy=_scipy.__version__, reference_version=str(_librosa.__version__)))
+        _meta = dict(numpy=np.__version__, scipy=_scipy.__version__, reference_version=str(_librosa.__version__))
+        (make_griffinlim if sys.argv[1] == "griffinlim" else make_vocoder)(_librosa, _meta)
     else:
         main()

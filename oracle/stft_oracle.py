@@ -468,6 +468,45 @@ def griffinlim(S, *, n_iter=32, hop_length=None, win_length=None, n_fft=None, wi
     return istft(angles, **kw_i)                                                    # :2885-2895
 
 
+# ----------------------------------------------------------------------------- phase vocoder / time stretch
+def phase_vocoder(D, *, rate=None, t_out=None, kind="linear"):
+    """``librosa/core/spectrum.py:1459-1519``: phase advance per output frame = phase difference of the two input frames around
+    its (fractional) input time, accumulated; magnitude interpolated (``scipy.interpolate.interp1d``, the reference's own
+    call ``:1507-1515``)."""
+    import scipy.interpolate
+
+    n_frames = D.shape[-1]
+    if (rate is None) == (t_out is None):
+        raise ParameterError("Must specify exactly one of `rate` or `t_out`")
+    if (rate is not None) and (rate <= 0):
+        raise ParameterError(f"rate={rate} must be a positive number")
+    if t_out is None:
+        t_out = np.arange(0.0, n_frames, rate)
+    t_out = np.asarray(t_out, dtype=float)
+    if np.any(t_out < 0) or np.any(t_out >= n_frames):
+        raise ParameterError("t_out values must be in the range [0, D.shape[-1])")
+    i0 = np.floor(t_out).astype(int)                                  # :1491-1492
+    i1 = np.minimum(i0 + 1, n_frames - 1)
+    ph = np.angle(D)                                                  # :1495
+    diff = ph[..., i1] - ph[..., i0]                                  # :1498
+    phase = np.empty_like(diff)
+    phase[..., 0] = np.angle(D[..., i0[0]])                           # :1503
+    phase[..., 1:] = diff[..., :-1]
+    np.cumsum(phase, axis=-1, out=phase)                              # :1507
+    mag_interp = scipy.interpolate.interp1d(np.arange(n_frames), np.abs(D), kind=kind, axis=-1, fill_value="extrapolate", assume_sorted=True, copy=False)
+    return phasor(phase, mag=mag_interp(t_out))                       # :1518
+
+
+def time_stretch(y, *, rate, **kwargs):
+    """``librosa/effects.py:464-484``: stft -> phase_vocoder -> istft(length=round(n / rate))."""
+    if rate <= 0:
+        raise ParameterError("rate must be a positive number")
+    D = stft(y, **kwargs)
+    Ds = phase_vocoder(D, rate=rate)
+    ikw = {k: v for k, v in kwargs.items() if k in ("hop_length", "win_length", "n_fft", "window", "center")}
+    return istft(Ds, dtype=y.dtype, length=round(y.shape[-1] / rate), **ikw)
+
+
 # ----------------------------------------------------------------------------- SURVEY.md 8f rank 4: block feeder
 def stream_blocks(y, *, block_length, frame_length, hop_length, fill_value=None):
     """Blocks ``librosa.stream`` yields for an already decoded signal ``y`` ((n,) or (channels, n)), stated directly from

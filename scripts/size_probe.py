@@ -11,9 +11,12 @@ what = sys.argv[4] if len(sys.argv) > 4 else "stft"
 dev = torch.device("cuda", 0)
 ctx = L.get_context(0)
 ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-for kv in os.environ.get("PROBE_OPTS", "").split(","):
-    if "=" in kv:
-        k, v = kv.split("="); ctx.set_option(k, int(v))
+def apply_opts():
+    for kv in os.environ.get("PROBE_OPTS", "").split(","):
+        if "=" in kv:
+            k, v = kv.split("="); ctx.set_option(k, int(v))
+if what != "istft":
+    apply_opts()
 n, batch = 22050 * 30, 256
 y = bench.make_batch(torch, batch, n, 0, dev)
 w = np.asarray(filters.get_window("hann", n_fft, fftbins=True), dtype=np.float32)
@@ -27,6 +30,7 @@ if what == "istft":
     ww = torch.from_numpy(np.ascontiguousarray(np.pad(ww, (0, max(0, n - len(ww))))[:n], dtype=np.float32)).to(dev)
     yr = torch.empty((batch, n), dtype=torch.float32, device=dev)
     ctx.stft_exec(pl, y.data_ptr(), batch, n, n, D.data_ptr())
+    apply_opts()  # (inverse-only kernel variants: after the forward transform that makes the input)
     fn = lambda: ctx.istft_exec(ip, D.data_ptr(), batch, T * bins, bins, T, ww.data_ptr(), yr.data_ptr(), n, n)
 else:
     fn = lambda: ctx.stft_exec(pl, y.data_ptr(), batch, n, n, D.data_ptr())

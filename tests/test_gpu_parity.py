@@ -929,3 +929,59 @@ def test_direct_framing(L, n_fft, hop, center, pad_mode, dtype):
     finally:
         ctx.set_option("v2", 1)
         ctx.set_option("direct", 1)
+
+
+# ---- phase vocoder / time stretch (librosa/core/spectrum.py:1364-1519, effects.py:404-484) -------------
+def _pv_close(a, ref):
+    tol = 1e-11 if a.dtype == np.complex128 else 3e-5
+    return a.shape == ref.shape and a.dtype == ref.dtype and np.all(np.abs(a - ref) <= tol * np.abs(ref) + tol * np.abs(ref).max())
+
+
+def test_phase_vocoder_and_time_stretch_golden(L):
+    import torch
+
+    g = np.load(os.path.join(GOLDEN_DIR, "vocoder.npz"))
+    D = g["D"]
+    assert _pv_close(L.phase_vocoder(D, rate=2.0), g["pv_rate2"])
+    assert _pv_close(L.phase_vocoder(D, rate=0.6), g["pv_rate06"])
+    assert _pv_close(L.phase_vocoder(D, t_out=g["t_out"]), g["pv_tout"])
+    assert _pv_close(L.phase_vocoder(g["D64"], rate=0.8), g["pv64_rate08"])
+    assert _pv_close(L.phase_vocoder(np.ascontiguousarray(D), rate=1.0), O.phase_vocoder(D, rate=1.0))
+    Dt = torch.from_numpy(np.ascontiguousarray(D)).cuda()
+    out = L.phase_vocoder(Dt, rate=0.6)
+    assert isinstance(out, torch.Tensor) and out.is_cuda and np.array_equal(out.cpu().numpy(), L.phase_vocoder(D, rate=0.6))
+    with pytest.warns(FutureWarning, match="deprecated"):
+        ts = L.effects.time_stretch(g["y"], rate=1.5, n_fft=1024, hop_length=256)
+    ref = g["ts_15"]
+    assert ts.shape == ref.shape and ts.dtype == ref.dtype and np.abs(ts - ref).max() <= 5e-5 * np.abs(ref).max()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", FutureWarning)
+        ts2 = L.effects.time_stretch(g["ys"], rate=0.7)
+        ref2 = g["ts_stereo_07_default"]
+        assert ts2.shape == ref2.shape and np.abs(ts2 - ref2).max() <= 5e-5 * np.abs(ref2).max()
+        tsd = L.effects.time_stretch(torch.from_numpy(g["ys"]).cuda(), rate=0.7)
+        assert isinstance(tsd, torch.Tensor) and np.array_equal(tsd.cpu().numpy(), ts2)
+    for bad in (dict(), dict(rate=1.0, t_out=np.arange(3.0)), dict(rate=-1), dict(t_out=np.array([0.0, 47.0])), dict(rate=2.0, kind="cubic")):
+        with pytest.raises(L.ParameterError):
+            L.phase_vocoder(D, **bad)
+    with pytest.raises(L.ParameterError):
+        L.effects.time_stretch(g["y"], rate=0)
+
+
+def test_device_resident_mask_round_trip(L):
+    """effects.hpss-shaped use (librosa/effects.py:161-185): stft -> mask -> istft with the spectra never leaving the device,
+    against the same chain through the oracle."""
+    import torch
+
+    y = golden_cases.make_signal("mix", 30000, 71, (2,), "float32")
+    D = L.stft(torch.from_numpy(y).cuda(), n_fft=1024)
+    mag = D.abs()
+    mask = (mag > mag.mean(dim=-1, keepdim=True)).to(D.dtype)   # a "harmonic / percussive"-style binary mask, computed on the device
+    yh = L.istft(D * mask, length=y.shape[-1])
+    assert isinstance(yh, torch.Tensor) and yh.is_cuda
+    Dr = O.stft(y, n_fft=1024)
+    mr = (np.abs(Dr) > np.abs(Dr).mean(axis=-1, keepdims=True)).astype(Dr.dtype)
+    # a bin whose magnitude sits within rounding of its row mean may flip sides: compare where the two masks agree
+    same = np.array_equal(mr, mask.cpu().numpy())
+    ref = O.istft(Dr * (mask.cpu().numpy() if not same else mr), length=y.shape[-1])
+    assert np.abs(yh.cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max()

@@ -268,3 +268,17 @@ def test_griffinlim_oracle_live_reference():
         S = np.abs(librosa.stft(y, **skw))
         assert np.array_equal(O.griffinlim(S, **gkw), librosa.griffinlim(S, **gkw))
     assert np.array_equal(O.phasor(np.linspace(-7, 7, 101)), librosa.util.phasor(np.linspace(-7, 7, 101)))
+
+
+# ---- phase vocoder / time stretch ---------------------------------------------------------------------
+def test_vocoder_oracle_matches_reference_golden():
+    """Restatements of librosa/core/spectrum.py:1459-1519 and effects.py:464-484 against the committed reference outputs
+    (oracle/make_golden.py::make_vocoder): bit for bit (same operation order; scipy's own interp1d)."""
+    g = np.load(os.path.join(GOLDEN_DIR, "vocoder.npz"))
+    D = g["D"]
+    assert np.array_equal(O.phase_vocoder(D, rate=2.0), g["pv_rate2"])
+    assert np.array_equal(O.phase_vocoder(D, rate=0.6), g["pv_rate06"])
+    assert np.array_equal(O.phase_vocoder(D, t_out=g["t_out"]), g["pv_tout"])
+    assert np.array_equal(O.phase_vocoder(g["D64"], rate=0.8), g["pv64_rate08"])
+    assert np.array_equal(O.time_stretch(g["y"], rate=1.5, n_fft=1024, hop_length=256), g["ts_15"])
+    assert np.array_equal(O.time_stretch(g["ys"], rate=0.7), g["ts_stereo_07_default"])
