@@ -324,6 +324,16 @@ template <class T> struct StftLaunch {
                 if (MODE != OUT_COMPLEX && a.power_mode == POW_GENERAL) kern = stft_kernel<Cfg, MODE, POW_GENERAL, 2>;
             }
         }
+        // n_fft >= 8192 (f32) with hop = n_fft / {2, 4, 8, 16}: the sample ring lives in registers (RA = 2 + log2 HD)
+        if constexpr ((MODE == OUT_COMPLEX || MODE == OUT_POWER) && sizeof(T) == 4 && Cfg::LOGM >= 12) {
+            const int hd = use_direct ? regring_hd<Cfg>(a.hop) : 0;
+#define LRA_PICKR(RAM)                                                                                       \
+    kern = stft_kernel<Cfg, MODE, POW_TWO, RAM>;                                                            \
+    if (MODE != OUT_COMPLEX && a.power_mode == POW_ONE) kern = stft_kernel<Cfg, MODE, POW_ONE, RAM>;        \
+    if (MODE != OUT_COMPLEX && a.power_mode == POW_GENERAL) kern = stft_kernel<Cfg, MODE, POW_GENERAL, RAM>;
+            if (hd == 2) { direct = true; LRA_PICKR(3) } else if (hd == 4) { direct = true; LRA_PICKR(4) } else if (hd == 8) { direct = true; LRA_PICKR(5) } else if (hd == 16) { direct = true; LRA_PICKR(6) }
+#undef LRA_PICKR
+        }
         // Second-generation kernel (lra_kernels2.h) where it applies: complex / power epilogues, 16 points per thread with
         // a two-butterfly last pass (n_fft 1024 / 2048 / 4096), hop = n_fft / {1, 2, 4, 8}.
         bool v2 = false;

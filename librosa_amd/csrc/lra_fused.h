@@ -105,6 +105,9 @@ LRA_CFG_ALIAS(cfg_f64_12, double, 12, 0)
     S(lra::C##_mel, 4, 1, RA) S(lra::C##_mel, 4, 2, RA) S(lra::C##_mel, 4, 3, RA)
 // direct framing (RA = 2: hop >= n_fft, no ring): complex and power epilogues
 #define LRA_STFT_DIRECT(S, C) S(lra::C, 0, 2, 2) S(lra::C, 1, 1, 2) S(lra::C, 1, 2, 2) S(lra::C, 1, 3, 2)
+// register ring (RA = 3 .. 6: hop = n_fft / 2, 4, 8, 16) for the large frames the second-generation kernel does not cover
+#define LRA_STFT_REGRING(S, C) LRA_STFT_REGRING1(S, C, 3) LRA_STFT_REGRING1(S, C, 4) LRA_STFT_REGRING1(S, C, 5) LRA_STFT_REGRING1(S, C, 6)
+#define LRA_STFT_REGRING1(S, C, RA) S(lra::C, 0, 2, RA) S(lra::C, 1, 1, RA) S(lra::C, 1, 2, RA) S(lra::C, 1, 3, RA)
 // f32: both ring addressings; the overlap-add row counts HC = R/2, R/4, R/8 (8, 4, 2 at 16 points per thread)
 #define LRA_F32_CFG(S, I, C, HCQ, HCE) LRA_STFT_SET(S, C, 0) LRA_STFT_SET(S, C, 1) LRA_STFT_DIRECT(S, C) I(lra::C, 0) I(lra::C, (2 * HCQ)) I(lra::C, HCQ) I(lra::C, HCE)
 #define LRA_F64_CFG(S, I, C) LRA_STFT_SET(S, C, 0) LRA_STFT_DIRECT(S, C) I(lra::C, 0)
@@ -115,7 +118,7 @@ LRA_CFG_ALIAS(cfg_f64_12, double, 12, 0)
 #define LRA_INST_GROUP_3(S, I) LRA_F32_CFG(S, I, cfg_f32_4, 4, 2) LRA_F32_CFG(S, I, cfg_f32_5, 4, 2) LRA_F32_CFG(S, I, cfg_f32_6, 4, 2)
 #define LRA_INST_GROUP_4(S, I) LRA_F32_CFG(S, I, cfg_f32_7, 4, 2) LRA_F32_CFG(S, I, cfg_f32_8, 4, 2)
 #define LRA_INST_GROUP_5(S, I) LRA_F32_CFG(S, I, cfg_f32_9, 4, 2) LRA_F32_CFG(S, I, cfg_f32_11, 4, 2)
-#define LRA_INST_GROUP_6(S, I) LRA_F32_CFG(S, I, cfg_f32_12, 4, 2) LRA_F32_CFG(S, I, cfg_f32_13, 4, 2)
+#define LRA_INST_GROUP_6(S, I) LRA_F32_CFG(S, I, cfg_f32_12, 4, 2) LRA_F32_CFG(S, I, cfg_f32_13, 4, 2) LRA_STFT_REGRING(S, cfg_f32_12) LRA_STFT_REGRING(S, cfg_f32_13)
 #define LRA_INST_GROUP_7(S, I) LRA_F64_CFG(S, I, cfg_f64_4) LRA_F64_CFG(S, I, cfg_f64_5) LRA_F64_CFG(S, I, cfg_f64_6) LRA_F64_CFG(S, I, cfg_f64_7) LRA_F64_CFG(S, I, cfg_f64_8)
 #define LRA_INST_GROUP_8(S, I) LRA_F64_CFG(S, I, cfg_f64_9) LRA_F64_CFG(S, I, cfg_f64_10) LRA_F64_CFG(S, I, cfg_f64_11) LRA_F64_CFG(S, I, cfg_f64_12)
 // second-generation forward kernels: T(CFG, HD, MODE, PM)

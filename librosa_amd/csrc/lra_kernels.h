@@ -136,6 +136,7 @@ template <class Cfg> struct FftRegs {
     static constexpr int NPFX = 2 * NPF;
     typename Cfg::real pf[NPFX];
     typename Cfg::cplx nxt[Cfg::R];  // direct framing (hop >= n_fft, no ring): the next frame's sample pairs in pass-0 register order, in flight during the current frame
+    typename Cfg::cplx raw[Cfg::R];  // register ring (hop = n_fft / HD, RAM = 3..6): this frame's sample pairs in pass-0 order; nxt[0 .. R/HD) then holds the next frame's new pairs
     // HOIST configurations: this thread's table values, loaded once before the frame loop.  (hipcc
     // does not hoist them by itself across the per-phase fences; re-reading ~52 table values per
     // frame from L2 left the waves 65 % of their time in s_waitcnt.)
@@ -448,6 +449,97 @@ template <class Cfg> LRA_HD void stft_direct_pass0(const StftArgs<typename Cfg::
         }
     }
     if (more) stft_direct_fetch<Cfg>(a, clip, frame + 1, tf, rg);
+    pass_dft<Cfg, 0>(rg, tf, a.tw);
+    pass_write<Cfg, 0>(rg.v, fr, tf);
+}
+
+// ---- register ring (stft_kernel<..., RA = 2 + log2 HD>, HD = 2 .. 16): hop = n_fft / HD with the hop a whole number of pass-0 rows --
+// The idea of the second-generation kernel (lra_kernels2.h) for the configurations whose last pass it cannot mirror (n_fft >=
+// 8192: 16 . 16 . 16): frame t+1's pass-0 element (tf, i, j) is frame t's element (tf, i, j + r0/HD), so the samples live in
+// 2R registers per thread, advanced by register moves, and only the R/HD new pairs per frame are loaded (one frame ahead,
+// before the frame's stores).  No ring in LDS: at n_fft = 8192 the slot shrinks from 67 KB to 35 KB (4 workgroups of four waves
+// per CU instead of 2) and the general ring addressing (a masked address per element and frame) disappears.
+template <class Cfg, int HD> struct RegRing {
+    static constexpr int lr = Cfg::logr(0), r0 = 1 << lr, nb0 = Cfg::R >> lr, sin0 = Cfg::M >> lr;
+    static constexpr int SJ = r0 / HD;       // pass-0 rows a frame advances by
+    static constexpr int NEW = Cfg::R / HD;  // new sample pairs per thread and frame
+    static constexpr bool ok = HD >= 2 && r0 % HD == 0 && Cfg::R % HD == 0;
+    static LRA_HD int q_of(int tf, int e) { return tf + (e / r0) * Cfg::TF + (e % r0) * sin0; }  // complex index of register element e
+    static LRA_HD int elem_of_new(int n) { return (n / SJ) * r0 + (r0 - SJ) + (n % SJ); }         // register element of new pair n
+};
+template <class Cfg> LRA_HD int regring_hd(int hop) {
+    for (int hd = 2; hd <= 16; hd *= 2)
+        if ((long long)hop * hd == Cfg::N && (1 << Cfg::logr(0)) % hd == 0 && Cfg::R % hd == 0) return hd;
+    return 0;
+}
+
+// all R pairs of a slot's first frame -> rg.raw
+template <class Cfg, int HD> LRA_HD void regring_fill(const StftArgs<typename Cfg::real>& a, int clip, int frame, int tf, FftRegs<Cfg>& rg) {
+    using T = typename Cfg::real;
+    const T* __restrict__ yb = a.y + (long long)clip * a.y_stride;
+    const long long p0 = (long long)frame * a.hop;
+    const bool live = frame < a.n_frames;
+    LRA_UNROLL
+    for (int e = 0; e < Cfg::R; ++e) {
+        const long long p = p0 + 2 * RegRing<Cfg, HD>::q_of(tf, e);
+        rg.raw[e] = live ? mk<T>(fetch_sample<T>(yb, p, a.pad, a.n, a.pad_mode), fetch_sample<T>(yb, p + 1, a.pad, a.n, a.pad_mode)) : mk<T>((T)0, (T)0);
+    }
+}
+
+// the NEW pairs of frame `next` -> rg.nxt (issued one frame ahead)
+template <class Cfg, int HD> LRA_HD void regring_issue(const StftArgs<typename Cfg::real>& a, int clip, int next, int tf, FftRegs<Cfg>& rg) {
+    using T = typename Cfg::real;
+    using C = typename Cfg::cplx;
+    using RR = RegRing<Cfg, HD>;
+    if (next >= a.n_frames) return;
+    const T* __restrict__ yb = a.y + (long long)clip * a.y_stride;
+    const long long p0 = (long long)next * a.hop;
+    const long long g0 = p0 + (Cfg::N - a.hop) - a.pad;  // clip position of the first NEW sample
+    if (g0 >= 0 && g0 + a.hop <= a.n) {
+        const T* __restrict__ src = yb + (p0 - a.pad) + 2 * tf;
+        if ((reinterpret_cast<size_t>(src) & (2 * sizeof(T) - 1)) == 0) {
+            LRA_UNROLL
+            for (int n = 0; n < RR::NEW; ++n) {
+                const int e = RR::elem_of_new(n);
+                rg.nxt[n] = *reinterpret_cast<const C*>(src + 2 * ((e / RR::r0) * Cfg::TF + (e % RR::r0) * RR::sin0));
+            }
+        } else {
+            LRA_UNROLL
+            for (int n = 0; n < RR::NEW; ++n) {
+                const int e = RR::elem_of_new(n);
+                const T* __restrict__ s2 = src + 2 * ((e / RR::r0) * Cfg::TF + (e % RR::r0) * RR::sin0);
+                rg.nxt[n] = mk<T>(s2[0], s2[1]);
+            }
+        }
+    } else {
+        LRA_UNROLL
+        for (int n = 0; n < RR::NEW; ++n) {
+            const long long p = p0 + 2 * RR::q_of(tf, RR::elem_of_new(n));
+            rg.nxt[n] = mk<T>(fetch_sample<T>(yb, p, a.pad, a.n, a.pad_mode), fetch_sample<T>(yb, p + 1, a.pad, a.n, a.pad_mode));
+        }
+    }
+}
+
+// phase B: advance the register ring (not for a slot's first frame), start the next frame's loads, window, pass 0
+template <class Cfg, int HD> LRA_HD void regring_pass0(const StftArgs<typename Cfg::real>& a, int clip, int frame, bool first, bool more, int tf, FftRegs<Cfg>& rg, Lds fr) {
+    using T = typename Cfg::real;
+    using C = typename Cfg::cplx;
+    using RR = RegRing<Cfg, HD>;
+    const C* __restrict__ win2 = reinterpret_cast<const C*>(a.win);
+    if (!first) {
+        LRA_UNROLL
+        for (int i = 0; i < RR::nb0; ++i) {
+            LRA_UNROLL
+            for (int j = 0; j < RR::r0; ++j) rg.raw[i * RR::r0 + j] = j + RR::SJ < RR::r0 ? rg.raw[i * RR::r0 + j + RR::SJ] : rg.nxt[i * RR::SJ + (j + RR::SJ - RR::r0)];
+        }
+    }
+    if (more) regring_issue<Cfg, HD>(a, clip, frame + 1, tf, rg);
+    const bool live = frame < a.n_frames;
+    LRA_UNROLL
+    for (int e = 0; e < Cfg::R; ++e) {
+        const C w = Cfg::HOIST ? rg.win2[e] : win2[RR::q_of(tf, e)];
+        rg.v[e] = live ? mk<T>(rg.raw[e].x * w.x, rg.raw[e].y * w.y) : mk<T>((T)0, (T)0);
+    }
     pass_dft<Cfg, 0>(rg, tf, a.tw);
     pass_write<Cfg, 0>(rg.v, fr, tf);
 }
@@ -891,7 +983,9 @@ template <class Cfg> inline int stft_slot_bytes(int mode, int n_mels, int tile) 
 // epilogue stages `mel_tile` frames per row before flushing them as contiguous runs.
 // RAM: ring addressing mode: 0 general, 1 row-aligned (hop = n_fft/4), 2 no ring at all (direct framing, hop >= n_fft; complex / power epilogues)
 template <class Cfg, int MODE, int PM = POW_TWO, int RAM = 0> LRA_HD void stft_block(const StftArgs<typename Cfg::real>& a_in, const int blk, Lds lds) {
-    constexpr bool RA = RAM == 1, DIRECT = RAM == 2;
+    constexpr bool RA = RAM == 1, DIRECT = RAM >= 2;        // DIRECT: no ring in LDS
+    constexpr int RHD = RAM >= 3 ? 1 << (RAM - 2) : 1;       // RAM = 3 .. 6: register ring with hop = n_fft / RHD
+    static_assert(RAM <= 2 || RegRing<Cfg, RHD>::ok, "register ring: the hop must be a whole number of pass-0 rows");
     static_assert(!DIRECT || MODE == OUT_COMPLEX || MODE == OUT_POWER, "direct framing serves the complex / power epilogues");
     StftArgs<typename Cfg::real> a = a_in;
     const int clip = blk / a.wg_per_clip;
@@ -931,7 +1025,9 @@ template <class Cfg, int MODE, int PM = POW_TWO, int RAM = 0> LRA_HD void stft_b
     } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC && MODE != OUT_MEL2 && MODE != OUT_MELR)  // the shared tables need a workgroup barrier, once
     LRA_PHASE(Cfg::NT, tid) {
         const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
-        if (DIRECT) {
+        if (RHD > 1) {
+            regring_fill<Cfg, RHD>(a, clip, f_first + slot * iters, tf, LRA_R(rg));
+        } else if (DIRECT) {
             stft_direct_fetch<Cfg>(a, clip, f_first + slot * iters, tf, LRA_R(rg));
         } else {
             stft_ring_fill<Cfg>(a, clip, f_first + slot * iters, tf, lds_sub(lds, slot * slot_bytes + stft_ring_off<Cfg>()));
@@ -952,7 +1048,8 @@ template <class Cfg, int MODE, int PM = POW_TWO, int RAM = 0> LRA_HD void stft_b
 #endif
             if (DEFER && it > 0 && frame - 1 < a.n_frames)
                 mel2_combine<Cfg>(a, clip, frame - 1, tf, (it - 1) % tile, tile, lds_sub(lds, a.shared_off), lds_sub(sl, slot_bytes - mel2_psum_bytes<Cfg>(a.n_mels)), lds_sub(sl, stft_tile_off<Cfg>()));
-            if (DIRECT) stft_direct_pass0<Cfg>(a, clip, frame, it + 1 < iters, tf, LRA_R(rg), sl);
+            if (RHD > 1) regring_pass0<Cfg, RHD>(a, clip, frame, it == 0, it + 1 < iters, tf, LRA_R(rg), sl);
+            else if (DIRECT) stft_direct_pass0<Cfg>(a, clip, frame, it + 1 < iters, tf, LRA_R(rg), sl);
             else stft_ring_load_pass0<Cfg, RA>(a, frame, tf, LRA_R(rg), lds_sub(sl, stft_ring_off<Cfg>()), sl);
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         LRA_TICK(1);

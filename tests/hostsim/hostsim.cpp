@@ -65,7 +65,21 @@ template <class T> struct StftSim {
             // direct framing (hop >= n_fft: no ring), same selection as StftLaunch::launch
             bool direct = false;
             if constexpr (MODE == OUT_COMPLEX || MODE == OUT_POWER) direct = !v2 && a.hop >= Cfg::N && !std::getenv("LRA_SIM_NO_DIRECT");
+            int rhd = 0;
+            if constexpr ((MODE == OUT_COMPLEX || MODE == OUT_POWER) && sizeof(typename Cfg::real) == 4 && Cfg::LOGM >= 12) rhd = (!v2 && !std::getenv("LRA_SIM_NO_DIRECT")) ? regring_hd<Cfg>(a.hop) : 0;
             if (v2) {
+            } else if (rhd) {
+                if constexpr ((MODE == OUT_COMPLEX || MODE == OUT_POWER) && sizeof(typename Cfg::real) == 4 && Cfg::LOGM >= 12) {
+                    a.slot_bytes = Cfg::FRAME_BYTES;
+                    a.shared_off = Cfg::FPB * a.slot_bytes;
+                    st.resize(Cfg::FPB * a.slot_bytes + shared_bytes);
+#define SIM_RR(RAM)                                                                                     \
+    if (a.power_mode == POW_TWO) stft_block<Cfg, MODE, POW_TWO, RAM>(a, (int)blk, lds);                 \
+    else if (a.power_mode == POW_ONE) stft_block<Cfg, MODE, POW_ONE, RAM>(a, (int)blk, lds);            \
+    else stft_block<Cfg, MODE, POW_GENERAL, RAM>(a, (int)blk, lds);
+                    if (rhd == 2) { SIM_RR(3) } else if (rhd == 4) { SIM_RR(4) } else if (rhd == 8) { SIM_RR(5) } else { SIM_RR(6) }
+#undef SIM_RR
+                }
             } else if (direct) {
                 if constexpr (MODE == OUT_COMPLEX || MODE == OUT_POWER) {
                     a.slot_bytes = Cfg::FRAME_BYTES;

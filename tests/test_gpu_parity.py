@@ -985,3 +985,22 @@ def test_device_resident_mask_round_trip(L):
     same = np.array_equal(mr, mask.cpu().numpy())
     ref = O.istft(Dr * (mask.cpu().numpy() if not same else mr), length=y.shape[-1])
     assert np.abs(yh.cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("n_fft,hop,center,pad_mode", [(8192, 512, True, "constant"), (8192, 4096, True, "reflect"), (8192, 1024, False, "constant"), (16384, 1024, True, "edge"), (16384, 8192, True, "symmetric")])
+def test_register_ring_large_frames(L, n_fft, hop, center, pad_mode):
+    """n_fft >= 8192 with hop = n_fft / {2, 4, 8, 16} (BASELINE configs[4]'s n_fft = 8192 leg): the sample ring lives in
+    registers (stft_kernel<..., RA = 3 .. 6>); with the option off the LDS-ring kernels must give the same numbers."""
+    ctx = L.get_context(0)
+    rng = np.random.default_rng(n_fft + hop)
+    y = rng.standard_normal((3, 90001)).astype(np.float32)
+    ref = O.stft(y, n_fft=n_fft, hop_length=hop, center=center, pad_mode=pad_mode)
+    try:
+        D = L.stft(y, n_fft=n_fft, hop_length=hop, center=center, pad_mode=pad_mode)
+        assert D.shape == ref.shape and _stft_close(D, ref)
+        S, _ = L._spectrogram(y=y, n_fft=n_fft, hop_length=hop, power=1, center=center, pad_mode=pad_mode)
+        assert np.all(np.abs(S - np.abs(ref)) <= 4e-6 * np.abs(ref).max())
+        ctx.set_option("direct", 0)
+        assert _stft_close(L.stft(y, n_fft=n_fft, hop_length=hop, center=center, pad_mode=pad_mode), ref)
+    finally:
+        ctx.set_option("direct", 1)
