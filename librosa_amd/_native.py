@@ -210,6 +210,7 @@ class Context:
         self._stft_plans = collections.OrderedDict()
         self._istft_plans = collections.OrderedDict()
         self._mel_plans = collections.OrderedDict()
+        self._mel_by_id = {}
         self._lock = threading.RLock()
         self.call_lock = threading.RLock()  # held by _arrays.Session for the duration of one public call
 
@@ -286,8 +287,21 @@ class Context:
         return self._cached_plan(self._istft_plans, key, create, self.lib.lra_istft_plan_destroy)
 
     def mel_plan(self, basis):
+        # Read-only arrays (what filters.mel_cached hands out) are recognised by identity: hashing the 525 KB of a 128 x 1025
+        # basis on every call cost more host time than the kernel it configures takes to run.
+        fast = isinstance(basis, np.ndarray) and not basis.flags.writeable and basis.flags.c_contiguous
+        if fast:
+            hit = self._mel_by_id.get(id(basis))
+            if hit is not None and hit[0] is basis:
+                plan = self._mel_plans.get(hit[1])
+                if plan is not None:
+                    return plan
         basis = np.ascontiguousarray(basis)
         key = (basis.shape, basis.dtype.str, basis.tobytes())
+        if fast:
+            if len(self._mel_by_id) > 4 * self.PLAN_CACHE_SIZE:
+                self._mel_by_id.clear()
+            self._mel_by_id[id(basis)] = (basis, key)
 
         def create():
             h = c_void_p()

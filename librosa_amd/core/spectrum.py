@@ -12,6 +12,7 @@ Extensions beyond the reference (which only accepts ``np.ndarray``):
 """
 from __future__ import annotations
 
+import functools
 import warnings
 
 import numpy as np
@@ -77,8 +78,7 @@ def _prepare_stft(y, n_fft, hop_length, win_length, window, center, pad_mode, _w
         raise ParameterError(f"hop_length={hop_length} must be a positive integer")
     if not util.is_positive_int(n_fft):
         raise ParameterError(f"n_fft={n_fft} must be a positive integer")
-    fft_window = filters.get_window(window, win_length, fftbins=True)
-    fft_window = util.pad_center(np.asarray(fft_window, dtype=np.float64), size=n_fft)
+    fft_window = _padded_window(window, win_length, n_fft)
     n = y.shape[-1]
     if center:
         if pad_mode in _REJECTED_PAD_MODES:
@@ -98,6 +98,24 @@ def _prepare_stft(y, n_fft, hop_length, win_length, window, center, pad_mode, _w
             raise ParameterError(f"n_fft={n_fft} is too large for uncentered analysis of input signal of length={n}")
         pad_mode = "constant"
     return y, int(hop_length), fft_window, bool(center), pad_mode
+
+
+@functools.lru_cache(maxsize=64)
+def _padded_window_cached(window, win_length, n_fft):
+    w = util.pad_center(np.asarray(filters.get_window(window, win_length, fftbins=True), dtype=np.float64), size=n_fft)
+    w.setflags(write=False)
+    return w
+
+
+def _padded_window(window, win_length, n_fft):
+    """``pad_center(get_window(window, win_length, fftbins=True), n_fft)`` in float64 (``core/spectrum.py:240-246``), memoised
+    for hashable window specifications (names, tuples); arrays and callables are evaluated every time."""
+    if isinstance(window, (str, tuple, float, int)):
+        try:
+            return _padded_window_cached(window, int(win_length), int(n_fft))
+        except TypeError:
+            pass
+    return util.pad_center(np.asarray(filters.get_window(window, win_length, fftbins=True), dtype=np.float64), size=n_fft)
 
 
 def _finite_check_covers_input(n, n_fft, hop, center):

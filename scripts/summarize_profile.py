@@ -32,7 +32,7 @@ def short(name):
         m = re.search(r">, (\d+), (\d), (\d)>\(", name)
         return f"stft2_kernel<{modes.get(m.group(2), '?') if m else '?'}>" + tag
     if "stft_kernel" in name:
-        m = re.search(r">, (\d), (\d), (true|false)>\(", name) or re.search(r">, (\d)(?:, \d)?>\(", name)
+        m = re.search(r">, (\d), (\d), (true|false|\d)>\(", name) or re.search(r">, (\d)(?:, \d)?>\(", name)
         return f"stft_kernel<{modes.get(m.group(1) if m else '?', '?')}>" + tag
     return name.split("(")[0][-60:]
 
