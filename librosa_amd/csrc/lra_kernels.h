@@ -882,7 +882,7 @@ template <class Cfg, class RG> LRA_HD void melr_hoist(const StftArgs<typename Cf
     for (int jj = 0; jj < Cfg::R; ++jj) rg.keep[jj] = a.melr_keep[jj * Cfg::TF + tf];
     LRA_UNROLL
     for (int b = 0; b < 2; ++b) {
-        const int m = tf + b * Cfg::TF;
+        const int m = 2 * tf + b;  // bands 2 tf and 2 tf + 1 (see melr_combine)
         LRA_UNROLL
         for (int h = 0; h < 2; ++h) {
             LRA_UNROLL
@@ -907,7 +907,9 @@ template <class Cfg, class RG> LRA_HD void melr_combine(const StftArgs<typename 
     }
     LRA_UNROLL
     for (int b = 0; b < 2; ++b) {
-        const int m = tf + b * TF;
+        // Bands 2 tf and 2 tf + 1: a thread's first band is even and its second odd for EVERY lane, which makes the burst phase
+        // below one value per wave and band slot wherever rows start 0 or 16 bytes into a 32-byte piece (n_frames a multiple of 4).
+        const int m = 2 * tf + b;
         if (m >= a.n_mels) break;
         T part[2];
         LRA_UNROLL
@@ -922,17 +924,35 @@ template <class Cfg, class RG> LRA_HD void melr_combine(const StftArgs<typename 
             part[h] = acc;
         }
         const T v = part[0] + part[1];
-        if (tile == 1) {  // register tile: slot it & 7 of this band's row; burst when the tile is full or the slot ends
+        if (tile == 1) {
+            // Register tile: the last MT frames of this band's row, stored as one burst.  The tile position is tied to the
+            // ABSOLUTE element index in the output (row starts are n_frames elements apart, not a multiple of MT), so that every
+            // full burst is one aligned MT x sizeof(T) = 32-byte piece: unaligned 32-byte bursts each dirtied two HBM sectors
+            // (306 MB written per launch for 169 MB of output).  A slot's first and last bursts are partial.
             constexpr int MT = RG::MELR_TILE;
-            const int s8 = it & (MT - 1);
+#ifndef LRA_MEL_ALIGNED_BURSTS
+#define LRA_MEL_ALIGNED_BURSTS 1
+#endif
+            const long long row0 = ((long long)clip * a.n_mels + m) * a.n_frames;  // element index of this band's row in the output
+            int s8;
+            if (!LRA_MEL_ALIGNED_BURSTS) {
+                s8 = it & (MT - 1);
+            } else if ((a.n_frames & 3) == 0 && Cfg::TF >= 64) {
+                // rows start 0 or 16 bytes into a 32-byte piece, alternating with the band's parity: with bands 2 tf and 2 tf + 1
+                // per thread the phase is (clip, frame, b) only -- scalar, so the tile select and the flush branch stay scalar
+                // (a per-lane phase made the flush run twice per MT frames under half masks: +2.8 % kernel time)
+                s8 = (int)(((long long)clip * a.n_mels * a.n_frames + (long long)b * a.n_frames + frame) & (MT - 1));
+            } else {
+                s8 = (int)((row0 + frame) & (MT - 1));
+            }
             LRA_UNROLL
             for (int k = 0; k < MT; ++k)
                 if (k == s8) rg.mt[b][k] = v;
             if (s8 == MT - 1 || last_of_slot) {
-                T* __restrict__ row = a.Mel + ((long long)clip * a.n_mels + m) * a.n_frames + (frame - s8);
+                T* __restrict__ row = a.Mel + (row0 + frame - s8);
                 LRA_UNROLL
                 for (int k = 0; k < MT; ++k)
-                    if (k <= s8) row[k] = rg.mt[b][k];
+                    if (k <= s8 && k >= s8 - it) row[k] = rg.mt[b][k];  // (only the frames this slot has produced so far)
             }
         } else {
             lds_st<T>(stage, (m * tile + (it % tile)) * (int)sizeof(T), v);

@@ -32,6 +32,11 @@ if what == "istft":
     ctx.stft_exec(pl, y.data_ptr(), batch, n, n, D.data_ptr())
     apply_opts()  # (inverse-only kernel variants: after the forward transform that makes the input)
     fn = lambda: ctx.istft_exec(ip, D.data_ptr(), batch, T * bins, bins, T, ww.data_ptr(), yr.data_ptr(), n, n)
+elif what == "mel":
+    n_mels = int(os.environ.get("PROBE_MELS", "128"))
+    mp = ctx.mel_plan(filters.mel(sr=22050, n_fft=n_fft, n_mels=n_mels))
+    Mo = torch.empty((batch, n_mels, T), dtype=torch.float32, device=dev)
+    fn = lambda: ctx.melspectrogram_exec(pl, mp, y.data_ptr(), batch, n, n, 2.0, Mo.data_ptr())
 else:
     fn = lambda: ctx.stft_exec(pl, y.data_ptr(), batch, n, n, D.data_ptr())
 for _ in range(5): fn()
