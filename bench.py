@@ -340,9 +340,9 @@ def main():
 
         def public_torch():
             fn = lambda: L.feature.melspectrogram(y=y, sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS, check_finite=False)
-            _, e = timed(fn, 10, 3, collective=False)
+            _, e = timed(fn, 10, 3, collective=False, ramp_ms=args.prewarm_ms / 4)
             fn2 = lambda: L.feature.melspectrogram(y=y, sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS)
-            _, e2 = timed(fn2, 10, 3, collective=False)
+            _, e2 = timed(fn2, 10, 3, collective=False, ramp_ms=args.prewarm_ms / 4)
             return {"ms_per_call": e / 10 * 1e3, "frames_per_s": frames_per_step / (e / 10), "ms_per_call_with_finite_check": e2 / 10 * 1e3,
                     "what": "librosa_amd.feature.melspectrogram(y=<device tensor>): argument validation, plan-cache lookup, per-context lock, output allocation + the kernel"}
 
@@ -373,10 +373,10 @@ def main():
         def db_and_mfcc():
             out = {}
             fn = lambda: L.power_to_db(M, ref=np.max)
-            _, e = timed(fn, 10, 3, collective=False)
+            _, e = timed(fn, 10, 3, collective=False, ramp_ms=args.prewarm_ms / 4)
             out["power_to_db"] = {"ms_per_call": e / 10 * 1e3, "GBps": 2 * M.numel() * 4 / (e / 10) / 1e9, "what": "power_to_db(M, ref=np.max) on the mel batch: per-clip max reduction + one elementwise pass (reads M twice, writes once)"}
             fn = lambda: L.feature.mfcc(y=y, sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS, check_finite=False)
-            _, e = timed(fn, 10, 3, collective=False)
+            _, e = timed(fn, 10, 3, collective=False, ramp_ms=args.prewarm_ms / 4)
             out["mfcc"] = {"ms_per_call": e / 10 * 1e3, "frames_per_s": frames_per_step / (e / 10), "what": "feature.mfcc(y=<device tensor>): fused mel kernel + per-clip max + DCT kernel with the dB scaling fused into its read (20 coefficients)"}
             return out
 
@@ -413,7 +413,7 @@ def main():
                     pl = plan if nf == N_FFT else ctx.stft_plan(nf, HOP, w, True, "constant", np.float32)
                     T_nf = ctx.stft_num_frames(pl, n)
                     Dn = D if nf == N_FFT else torch.empty((batch, T_nf, nf // 2 + 1), dtype=torch.complex64, device=device)
-                    _, ev_n = timed(lambda: ctx.stft_exec(pl, yp, batch, n, n, Dn.data_ptr()), max(3, args.steps // 2), 2, collective=False)
+                    _, ev_n = timed(lambda: ctx.stft_exec(pl, yp, batch, n, n, Dn.data_ptr()), max(3, args.steps // 2), 2, collective=False, ramp_ms=args.prewarm_ms / 4)
                     per = ev_n / max(3, args.steps // 2)
                     bytes_n = batch * T_nf * ((nf // 2 + 1) * 8 + HOP * 4)
                     parts[str(nf)] = {"ms": per * 1e3, "GBps": bytes_n / per / 1e9}
