@@ -325,7 +325,7 @@ template <class T> struct StftLaunch {
             }
         }
         // n_fft >= 8192 (f32) with hop = n_fft / {2, 4, 8, 16}: the sample ring lives in registers (RA = 2 + log2 HD)
-        if constexpr ((MODE == OUT_COMPLEX || MODE == OUT_POWER) && sizeof(T) == 4 && Cfg::LOGM >= 12) {
+        if constexpr ((MODE == OUT_COMPLEX || MODE == OUT_POWER) && sizeof(T) == 4 && (Cfg::LOGM >= 12 || Cfg::LOGM == 7 || Cfg::LOGM == 8)) {
             const int hd = use_direct ? regring_hd<Cfg>(a.hop) : 0;
 #define LRA_PICKR(RAM)                                                                                       \
     kern = stft_kernel<Cfg, MODE, POW_TWO, RAM>;                                                            \

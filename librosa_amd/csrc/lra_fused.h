@@ -116,7 +116,7 @@ LRA_CFG_ALIAS(cfg_f64_12, double, 12, 0)
 #define LRA_INST_GROUP_1(S, I) LRA_F32_CFG(S, I, cfg_f32_10v4, 2, 1)
 #define LRA_INST_GROUP_2(S, I) LRA_F32_CFG(S, I, cfg_f32_10v1, 2, 1)
 #define LRA_INST_GROUP_3(S, I) LRA_F32_CFG(S, I, cfg_f32_4, 4, 2) LRA_F32_CFG(S, I, cfg_f32_5, 4, 2) LRA_F32_CFG(S, I, cfg_f32_6, 4, 2)
-#define LRA_INST_GROUP_4(S, I) LRA_F32_CFG(S, I, cfg_f32_7, 4, 2) LRA_F32_CFG(S, I, cfg_f32_8, 4, 2)
+#define LRA_INST_GROUP_4(S, I) LRA_F32_CFG(S, I, cfg_f32_7, 4, 2) LRA_F32_CFG(S, I, cfg_f32_8, 4, 2) LRA_STFT_REGRING(S, cfg_f32_7) LRA_STFT_REGRING(S, cfg_f32_8)
 #define LRA_INST_GROUP_5(S, I) LRA_F32_CFG(S, I, cfg_f32_9, 4, 2) LRA_F32_CFG(S, I, cfg_f32_11, 4, 2)
 #define LRA_INST_GROUP_6(S, I) LRA_F32_CFG(S, I, cfg_f32_12, 4, 2) LRA_F32_CFG(S, I, cfg_f32_13, 4, 2) LRA_STFT_REGRING(S, cfg_f32_12) LRA_STFT_REGRING(S, cfg_f32_13)
 #define LRA_INST_GROUP_7(S, I) LRA_F64_CFG(S, I, cfg_f64_4) LRA_F64_CFG(S, I, cfg_f64_5) LRA_F64_CFG(S, I, cfg_f64_6) LRA_F64_CFG(S, I, cfg_f64_7) LRA_F64_CFG(S, I, cfg_f64_8)

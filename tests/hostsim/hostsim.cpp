@@ -66,10 +66,10 @@ template <class T> struct StftSim {
             bool direct = false;
             if constexpr (MODE == OUT_COMPLEX || MODE == OUT_POWER) direct = !v2 && a.hop >= Cfg::N && !std::getenv("LRA_SIM_NO_DIRECT");
             int rhd = 0;
-            if constexpr ((MODE == OUT_COMPLEX || MODE == OUT_POWER) && sizeof(typename Cfg::real) == 4 && Cfg::LOGM >= 12) rhd = (!v2 && !std::getenv("LRA_SIM_NO_DIRECT")) ? regring_hd<Cfg>(a.hop) : 0;
+            if constexpr ((MODE == OUT_COMPLEX || MODE == OUT_POWER) && sizeof(typename Cfg::real) == 4 && (Cfg::LOGM >= 12 || Cfg::LOGM == 7 || Cfg::LOGM == 8)) rhd = (!v2 && !std::getenv("LRA_SIM_NO_DIRECT")) ? regring_hd<Cfg>(a.hop) : 0;
             if (v2) {
             } else if (rhd) {
-                if constexpr ((MODE == OUT_COMPLEX || MODE == OUT_POWER) && sizeof(typename Cfg::real) == 4 && Cfg::LOGM >= 12) {
+                if constexpr ((MODE == OUT_COMPLEX || MODE == OUT_POWER) && sizeof(typename Cfg::real) == 4 && (Cfg::LOGM >= 12 || Cfg::LOGM == 7 || Cfg::LOGM == 8)) {
                     a.slot_bytes = Cfg::FRAME_BYTES;
                     a.shared_off = Cfg::FPB * a.slot_bytes;
                     st.resize(Cfg::FPB * a.slot_bytes + shared_bytes);
