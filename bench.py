@@ -362,8 +362,13 @@ def main():
             t0 = time.perf_counter()
             Dh = L.stft(yh, n_fft=N_FFT, hop_length=HOP)
             dts = time.perf_counter() - t0
+            L.istft(Dh, hop_length=HOP, length=yh.shape[-1])
+            t0 = time.perf_counter()
+            yi = L.istft(Dh, hop_length=HOP, length=yh.shape[-1])
+            dti = time.perf_counter() - t0
             return {"melspectrogram": {"clips": nb, "ms": dt * 1e3, "frames_per_s": nb * n_frames / dt, "host_bytes": int(yh.nbytes + Mh.nbytes)},
                     "stft": {"clips": nb, "ms": dts * 1e3, "frames_per_s": nb * n_frames / dts, "host_bytes": int(yh.nbytes + Dh.nbytes)},
+                    "istft": {"clips": nb, "ms": dti * 1e3, "frames_per_s": nb * n_frames / dti, "host_bytes": int(yi.nbytes + Dh.nbytes)},
                     "first_calls_ms": first * 1e3,
                     "what": "public drop-in on np.ndarray through the native host pipeline (lra_stft_exec_host: pinned two-slot staging, finite scan fused into the staging copy, "
                             "upload / kernel / download overlapped); steady state, `first_calls_ms` = the two calls that sized the staging buffers; informative only"}

@@ -155,6 +155,12 @@ void lra_istft_plan_destroy(lra_istft_plan* plan);
 int lra_istft_exec(lra_istft_plan* plan, const void* D, int64_t batch, int64_t d_batch_stride, int64_t d_frame_stride, int64_t n_used,
                    const void* wss, void* y, int64_t out_len, int64_t y_stride);
 
+/* Host-buffer form (librosa.istft on np.ndarrays): D_host [batch][n_frames][n_bins] complex, packed, pageable; wss_host
+ * [out_len] reals; y_host [batch] rows of out_len reals, y_stride apart.  Same staged, overlapped transfer as
+ * lra_stft_exec_host. */
+int lra_istft_exec_host(lra_istft_plan* plan, const void* D_host, int64_t batch, int64_t n_frames, int64_t n_used, const void* wss_host, void* y_host,
+                        int64_t out_len, int64_t y_stride);
+
 /* ---- decibel scaling: librosa.power_to_db / amplitude_to_db, librosa/core/spectrum.py:1735-1883, 1946-2038 ---- */
 /* Arrays are [batch][per_item] (the shim flattens the reduced axes -- "auto" = the last two -- into per_item).
  * out_max[b] = max_i |x[b][i]|: the reduction behind ref=np.max and top_db (log_spec.max(axes), :1877-1881). */

@@ -71,6 +71,7 @@ SIGNATURES = {
     "lra_item_absmax_exec": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "lra_to_db_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_int, c_double]),
     "lra_from_db_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_double]),
+    "lra_istft_exec_host": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64]),
     "lra_stft_exec_host": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p, c_int64, POINTER(c_int)]),
     "lra_phase_vocoder_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_int]),
     "lra_griffinlim_init": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int]),
@@ -339,6 +340,9 @@ class Context:
         flag = c_int(0)
         _check(self.lib.lra_stft_exec_host(plan, mel_plan, int(kind), c_void_p(y_host_ptr), batch, n, y_stride, float(power), c_void_p(out_host_ptr), int(out_item_stride), ctypes.byref(flag)))
         return bool(flag.value)
+
+    def istft_exec_host(self, plan, d_host_ptr, batch, n_frames, n_used, wss_host_ptr, y_host_ptr, out_len, y_stride):
+        _check(self.lib.lra_istft_exec_host(plan, c_void_p(d_host_ptr), batch, n_frames, n_used, c_void_p(wss_host_ptr), c_void_p(y_host_ptr), out_len, y_stride))
 
     def mel_apply_exec(self, mel_plan, s_ptr, batch, n_frames, batch_stride, bin_stride, frame_stride, out_ptr):
         _check(self.lib.lra_mel_apply_exec(mel_plan, c_void_p(s_ptr), batch, n_frames, batch_stride, bin_stride, frame_stride, c_void_p(out_ptr)))

@@ -347,6 +347,17 @@ def istft(stft_matrix, *, hop_length=None, win_length=None, n_fft=None, window="
                 d_ptr = sess.scratch(batch * n_total * n_bins * cplx.itemsize)
                 _transpose_batched(ctx, src.data_ptr(), d_ptr, batch, n_bins, n_total, cplx.itemsize)
         else:
+            if Dt.flags["C_CONTIGUOUS"] and Dt.dtype == cplx:
+                # NumPy in, NumPy out with the spectrum already frame-major (what stft returns): the native host pipeline
+                yh = out if (out is not None and out.dtype == real and out.flags["C_CONTIGUOUS"]) else np.empty((batch, int(expected)), dtype=real)
+                ctx.istft_exec_host(plan, Dt.ctypes.data, batch, n_total, n_used, wss.ctypes.data, yh.ctypes.data, int(expected), int(expected))
+                if yh is out:
+                    return out
+                y = _arrays.cast(yh.reshape(shape), out_dtype)
+                if out is not None:
+                    out[...] = y
+                    return out
+                return y
             if Dt.flags["C_CONTIGUOUS"]:
                 d_ptr = sess.input_raw(Dt, cplx)
             else:

@@ -89,6 +89,8 @@ struct HostPipe {
     void* pin_out[2] = {nullptr, nullptr};
     void* dev_in[2] = {nullptr, nullptr};
     void* dev_out[2] = {nullptr, nullptr};
+    void* dev_aux = nullptr;  // small per-call table (the inverse transform's window sum-square)
+    size_t aux_cap = 0;
     hipStream_t s_in = nullptr, s_out = nullptr;
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     void release_buffers(bool in, bool out) {
@@ -109,6 +111,7 @@ struct HostPipe {
     }
     ~HostPipe() {
         release_buffers(true, true);
+        if (dev_aux) (void)hipFree(dev_aux);
         for (int i = 0; i < 2; ++i) {
             if (ev_in[i]) (void)hipEventDestroy(ev_in[i]);
             if (ev_comp[i]) (void)hipEventDestroy(ev_comp[i]);
@@ -1112,6 +1115,60 @@ int pipe_ensure(lra_ctx* ctx, size_t in_bytes, size_t out_bytes) {
     return LRA_OK;
 }
 
+// The staged loop shared by the host-buffer entry points: `batch` items of in_item bytes (in_stride apart in the caller's
+// buffer) go up, launch(dev_in, dev_out, first_item, n_items) runs on the compute stream, out_item bytes per item come down
+// (out_stride apart).  Slot s = stage & 1; events order slot reuse; the host thread copies stage c in while stage c - 1's
+// kernel / download run, then hands stage c - 1 to the caller.
+template <class Launch>
+int host_pipeline(lra_ctx* ctx, int64_t batch, size_t in_item, size_t in_stride, size_t out_item, size_t out_stride, const char* in, char* out, int scan_elem, bool* bad_out, Launch&& launch) {
+    // items per stage: ~pipe_chunk_mb of traffic, at least one item, at least two stages when there are two items
+    int64_t per = (int64_t)(((size_t)ctx->opt_pipe_chunk_mb << 20) / (in_item + out_item));
+    per = std::max<int64_t>(1, std::min<int64_t>(per, (batch + 1) / 2));
+    LRA_TRY(pipe_ensure(ctx, (size_t)per * in_item, (size_t)per * out_item));
+    HostPipe* hp = ctx->pipe;
+    hipStream_t compute = ctx->stream;
+    const int64_t chunks = (batch + per - 1) / per;
+    auto drain = [&](int64_t c) -> int {  // pinned_out[slot of c] -> the caller's buffer
+        const int s = (int)(c & 1);
+        const int64_t b0 = c * per, nb = std::min(per, batch - b0);
+        LRA_HIP(hipEventSynchronize(hp->ev_out[s]));
+        staged_copy(out + (size_t)b0 * out_stride, out_stride, (const char*)hp->pin_out[s], out_item, (size_t)nb, out_item, ctx->opt_pipe_threads);
+        return LRA_OK;
+    };
+    auto body = [&]() -> int {
+        bool bad = false;
+        for (int64_t c = 0; c < chunks; ++c) {
+            const int s = (int)(c & 1);
+            const int64_t b0 = c * per, nb = std::min(per, batch - b0);
+            // slot s: its previous upload (stage c - 2) must have left the pinned buffer before the host overwrites it
+            if (c >= 2) LRA_HIP(hipEventSynchronize(hp->ev_in[s]));
+            if (staged_copy((char*)hp->pin_in[s], in_item, in + (size_t)b0 * in_stride, in_stride, (size_t)nb, in_item, ctx->opt_pipe_threads, scan_elem)) bad = true;
+            if (c >= 2) LRA_HIP(hipStreamWaitEvent(hp->s_in, hp->ev_comp[s], 0));  // dev_in[s] is still read by stage c - 2's kernel
+            LRA_HIP(hipMemcpyAsync(hp->dev_in[s], hp->pin_in[s], (size_t)nb * in_item, hipMemcpyHostToDevice, hp->s_in));
+            LRA_HIP(hipEventRecord(hp->ev_in[s], hp->s_in));
+            LRA_HIP(hipStreamWaitEvent(compute, hp->ev_in[s], 0));
+            if (c >= 2) LRA_HIP(hipStreamWaitEvent(compute, hp->ev_out[s], 0));  // dev_out[s] still being downloaded (stage c - 2)
+            LRA_TRY(launch(hp->dev_in[s], hp->dev_out[s], b0, nb));
+            LRA_HIP(hipEventRecord(hp->ev_comp[s], compute));
+            // the previous stage's download has been running meanwhile: hand it to the caller before its pinned slot is reused
+            if (c >= 1) LRA_TRY(drain(c - 1));
+            LRA_HIP(hipStreamWaitEvent(hp->s_out, hp->ev_comp[s], 0));
+            LRA_HIP(hipMemcpyAsync(hp->pin_out[s], hp->dev_out[s], (size_t)nb * out_item, hipMemcpyDeviceToHost, hp->s_out));
+            LRA_HIP(hipEventRecord(hp->ev_out[s], hp->s_out));
+        }
+        LRA_TRY(drain(chunks - 1));
+        if (bad_out) *bad_out = bad;
+        return LRA_OK;
+    };
+    const int rc = body();
+    if (rc != LRA_OK) {  // leave no work in flight on buffers the next call reuses
+        (void)hipStreamSynchronize(hp->s_in);
+        (void)hipStreamSynchronize(compute);
+        (void)hipStreamSynchronize(hp->s_out);
+    }
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1560,55 +1617,13 @@ int lra_stft_exec_host(lra_stft_plan* p, lra_mel_plan* mel, int kind, const void
     const size_t out_item = kind == 0 ? (size_t)T * n_bins * 2 * es : kind == 1 ? (size_t)T * n_bins * es : (size_t)T * mel->n_mels * es;
     if (out_item_stride <= 0) out_item_stride = (int64_t)(out_item / es);
     if ((size_t)out_item_stride * es < out_item) return fail(LRA_EINVAL, "out_item_stride smaller than one item");
-    // clips per stage: ~pipe_chunk_mb of traffic, at least one clip, at least two stages when there are two clips
-    int64_t per = (int64_t)(((size_t)ctx->opt_pipe_chunk_mb << 20) / (in_item + out_item));
-    per = std::max<int64_t>(1, std::min<int64_t>(per, (batch + 1) / 2));
-    LRA_TRY(pipe_ensure(ctx, (size_t)per * in_item, (size_t)per * out_item));
-    HostPipe* hp = ctx->pipe;
-    hipStream_t compute = ctx->stream;
-    const int64_t chunks = (batch + per - 1) / per;
-    const char* yh = (const char*)y_host;
-    char* oh = (char*)out_host;
-    auto drain = [&](int64_t c) -> int {  // pinned_out[slot of c] -> the caller's buffer
-        const int s = (int)(c & 1);
-        const int64_t b0 = c * per, nb = std::min(per, batch - b0);
-        LRA_HIP(hipEventSynchronize(hp->ev_out[s]));
-        staged_copy(oh + (size_t)b0 * out_item_stride * es, (size_t)out_item_stride * es, (const char*)hp->pin_out[s], out_item, (size_t)nb, out_item, ctx->opt_pipe_threads);
-        return LRA_OK;
-    };
-    int rc = LRA_OK;
+    const int mode = kind == 0 ? OUT_COMPLEX : kind == 1 ? OUT_POWER : OUT_MEL;
     bool bad_samples = false;
-    for (int64_t c = 0; c < chunks && rc == LRA_OK; ++c) {
-        const int s = (int)(c & 1);
-        const int64_t b0 = c * per, nb = std::min(per, batch - b0);
-        // slot s: its previous upload (chunk c - 2) must have left the pinned buffer before the host overwrites it
-        if (c >= 2) LRA_HIP(hipEventSynchronize(hp->ev_in[s]));
-        if (staged_copy((char*)hp->pin_in[s], in_item, yh + (size_t)b0 * y_stride * es, (size_t)y_stride * es, (size_t)nb, in_item, ctx->opt_pipe_threads, nonfinite ? (int)es : 0))
-            bad_samples = true;
-        if (c >= 2) LRA_HIP(hipStreamWaitEvent(hp->s_in, hp->ev_comp[s], 0));  // dev_in[s] is still read by chunk c - 2's kernel
-        LRA_HIP(hipMemcpyAsync(hp->dev_in[s], hp->pin_in[s], (size_t)nb * in_item, hipMemcpyHostToDevice, hp->s_in));
-        LRA_HIP(hipEventRecord(hp->ev_in[s], hp->s_in));
-        LRA_HIP(hipStreamWaitEvent(compute, hp->ev_in[s], 0));
-        if (c >= 2) LRA_HIP(hipStreamWaitEvent(compute, hp->ev_out[s], 0));  // dev_out[s] still being downloaded (chunk c - 2)
-        const int mode = kind == 0 ? OUT_COMPLEX : kind == 1 ? OUT_POWER : OUT_MEL;
-        rc = p->dtype == LRA_F64 ? stft_run<double>(p, mode, hp->dev_in[s], nb, n, n, power, kind == 2 ? mel : nullptr, hp->dev_out[s])
-                                 : stft_run<float>(p, mode, hp->dev_in[s], nb, n, n, power, kind == 2 ? mel : nullptr, hp->dev_out[s]);
-        if (rc != LRA_OK) break;
-        LRA_HIP(hipEventRecord(hp->ev_comp[s], compute));
-        // the previous chunk's download has been running meanwhile: hand it to the caller before its pinned slot is reused
-        if (c >= 1) rc = drain(c - 1);
-        if (rc != LRA_OK) break;
-        LRA_HIP(hipStreamWaitEvent(hp->s_out, hp->ev_comp[s], 0));
-        LRA_HIP(hipMemcpyAsync(hp->pin_out[s], hp->dev_out[s], (size_t)nb * out_item, hipMemcpyDeviceToHost, hp->s_out));
-        LRA_HIP(hipEventRecord(hp->ev_out[s], hp->s_out));
-    }
-    if (rc == LRA_OK) rc = drain(chunks - 1);
-    if (rc != LRA_OK) {  // leave no work in flight on buffers the next call reuses
-        (void)hipStreamSynchronize(hp->s_in);
-        (void)hipStreamSynchronize(compute);
-        (void)hipStreamSynchronize(hp->s_out);
-        return rc;
-    }
+    LRA_TRY(host_pipeline(ctx, batch, in_item, (size_t)y_stride * es, out_item, (size_t)out_item_stride * es, (const char*)y_host, (char*)out_host, nonfinite ? (int)es : 0, &bad_samples,
+                          [&](void* d_in, void* d_out, int64_t, int64_t nb) -> int {
+                              return p->dtype == LRA_F64 ? stft_run<double>(p, mode, d_in, nb, n, n, power, kind == 2 ? mel : nullptr, d_out)
+                                                         : stft_run<float>(p, mode, d_in, nb, n, n, power, kind == 2 ? mel : nullptr, d_out);
+                          }));
     if (nonfinite) *nonfinite = bad_samples ? 1 : 0;
     return LRA_OK;
 }
@@ -1687,6 +1702,35 @@ int lra_istft_exec(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_ba
     if (!p) return fail(LRA_EINVAL, "null plan");
     return p->dtype == LRA_F64 ? istft_run<double>(p, D, batch, d_batch_stride, d_frame_stride, n_used, wss, y, out_len, y_stride)
                                : istft_run<float>(p, D, batch, d_batch_stride, d_frame_stride, n_used, wss, y, out_len, y_stride);
+}
+
+int lra_istft_exec_host(lra_istft_plan* p, const void* D_host, int64_t batch, int64_t n_frames, int64_t n_used, const void* wss_host, void* y_host, int64_t out_len,
+                        int64_t y_stride) {
+    if (!p) return fail(LRA_EINVAL, "null plan");
+    lra_ctx* ctx = p->ctx;
+    LRA_BIND(ctx);
+    if (batch <= 0 || out_len <= 0) return LRA_OK;
+    if (!D_host || !wss_host || !y_host) return fail(LRA_EINVAL, "null data pointer");
+    if (n_frames <= 0 || n_used < 0 || n_used > n_frames) return fail(LRA_EINVAL, "bad frame counts");
+    if (y_stride < out_len) return fail(LRA_EINVAL, "y_stride smaller than out_len");
+    const size_t es = real_bytes(p->dtype);
+    const int64_t n_bins = p->n_fft / 2 + 1;
+    const size_t in_item = (size_t)n_frames * n_bins * 2 * es, out_item = (size_t)out_len * es;
+    LRA_TRY(pipe_ensure(ctx, 16, 16));  // (creates the pipe; host_pipeline sizes the slots)
+    HostPipe* hp = ctx->pipe;
+    if (out_item > hp->aux_cap) {
+        if (hp->dev_aux) (void)hipFree(hp->dev_aux);
+        hp->dev_aux = nullptr;
+        hp->aux_cap = 0;
+        LRA_HIP(hipMalloc(&hp->dev_aux, out_item));
+        hp->aux_cap = out_item;
+    }
+    LRA_HIP(hipMemcpyAsync(hp->dev_aux, wss_host, out_item, hipMemcpyHostToDevice, ctx->stream));
+    return host_pipeline(ctx, batch, in_item, in_item, out_item, (size_t)y_stride * es, (const char*)D_host, (char*)y_host, 0, nullptr,
+                         [&](void* d_in, void* d_out, int64_t, int64_t nb) -> int {
+                             return p->dtype == LRA_F64 ? istft_run<double>(p, d_in, nb, n_frames * n_bins, n_bins, n_used, hp->dev_aux, d_out, out_len, out_len)
+                                                        : istft_run<float>(p, d_in, nb, n_frames * n_bins, n_bins, n_used, hp->dev_aux, d_out, out_len, out_len);
+                         });
 }
 
 // ---- decibel scaling and MFCC (lra_post.h) -------------------------------------------------------------------------

@@ -18,5 +18,10 @@ for mb in (16, 48, 128):
         L.feature.melspectrogram(y=y, sr=22050)
         t0 = time.perf_counter(); M = L.feature.melspectrogram(y=y, sr=22050); tm = time.perf_counter() - t0
         print(f"chunk {mb:4d} MB threads {th:2d}: stft {ts*1e3:7.2f} ms ({(y.nbytes + D.nbytes)/ts/1e9:5.1f} GB/s host bytes)   mel {tm*1e3:7.2f} ms ({(y.nbytes + M.nbytes)/tm/1e9:5.1f} GB/s)", flush=True)
+ctx.set_option("pipe_chunk_mb", 128); ctx.set_option("pipe_threads", 8)
+D = L.stft(y, n_fft=2048, hop_length=512)
+L.istft(D, hop_length=512, length=y.shape[-1])
+t0 = time.perf_counter(); yi = L.istft(D, hop_length=512, length=y.shape[-1]); ti = time.perf_counter() - t0
+print(f"istft numpy end to end: {ti*1e3:.2f} ms ({(D.nbytes + yi.nbytes)/ti/1e9:.1f} GB/s host bytes), max err {np.abs(yi - y).max():.2e}")
 t0 = time.perf_counter(); np.isfinite(y).all(); print("np.isfinite scan", (time.perf_counter() - t0) * 1e3, "ms")
 t0 = time.perf_counter(); y.copy(); print("np copy 169 MB", (time.perf_counter() - t0) * 1e3, "ms")

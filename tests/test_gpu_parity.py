@@ -850,6 +850,13 @@ def test_host_pipeline_chunking_and_finite_scan(L):
             assert _stft_close(S.astype(np.complex64), np.abs(O.stft(y, n_fft=1024, hop_length=256)).astype(np.complex64))
             D64 = L.stft(y64, n_fft=1000, hop_length=250)  # rocFFT path, float64
             assert _stft_close(D64, O.stft(y64, n_fft=1000, hop_length=250))
+            # inverse through lra_istft_exec_host (frame-major spectrum, as stft returns it) == the device-tensor path
+            yi = L.istft(D, hop_length=256, length=y.shape[-1])
+            assert np.array_equal(yi, L.istft(torch.from_numpy(np.ascontiguousarray(D)).cuda(), hop_length=256, length=y.shape[-1]).cpu().numpy())
+            pre = np.zeros_like(yi)
+            assert L.istft(D, hop_length=256, length=y.shape[-1], out=pre) is pre and np.array_equal(pre, yi)
+            assert np.array_equal(L.istft(np.ascontiguousarray(D), hop_length=256, length=y.shape[-1]), yi)  # C-ordered spectrum: device transposition
+            assert np.abs(L.istft(D64, hop_length=250, n_fft=1000, length=y.shape[-1]) - y64).max() <= 1e-9
         ctx.set_option("pipe_chunk_mb", 1)
         for b, i in ((0, 0), (10, 39999), (5, 20001)):
             for v in (np.nan, np.inf, -np.inf):
