@@ -876,7 +876,9 @@ template <class Cfg, int PM> LRA_HD void melr_split_accumulate(const StftArgs<ty
 
 // prologue: per-thread constants of the run-ordered epilogue -> registers (restart factors; the first MELR_PHOIST
 // entries of both piece lists of mel bands tf and tf + TF)
-template <class Cfg, class RG> LRA_HD void melr_hoist(const StftArgs<typename Cfg::real>& a, int tf, RG& rg) {
+// `base`: byte offset added to every hoisted address (the second-generation kernel passes its slot's offset, so that the 16
+// piece reads per frame need no address arithmetic at all)
+template <class Cfg, class RG> LRA_HD void melr_hoist(const StftArgs<typename Cfg::real>& a, int tf, RG& rg, int base = 0) {
     constexpr int PH = RG::MELR_PHOIST;
     LRA_UNROLL
     for (int jj = 0; jj < Cfg::R; ++jj) rg.keep[jj] = a.melr_keep[jj * Cfg::TF + tf];
@@ -886,7 +888,7 @@ template <class Cfg, class RG> LRA_HD void melr_hoist(const StftArgs<typename Cf
         LRA_UNROLL
         for (int h = 0; h < 2; ++h) {
             LRA_UNROLL
-            for (int q = 0; q < PH; ++q) rg.mad[b][h * PH + q] = m < a.n_mels ? a.melr_addr[(h * a.melr_pmax + q) * a.n_mels + m] : a.melr_zero;
+            for (int q = 0; q < PH; ++q) rg.mad[b][h * PH + q] = base + (m < a.n_mels ? a.melr_addr[(h * a.melr_pmax + q) * a.n_mels + m] : a.melr_zero);
         }
     }
 }
@@ -894,8 +896,9 @@ template <class Cfg, class RG> LRA_HD void melr_hoist(const StftArgs<typename Cf
 // phase: mel[m] = sum of the B totals of segment m's pieces + sum of the A totals of segment m+1's pieces
 // (ascending bins).  Bands tf and tf + TF use the hoisted address lists; longer lists / further bands read
 // theirs from the shared table.
+// rs_hoisted: the region the hoisted addresses (rg.mad) are relative to (see melr_hoist's `base`)
 template <class Cfg, class RG> LRA_HD void melr_combine(const StftArgs<typename Cfg::real>& a, int clip, int frame, int tf, int it, int tile, bool last_of_slot, RG& rg, Lds sh,
-                                                        Lds rs, Lds stage) {
+                                                        Lds rs, Lds stage, Lds rs_hoisted) {
     using T = typename Cfg::real;
     constexpr int PH = RG::MELR_PHOIST, TF = Cfg::TF;
     const bool more = a.melr_pmax > PH;  // uniform
@@ -903,7 +906,7 @@ template <class Cfg, class RG> LRA_HD void melr_combine(const StftArgs<typename 
     LRA_UNROLL
     for (int b = 0; b < 2; ++b) {
         LRA_UNROLL
-        for (int q = 0; q < 2 * PH; ++q) x[b][q] = lds_ld<T>(rs, rg.mad[b][q]);
+        for (int q = 0; q < 2 * PH; ++q) x[b][q] = lds_ld<T>(rs_hoisted, rg.mad[b][q]);
     }
     LRA_UNROLL
     for (int b = 0; b < 2; ++b) {
@@ -1111,7 +1114,7 @@ template <class Cfg, int MODE, int PM = POW_TWO, int RAM = 0> LRA_HD void stft_b
                 const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
                 const Lds sl = lds_sub(lds, slot * slot_bytes);
                 if (frame < a.n_frames) {
-                    if constexpr (MODE == OUT_MELR) melr_combine<Cfg>(a, clip, frame, tf, it, tile, it + 1 == iters || frame + 1 >= a.n_frames, LRA_R(rg), lds_sub(lds, a.shared_off), sl, lds_sub(sl, stft_tile_off<Cfg>()));
+                    if constexpr (MODE == OUT_MELR) melr_combine<Cfg>(a, clip, frame, tf, it, tile, it + 1 == iters || frame + 1 >= a.n_frames, LRA_R(rg), lds_sub(lds, a.shared_off), sl, lds_sub(sl, stft_tile_off<Cfg>()), sl);
                     else mel_reduce_slot<Cfg>(a, tf, it % tile, tile, sl, lds_sub(sl, stft_tile_off<Cfg>()));
                 }
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)

@@ -222,6 +222,17 @@ LRA_HD void v2_last_split_store(const StftArgs<typename Cfg::real>& a, int clip,
     C* __restrict__ const D = MODE == OUT_COMPLEX ? a.D + row : nullptr;
     T* __restrict__ const S = MODE == OUT_POWER ? a.S + row : nullptr;
     const int sh = (MODE == OUT_COMPLEX && STAGED) ? v2_row_shift<Cfg>(a, clip, frame) : 0;
+    // OUT_MELR: byte addresses of the power-row slots of this thread's four bin families (k = tf + q s and M - k, with lane 0's
+    // alternative bases), pinned in registers: left to itself hipcc re-derives (k >> 3) * 12 + (k & 7) for each of the 16 stores
+    // (4 VALU instructions each) rather than keep four values live
+    int pwk_lo = 0, pwk_hi = 0, pwm_lo = 0, pwm_hi = 0;
+    if (MODE == OUT_MELR) {
+        pwk_lo = v2_pw_index(tf) * (int)sizeof(T);
+        pwk_hi = v2_pw_index(tfh) * (int)sizeof(T);
+        pwm_lo = v2_pw_index(M - tf) * (int)sizeof(T);
+        pwm_hi = v2_pw_index(M - tfh) * (int)sizeof(T);
+        LRA_KEEP(pwk_lo); LRA_KEEP(pwk_hi); LRA_KEEP(pwm_lo); LRA_KEEP(pwm_hi);
+    }
     LRA_UNROLL
     for (int q = 0; q < r; ++q) {
         // pair slot q.  Lanes 1..: (A[q], B[r-1-q]) = (Z[k], Z[M-k]), k = tf + q s.  Lane 0: q < r/2: (A[q], A[r-q]), k = q s;
@@ -244,9 +255,8 @@ LRA_HD void v2_last_split_store(const StftArgs<typename Cfg::real>& a, int clip,
         if (MODE == OUT_MELR) {
             // power row -> LDS (the frame area is free: every Z is in registers), bin k at float (k / 8) 12 + k % 8: runs of 8
             // bins 48 bytes apart, so that the 16-byte run reads of v2_mel_runs_read hit disjoint banks.  Per-thread bases + immediates.
-            const int tfo = q < r / 2 ? tf : tfh;
-            lds_st<T>(stage, (v2_pw_index(tfo) + 24 * q * (s / 16)) * (int)sizeof(T), spec_power<T, PM>(xk, a.power));
-            lds_st<T>(stage, (v2_pw_index(M - tfo) - 24 * q * (s / 16)) * (int)sizeof(T), spec_power<T, PM>(xm, a.power));
+            lds_st<T>(stage, (q < r / 2 ? pwk_lo : pwk_hi) + 24 * q * (s / 16) * (int)sizeof(T), spec_power<T, PM>(xk, a.power));
+            lds_st<T>(stage, (q < r / 2 ? pwm_lo : pwm_hi) - 24 * q * (s / 16) * (int)sizeof(T), spec_power<T, PM>(xm, a.power));
         } else if (MODE == OUT_COMPLEX && STAGED) {
             // the row goes to LDS in bin order (the frame area is free: every Z is in registers), shifted so that LDS and
             // global addresses agree modulo 16; v2_store_row then writes it as aligned 16-byte pieces.  Of the two bins that
@@ -374,7 +384,7 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
         v2_fill<Cfg, HD>(a, clip, f_first + slot * iters, tf, LRA_R(rg));
         if (MODE == OUT_MELR) {
             melr_tables_to_lds<Cfg>(a, tid, lds_sub(lds, a.shared_off));
-            melr_hoist<Cfg>(a, tf, LRA_R(rg));
+            melr_hoist<Cfg>(a, tf, LRA_R(rg), slot * SB);  // (addresses relative to the workgroup's LDS, not to the slot)
         }
     } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC && MODE != OUT_MELR)  // the shared mel tables need a workgroup barrier, once
     for (int it = 0; it < iters; ++it) {
@@ -425,7 +435,7 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
                 const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
                 const Lds sl = lds_sub(lds, slot * SB);
                 if (frame < a.n_frames)
-                    melr_combine<Cfg>(a, clip, frame, tf, it, 1, it + 1 == iters || frame + 1 >= a.n_frames, LRA_R(rg), lds_sub(lds, a.shared_off), sl, sl);
+                    melr_combine<Cfg>(a, clip, frame, tf, it, 1, it + 1 == iters || frame + 1 >= a.n_frames, LRA_R(rg), lds_sub(lds, a.shared_off), sl, sl, lds);
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         }
     }
