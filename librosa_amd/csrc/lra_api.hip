@@ -508,6 +508,9 @@ template <class T> struct IstftLaunch {
             if constexpr (Cfg::R >= 8) {
                 if (hc == Cfg::R / 8) { kern = istft_kernel<Cfg, Cfg::R / 8>; lds = istft_lds_bytes<Cfg, Cfg::R / 8>(); }
             }
+            if constexpr (Cfg::R >= 16) {
+                if (hc == Cfg::R / 16) { kern = istft_kernel<Cfg, Cfg::R / 16>; lds = istft_lds_bytes<Cfg, Cfg::R / 16>(); }
+            }
         }
         if (lds > 160 * 1024) { too_big = true; return; }
         // Frames per strip.  Each strip replays warm_frames frames before its own, so long strips are cheap;

@@ -109,7 +109,10 @@ LRA_CFG_ALIAS(cfg_f64_12, double, 12, 0)
 #define LRA_STFT_REGRING(S, C) LRA_STFT_REGRING1(S, C, 3) LRA_STFT_REGRING1(S, C, 4) LRA_STFT_REGRING1(S, C, 5) LRA_STFT_REGRING1(S, C, 6)
 #define LRA_STFT_REGRING1(S, C, RA) S(lra::C, 0, 2, RA) S(lra::C, 1, 1, RA) S(lra::C, 1, 2, RA) S(lra::C, 1, 3, RA)
 // f32: both ring addressings; the overlap-add row counts HC = R/2, R/4, R/8 (8, 4, 2 at 16 points per thread)
-#define LRA_F32_CFG(S, I, C, HCQ, HCE) LRA_STFT_SET(S, C, 0) LRA_STFT_SET(S, C, 1) LRA_STFT_DIRECT(S, C) I(lra::C, 0) I(lra::C, (2 * HCQ)) I(lra::C, HCQ) I(lra::C, HCE)
+// (HCS: rows per hop at hop = n_fft / 16 -- 1 for the 16-point configurations, which are the only ones with that instance)
+#define LRA_F32_CFG(S, I, C, HCQ, HCE) LRA_STFT_SET(S, C, 0) LRA_STFT_SET(S, C, 1) LRA_STFT_DIRECT(S, C) I(lra::C, 0) I(lra::C, (2 * HCQ)) I(lra::C, HCQ) I(lra::C, HCE) LRA_ISTFT_HCS_##HCE(I, C)
+#define LRA_ISTFT_HCS_2(I, C) I(lra::C, 1)
+#define LRA_ISTFT_HCS_1(I, C)
 #define LRA_F64_CFG(S, I, C) LRA_STFT_SET(S, C, 0) LRA_STFT_DIRECT(S, C) I(lra::C, 0)
 
 #define LRA_INST_GROUP_0(S, I) LRA_F32_CFG(S, I, cfg_f32_10, 4, 2)
@@ -128,7 +131,7 @@ LRA_CFG_ALIAS(cfg_f64_12, double, 12, 0)
 #define LRA_STFT2_MEL(T, C) LRA_STFT2_MEL_HD(T, C, 1) LRA_STFT2_MEL_HD(T, C, 2) LRA_STFT2_MEL_HD(T, C, 4) LRA_STFT2_MEL_HD(T, C, 8)
 #define LRA_INST2_GROUP_9(T, I) LRA_STFT2_CFG(T, cfg_f32_10) LRA_STFT2_MEL(T, cfg_f32_10_mel)
 // ... and the inverse kernel on the ascending-radix configuration (Hermitian step fused into the first pass)
-#define LRA_INST2_GROUP_10(T, I) LRA_STFT2_CFG(T, cfg_f32_9) LRA_STFT2_CFG(T, cfg_f32_11) I(lra::cfg_f32_10r, 8) I(lra::cfg_f32_10r, 4) I(lra::cfg_f32_10r, 2)
+#define LRA_INST2_GROUP_10(T, I) LRA_STFT2_CFG(T, cfg_f32_9) LRA_STFT2_CFG(T, cfg_f32_11) I(lra::cfg_f32_10r, 8) I(lra::cfg_f32_10r, 4) I(lra::cfg_f32_10r, 2) I(lra::cfg_f32_10r, 1)
 #define LRA_INST2_ALL(T, I) LRA_INST2_GROUP_9(T, I) LRA_INST2_GROUP_10(T, I)
 #define LRA_INST_NUM_GROUPS 11
 #define LRA_INST_ALL(S, I)                                                                                                   \

@@ -165,6 +165,9 @@ template <class T> struct IstftSim {
                 if (!ran && hc == Cfg::R / 8) { st.resize(istft_lds_bytes<Cfg, Cfg::R / 8>()); istft_block<Cfg, Cfg::R / 8>(a, (int)blk, lds); ran = true; }
             }
             if (!ran) st.resize(istft_lds_bytes<Cfg, 0>());
+            if constexpr (sizeof(typename Cfg::real) == 4 && Cfg::R >= 16) {
+                if (!ran && hc == Cfg::R / 16) { st.resize(istft_lds_bytes<Cfg, Cfg::R / 16>()); istft_block<Cfg, Cfg::R / 16>(a, (int)blk, lds); ran = true; }
+            }
             if (!ran) istft_block<Cfg, 0>(a, (int)blk, lds);
             diag[8] = rows;
             diag[0] += st.races; diag[1] += st.uninit;

@@ -1011,3 +1011,18 @@ def test_register_ring_large_frames(L, n_fft, hop, center, pad_mode):
         assert _stft_close(L.stft(y, n_fft=n_fft, hop_length=hop, center=center, pad_mode=pad_mode), ref)
     finally:
         ctx.set_option("direct", 1)
+
+
+@pytest.mark.parametrize("n_fft,hop", [(8192, 512), (2048, 128), (4096, 256), (16384, 1024), (256, 16)])
+def test_istft_sixteenth_hop(L, n_fft, hop):
+    """hop = n_fft / 16 takes the row-aligned overlap-add with one row per hop (n_fft = 8192 at hop 512 is the inverse of
+    BASELINE configs[4]'s widest leg); round trip and oracle comparison, with and without `length`."""
+    rng = np.random.default_rng(n_fft + hop)
+    y = rng.standard_normal((2, 100003)).astype(np.float32)
+    D = O.stft(y, n_fft=n_fft, hop_length=hop)
+    for length in (None, y.shape[-1], 90000):
+        ref = O.istft(D, hop_length=hop, length=length)
+        got = L.istft(D, hop_length=hop, length=length)
+        wss = _wss_for(dict(n_fft=n_fft, hop_length=hop), D.shape[-1], ref.shape[-1], length, np.float32)
+        assert got.shape == ref.shape and _istft_close(got, ref, wss)
+    assert np.abs(L.istft(D, hop_length=hop, length=y.shape[-1]) - y).max() <= 2e-5

@@ -203,6 +203,9 @@ def _istft_inputs(y, n_fft, hop, center, length, window="hann", win_length=None)
         (2048, 512, 9000, False, None, np.float32, 1, "hann", None, 5),
         (2048, 1024, 20000, True, "n", np.float32, 3, "hann", None, 5),
         (2048, 256, 9000, True, 7000, np.float32, 4, "hann", 1200, 5),
+        (2048, 128, 9000, True, "n", np.float32, 3, "hann", None, 0),    # hop = n_fft/16: row-aligned overlap-add with one row per hop
+        (8192, 512, 30000, True, None, np.float32, 2, "hann", None, 0),  # ... four waves per frame
+        (2048, 128, 9000, False, 7000, np.float32, 5, "blackmanharris", None, 5),
         (2048, 1024, 20000, True, "n", np.float32, 3, "hann", None, 0),  # hop = n_fft/2: row-aligned overlap-add with HC = R/2
         (1024, 512, 9000, True, "n", np.float32, 2, "hann", None, 0),
         (1024, 256, 9000, False, None, np.float32, 2, "hann", None, 0),
