@@ -133,7 +133,7 @@ namespace {
 // clips x frames of the call; so that variable-length inputs neither create a plan per call nor grow device memory
 // without bound, a call runs as full chunks of kFftChunk transforms (one canonical plan) plus one remainder, and the
 // cache keeps at most kMaxFftPlans plans (least recently used evicted and destroyed).
-constexpr long long kFftChunk = 8192;
+constexpr long long kFftChunk = 65536;  // (8192 made a 256-clip call 129 rocfft_execute launches: launch-bound)
 constexpr size_t kMaxFftPlans = 8;
 struct FftPlanCache {
     std::vector<std::pair<long long, rocfft_plan>> plans;  // most recently used last; key = number of transforms
