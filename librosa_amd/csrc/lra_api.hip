@@ -595,6 +595,29 @@ template <class T> __global__ void power_kernel(const cx<T>* __restrict__ D, T* 
     else S[i] = spec_power<T, POW_GENERAL>(D[i], power);
 }
 
+// General mel path: S^T[b][f][t] = |D[b][t][f]|^power through a 32 x 33 LDS tile, so that both the read of D (lanes along f)
+// and mel_apply_kernel's reads of S (lanes along t) are coalesced; with S in D's [t][f] layout the band sums read one
+// element per 4 (bins + 1) bytes.
+template <class T> __global__ void power_transpose_kernel(const cx<T>* __restrict__ D, T* __restrict__ St, long long n_frames, long long bins, int power_mode, T power) {
+    __shared__ T tile[32][33];
+    const long long b = blockIdx.z;
+    const long long t0 = (long long)blockIdx.y * 32, f0 = (long long)blockIdx.x * 32;
+    const cx<T>* __restrict__ d = D + b * n_frames * bins;
+    T* __restrict__ s = St + b * n_frames * bins;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const long long t = t0 + j, f = f0 + threadIdx.x;
+        if (t < n_frames && f < bins) {
+            const cx<T> z = d[t * bins + f];
+            tile[j][threadIdx.x] = power_mode == POW_TWO ? spec_power<T, POW_TWO>(z, power) : power_mode == POW_ONE ? spec_power<T, POW_ONE>(z, power) : spec_power<T, POW_GENERAL>(z, power);
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const long long f = f0 + j, t = t0 + threadIdx.x;
+        if (f < bins && t < n_frames) s[f * n_frames + t] = tile[threadIdx.x][j];
+    }
+}
+
 // M[b][m][t] = sum_i val[off[m]+i] * S[b*bs + (c0[m]+i)*fs_bin + t*fs_frame]
 template <class T>
 __global__ void mel_apply_kernel(const T* __restrict__ S, long long batch_stride, long long bin_stride, long long frame_stride, long long n_frames,
@@ -884,13 +907,19 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
         const long long clips = std::min<long long>(group, batch - c0);
         LRA_TRY(stft_general<T>(p, (const T*)y + c0 * y_stride, clips, n, y_stride, n_frames, Dtmp));
         const long long count = clips * n_frames * bins;
-        T* Sdst = mode == OUT_POWER ? (T*)out + c0 * n_frames * bins : Stmp;
-        hipLaunchKernelGGL(power_kernel<T>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, Dtmp, Sdst, count, power_mode_of(power), (T)power);
-        LRA_HIP(hipGetLastError());
-        if (mode == OUT_MEL) {
+        if (mode == OUT_POWER) {
+            hipLaunchKernelGGL(power_kernel<T>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, Dtmp, (T*)out + c0 * n_frames * bins, count, power_mode_of(power), (T)power);
+            LRA_HIP(hipGetLastError());
+        } else {  // OUT_MEL: |D|^p transposed to [clip][bin][frame], then the banded product with lanes along the frames
+            for (long long cz = 0; cz < clips; cz += 65535) {
+                const long long nz = std::min<long long>(65535, clips - cz);
+                hipLaunchKernelGGL(power_transpose_kernel<T>, dim3((unsigned)((bins + 31) / 32), (unsigned)((n_frames + 31) / 32), (unsigned)nz), dim3(32, 8), 0, ctx->stream,
+                                   Dtmp + cz * n_frames * bins, Stmp + cz * n_frames * bins, (long long)n_frames, (long long)bins, power_mode_of(power), (T)power);
+            }
+            LRA_HIP(hipGetLastError());
             const long long tblocks = (n_frames + 255) / 256;
-            hipLaunchKernelGGL(mel_apply_kernel<T>, dim3((unsigned)(tblocks * mel->n_mels * clips)), dim3(256), 0, ctx->stream, Stmp, n_frames * bins, 1LL,
-                               (long long)bins, n_frames, mel->n_mels, mel->d_c0, mel->d_len, mel->d_off, (const T*)mel->d_val,
+            hipLaunchKernelGGL(mel_apply_kernel<T>, dim3((unsigned)(tblocks * mel->n_mels * clips)), dim3(256), 0, ctx->stream, Stmp, n_frames * bins, (long long)n_frames,
+                               1LL, n_frames, mel->n_mels, mel->d_c0, mel->d_len, mel->d_off, (const T*)mel->d_val,
                                (T*)out + c0 * mel->n_mels * n_frames);
             LRA_HIP(hipGetLastError());
         }
