@@ -200,6 +200,20 @@ int lra_griffinlim_init(lra_ctx* ctx, const void* u, const void* S, void* angles
  * two input frames around each time (:1491-1507); magnitude: scipy interp1d(kind="linear") of |D| (:1507-1515). */
 int lra_phase_vocoder_exec(lra_ctx* ctx, const void* D, void* out, int64_t batch, int64_t n_frames, int n_bins, const double* t_out_host, int64_t n_out, int dtype);
 
+/* ---- multi-GPU: the trivial gather of the sharded result (the reference has no counterpart) ----------------- */
+/* One process per GPU.  Clips shard by contiguous ranges with no collective on the data path; these entry points gather the
+ * per-rank results over RCCL (xGMI) for hosts that do not use torch.distributed.  RCCL is bound at run time (dlopen): the
+ * library does not depend on it.  Rank 0 obtains an id (LRA_COMM_ID_BYTES bytes) and the host program hands it to the other
+ * ranks (MPI, a file, a socket); every rank then creates its communicator on its own context (= device + stream). */
+#define LRA_COMM_ID_BYTES 128
+typedef struct lra_comm lra_comm;
+int lra_comm_unique_id(void* id_out);
+int lra_comm_init(lra_ctx* ctx, int rank, int n_ranks, const void* id, lra_comm** out);
+/* recv_dev[r * bytes_per_rank ...] = rank r's send_dev[0 .. bytes_per_rank), enqueued on the context's stream (stream-ordered
+ * after the kernels that produced send_dev); equal shard sizes -- the shim gathers unequal shards piecewise. */
+int lra_comm_allgather(lra_comm* comm, const void* send_dev, void* recv_dev, size_t bytes_per_rank);
+void lra_comm_destroy(lra_comm* comm);
+
 /* ---- layout helper: dst[b][c][r] = src[b][r][c], elem_bytes in {4, 8, 16} ------------------ */
 int lra_transpose(lra_ctx* ctx, const void* src, void* dst, int64_t batch, int64_t rows, int64_t cols, int elem_bytes);
 

@@ -73,6 +73,10 @@ SIGNATURES = {
     "lra_from_db_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_double]),
     "lra_istft_exec_host": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64]),
     "lra_stft_exec_host": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p, c_int64, POINTER(c_int)]),
+    "lra_comm_unique_id": (c_int, [c_void_p]),
+    "lra_comm_init": (c_int, [c_void_p, c_int, c_int, c_void_p, POINTER(c_void_p)]),
+    "lra_comm_allgather": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    "lra_comm_destroy": (None, [c_void_p]),
     "lra_phase_vocoder_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_int]),
     "lra_griffinlim_init": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int]),
     "lra_griffinlim_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_double, c_double, c_int]),
@@ -385,6 +389,42 @@ class Context:
 
 _contexts = {}
 _ctx_lock = threading.Lock()
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """RCCL unique id for a new communicator (rank 0 calls this; the host program distributes the bytes)."""
+    buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+    _check(load_library().lra_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """Native RCCL communicator of one rank (``include/librosa_amd.h``: ``lra_comm_*``), bound to a context's device and stream."""
+
+    def __init__(self, ctx, rank, n_ranks, unique_id: bytes):
+        self.ctx, self.rank, self.n_ranks = ctx, int(rank), int(n_ranks)
+        self.lib = ctx.lib
+        h = c_void_p()
+        buf = ctypes.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        _check(self.lib.lra_comm_init(ctx.handle, self.rank, self.n_ranks, buf, byref(h)))
+        self.handle = h
+
+    def allgather(self, send_ptr, recv_ptr, bytes_per_rank):
+        _check(self.lib.lra_comm_allgather(self.handle, c_void_p(send_ptr), c_void_p(recv_ptr), int(bytes_per_rank)))
+
+    def close(self):
+        if self.handle:
+            self.lib.lra_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def get_context(device=None):

@@ -7,6 +7,7 @@
 //   * any other n_fft (the reference's tests use 501, 755, 1023, 1025, 2049): a framing kernel +
 //     rocFFT batched R2C/C2R + small elementwise kernels.
 // No CPU fallback exists: without a device every entry point that touches data fails.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rocfft/rocfft.h>
 
@@ -1203,6 +1204,54 @@ int host_pipeline(lra_ctx* ctx, int64_t batch, size_t in_item, size_t in_stride,
 
 }  // namespace
 
+// ---- RCCL, bound at run time (the library does not link it: single-GPU users never load it) --------------------------------
+struct lra_comm {
+    lra_ctx* ctx = nullptr;
+    void* nccl = nullptr;  // ncclComm_t
+    int rank = 0, n_ranks = 1;
+};
+
+namespace {
+
+struct RcclApi {
+    struct Id { char b[128]; };  // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128), passed by value
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, Id, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+
+RcclApi* rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // a copy the process has already loaded (PyTorch bundles its own) wins: two RCCLs in one process do not share state
+        for (const char* name : {"librccl.so", "librccl.so.1"}) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+            if (api.lib) break;
+        }
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            if (api.lib) break;
+            api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        }
+        if (!api.lib) return;
+        api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+        api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
+        api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+        api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+    });
+    return (api.lib && api.GetUniqueId && api.CommInitRank && api.AllGather && api.CommDestroy) ? &api : nullptr;
+}
+
+int rccl_fail(RcclApi* api, const char* what, int rc) {
+    return fail(LRA_EHIP, std::string(what) + ": " + (api && api->GetErrorString ? api->GetErrorString(rc) : "RCCL error") + " (" + std::to_string(rc) + ")");
+}
+
+}  // namespace
+
 extern "C" {
 
 const char* lra_last_error(void) { return g_err.c_str(); }
@@ -1900,6 +1949,54 @@ int lra_debug_phase_ticks(lra_ctx* ctx, unsigned long long* out16) {
 #endif
 
 // ---- transpose ----------------------------------------------------------------------------------
+// ---- multi-GPU: gather of the sharded result over RCCL / xGMI ---------------------------------------------------
+int lra_comm_unique_id(void* id_out) {
+    if (!id_out) return fail(LRA_EINVAL, "null id buffer");
+    RcclApi* api = rccl_api();
+    if (!api) return fail(LRA_ENODEV, "RCCL (librccl.so) is not available");
+    const int rc = api->GetUniqueId(id_out);
+    return rc == 0 ? LRA_OK : rccl_fail(api, "ncclGetUniqueId", rc);
+}
+
+int lra_comm_init(lra_ctx* ctx, int rank, int n_ranks, const void* id, lra_comm** out) {
+    LRA_BIND(ctx);
+    if (!out || !id) return fail(LRA_EINVAL, "null argument");
+    *out = nullptr;
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(LRA_EINVAL, "bad rank / n_ranks");
+    RcclApi* api = rccl_api();
+    if (!api) return fail(LRA_ENODEV, "RCCL (librccl.so) is not available");
+    RcclApi::Id uid;
+    std::memcpy(uid.b, id, sizeof(uid.b));
+    void* comm = nullptr;
+    const int rc = api->CommInitRank(&comm, n_ranks, uid, rank);  // the communicator binds to the calling thread's current device = ctx's (LRA_BIND)
+    if (rc != 0) return rccl_fail(api, "ncclCommInitRank", rc);
+    lra_comm* c = new lra_comm();
+    c->ctx = ctx;
+    c->nccl = comm;
+    c->rank = rank;
+    c->n_ranks = n_ranks;
+    *out = c;
+    return LRA_OK;
+}
+
+int lra_comm_allgather(lra_comm* comm, const void* send_dev, void* recv_dev, size_t bytes_per_rank) {
+    if (!comm) return fail(LRA_EINVAL, "null communicator");
+    LRA_BIND(comm->ctx);
+    if (!bytes_per_rank) return LRA_OK;
+    if (!send_dev || !recv_dev) return fail(LRA_EINVAL, "null data pointer");
+    RcclApi* api = rccl_api();
+    if (!api) return fail(LRA_ENODEV, "RCCL (librccl.so) is not available");
+    const int rc = api->AllGather(send_dev, recv_dev, bytes_per_rank, /* ncclInt8 */ 0, comm->nccl, comm->ctx->stream);
+    return rc == 0 ? LRA_OK : rccl_fail(api, "ncclAllGather", rc);
+}
+
+void lra_comm_destroy(lra_comm* comm) {
+    if (!comm) return;
+    RcclApi* api = rccl_api();
+    if (api && comm->nccl) (void)api->CommDestroy(comm->nccl);
+    delete comm;
+}
+
 int lra_transpose(lra_ctx* ctx, const void* src, void* dst, int64_t batch, int64_t rows, int64_t cols, int elem_bytes) {
     LRA_BIND(ctx);
     if (batch <= 0 || rows <= 0 || cols <= 0) return LRA_OK;

@@ -106,3 +106,29 @@ def gather_shards(local, n_items: int, group=None, n_chunks: int = 1):
     for lo, hi in chunk_ranges(biggest, n_chunks):
         g.push(lo, hi, local[lo : min(hi, mine)])
     return g.wait()
+
+
+class NativeGather:
+    """The same gather through the C ABI's own RCCL binding (``lra_comm_*``, ``include/librosa_amd.h``) for host programs that
+    do not run ``torch.distributed``: the caller distributes ``unique_id`` (from ``librosa_amd._native.comm_unique_id()`` on rank 0)
+    by whatever channel it has; ``all_gather(local)`` enqueues ONE ncclAllGather on the context's stream -- stream-ordered after
+    the kernels that produced ``local`` -- and returns the full ``(world * clips, ...)`` device tensor.  Equal shards only."""
+
+    def __init__(self, ctx, rank: int, world: int, unique_id: bytes):
+        from . import _native
+
+        self.ctx = ctx
+        self.world = int(world)
+        self.comm = _native.Comm(ctx, rank, world, unique_id)
+
+    def all_gather(self, local):
+        import torch
+
+        local = local.contiguous()
+        full = torch.empty((self.world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        self.ctx.set_stream(torch.cuda.current_stream(local.device).cuda_stream)
+        self.comm.allgather(local.data_ptr(), full.data_ptr(), local.numel() * local.element_size())
+        return full
+
+    def close(self):
+        self.comm.close()

@@ -1026,3 +1026,25 @@ def test_istft_sixteenth_hop(L, n_fft, hop):
         wss = _wss_for(dict(n_fft=n_fft, hop_length=hop), D.shape[-1], ref.shape[-1], length, np.float32)
         assert got.shape == ref.shape and _istft_close(got, ref, wss)
     assert np.abs(L.istft(D, hop_length=hop, length=y.shape[-1]) - y).max() <= 2e-5
+
+
+def test_native_rccl_communicator(L):
+    """lra_comm_* (RCCL bound at run time through the C ABI) at world size 1 -- all a one-GPU box can run: id, communicator on
+    the context's device, an all-gather enqueued behind the kernel that produced its input."""
+    import torch
+
+    from librosa_amd import _native
+    from librosa_amd.distributed import NativeGather
+
+    uid = _native.comm_unique_id()
+    assert len(uid) == _native.COMM_ID_BYTES and any(uid)
+    ctx = L.get_context(0)
+    g = NativeGather(ctx, 0, 1, uid)
+    y = torch.from_numpy(O.config_input(3, n=22050)).cuda()
+    M = L.feature.melspectrogram(y=y, sr=22050)
+    full = g.all_gather(M)
+    torch.cuda.synchronize()
+    assert full.shape == M.shape and torch.equal(full, M)
+    g.close()
+    with pytest.raises(L.ParameterError):
+        _native.Comm(ctx, 2, 1, uid)  # rank outside the world
