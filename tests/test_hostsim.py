@@ -253,3 +253,17 @@ def test_pad_index_matches_numpy():
             assert np.array_equal(got, ref), (n, mode)
         got = [lib.hostsim_pad_index(g, n, 0) for g in (-3, -1, n, n + 4)]
         assert got == [-1, -1, -1, -1]
+
+
+@pytest.mark.parametrize("n_fft,hop,power,iters,n", [(512, 512, 2.0, 3, 9000), (512, 128, 1.0, 5, 5000), (8192, 512, 1.7, 2, 30000), (256, 300, 2.0, 4, 5000), (8192, 8192, 1.0, 2, 50000)])
+def test_power_epilogue_without_lds_ring(n_fft, hop, power, iters, n, monkeypatch):
+    """|X|^power through the ring-less framings of the first-generation body: direct framing (hop >= n_fft) and the register ring
+    (hop = n_fft / 2 .. 16 at n_fft = 256, 512 and >= 8192)."""
+    monkeypatch.setenv("LRA_SIM_NO_V2", "1")
+    rng = np.random.default_rng(n_fft + hop + n)
+    y = rng.standard_normal((2, n)).astype(np.float32)
+    win = O.get_window("hann", n_fft)
+    S, d = H.stft(y, n_fft, hop, win, mode=1, power=power, iters_per_wg=iters)
+    _check_diag(d)
+    ref = np.moveaxis(np.abs(O.stft(y, n_fft=n_fft, hop_length=hop)) ** power, -1, -2)
+    assert S.shape == ref.shape and np.abs(S - ref).max() <= 4e-6 * ref.max()
