@@ -174,8 +174,9 @@ int lra_to_db_exec(lra_ctx* ctx, const void* x, void* out, int64_t batch, int64_
 int lra_from_db_exec(lra_ctx* ctx, const void* x, void* out, int64_t count, int dtype, int amplitude, double ref);
 
 /* ---- MFCC: librosa.feature.mfcc, librosa/feature/spectral.py:1843-2019 --------------------------------------------- */
-/* out[b][k][t] = lift[k] * sum_m basis[k][m] * f(S[b][m][t]), k < n_out.  basis (device): the rows of
- * scipy.fft.dct(eye(n_in), axis=0, type, norm) (:2005), n_out rows rounded up to a multiple of 128 with zero rows;
+/* out[b][k][t] = lift[k] * sum_m basis[m][k] * f(S[b][m][t]), k < n_out.  basis (device): band-major [n_in][ldc],
+ * basis[m][k] = scipy.fft.dct(eye(n_in), axis=0, type, norm)[k][m] (:2005), ldc = n_out rounded up to a multiple of 128, zeros
+ * beyond n_out;
  * lift (device, [n_out]): 1 + (lifter/2) sin(pi (k+1) / lifter) or ones (:2008-2015).  fuse_db != 0: f is the decibel
  * scaling of lra_to_db_exec (power domain), so that mfcc(y=...) reads the mel power spectrogram once (:2001). */
 int lra_dct_exec(lra_ctx* ctx, const void* S, void* out, int64_t batch, int n_in, int n_out, int64_t n_frames, int dtype, const void* basis, const void* lift,

@@ -1046,12 +1046,13 @@ int dct_run(lra_ctx* ctx, const T* S, T* out, long long batch, int n_in, int n_o
     const long long tblocks = (n_frames + 255) / 256;
     const long long grid = tblocks * batch;
     if (grid > 0x7fffffffLL) return fail(LRA_EINVAL, "grid too large");
-    // the basis arrives padded to whole groups of 128 rows of zeros beyond n_out (lra_dct_exec's contract); every group is one launch
+    // the basis arrives band-major, its coefficient axis padded with zeros to whole groups of 128 (lra_dct_exec's contract); every group is one launch
+    const int ldc = (n_out + 127) / 128 * 128;  // the band-major basis [n_in][ldc] (lra_dct_exec's contract)
     for (int k0 = 0; k0 < n_out; k0 += 128) {
         const int rows = n_out - k0 < 128 ? n_out - k0 : 128;
-        const T* Ck = C + (size_t)k0 * n_in;
+        const T* Ck = C + k0;
         T* ok = out + (size_t)k0 * n_frames;
-#define LRA_DCT(N) hipLaunchKernelGGL((dct_rows_kernel<T, N, DB>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, S, ok, n_frames, n_in, rows, n_out, Ck, lift + k0, d)
+#define LRA_DCT(N) hipLaunchKernelGGL((dct_rows_kernel<T, N, DB>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, S, ok, n_frames, n_in, rows, n_out, Ck, ldc, lift + k0, d)
         if (rows <= 16) LRA_DCT(16);
         else if (rows <= 32) LRA_DCT(32);
         else if (rows <= 64) LRA_DCT(64);

@@ -105,10 +105,13 @@ template <class T, bool AMP> __global__ __launch_bounds__(256) void from_db_kern
 // out[b][k][t] = lift[k] * sum_m C[k][m] * f(S[b][m][t]),  k < n_out <= NOUT,  f = identity or the decibel scaling above
 // (DB: the fused mfcc(y=...) path reads the mel POWER spectrogram once and never materialises power_to_db's output).
 // One thread per frame t (lanes along the contiguous axis: every S row access is a 256-byte coalesced wave load), NOUT
-// accumulators in registers, the basis C through uniform (scalar-cache) loads: 2 n_in NOUT flops per 4 n_in bytes read.
+// accumulators in registers, the basis C through uniform (scalar-cache) loads: 2 n_in NOUT flops per 4 n_in bytes read.  The
+// basis is stored band-major ([n_in][ldc]) so that the NOUT coefficients of one band are contiguous (s_load_dwordx8/x16);
+// coefficient-major storage made every one of them its own scalar load.
 template <class T, int NOUT, bool DB>
 __global__ __launch_bounds__(256) void dct_rows_kernel(const T* __restrict__ S, T* __restrict__ out, long long n_frames, int n_in, int n_out /* rows of this launch */, int out_rows /* rows of `out` per item */,
-                                                       const T* __restrict__ C /* [NOUT][n_in], zero rows beyond n_out */, const T* __restrict__ lift /* [n_out] */, DbArgs<T> d) {
+                                                       const T* __restrict__ C /* [n_in][ldc]: column k of row m = basis[k][m], zero columns beyond n_out */, int ldc,
+                                                       const T* __restrict__ lift /* [n_out] */, DbArgs<T> d) {
     const long long tblocks = (n_frames + 255) / 256;
     const long long b = blockIdx.x / tblocks;
     const long long t = (blockIdx.x % tblocks) * 256 + threadIdx.x;
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(256) void dct_rows_kernel(const T* __restrict__ S, 
             v = db > floor_db ? db : floor_db;
         }
 #pragma unroll
-        for (int k = 0; k < NOUT; ++k) acc[k] += C[k * n_in + m] * v;
+        for (int k = 0; k < NOUT; ++k) acc[k] += C[(long long)m * ldc + k] * v;  // NOUT contiguous coefficients per band: wide scalar loads
     }
     T* __restrict__ o = out + b * (long long)out_rows * n_frames + t;
 #pragma unroll

@@ -37,7 +37,7 @@ def melspectrogram(*, y=None, sr=22050, S=None, n_fft=2048, hop_length=512, win_
 
 def _dct_tables(n_in, n_mfcc, dct_type, norm, lifter, real):
     """Host tables of the MFCC contraction: the first ``n_mfcc`` rows of scipy's DCT applied to the identity (float64 recipe,
-    rounded once to the compute dtype; zero rows up to a multiple of 128, the C ABI's contract) and the lifter weights
+    rounded once to the compute dtype; stored band-major with the coefficient axis zero-padded to a multiple of 128, the C ABI's contract) and the lifter weights
     ``1 + (lifter / 2) sin(pi (k + 1) / lifter)`` in the result dtype (``feature/spectral.py:2005-2015``)."""
     import scipy.fft
 
@@ -46,8 +46,8 @@ def _dct_tables(n_in, n_mfcc, dct_type, norm, lifter, real):
     full = scipy.fft.dct(np.eye(n_in, dtype=np.float64), axis=0, type=dct_type, norm=norm)
     n_out = min(int(n_mfcc), n_in)
     rows = -(-n_out // 128) * 128
-    basis = np.zeros((rows, n_in), dtype=real)
-    basis[:n_out] = full[:n_out]
+    basis = np.zeros((n_in, rows), dtype=real)  # band-major: the coefficients of one band are contiguous (the kernel's scalar loads)
+    basis[:, :n_out] = full[:n_out].T
     if lifter > 0:
         if n_out != int(n_mfcc):
             raise ParameterError(f"n_mfcc={n_mfcc} exceeds the {n_in} bands of the input: the lifter cannot be applied")
