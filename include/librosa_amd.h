@@ -201,6 +201,22 @@ int lra_griffinlim_init(lra_ctx* ctx, const void* u, const void* S, void* angles
  * two input frames around each time (:1491-1507); magnitude: scipy interp1d(kind="linear") of |D| (:1507-1515). */
 int lra_phase_vocoder_exec(lra_ctx* ctx, const void* D, void* out, int64_t batch, int64_t n_frames, int n_bins, const double* t_out_host, int64_t n_out, int dtype);
 
+/* ---- PCEN: librosa.pcen, librosa/core/spectrum.py:2396-2666 (the consumer of the streaming STFT in
+ * docs/examples/plot_pcen_stream.py:71-80) ---------------------------------------------------------------------------------- */
+/* S, ref: [rows][n_frames] real of `dtype` (device), time on the last axis; ref = the array the smoother runs over (NULL: S itself,
+ * i.e. max_size == 1 and no ref=, :2628-2630).  out: [rows][n_frames] FLOAT64 whatever `dtype` is -- the reference's filter state
+ * is float64 and promotes everything after it (:2649-2665).
+ *   M = scipy.signal.lfilter([b], [1, b - 1], ref, zi, axis=time)   smooth = exp(-gain (log eps + log1p(M / eps)))
+ *   out = log1p(S smooth) | exp(power (log S + log smooth)) | bias**power expm1(power log1p(S smooth / bias))   (power == 0 | bias == 0 | else)
+ * zi: device float64 [rows] initial filter state (a previous call's zf) or NULL = zi_scalar for every row (the caller's
+ * scipy.signal.lfilter_zi([b], [1, b - 1]), :2649-2652).  zf: device float64 [rows] final state or NULL (return_zf, :2655). */
+int lra_pcen_exec(lra_ctx* ctx, const void* S, const void* ref, void* out, int64_t rows, int64_t n_frames, int dtype, double b, double gain, double bias, double power, double eps,
+                  const void* zi, double zi_scalar, void* zf);
+
+/* scipy.ndimage.maximum_filter1d(S, size, axis) with mode="reflect", origin 0 -- pcen's max_size > 1 (:2640-2642).  S, out:
+ * [outer][n_bands][inner] of `dtype` (device), the filter runs over n_bands: out[m] = max(S[m - size/2 .. m - size/2 + size - 1]). */
+int lra_maxfilter_exec(lra_ctx* ctx, const void* S, void* out, int64_t outer, int n_bands, int64_t inner, int size, int dtype);
+
 /* ---- multi-GPU: the trivial gather of the sharded result (the reference has no counterpart) ----------------- */
 /* One process per GPU.  Clips shard by contiguous ranges with no collective on the data path; these entry points gather the
  * per-rank results over RCCL (xGMI) for hosts that do not use torch.distributed.  RCCL is bound at run time (dlopen): the

@@ -80,6 +80,8 @@ SIGNATURES = {
     "lra_phase_vocoder_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_int]),
     "lra_griffinlim_init": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int]),
     "lra_griffinlim_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_double, c_double, c_int]),
+    "lra_pcen_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_double, c_double, c_double, c_double, c_double, c_void_p, c_double, c_void_p]),
+    "lra_maxfilter_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_int]),
     "lra_dct_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_int, c_double, c_double, c_void_p, c_void_p, c_int, c_double]),
 }
 
@@ -372,6 +374,13 @@ class Context:
     def phase_vocoder_exec(self, d_ptr, out_ptr, batch, n_frames, n_bins, t_out, dtype):
         t = np.ascontiguousarray(t_out, dtype=np.float64)
         _check(self.lib.lra_phase_vocoder_exec(self.handle, c_void_p(d_ptr), c_void_p(out_ptr), batch, n_frames, n_bins, c_void_p(t.ctypes.data), len(t), dtype_code(dtype)))
+
+    def pcen_exec(self, s_ptr, ref_ptr, out_ptr, rows, n_frames, dtype, b, gain, bias, power, eps, zi_ptr, zi_scalar, zf_ptr):
+        _check(self.lib.lra_pcen_exec(self.handle, c_void_p(s_ptr), c_void_p(ref_ptr or None), c_void_p(out_ptr), rows, n_frames, dtype_code(dtype), float(b), float(gain), float(bias),
+                                      float(power), float(eps), c_void_p(zi_ptr or None), float(zi_scalar), c_void_p(zf_ptr or None)))
+
+    def maxfilter_exec(self, s_ptr, out_ptr, outer, n_bands, inner, size, dtype):
+        _check(self.lib.lra_maxfilter_exec(self.handle, c_void_p(s_ptr), c_void_p(out_ptr), outer, n_bands, inner, int(size), dtype_code(dtype)))
 
     def memset(self, ptr, value, nbytes):
         _check(self.lib.lra_memset(self.handle, c_void_p(ptr), int(value), int(nbytes)))

@@ -594,6 +594,130 @@ def phase_vocoder(D, *, rate=None, t_out=None, kind="linear", hop_length=_DEPREC
 
 
 # ---------------------------------------------------------------------------------------------------
+# PCEN (the consumer of the streaming STFT, docs/examples/plot_pcen_stream.py:71-80): librosa/core/spectrum.py:2396-2666
+# ---------------------------------------------------------------------------------------------------
+def pcen(S, *, sr=22050, hop_length=512, gain=0.98, bias=2, power=0.5, time_constant=0.400, eps=1e-6, b=None, max_size=1, ref=None, axis=-1, max_axis=None,
+         zi=None, return_zf=False):
+    """Per-channel energy normalisation; drop-in for ``librosa.pcen`` (``librosa/core/spectrum.py:2396-2666``).
+
+    ``P = (S / (eps + M)**gain + bias)**power - bias**power`` with ``M`` the first-order IIR smoothing of ``S`` (or of its
+    max-filtered version / of ``ref``) along ``axis``, evaluated in the reference's own log-domain form and, like the
+    reference, in float64 whatever ``S`` is.  Two device kernels (``csrc/lra_post.h``): the optional band max-filter and one
+    fused pass (smoother recurrence per row with the filter state in a register + the elementwise normalisation).  ``zi`` /
+    ``return_zf`` carry the filter state between blocks, so ``stream`` -> ``stft(center=False, out=D)`` -> ``pcen(zi=...)``
+    runs block by block.  Accepts NumPy arrays or device tensors (device tensors are returned for device input).
+    """
+    if power < 0:
+        raise ParameterError(f"power={power} must be nonnegative")
+    if gain < 0:
+        raise ParameterError(f"gain={gain} must be non-negative")
+    if bias < 0:
+        raise ParameterError(f"bias={bias} must be non-negative")
+    if eps <= 0:
+        raise ParameterError(f"eps={eps} must be strictly positive")
+    if time_constant <= 0:
+        raise ParameterError(f"time_constant={time_constant} must be strictly positive")
+    if not util.is_positive_int(max_size):
+        raise ParameterError(f"max_size={max_size} must be a positive integer")
+    if b is None:
+        t_frames = time_constant * sr / float(hop_length)
+        b = (np.sqrt(1 + 4 * t_frames**2) - 1) / (2 * t_frames**2)
+    if not 0 <= b <= 1:
+        raise ParameterError(f"b={b} must be between 0 and 1")
+
+    on_device = is_torch_tensor(S)
+    if not on_device:
+        S = np.asarray(S)
+    in_dtype = _arrays.numpy_dtype_of(S)
+    if in_dtype.kind == "c":
+        warnings.warn("pcen was called on complex input so phase information will be discarded. To suppress this warning, call pcen(np.abs(D)) instead.", stacklevel=2)
+        S = S.abs() if on_device else np.abs(S)
+        in_dtype = _arrays.numpy_dtype_of(S)
+    ndim = S.ndim
+    if ndim == 0:
+        raise ParameterError("pcen needs at least a 1-dimensional input")
+    if ref is None and max_size > 1:
+        if ndim == 1:
+            raise ParameterError("Max-filtering cannot be applied to 1-dimensional input")
+        if max_axis is None:
+            if ndim != 2:
+                raise ParameterError(f"Max-filtering a {ndim:d}-dimensional spectrogram requires you to specify max_axis")
+            max_axis = int(np.mod(1 - axis, 2))
+    axis = int(axis) % ndim
+    shape = tuple(int(n) for n in S.shape)
+    if ref is not None:
+        if not (is_torch_tensor(ref) or on_device):
+            ref = np.asarray(ref)
+        if tuple(ref.shape) != shape:
+            try:
+                ref = ref.expand(shape) if is_torch_tensor(ref) else np.broadcast_to(ref, shape)
+            except (RuntimeError, ValueError) as exc:
+                raise ParameterError(f"ref of shape {tuple(ref.shape)} does not broadcast to S of shape {shape}") from exc
+    # float32 stays float32 on the way in (the kernel widens it); anything else (integers, float64, float16) enters as float64, as NumPy promotes it
+    f32_in = in_dtype == np.float32 and (ref is None or _arrays.numpy_dtype_of(ref) == np.float32)
+    real = np.dtype(np.float32) if f32_in else np.dtype(np.float64)
+    perm = [a for a in range(ndim) if a != axis] + [axis]
+    moved = perm != list(range(ndim))
+    shape_p = tuple(shape[a] for a in perm)
+    n_frames = shape_p[-1]
+    rows = int(np.prod(shape_p[:-1], dtype=np.int64)) if ndim > 1 else 1
+    state_shape = tuple(1 if a == axis else shape[a] for a in range(ndim))
+
+    def time_last(x):
+        if not moved:
+            return x
+        return x.permute(*perm) if is_torch_tensor(x) else np.transpose(x, perm)
+
+    def time_back(x, shp):
+        x = x.reshape(shp)
+        if not moved:
+            return x
+        inv = [int(i) for i in np.argsort(perm)]
+        return x.permute(*inv) if is_torch_tensor(x) else np.transpose(x, inv)
+
+    sess = _arrays.Session(S if on_device else np.empty(0))
+    try:
+        ctx = sess.ctx
+
+        def put(x, dtype):
+            if sess.is_torch and not is_torch_tensor(x):
+                x = _as_like(sess, np.ascontiguousarray(x))
+            return sess.input_raw(x, dtype)
+
+        s_ptr = put(time_last(S), real)
+        ref_ptr = None
+        if ref is not None:
+            ref_ptr = put(time_last(ref), real)
+        elif max_size > 1:
+            band = perm.index(int(max_axis) % ndim)
+            outer = int(np.prod(shape_p[:band], dtype=np.int64))
+            inner = int(np.prod(shape_p[band + 1:], dtype=np.int64))
+            ref_ptr = sess.scratch(max(rows * n_frames, 1) * real.itemsize)
+            ctx.maxfilter_exec(s_ptr, ref_ptr, outer, shape_p[band], inner, int(max_size), real)
+        zi_ptr, zi_scalar = None, 0.0
+        if zi is None:
+            import scipy.signal
+
+            zi_scalar = float(scipy.signal.lfilter_zi([b], [1, b - 1])[0])
+        else:
+            if not is_torch_tensor(zi):
+                zi = np.asarray(zi, dtype=np.float64)
+            try:
+                zi = zi.expand(state_shape) if is_torch_tensor(zi) else np.broadcast_to(zi, state_shape)
+            except (RuntimeError, ValueError) as exc:
+                raise ParameterError(f"zi of shape {tuple(zi.shape)} does not match the filter state shape {state_shape}") from exc
+            zi_ptr = put(time_last(zi).reshape(-1), np.float64)
+        out_ptr, out_handle = sess.output(shape_p, np.float64)
+        zf_ptr, zf_handle = sess.output((rows,), np.float64) if return_zf else (None, None)
+        ctx.pcen_exec(s_ptr, ref_ptr, out_ptr, rows, n_frames, real, b, gain, bias, power, eps, zi_ptr, zi_scalar, zf_ptr)
+        out = time_back(sess.result(out_handle), shape_p)
+        zf = time_back(sess.result(zf_handle), shape_p[:-1] + (1,)) if return_zf else None
+    finally:
+        sess.close()
+    return (out, zf) if return_zf else out
+
+
+# ---------------------------------------------------------------------------------------------------
 # decibel scaling (SURVEY.md 8f rank 1): librosa/core/spectrum.py:1735-1883, 1898-1925, 1946-2038, 2054-2082
 # ---------------------------------------------------------------------------------------------------
 def _db_axes(ndim, axes):

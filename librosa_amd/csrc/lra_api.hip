@@ -27,6 +27,7 @@
 #include "lra_fused.h"
 #include "lra_mel.h"
 #include "lra_post.h"
+#include "lra_pcen.h"
 
 using namespace lra;
 
@@ -1916,6 +1917,65 @@ int lra_phase_vocoder_exec(lra_ctx* ctx, const void* D, void* out, int64_t batch
     }
     (void)hipFreeAsync(d_steps, ctx->stream);
     if (e != hipSuccess) return fail(LRA_EHIP, std::string("phase_vocoder: ") + hipGetErrorString(e));
+    return LRA_OK;
+}
+
+int lra_pcen_exec(lra_ctx* ctx, const void* S, const void* ref, void* out, int64_t rows, int64_t n_frames, int dtype, double b, double gain, double bias, double power, double eps,
+                  const void* zi, double zi_scalar, void* zf) {
+    LRA_BIND(ctx);
+    // the reference's own argument checks (:2598-2625); the shim raises ParameterError before getting here
+    if (power < 0 || gain < 0 || bias < 0 || !(eps > 0) || !(b >= 0 && b <= 1)) return fail(LRA_EINVAL, "pcen: power, gain, bias must be non-negative, eps positive, b in [0, 1]");
+    if (rows <= 0) return LRA_OK;
+    if (n_frames <= 0) {  // no frames: the state passes through (scipy.signal.lfilter on an empty axis)
+        if (zf) {
+            if (zi) {
+                LRA_HIP(hipMemcpyAsync(zf, zi, (size_t)rows * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+            } else {
+                std::vector<double> fill((size_t)rows, zi_scalar);
+                LRA_HIP(hipMemcpyAsync(zf, fill.data(), fill.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+                LRA_HIP(hipStreamSynchronize(ctx->stream));
+            }
+        }
+        return LRA_OK;
+    }
+    if (!S || !out) return fail(LRA_EINVAL, "null data pointer");
+    if (dtype != LRA_F32 && dtype != LRA_F64) return fail(LRA_EINVAL, "pcen: dtype must be LRA_F32 or LRA_F64");
+    PcenArgs p;
+    p.b = b;
+    p.a1 = b - 1.0;
+    p.zi_scalar = zi_scalar;
+    p.neg_gain = -gain;
+    p.log_eps = std::log(eps);
+    p.eps = eps;
+    p.power = power;
+    p.bias = bias;
+    p.bias_pow = std::pow(bias, power);
+    p.mode = power == 0 ? 0 : (bias == 0 ? 1 : 2);
+    const unsigned grid = (unsigned)((rows + kPcenRows - 1) / kPcenRows);
+    if (dtype == LRA_F64)
+        hipLaunchKernelGGL(pcen_kernel<double>, dim3(grid), dim3(64), 0, ctx->stream, (const double*)S, (const double*)(ref ? ref : S), (double*)out, (long long)rows, (long long)n_frames, p,
+                           (const double*)zi, (double*)zf);
+    else
+        hipLaunchKernelGGL(pcen_kernel<float>, dim3(grid), dim3(64), 0, ctx->stream, (const float*)S, (const float*)(ref ? ref : S), (double*)out, (long long)rows, (long long)n_frames, p,
+                           (const double*)zi, (double*)zf);
+    LRA_HIP(hipGetLastError());
+    return LRA_OK;
+}
+
+int lra_maxfilter_exec(lra_ctx* ctx, const void* S, void* out, int64_t outer, int n_bands, int64_t inner, int size, int dtype) {
+    LRA_BIND(ctx);
+    if (size < 1) return fail(LRA_EINVAL, "maxfilter: size must be a positive integer");
+    if (outer <= 0 || n_bands <= 0 || inner <= 0) return LRA_OK;
+    if (!S || !out) return fail(LRA_EINVAL, "null data pointer");
+    if (dtype != LRA_F32 && dtype != LRA_F64) return fail(LRA_EINVAL, "maxfilter: dtype must be LRA_F32 or LRA_F64");
+    const long long count = (long long)outer * n_bands * inner;
+    if ((count + 255) / 256 > 0x7fffffffLL) return fail(LRA_EINVAL, "maxfilter: array too large for one launch");
+    const unsigned grid = (unsigned)((count + 255) / 256);
+    if (dtype == LRA_F64)
+        hipLaunchKernelGGL(maxfilter_bands_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)S, (double*)out, (long long)outer, n_bands, (long long)inner, size);
+    else
+        hipLaunchKernelGGL(maxfilter_bands_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)S, (float*)out, (long long)outer, n_bands, (long long)inner, size);
+    LRA_HIP(hipGetLastError());
     return LRA_OK;
 }
 

@@ -1007,7 +1007,7 @@ template <class Cfg> inline int stft_slot_bytes(int mode, int n_mels, int tile) 
 // RAM: ring addressing mode: 0 general, 1 row-aligned (hop = n_fft/4), 2 no ring at all (direct framing, hop >= n_fft; complex / power epilogues)
 template <class Cfg, int MODE, int PM = POW_TWO, int RAM = 0> LRA_HD void stft_block(const StftArgs<typename Cfg::real>& a_in, const int blk, Lds lds) {
     constexpr bool RA = RAM == 1, DIRECT = RAM >= 2;        // DIRECT: no ring in LDS
-    constexpr int RHD = RAM >= 3 ? 1 << (RAM - 2) : 1;       // RAM = 3 .. 6: register ring with hop = n_fft / RHD
+    constexpr int RHD = 1 << (RAM >= 3 ? RAM - 2 : 0);      // RAM = 3 .. 6: register ring with hop = n_fft / RHD
     static_assert(RAM <= 2 || RegRing<Cfg, RHD>::ok, "register ring: the hop must be a whole number of pass-0 rows");
     static_assert(!DIRECT || MODE == OUT_COMPLEX || MODE == OUT_POWER, "direct framing serves the complex / power epilogues");
     StftArgs<typename Cfg::real> a = a_in;

@@ -86,3 +86,25 @@ def split_mel_kwargs(mel_kwargs):
     kw = dict(mel_kwargs)
     power = kw.pop("power", 2.0)
     return power, kw
+
+
+PCEN_CASES = {
+    # name: (input key, kwargs)      inputs: M = mel power (2, 32, 47) float32, A = |stft| (65, 61) float32, A64 = float64 copy of A
+    "default": ("A", dict()),
+    "default_f64": ("A64", dict()),
+    "log": ("A", dict(power=0)),
+    "nobias": ("A", dict(bias=0, power=0.25)),
+    "speech_max3": ("A", dict(gain=0.8, bias=10, power=0.25, time_constant=0.06, max_size=3)),
+    "b_explicit": ("A", dict(b=0.11, sr=16000, hop_length=160)),
+    "time_first": ("At", dict(axis=0, max_size=4)),
+    "stereo_max5": ("M", dict(max_size=5, max_axis=-2)),
+    "stereo_timeaxis1": ("Mt", dict(axis=1)),
+}
+
+
+def pcen_inputs(g):
+    """The input arrays PCEN_CASES names, from the two stored ones."""
+    import numpy as np
+
+    M, A = g["M"], g["A"]
+    return dict(M=M, A=A, A64=A.astype(np.float64), At=np.ascontiguousarray(A.T), Mt=np.ascontiguousarray(np.swapaxes(M, 1, 2)))

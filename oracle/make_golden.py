@@ -90,6 +90,7 @@ def main():
     make_db_mfcc(librosa, meta)
     make_griffinlim(librosa, meta)
     make_vocoder(librosa, meta)
+    make_pcen(librosa, meta)
 
 
 def make_vocoder(librosa, meta):
@@ -115,6 +116,25 @@ def make_vocoder(librosa, meta):
     store["pv64_rate08"] = librosa.phase_vocoder(D64, rate=0.8)
     np.savez_compressed(os.path.join(OUT, "vocoder.npz"), params=json.dumps(dict(case="vocoder", **meta)), **store)
     print("vocoder done")
+
+
+def make_pcen(librosa, meta):
+    """librosa.pcen outputs of the reference, incl. the block-wise use of docs/examples/plot_pcen_stream.py."""
+    y = golden_cases.make_signal("mix", 12000, 81, (2,), "float32")
+    M = librosa.feature.melspectrogram(y=y, sr=golden_cases.SR, n_fft=1024, hop_length=256, n_mels=32)   # (2, 32, 47)
+    A = np.abs(librosa.stft(y[0], n_fft=128, hop_length=200))                                               # (65, 61)
+    store = dict(M=M, A=A)
+    inputs = golden_cases.pcen_inputs(store)
+    for name, (key, kw) in golden_cases.PCEN_CASES.items():
+        store[name] = librosa.pcen(inputs[key], **kw)
+    ref = np.maximum(A, np.roll(A, 1, axis=0))
+    store["ref_in"] = ref
+    store["with_ref"] = librosa.pcen(A, ref=ref)
+    p1, z1 = librosa.pcen(A[:, :25], return_zf=True)                 # two blocks, the state carried over
+    p2, z2 = librosa.pcen(A[:, 25:], zi=z1, return_zf=True)
+    store.update(block1=p1, zf1=z1, block2=p2, zf2=z2)
+    np.savez_compressed(os.path.join(OUT, "pcen.npz"), params=json.dumps(dict(case="pcen", **meta)), **store)
+    print("pcen done")
 
 
 def make_griffinlim(librosa, meta):
@@ -160,11 +180,11 @@ def make_db_mfcc(librosa, meta):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("griffinlim", "vocoder"):  # only this fixture (the others are unchanged)
+    if len(sys.argv) > 1 and sys.argv[1] in ("griffinlim", "vocoder", "pcen"):  # only this fixture (the others are unchanged)
         _librosa = ref_shim.load_reference()
         import scipy as _scipy
 
         _meta = dict(numpy=np.__version__, scipy=_scipy.__version__, reference_version=str(_librosa.__version__))
-        (make_griffinlim if sys.argv[1] == "griffinlim" else make_vocoder)(_librosa, _meta)
+        dict(griffinlim=make_griffinlim, vocoder=make_vocoder, pcen=make_pcen)[sys.argv[1]](_librosa, _meta)
     else:
         main()

@@ -526,6 +526,84 @@ def stream_blocks(y, *, block_length, frame_length, hop_length, fill_value=None)
     return out
 
 
+# ----------------------------------------------------------------------------- PCEN (the streaming example's consumer)
+def maximum_filter1d(x, size, axis):
+    """``scipy.ndimage.maximum_filter1d(x, size, axis=axis)`` as the reference calls it (``librosa/core/spectrum.py:2640-2642``:
+    default ``mode="reflect"`` = half-sample symmetric extension, ``origin=0``): ``out[i] = max(x[i - size//2 : i - size//2 + size])``."""
+    x = np.moveaxis(np.asarray(x), axis, -1)
+    n = x.shape[-1]
+    left, right = size // 2, size - size // 2 - 1
+    idx = np.arange(-left, n + right) % (2 * n)                       # reflect with period 2n: ... b a | a b c ... | c b ...
+    idx = np.where(idx < n, idx, 2 * n - 1 - idx)
+    ext = x[..., idx]
+    out = ext[..., 0:n].copy()
+    for j in range(1, size):
+        np.maximum(out, ext[..., j : j + n], out=out)
+    return np.moveaxis(out, -1, axis)
+
+
+def lfilter_first_order(b, x, zi, axis):
+    """``scipy.signal.lfilter([b], [1, b - 1], x, zi=zi, axis=axis)`` (``:2655``): transposed direct form II in float64,
+    ``y[n] = z + b x[n]``, ``z = 0 x[n] - (b - 1) y[n]``; returns ``(y, zf)`` with ``zf`` shaped like ``x`` with ``axis`` of length 1."""
+    x = np.moveaxis(np.asarray(x, dtype=np.float64), axis, -1)
+    z = np.broadcast_to(np.moveaxis(np.asarray(zi, dtype=np.float64), axis, -1), x.shape[:-1] + (1,))[..., 0].copy()
+    y = np.empty_like(x)
+    a1 = b - 1.0
+    for n in range(x.shape[-1]):
+        y[..., n] = z + b * x[..., n]
+        z = x[..., n] * 0.0 - y[..., n] * a1
+    return np.moveaxis(y, -1, axis), np.moveaxis(z[..., None], -1, axis)
+
+
+def pcen(S, *, sr=22050, hop_length=512, gain=0.98, bias=2, power=0.5, time_constant=0.400, eps=1e-6, b=None, max_size=1, ref=None, axis=-1, max_axis=None,
+         zi=None, return_zf=False):
+    """``librosa/core/spectrum.py:2598-2666``."""
+    if power < 0:
+        raise ParameterError(f"power={power} must be nonnegative")                 # :2598-2599
+    if gain < 0:
+        raise ParameterError(f"gain={gain} must be non-negative")
+    if bias < 0:
+        raise ParameterError(f"bias={bias} must be non-negative")
+    if eps <= 0:
+        raise ParameterError(f"eps={eps} must be strictly positive")
+    if time_constant <= 0:
+        raise ParameterError(f"time_constant={time_constant} must be strictly positive")
+    if not (isinstance(max_size, (int, np.integer)) and max_size > 0):
+        raise ParameterError(f"max_size={max_size} must be a positive integer")   # :2613-2614
+    if b is None:
+        t_frames = time_constant * sr / float(hop_length)                          # :2616-2621
+        b = (np.sqrt(1 + 4 * t_frames**2) - 1) / (2 * t_frames**2)
+    if not 0 <= b <= 1:
+        raise ParameterError(f"b={b} must be between 0 and 1")
+    S = np.asarray(S)
+    if np.issubdtype(S.dtype, np.complexfloating):                                  # :2626-2633
+        warnings.warn("pcen was called on complex input so phase information will be discarded. To suppress this warning, call pcen(np.abs(D)) instead.", stacklevel=2)
+        S = np.abs(S)
+    if ref is None:                                                                 # :2635-2655
+        if max_size == 1:
+            ref = S
+        elif S.ndim == 1:
+            raise ParameterError("Max-filtering cannot be applied to 1-dimensional input")
+        else:
+            if max_axis is None:
+                if S.ndim != 2:
+                    raise ParameterError(f"Max-filtering a {S.ndim:d}-dimensional spectrogram requires you to specify max_axis")
+                max_axis = np.mod(1 - axis, 2)
+            ref = maximum_filter1d(S, max_size, max_axis)
+    if zi is None:
+        zi = np.empty((1,) * np.ndim(ref))
+        zi[:] = scipy.signal.lfilter_zi([b], [1, b - 1])[:]                        # :2649-2652
+    S_smooth, zf = lfilter_first_order(b, ref, zi, axis)                            # :2655
+    smooth = np.exp(-gain * (np.log(eps) + np.log1p(S_smooth / eps)))               # :2658
+    if power == 0:
+        S_out = np.log1p(S * smooth)                                                # :2661
+    elif bias == 0:
+        S_out = np.exp(power * (np.log(S) + np.log(smooth)))                        # :2663
+    else:
+        S_out = (bias**power) * np.expm1(power * np.log1p(S * smooth / bias))       # :2665
+    return (S_out, zf) if return_zf else S_out
+
+
 # ----------------------------------------------------------------------------- synthetic inputs
 def config_input(batch, n=661500, sr=22050, seed=440, first_clip=0):
     """SURVEY.md 8(d) config-2/3 generator: 0.1*noise + 0.5*sin(2 pi f_i t), f_i = 110*2^((i%72)/12).

@@ -128,3 +128,42 @@ def istft(D, n_fft, hop, win, wss, out_len, n_used, center=True, strip_groups=4,
             _p(ws), _p(wss), ctypes.c_double(float(np.finfo(rt).tiny)), _p(y), ctypes.c_longlong(out_len), ctypes.c_int(strip_groups), ctypes.c_int(variant), _p(diag))
     assert rc == 0
     return y, dict(races=int(diag[0]), uninit=int(diag[1]), NT=int(diag[2]), FPB=int(diag[3]), P=int(diag[4]), lds=int(diag[5]), wave_sync=int(diag[6]), ring_aligned=int(diag[8]))
+
+
+# ---- PCEN / band max-filter kernels (librosa_amd/csrc/lra_pcen.h) on host threads: tests/hostsim/postsim.cpp -----------------------
+POST_SRC = os.path.join(HERE, "hostsim", "postsim.cpp")
+POST_SO = os.path.join(HERE, "hostsim", "_postsim.so")
+_post = None
+
+
+def post_lib():
+    global _post
+    if _post is None:
+        deps = [POST_SRC, os.path.join(CSRC, "lra_pcen.h")]
+        if not os.path.exists(POST_SO) or any(os.path.getmtime(d) > os.path.getmtime(POST_SO) for d in deps):
+            subprocess.check_call(["g++", "-O1", "-std=c++17", "-w", "-fPIC", "-shared", "-pthread", POST_SRC, "-o", POST_SO])
+        _post = ctypes.CDLL(POST_SO)
+        c = ctypes
+        _post.postsim_pcen.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_longlong, c.c_longlong, c.c_int] + [c.c_double] * 5 + [c.c_void_p, c.c_double, c.c_void_p]
+        _post.postsim_maxfilter.argtypes = [c.c_void_p, c.c_void_p, c.c_longlong, c.c_int, c.c_longlong, c.c_int, c.c_int]
+    return _post
+
+
+def pcen(S, *, b, gain, bias, power, eps, zi_scalar, ref=None, zi=None, want_zf=False):
+    """S: (rows, n_frames) float32 / float64 -> (out float64, zf or None), through the kernel body of lra_pcen_exec."""
+    S = np.ascontiguousarray(S)
+    rows, n = S.shape
+    out = np.full((rows, n), np.nan)
+    zf = np.full(rows, np.nan) if want_zf else None
+    ref = None if ref is None else np.ascontiguousarray(ref, dtype=S.dtype)
+    zi = None if zi is None else np.ascontiguousarray(zi, dtype=np.float64)
+    post_lib().postsim_pcen(_p(S), _p(ref), _p(out), rows, n, int(S.dtype == np.float64), b, gain, bias, power, eps, _p(zi), zi_scalar, _p(zf))
+    return out, zf
+
+
+def maxfilter(S, size):
+    """S: (outer, n_bands, inner) -> max over a window of ``size`` bands (scipy.ndimage.maximum_filter1d, mode="reflect")."""
+    S = np.ascontiguousarray(S)
+    out = np.empty_like(S)
+    post_lib().postsim_maxfilter(_p(S), _p(out), S.shape[0], S.shape[1], S.shape[2], int(size), int(S.dtype == np.float64))
+    return out

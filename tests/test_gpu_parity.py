@@ -1048,3 +1048,141 @@ def test_native_rccl_communicator(L):
     g.close()
     with pytest.raises(L.ParameterError):
         _native.Comm(ctx, 2, 1, uid)  # rank outside the world
+
+
+# ---- PCEN (librosa/core/spectrum.py:2396-2666, docs/examples/plot_pcen_stream.py:71-80) -----------------------
+# The reference computes PCEN in float64 for every input type; the device does too.  The smoother recurrence is the same
+# sequence of IEEE operations (the filter state is compared to 1e-15); the elementwise part goes through exp / log1p / expm1 /
+# log, where device and host libm differ in the last bits: 1e-11 relative.  bias == 0 takes log(S) in S's own precision
+# (float32 for float32 input, NumPy's SIMD loop): 1e-5 relative there.
+def _pcen_close(got, ref, tol=1e-11):
+    return got.shape == ref.shape and got.dtype == ref.dtype and np.all(np.abs(got - ref) <= tol * np.abs(ref))
+
+
+def test_pcen_golden(L):
+    import torch
+
+    g = np.load(os.path.join(GOLDEN_DIR, "pcen.npz"))
+    inputs = golden_cases.pcen_inputs(g)
+    for name, (key, kw) in golden_cases.PCEN_CASES.items():
+        tol = 1e-5 if (kw.get("bias", 2) == 0 and inputs[key].dtype == np.float32) else 1e-11
+        got = L.pcen(inputs[key], **kw)
+        assert _pcen_close(got, g[name], tol), (name, np.max(np.abs(got - g[name]) / np.abs(g[name]).clip(1e-300)))
+        dev = L.pcen(torch.from_numpy(inputs[key]).cuda(), **kw)
+        assert isinstance(dev, torch.Tensor) and dev.is_cuda and dev.dtype == torch.float64 and np.array_equal(dev.cpu().numpy(), got), name
+    assert _pcen_close(L.pcen(g["A"], ref=g["ref_in"]), g["with_ref"])
+    # two blocks with the carried filter state (the streaming example), NumPy and device-resident
+    p1, z1 = L.pcen(g["A"][:, :25], return_zf=True)
+    p2, z2 = L.pcen(g["A"][:, 25:], zi=z1, return_zf=True)
+    for got, key in ((p1, "block1"), (p2, "block2")):
+        assert _pcen_close(got, g[key]), key
+    for got, key in ((z1, "zf1"), (z2, "zf2")):
+        assert _pcen_close(got, g[key], 1e-15), key
+    At = torch.from_numpy(g["A"]).cuda()
+    q1, y1 = L.pcen(At[:, :25], return_zf=True)
+    q2, y2 = L.pcen(At[:, 25:], zi=y1, return_zf=True)
+    assert y1.is_cuda and np.array_equal(q2.cpu().numpy(), p2) and np.array_equal(y2.cpu().numpy(), z2)
+    q2b = L.pcen(At[:, 25:], zi=z1)                               # host state, device data
+    assert np.array_equal(q2b.cpu().numpy(), p2)
+
+
+def test_pcen_reference_test_matrix(L):
+    """The reference's own PCEN tests (tests/test_core.py:2354-2573) against the device path."""
+    rng = np.random.default_rng(628318)
+    S = np.abs(rng.standard_normal((9, 30)))
+    for kw in (dict(gain=-1), dict(bias=-1), dict(power=-0.1), dict(b=-2), dict(b=2), dict(time_constant=-2), dict(eps=0), dict(max_size=1.5), dict(max_size=0)):
+        with pytest.raises(L.ParameterError):
+            L.pcen(S, **{**dict(gain=1, bias=1, power=1, b=0.5, time_constant=0.5, eps=1e-6, max_size=1), **kw})
+    for p in (0.5, 1, 2):   # b=1, gain=0, bias=0: all filtering disabled
+        assert np.allclose(L.pcen(S, gain=0, bias=0, power=p, b=1, time_constant=0.5, eps=1e-6, max_size=1), S**p)
+    assert np.allclose(L.pcen(S, gain=1, bias=0, power=1, b=1, time_constant=0.5, eps=1e-20, max_size=1), np.ones_like(S))
+    for power in (0, 1e-3):
+        for bias in (0, 1):
+            P = L.pcen(S, gain=0.0, bias=bias, power=power, eps=1e-20)
+            back = np.expm1(P) if power == 0 else (np.exp(1.0 / power * np.log(P)) if bias == 0 else np.expm1(1.0 / power * np.log1p(P)))
+            assert np.allclose(S, back)
+    with pytest.warns(UserWarning, match="complex"):
+        P = L.pcen(np.ones((9, 30), dtype=complex), gain=1, bias=0, power=1, time_constant=0.5, eps=1e-20, b=1, max_size=1)
+    assert P.shape == (9, 30) and np.allclose(P, 1)
+    for max_size in (1, 3):
+        assert np.allclose(L.pcen(np.zeros((9, 30)), gain=0.98, bias=2.0, power=0.5, b=None, time_constant=0.395, eps=1e-6, max_size=max_size), 0)
+    X = rng.standard_normal((3, 100, 50)) ** 2
+    for ms in (1, 3):
+        P1 = L.pcen(X[0], max_size=ms)
+        assert _pcen_close(P1, O.pcen(X[0], max_size=ms))
+        assert np.array_equal(P1, L.pcen(X[0], axis=-1, max_size=ms)) and np.array_equal(P1, L.pcen(X[0].T, axis=0, max_size=ms).T)
+    Pa = L.pcen(X)
+    Pm = L.pcen(X, max_size=3, max_axis=1)
+    for i in range(3):
+        assert np.array_equal(L.pcen(X[i]), Pa[i]) and np.array_equal(L.pcen(X[i], max_size=3), Pm[i])
+    with pytest.raises(L.ParameterError):
+        L.pcen(X, max_size=3)                      # 3-d input needs max_axis
+    with pytest.raises(L.ParameterError):
+        L.pcen(np.arange(100), max_size=3)         # no max filter over a 1-d input
+    X2 = rng.standard_normal((100, 50)) ** 2
+    assert np.allclose(L.pcen(X2, gain=1, bias=0, power=1, b=1, ref=np.ones_like(X2), eps=1e-20), X2)
+    for x in (np.arange(100), np.arange(100).reshape((10, 10))):     # integer input, 1-d and 2-d, split in two blocks
+        x1, x2 = x[..., :20], x[..., 20:]
+        p1, zf1 = L.pcen(x1, return_zf=True)
+        p2, _ = L.pcen(x2, zi=zf1, return_zf=True)
+        full = L.pcen(x)
+        assert np.allclose(full, np.hstack([p1, p2])) and _pcen_close(full, O.pcen(x))
+    x = rng.standard_normal((20, 50, 60)) ** 2
+    for axis in (0, 1, 2, -2, -1):
+        s1, s2 = [slice(None)] * 3, [slice(None)] * 3
+        s1[axis], s2[axis] = slice(0, 10), slice(10, None)
+        p1, zf1 = L.pcen(x[tuple(s1)], return_zf=True, axis=axis)
+        p2, _ = L.pcen(x[tuple(s2)], zi=zf1, return_zf=True, axis=axis)
+        full = L.pcen(x, axis=axis)
+        assert np.allclose(full, np.concatenate([p1, p2], axis=axis), rtol=1e-12, atol=0) and _pcen_close(full, O.pcen(x, axis=axis))
+        assert zf1.shape == tuple(1 if a == axis % 3 else x[tuple(s1)].shape[a] for a in range(3))
+
+
+def test_pcen_streaming_example(L):
+    """docs/examples/plot_pcen_stream.py:62-80: stream -> stft(center=False, out=D) -> pcen(|D|, zi=zi, return_zf=True), block by block,
+    against the oracle's PCEN with the same carried state and against one PCEN pass over all frames."""
+    n_fft, hop, block_length, sr = 2048, 512, 16, 22050
+    y = O.config_input(1, n=sr * 4)[0]
+    D, zi, zo, got, exp, mags = None, None, None, [], [], []
+    for blk in L.stream(y, block_length=block_length, frame_length=n_fft, hop_length=hop):
+        D = L.stft(blk, n_fft=n_fft, hop_length=hop, center=False, out=D)
+        mag = np.abs(D)
+        mags.append(mag)
+        P, zi = L.pcen(mag, sr=sr, hop_length=hop, zi=zi, return_zf=True)
+        got.append(P)
+        # the oracle on the SAME magnitudes (the block STFTs have their own parity tests; PCEN's gain control would amplify their
+        # float32 noise floor in quiet bins)
+        Po, zo = O.pcen(mag, sr=sr, hop_length=hop, zi=zo, return_zf=True)
+        exp.append(Po)
+        assert _pcen_close(zi, zo, 1e-15)
+    got, exp = np.concatenate(got, axis=-1), np.concatenate(exp, axis=-1)
+    assert _pcen_close(got, exp)
+    n_whole = 1 + (len(y) - n_fft) // hop
+    assert got.shape == (1025, n_whole)
+    whole = L.pcen(np.concatenate(mags, axis=-1), sr=sr, hop_length=hop)      # one pass over all frames == block by block with the carried state
+    assert np.array_equal(got, whole)
+
+
+def test_pcen_full_size_properties(L):
+    """BASELINE configs[1] shape: the mel spectrograms of 256 clips x 30 s (256 x 128 x 1292 float32), device-resident.  Sampled rows
+    against the oracle; two blocks with the carried state == one pass; max-filtered variant against the oracle on one clip."""
+    import torch
+
+    torch.manual_seed(5)
+    M = torch.rand((256, 128, 1292), device="cuda", dtype=torch.float32) ** 4 * 50.0
+    P = L.pcen(M)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    P = L.pcen(M)
+    ev1.record()
+    torch.cuda.synchronize()
+    print(f"pcen 256x128x1292 f32 -> f64: {ev0.elapsed_time(ev1):.3f} ms")
+    assert P.shape == M.shape and P.dtype == torch.float64
+    for clip in (0, 131, 255):
+        assert _pcen_close(P[clip].cpu().numpy(), O.pcen(M[clip].cpu().numpy()))
+    p1, zf = L.pcen(M[..., :700], return_zf=True)
+    p2 = L.pcen(M[..., 700:], zi=zf)
+    assert torch.equal(torch.cat([p1, p2], dim=-1), P)
+    Pm = L.pcen(M[:2], max_size=3, max_axis=-2)
+    assert _pcen_close(Pm[1].cpu().numpy(), O.pcen(M[1].cpu().numpy(), max_size=3))

@@ -267,3 +267,106 @@ def test_power_epilogue_without_lds_ring(n_fft, hop, power, iters, n, monkeypatc
     _check_diag(d)
     ref = np.moveaxis(np.abs(O.stft(y, n_fft=n_fft, hop_length=hop)) ** power, -1, -2)
     assert S.shape == ref.shape and np.abs(S - ref).max() <= 4e-6 * ref.max()
+
+
+# ---- PCEN kernels (librosa_amd/csrc/lra_pcen.h) on host threads ----------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("rows,n", [(1, 1), (5, 63), (16, 64), (17, 65), (40, 200)])
+def test_pcen_body(dtype, rows, n):
+    """Rows not a multiple of the 16 a wave owns, frame counts around the 64-frame tile, every output branch, carried state."""
+    import scipy.signal
+
+    rng = np.random.default_rng(rows * 1000 + n)
+    X = (rng.standard_normal((rows, n)) ** 2).astype(dtype)
+    base = dict(b=0.05, gain=0.98, bias=2.0, power=0.5, eps=1e-6)
+    for kw in (dict(), dict(power=0.0), dict(bias=0.0, power=0.25), dict(gain=0.8, bias=10.0, power=0.25), dict(b=1.0, gain=1.0, bias=0.0, power=1.0, eps=1e-20)):
+        a = {**base, **kw}
+        got, zf = H.pcen(X, zi_scalar=float(scipy.signal.lfilter_zi([a["b"]], [1, a["b"] - 1])[0]), want_zf=True, **a)
+        exp, ezf = O.pcen(X, return_zf=True, **a)
+        # log(S) of float32 input is a float32 log in the reference (NumPy's SIMD loop): last-bit differences scale with |log S|
+        tol = 5e-6 if (dtype == np.float32 and a["bias"] == 0) else 1e-13
+        assert np.all(np.abs(got - exp) <= tol * np.abs(exp)), (kw, np.max(np.abs(got - exp) / np.abs(exp).clip(1e-300)))
+        assert np.array_equal(zf, ezf[:, 0])
+    zi = rng.random(rows)
+    ref = (rng.standard_normal((rows, n)) ** 2).astype(dtype)
+    got, zf = H.pcen(X, ref=ref, zi=zi, zi_scalar=np.nan, want_zf=True, **base)
+    exp, ezf = O.pcen(X, ref=ref, zi=zi[:, None], return_zf=True, **base)
+    assert np.all(np.abs(got - exp) <= 1e-13 * np.abs(exp)) and np.array_equal(zf, ezf[:, 0])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_maxfilter_body(dtype):
+    rng = np.random.default_rng(8)
+    for shape in ((1, 1, 1), (2, 7, 5), (3, 40, 70), (1, 5, 300)):
+        X = rng.standard_normal(shape).astype(dtype)
+        for size in (1, 2, 3, 4, 9, 23):
+            assert np.array_equal(H.maxfilter(X, size), O.maximum_filter1d(X, size, 1)), (shape, size)
+
+
+class _SimSession:
+    """Stands in for librosa_amd._arrays.Session in the CPU test below: host arrays instead of device buffers, and a context whose
+    pcen / max-filter entry points run the kernel bodies on host threads (the argument order of librosa_amd._native.Context)."""
+
+    is_torch = False
+
+    def __init__(self, like):
+        self._keep = []
+        self.ctx = self
+
+    def input_raw(self, a, dtype):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        self._keep.append(a)
+        return a.ctypes.data
+
+    def scratch(self, nbytes):
+        a = np.empty(max(int(nbytes), 16), dtype=np.uint8)
+        self._keep.append(a)
+        return a.ctypes.data
+
+    def output(self, shape, dtype):
+        a = np.full(shape, np.nan, dtype=dtype)
+        return a.ctypes.data, a
+
+    def result(self, handle):
+        return handle
+
+    def close(self):
+        pass
+
+    def pcen_exec(self, s_ptr, ref_ptr, out_ptr, rows, n_frames, dtype, b, gain, bias, power, eps, zi_ptr, zi_scalar, zf_ptr):
+        H.post_lib().postsim_pcen(s_ptr, ref_ptr, out_ptr, rows, n_frames, int(np.dtype(dtype) == np.float64), float(b), float(gain), float(bias), float(power), float(eps), zi_ptr,
+                                  float(zi_scalar), zf_ptr)
+
+    def maxfilter_exec(self, s_ptr, out_ptr, outer, n_bands, inner, size, dtype):
+        H.post_lib().postsim_maxfilter(s_ptr, out_ptr, outer, n_bands, inner, int(size), int(np.dtype(dtype) == np.float64))
+
+
+def test_pcen_shim_layouts_through_simulator(monkeypatch):
+    """librosa_amd.pcen's host side (axis / max_axis permutations, state shapes, broadcasting of zi and ref, dtype promotion) with the
+    kernels run by the simulator: against the oracle on the layouts of the reference's tests (tests/test_core.py:2459-2573)."""
+    import librosa_amd
+    from librosa_amd import _arrays
+
+    monkeypatch.setattr(_arrays, "Session", _SimSession)
+    rng = np.random.default_rng(77)
+    X = rng.standard_normal((3, 20, 33)) ** 2
+
+    def close(got, exp):
+        if isinstance(got, tuple):
+            return all(close(g, e) for g, e in zip(got, exp))
+        return got.shape == exp.shape and got.dtype == exp.dtype and np.all(np.abs(got - exp) <= 1e-13 * np.abs(exp))
+
+    for kw in (dict(), dict(axis=0), dict(axis=1), dict(axis=-2, return_zf=True), dict(max_size=3, max_axis=1), dict(max_size=4, max_axis=0, axis=1), dict(max_size=2, max_axis=2, axis=0),
+               dict(max_size=3, max_axis=-1), dict(power=0, b=0.3, return_zf=True)):
+        assert close(librosa_amd.pcen(X, **kw), O.pcen(X, **kw)), kw
+    for kw in (dict(), dict(max_size=3), dict(axis=0, max_size=5), dict(ref=np.ones((20, 1))), dict(ref=X[1].astype(np.float32)), dict(zi=np.full((1, 1), 0.25)), dict(zi=rng.random((20, 1)), return_zf=True)):
+        for A in (X[0], X[0].astype(np.float32), np.asfortranarray(X[0])):
+            assert close(librosa_amd.pcen(A, **kw), O.pcen(A, **kw)), kw
+    assert close(librosa_amd.pcen(np.arange(50)), O.pcen(np.arange(50)))
+    assert close(librosa_amd.pcen(np.arange(50), return_zf=True), O.pcen(np.arange(50), return_zf=True))
+    s1, z1 = librosa_amd.pcen(X[:, :, :10], axis=-1, return_zf=True)
+    assert z1.shape == (3, 20, 1) and close(librosa_amd.pcen(X[:, :, 10:], zi=z1), O.pcen(X[:, :, 10:], zi=z1))
+    with pytest.raises(librosa_amd.ParameterError):
+        librosa_amd.pcen(X[0], zi=np.zeros((3, 1)))
+    with pytest.raises(librosa_amd.ParameterError):
+        librosa_amd.pcen(X[0], ref=np.ones((3, 3)))

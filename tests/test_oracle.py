@@ -282,3 +282,51 @@ def test_vocoder_oracle_matches_reference_golden():
     assert np.array_equal(O.phase_vocoder(g["D64"], rate=0.8), g["pv64_rate08"])
     assert np.array_equal(O.time_stretch(g["y"], rate=1.5, n_fft=1024, hop_length=256), g["ts_15"])
     assert np.array_equal(O.time_stretch(g["ys"], rate=0.7), g["ts_stereo_07_default"])
+
+
+# ---- PCEN ------------------------------------------------------------------------------------------------
+def test_pcen_oracle_matches_reference_golden():
+    """librosa.pcen (core/spectrum.py:2396-2666) restated -- incl. its scipy.signal.lfilter recurrence and scipy.ndimage max-filter -- vs
+    outputs of the unmodified reference (oracle/make_golden.py::make_pcen): bit for bit, float64 results for every input type."""
+    g = np.load(os.path.join(GOLDEN_DIR, "pcen.npz"))
+    inputs = golden_cases.pcen_inputs(g)
+    for name, (key, kw) in golden_cases.PCEN_CASES.items():
+        got = O.pcen(inputs[key], **kw)
+        assert got.dtype == np.float64 and np.array_equal(got, g[name]), name
+    assert np.array_equal(O.pcen(g["A"], ref=g["ref_in"]), g["with_ref"])
+    p1, z1 = O.pcen(g["A"][:, :25], return_zf=True)
+    p2, z2 = O.pcen(g["A"][:, 25:], zi=z1, return_zf=True)
+    for got, key in ((p1, "block1"), (z1, "zf1"), (p2, "block2"), (z2, "zf2")):
+        assert got.shape == g[key].shape and np.array_equal(got, g[key]), key
+    # the property the reference tests (tests/test_core.py:2533-2573): block-wise with the carried state == one pass
+    assert np.allclose(np.hstack([p1, p2]), O.pcen(g["A"]), rtol=1e-12, atol=0)
+
+
+def test_pcen_oracle_reference_known_answers():
+    """The closed-form cases of the reference's own tests (tests/test_core.py:2386-2456, 2516-2530)."""
+    rng = np.random.default_rng(20)
+    S = np.abs(rng.standard_normal((9, 30)))
+    for p in (0.5, 1, 2):
+        assert np.allclose(O.pcen(S, gain=0, bias=0, power=p, b=1, time_constant=0.5, eps=1e-6, max_size=1), S**p)
+    assert np.allclose(O.pcen(S, gain=1, bias=0, power=1, b=1, time_constant=0.5, eps=1e-20, max_size=1), np.ones_like(S))
+    for max_size in (1, 3):
+        assert np.allclose(O.pcen(np.zeros((9, 30)), time_constant=0.395, max_size=max_size), 0)
+    X = rng.standard_normal((100, 50)) ** 2
+    assert np.allclose(O.pcen(X, gain=1, bias=0, power=1, b=1, ref=np.ones_like(X), eps=1e-20), X)
+    with pytest.warns(UserWarning, match="complex"):
+        assert np.allclose(O.pcen(np.ones((9, 30), dtype=complex), gain=1, bias=0, power=1, time_constant=0.5, eps=1e-20, b=1, max_size=1), 1)
+    import scipy.ndimage
+
+    for size in (1, 2, 3, 6, 130):
+        for ax in (0, 1):
+            assert np.array_equal(O.maximum_filter1d(X, size, ax), scipy.ndimage.maximum_filter1d(X, size, axis=ax))
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="/root/reference not present (GPU box)")
+def test_pcen_oracle_live_reference():
+    L = ref_shim.load_reference()
+    rng = np.random.default_rng(21)
+    X = (rng.standard_normal((3, 40, 70)) ** 2).astype(np.float32)
+    for kw in (dict(), dict(axis=1), dict(max_size=3, max_axis=1), dict(power=0, b=0.3), dict(bias=0, power=2)):
+        assert np.array_equal(O.pcen(X, **kw), L.pcen(X, **kw)), kw
+    assert np.array_equal(O.pcen(np.arange(100)), L.pcen(np.arange(100)))
