@@ -217,6 +217,24 @@ int lra_pcen_exec(lra_ctx* ctx, const void* S, const void* ref, void* out, int64
  * [outer][n_bands][inner] of `dtype` (device), the filter runs over n_bands: out[m] = max(S[m - size/2 .. m - size/2 + size - 1]). */
 int lra_maxfilter_exec(lra_ctx* ctx, const void* S, void* out, int64_t outer, int n_bands, int64_t inner, int size, int dtype);
 
+/* ---- constant-Q / variable-Q transform: librosa.cqt / librosa.vqt, librosa/core/constantq.py:42-225, 820-1122 ---------------------
+ * The octave recursion (:1054-1099) is, per octave: lra_stft_exec with a rectangular window (__cqt_response, :1202-1204), then
+ * lra_cqt_project_exec (the sparse filter basis applied to every frame, :1213-1218, with the length scaling :1116-1118 and the
+ * stacking of __trim_stack :1168-1194 folded in), then lra_fir_decimate_exec (audio.resample by 2, :1095-1098). */
+
+/* out[clip][n] = (sum_k taps[k] x[clip][(n + first) down - k]) / div * mul, x = 0 outside [0, n_in), 0 <= n < n_out.
+ * With taps = the zero-prefixed filter, first = n_pre_remove and n_out = ceil(n_in / down) this is
+ * scipy.signal.resample_poly(x, 1, down) (librosa/core/audio.py:676-693), summed in its order; div = sqrt(1 / down) is
+ * resample(scale=True) (:719-720).  x, out, taps: real of `dtype` (device). */
+int lra_fir_decimate_exec(lra_ctx* ctx, const void* x, void* out, int64_t batch, int64_t n_in, int64_t n_out, const void* taps, int n_taps, int down, int first, double div, double mul,
+                          int dtype);
+
+/* out[clip][t][bin0 + r] = (sum_j val[j] D[clip][t][col[j]], j in row row0 + r of the CSR basis) / sqrt_len[r], 0 <= r < n_rows,
+ * 0 <= t < n_frames.  D: [clip][frames_in][n_bins] complex (lra_stft_exec's layout), out: [clip][n_frames][n_total] complex, both of
+ * `dtype`'s precision; row_ptr / col: int32, val: complex (device); sqrt_len: float64 [n_rows] (device) or NULL (scale=False). */
+int lra_cqt_project_exec(lra_ctx* ctx, const void* D, void* out, const void* row_ptr, const void* col, const void* val, const void* sqrt_len, int64_t batch, int64_t frames_in, int n_bins,
+                         int64_t n_frames, int n_total, int bin0, int row0, int n_rows, int dtype);
+
 /* ---- multi-GPU: the trivial gather of the sharded result (the reference has no counterpart) ----------------- */
 /* One process per GPU.  Clips shard by contiguous ranges with no collective on the data path; these entry points gather the
  * per-rank results over RCCL (xGMI) for hosts that do not use torch.distributed.  RCCL is bound at run time (dlopen): the

@@ -24,7 +24,8 @@ def _torch():
 
     if not _NP2TORCH:
         _NP2TORCH.update({np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
-                          np.dtype(np.complex64): torch.complex64, np.dtype(np.complex128): torch.complex128})
+                          np.dtype(np.complex64): torch.complex64, np.dtype(np.complex128): torch.complex128,
+                          np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64})   # integers: index tables (CSR bases) and integer-valued inputs
     return torch
 
 

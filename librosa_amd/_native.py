@@ -82,6 +82,8 @@ SIGNATURES = {
     "lra_griffinlim_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_double, c_double, c_int]),
     "lra_pcen_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_double, c_double, c_double, c_double, c_double, c_void_p, c_double, c_void_p]),
     "lra_maxfilter_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_int]),
+    "lra_fir_decimate_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_double, c_double, c_int]),
+    "lra_cqt_project_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int64, c_int, c_int, c_int, c_int, c_int]),
     "lra_dct_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_int, c_double, c_double, c_void_p, c_void_p, c_int, c_double]),
 }
 
@@ -381,6 +383,14 @@ class Context:
 
     def maxfilter_exec(self, s_ptr, out_ptr, outer, n_bands, inner, size, dtype):
         _check(self.lib.lra_maxfilter_exec(self.handle, c_void_p(s_ptr), c_void_p(out_ptr), outer, n_bands, inner, int(size), dtype_code(dtype)))
+
+    def fir_decimate_exec(self, x_ptr, out_ptr, batch, n_in, n_out, taps_ptr, n_taps, down, first, div, mul, dtype):
+        _check(self.lib.lra_fir_decimate_exec(self.handle, c_void_p(x_ptr), c_void_p(out_ptr), batch, n_in, n_out, c_void_p(taps_ptr), int(n_taps), int(down), int(first), float(div),
+                                              float(mul), dtype_code(dtype)))
+
+    def cqt_project_exec(self, d_ptr, out_ptr, row_ptr, col_ptr, val_ptr, sqrt_len_ptr, batch, frames_in, n_bins, n_frames, n_total, bin0, row0, n_rows, dtype):
+        _check(self.lib.lra_cqt_project_exec(self.handle, c_void_p(d_ptr), c_void_p(out_ptr), c_void_p(row_ptr), c_void_p(col_ptr), c_void_p(val_ptr), c_void_p(sqrt_len_ptr or None), batch,
+                                             frames_in, int(n_bins), n_frames, int(n_total), int(bin0), int(row0), int(n_rows), dtype_code(dtype)))
 
     def memset(self, ptr, value, nbytes):
         _check(self.lib.lra_memset(self.handle, c_void_p(ptr), int(value), int(nbytes)))

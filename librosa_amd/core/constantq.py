@@ -1,0 +1,230 @@
+"""Constant-Q and variable-Q transforms on the device: drop-ins for ``librosa.cqt`` / ``librosa.vqt``
+(``librosa/core/constantq.py:42-225, 820-1122``; SURVEY.md 8f rank 4, "CQT/VQT octave recursion").
+
+The recursion the reference runs on the host -- per octave a rectangular-window STFT (``__cqt_response``, ``:1197-1223``), the
+sparse frequency-domain filter basis applied to every frame (``:1218``), then ``audio.resample`` by two (``:1095-1098``) -- stays in
+HBM from the first sample to the stacked result: ``lra_stft_exec`` -> ``lra_cqt_project_exec`` (projection + length scaling + the
+stacking of ``__trim_stack``) -> ``lra_fir_decimate_exec``, one octave after the other on one stream.  The host builds the tables
+(frequencies, filter lengths, the wavelet basis and its FFT, the sparsification: float64 / complex64 recipes identical to the
+reference's, see ``librosa_amd.filters.wavelet``) once per parameter set and keeps them.
+
+Resampling.  The reference's default ``res_type="soxr_hq"`` calls the ``soxr`` package, which is not in the build image (the
+reference itself cannot run its default there).  ``res_type="polyphase"`` is reproduced exactly (scipy's Kaiser-5 design and
+summation order: bit-identical signals between octaves).  The band-limited resamplers with an exact rate ratio (the ``soxr_*``
+family, resampy's ``kaiser_*``, samplerate's ``sinc_*``) run this library's own linear-phase decimator with soxr-HQ's band edges
+(pass band to 0.913 of the new Nyquist, 125 dB stop band from the new Nyquist on): the constant-Q filters of the next octave lie
+below 0.8 of the new Nyquist (``:1093``), inside every such filter's pass band, so the transforms agree to the resamplers'
+pass-band ripple -- 2.6e-3 of the peak against the reference's ``"polyphase"`` result, whose Kaiser-5 filter droops most; parity
+for this family is that tolerance statement, not pinned against soxr.  ``"fft"`` / ``"scipy"`` (whole-signal
+``scipy.signal.resample``, which also stretches time when a length is odd) and the non-band-limited ``"linear"`` /
+``"zero_order_hold"`` are not provided.
+"""
+from __future__ import annotations
+
+import functools
+import warnings
+
+import numpy as np
+import scipy.fft
+import scipy.signal
+
+from .. import _arrays
+from .. import filters
+from ..util import utils as util
+from ..util.exceptions import ParameterError
+from ..util.utils import is_torch_tensor
+from .intervals import interval_frequencies
+from .spectrum import _DEVICE_PAD_MODES, _all_finite, _as_like
+
+__all__ = ["cqt", "vqt"]
+
+_C1_HZ = 440.0 * (2.0 ** ((24 - 69) / 12))  # note_to_hz("C1") (core/convert.py:573-620): MIDI note 24
+
+
+_FIR_LIKE = ("kaiser_best", "kaiser_fast", "sinc_best", "sinc_medium", "sinc_fastest")
+
+
+def _two_factors(x):
+    """How many times 2 divides ``x`` (``constantq.py:1271-1284``)."""
+    n = 0
+    while x > 0 and x % 2 == 0:
+        n += 1
+        x //= 2
+    return n
+
+
+def _decimator(down, res_type, real):
+    """(taps incl. leading zeros, first output's offset) of the FIR that decimates by ``down``.
+
+    ``"polyphase"``: ``scipy.signal.resample_poly(x, 1, down)``'s own design and alignment (its default Kaiser-5 window, 10 ``down``
+    taps each side, the zero prefix that centres the output grid).  Anything else: a Kaiser design with soxr-HQ's band edges."""
+    if not isinstance(res_type, str) or not (res_type == "polyphase" or res_type.startswith("soxr") or res_type in _FIR_LIKE):
+        raise ParameterError(f"res_type={res_type!r} is not provided by librosa_amd.vqt: use 'polyphase' (scipy's design, reproduced exactly) or a band-limited "
+                             "resampler name (soxr_*, kaiser_*, sinc_*: the library's own decimator)")
+    if res_type == "polyphase":
+        half = 10 * down
+        taps = scipy.signal.firwin(2 * half + 1, 1.0 / down, window=("kaiser", 5.0)).astype(real)
+        lead = down - half % down
+        return np.concatenate([np.zeros(lead, dtype=real), taps]), (half + lead) // down
+    width = 0.087 / down                      # transition: 0.913 .. 1.0 of the new Nyquist, in units of the old Nyquist
+    n_taps, beta = scipy.signal.kaiserord(125.0, width)
+    half = -(-(n_taps // 2) // down) * down   # half length rounded up to a multiple of `down`: integer output alignment without a prefix
+    taps = scipy.signal.firwin(2 * half + 1, (1.0 - 0.5 * 0.087) / down, window=("kaiser", beta)).astype(real)
+    return taps, half // down
+
+
+@functools.lru_cache(maxsize=16)
+def _plan(sr, hop_length, fmin, n_bins, intervals, gamma, bins_per_octave, filter_scale, norm, sparsity, window, scale, cplx_str):
+    """Everything that does not depend on the signal: per-octave FFT size, hop, sparse basis (CSR arrays), row selection and
+    scaling of the stacked result, and the downsampling schedule (``constantq.py:1000-1099`` without the data)."""
+    cplx = np.dtype(cplx_str)
+    freqs = interval_frequencies(n_bins, fmin=fmin, intervals=intervals if isinstance(intervals, str) else list(intervals), bins_per_octave=bins_per_octave, sort=True)
+    if n_bins == 1:
+        r = 2 ** (1 / bins_per_octave)
+        alpha = np.atleast_1d((r**2 - 1) / (r**2 + 1))                       # :1577-1597
+    else:
+        alpha = filters._relative_bandwidth(freqs=freqs)
+    lengths, reach = filters.wavelet_lengths(freqs=freqs, sr=sr, window=window, filter_scale=filter_scale, gamma=gamma, alpha=alpha)
+    nyquist = sr / 2.0
+    if reach > nyquist:
+        raise ParameterError(f"Wavelet basis with max frequency={np.max(freqs[-bins_per_octave:])} would exceed the Nyquist frequency={nyquist}. "
+                             "Try reducing the number of frequency bins.")
+    n_octaves = int(np.ceil(float(n_bins) / bins_per_octave))
+    per_octave = min(bins_per_octave, n_bins)
+    early = min(max(0, int(np.ceil(np.log2(nyquist / reach)) - 1) - 1), max(0, _two_factors(hop_length) - n_octaves + 1))   # :1226-1232
+    sr0 = sr / float(2**early)
+    hop0 = hop_length // (2**early)
+    octaves, top = [], n_bins
+    cur_sr, cur_hop = sr0, hop0
+    for i in range(n_octaves):
+        sl = slice(-per_octave, None) if i == 0 else slice(-per_octave * (i + 1), -per_octave * i)
+        f_oct, a_oct = freqs[sl], alpha[sl]
+        basis, f_lengths = filters.wavelet(freqs=f_oct, sr=cur_sr, filter_scale=filter_scale, norm=norm, pad_fft=True, window=window, gamma=gamma, alpha=a_oct)
+        n_fft = basis.shape[1]
+        basis *= f_lengths[:, np.newaxis] / float(n_fft)                      # :1157
+        spectrum = scipy.fft.fft(basis, n=n_fft, axis=1)[:, : (n_fft // 2) + 1]
+        sparse = util.sparsify_rows(spectrum, quantile=sparsity, dtype=cplx)
+        sparse[:] *= np.sqrt(sr0 / cur_sr)                                    # :1080
+        sparse.sort_indices()
+        rows = sparse.shape[0]
+        keep = min(rows, top)                                                 # __trim_stack (:1183-1192): the last octave may keep only its highest filters
+        octaves.append(dict(n_fft=n_fft, hop=cur_hop, row_ptr=np.ascontiguousarray(sparse.indptr, dtype=np.int32), col=np.ascontiguousarray(sparse.indices, dtype=np.int32),
+                            val=np.ascontiguousarray(sparse.data, dtype=cplx), row0=rows - keep, n_rows=keep, bin0=top - keep, halve=False))
+        top -= keep
+        if i < n_octaves - 1 and cur_hop % 2 == 0 and freqs[sl.start - 1] <= cur_sr / 5:     # :1093
+            octaves[-1]["halve"] = True
+            cur_hop //= 2
+            cur_sr /= 2.0
+    sqrt_len = None
+    if scale:
+        l0, _ = filters.wavelet_lengths(freqs=freqs, sr=sr0, window=window, filter_scale=filter_scale, gamma=gamma, alpha=alpha)   # :1103-1112
+        sqrt_len = np.sqrt(l0)
+    return dict(early=early, octaves=octaves, sqrt_len=sqrt_len)
+
+
+def vqt(y, *, sr=22050, hop_length=512, fmin=None, n_bins=84, intervals="equal", gamma=None, bins_per_octave=12, tuning=0.0, filter_scale=1, norm=1, sparsity=0.01,
+        window="hann", scale=True, pad_mode="constant", res_type="soxr_hq", dtype=None):
+    """Variable-Q transform; drop-in for ``librosa.vqt`` (``librosa/core/constantq.py:820-1122``).
+
+    Returns ``(..., n_bins, n_frames)`` complex (complex64 for float32 audio).  ``y`` may be a device tensor (a device tensor is
+    returned).  Not provided: ``tuning=None`` (needs the pitch tracker behind ``estimate_tuning``), named just-intonation interval
+    sets (``intervals`` must be ``"equal"`` or an explicit list), ``n_bins=None``.  See the module docstring for ``res_type``.
+    """
+    if not isinstance(intervals, str):
+        intervals = tuple(float(v) for v in intervals)
+        bins_per_octave = len(intervals)
+    elif intervals != "equal":
+        raise ParameterError(f"intervals={intervals!r}: librosa_amd.vqt takes 'equal' or an explicit list of intervals")
+    if fmin is None:
+        fmin = _C1_HZ
+    if tuning is None:
+        raise ParameterError("tuning=None (automatic tuning estimation) is not provided by librosa_amd; pass a number")
+    if n_bins is None:
+        raise ParameterError("n_bins=None is not provided by librosa_amd; pass the number of bins")
+    if not util.is_positive_int(hop_length):
+        raise ParameterError(f"hop_length={hop_length} must be a positive integer")
+    on_device = is_torch_tensor(y)
+    if on_device:
+        if not y.is_floating_point():
+            raise ParameterError("Audio data must be floating-point")
+    else:
+        util.valid_audio(y)
+    in_dtype = _arrays.numpy_dtype_of(y)
+    cplx = np.dtype(util.dtype_r2c(in_dtype)) if dtype is None else np.dtype(dtype)
+    if cplx.kind != "c":
+        raise ParameterError(f"dtype={cplx} must be a complex type")
+    real = np.dtype(np.float64) if cplx == np.complex128 else np.dtype(np.float32)
+    fmin = fmin * 2.0 ** (tuning / bins_per_octave)
+    if fmin >= sr / 2:
+        raise ParameterError(f"fmin={fmin} must be less than sr/2={sr/2}")
+    if not (isinstance(pad_mode, str) and pad_mode in _DEVICE_PAD_MODES):
+        raise ParameterError(f"pad_mode={pad_mode!r} is not supported by librosa_amd.vqt")
+    _decimator(2, res_type, real)  # validates res_type (also when no octave needs a decimation)
+    try:
+        plan = _plan(float(sr), int(hop_length), float(fmin), int(n_bins), intervals, None if gamma is None else float(gamma), int(bins_per_octave), float(filter_scale),
+                     None if norm is None else float(norm), float(sparsity), window, bool(scale), cplx.str)
+    except TypeError:  # unhashable window specification: build without the cache
+        plan = _plan.__wrapped__(float(sr), int(hop_length), float(fmin), int(n_bins), intervals, None if gamma is None else float(gamma), int(bins_per_octave), float(filter_scale),
+                                 None if norm is None else float(norm), float(sparsity), window, bool(scale), cplx.str)
+    octaves = plan["octaves"]
+    n = int(y.shape[-1])
+    lead = tuple(int(s) for s in y.shape[:-1])
+    factor = 2 ** plan["early"]
+    if plan["early"] and n < factor:
+        raise ParameterError(f"Input signal length={n:d} is too short for {len(octaves):d}-octave CQT")
+    # signal length and frame count of every octave (centred frames: 1 + n // hop)
+    lens = [-(-n // factor) if plan["early"] else n]
+    for o in octaves[:-1]:
+        lens.append(-(-lens[-1] // 2) if o["halve"] else lens[-1])
+    frames = [1 + ln // o["hop"] for ln, o in zip(lens, octaves)]
+    n_frames = min(frames)
+    sess = _arrays.Session(y if on_device else np.empty(0))
+    try:
+        ctx = sess.ctx
+        y_ptr, batch, _, _ = sess.input_2d(y, real)
+        check = on_device
+        if check:
+            ctx.nonfinite_reset()
+
+        def upload(a, dtype):
+            return sess.input_raw(_as_like(sess, a), dtype)
+
+        if plan["early"]:
+            taps, first = _decimator(factor, res_type, real)
+            nxt = sess.scratch(batch * lens[0] * real.itemsize)
+            # resample(scale=True) divides by sqrt(1 / factor); an unscaled transform multiplies by sqrt(factor) on top (:1254-1264)
+            ctx.fir_decimate_exec(y_ptr, nxt, batch, n, lens[0], upload(taps, real), len(taps), factor, first, np.sqrt(1.0 / factor), 1.0 if scale else np.sqrt(factor), real)
+            y_ptr = nxt
+        out_ptr, handle = sess.output((batch, n_frames, n_bins), cplx)
+        d_bytes = max(f * (o["n_fft"] // 2 + 1) for f, o in zip(frames, octaves)) * batch * cplx.itemsize
+        d_ptr = sess.scratch(d_bytes)
+        sqrt_len_ptr = upload(plan["sqrt_len"], np.float64) if plan["sqrt_len"] is not None else None
+        half_taps = None
+        for i, o in enumerate(octaves):
+            n_fft, hop = o["n_fft"], o["hop"]
+            if n_fft > lens[i]:   # the warning of the reference's stft (core/spectrum.py:267-271), once per octave it applies to
+                warnings.warn(f"n_fft={n_fft} is too large for input signal of length={lens[i]}", stacklevel=3)
+            splan = ctx.stft_plan(n_fft, hop, np.ones(n_fft, dtype=real), True, pad_mode, real)          # window="ones" (:1197)
+            ctx.stft_exec(splan, y_ptr, batch, lens[i], lens[i], d_ptr)
+            ctx.cqt_project_exec(d_ptr, out_ptr, upload(o["row_ptr"], np.int32), upload(o["col"], np.int32), upload(o["val"], cplx),
+                                 (sqrt_len_ptr + 8 * o["bin0"]) if sqrt_len_ptr else None, batch, frames[i], n_fft // 2 + 1, n_frames, n_bins, o["bin0"], o["row0"], o["n_rows"], real)
+            if o["halve"]:
+                if half_taps is None:
+                    taps, first = _decimator(2, res_type, real)
+                    half_taps = (upload(taps, real), len(taps), first)
+                nxt = sess.scratch(batch * lens[i + 1] * real.itemsize)
+                ctx.fir_decimate_exec(y_ptr, nxt, batch, lens[i], lens[i + 1], half_taps[0], half_taps[1], 2, half_taps[2], np.sqrt(0.5), 1.0, real)
+                y_ptr = nxt
+        if check and ctx.nonfinite_read() and not _all_finite(y):
+            raise ParameterError("Audio buffer is not finite everywhere")
+        res = sess.result(handle)
+    finally:
+        sess.close()
+    return _arrays.swap_last_two(res.reshape(lead + (n_frames, n_bins)))
+
+
+def cqt(y, *, sr=22050, hop_length=512, fmin=None, n_bins=84, bins_per_octave=12, tuning=0.0, filter_scale=1, norm=1, sparsity=0.01, window="hann", scale=True,
+        pad_mode="constant", res_type="soxr_hq", dtype=None):
+    """Constant-Q transform; drop-in for ``librosa.cqt`` (``librosa/core/constantq.py:42-225``): the ``gamma=0`` case of :func:`vqt`."""
+    return vqt(y, sr=sr, hop_length=hop_length, fmin=fmin, n_bins=n_bins, intervals="equal", gamma=0, bins_per_octave=bins_per_octave, tuning=tuning, filter_scale=filter_scale,
+               norm=norm, sparsity=sparsity, window=window, scale=scale, pad_mode=pad_mode, res_type=res_type, dtype=dtype)

@@ -391,7 +391,10 @@ def _fit_bins(D, n_bins):
 
 def _as_like(sess, host_array):
     if sess.is_torch:
-        return _arrays._torch().from_numpy(np.ascontiguousarray(host_array)).to(sess.device)
+        a = np.ascontiguousarray(host_array)
+        if not a.flags.writeable:   # e.g. a broadcast view: torch refuses to wrap read-only memory silently
+            a = a.copy()
+        return _arrays._torch().from_numpy(a).to(sess.device)
     return host_array
 
 

@@ -28,6 +28,7 @@
 #include "lra_mel.h"
 #include "lra_post.h"
 #include "lra_pcen.h"
+#include "lra_cqt.h"
 
 using namespace lra;
 
@@ -1975,6 +1976,48 @@ int lra_maxfilter_exec(lra_ctx* ctx, const void* S, void* out, int64_t outer, in
         hipLaunchKernelGGL(maxfilter_bands_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)S, (double*)out, (long long)outer, n_bands, (long long)inner, size);
     else
         hipLaunchKernelGGL(maxfilter_bands_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)S, (float*)out, (long long)outer, n_bands, (long long)inner, size);
+    LRA_HIP(hipGetLastError());
+    return LRA_OK;
+}
+
+int lra_fir_decimate_exec(lra_ctx* ctx, const void* x, void* out, int64_t batch, int64_t n_in, int64_t n_out, const void* taps, int n_taps, int down, int first, double div, double mul,
+                          int dtype) {
+    LRA_BIND(ctx);
+    if (n_taps < 1 || down < 1 || first < 0 || !(div > 0)) return fail(LRA_EINVAL, "fir_decimate: n_taps and down must be positive, first non-negative, div positive");
+    if (batch <= 0 || n_out <= 0) return LRA_OK;
+    if (n_in <= 0) return fail(LRA_EINVAL, "fir_decimate: empty input");
+    if (!x || !out || !taps) return fail(LRA_EINVAL, "null data pointer");
+    if (dtype != LRA_F32 && dtype != LRA_F64) return fail(LRA_EINVAL, "fir_decimate: dtype must be LRA_F32 or LRA_F64");
+    const long long count = (long long)batch * n_out;
+    if ((count + 255) / 256 > 0x7fffffffLL) return fail(LRA_EINVAL, "fir_decimate: array too large for one launch");
+    const unsigned grid = (unsigned)((count + 255) / 256);
+    if (dtype == LRA_F64)
+        hipLaunchKernelGGL(fir_decimate_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)x, (double*)out, (const double*)taps, (long long)batch, (long long)n_in,
+                           (long long)n_out, n_taps, down, first, div, mul);
+    else
+        hipLaunchKernelGGL(fir_decimate_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)x, (float*)out, (const float*)taps, (long long)batch, (long long)n_in,
+                           (long long)n_out, n_taps, down, first, div, mul);
+    LRA_HIP(hipGetLastError());
+    return LRA_OK;
+}
+
+int lra_cqt_project_exec(lra_ctx* ctx, const void* D, void* out, const void* row_ptr, const void* col, const void* val, const void* sqrt_len, int64_t batch, int64_t frames_in, int n_bins,
+                         int64_t n_frames, int n_total, int bin0, int row0, int n_rows, int dtype) {
+    LRA_BIND(ctx);
+    if (n_bins < 1 || n_total < 1 || bin0 < 0 || row0 < 0 || n_rows < 0 || bin0 + n_rows > n_total || n_frames > frames_in)
+        return fail(LRA_EINVAL, "cqt_project: the octave's rows must fit the stacked result and its frames the STFT's");
+    if (batch <= 0 || n_frames <= 0 || n_rows == 0) return LRA_OK;
+    if (!D || !out || !row_ptr || !col || !val) return fail(LRA_EINVAL, "null data pointer");
+    if (dtype != LRA_F32 && dtype != LRA_F64) return fail(LRA_EINVAL, "cqt_project: dtype must be LRA_F32 or LRA_F64");
+    const long long count = (long long)batch * n_frames * n_rows;
+    if ((count + 255) / 256 > 0x7fffffffLL) return fail(LRA_EINVAL, "cqt_project: array too large for one launch");
+    const unsigned grid = (unsigned)((count + 255) / 256);
+    if (dtype == LRA_F64)
+        hipLaunchKernelGGL(cqt_project_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream, (const CqtCplx<double>*)D, (CqtCplx<double>*)out, (const int*)row_ptr, (const int*)col,
+                           (const CqtCplx<double>*)val, (const double*)sqrt_len, (long long)batch, (long long)frames_in, n_bins, (long long)n_frames, n_total, bin0, row0, n_rows);
+    else
+        hipLaunchKernelGGL(cqt_project_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, (const CqtCplx<float>*)D, (CqtCplx<float>*)out, (const int*)row_ptr, (const int*)col,
+                           (const CqtCplx<float>*)val, (const double*)sqrt_len, (long long)batch, (long long)frames_in, n_bins, (long long)n_frames, n_total, bin0, row0, n_rows);
     LRA_HIP(hipGetLastError());
     return LRA_OK;
 }

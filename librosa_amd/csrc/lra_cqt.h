@@ -1,0 +1,89 @@
+// lra_cqt.h -- the two kernels the constant-Q / variable-Q octave recursion adds to the STFT (SURVEY.md 8f rank 4;
+// librosa/core/constantq.py:1054-1099): the FIR decimator between octaves and the sparse filter-basis projection of every frame.
+// Self-contained so that tests/hostsim/postsim.cpp can run the same kernel bodies on host threads (-DLRA_POSTSIM).
+//
+//   per octave:  D = stft(y, n_fft, hop, window="ones")                    the existing forward kernel ([clip][frame][bin])
+//                C[clip][frame][bin0 + r] = (basis[r] . D[clip][frame]) / sqrt(length[r])       cqt_project_kernel
+//                y = decimate(y, 2) * sqrt(2)                                                  fir_decimate_kernel
+#pragma once
+
+#ifndef LRA_POSTSIM
+#include <hip/hip_runtime.h>
+#endif
+
+namespace lra {
+
+template <class T> struct CqtCplx { T x, y; };
+
+// one rounding per operation, sums in the order of the host libraries (scipy's upfirdn and CSR products are plain C loops)
+#pragma clang fp contract(off)
+template <class T> struct CqtOps {
+    static __device__ __forceinline__ T madd(T acc, T a, T b) { return acc + a * b; }
+    // acc + a * b for complex a, b: (ar br - ai bi, ar bi + ai br), as scipy.sparse's complex wrapper multiplies
+    static __device__ __forceinline__ CqtCplx<T> cmadd(CqtCplx<T> acc, CqtCplx<T> a, CqtCplx<T> b) {
+        const T re = a.x * b.x - a.y * b.y;
+        const T im = a.x * b.y + a.y * b.x;
+        CqtCplx<T> r;
+        r.x = acc.x + re;
+        r.y = acc.y + im;
+        return r;
+    }
+};
+#pragma clang fp contract(fast)
+
+// ---- FIR decimator: scipy.signal.resample_poly(x, 1, down) with zero padding (librosa/core/audio.py:676-693, the resampler behind
+// constantq.py:1095-1098 and :1254-1256 for res_type="polyphase"; also the carrier of this library's own half-band design for the
+// resamplers that are not in the image) ---------------------------------------------------------------------------------------------
+//   out[clip][n] = (sum_k h[k] x[clip][(n + first) * down - k]) / div,   x = 0 outside [0, n_in),   0 <= n < n_out
+// h: the padded filter scipy hands to upfirdn (n_pre_pad zeros in front), `first` = n_pre_remove, the sum runs over ascending input
+// index like upfirdn's inner loop; div = sqrt(ratio) from resample(scale=True) (:719-720), applied in float64 as NumPy does for a
+// float64 scalar divisor (mul likewise).  A thread per output sample; neighbouring threads read overlapping input windows through L1.
+template <class T>
+__global__ __launch_bounds__(256) void fir_decimate_kernel(const T* __restrict__ x, T* __restrict__ out, const T* __restrict__ h, long long batch, long long n_in, long long n_out, int n_taps,
+                                                           int down, int first, double div, double mul) {
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= batch * n_out) return;
+    const long long clip = id / n_out, n = id % n_out;
+    const T* __restrict__ xc = x + clip * n_in;
+    const long long top = (n + first) * (long long)down;  // input index under tap 0
+    long long lo = top - (n_taps - 1);
+    if (lo < 0) lo = 0;
+    const long long hi = top < n_in - 1 ? top : n_in - 1;
+    T acc = (T)0;
+    for (long long i = lo; i <= hi; ++i) acc = CqtOps<T>::madd(acc, xc[i], h[top - i]);
+    const T scaled = (T)((double)acc / div);
+    out[id] = mul == 1.0 ? scaled : (T)((double)scaled * mul);  // `y *= sqrt(factor)` of the unscaled transform (constantq.py:1263-1264)
+}
+
+// ---- sparse basis projection: fft_basis.dot(D) of __cqt_response (constantq.py:1213-1218) and the length scaling (:1116-1118),
+// written straight into the octave's rows of the stacked result (__trim_stack, :1168-1194) ------------------------------------------
+// basis: CSR over the octave's filters (row_ptr[n_rows + 1], col[], val[]: complex, already times sqrt(sr / my_sr)); rows row0 ..
+// row0 + n_rows - 1 are used (the lowest octave may keep only its highest filters).  D: [clip][frames_in][n_bins];  out:
+// [clip][n_frames][n_total], this octave at columns bin0 ...  sqrt_len: sqrt(length) per used row (float64) or nullptr
+// (scale=False); the reference divides the complex64 result by that float64 array, which NumPy evaluates in complex128 as a
+// multiplication by the reciprocal (Smith's division with a zero imaginary divisor) before rounding back.
+// A thread per (clip, frame, row), rows fastest: the lanes of a wave share a handful of D rows (L1) and write contiguous outputs.
+template <class T>
+__global__ __launch_bounds__(256) void cqt_project_kernel(const CqtCplx<T>* __restrict__ D, CqtCplx<T>* __restrict__ out, const int* __restrict__ row_ptr, const int* __restrict__ col,
+                                                          const CqtCplx<T>* __restrict__ val, const double* __restrict__ sqrt_len, long long batch, long long frames_in, int n_bins,
+                                                          long long n_frames, int n_total, int bin0, int row0, int n_rows) {
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= batch * n_frames * n_rows) return;
+    const int r = (int)(id % n_rows);
+    const long long t = (id / n_rows) % n_frames;
+    const long long clip = id / ((long long)n_rows * n_frames);
+    const CqtCplx<T>* __restrict__ d = D + (clip * frames_in + t) * n_bins;
+    CqtCplx<T> acc;
+    acc.x = (T)0;
+    acc.y = (T)0;
+    const int j1 = row_ptr[row0 + r + 1];
+    for (int j = row_ptr[row0 + r]; j < j1; ++j) acc = CqtOps<T>::cmadd(acc, val[j], d[col[j]]);
+    if (sqrt_len) {
+        const double scl = 1.0 / sqrt_len[r];
+        acc.x = (T)((double)acc.x * scl);
+        acc.y = (T)((double)acc.y * scl);
+    }
+    out[(clip * n_frames + t) * n_total + bin0 + r] = acc;
+}
+
+}  // namespace lra

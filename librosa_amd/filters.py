@@ -105,3 +105,99 @@ def mel_cached(*, sr, n_fft, n_mels=128, fmin=0.0, fmax=None, htk=False, norm="s
     for m in msgs:
         warnings.warn(m, stacklevel=3)
     return B
+
+
+# ---------------------------------------------------------------------------------------------------
+# wavelet (constant-Q / variable-Q) filter tables: librosa/filters.py:73-113, 397-722, 838-911
+# Host-side float64 table math, like the mel basis; the device sees only the sparse frequency-domain
+# basis built from these (librosa_amd/core/constantq.py).
+# ---------------------------------------------------------------------------------------------------
+# equivalent noise bandwidths (in FFT bins) of the named windows a wavelet basis is usually built with; any other window is measured
+# on a 1000-point instance exactly as the reference does for names it has no entry for (filters.py:905-909)
+_WINDOW_ENBW = {
+    "hann": 1.50018310546875, "han": 1.50018310546875, "hamming": 1.3629455320350348, "hamm": 1.3629455320350348, "ham": 1.3629455320350348,
+    "blackman": 1.7269681554262326, "black": 1.7269681554262326, "blk": 1.7269681554262326,
+    "blackmanharris": 2.0045975283585014, "blackharr": 2.0045975283585014, "bkh": 2.0045975283585014,
+    "bartlett": 1.3334961334912805, "bart": 1.3334961334912805, "brt": 1.3334961334912805,
+    "barthann": 1.4560255965133932, "brthan": 1.4560255965133932, "bth": 1.4560255965133932,
+    "bohman": 1.7859588613860062, "bman": 1.7859588613860062, "bmn": 1.7859588613860062,
+    "boxcar": 1.0, "box": 1.0, "ones": 1.0, "rect": 1.0, "rectangular": 1.0,
+    "cosine": 1.2337005350199792, "halfcosine": 1.2337005350199792,
+    "flattop": 2.7762255046484143, "flat": 2.7762255046484143, "flt": 2.7762255046484143,
+    "nuttall": 1.9763500280946082, "nut": 1.9763500280946082, "nutl": 1.9763500280946082,
+    "parzen": 1.9174603174603191, "parz": 1.9174603174603191, "par": 1.9174603174603191,
+    "triang": 1.3331706523555851, "triangle": 1.3331706523555851, "tri": 1.3331706523555851,
+}
+
+
+def window_bandwidth(window, n=1000):
+    """Equivalent noise bandwidth of a window function, in FFT bins (``librosa.filters.window_bandwidth``, ``filters.py:838-911``)."""
+    name = getattr(window, "__name__", window)
+    try:
+        known = name in _WINDOW_ENBW
+    except TypeError:  # unhashable specification (a list / array window)
+        known = False
+    if known:
+        return _WINDOW_ENBW[name]
+    w = get_window(window, n)
+    enbw = n * np.sum(w**2) / (np.sum(w) ** 2 + _u.tiny(w))
+    if isinstance(name, (str, tuple)) or np.isscalar(name):
+        _WINDOW_ENBW[name] = enbw
+    return enbw
+
+
+def _relative_bandwidth(*, freqs):
+    """Relative bandwidth ``alpha`` per frequency from the local bins-per-octave spacing (``filters.py:555-585``)."""
+    if len(freqs) <= 1:
+        raise ParameterError(f"2 or more frequencies are required to compute bandwidths. Given freqs={freqs}")
+    log_f = np.log2(freqs)
+    density = np.empty_like(freqs)                       # bins per octave around each frequency
+    density[0] = 1 / (log_f[1] - log_f[0])
+    density[-1] = 1 / (log_f[-1] - log_f[-2])
+    density[1:-1] = 2 / (log_f[2:] - log_f[:-2])
+    step = 2.0 ** (2 / density)
+    return (step - 1) / (step + 1)
+
+
+def wavelet_lengths(*, freqs, sr=22050, window="hann", filter_scale=1, gamma=0, alpha=None):
+    """(fractional filter lengths in samples, highest frequency any filter reaches); ``librosa.filters.wavelet_lengths``
+    (``filters.py:424-551``).  ``gamma=None`` is the ERB-proportional offset ``24.7 alpha / 0.108``."""
+    freqs = np.asarray(freqs)
+    if filter_scale <= 0:
+        raise ParameterError(f"filter_scale={filter_scale} must be positive")
+    if gamma is not None and gamma < 0:
+        raise ParameterError(f"gamma={gamma} must be non-negative")
+    if np.any(freqs <= 0):
+        raise ParameterError("frequencies must be strictly positive")
+    if len(freqs) > 1 and np.any(freqs[:-1] > freqs[1:]):
+        raise ParameterError(f"Frequency array={freqs} must be in strictly ascending order")
+    alpha = _relative_bandwidth(freqs=freqs) if alpha is None else np.asarray(alpha)
+    offset = alpha * 24.7 / 0.108 if gamma is None else gamma
+    q = float(filter_scale) / alpha
+    reach = max(freqs * (1 + 0.5 * window_bandwidth(window) / q) + 0.5 * offset)
+    return q * sr / (freqs + offset / alpha), reach
+
+
+def _fractional_window(window, length):
+    """A window of fractional ``length``: the integer window of ``floor(length)`` in a ``ceil(length)`` frame (``filters.py:397-420``)."""
+    whole, frame = int(np.floor(length)), int(np.ceil(length))
+    w = get_window(window, whole)
+    if len(w) < frame:
+        w = np.pad(w, [(0, frame - len(w))], mode="constant")
+    w[whole:] = 0.0
+    return w
+
+
+def wavelet(*, freqs, sr=22050, window="hann", filter_scale=1, pad_fft=True, norm=1, dtype=np.complex64, gamma=0, alpha=None, **kwargs):
+    """Time-domain wavelet basis: one windowed complex exponential per frequency, centred in a common frame;
+    ``librosa.filters.wavelet`` (``filters.py:589-722``).  Returns ``(filters [n, frame], lengths [n])``."""
+    lengths, _ = wavelet_lengths(freqs=freqs, sr=sr, window=window, filter_scale=filter_scale, gamma=gamma, alpha=alpha)
+    rows = []
+    for length, f in zip(lengths, freqs):
+        arg = np.arange(-length // 2, length // 2, dtype=float) * 2 * np.pi * f / sr
+        tone = np.cos(arg) + 1j * np.sin(arg)
+        tone *= _fractional_window(window, len(tone))
+        rows.append(_u.normalize(tone, norm=norm))
+    longest = max(lengths)
+    frame = int(2.0 ** (np.ceil(np.log2(longest)))) if pad_fft else int(np.ceil(longest))
+    return np.asarray([_u.pad_center(r, size=frame, **kwargs) for r in rows], dtype=dtype), lengths

@@ -129,3 +129,23 @@ def normalize(S, *, norm=np.inf, axis=0, threshold=None):
     out = np.empty_like(S)
     out[...] = S / scale
     return out
+
+
+def sparsify_rows(x, *, quantile=0.01, dtype=None):
+    """Row-wise sparsification: in every row, drop the smallest-magnitude entries that together hold less than ``quantile`` of
+    the row's l1 mass; returns a ``scipy.sparse.csr_array`` (``librosa.util.sparsify_rows``, ``util/utils.py:1500-1597``)."""
+    import scipy.sparse
+
+    x = np.asarray(x)
+    if x.ndim == 1:
+        x = x.reshape((1, -1))
+    elif x.ndim > 2:
+        raise ParameterError(f"Input must have 2 or fewer dimensions. Provided x.shape={x.shape}.")
+    if not 0.0 <= quantile < 1:
+        raise ParameterError(f"Invalid quantile {quantile:.2f}")
+    out_dtype = np.dtype(x.dtype if dtype is None else dtype)
+    magnitude = np.abs(x)
+    ascending = np.sort(magnitude, axis=1)
+    share = np.cumsum(ascending / np.sum(magnitude, axis=1, keepdims=True), axis=1)
+    cut = ascending[np.arange(x.shape[0]), np.argmin(share < quantile, axis=1)]          # per row: the smallest magnitude kept
+    return scipy.sparse.csr_array((x * (magnitude >= cut[:, np.newaxis])).astype(out_dtype, copy=False))

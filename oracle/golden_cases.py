@@ -108,3 +108,17 @@ def pcen_inputs(g):
 
     M, A = g["M"], g["A"]
     return dict(M=M, A=A, A64=A.astype(np.float64), At=np.ascontiguousarray(A.T), Mt=np.ascontiguousarray(np.swapaxes(M, 1, 2)))
+
+
+CQT_CASES = {
+    # name: (function, signal (kind, n, seed, channels, dtype), kwargs); all with res_type="polyphase" (the resampler both sides can run)
+    "cqt_default": ("cqt", ("mix", 33075, 91, None, "float32"), dict()),
+    "cqt_stereo_60": ("cqt", ("mix", 20000, 92, (2,), "float32"), dict(hop_length=256, n_bins=60)),
+    "cqt_early_downsample": ("cqt", ("chirp", 33075, 93, None, "float32"), dict(n_bins=24)),
+    "cqt_partial_octave": ("cqt", ("mix", 22050, 94, None, "float32"), dict(n_bins=30, fmin=65.4, tuning=0.25, norm=2, scale=False)),
+    "cqt_f64": ("cqt", ("mix", 22050, 95, None, "float64"), dict(n_bins=48, bins_per_octave=24, fmin=220.0)),
+    "cqt_hamming_reflect": ("cqt", ("mix", 22050, 96, None, "float32"), dict(filter_scale=0.5, pad_mode="reflect", window="hamming", sparsity=0.05)),
+    "vqt_default": ("vqt", ("mix", 22050, 97, None, "float32"), dict()),
+    "vqt_gamma_36": ("vqt", ("mix", 22050, 98, (2,), "float32"), dict(gamma=5.0, bins_per_octave=36, n_bins=108, hop_length=128)),
+    "vqt_intervals": ("vqt", ("mix", 22050, 99, None, "float32"), dict(intervals=[1.0, 1.2, 1.5, 1.8], n_bins=16, fmin=200.0, gamma=0)),
+}

@@ -91,6 +91,7 @@ def main():
     make_griffinlim(librosa, meta)
     make_vocoder(librosa, meta)
     make_pcen(librosa, meta)
+    make_cqt(librosa, meta)
 
 
 def make_vocoder(librosa, meta):
@@ -137,6 +138,16 @@ def make_pcen(librosa, meta):
     print("pcen done")
 
 
+def make_cqt(librosa, meta):
+    """librosa.cqt / librosa.vqt outputs of the reference (res_type="polyphase": soxr is not in the image)."""
+    store = {}
+    for name, (fn, (kind, n, seed, channels, dtype), kw) in golden_cases.CQT_CASES.items():
+        y = golden_cases.make_signal(kind, n, seed, channels, dtype)
+        store[name] = getattr(librosa, fn)(y, sr=golden_cases.SR, res_type="polyphase", **kw)
+    np.savez_compressed(os.path.join(OUT, "cqt.npz"), params=json.dumps(dict(case="cqt", **meta)), **store)
+    print("cqt done")
+
+
 def make_griffinlim(librosa, meta):
     """librosa.griffinlim outputs of the reference on |stft| of seeded signals."""
     store = {}
@@ -180,11 +191,11 @@ def make_db_mfcc(librosa, meta):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("griffinlim", "vocoder", "pcen"):  # only this fixture (the others are unchanged)
+    if len(sys.argv) > 1 and sys.argv[1] in ("griffinlim", "vocoder", "pcen", "cqt"):  # only this fixture (the others are unchanged)
         _librosa = ref_shim.load_reference()
         import scipy as _scipy
 
         _meta = dict(numpy=np.__version__, scipy=_scipy.__version__, reference_version=str(_librosa.__version__))
-        dict(griffinlim=make_griffinlim, vocoder=make_vocoder, pcen=make_pcen)[sys.argv[1]](_librosa, _meta)
+        dict(griffinlim=make_griffinlim, vocoder=make_vocoder, pcen=make_pcen, cqt=make_cqt)[sys.argv[1]](_librosa, _meta)
     else:
         main()

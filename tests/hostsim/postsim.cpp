@@ -1,4 +1,5 @@
-// postsim.cpp -- runs the PCEN / band max-filter kernel bodies of librosa_amd/csrc/lra_pcen.h on host threads.
+// postsim.cpp -- runs the PCEN / band max-filter kernel bodies of librosa_amd/csrc/lra_pcen.h and the constant-Q kernels of lra_cqt.h on
+// host threads.
 //
 // TEST INFRASTRUCTURE ONLY.  Built by tests/test_hostsim.py (g++ -DLRA_POSTSIM -pthread) into tests/hostsim/_postsim.so.  One OS
 // thread per lane of a workgroup, __syncthreads() is a barrier across them, __shared__ is a static the lanes share; workgroups run
@@ -47,6 +48,7 @@ using std::log;
 using std::log1p;
 
 #include "../../librosa_amd/csrc/lra_pcen.h"
+#include "../../librosa_amd/csrc/lra_cqt.h"
 
 namespace {
 template <class F> void run_grid(unsigned grid, unsigned block, F body) {
@@ -61,6 +63,15 @@ template <class F> void run_grid(unsigned grid, unsigned block, F body) {
             });
         for (auto& l : lanes) l.join();
     }
+}
+// kernels without __syncthreads: the lanes of a workgroup one after the other on the calling thread
+template <class F> void run_grid_serial(unsigned grid, unsigned block, F body) {
+    for (unsigned b = 0; b < grid; ++b)
+        for (unsigned t = 0; t < block; ++t) {
+            threadIdx.x = t;
+            blockIdx.x = b;
+            body();
+        }
 }
 }  // namespace
 
@@ -91,9 +102,35 @@ int postsim_maxfilter(const void* S, void* out, long long outer, int n_bands, lo
     const long long count = outer * n_bands * inner;
     const unsigned grid = (unsigned)((count + 255) / 256);
     if (is_f64)
-        run_grid(grid, 256, [=] { lra::maxfilter_bands_kernel<double>((const double*)S, (double*)out, outer, n_bands, inner, size); });
+        run_grid_serial(grid, 256, [=] { lra::maxfilter_bands_kernel<double>((const double*)S, (double*)out, outer, n_bands, inner, size); });
     else
-        run_grid(grid, 256, [=] { lra::maxfilter_bands_kernel<float>((const float*)S, (float*)out, outer, n_bands, inner, size); });
+        run_grid_serial(grid, 256, [=] { lra::maxfilter_bands_kernel<float>((const float*)S, (float*)out, outer, n_bands, inner, size); });
+    return 0;
+}
+
+// the launches of lra_fir_decimate_exec / lra_cqt_project_exec (lra_api.hip)
+int postsim_fir_decimate(const void* x, void* out, long long batch, long long n_in, long long n_out, const void* taps, int n_taps, int down, int first, double div, double mul, int is_f64) {
+    const unsigned grid = (unsigned)((batch * n_out + 255) / 256);
+    if (is_f64)
+        run_grid_serial(grid, 256, [=] { lra::fir_decimate_kernel<double>((const double*)x, (double*)out, (const double*)taps, batch, n_in, n_out, n_taps, down, first, div, mul); });
+    else
+        run_grid_serial(grid, 256, [=] { lra::fir_decimate_kernel<float>((const float*)x, (float*)out, (const float*)taps, batch, n_in, n_out, n_taps, down, first, div, mul); });
+    return 0;
+}
+
+int postsim_cqt_project(const void* D, void* out, const int* row_ptr, const int* col, const void* val, const double* sqrt_len, long long batch, long long frames_in, int n_bins,
+                        long long n_frames, int n_total, int bin0, int row0, int n_rows, int is_f64) {
+    const unsigned grid = (unsigned)((batch * n_frames * n_rows + 255) / 256);
+    if (is_f64)
+        run_grid_serial(grid, 256, [=] {
+            lra::cqt_project_kernel<double>((const lra::CqtCplx<double>*)D, (lra::CqtCplx<double>*)out, row_ptr, col, (const lra::CqtCplx<double>*)val, sqrt_len, batch, frames_in, n_bins,
+                                            n_frames, n_total, bin0, row0, n_rows);
+        });
+    else
+        run_grid_serial(grid, 256, [=] {
+            lra::cqt_project_kernel<float>((const lra::CqtCplx<float>*)D, (lra::CqtCplx<float>*)out, row_ptr, col, (const lra::CqtCplx<float>*)val, sqrt_len, batch, frames_in, n_bins, n_frames,
+                                           n_total, bin0, row0, n_rows);
+        });
     return 0;
 }
 }

@@ -139,13 +139,15 @@ _post = None
 def post_lib():
     global _post
     if _post is None:
-        deps = [POST_SRC, os.path.join(CSRC, "lra_pcen.h")]
+        deps = [POST_SRC, os.path.join(CSRC, "lra_pcen.h"), os.path.join(CSRC, "lra_cqt.h")]
         if not os.path.exists(POST_SO) or any(os.path.getmtime(d) > os.path.getmtime(POST_SO) for d in deps):
             subprocess.check_call(["g++", "-O1", "-std=c++17", "-w", "-fPIC", "-shared", "-pthread", POST_SRC, "-o", POST_SO])
         _post = ctypes.CDLL(POST_SO)
         c = ctypes
         _post.postsim_pcen.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_longlong, c.c_longlong, c.c_int] + [c.c_double] * 5 + [c.c_void_p, c.c_double, c.c_void_p]
         _post.postsim_maxfilter.argtypes = [c.c_void_p, c.c_void_p, c.c_longlong, c.c_int, c.c_longlong, c.c_int, c.c_int]
+        _post.postsim_fir_decimate.argtypes = [c.c_void_p, c.c_void_p, c.c_longlong, c.c_longlong, c.c_longlong, c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_double, c.c_double, c.c_int]
+        _post.postsim_cqt_project.argtypes = [c.c_void_p] * 6 + [c.c_longlong, c.c_longlong, c.c_int, c.c_longlong, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int]
     return _post
 
 
@@ -166,4 +168,24 @@ def maxfilter(S, size):
     S = np.ascontiguousarray(S)
     out = np.empty_like(S)
     post_lib().postsim_maxfilter(_p(S), _p(out), S.shape[0], S.shape[1], S.shape[2], int(size), int(S.dtype == np.float64))
+    return out
+
+
+def fir_decimate(x, taps, down, first, n_out, div=1.0, mul=1.0):
+    """x: (batch, n_in) -> (batch, n_out) through the kernel body of lra_fir_decimate_exec."""
+    x = np.ascontiguousarray(x)
+    taps = np.ascontiguousarray(taps, dtype=x.dtype)
+    out = np.full((x.shape[0], n_out), np.nan, dtype=x.dtype)
+    post_lib().postsim_fir_decimate(_p(x), _p(out), x.shape[0], x.shape[1], n_out, _p(taps), len(taps), int(down), int(first), float(div), float(mul), int(x.dtype == np.float64))
+    return out
+
+
+def cqt_project(D, csr, n_frames, n_total, bin0, row0, n_rows, sqrt_len=None):
+    """D: (batch, frames_in, n_bins) complex -> the octave's rows of a (batch, n_frames, n_total) result (zeros elsewhere)."""
+    D = np.ascontiguousarray(D)
+    out = np.zeros((D.shape[0], n_frames, n_total), dtype=D.dtype)
+    rp, col = np.ascontiguousarray(csr.indptr, dtype=np.int32), np.ascontiguousarray(csr.indices, dtype=np.int32)
+    val = np.ascontiguousarray(csr.data, dtype=D.dtype)
+    sl = None if sqrt_len is None else np.ascontiguousarray(sqrt_len, dtype=np.float64)
+    post_lib().postsim_cqt_project(_p(D), _p(out), _p(rp), _p(col), _p(val), _p(sl), D.shape[0], D.shape[1], D.shape[2], n_frames, n_total, bin0, row0, n_rows, int(D.dtype == np.complex128))
     return out

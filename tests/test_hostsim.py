@@ -303,6 +303,47 @@ def test_maxfilter_body(dtype):
             assert np.array_equal(H.maxfilter(X, size), O.maximum_filter1d(X, size, 1)), (shape, size)
 
 
+class _SimCtx:
+    """The entry points of librosa_amd._native.Context that the PCEN and constant-Q shims call, on host memory: the kernels of
+    lra_pcen.h / lra_cqt.h through the simulator, the STFT through the oracle (the forward kernel bodies have their own cases above)."""
+
+    @staticmethod
+    def _view(ptr, shape, dtype):
+        import ctypes
+
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        return np.frombuffer((ctypes.c_char * n).from_address(ptr), dtype=dtype).reshape(shape)
+
+    def nonfinite_reset(self):
+        pass
+
+    def nonfinite_read(self):
+        return False
+
+    def stft_plan(self, n_fft, hop, window, center, pad_mode, dtype):
+        return dict(n_fft=int(n_fft), hop=int(hop), window=np.asarray(window), center=center, pad_mode=pad_mode, dtype=np.dtype(dtype))
+
+    def stft_exec(self, plan, y_ptr, batch, n, y_stride, out_ptr):
+        y = self._view(y_ptr, (batch, n), plan["dtype"])
+        # a float64 window, as the reference holds it: the product of window and frame, and with it the FFT, is then float64 (core/spectrum.py:264, 372)
+        D = O.stft(y, n_fft=plan["n_fft"], hop_length=plan["hop"], window=plan["window"].astype(np.float64), center=plan["center"], pad_mode=plan["pad_mode"])   # (batch, bins, frames)
+        self._view(out_ptr, (batch, D.shape[-1], D.shape[-2]), D.dtype)[...] = np.swapaxes(D, -1, -2)
+
+    def fir_decimate_exec(self, x_ptr, out_ptr, batch, n_in, n_out, taps_ptr, n_taps, down, first, div, mul, dtype):
+        H.post_lib().postsim_fir_decimate(x_ptr, out_ptr, batch, n_in, n_out, taps_ptr, int(n_taps), int(down), int(first), float(div), float(mul), int(np.dtype(dtype) == np.float64))
+
+    def cqt_project_exec(self, d_ptr, out_ptr, row_ptr, col_ptr, val_ptr, sqrt_len_ptr, batch, frames_in, n_bins, n_frames, n_total, bin0, row0, n_rows, dtype):
+        H.post_lib().postsim_cqt_project(d_ptr, out_ptr, row_ptr, col_ptr, val_ptr, sqrt_len_ptr, batch, frames_in, int(n_bins), n_frames, int(n_total), int(bin0), int(row0), int(n_rows),
+                                         int(np.dtype(dtype) == np.float64))
+
+    def pcen_exec(self, s_ptr, ref_ptr, out_ptr, rows, n_frames, dtype, b, gain, bias, power, eps, zi_ptr, zi_scalar, zf_ptr):
+        H.post_lib().postsim_pcen(s_ptr, ref_ptr, out_ptr, rows, n_frames, int(np.dtype(dtype) == np.float64), float(b), float(gain), float(bias), float(power), float(eps), zi_ptr,
+                                  float(zi_scalar), zf_ptr)
+
+    def maxfilter_exec(self, s_ptr, out_ptr, outer, n_bands, inner, size, dtype):
+        H.post_lib().postsim_maxfilter(s_ptr, out_ptr, outer, n_bands, inner, int(size), int(np.dtype(dtype) == np.float64))
+
+
 class _SimSession:
     """Stands in for librosa_amd._arrays.Session in the CPU test below: host arrays instead of device buffers, and a context whose
     pcen / max-filter entry points run the kernel bodies on host threads (the argument order of librosa_amd._native.Context)."""
@@ -311,7 +352,7 @@ class _SimSession:
 
     def __init__(self, like):
         self._keep = []
-        self.ctx = self
+        self.ctx = _SimCtx()
 
     def input_raw(self, a, dtype):
         a = np.ascontiguousarray(a, dtype=dtype)
@@ -333,12 +374,27 @@ class _SimSession:
     def close(self):
         pass
 
-    def pcen_exec(self, s_ptr, ref_ptr, out_ptr, rows, n_frames, dtype, b, gain, bias, power, eps, zi_ptr, zi_scalar, zf_ptr):
-        H.post_lib().postsim_pcen(s_ptr, ref_ptr, out_ptr, rows, n_frames, int(np.dtype(dtype) == np.float64), float(b), float(gain), float(bias), float(power), float(eps), zi_ptr,
-                                  float(zi_scalar), zf_ptr)
+    def input_2d(self, x, dtype):
+        a = np.ascontiguousarray(x, dtype=dtype).reshape(-1, x.shape[-1])
+        self._keep.append(a)
+        return a.ctypes.data, a.shape[0], a.shape[1], a.shape[1]
 
-    def maxfilter_exec(self, s_ptr, out_ptr, outer, n_bands, inner, size, dtype):
-        H.post_lib().postsim_maxfilter(s_ptr, out_ptr, outer, n_bands, inner, int(size), int(np.dtype(dtype) == np.float64))
+
+def _sim_torch_session(real_session):
+    """librosa_amd._arrays.Session's own tensor marshalling (input_2d / input_raw / output / scratch / result), on CPU tensors whose
+    data_ptr() the simulator can read: the device-tensor code paths of the shims run in the CPU suite."""
+    import torch
+
+    class _SimTorchSession(real_session):
+        def __init__(self, like):
+            assert isinstance(like, torch.Tensor)
+            self.is_torch = True
+            self._keep = []
+            self._locked = False
+            self.device = torch.device("cpu")
+            self.ctx = _SimCtx()
+
+    return _SimTorchSession
 
 
 def test_pcen_shim_layouts_through_simulator(monkeypatch):
@@ -370,3 +426,130 @@ def test_pcen_shim_layouts_through_simulator(monkeypatch):
         librosa_amd.pcen(X[0], zi=np.zeros((3, 1)))
     with pytest.raises(librosa_amd.ParameterError):
         librosa_amd.pcen(X[0], ref=np.ones((3, 3)))
+
+
+# ---- constant-Q kernels (librosa_amd/csrc/lra_cqt.h) on the host ---------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("down,n", [(2, 1), (2, 41), (2, 1000), (2, 1001), (4, 999), (8, 4096), (3, 500)])
+def test_fir_decimate_body_is_resample_poly(dtype, down, n):
+    """The decimator with scipy's own design and alignment == scipy.signal.resample_poly(x, 1, down), bit for bit (same taps,
+    same summation order, no contraction), incl. the scale=True division of librosa.resample."""
+    import scipy.signal
+    from librosa_amd.core.constantq import _decimator
+
+    rng = np.random.default_rng(down * 7919 + n)
+    x = rng.standard_normal((3, n)).astype(dtype)
+    taps, first = _decimator(down, "polyphase", np.dtype(dtype))
+    n_out = -(-n // down)
+    got = H.fir_decimate(x, taps, down, first, n_out)
+    assert np.array_equal(got, scipy.signal.resample_poly(x, 1, down, axis=-1))
+    import cqt_oracle as CQ
+
+    got = H.fir_decimate(x, taps, down, first, n_out, div=np.sqrt(1.0 / down))
+    assert np.array_equal(got, CQ.resample(x, orig_sr=down, target_sr=1, res_type="polyphase", scale=True))
+
+
+def test_own_decimator_design():
+    """The default decimator (soxr-HQ band edges): unit DC gain, pass band flat to 1e-5 up to 0.913 of the new Nyquist, more than
+    120 dB down from the new Nyquist on, integer alignment (a centred impulse stays centred)."""
+    import scipy.signal
+    from librosa_amd.core.constantq import _decimator
+
+    for down in (2, 4, 8):
+        taps, first = _decimator(down, "soxr_hq", np.dtype(np.float64))
+        assert len(taps) % 2 == 1 and (len(taps) // 2) == first * down and np.allclose(taps, taps[::-1])
+        w, h = scipy.signal.freqz(taps, worN=1 << 15)
+        f = w / np.pi * down                              # in units of the new Nyquist
+        mag = np.abs(h)
+        assert abs(mag[0] - 1) < 1e-12 and np.all(np.abs(mag[f <= 0.913] - 1) < 1e-5) and np.all(mag[f >= 1.0] < 1e-6)
+        x = np.zeros((1, 64 * down + 1))
+        x[0, 32 * down] = 1.0
+        y = H.fir_decimate(x, taps, down, first, -(-x.shape[1] // down))
+        assert np.argmax(np.abs(y[0])) == 32 and abs(y[0, 32] - taps[len(taps) // 2]) < 1e-15
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_cqt_project_body(dtype):
+    """Sparse basis x frames + length scaling + stacking offsets against scipy.sparse's product on the same arrays."""
+    import scipy.sparse
+
+    rng = np.random.default_rng(12)
+    n_bins, rows = 129, 12
+    dense = (rng.standard_normal((rows, n_bins)) + 1j * rng.standard_normal((rows, n_bins))) * (rng.random((rows, n_bins)) < 0.15)
+    csr = scipy.sparse.csr_array(dense.astype(dtype))
+    D = (rng.standard_normal((2, 37, n_bins)) + 1j * rng.standard_normal((2, 37, n_bins))).astype(dtype)
+    sqrt_len = np.sqrt(rng.random(rows) * 100 + 1)
+    for (n_frames, n_total, bin0, row0, n_rows, scaled) in ((37, 40, 20, 0, 12, True), (30, 12, 0, 0, 12, False), (37, 7, 0, 5, 7, True), (1, 30, 18, 0, 12, True)):
+        got = H.cqt_project(D, csr, n_frames, n_total, bin0, row0, n_rows, sqrt_len[row0 : row0 + n_rows] if scaled else None)
+        exp = np.zeros_like(got)
+        for b in range(2):
+            block = csr.dot(D[b].T)[row0 : row0 + n_rows, :n_frames]           # (rows, frames), scipy's own accumulation order
+            if scaled:
+                block = (block / sqrt_len[row0 : row0 + n_rows, None]).astype(dtype)
+            exp[b, :, bin0 : bin0 + n_rows] = block.T
+        assert np.array_equal(got, exp), (n_frames, n_total, bin0, row0)
+
+
+@pytest.mark.filterwarnings("ignore:n_fft=")
+def test_cqt_shim_through_simulator(monkeypatch):
+    """librosa_amd.cqt / vqt's host side (tables, octave schedule, early downsampling, stacking, scaling) with the decimator and the
+    projection run by the simulator and the STFT by the oracle: bit for bit the oracle's transform for res_type="polyphase"."""
+    import cqt_oracle as CQ
+    import golden_cases
+    import librosa_amd
+    from librosa_amd import _arrays
+
+    monkeypatch.setattr(_arrays, "Session", _SimSession)
+    y = golden_cases.make_signal("mix", 22050, 3, None, "float32")
+    ys = golden_cases.make_signal("mix", 9000, 4, (2,), "float32")
+    for kw in (dict(), dict(hop_length=256, n_bins=60), dict(n_bins=24), dict(n_bins=30, bins_per_octave=12), dict(scale=False, n_bins=24), dict(fmin=110.0, n_bins=36, tuning=0.2, norm=2),
+               dict(filter_scale=0.5, pad_mode="reflect", window="hamming", sparsity=0.05), dict(n_bins=1)):
+        got = librosa_amd.cqt(y, res_type="polyphase", **kw)
+        exp = CQ.cqt(y, res_type="polyphase", **kw)
+        assert got.shape == exp.shape and got.dtype == exp.dtype and np.array_equal(got, exp), kw
+    for kw in (dict(gamma=None, bins_per_octave=24, n_bins=96), dict(gamma=5, scale=False), dict(intervals=[1, 1.2, 1.5, 1.8], n_bins=16, fmin=200.0, gamma=0)):
+        assert np.array_equal(librosa_amd.vqt(ys, res_type="polyphase", **kw), CQ.vqt(ys, res_type="polyphase", **kw)), kw
+    y64 = y.astype(np.float64)
+    got, exp = librosa_amd.cqt(y64, res_type="polyphase", n_bins=48), CQ.cqt(y64, res_type="polyphase", n_bins=48)
+    assert got.dtype == np.complex128 and np.array_equal(got, exp)
+    for bad in (dict(tuning=None), dict(n_bins=None), dict(fmin=20000.0), dict(n_bins=200), dict(pad_mode="wrap"), dict(hop_length=0)):
+        with pytest.raises(librosa_amd.ParameterError):
+            librosa_amd.cqt(y, **bad)
+    with pytest.raises(librosa_amd.ParameterError):
+        librosa_amd.vqt(y, intervals="pythagorean")
+
+
+@pytest.mark.filterwarnings("ignore:n_fft=")
+def test_tensor_code_paths_through_simulator(monkeypatch):
+    """The device-tensor branches of librosa_amd.pcen / cqt (tensor marshalling, table uploads, carried state as a tensor, results
+    as tensors), exercised on CPU tensors: same values as the NumPy branches."""
+    import torch
+
+    import golden_cases
+    import librosa_amd
+    from librosa_amd import _arrays
+
+    rng = np.random.default_rng(31)
+    X = (rng.standard_normal((2, 20, 33)) ** 2).astype(np.float32)
+    y = golden_cases.make_signal("mix", 12000, 8, (2,), "float32")
+    real_session = _arrays.Session
+    monkeypatch.setattr(_arrays, "Session", _SimSession)
+    host = dict(p=librosa_amd.pcen(X), pm=librosa_amd.pcen(X, max_size=3, max_axis=1, axis=2), pz=librosa_amd.pcen(X[..., :10], return_zf=True), pt=librosa_amd.pcen(X, axis=1),
+                c=librosa_amd.cqt(y, res_type="polyphase", n_bins=48), v=librosa_amd.vqt(y, n_bins=36, scale=False))
+    monkeypatch.setattr(_arrays, "Session", _sim_torch_session(real_session))
+    Xt, yt = torch.from_numpy(X), torch.from_numpy(y)
+    p = librosa_amd.pcen(Xt)
+    assert isinstance(p, torch.Tensor) and p.dtype == torch.float64 and np.array_equal(p.numpy(), host["p"])
+    assert np.array_equal(librosa_amd.pcen(Xt, max_size=3, max_axis=1, axis=2).numpy(), host["pm"])
+    assert np.array_equal(librosa_amd.pcen(Xt, axis=1).numpy(), host["pt"])
+    p1, z1 = librosa_amd.pcen(Xt[..., :10], return_zf=True)
+    assert isinstance(z1, torch.Tensor) and np.array_equal(p1.numpy(), host["pz"][0]) and np.array_equal(z1.numpy(), host["pz"][1])
+    p2 = librosa_amd.pcen(Xt[..., 10:], zi=z1)                       # tensor state
+    p2h = librosa_amd.pcen(Xt[..., 10:], zi=host["pz"][1])           # host state, tensor data
+    assert np.array_equal(p2.numpy(), p2h.numpy()) and np.allclose(torch.cat([p1, p2], dim=-1).numpy(), host["p"], rtol=1e-12, atol=0)
+    assert np.array_equal(librosa_amd.pcen(Xt.to(torch.int32)).numpy(), librosa_amd.pcen(torch.from_numpy(X.astype(np.int32).astype(np.float64))).numpy())
+    c = librosa_amd.cqt(yt, res_type="polyphase", n_bins=48)
+    assert isinstance(c, torch.Tensor) and c.dtype == torch.complex64 and tuple(c.shape) == host["c"].shape and np.array_equal(c.numpy(), host["c"])
+    assert np.array_equal(librosa_amd.vqt(yt, n_bins=36, scale=False).numpy(), host["v"])
+    with pytest.raises(librosa_amd.ParameterError):
+        librosa_amd.cqt(yt.to(torch.int32))

@@ -330,3 +330,45 @@ def test_pcen_oracle_live_reference():
     for kw in (dict(), dict(axis=1), dict(max_size=3, max_axis=1), dict(power=0, b=0.3), dict(bias=0, power=2)):
         assert np.array_equal(O.pcen(X, **kw), L.pcen(X, **kw)), kw
     assert np.array_equal(O.pcen(np.arange(100)), L.pcen(np.arange(100)))
+
+
+# ---- constant-Q / variable-Q transform ---------------------------------------------------------------------
+import cqt_oracle as CQ  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(golden_cases.CQT_CASES))
+def test_cqt_oracle_matches_reference_golden(name):
+    """librosa.cqt / vqt (core/constantq.py:42-225, 820-1122) restated -- wavelet tables, sparsification, octave recursion, stacking --
+    vs outputs of the unmodified reference (oracle/make_golden.py::make_cqt): bit for bit."""
+    fn, (kind, n, seed, channels, dtype), kw = golden_cases.CQT_CASES[name]
+    g = np.load(os.path.join(GOLDEN_DIR, "cqt.npz"))
+    y = golden_cases.make_signal(kind, n, seed, channels, dtype)
+    got = getattr(CQ, fn)(y, sr=golden_cases.SR, res_type="polyphase", **kw)
+    assert got.shape == g[name].shape and got.dtype == g[name].dtype and np.array_equal(got, g[name])
+
+
+def test_cqt_oracle_known_answers():
+    """What the reference's tests assert about the transform itself (tests/test_constantq.py: shape and dtype, the energy of a pure tone
+    sits in its bin, an impulse gives a flat column) and about its tables (filters.wavelet_lengths vs constant_q lengths)."""
+    sr = 22050
+    for midi in (36, 60, 81):
+        f = 440.0 * 2.0 ** ((midi - 69) / 12)
+        y = np.sin(2 * np.pi * f * np.arange(sr) / sr).astype(np.float32)
+        C = np.abs(CQ.cqt(y, sr=sr))
+        assert C.shape == (84, 1 + sr // 512) and np.all(np.argmax(C[:, 5:-5], axis=0) == midi - 24)
+    freqs = CQ.interval_frequencies(84, fmin=CQ.C1_HZ, bins_per_octave=12)
+    assert np.allclose(freqs[12::12] / freqs[:-12:12], 2.0) and abs(freqs[0] - 32.7032) < 1e-4
+    lengths, cutoff = CQ.wavelet_lengths(freqs=freqs, sr=sr)
+    assert np.all(np.diff(lengths) < 0) and cutoff < sr / 2
+    basis, l2 = CQ.wavelet(freqs=freqs[-12:], sr=sr)
+    assert basis.shape == (12, 256) and np.allclose(l2, lengths[-12:], rtol=1e-9) and np.allclose(np.sum(np.abs(basis), axis=1), 1.0, atol=1e-6)   # norm=1
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="/root/reference not present (GPU box)")
+def test_cqt_oracle_live_reference():
+    L = ref_shim.load_reference()
+    y = golden_cases.make_signal("mix", 16000, 5, (2,), "float32")
+    for rt in ("polyphase", "fft"):
+        for kw in (dict(), dict(n_bins=36, hop_length=64), dict(scale=False, n_bins=24)):
+            assert np.array_equal(CQ.cqt(y, sr=22050, res_type=rt, **kw), L.cqt(y, sr=22050, res_type=rt, **kw)), (rt, kw)
+        assert np.array_equal(CQ.vqt(y, sr=22050, res_type=rt, gamma=None), L.vqt(y, sr=22050, res_type=rt))
