@@ -1988,15 +1988,30 @@ int lra_fir_decimate_exec(lra_ctx* ctx, const void* x, void* out, int64_t batch,
     if (n_in <= 0) return fail(LRA_EINVAL, "fir_decimate: empty input");
     if (!x || !out || !taps) return fail(LRA_EINVAL, "null data pointer");
     if (dtype != LRA_F32 && dtype != LRA_F64) return fail(LRA_EINVAL, "fir_decimate: dtype must be LRA_F32 or LRA_F64");
-    const long long count = (long long)batch * n_out;
-    if ((count + 255) / 256 > 0x7fffffffLL) return fail(LRA_EINVAL, "fir_decimate: array too large for one launch");
-    const unsigned grid = (unsigned)((count + 255) / 256);
+    const long long blocks_per_clip = (n_out + 255) / 256;
+    if (blocks_per_clip * batch > 0x7fffffffLL) return fail(LRA_EINVAL, "fir_decimate: array too large for one launch");
+    const size_t elem = dtype == LRA_F64 ? 8 : 4;
+    const size_t lds = ((size_t)255 * down + n_taps) * elem;  // the workgroup's input span
+    if (lds > 64 * 1024) {  // span too long to stage: the direct kernel
+        const long long count = (long long)batch * n_out;
+        if ((count + 255) / 256 > 0x7fffffffLL) return fail(LRA_EINVAL, "fir_decimate: array too large for one launch");
+        const unsigned dgrid = (unsigned)((count + 255) / 256);
+        if (dtype == LRA_F64)
+            hipLaunchKernelGGL(fir_decimate_direct_kernel<double>, dim3(dgrid), dim3(256), 0, ctx->stream, (const double*)x, (double*)out, (const double*)taps, (long long)batch, (long long)n_in,
+                               (long long)n_out, n_taps, down, first, div, mul);
+        else
+            hipLaunchKernelGGL(fir_decimate_direct_kernel<float>, dim3(dgrid), dim3(256), 0, ctx->stream, (const float*)x, (float*)out, (const float*)taps, (long long)batch, (long long)n_in,
+                               (long long)n_out, n_taps, down, first, div, mul);
+        LRA_HIP(hipGetLastError());
+        return LRA_OK;
+    }
+    const unsigned grid = (unsigned)(blocks_per_clip * batch);
     if (dtype == LRA_F64)
-        hipLaunchKernelGGL(fir_decimate_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)x, (double*)out, (const double*)taps, (long long)batch, (long long)n_in,
-                           (long long)n_out, n_taps, down, first, div, mul);
+        hipLaunchKernelGGL(fir_decimate_kernel<double>, dim3(grid), dim3(256), lds, ctx->stream, (const double*)x, (double*)out, (const double*)taps, (long long)n_in, (long long)n_out,
+                           (int)blocks_per_clip, n_taps, down, first, div, mul);
     else
-        hipLaunchKernelGGL(fir_decimate_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)x, (float*)out, (const float*)taps, (long long)batch, (long long)n_in,
-                           (long long)n_out, n_taps, down, first, div, mul);
+        hipLaunchKernelGGL(fir_decimate_kernel<float>, dim3(grid), dim3(256), lds, ctx->stream, (const float*)x, (float*)out, (const float*)taps, (long long)n_in, (long long)n_out,
+                           (int)blocks_per_clip, n_taps, down, first, div, mul);
     LRA_HIP(hipGetLastError());
     return LRA_OK;
 }

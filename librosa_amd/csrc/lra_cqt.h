@@ -37,10 +37,12 @@ template <class T> struct CqtOps {
 //   out[clip][n] = (sum_k h[k] x[clip][(n + first) * down - k]) / div,   x = 0 outside [0, n_in),   0 <= n < n_out
 // h: the padded filter scipy hands to upfirdn (n_pre_pad zeros in front), `first` = n_pre_remove, the sum runs over ascending input
 // index like upfirdn's inner loop; div = sqrt(ratio) from resample(scale=True) (:719-720), applied in float64 as NumPy does for a
-// float64 scalar divisor (mul likewise).  A thread per output sample; neighbouring threads read overlapping input windows through L1.
+// float64 scalar divisor (mul likewise).
+// Fallback for spans that do not fit the LDS (large early-downsampling factors): a thread per output sample reading the signal
+// directly; neighbouring threads read overlapping windows through L1.  Same sum, same order.
 template <class T>
-__global__ __launch_bounds__(256) void fir_decimate_kernel(const T* __restrict__ x, T* __restrict__ out, const T* __restrict__ h, long long batch, long long n_in, long long n_out, int n_taps,
-                                                           int down, int first, double div, double mul) {
+__global__ __launch_bounds__(256) void fir_decimate_direct_kernel(const T* __restrict__ x, T* __restrict__ out, const T* __restrict__ h, long long batch, long long n_in, long long n_out,
+                                                                  int n_taps, int down, int first, double div, double mul) {
     const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
     if (id >= batch * n_out) return;
     const long long clip = id / n_out, n = id % n_out;
@@ -52,7 +54,43 @@ __global__ __launch_bounds__(256) void fir_decimate_kernel(const T* __restrict__
     T acc = (T)0;
     for (long long i = lo; i <= hi; ++i) acc = CqtOps<T>::madd(acc, xc[i], h[top - i]);
     const T scaled = (T)((double)acc / div);
-    out[id] = mul == 1.0 ? scaled : (T)((double)scaled * mul);  // `y *= sqrt(factor)` of the unscaled transform (constantq.py:1263-1264)
+    out[id] = mul == 1.0 ? scaled : (T)((double)scaled * mul);
+}
+
+// A workgroup produces 256 consecutive outputs of one clip: their common input span (255 down + n_taps samples) is staged in LDS
+// once (zeros outside the signal: adding 0 * h leaves the running sum unchanged), every thread then walks its n_taps-long window of
+// it; the tap index is the same for all lanes in each step, so the taps come through the scalar cache.
+#ifdef LRA_POSTSIM
+#define LRA_DYN_LDS(T, name) T* name = reinterpret_cast<T*>(g_postsim_dyn_lds)
+#else
+#define LRA_DYN_LDS(T, name)                         \
+    extern __shared__ unsigned char lra_dyn_lds_raw[]; \
+    T* name = reinterpret_cast<T*>(lra_dyn_lds_raw)
+#endif
+
+template <class T>
+__global__ __launch_bounds__(256) void fir_decimate_kernel(const T* __restrict__ x, T* __restrict__ out, const T* __restrict__ h, long long n_in, long long n_out, int blocks_per_clip, int n_taps,
+                                                           int down, int first, double div, double mul) {
+    LRA_DYN_LDS(T, xs);
+    const long long clip = blockIdx.x / blocks_per_clip;
+    const long long n0 = (long long)(blockIdx.x % blocks_per_clip) * 256;
+    const int t = threadIdx.x;
+    const T* __restrict__ xc = x + clip * n_in;
+    const long long base = (n0 + first) * (long long)down - (n_taps - 1);  // input index of xs[0]
+    const int span = 255 * down + n_taps;
+    for (int s = t; s < span; s += 256) {
+        const long long gi = base + s;
+        xs[s] = (gi >= 0 && gi < n_in) ? xc[gi] : (T)0;
+    }
+    __syncthreads();
+    const T* __restrict__ w = xs + t * down;  // this output's window, oldest sample first
+    T acc = (T)0;
+    for (int j = 0; j < n_taps; ++j) acc = CqtOps<T>::madd(acc, w[j], h[n_taps - 1 - j]);
+    const long long n = n0 + t;
+    if (n < n_out) {
+        const T scaled = (T)((double)acc / div);
+        out[clip * n_out + n] = mul == 1.0 ? scaled : (T)((double)scaled * mul);  // `y *= sqrt(factor)` of the unscaled transform (constantq.py:1263-1264)
+    }
 }
 
 // ---- sparse basis projection: fft_basis.dot(D) of __cqt_response (constantq.py:1213-1218) and the length scaling (:1116-1118),

@@ -47,6 +47,8 @@ using std::expm1;
 using std::log;
 using std::log1p;
 
+alignas(16) static unsigned char g_postsim_dyn_lds[64 * 1024];  // the dynamic LDS of the workgroup being run
+
 #include "../../librosa_amd/csrc/lra_pcen.h"
 #include "../../librosa_amd/csrc/lra_cqt.h"
 
@@ -110,11 +112,20 @@ int postsim_maxfilter(const void* S, void* out, long long outer, int n_bands, lo
 
 // the launches of lra_fir_decimate_exec / lra_cqt_project_exec (lra_api.hip)
 int postsim_fir_decimate(const void* x, void* out, long long batch, long long n_in, long long n_out, const void* taps, int n_taps, int down, int first, double div, double mul, int is_f64) {
-    const unsigned grid = (unsigned)((batch * n_out + 255) / 256);
+    const int blocks_per_clip = (int)((n_out + 255) / 256);
+    if ((size_t)(255 * down + n_taps) * (is_f64 ? 8 : 4) > sizeof(g_postsim_dyn_lds)) {  // as lra_fir_decimate_exec: the direct kernel
+        const unsigned dgrid = (unsigned)((batch * n_out + 255) / 256);
+        if (is_f64)
+            run_grid_serial(dgrid, 256, [=] { lra::fir_decimate_direct_kernel<double>((const double*)x, (double*)out, (const double*)taps, batch, n_in, n_out, n_taps, down, first, div, mul); });
+        else
+            run_grid_serial(dgrid, 256, [=] { lra::fir_decimate_direct_kernel<float>((const float*)x, (float*)out, (const float*)taps, batch, n_in, n_out, n_taps, down, first, div, mul); });
+        return 0;
+    }
+    const unsigned grid = (unsigned)(blocks_per_clip * batch);
     if (is_f64)
-        run_grid_serial(grid, 256, [=] { lra::fir_decimate_kernel<double>((const double*)x, (double*)out, (const double*)taps, batch, n_in, n_out, n_taps, down, first, div, mul); });
+        run_grid(grid, 256, [=] { lra::fir_decimate_kernel<double>((const double*)x, (double*)out, (const double*)taps, n_in, n_out, blocks_per_clip, n_taps, down, first, div, mul); });
     else
-        run_grid_serial(grid, 256, [=] { lra::fir_decimate_kernel<float>((const float*)x, (float*)out, (const float*)taps, batch, n_in, n_out, n_taps, down, first, div, mul); });
+        run_grid(grid, 256, [=] { lra::fir_decimate_kernel<float>((const float*)x, (float*)out, (const float*)taps, n_in, n_out, blocks_per_clip, n_taps, down, first, div, mul); });
     return 0;
 }
 

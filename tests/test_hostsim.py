@@ -430,7 +430,7 @@ def test_pcen_shim_layouts_through_simulator(monkeypatch):
 
 # ---- constant-Q kernels (librosa_amd/csrc/lra_cqt.h) on the host ---------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("down,n", [(2, 1), (2, 41), (2, 1000), (2, 1001), (4, 999), (8, 4096), (3, 500)])
+@pytest.mark.parametrize("down,n", [(2, 1), (2, 41), (2, 1000), (2, 1001), (4, 999), (8, 4096), (3, 500), (128, 40000)])   # the last: span beyond the LDS -> direct kernel
 def test_fir_decimate_body_is_resample_poly(dtype, down, n):
     """The decimator with scipy's own design and alignment == scipy.signal.resample_poly(x, 1, down), bit for bit (same taps,
     same summation order, no contraction), incl. the scale=True division of librosa.resample."""
