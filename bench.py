@@ -25,6 +25,7 @@ Extra keys on the JSON line (rank 0):
   dropin_torch    the PUBLIC drop-in (librosa_amd.feature.melspectrogram on a device tensor: validation, plan cache, lock)
   end_to_end_numpy  the public drop-in on NumPy input: H2D + kernel + D2H (PCIe-bound; informative, never `value`)
   power_to_db / mfcc  the SURVEY 8(f) consumers on the same batch (device tensors)
+  pcen_cqt        pcen on the mel batch; the true constant-Q transform (84 bins) of 64 clips, device tensors
   cqt_lite        BASELINE configs[4]: STFTs at n_fft 512 / 2048 / 8192 over the same batch (N=1 only)
   cpu_baseline    the NumPy/scipy.fft oracle (a port of the reference path) on this box's host cores, rank 0 at N=1 only, on
                   a bounded sample of the same workload (one core); cpu_baseline_all_cores = one independent process per core
@@ -408,6 +409,25 @@ def main():
                             "ms_setup = host-drawn uniform phases (the reference's rng stream: 42 M float64 draws for 32 clips) + their upload + the final istft"}
 
         measure("griffinlim", griffinlim_key)
+
+        def pcen_and_cqt():
+            out = {}
+            fn = lambda: L.pcen(M, sr=SR, hop_length=HOP)
+            _, e = timed(fn, 10, 3, collective=False, ramp_ms=args.prewarm_ms / 4)
+            out["pcen"] = {"ms_per_call": e / 10 * 1e3, "GBps": M.numel() * (4 + 8) / (e / 10) / 1e9,
+                           "what": "pcen(M) on the mel batch: first-order smoother along time fused with the normalisation, float32 in, float64 out (the reference's result type); "
+                                   "bound by the float64 transcendentals, not by HBM"}
+            nb = min(64, batch)
+            yc = y[:nb]
+            for key, rt in (("cqt_polyphase", "polyphase"), ("cqt_default", "soxr_hq")):
+                fn = lambda: L.cqt(yc, sr=SR, hop_length=HOP, res_type=rt)
+                _, e = timed(fn, 5, 2, collective=False, ramp_ms=args.prewarm_ms / 4)
+                out[key] = {"clips": nb, "ms_per_call": e / 5 * 1e3, "frames_per_s": nb * n_frames / (e / 5),
+                            "what": f"librosa_amd.cqt(<device audio>, 84 bins, res_type={rt!r}): 7 octaves of rectangular-window STFT + sparse basis projection + FIR decimation, "
+                                    "device-resident (the constant-Q transform BASELINE config 5 approximates)"}
+            return out
+
+        measure("pcen_cqt", pcen_and_cqt)
         # BASELINE config 5 (CQT-lite): three STFTs at n_fft = 512 / 2048 / 8192 over the same batch, shared hop 512
         if not args.no_cqt:
             def cqt_lite():
