@@ -220,6 +220,7 @@ class Context:
         self._istft_plans = collections.OrderedDict()
         self._mel_plans = collections.OrderedDict()
         self._mel_by_id = {}
+        self._tables = collections.OrderedDict()
         self._lock = threading.RLock()
         self.call_lock = threading.RLock()  # held by _arrays.Session for the duration of one public call
 
@@ -257,6 +258,23 @@ class Context:
         return Event(self)
 
     PLAN_CACHE_SIZE = 48
+    TABLE_CACHE_SIZE = 512
+
+    def device_table(self, key, build):
+        """Device pointer of a small read-only table kept under ``key`` for the life of the context (LRU-bounded); ``build()`` returns
+        the host array on a miss.  The upload is synchronous, so the table is usable from any stream of the device afterwards."""
+        with self._lock:
+            buf = self._tables.get(key)
+            if buf is not None:
+                self._tables.move_to_end(key)
+                return buf.ptr
+            host = np.ascontiguousarray(build())
+            buf = DeviceBuffer(self, max(host.nbytes, 16)).upload(host)
+            self._tables[key] = buf
+            while len(self._tables) > self.TABLE_CACHE_SIZE:
+                _, old = self._tables.popitem(last=False)
+                old.free()
+            return buf.ptr
 
     def _cached_plan(self, cache, key, create, destroy):
         """LRU lookup; on overflow the oldest plan is destroyed (hipFree synchronises with the device first)."""

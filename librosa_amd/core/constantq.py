@@ -160,12 +160,13 @@ def vqt(y, *, sr=22050, hop_length=512, fmin=None, n_bins=84, intervals="equal",
     if not (isinstance(pad_mode, str) and pad_mode in _DEVICE_PAD_MODES):
         raise ParameterError(f"pad_mode={pad_mode!r} is not supported by librosa_amd.vqt")
     _decimator(2, res_type, real)  # validates res_type (also when no octave needs a decimation)
+    plan_key = (float(sr), int(hop_length), float(fmin), int(n_bins), intervals, None if gamma is None else float(gamma), int(bins_per_octave), float(filter_scale),
+                None if norm is None else float(norm), float(sparsity), window, bool(scale), cplx.str)
     try:
-        plan = _plan(float(sr), int(hop_length), float(fmin), int(n_bins), intervals, None if gamma is None else float(gamma), int(bins_per_octave), float(filter_scale),
-                     None if norm is None else float(norm), float(sparsity), window, bool(scale), cplx.str)
-    except TypeError:  # unhashable window specification: build without the cache
-        plan = _plan.__wrapped__(float(sr), int(hop_length), float(fmin), int(n_bins), intervals, None if gamma is None else float(gamma), int(bins_per_octave), float(filter_scale),
-                                 None if norm is None else float(norm), float(sparsity), window, bool(scale), cplx.str)
+        plan = _plan(*plan_key)
+    except TypeError:  # unhashable window specification: build without the caches (host tables here, device copies below)
+        plan = _plan.__wrapped__(*plan_key)
+        plan_key = None
     octaves = plan["octaves"]
     n = int(y.shape[-1])
     lead = tuple(int(s) for s in y.shape[:-1])
@@ -186,19 +187,26 @@ def vqt(y, *, sr=22050, hop_length=512, fmin=None, n_bins=84, intervals="equal",
         if check:
             ctx.nonfinite_reset()
 
-        def upload(a, dtype):
-            return sess.input_raw(_as_like(sess, a), dtype)
+        def table(name, a, dtype):
+            """Device copy of a host table: kept in the context under the plan's key, or uploaded for this call only."""
+            if plan_key is None:
+                return sess.input_raw(_as_like(sess, a), dtype)
+            return ctx.device_table(("cqt", plan_key, name, np.dtype(dtype).str), lambda: np.ascontiguousarray(a, dtype=dtype))
+
+        def decimator(down):
+            taps, first = _decimator(down, res_type, real)
+            return ctx.device_table(("fir", down, res_type, real.str), lambda: taps), len(taps), first
 
         if plan["early"]:
-            taps, first = _decimator(factor, res_type, real)
+            taps_ptr, n_taps, first = decimator(factor)
             nxt = sess.scratch(batch * lens[0] * real.itemsize)
             # resample(scale=True) divides by sqrt(1 / factor); an unscaled transform multiplies by sqrt(factor) on top (:1254-1264)
-            ctx.fir_decimate_exec(y_ptr, nxt, batch, n, lens[0], upload(taps, real), len(taps), factor, first, np.sqrt(1.0 / factor), 1.0 if scale else np.sqrt(factor), real)
+            ctx.fir_decimate_exec(y_ptr, nxt, batch, n, lens[0], taps_ptr, n_taps, factor, first, np.sqrt(1.0 / factor), 1.0 if scale else np.sqrt(factor), real)
             y_ptr = nxt
         out_ptr, handle = sess.output((batch, n_frames, n_bins), cplx)
         d_bytes = max(f * (o["n_fft"] // 2 + 1) for f, o in zip(frames, octaves)) * batch * cplx.itemsize
         d_ptr = sess.scratch(d_bytes)
-        sqrt_len_ptr = upload(plan["sqrt_len"], np.float64) if plan["sqrt_len"] is not None else None
+        sqrt_len_ptr = table("sqrt_len", plan["sqrt_len"], np.float64) if plan["sqrt_len"] is not None else None
         half_taps = None
         for i, o in enumerate(octaves):
             n_fft, hop = o["n_fft"], o["hop"]
@@ -206,12 +214,11 @@ def vqt(y, *, sr=22050, hop_length=512, fmin=None, n_bins=84, intervals="equal",
                 warnings.warn(f"n_fft={n_fft} is too large for input signal of length={lens[i]}", stacklevel=3)
             splan = ctx.stft_plan(n_fft, hop, np.ones(n_fft, dtype=real), True, pad_mode, real)          # window="ones" (:1197)
             ctx.stft_exec(splan, y_ptr, batch, lens[i], lens[i], d_ptr)
-            ctx.cqt_project_exec(d_ptr, out_ptr, upload(o["row_ptr"], np.int32), upload(o["col"], np.int32), upload(o["val"], cplx),
+            ctx.cqt_project_exec(d_ptr, out_ptr, table(f"row_ptr{i}", o["row_ptr"], np.int32), table(f"col{i}", o["col"], np.int32), table(f"val{i}", o["val"], cplx),
                                  (sqrt_len_ptr + 8 * o["bin0"]) if sqrt_len_ptr else None, batch, frames[i], n_fft // 2 + 1, n_frames, n_bins, o["bin0"], o["row0"], o["n_rows"], real)
             if o["halve"]:
                 if half_taps is None:
-                    taps, first = _decimator(2, res_type, real)
-                    half_taps = (upload(taps, real), len(taps), first)
+                    half_taps = decimator(2)
                 nxt = sess.scratch(batch * lens[i + 1] * real.itemsize)
                 ctx.fir_decimate_exec(y_ptr, nxt, batch, lens[i], lens[i + 1], half_taps[0], half_taps[1], 2, half_taps[2], np.sqrt(0.5), 1.0, real)
                 y_ptr = nxt

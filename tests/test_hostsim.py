@@ -314,6 +314,12 @@ class _SimCtx:
         n = int(np.prod(shape)) * np.dtype(dtype).itemsize
         return np.frombuffer((ctypes.c_char * n).from_address(ptr), dtype=dtype).reshape(shape)
 
+    def device_table(self, key, build):
+        tables = self.__dict__.setdefault("_tables", {})
+        if key not in tables:
+            tables[key] = np.ascontiguousarray(build())
+        return tables[key].ctypes.data
+
     def nonfinite_reset(self):
         pass
 
