@@ -17,7 +17,7 @@ from .core.convert import fft_frequencies, mel_frequencies
 from .util import utils as _u
 from .util.exceptions import ParameterError
 
-__all__ = ["get_window", "mel", "window_sumsquare"]
+__all__ = ["get_window", "mel", "window_sumsquare", "window_bandwidth", "wavelet", "wavelet_lengths"]
 
 
 def get_window(window, Nx, *, fftbins=True):
