@@ -53,8 +53,9 @@ def _two_factors(x):
     return n
 
 
+@functools.lru_cache(maxsize=64)
 def _decimator(down, res_type, real):
-    """(taps incl. leading zeros, first output's offset) of the FIR that decimates by ``down``.
+    """(taps incl. leading zeros, first output's offset) of the FIR that decimates by ``down`` (cached: treat the taps as read-only).
 
     ``"polyphase"``: ``scipy.signal.resample_poly(x, 1, down)``'s own design and alignment (its default Kaiser-5 window, 10 ``down``
     taps each side, the zero prefix that centres the output grid).  Anything else: a Kaiser design with soxr-HQ's band edges."""
