@@ -167,6 +167,16 @@ template <class Cfg, int HD> LRA_HD void v2_shift(Regs2<Cfg, HD>& rg) {
     }
 }
 
+// window and pass-0 butterflies: registers only (raw x window -> v)
+template <class Cfg, int HD> LRA_HD void v2_pass0_arith(bool live, Regs2<Cfg, HD>& rg) {
+    using T = typename Cfg::real;
+    constexpr int r0 = Regs2<Cfg, HD>::r0, nb0 = Regs2<Cfg, HD>::nb0;
+    LRA_UNROLL
+    for (int e = 0; e < Cfg::R; ++e) rg.v[e] = live ? mk<T>(rg.raw[e].x * rg.win2[e].x, rg.raw[e].y * rg.win2[e].y) : mk<T>((T)0, (T)0);
+    LRA_UNROLL
+    for (int i = 0; i < nb0; ++i) Dft<r0, T>::run(rg.v + i * r0);
+}
+
 // phase: window, pass-0 butterflies, first LDS write of the frame
 template <class Cfg, int HD> LRA_HD void v2_pass0(bool live, int tf, Regs2<Cfg, HD>& rg, Lds fr) {
     using T = typename Cfg::real;
@@ -377,6 +387,23 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
 #define LRA_V2_STAGED 0
 #endif
     constexpr bool STAGED = MODE == OUT_COMPLEX && LRA_V2_STAGED && sizeof(typename Cfg::real) == 4 && (Cfg::M + 3) * (int)sizeof(typename Cfg::cplx) <= SB;
+    // Mel epilogue, experiment (default off): window + pass-0 butterflies of frame t + 1 are register-only work
+    // and the butterfly registers are dead once the power row is written, so they are issued inside the epilogue of frame t to
+    // fill its LDS round trips -- 1: after the run reads, 2: after the running sums' stores, 3: after the band combine's reads
+    // are consumed (i.e. only ahead of the next frame's LDS write); the frame loop then opens with the LDS write alone.
+#ifndef LRA_V2_EARLY_PASS0
+#define LRA_V2_EARLY_PASS0 0
+#endif
+    constexpr int EARLY_AT = MODE == OUT_MELR ? LRA_V2_EARLY_PASS0 : 0;
+    constexpr bool EARLY = EARLY_AT != 0;
+    static_assert(EARLY_AT >= 0 && EARLY_AT <= 3, "LRA_V2_EARLY_PASS0: 0 (off) or the epilogue phase 1..3 that carries the next frame's pass 0");
+#define LRA_EARLY_NEXT_PASS0(at)                                                                                   \
+    if (EARLY_AT == at && it + 1 < iters) {                                                                        \
+        const int slot_e = slot_of<Cfg>(tid), tf_e = lane_of<Cfg>(tid), next_e = f_first + slot_e * iters + it + 1; \
+        v2_shift<Cfg, HD>(LRA_R(rg));                                  /* the pairs loaded one frame ago */        \
+        if (it + 2 < iters) v2_issue_loads<Cfg, HD>(a, clip, next_e + 1, tf_e, LRA_R(rg));                          \
+        v2_pass0_arith<Cfg, HD>(next_e < a.n_frames, LRA_R(rg));                                                   \
+    }
     LRA_REGS(RG, rg, Cfg::NT);
     LRA_PHASE(Cfg::NT, tid) {
         const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
@@ -386,15 +413,24 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
             melr_tables_to_lds<Cfg>(a, tid, lds_sub(lds, a.shared_off));
             melr_hoist<Cfg>(a, tf, LRA_R(rg), slot * SB);  // (addresses relative to the workgroup's LDS, not to the slot)
         }
+        if (EARLY) {
+            const int frame0 = f_first + slot * iters;
+            if (iters > 1) v2_issue_loads<Cfg, HD>(a, clip, frame0 + 1, tf, LRA_R(rg));
+            v2_pass0_arith<Cfg, HD>(frame0 < a.n_frames, LRA_R(rg));
+        }
     } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC && MODE != OUT_MELR)  // the shared mel tables need a workgroup barrier, once
     for (int it = 0; it < iters; ++it) {
         if (f_first + it >= a.n_frames) break;  // slot 0 has the smallest frame index: uniform exit
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
             RG& r = LRA_R(rg);
-            if (it > 0) v2_shift<Cfg, HD>(r);                                       // consumes the pairs loaded during the previous frame
-            if (it + 1 < iters) v2_issue_loads<Cfg, HD>(a, clip, frame + 1, tf, r);  // ... and starts the next batch, BEFORE this frame's stores
-            v2_pass0<Cfg, HD>(frame < a.n_frames, tf, r, lds_sub(lds, slot * SB));
+            if (EARLY) {
+                pass_write<Cfg, 0>(r.v, lds_sub(lds, slot * SB), tf);                   // the butterflies ran during the previous frame's epilogue
+            } else {
+                if (it > 0) v2_shift<Cfg, HD>(r);                                       // consumes the pairs loaded during the previous frame
+                if (it + 1 < iters) v2_issue_loads<Cfg, HD>(a, clip, frame + 1, tf, r);  // ... and starts the next batch, BEFORE this frame's stores
+                v2_pass0<Cfg, HD>(frame < a.n_frames, tf, r, lds_sub(lds, slot * SB));
+            }
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
 #define LRA_MID_PASS2(p)                                                                                                  \
         if (Cfg::P - 1 > p) {                                                                                             \
@@ -427,18 +463,22 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
             // -> rs; then every band adds its piece totals (melr_combine, shared with the first-generation kernel)
             LRA_PHASE(Cfg::NT, tid) {
                 v2_mel_runs_read<Cfg, HD>(LRA_R(rg), lds_sub(lds, slot_of<Cfg>(tid) * SB), lane_of<Cfg>(tid));
+                LRA_EARLY_NEXT_PASS0(1)
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
             LRA_PHASE(Cfg::NT, tid) {
                 v2_mel_accumulate<Cfg, HD>(a, lane_of<Cfg>(tid), LRA_R(rg), lds_sub(lds, slot_of<Cfg>(tid) * SB), lds_sub(lds, a.shared_off));
+                LRA_EARLY_NEXT_PASS0(2)
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
             LRA_PHASE(Cfg::NT, tid) {
                 const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
                 const Lds sl = lds_sub(lds, slot * SB);
                 if (frame < a.n_frames)
                     melr_combine<Cfg>(a, clip, frame, tf, it, 1, it + 1 == iters || frame + 1 >= a.n_frames, LRA_R(rg), lds_sub(lds, a.shared_off), sl, sl, lds);
+                LRA_EARLY_NEXT_PASS0(3)
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         }
     }
+#undef LRA_EARLY_NEXT_PASS0
 }
 
 }  // namespace lra

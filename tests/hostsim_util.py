@@ -10,7 +10,10 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "hostsim", "hostsim.cpp")
-SO = os.path.join(HERE, "hostsim", "_hostsim.so")
+# LRA_HOSTSIM_DEFINES="-DLRA_V2_EARLY_PASS0=1 ...": simulate a kernel experiment (compile-time flag) in its own library
+EXTRA_DEFINES = os.environ.get("LRA_HOSTSIM_DEFINES", "").split()
+_TAG = "".join(c if c.isalnum() else "_" for c in "".join(EXTRA_DEFINES))
+SO = os.path.join(HERE, "hostsim", f"_hostsim{_TAG}.so")
 CSRC = os.path.join(os.path.dirname(HERE), "librosa_amd", "csrc")
 
 PAD_MODES = {"constant": 0, "reflect": 1, "edge": 2, "symmetric": 3}
@@ -29,10 +32,10 @@ def build():
         # four objects in parallel (one per transform x dtype), then one link
         from concurrent.futures import ThreadPoolExecutor
 
-        objs = [os.path.join(HERE, "hostsim", f"_part{i}.o") for i in (1, 2, 3, 4)]
+        objs = [os.path.join(HERE, "hostsim", f"_part{i}{_TAG}.o") for i in (1, 2, 3, 4)]
 
         def cc(i):
-            subprocess.check_call(["g++", "-O1", "-std=c++17", "-w", "-fPIC", f"-DHOSTSIM_PART={i}", "-c", SRC, "-o", objs[i - 1]])
+            subprocess.check_call(["g++", "-O1", "-std=c++17", "-w", "-fPIC", f"-DHOSTSIM_PART={i}"] + EXTRA_DEFINES + ["-c", SRC, "-o", objs[i - 1]])
 
         with ThreadPoolExecutor(max_workers=4) as pool:
             list(pool.map(cc, (1, 2, 3, 4)))
