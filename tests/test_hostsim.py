@@ -559,3 +559,65 @@ def test_tensor_code_paths_through_simulator(monkeypatch):
     assert np.array_equal(librosa_amd.vqt(yt, n_bins=36, scale=False).numpy(), host["v"])
     with pytest.raises(librosa_amd.ParameterError):
         librosa_amd.cqt(yt.to(torch.int32))
+
+
+@pytest.mark.filterwarnings("ignore")
+def test_shims_seeded_sweep_through_simulator(monkeypatch):
+    """A seeded sweep over shapes, axes, max-filter axes, carried states and parameter sets (PCEN) and over rates, hops, bin counts,
+    octave widths, filter scales, pad modes and signal lengths down to a few hundred samples (CQT): the shims with simulated
+    kernels against the oracle; where the oracle raises, the shim raises too."""
+    import cqt_oracle as CQ
+    import librosa_amd
+    from librosa_amd import _arrays
+
+    monkeypatch.setattr(_arrays, "Session", _SimSession)
+    rng = np.random.default_rng(2024)
+    compared = 0
+    for _ in range(60):
+        nd = int(rng.integers(1, 5))
+        shape = tuple(int(rng.integers(1, 9)) for _ in range(nd))
+        dt = rng.choice([np.float32, np.float64])
+        X = (rng.standard_normal(shape) ** 2).astype(dt)
+        axis = int(rng.integers(-nd, nd))
+        kw = dict(axis=axis, gain=float(rng.choice([0.98, 0.5, 0.0])), bias=float(rng.choice([2.0, 0.0, 10.0])), power=float(rng.choice([0.5, 0.0, 0.25, 1.0])),
+                  time_constant=float(rng.choice([0.4, 0.06])), eps=float(rng.choice([1e-6, 1e-3])))
+        if nd >= 2 and rng.random() < 0.5:
+            kw.update(max_size=int(rng.integers(1, 6)), max_axis=int(rng.integers(-nd, nd)))
+        if rng.random() < 0.3:
+            kw["b"] = float(rng.random())
+        if rng.random() < 0.3:
+            kw["return_zf"] = True
+        if rng.random() < 0.3:
+            kw["zi"] = rng.random(tuple(1 if a == axis % nd else shape[a] for a in range(nd)))
+        try:
+            exp = O.pcen(X, **kw)
+        except O.ParameterError:
+            with pytest.raises(librosa_amd.ParameterError):
+                librosa_amd.pcen(X, **kw)
+            continue
+        got = librosa_amd.pcen(X, **kw)
+        tol = 5e-6 if (kw["bias"] == 0 and dt == np.float32) else 1e-12
+        for g, e in zip(got if isinstance(got, tuple) else (got,), exp if isinstance(exp, tuple) else (exp,)):
+            assert g.shape == e.shape and g.dtype == e.dtype and np.all((np.abs(g - e) <= tol * np.abs(e)) | (g == e)), (shape, kw)
+        compared += 1
+    assert compared >= 50
+    compared = 0
+    for _ in range(20):
+        n = int(rng.choice([300, 1000, 5000, 12000]))
+        ch = int(rng.choice([0, 1, 2]))
+        y = rng.standard_normal((n,) if ch == 0 else (ch, n)).astype(rng.choice([np.float32, np.float64]))
+        bpo = int(rng.choice([12, 24, 7]))
+        kw = dict(sr=float(rng.choice([22050, 16000, 44100])), hop_length=int(rng.choice([512, 256, 64, 100, 384])), n_bins=int(rng.integers(1, 6 * bpo)), bins_per_octave=bpo,
+                  fmin=float(rng.choice([32.7, 55.0, 110.0, 400.0])), filter_scale=float(rng.choice([1.0, 0.5, 2.0])), scale=bool(rng.random() < 0.7),
+                  pad_mode=str(rng.choice(["constant", "reflect", "edge"])), tuning=float(rng.choice([0.0, 0.3])), sparsity=float(rng.choice([0.01, 0.0, 0.1])),
+                  norm=rng.choice([1, 2, np.inf]), window=str(rng.choice(["hann", "hamming"])))
+        try:
+            exp = CQ.cqt(y, res_type="polyphase", **kw)
+        except (O.ParameterError, ValueError):
+            with pytest.raises((librosa_amd.ParameterError, ValueError)):
+                librosa_amd.cqt(y, res_type="polyphase", **kw)
+            continue
+        got = librosa_amd.cqt(y, res_type="polyphase", **kw)
+        assert got.shape == exp.shape and got.dtype == exp.dtype and np.array_equal(got, exp), (n, y.shape, kw)
+        compared += 1
+    assert compared >= 12
