@@ -235,6 +235,20 @@ int lra_fir_decimate_exec(lra_ctx* ctx, const void* x, void* out, int64_t batch,
 int lra_cqt_project_exec(lra_ctx* ctx, const void* D, void* out, const void* row_ptr, const void* col, const void* val, const void* sqrt_len, int64_t batch, int64_t frames_in, int n_bins,
                          int64_t n_frames, int n_total, int bin0, int row0, int n_rows, int dtype);
 
+/* ---- harmonic / percussive separation: librosa.decompose.hpss, librosa/decompose.py:371-528 (between the stft and the two istft of
+ * librosa.effects.hpss / harmonic / percussive, librosa/effects.py:70-301) --------------------------------------------------------- */
+/* mag[i] = |D[i]| (np.abs of the complex spectrogram, core/spectrum.py:1347); D complex, mag real of `dtype`'s precision (device). */
+int lra_magnitude_exec(lra_ctx* ctx, const void* D, void* mag, int64_t count, int dtype);
+
+/* mag: [clip][frame][bin] real (device; |D|, or any non-negative real spectrogram S).  One pass: harm / perc = medians over win_harm
+ * frames / win_perc bins (scipy.ndimage.median_filter, mode="reflect", :499-510), the two soft masks (util.softmask with `power`,
+ * margins, split_zeros = both margins 1, :512-520; power = inf: hard masks), and
+ *   want_mask != 0:  out_h / out_p = the masks (real)                                                          (:522-523)
+ *   D == NULL:       out_h / out_p = S * mask (real)                                                            (:528, phase = 1)
+ *   else:            out_h / out_p = (|D| * mask) * D / |D| (complex, same layout; phase 1 + 0j where |D| == 0)  (:528, :471-472) */
+int lra_hpss_exec(lra_ctx* ctx, const void* mag, const void* D, void* out_h, void* out_p, int64_t batch, int64_t n_frames, int n_bins, int win_harm, int win_perc, double power,
+                  double margin_harm, double margin_perc, int want_mask, int dtype);
+
 /* ---- multi-GPU: the trivial gather of the sharded result (the reference has no counterpart) ----------------- */
 /* One process per GPU.  Clips shard by contiguous ranges with no collective on the data path; these entry points gather the
  * per-rank results over RCCL (xGMI) for hosts that do not use torch.distributed.  RCCL is bound at run time (dlopen): the

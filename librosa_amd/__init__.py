@@ -12,7 +12,7 @@ sum-square); all signal arithmetic runs in hand-written HIP kernels through the 
 ``include/librosa_amd.h``.  There is no CPU fallback: without the built library and a GPU, compute
 calls raise ``librosa_amd.NativeError``.
 """
-from . import core, effects, feature, filters, util
+from . import core, decompose, effects, feature, filters, util
 from ._native import NativeError, device_count, get_context
 from .core import (_spectrogram, amplitude_to_db, cqt, interval_frequencies, vqt, db_to_amplitude, db_to_power, fft_frequencies, griffinlim, hz_to_mel, istft, pcen, phase_vocoder, mel_frequencies, mel_to_hz,
                    power_to_db, stft, stream)
@@ -20,5 +20,5 @@ from .util.exceptions import LibrosaError, ParameterError
 
 __version__ = "0.1.0"
 
-__all__ = ["core", "effects", "feature", "filters", "util", "stft", "istft", "_spectrogram", "griffinlim", "phase_vocoder", "pcen", "cqt", "vqt", "interval_frequencies", "stream", "power_to_db", "amplitude_to_db", "db_to_power", "db_to_amplitude", "hz_to_mel", "mel_to_hz", "fft_frequencies", "mel_frequencies",
+__all__ = ["core", "decompose", "effects", "feature", "filters", "util", "stft", "istft", "_spectrogram", "griffinlim", "phase_vocoder", "pcen", "cqt", "vqt", "interval_frequencies", "stream", "power_to_db", "amplitude_to_db", "db_to_power", "db_to_amplitude", "hz_to_mel", "mel_to_hz", "fft_frequencies", "mel_frequencies",
            "LibrosaError", "ParameterError", "NativeError", "device_count", "get_context"]

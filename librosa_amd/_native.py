@@ -84,6 +84,8 @@ SIGNATURES = {
     "lra_maxfilter_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_int]),
     "lra_fir_decimate_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_double, c_double, c_int]),
     "lra_cqt_project_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int64, c_int, c_int, c_int, c_int, c_int]),
+    "lra_magnitude_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int]),
+    "lra_hpss_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_double, c_double, c_double, c_int, c_int]),
     "lra_dct_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_int, c_double, c_double, c_void_p, c_void_p, c_int, c_double]),
 }
 
@@ -409,6 +411,13 @@ class Context:
     def cqt_project_exec(self, d_ptr, out_ptr, row_ptr, col_ptr, val_ptr, sqrt_len_ptr, batch, frames_in, n_bins, n_frames, n_total, bin0, row0, n_rows, dtype):
         _check(self.lib.lra_cqt_project_exec(self.handle, c_void_p(d_ptr), c_void_p(out_ptr), c_void_p(row_ptr), c_void_p(col_ptr), c_void_p(val_ptr), c_void_p(sqrt_len_ptr or None), batch,
                                              frames_in, int(n_bins), n_frames, int(n_total), int(bin0), int(row0), int(n_rows), dtype_code(dtype)))
+
+    def magnitude_exec(self, d_ptr, mag_ptr, count, dtype):
+        _check(self.lib.lra_magnitude_exec(self.handle, c_void_p(d_ptr), c_void_p(mag_ptr), count, dtype_code(dtype)))
+
+    def hpss_exec(self, mag_ptr, d_ptr, out_h_ptr, out_p_ptr, batch, n_frames, n_bins, win_harm, win_perc, power, margin_harm, margin_perc, want_mask, dtype):
+        _check(self.lib.lra_hpss_exec(self.handle, c_void_p(mag_ptr), c_void_p(d_ptr or None), c_void_p(out_h_ptr), c_void_p(out_p_ptr), batch, n_frames, int(n_bins), int(win_harm), int(win_perc),
+                                      float(power), float(margin_harm), float(margin_perc), int(bool(want_mask)), dtype_code(dtype)))
 
     def memset(self, ptr, value, nbytes):
         _check(self.lib.lra_memset(self.handle, c_void_p(ptr), int(value), int(nbytes)))

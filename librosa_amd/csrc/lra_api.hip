@@ -29,6 +29,7 @@
 #include "lra_post.h"
 #include "lra_pcen.h"
 #include "lra_cqt.h"
+#include "lra_hpss.h"
 
 using namespace lra;
 
@@ -1255,6 +1256,25 @@ int rccl_fail(RcclApi* api, const char* what, int rc) {
 
 }  // namespace
 
+namespace {
+template <class T> void hpss_launch(lra_ctx* ctx, const void* mag, const void* D, void* out_h, void* out_p, const HpssArgs& a, unsigned grid) {
+    const int widest = a.win_harm > a.win_perc ? a.win_harm : a.win_perc;
+    int slots = widest <= 32 ? 32 : 0;
+    if constexpr (sizeof(T) == 4) slots = widest <= 32 ? 32 : (widest <= 64 ? 64 : 0);  // 64 float64 slots would not fit the register file: counting selection instead
+    if (slots == 32) {
+        hipLaunchKernelGGL((hpss_kernel<T, 32>), dim3(grid), dim3(256), 0, ctx->stream, (const T*)mag, (const HpssCplx<T>*)D, out_h, out_p, a);
+        return;
+    }
+    if constexpr (sizeof(T) == 4) {
+        if (slots == 64) {
+            hipLaunchKernelGGL((hpss_kernel<T, 64>), dim3(grid), dim3(256), 0, ctx->stream, (const T*)mag, (const HpssCplx<T>*)D, out_h, out_p, a);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((hpss_kernel<T, 0>), dim3(grid), dim3(256), 0, ctx->stream, (const T*)mag, (const HpssCplx<T>*)D, out_h, out_p, a);
+}
+}  // namespace
+
 extern "C" {
 
 const char* lra_last_error(void) { return g_err.c_str(); }
@@ -2033,6 +2053,50 @@ int lra_cqt_project_exec(lra_ctx* ctx, const void* D, void* out, const void* row
     else
         hipLaunchKernelGGL(cqt_project_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, (const CqtCplx<float>*)D, (CqtCplx<float>*)out, (const int*)row_ptr, (const int*)col,
                            (const CqtCplx<float>*)val, (const double*)sqrt_len, (long long)batch, (long long)frames_in, n_bins, (long long)n_frames, n_total, bin0, row0, n_rows);
+    LRA_HIP(hipGetLastError());
+    return LRA_OK;
+}
+
+int lra_magnitude_exec(lra_ctx* ctx, const void* D, void* mag, int64_t count, int dtype) {
+    LRA_BIND(ctx);
+    if (count <= 0) return LRA_OK;
+    if (!D || !mag) return fail(LRA_EINVAL, "null data pointer");
+    if (dtype != LRA_F32 && dtype != LRA_F64) return fail(LRA_EINVAL, "magnitude: dtype must be LRA_F32 or LRA_F64");
+    if ((count + 255) / 256 > 0x7fffffffLL) return fail(LRA_EINVAL, "magnitude: array too large for one launch");
+    const unsigned grid = (unsigned)((count + 255) / 256);
+    if (dtype == LRA_F64)
+        hipLaunchKernelGGL(magnitude_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream, (const HpssCplx<double>*)D, (double*)mag, (long long)count);
+    else
+        hipLaunchKernelGGL(magnitude_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, (const HpssCplx<float>*)D, (float*)mag, (long long)count);
+    LRA_HIP(hipGetLastError());
+    return LRA_OK;
+}
+
+int lra_hpss_exec(lra_ctx* ctx, const void* mag, const void* D, void* out_h, void* out_p, int64_t batch, int64_t n_frames, int n_bins, int win_harm, int win_perc, double power,
+                  double margin_harm, double margin_perc, int want_mask, int dtype) {
+    LRA_BIND(ctx);
+    if (win_harm < 1 || win_perc < 1) return fail(LRA_EINVAL, "hpss: kernel sizes must be positive");
+    if (margin_harm < 1 || margin_perc < 1) return fail(LRA_EINVAL, "Margins must be >= 1.0. A typical range is between 1 and 10.");
+    if (!(power > 0)) return fail(LRA_EINVAL, "power must be strictly positive");
+    if (batch <= 0 || n_frames <= 0 || n_bins <= 0) return LRA_OK;
+    if (!mag || !out_h || !out_p) return fail(LRA_EINVAL, "null data pointer");
+    if (dtype != LRA_F32 && dtype != LRA_F64) return fail(LRA_EINVAL, "hpss: dtype must be LRA_F32 or LRA_F64");
+    const long long count = (long long)batch * n_frames * n_bins;
+    if ((count + 255) / 256 > 0x7fffffffLL) return fail(LRA_EINVAL, "hpss: array too large for one launch");
+    HpssArgs a;
+    a.batch = batch;
+    a.n_frames = n_frames;
+    a.n_bins = n_bins;
+    a.win_harm = win_harm;
+    a.win_perc = win_perc;
+    a.hard = std::isinf(power) ? 1 : 0;
+    a.power = a.hard ? 1.0 : power;
+    a.margin_harm = margin_harm;
+    a.margin_perc = margin_perc;
+    a.want_mask = want_mask ? 1 : 0;
+    const unsigned grid = (unsigned)((count + 255) / 256);
+    if (dtype == LRA_F64) hpss_launch<double>(ctx, mag, D, out_h, out_p, a, grid);
+    else hpss_launch<float>(ctx, mag, D, out_h, out_p, a, grid);
     LRA_HIP(hipGetLastError());
     return LRA_OK;
 }

@@ -1,21 +1,20 @@
 """Time-domain effects built on the path: ``librosa/effects.py``.
 
-``time_stretch`` is the reference's stft -> phase vocoder -> istft chain (``librosa/effects.py:464-484``) with all three
-stages on the device; for a device tensor nothing crosses PCIe, for an ``np.ndarray`` only the signal goes up and the
-stretched signal comes down.  ``hpss`` (``:161-185``) is the same round trip around ``decompose.hpss`` (median filtering,
-outside this repository's scope): compute the masks with any array library on ``librosa_amd.stft``'s device result and
-hand the masked spectra to ``librosa_amd.istft`` -- both ends stay on the device.
+``time_stretch`` is the reference's stft -> phase vocoder -> istft chain (``librosa/effects.py:464-484``) and ``hpss`` /
+``harmonic`` / ``percussive`` its stft -> ``decompose.hpss`` -> istft chain (``:70-301``), with every stage on the device: for a
+device tensor nothing crosses PCIe, for an ``np.ndarray`` only the signal goes up and the result comes down.
 """
 from __future__ import annotations
 
 import numpy as np
 
 from . import _arrays
+from . import decompose
 from .core import spectrum
 from .util.exceptions import ParameterError
 from .util.utils import is_torch_tensor
 
-__all__ = ["time_stretch"]
+__all__ = ["time_stretch", "hpss", "harmonic", "percussive"]
 
 
 def time_stretch(y, *, rate, **kwargs):
@@ -46,3 +45,48 @@ def time_stretch(y, *, rate, **kwargs):
     ikw.pop("pad_mode", None)
     out = spectrum.istft(Ds, dtype=_arrays.numpy_dtype_of(y), length=len_stretch, **ikw)
     return out.cpu().numpy() if staged else out
+
+
+def _stage(y):
+    """(array the transforms run on, whether it was staged from host memory): an ``np.ndarray`` is validated and uploaded once, so
+    that the spectra between the transforms never leave the device (torch is the device allocator here)."""
+    if is_torch_tensor(y):
+        return y, False
+    spectrum._validate_audio(y, True)
+    try:
+        torch = _arrays._torch()
+    except ImportError:  # without torch every stage moves its own arrays
+        return y, False
+    if not np.isfinite(y).all():
+        raise ParameterError("Audio buffer is not finite everywhere")
+    return torch.from_numpy(np.ascontiguousarray(y)).to(f"cuda:{_arrays._native.get_context().device}"), True
+
+
+def _hpss_parts(y, which, kernel_size, power, mask, margin, n_fft, hop_length, win_length, window, center, pad_mode):
+    yd, staged = _stage(y)
+    D = spectrum.stft(yd, n_fft=n_fft, hop_length=hop_length, win_length=win_length, window=window, center=center, pad_mode=pad_mode, check_finite=not staged)
+    parts = decompose.hpss(D, kernel_size=kernel_size, power=power, mask=mask, margin=margin)
+    # the reference inverts WITHOUT passing `window` on (effects.py:161-183): the inverse always uses its default window
+    ikw = dict(dtype=_arrays.numpy_dtype_of(y), n_fft=n_fft, hop_length=hop_length, win_length=win_length, center=center, length=y.shape[-1])
+    if mask:  # the reference then inverts the (real-valued) masks themselves; irfft takes them as spectra with zero phase
+        cplx = np.dtype(np.complex128) if _arrays.numpy_dtype_of(D) == np.complex128 else np.dtype(np.complex64)
+        parts = [_arrays.cast(p, cplx) for p in parts]
+    out = [spectrum.istft(parts[i], **ikw) for i in which]
+    return [o.cpu().numpy() if staged else o for o in out]
+
+
+def hpss(y, *, kernel_size=31, power=2.0, mask=False, margin=1.0, n_fft=2048, hop_length=None, win_length=None, window="hann", center=True, pad_mode="constant"):
+    """Decompose an audio series into harmonic and percussive components; drop-in for ``librosa.effects.hpss``
+    (``librosa/effects.py:70-185``): ``stft`` -> ``decompose.hpss`` -> two ``istft``, device-resident in between."""
+    h, p = _hpss_parts(y, (0, 1), kernel_size, power, mask, margin, n_fft, hop_length, win_length, window, center, pad_mode)
+    return h, p
+
+
+def harmonic(y, *, kernel_size=31, power=2.0, mask=False, margin=1.0, n_fft=2048, hop_length=None, win_length=None, window="hann", center=True, pad_mode="constant"):
+    """Harmonic component of an audio series; drop-in for ``librosa.effects.harmonic`` (``librosa/effects.py:188-243``)."""
+    return _hpss_parts(y, (0,), kernel_size, power, mask, margin, n_fft, hop_length, win_length, window, center, pad_mode)[0]
+
+
+def percussive(y, *, kernel_size=31, power=2.0, mask=False, margin=1.0, n_fft=2048, hop_length=None, win_length=None, window="hann", center=True, pad_mode="constant"):
+    """Percussive component of an audio series; drop-in for ``librosa.effects.percussive`` (``librosa/effects.py:246-301``)."""
+    return _hpss_parts(y, (1,), kernel_size, power, mask, margin, n_fft, hop_length, win_length, window, center, pad_mode)[0]

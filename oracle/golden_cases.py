@@ -122,3 +122,17 @@ CQT_CASES = {
     "vqt_gamma_36": ("vqt", ("mix", 22050, 98, (2,), "float32"), dict(gamma=5.0, bins_per_octave=36, n_bins=108, hop_length=128)),
     "vqt_intervals": ("vqt", ("mix", 22050, 99, None, "float32"), dict(intervals=[1.0, 1.2, 1.5, 1.8], n_bins=16, fmin=200.0, gamma=0)),
 }
+
+
+HPSS_CASES = {
+    # name: decompose.hpss kwargs on D = stft(mix, n_fft=128, hop=100) (65, 61) complex64; "power_*": on |D|**2 (real input)
+    "default": dict(),
+    "kernels_margins": dict(kernel_size=(13, 31), margin=(1.0, 3.0)),
+    "masks_p1": dict(power=1.0, mask=True),
+    "even_kernel_p35": dict(kernel_size=8, power=3.5),
+    "hard": dict(power=np.inf),
+    "hard_masks": dict(power=np.inf, mask=True),
+    "long_kernel": dict(kernel_size=(70, 9)),
+    "power_default": dict(),
+    "power_masks_margin": dict(margin=2.5, mask=True),
+}

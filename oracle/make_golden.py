@@ -92,6 +92,7 @@ def main():
     make_vocoder(librosa, meta)
     make_pcen(librosa, meta)
     make_cqt(librosa, meta)
+    make_hpss(librosa, meta)
 
 
 def make_vocoder(librosa, meta):
@@ -148,6 +149,22 @@ def make_cqt(librosa, meta):
     print("cqt done")
 
 
+def make_hpss(librosa, meta):
+    """librosa.decompose.hpss / effects.hpss outputs of the reference."""
+    y = golden_cases.make_signal("mix", 6000, 85, (2,), "float32")
+    D = librosa.stft(y[0], n_fft=128, hop_length=100)                  # (65, 61)
+    store = dict(y=y, D=np.ascontiguousarray(D))
+    for name, kw in golden_cases.HPSS_CASES.items():
+        h, p = librosa.decompose.hpss(D if not name.startswith("power_") else np.abs(D) ** 2, **kw)
+        store[f"{name}__h"], store[f"{name}__p"] = h, p
+    h, p = librosa.effects.hpss(y, n_fft=512, margin=(1.0, 2.0))
+    store["effects_h"], store["effects_p"] = h, p
+    store["effects_harmonic_default"] = librosa.effects.harmonic(y[0])
+    store["effects_percussive_k9"] = librosa.effects.percussive(y[0], kernel_size=9, n_fft=1024, hop_length=256)
+    np.savez_compressed(os.path.join(OUT, "hpss.npz"), params=json.dumps(dict(case="hpss", **meta)), **store)
+    print("hpss done")
+
+
 def make_griffinlim(librosa, meta):
     """librosa.griffinlim outputs of the reference on |stft| of seeded signals."""
     store = {}
@@ -191,11 +208,11 @@ def make_db_mfcc(librosa, meta):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("griffinlim", "vocoder", "pcen", "cqt"):  # only this fixture (the others are unchanged)
+    if len(sys.argv) > 1 and sys.argv[1] in ("griffinlim", "vocoder", "pcen", "cqt", "hpss"):  # only this fixture (the others are unchanged)
         _librosa = ref_shim.load_reference()
         import scipy as _scipy
 
         _meta = dict(numpy=np.__version__, scipy=_scipy.__version__, reference_version=str(_librosa.__version__))
-        dict(griffinlim=make_griffinlim, vocoder=make_vocoder, pcen=make_pcen, cqt=make_cqt)[sys.argv[1]](_librosa, _meta)
+        dict(griffinlim=make_griffinlim, vocoder=make_vocoder, pcen=make_pcen, cqt=make_cqt, hpss=make_hpss)[sys.argv[1]](_librosa, _meta)
     else:
         main()

@@ -604,6 +604,80 @@ def pcen(S, *, sr=22050, hop_length=512, gain=0.98, bias=2, power=0.5, time_cons
     return (S_out, zf) if return_zf else S_out
 
 
+# ----------------------------------------------------------------------------- harmonic / percussive separation
+def magphase(D, *, power=1):
+    """``librosa/core/spectrum.py:1347-1361``: magnitude and unit phasor (1 + 0j where the magnitude is zero)."""
+    mag = np.abs(D)
+    zeros_to_ones = mag == 0
+    mag_nonzero = mag + zeros_to_ones
+    phase = np.empty_like(D, dtype=dtype_r2c(D.dtype))
+    phase.real = D.real / mag_nonzero + zeros_to_ones
+    phase.imag = D.imag / mag_nonzero
+    mag **= power
+    return mag, phase
+
+
+def softmask(X, X_ref, *, power=1, split_zeros=False):
+    """``librosa/util/utils.py:1895-1932``: ``X**p / (X**p + X_ref**p)`` evaluated relative to the larger of the two."""
+    if X.shape != X_ref.shape:
+        raise ParameterError(f"Shape mismatch: {X.shape}!={X_ref.shape}")
+    if np.any(X < 0) or np.any(X_ref < 0):
+        raise ParameterError("X and X_ref must be non-negative")
+    if power <= 0:
+        raise ParameterError("power must be strictly positive")
+    dtype = X.dtype if np.issubdtype(X.dtype, np.floating) else np.float32
+    Z = np.maximum(X, X_ref).astype(dtype)
+    bad_idx = Z < np.finfo(dtype).tiny
+    Z[bad_idx] = 1
+    if np.isfinite(power):
+        mask = (X / Z) ** power
+        ref_mask = (X_ref / Z) ** power
+        good_idx = ~bad_idx
+        mask[good_idx] /= mask[good_idx] + ref_mask[good_idx]
+        mask[bad_idx] = 0.5 if split_zeros else 0.0
+    else:
+        mask = X > X_ref
+    return mask
+
+
+def hpss(S, *, kernel_size=31, power=2.0, mask=False, margin=1.0):
+    """``librosa/decompose.py:371-528`` (body ``:470-528``): median filters along time (harmonic) and frequency (percussive)
+    through ``scipy.ndimage.median_filter`` as the reference calls it (``mode="reflect"``), soft masks, masked spectrogram with the
+    original phase."""
+    from scipy.ndimage import median_filter
+
+    if np.iscomplexobj(S):
+        S, phase = magphase(S)
+    else:
+        phase = 1
+    win_harm, win_perc = kernel_size if isinstance(kernel_size, (tuple, list)) else (kernel_size, kernel_size)
+    margin_harm, margin_perc = margin if isinstance(margin, (tuple, list)) else (margin, margin)
+    if margin_harm < 1 or margin_perc < 1:
+        raise ParameterError("Margins must be >= 1.0. A typical range is between 1 and 10.")
+    harm_shape = [1] * S.ndim
+    harm_shape[-1] = int(win_harm)
+    perc_shape = [1] * S.ndim
+    perc_shape[-2] = int(win_perc)
+    harm = np.empty_like(S)
+    harm[:] = median_filter(S, size=harm_shape, mode="reflect")
+    perc = np.empty_like(S)
+    perc[:] = median_filter(S, size=perc_shape, mode="reflect")
+    split_zeros = margin_harm == 1 and margin_perc == 1
+    mask_harm = softmask(harm, perc * margin_harm, power=power, split_zeros=split_zeros)
+    mask_perc = softmask(perc, harm * margin_perc, power=power, split_zeros=split_zeros)
+    if mask:
+        return mask_harm, mask_perc
+    return ((S * mask_harm) * phase, (S * mask_perc) * phase)
+
+
+def effects_hpss(y, *, kernel_size=31, power=2.0, mask=False, margin=1.0, n_fft=2048, hop_length=None, win_length=None, window="hann", center=True, pad_mode="constant"):
+    """``librosa/effects.py:70-185``: stft -> decompose.hpss -> two istft (which are called WITHOUT ``window``, as in the reference)."""
+    D = stft(y, n_fft=n_fft, hop_length=hop_length, win_length=win_length, window=window, center=center, pad_mode=pad_mode)
+    Dh, Dp = hpss(D, kernel_size=kernel_size, power=power, mask=mask, margin=margin)
+    ikw = dict(dtype=y.dtype, n_fft=n_fft, hop_length=hop_length, win_length=win_length, center=center, length=y.shape[-1])
+    return istft(Dh, **ikw), istft(Dp, **ikw)
+
+
 # ----------------------------------------------------------------------------- synthetic inputs
 def config_input(batch, n=661500, sr=22050, seed=440, first_clip=0):
     """SURVEY.md 8(d) config-2/3 generator: 0.1*noise + 0.5*sin(2 pi f_i t), f_i = 110*2^((i%72)/12).

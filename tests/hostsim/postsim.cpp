@@ -46,11 +46,15 @@ using std::exp;
 using std::expm1;
 using std::log;
 using std::log1p;
+using std::hypot;
+using std::pow;
+using std::sqrt;
 
 alignas(16) static unsigned char g_postsim_dyn_lds[64 * 1024];  // the dynamic LDS of the workgroup being run
 
 #include "../../librosa_amd/csrc/lra_pcen.h"
 #include "../../librosa_amd/csrc/lra_cqt.h"
+#include "../../librosa_amd/csrc/lra_hpss.h"
 
 namespace {
 template <class F> void run_grid(unsigned grid, unsigned block, F body) {
@@ -74,6 +78,23 @@ template <class F> void run_grid_serial(unsigned grid, unsigned block, F body) {
             blockIdx.x = b;
             body();
         }
+}
+}  // namespace
+
+namespace {
+template <class T> void sim_hpss(const void* mag, const void* D, void* out_h, void* out_p, const lra::HpssArgs& a, unsigned grid) {
+    const int widest = a.win_harm > a.win_perc ? a.win_harm : a.win_perc;  // the same selection as hpss_launch (lra_api.hip)
+    if (widest <= 32) {
+        run_grid_serial(grid, 256, [=] { lra::hpss_kernel<T, 32>((const T*)mag, (const lra::HpssCplx<T>*)D, out_h, out_p, a); });
+        return;
+    }
+    if constexpr (sizeof(T) == 4) {
+        if (widest <= 64) {
+            run_grid_serial(grid, 256, [=] { lra::hpss_kernel<T, 64>((const T*)mag, (const lra::HpssCplx<T>*)D, out_h, out_p, a); });
+            return;
+        }
+    }
+    run_grid_serial(grid, 256, [=] { lra::hpss_kernel<T, 0>((const T*)mag, (const lra::HpssCplx<T>*)D, out_h, out_p, a); });
 }
 }  // namespace
 
@@ -142,6 +163,33 @@ int postsim_cqt_project(const void* D, void* out, const int* row_ptr, const int*
             lra::cqt_project_kernel<float>((const lra::CqtCplx<float>*)D, (lra::CqtCplx<float>*)out, row_ptr, col, (const lra::CqtCplx<float>*)val, sqrt_len, batch, frames_in, n_bins, n_frames,
                                            n_total, bin0, row0, n_rows);
         });
+    return 0;
+}
+
+// the launches of lra_magnitude_exec / lra_hpss_exec (lra_api.hip)
+int postsim_magnitude(const void* D, void* mag, long long count, int is_f64) {
+    const unsigned grid = (unsigned)((count + 255) / 256);
+    if (is_f64) run_grid_serial(grid, 256, [=] { lra::magnitude_kernel<double>((const lra::HpssCplx<double>*)D, (double*)mag, count); });
+    else run_grid_serial(grid, 256, [=] { lra::magnitude_kernel<float>((const lra::HpssCplx<float>*)D, (float*)mag, count); });
+    return 0;
+}
+
+int postsim_hpss(const void* mag, const void* D, void* out_h, void* out_p, long long batch, long long n_frames, int n_bins, int win_harm, int win_perc, double power, double margin_harm,
+                 double margin_perc, int want_mask, int is_f64) {
+    lra::HpssArgs a;
+    a.batch = batch;
+    a.n_frames = n_frames;
+    a.n_bins = n_bins;
+    a.win_harm = win_harm;
+    a.win_perc = win_perc;
+    a.hard = std::isinf(power) ? 1 : 0;
+    a.power = a.hard ? 1.0 : power;
+    a.margin_harm = margin_harm;
+    a.margin_perc = margin_perc;
+    a.want_mask = want_mask ? 1 : 0;
+    const unsigned grid = (unsigned)((batch * n_frames * n_bins + 255) / 256);
+    if (is_f64) sim_hpss<double>(mag, D, out_h, out_p, a, grid);
+    else sim_hpss<float>(mag, D, out_h, out_p, a, grid);
     return 0;
 }
 }

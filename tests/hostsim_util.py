@@ -142,7 +142,7 @@ _post = None
 def post_lib():
     global _post
     if _post is None:
-        deps = [POST_SRC, os.path.join(CSRC, "lra_pcen.h"), os.path.join(CSRC, "lra_cqt.h")]
+        deps = [POST_SRC] + [os.path.join(CSRC, h) for h in ("lra_pcen.h", "lra_cqt.h", "lra_hpss.h")]
         if not os.path.exists(POST_SO) or any(os.path.getmtime(d) > os.path.getmtime(POST_SO) for d in deps):
             subprocess.check_call(["g++", "-O1", "-std=c++17", "-w", "-fPIC", "-shared", "-pthread", POST_SRC, "-o", POST_SO])
         _post = ctypes.CDLL(POST_SO)
@@ -150,6 +150,8 @@ def post_lib():
         _post.postsim_pcen.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_longlong, c.c_longlong, c.c_int] + [c.c_double] * 5 + [c.c_void_p, c.c_double, c.c_void_p]
         _post.postsim_maxfilter.argtypes = [c.c_void_p, c.c_void_p, c.c_longlong, c.c_int, c.c_longlong, c.c_int, c.c_int]
         _post.postsim_fir_decimate.argtypes = [c.c_void_p, c.c_void_p, c.c_longlong, c.c_longlong, c.c_longlong, c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_double, c.c_double, c.c_int]
+        _post.postsim_magnitude.argtypes = [c.c_void_p, c.c_void_p, c.c_longlong, c.c_int]
+        _post.postsim_hpss.argtypes = [c.c_void_p] * 4 + [c.c_longlong, c.c_longlong, c.c_int, c.c_int, c.c_int, c.c_double, c.c_double, c.c_double, c.c_int, c.c_int]
         _post.postsim_cqt_project.argtypes = [c.c_void_p] * 6 + [c.c_longlong, c.c_longlong, c.c_int, c.c_longlong, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int]
     return _post
 
@@ -192,3 +194,21 @@ def cqt_project(D, csr, n_frames, n_total, bin0, row0, n_rows, sqrt_len=None):
     sl = None if sqrt_len is None else np.ascontiguousarray(sqrt_len, dtype=np.float64)
     post_lib().postsim_cqt_project(_p(D), _p(out), _p(rp), _p(col), _p(val), _p(sl), D.shape[0], D.shape[1], D.shape[2], n_frames, n_total, bin0, row0, n_rows, int(D.dtype == np.complex128))
     return out
+
+
+def hpss(D, *, win_harm=31, win_perc=31, power=2.0, margin_harm=1.0, margin_perc=1.0, want_mask=False):
+    """D: (batch, frames, bins) complex or real, the STFT kernel's layout -> (harmonic, percussive) through the kernel bodies of
+    lra_magnitude_exec / lra_hpss_exec."""
+    D = np.ascontiguousarray(D)
+    cplx = np.iscomplexobj(D)
+    real = np.dtype(np.float64) if D.dtype in (np.complex128, np.float64) else np.dtype(np.float32)
+    if cplx:
+        mag = np.full(D.shape, np.nan, dtype=real)
+        post_lib().postsim_magnitude(_p(D), _p(mag), D.size, int(real == np.float64))
+    else:
+        mag = D
+    odt = real if (want_mask or not cplx) else D.dtype
+    oh, op = np.full(D.shape, np.nan, dtype=odt), np.full(D.shape, np.nan, dtype=odt)
+    post_lib().postsim_hpss(_p(mag), _p(D) if cplx else None, _p(oh), _p(op), D.shape[0], D.shape[1], D.shape[2], int(win_harm), int(win_perc), float(power), float(margin_harm),
+                            float(margin_perc), int(want_mask), int(real == np.float64))
+    return oh, op

@@ -1268,3 +1268,84 @@ def test_cqt_full_size(L):
         assert _cqt_close(C[clip].cpu().numpy(), ref)
         assert torch.equal(L.cqt(Y[clip], sr=22050, res_type="polyphase"), C[clip])
         assert (Cd[clip] - C[clip]).abs().max().item() <= 1e-2 * np.abs(ref).max()
+
+
+# ---- harmonic / percussive separation (librosa/decompose.py:371-528, librosa/effects.py:70-301) ------------------
+# The medians are selections (no arithmetic), the masks a handful of float operations: real-valued input reproduces the reference to the
+# last bits; complex input goes through |D| first, where NumPy's float32 hypot and the device's differ in the last bit, so everything
+# after it is compared at 1e-5 of the peak (float32) / 1e-12 (float64).
+def _hpss_close(got, ref, tol):
+    return got.shape == ref.shape and got.dtype == ref.dtype and np.abs(got.astype(np.complex128) - ref).max() <= tol * max(np.abs(ref).max(), 1e-30)
+
+
+def test_hpss_golden(L):
+    import torch
+
+    g = np.load(os.path.join(GOLDEN_DIR, "hpss.npz"))
+    D, y = g["D"], g["y"]
+    for name, kw in golden_cases.HPSS_CASES.items():
+        inp = np.abs(D) ** 2 if name.startswith("power_") else D
+        got = L.decompose.hpss(inp, **kw)
+        dev = L.decompose.hpss(torch.from_numpy(inp).cuda(), **kw)
+        for part, key, d in zip(got, (f"{name}__h", f"{name}__p"), dev):
+            ref = g[key]
+            assert isinstance(d, torch.Tensor) and d.is_cuda and np.array_equal(d.cpu().numpy(), part), key
+            if ref.dtype == bool:   # hard masks: a comparison of two medians; |D|'s last bit may flip a tie
+                assert part.dtype == bool and part.shape == ref.shape and np.mean(part != ref) <= 1e-3, key
+            elif np.isinf(kw.get("power", 2.0)):   # masked spectra under hard masks: all but a flipped tie within the usual bound
+                assert part.shape == ref.shape and part.dtype == ref.dtype and np.mean(np.abs(part - ref) > 1e-5 * np.abs(ref).max()) <= 1e-3, key
+            else:
+                assert _hpss_close(part, ref, 1e-5), (key, np.abs(part - ref).max() / np.abs(ref).max())
+    D64 = D.astype(np.complex128)
+    for part, ref in zip(L.decompose.hpss(D64, margin=(1.0, 2.0)), O.hpss(D64, margin=(1.0, 2.0))):
+        assert _hpss_close(part, ref, 1e-12)
+    # the effects chains: stft -> hpss -> istft, device-resident
+    scale = np.abs(y).max()
+    h, p = L.effects.hpss(y, n_fft=512, margin=(1.0, 2.0))
+    assert h.shape == y.shape and h.dtype == y.dtype and np.abs(h - g["effects_h"]).max() <= 1e-4 * scale and np.abs(p - g["effects_p"]).max() <= 1e-4 * scale
+    assert np.abs(L.effects.harmonic(y[0]) - g["effects_harmonic_default"]).max() <= 1e-4 * scale
+    assert np.abs(L.effects.percussive(y[0], kernel_size=9, n_fft=1024, hop_length=256) - g["effects_percussive_k9"]).max() <= 1e-4 * scale
+    ht, pt = L.effects.hpss(torch.from_numpy(y).cuda(), n_fft=512, margin=(1.0, 2.0))
+    assert isinstance(ht, torch.Tensor) and ht.is_cuda and np.array_equal(ht.cpu().numpy(), h) and np.array_equal(pt.cpu().numpy(), p)
+    for bad in (dict(margin=0.5), dict(margin=(1.0, 0.9)), dict(power=0), dict(kernel_size=0)):
+        with pytest.raises(L.ParameterError):
+            L.decompose.hpss(D, **bad)
+
+
+def test_hpss_reference_properties_and_full_size(L):
+    """The reference's own assertions (tests/test_decompose.py: H + P == D, real input, margins; tests/test_effects.py: test_hpss) and
+    the BASELINE clip shape: 32 clips x 30 s (32 x 1025 x 1292 complex64) separated on the device, a sampled clip against the oracle."""
+    import torch
+
+    rng = np.random.default_rng(33)
+    D = (rng.standard_normal((33, 50)) + 1j * rng.standard_normal((33, 50))).astype(np.complex64)
+    H_, P_ = L.decompose.hpss(D)
+    assert np.allclose(H_ + P_, D, atol=1e-6)
+    S = np.abs(D)
+    Hs, Ps = L.decompose.hpss(S)
+    assert np.allclose(Hs + Ps, S, atol=1e-6) and np.all(Hs >= 0) and np.all(Ps >= 0)
+    mh, mp = L.decompose.hpss(S, mask=True)
+    assert np.allclose(mh + mp, 1.0, atol=1e-6)
+    Hm, Pm = L.decompose.hpss(S, margin=(1.0, 4.0))
+    assert np.all(Hm + Pm <= S * (1 + 1e-6))
+    Y = torch.from_numpy(O.config_input(32)).cuda()
+    Dd = L.stft(Y)
+    Hd, Pd = L.decompose.hpss(Dd)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    Hd, Pd = L.decompose.hpss(Dd)
+    ev1.record()
+    torch.cuda.synchronize()
+    print(f"decompose.hpss 32 x 1025 x 1292 complex64: {ev0.elapsed_time(ev1):.2f} ms")
+    assert Hd.shape == Dd.shape and Hd.dtype == torch.complex64
+    assert (Hd + Pd - Dd).abs().max().item() <= 1e-5 * Dd.abs().max().item()
+    clip = 17
+    rh, rp = O.hpss(Dd[clip].cpu().numpy())
+    assert _hpss_close(Hd[clip].cpu().numpy(), rh, 1e-5) and _hpss_close(Pd[clip].cpu().numpy(), rp, 1e-5)
+    h1, p1 = L.decompose.hpss(Dd[clip])
+    assert torch.equal(h1, Hd[clip]) and torch.equal(p1, Pd[clip])
+    yh, yp = L.effects.hpss(Y[:4])
+    eh, ep = O.effects_hpss(Y[1].cpu().numpy())
+    scale = float(np.abs(eh).max() + np.abs(ep).max())
+    assert np.abs(yh[1].cpu().numpy() - eh).max() <= 1e-4 * scale and np.abs(yp[1].cpu().numpy() - ep).max() <= 1e-4 * scale

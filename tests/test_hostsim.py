@@ -342,6 +342,19 @@ class _SimCtx:
         H.post_lib().postsim_cqt_project(d_ptr, out_ptr, row_ptr, col_ptr, val_ptr, sqrt_len_ptr, batch, frames_in, int(n_bins), n_frames, int(n_total), int(bin0), int(row0), int(n_rows),
                                          int(np.dtype(dtype) == np.float64))
 
+    def transpose(self, src_ptr, dst_ptr, batch, rows, cols, elem_bytes):
+        """dst[b][c][r] = src[b][r][c] (lra_transpose)."""
+        dt = {4: np.float32, 8: np.float64, 16: np.complex128}[int(elem_bytes)]
+        src = self._view(src_ptr, (batch, rows, cols), dt)
+        self._view(dst_ptr, (batch, cols, rows), dt)[...] = np.swapaxes(src, 1, 2)
+
+    def magnitude_exec(self, d_ptr, mag_ptr, count, dtype):
+        H.post_lib().postsim_magnitude(d_ptr, mag_ptr, count, int(np.dtype(dtype) == np.float64))
+
+    def hpss_exec(self, mag_ptr, d_ptr, out_h_ptr, out_p_ptr, batch, n_frames, n_bins, win_harm, win_perc, power, margin_harm, margin_perc, want_mask, dtype):
+        H.post_lib().postsim_hpss(mag_ptr, d_ptr, out_h_ptr, out_p_ptr, batch, n_frames, int(n_bins), int(win_harm), int(win_perc), float(power), float(margin_harm), float(margin_perc),
+                                  int(bool(want_mask)), int(np.dtype(dtype) == np.float64))
+
     def pcen_exec(self, s_ptr, ref_ptr, out_ptr, rows, n_frames, dtype, b, gain, bias, power, eps, zi_ptr, zi_scalar, zf_ptr):
         H.post_lib().postsim_pcen(s_ptr, ref_ptr, out_ptr, rows, n_frames, int(np.dtype(dtype) == np.float64), float(b), float(gain), float(bias), float(power), float(eps), zi_ptr,
                                   float(zi_scalar), zf_ptr)
@@ -621,3 +634,81 @@ def test_shims_seeded_sweep_through_simulator(monkeypatch):
         assert got.shape == exp.shape and got.dtype == exp.dtype and np.array_equal(got, exp), (n, y.shape, kw)
         compared += 1
     assert compared >= 12
+
+
+# ---- harmonic / percussive separation (librosa_amd/csrc/lra_hpss.h) -------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_hpss_body(dtype):
+    """Both medians (sorting networks of 32 and 64 slots, counting selection beyond; odd and even windows; windows longer than the axis),
+    soft / hard masks, margins, masked output with the input's phase -- against the oracle (bit-identical to the reference).  Real
+    input: bit for bit (the median is a selection); complex input and non-trivial exponents: last-bit differences of |D| and pow."""
+    import golden_cases
+
+    y = golden_cases.make_signal("mix", 6000, 7, (2,), "float32").astype(dtype)
+    D = O.stft(y, n_fft=128, hop_length=64)                       # (2, 65, 95)
+    Dt = np.ascontiguousarray(np.swapaxes(D, -1, -2))
+    eps = 1e-6 if dtype == np.float32 else 1e-14
+    for kw in (dict(), dict(kernel_size=(13, 31), margin=(1.0, 3.0)), dict(power=1.0, mask=True), dict(kernel_size=8, power=3.5), dict(power=np.inf), dict(margin=2.5, mask=True),
+               dict(kernel_size=(40, 5)), dict(kernel_size=(70, 9), power=0.5), dict(kernel_size=(3, 200))):
+        wh, wp = kw.get("kernel_size", 31) if isinstance(kw.get("kernel_size", 31), tuple) else (kw.get("kernel_size", 31),) * 2
+        mh, mp = kw.get("margin", 1.0) if isinstance(kw.get("margin", 1.0), tuple) else (kw.get("margin", 1.0),) * 2
+        for inp, inp_t in ((D, Dt), (np.abs(D) ** 2, np.abs(Dt) ** 2)):
+            exp = O.hpss(inp, **kw)
+            got = H.hpss(inp_t, win_harm=wh, win_perc=wp, power=kw.get("power", 2.0), margin_harm=mh, margin_perc=mp, want_mask=kw.get("mask", False))
+            for g, e in zip(got, exp):
+                e = np.swapaxes(e, -1, -2).astype(g.dtype)
+                if np.iscomplexobj(inp) or kw.get("power", 2.0) == 3.5:
+                    assert np.abs(g - e).max() <= eps * max(np.abs(e).max(), 1e-30), kw
+                else:
+                    assert np.array_equal(g, e), kw
+
+
+def test_hpss_shims_through_simulator(monkeypatch):
+    """librosa_amd.decompose.hpss (layouts, dtypes, NumPy and tensor code paths, argument errors) and librosa_amd.effects.hpss / harmonic
+    / percussive (with the two transforms supplied by the oracle) against the oracle's chain."""
+    import torch
+
+    import golden_cases
+    import librosa_amd
+    from librosa_amd import _arrays, effects
+    from librosa_amd.core import spectrum
+
+    real_session = _arrays.Session
+    monkeypatch.setattr(_arrays, "Session", _SimSession)
+    y = golden_cases.make_signal("mix", 5000, 9, (2,), "float32")
+    D = O.stft(y, n_fft=256, hop_length=64)                        # (2, 129, 79)
+
+    def close(got, exp, tol=1e-6):
+        return all(g.shape == e.shape and g.dtype == e.dtype and np.abs(g.astype(np.complex128) - e).max() <= tol * max(np.abs(e).max(), 1e-30) for g, e in zip(got, exp))
+
+    for kw in (dict(), dict(kernel_size=(9, 17), margin=(1.0, 2.0)), dict(mask=True, power=1.0), dict(mask=True, power=np.inf), dict(kernel_size=40)):
+        assert close(librosa_amd.decompose.hpss(D, **kw), O.hpss(D, **kw)), kw
+        assert close(librosa_amd.decompose.hpss(D[0], **kw), O.hpss(D[0], **kw)), kw
+        P = np.abs(D) ** 2
+        got, exp = librosa_amd.decompose.hpss(P, **kw), O.hpss(P, **kw)
+        assert all(np.array_equal(g, e) and g.dtype == e.dtype for g, e in zip(got, exp)), kw
+    assert close(librosa_amd.decompose.hpss(D.astype(np.complex128)), O.hpss(D.astype(np.complex128)), 1e-14)
+    for bad in (dict(margin=0.5), dict(margin=(1.0, 0.9)), dict(power=0), dict(kernel_size=0)):
+        with pytest.raises(librosa_amd.ParameterError):
+            librosa_amd.decompose.hpss(D, **bad)
+    with pytest.raises(librosa_amd.ParameterError):
+        librosa_amd.decompose.hpss(-np.abs(D))
+    # tensor code path (CPU tensors; a transposed view of a frame-major buffer, like librosa_amd.stft's result, needs no transpose)
+    host = librosa_amd.decompose.hpss(D, margin=(1.0, 2.0))
+    monkeypatch.setattr(_arrays, "Session", _sim_torch_session(real_session))
+    Dt = torch.from_numpy(np.ascontiguousarray(np.swapaxes(D, -1, -2))).transpose(-1, -2)
+    dev = librosa_amd.decompose.hpss(Dt, margin=(1.0, 2.0))
+    assert all(isinstance(d, torch.Tensor) and d.dtype == torch.complex64 and np.array_equal(d.numpy(), h) for d, h in zip(dev, host))
+    dev = librosa_amd.decompose.hpss(torch.from_numpy(np.abs(D)), mask=True)
+    assert all(np.array_equal(d.numpy(), h) for d, h in zip(dev, O.hpss(np.abs(D), mask=True)))
+    # effects: the shim's own chaining (which istft arguments, which component), transforms by the oracle
+    monkeypatch.setattr(_arrays, "Session", _SimSession)
+    monkeypatch.setattr(effects, "_stage", lambda a: (a, False))
+    monkeypatch.setattr(spectrum, "stft", lambda a, check_finite=True, **kw: O.stft(a, **kw))
+    monkeypatch.setattr(spectrum, "istft", lambda a, **kw: O.istft(np.ascontiguousarray(a), **kw))
+    for kw in (dict(n_fft=512), dict(n_fft=256, hop_length=64, margin=(1.0, 3.0), kernel_size=(9, 17)), dict(n_fft=256, window="hamming", win_length=200)):
+        eh, ep = O.effects_hpss(y, **kw)
+        gh, gp = effects.hpss(y, **kw)
+        scale = np.abs(y).max()
+        assert gh.shape == y.shape and gh.dtype == y.dtype and np.abs(gh - eh).max() <= 1e-5 * scale and np.abs(gp - ep).max() <= 1e-5 * scale, kw
+        assert np.array_equal(effects.harmonic(y, **kw), gh) and np.array_equal(effects.percussive(y, **kw), gp)

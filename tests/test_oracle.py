@@ -372,3 +372,38 @@ def test_cqt_oracle_live_reference():
         for kw in (dict(), dict(n_bins=36, hop_length=64), dict(scale=False, n_bins=24)):
             assert np.array_equal(CQ.cqt(y, sr=22050, res_type=rt, **kw), L.cqt(y, sr=22050, res_type=rt, **kw)), (rt, kw)
         assert np.array_equal(CQ.vqt(y, sr=22050, res_type=rt, gamma=None), L.vqt(y, sr=22050, res_type=rt))
+
+
+# ---- harmonic / percussive separation ----------------------------------------------------------------------------
+def test_hpss_oracle_matches_reference_golden():
+    """librosa.decompose.hpss (decompose.py:470-528) with util.softmask and magphase, and the effects.hpss / harmonic / percussive chains
+    (effects.py:70-301), restated, vs outputs of the unmodified reference (oracle/make_golden.py::make_hpss): bit for bit."""
+    g = np.load(os.path.join(GOLDEN_DIR, "hpss.npz"))
+    D, y = g["D"], g["y"]
+    for name, kw in golden_cases.HPSS_CASES.items():
+        h, p = O.hpss(np.abs(D) ** 2 if name.startswith("power_") else D, **kw)
+        for got, key in ((h, f"{name}__h"), (p, f"{name}__p")):
+            assert got.dtype == g[key].dtype and np.array_equal(got, g[key]), key
+    h, p = O.effects_hpss(y, n_fft=512, margin=(1.0, 2.0))
+    assert np.array_equal(h, g["effects_h"]) and np.array_equal(p, g["effects_p"])
+    assert np.array_equal(O.effects_hpss(y[0])[0], g["effects_harmonic_default"])
+    assert np.array_equal(O.effects_hpss(y[0], kernel_size=9, n_fft=1024, hop_length=256)[1], g["effects_percussive_k9"])
+
+
+def test_hpss_oracle_known_answers():
+    """What the reference's tests assert (tests/test_decompose.py: test_hpss, test_real_hpss, test_hpss_margin_error; tests/test_effects.py:
+    test_hpss): H + P == D for margin 1, masks sum to one, components are non-negative parts, margins below one are rejected."""
+    rng = np.random.default_rng(33)
+    D = (rng.standard_normal((33, 50)) + 1j * rng.standard_normal((33, 50))).astype(np.complex64)
+    H_, P_ = O.hpss(D)
+    assert np.allclose(H_ + P_, D, atol=1e-6)
+    S = np.abs(D)
+    Hs, Ps = O.hpss(S)
+    assert np.allclose(Hs + Ps, S, atol=1e-6) and np.all(Hs >= 0) and np.all(Ps >= 0)
+    mh, mp = O.hpss(S, mask=True)
+    assert np.allclose(mh + mp, 1.0, atol=1e-6)
+    for m in (0.9, (1.0, 0.5), (0.5, 1.0)):
+        with pytest.raises(O.ParameterError):
+            O.hpss(S, margin=m)
+    Hm, Pm = O.hpss(S, margin=(1.0, 4.0))
+    assert np.all(Hm + Pm <= S * (1 + 1e-6))     # wider margins leave a residual
