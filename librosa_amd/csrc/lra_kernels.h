@@ -1274,6 +1274,53 @@ template <class Cfg> LRA_HD void istft_spec_load_mir(const IstftArgs<typename Cf
     rg.xmid = X[M / 2];
 }
 
+// The two halves of istft_unsplit_pass0 below, for the LRA_ISTFT_EARLY experiment: the register-only part (pairs -> conj Z' in
+// first-pass order, first-pass butterflies) and the first LDS write of the frame.
+template <class Cfg> LRA_HD void istft_unsplit_pass0_arith(int tf, FftRegs<Cfg>& rg) {
+    using T = typename Cfg::real;
+    using C = typename Cfg::cplx;
+    constexpr int r0 = 1 << Cfg::logr(0);
+    const bool l0 = tf == 0;
+    C zk[r0], zm[r0];
+    LRA_UNROLL
+    for (int q = 0; q < r0; ++q) {
+        const C xk = rg.xk[q], xm = rg.xm[q];
+        const C E = add_conj(xk, xm);
+        const C O = cmul2_conj(sub_conj(xk, xm), rg.twr[q]);
+        zk[q] = conj_add_mi_neg(E, O);
+        zm[q] = add_mi(E, O);
+    }
+    const C z0 = mk<T>(rg.xk[0].x + rg.xm[0].x, -(rg.xk[0].x - rg.xm[0].x));
+    const C mid2 = mk<T>((T)2 * rg.xmid.x, (T)2 * rg.xmid.y);
+    C* A = rg.v;
+    C* B = rg.v + r0;
+    LRA_UNROLL
+    for (int j = 0; j < r0; ++j) {
+        C a0;
+        if (j == 0) a0 = z0;
+        else if (j < r0 / 2) a0 = zk[j];
+        else if (j == r0 / 2) a0 = mid2;
+        else a0 = zm[r0 - j];
+        const C b0 = j < r0 / 2 ? zk[r0 / 2 + j] : zm[3 * r0 / 2 - 1 - j];
+        A[j] = l0 ? a0 : zk[j];
+        B[j] = l0 ? b0 : zm[r0 - 1 - j];
+    }
+    Dft<r0, T>::run(A);
+    Dft<r0, T>::run(B);
+}
+template <class Cfg> LRA_HD void istft_unsplit_pass0_write(int tf, FftRegs<Cfg>& rg, Lds fr) {
+    using C = typename Cfg::cplx;
+    constexpr int r0 = 1 << Cfg::logr(0);
+    const C* A = rg.v;
+    const C* B = rg.v + r0;
+    const int baseA = tf * (r0 + 1) * (int)sizeof(C), baseB = mir_bfly<Cfg>(tf) * (r0 + 1) * (int)sizeof(C);
+    LRA_UNROLL
+    for (int j = 0; j < r0; ++j) {
+        lds_st<C>(fr, baseA + j * (int)sizeof(C), A[j]);
+        lds_st<C>(fr, baseB + j * (int)sizeof(C), B[j]);
+    }
+}
+
 // phase: pairs -> conj Z' in first-pass order, first-pass butterflies, first LDS write of the frame
 template <class Cfg> LRA_HD void istft_unsplit_pass0(int tf, FftRegs<Cfg>& rg, Lds fr) {
     using T = typename Cfg::real;
@@ -1589,6 +1636,13 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
     const int steps = a.warm_frames + a.strip_frames + (has_last ? a.drain_steps : 0);
     const bool defer = ROWS || 4 * a.hop <= Cfg::N;  // finished samples per hop fit the hold-back registers
     constexpr bool rows = ROWS;
+    // Experiment (default off): the Hermitian step + first-pass butterflies of frame t + 1 are register-only work on
+    // the prefetched spectrum; issued at the end of frame t's overlap-add phase (whose butterfly registers are dead by then) they fill
+    // that phase's LDS round trips, and the frame loop opens with the LDS write alone.  The prefetch of frame t + 2 follows them.
+#ifndef LRA_ISTFT_EARLY
+#define LRA_ISTFT_EARLY 0
+#endif
+    constexpr bool EARLY = LRA_ISTFT_EARLY && ROWS && MIR;
     LRA_TICK_DECL;  // (the pass macro shared with the forward kernel ticks; the inverse kernel does not report)
     LRA_REGS(FftRegs<Cfg>, rg, Cfg::NT);
     // the slot's strip (64-bit divisions) is worked out once, from the un-laundered thread index
@@ -1607,6 +1661,10 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
         const int t = s.t0 - a.warm_frames;
         if constexpr (MIR) istft_spec_load_mir<Cfg>(a, s.clip, t, s.active && t >= 0 && t < s.t1, tf, LRA_R(rg));
         else istft_spec_load<Cfg>(a, s.clip, t, s.active && t >= 0 && t < s.t1, tf, LRA_R(rg));
+        if constexpr (EARLY) {
+            if (steps > 0) istft_unsplit_pass0_arith<Cfg>(tf, LRA_R(rg));
+            if (steps > 1) istft_spec_load_mir<Cfg>(a, s.clip, t + 1, s.active && t + 1 >= 0 && t + 1 < s.t1, tf, LRA_R(rg));
+        }
     } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
     for (int j = 0; j < steps; ++j) {
         if (!Cfg::HOIST) { LRA_LAUNDER(a.win_scaled); LRA_LAUNDER(a.tw); LRA_LAUNDER(a.twr); }
@@ -1616,13 +1674,14 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
             const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
             const IstftSlot<Cfg> s = LRA_R(sl);
             const int t = s.t0 - a.warm_frames + j;
-            if constexpr (MIR) istft_unsplit_pass0<Cfg>(tf, LRA_R(rg), lds_sub(lds, slot * SB));
+            if constexpr (EARLY) istft_unsplit_pass0_write<Cfg>(tf, LRA_R(rg), lds_sub(lds, slot * SB));
+            else if constexpr (MIR) istft_unsplit_pass0<Cfg>(tf, LRA_R(rg), lds_sub(lds, slot * SB));
             else istft_split_write<Cfg>(a, tf, LRA_R(rg), lds_sub(lds, slot * SB));
             if (defer && j > 0 && s.active) {
                 if constexpr (rows) istft_flush_rows<Cfg, HC>(a, s.clip, t - 1, t - 1 >= s.t0 && (s.last || t - 1 < s.t1), tf, LRA_R(rg));
                 else istft_flush_out<Cfg>(a, s.clip, t - 1, s.write_lo, s.write_hi, tf, LRA_R(rg));
             }
-            if (j + 1 < steps) {
+            if (!EARLY && j + 1 < steps) {
                 if constexpr (MIR) istft_spec_load_mir<Cfg>(a, s.clip, t + 1, s.active && t + 1 >= 0 && t + 1 < s.t1, tf, LRA_R(rg));
                 else istft_spec_load<Cfg>(a, s.clip, t + 1, s.active && t + 1 >= 0 && t + 1 < s.t1, tf, LRA_R(rg));
             }
@@ -1651,6 +1710,10 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
                 const IstftSlot<Cfg> s = LRA_R(sl);
                 const int t = s.t0 - a.warm_frames + j;
                 if (s.active) istft_last_ola_rows<Cfg, HC>(a, t >= 0 && t < s.t1, tf, LRA_R(rg), lds_sub(lds, slot * SB));
+                if constexpr (EARLY) {
+                    if (j + 1 < steps) istft_unsplit_pass0_arith<Cfg>(tf, LRA_R(rg));   // frame t + 1, prefetched one iteration ago
+                    if (j + 2 < steps) istft_spec_load_mir<Cfg>(a, s.clip, t + 2, s.active && t + 2 >= 0 && t + 2 < s.t1, tf, LRA_R(rg));
+                }
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
             continue;
         }
