@@ -422,9 +422,28 @@ def main():
             for key, rt in (("cqt_polyphase", "polyphase"), ("cqt_default", "soxr_hq")):
                 fn = lambda: L.cqt(yc, sr=SR, hop_length=HOP, res_type=rt)
                 _, e = timed(fn, 5, 2, collective=False, ramp_ms=args.prewarm_ms / 4)
-                out[key] = {"clips": nb, "ms_per_call": e / 5 * 1e3, "frames_per_s": nb * n_frames / (e / 5),
+                alg_bytes = nb * (n * 4 + 84 * n_frames * 8)  # PCM read once + the stacked complex64 result written once
+                out[key] = {"clips": nb, "ms_per_call": e / 5 * 1e3, "frames_per_s": nb * n_frames / (e / 5), "GBps_algorithmic": alg_bytes / (e / 5) / 1e9,
                             "what": f"librosa_amd.cqt(<device audio>, 84 bins, res_type={rt!r}): 7 octaves of rectangular-window STFT + sparse basis projection + FIR decimation, "
-                                    "device-resident (the constant-Q transform BASELINE config 5 approximates)"}
+                                    "device-resident (the constant-Q transform BASELINE config 5 approximates); 20 small launches: latency-, not bandwidth-bound"}
+            # the same two rows through the oracle (port of the reference) on one host core, one clip each: a reported baseline
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import cqt_oracle as CQ
+                import stft_oracle as O
+
+                y1 = y[0].cpu().numpy()
+                t0 = time.perf_counter()
+                CQ.cqt(y1, sr=SR, hop_length=HOP, res_type="polyphase")
+                t_cqt = time.perf_counter() - t0
+                m1 = M[0].cpu().numpy()
+                t0 = time.perf_counter()
+                O.pcen(m1, sr=SR, hop_length=HOP)
+                t_pcen = time.perf_counter() - t0
+                out["cpu_baseline"] = {"kind": "port", "cores": 1, "sample": "one 30 s clip each", "cqt_ms_per_clip": t_cqt * 1e3, "pcen_ms_per_clip": t_pcen * 1e3,
+                                       "gpu_cqt_ms_per_clip": out["cqt_polyphase"]["ms_per_call"] / nb, "gpu_pcen_ms_per_clip": out["pcen"]["ms_per_call"] / batch}
+            except Exception as exc:  # pragma: no cover
+                out["cpu_baseline"] = {"error": repr(exc)}
             return out
 
         measure("pcen_cqt", pcen_and_cqt)
