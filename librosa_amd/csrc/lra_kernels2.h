@@ -167,14 +167,21 @@ template <class Cfg, int HD> LRA_HD void v2_shift(Regs2<Cfg, HD>& rg) {
     }
 }
 
-// window and pass-0 butterflies: registers only (raw x window -> v)
-template <class Cfg, int HD> LRA_HD void v2_pass0_arith(bool live, Regs2<Cfg, HD>& rg) {
+// window and pass-0 butterflies: registers only (raw x window -> v), in two halves for the LRA_V2_EARLY_PASS0 placements
+template <class Cfg, int HD> LRA_HD void v2_pass0_window(bool live, Regs2<Cfg, HD>& rg) {
+    using T = typename Cfg::real;
+    LRA_UNROLL
+    for (int e = 0; e < Cfg::R; ++e) rg.v[e] = live ? mk<T>(rg.raw[e].x * rg.win2[e].x, rg.raw[e].y * rg.win2[e].y) : mk<T>((T)0, (T)0);
+}
+template <class Cfg, int HD> LRA_HD void v2_pass0_dft(Regs2<Cfg, HD>& rg) {
     using T = typename Cfg::real;
     constexpr int r0 = Regs2<Cfg, HD>::r0, nb0 = Regs2<Cfg, HD>::nb0;
     LRA_UNROLL
-    for (int e = 0; e < Cfg::R; ++e) rg.v[e] = live ? mk<T>(rg.raw[e].x * rg.win2[e].x, rg.raw[e].y * rg.win2[e].y) : mk<T>((T)0, (T)0);
-    LRA_UNROLL
     for (int i = 0; i < nb0; ++i) Dft<r0, T>::run(rg.v + i * r0);
+}
+template <class Cfg, int HD> LRA_HD void v2_pass0_arith(bool live, Regs2<Cfg, HD>& rg) {
+    v2_pass0_window<Cfg, HD>(live, rg);
+    v2_pass0_dft<Cfg, HD>(rg);
 }
 
 // phase: window, pass-0 butterflies, first LDS write of the frame
@@ -390,14 +397,26 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
     // Mel epilogue, experiment (default off): window + pass-0 butterflies of frame t + 1 are register-only work
     // and the butterfly registers are dead once the power row is written, so they are issued inside the epilogue of frame t to
     // fill its LDS round trips -- 1: after the run reads, 2: after the running sums' stores, 3: after the band combine's reads
-    // are consumed (i.e. only ahead of the next frame's LDS write); the frame loop then opens with the LDS write alone.
+    // are consumed (i.e. only ahead of the next frame's LDS write), 4: window multiply in phase 1 and butterflies in phase 3; the
+    // frame loop then opens with the LDS write alone.
 #ifndef LRA_V2_EARLY_PASS0
 #define LRA_V2_EARLY_PASS0 0
 #endif
     constexpr int EARLY_AT = MODE == OUT_MELR ? LRA_V2_EARLY_PASS0 : 0;
     constexpr bool EARLY = EARLY_AT != 0;
-    static_assert(EARLY_AT >= 0 && EARLY_AT <= 3, "LRA_V2_EARLY_PASS0: 0 (off) or the epilogue phase 1..3 that carries the next frame's pass 0");
+    static_assert(EARLY_AT >= 0 && EARLY_AT <= 4, "LRA_V2_EARLY_PASS0: 0 (off), the epilogue phase 1..3 that carries the next frame's pass 0, or 4 (split over phases 1 and 3)");
+    // (4: ring shift, prefetch and window multiply after the run reads = phase 1, the butterflies after the band combine = phase 3)
 #define LRA_EARLY_NEXT_PASS0(at)                                                                                   \
+    if (EARLY_AT == 4 && (at == 1 || at == 3) && it + 1 < iters) {                                                  \
+        const int slot_e = slot_of<Cfg>(tid), tf_e = lane_of<Cfg>(tid), next_e = f_first + slot_e * iters + it + 1; \
+        if (at == 1) {                                                                                             \
+            v2_shift<Cfg, HD>(LRA_R(rg));                                                                          \
+            if (it + 2 < iters) v2_issue_loads<Cfg, HD>(a, clip, next_e + 1, tf_e, LRA_R(rg));                      \
+            v2_pass0_window<Cfg, HD>(next_e < a.n_frames, LRA_R(rg));                                              \
+        } else {                                                                                                   \
+            v2_pass0_dft<Cfg, HD>(LRA_R(rg));                                                                      \
+        }                                                                                                          \
+    }                                                                                                              \
     if (EARLY_AT == at && it + 1 < iters) {                                                                        \
         const int slot_e = slot_of<Cfg>(tid), tf_e = lane_of<Cfg>(tid), next_e = f_first + slot_e * iters + it + 1; \
         v2_shift<Cfg, HD>(LRA_R(rg));                                  /* the pairs loaded one frame ago */        \
