@@ -6,7 +6,9 @@ path and its inverse, behind librosa's own Python signatures.
     M = librosa.feature.melspectrogram(y=y, sr=22050, n_fft=2048, hop_length=512, n_mels=128)
     y2 = librosa.istft(D, hop_length=512, length=len(y))
 
-Only this path is provided (see DESIGN.md for the scope table).  Host-side Python validates
+Only this path and the callers right next to it are provided -- decibel scaling, ``feature.mfcc``, ``griffinlim``,
+``phase_vocoder`` / ``effects.time_stretch``, ``decompose.hpss`` / ``effects.hpss``, ``pcen``, ``cqt`` / ``vqt``, ``stream`` (see
+DESIGN.md for the scope table).  Host-side Python validates
 arguments exactly like the reference and builds the small float64 tables (window, mel basis, window
 sum-square); all signal arithmetic runs in hand-written HIP kernels through the C ABI declared in
 ``include/librosa_amd.h``.  There is no CPU fallback: without the built library and a GPU, compute
