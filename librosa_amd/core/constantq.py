@@ -74,6 +74,25 @@ def _decimator(down, res_type, real):
     return taps, half // down
 
 
+def _auto_n_bins(sr, fmin, intervals, gamma, bins_per_octave, filter_scale, window):
+    """``n_bins=None``: as many bins as stay below the Nyquist frequency (``constantq.py:1000-1007, 1017-1019`` with ``__clip_freqs``
+    ``:1599-1657``: one octave more than fits, then the longest prefix whose filters' upper edges are below ``sr / 2``)."""
+    n_over = int(np.ceil(bins_per_octave * (np.log2(sr) - np.log2(fmin))))
+    freqs = interval_frequencies(n_over, fmin=fmin, intervals=intervals if isinstance(intervals, str) else list(intervals), bins_per_octave=bins_per_octave, sort=True)
+    log_f = np.log2(freqs)
+    density = 1 / np.diff(log_f, prepend=0)
+    density[0] = 1 / (log_f[1] - log_f[0])
+    step = 2.0 ** (2 / density)
+    alpha = (step - 1) / (step + 1)
+    offset = alpha * 24.7 / 0.108 if gamma is None else gamma
+    q = float(filter_scale) / alpha
+    upper_edge = np.maximum.accumulate(freqs * (1 + 0.5 * filters.window_bandwidth(window) / q) + 0.5 * offset)
+    keep = int(np.searchsorted(upper_edge, sr / 2.0, side="left"))
+    if keep < 1:
+        raise ParameterError(f"Unable to construct wavelet basis for fmin={freqs[0]:.2f} Hz and sr={sr:.2f} Hz.")
+    return keep
+
+
 @functools.lru_cache(maxsize=16)
 def _plan(sr, hop_length, fmin, n_bins, intervals, gamma, bins_per_octave, filter_scale, norm, sparsity, window, scale, cplx_str):
     """Everything that does not depend on the signal: per-octave FFT size, hop, sparse basis (CSR arrays), row selection and
@@ -129,7 +148,7 @@ def vqt(y, *, sr=22050, hop_length=512, fmin=None, n_bins=84, intervals="equal",
 
     Returns ``(..., n_bins, n_frames)`` complex (complex64 for float32 audio).  ``y`` may be a device tensor (a device tensor is
     returned).  Not provided: ``tuning=None`` (needs the pitch tracker behind ``estimate_tuning``), named just-intonation interval
-    sets (``intervals`` must be ``"equal"`` or an explicit list), ``n_bins=None``.  See the module docstring for ``res_type``.
+    sets (``intervals`` must be ``"equal"`` or an explicit list).  See the module docstring for ``res_type``.
     """
     if not isinstance(intervals, str):
         intervals = tuple(float(v) for v in intervals)
@@ -140,8 +159,6 @@ def vqt(y, *, sr=22050, hop_length=512, fmin=None, n_bins=84, intervals="equal",
         fmin = _C1_HZ
     if tuning is None:
         raise ParameterError("tuning=None (automatic tuning estimation) is not provided by librosa_amd; pass a number")
-    if n_bins is None:
-        raise ParameterError("n_bins=None is not provided by librosa_amd; pass the number of bins")
     if not util.is_positive_int(hop_length):
         raise ParameterError(f"hop_length={hop_length} must be a positive integer")
     on_device = is_torch_tensor(y)
@@ -158,6 +175,8 @@ def vqt(y, *, sr=22050, hop_length=512, fmin=None, n_bins=84, intervals="equal",
     fmin = fmin * 2.0 ** (tuning / bins_per_octave)
     if fmin >= sr / 2:
         raise ParameterError(f"fmin={fmin} must be less than sr/2={sr/2}")
+    if n_bins is None:
+        n_bins = _auto_n_bins(float(sr), float(fmin), intervals, None if gamma is None else float(gamma), int(bins_per_octave), float(filter_scale), window)
     if not (isinstance(pad_mode, str) and pad_mode in _DEVICE_PAD_MODES):
         raise ParameterError(f"pad_mode={pad_mode!r} is not supported by librosa_amd.vqt")
     _decimator(2, res_type, real)  # validates res_type (also when no octave needs a decimation)

@@ -181,9 +181,25 @@ def cqt_response(y, n_fft, hop_length, fft_basis, mode, dtype=None):
     return out.reshape(D.shape[:-2] + (fft_basis.shape[0], D.shape[-1]))
 
 
+def clip_freqs(freqs, window, filter_scale, gamma, sr):
+    """``librosa/core/constantq.py:1630-1657``: the longest prefix of ``freqs`` whose filters all stay below the Nyquist frequency."""
+    logf = np.log2(freqs)
+    window_bw = window_bandwidth(window)
+    bpo = 1 / np.diff(logf, prepend=0)
+    bpo[0] = 1 / (logf[1] - logf[0])
+    alpha = (2.0 ** (2 / bpo) - 1) / (2.0 ** (2 / bpo) + 1)
+    gamma_ = alpha * 24.7 / 0.108 if gamma is None else gamma
+    Q = float(filter_scale) / alpha
+    f_cutoff = np.maximum.accumulate(freqs * (1 + 0.5 * window_bw / Q) + 0.5 * gamma_)
+    idx = np.searchsorted(f_cutoff, sr / 2.0, side="left")
+    if idx < 1:
+        raise ParameterError(f"Unable to construct wavelet basis for fmin={freqs[0]:.2f} Hz and sr={sr:.2f} Hz.")
+    return freqs[:idx]
+
+
 def vqt(y, *, sr=22050, hop_length=512, fmin=None, n_bins=84, intervals="equal", gamma=None, bins_per_octave=12, tuning=0.0, filter_scale=1, norm=1, sparsity=0.01,
         window="hann", scale=True, pad_mode="constant", res_type="polyphase", dtype=None):
-    """``librosa/core/constantq.py:977-1122``.  ``tuning=None`` (pitch tracking) and automatic ``n_bins=None`` clipping are the caller's."""
+    """``librosa/core/constantq.py:977-1122``.  ``tuning=None`` (pitch tracking) is the caller's."""
     if not isinstance(intervals, str):
         bins_per_octave = len(intervals)
     if fmin is None:
@@ -195,9 +211,13 @@ def vqt(y, *, sr=22050, hop_length=512, fmin=None, n_bins=84, intervals="equal",
     fmin = fmin * 2.0 ** (tuning / bins_per_octave)
     if fmin >= sr / 2:
         raise ParameterError(f"fmin={fmin} must be less than sr/2={sr/2}")
-    if n_bins is None:
-        raise ParameterError("n_bins=None is not restated")
+    auto_n_bins = n_bins is None
+    if auto_n_bins:                                                          # :1000-1007: one octave more than fits, clipped below
+        n_bins = int(np.ceil(bins_per_octave * (np.log2(sr) - np.log2(fmin))))
     freqs = interval_frequencies(n_bins, fmin=fmin, intervals=intervals, bins_per_octave=bins_per_octave, sort=True)
+    if auto_n_bins:
+        freqs = clip_freqs(freqs, window, filter_scale, gamma, sr)
+        n_bins = len(freqs)
     if n_bins == 1:
         r = 2 ** (1 / bins_per_octave)
         alpha = np.atleast_1d((r**2 - 1) / (r**2 + 1))                       # :1577-1597

@@ -526,12 +526,16 @@ def test_cqt_shim_through_simulator(monkeypatch):
         got = librosa_amd.cqt(y, res_type="polyphase", **kw)
         exp = CQ.cqt(y, res_type="polyphase", **kw)
         assert got.shape == exp.shape and got.dtype == exp.dtype and np.array_equal(got, exp), kw
+    for kw in (dict(n_bins=None), dict(n_bins=None, fmin=110.0, bins_per_octave=24), dict(n_bins=None, sr=16000, fmin=200.0, filter_scale=0.5)):   # as many bins as fit below Nyquist
+        got, exp = librosa_amd.cqt(y, res_type="polyphase", **kw), CQ.cqt(y, res_type="polyphase", **kw)
+        assert got.shape == exp.shape and np.array_equal(got, exp), kw
+    assert np.array_equal(librosa_amd.vqt(y, n_bins=None, res_type="polyphase"), CQ.vqt(y, n_bins=None, gamma=None, res_type="polyphase"))
     for kw in (dict(gamma=None, bins_per_octave=24, n_bins=96), dict(gamma=5, scale=False), dict(intervals=[1, 1.2, 1.5, 1.8], n_bins=16, fmin=200.0, gamma=0)):
         assert np.array_equal(librosa_amd.vqt(ys, res_type="polyphase", **kw), CQ.vqt(ys, res_type="polyphase", **kw)), kw
     y64 = y.astype(np.float64)
     got, exp = librosa_amd.cqt(y64, res_type="polyphase", n_bins=48), CQ.cqt(y64, res_type="polyphase", n_bins=48)
     assert got.dtype == np.complex128 and np.array_equal(got, exp)
-    for bad in (dict(tuning=None), dict(n_bins=None), dict(fmin=20000.0), dict(n_bins=200), dict(pad_mode="wrap"), dict(hop_length=0)):
+    for bad in (dict(tuning=None), dict(fmin=20000.0), dict(n_bins=200), dict(pad_mode="wrap"), dict(hop_length=0)):
         with pytest.raises(librosa_amd.ParameterError):
             librosa_amd.cqt(y, **bad)
     with pytest.raises(librosa_amd.ParameterError):
