@@ -165,8 +165,12 @@ int lra_istft_exec_host(lra_istft_plan* plan, const void* D_host, int64_t batch,
 /* Arrays are [batch][per_item] (the shim flattens the reduced axes -- "auto" = the last two -- into per_item).
  * out_max[b] = max_i |x[b][i]|: the reduction behind ref=np.max and top_db (log_spec.max(axes), :1877-1881). */
 int lra_item_absmax_exec(lra_ctx* ctx, const void* x, int64_t batch, int64_t per_item, int dtype, void* out_max);
+/* absolute != 0: as above (amplitude_to_db takes np.abs of every input, :2011).  absolute == 0: out_max[b] = max(0, max_i x[b][i]) --
+ * power_to_db leaves real input signed (:1855-1859), and every use of the maximum is max(amin, .) with amin > 0. */
+int lra_item_max_exec(lra_ctx* ctx, const void* x, int64_t batch, int64_t per_item, int dtype, int absolute, void* out_max);
 /* out = 10 log10(max(amin, mag)) - 10 log10(max(amin, ref)), floored at its per-item maximum - top_db (:1873-1881).
- * amplitude != 0: mag = x**2, ref -> ref**2 (amplitude_to_db, :2030-2037; pass amin already squared), else mag = |x|.
+ * amplitude != 0: mag = x**2, ref -> ref**2 (amplitude_to_db, :2030-2037; pass amin already squared), else mag = x as it is
+ * (complex input has its modulus taken by the caller, :1855-1859; negative real values floor at amin).
  * ref_items (device, [batch]) overrides ref_scalar; item_max (device, [batch], input domain) is read when use_top_db. */
 int lra_to_db_exec(lra_ctx* ctx, const void* x, void* out, int64_t batch, int64_t per_item, int dtype, int amplitude, double amin, double ref_scalar,
                    const void* ref_items, const void* item_max, int use_top_db, double top_db);

@@ -69,6 +69,7 @@ SIGNATURES = {
     "lra_istft_exec": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64]),
     "lra_transpose": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int]),
     "lra_item_absmax_exec": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "lra_item_max_exec": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     "lra_to_db_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_int, c_double]),
     "lra_from_db_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_double]),
     "lra_istft_exec_host": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64]),
@@ -380,6 +381,10 @@ class Context:
 
     def item_absmax_exec(self, x_ptr, batch, per_item, dtype, out_ptr):
         _check(self.lib.lra_item_absmax_exec(self.handle, c_void_p(x_ptr), batch, per_item, dtype_code(dtype), c_void_p(out_ptr)))
+
+    def item_max_exec(self, x_ptr, batch, per_item, dtype, out_ptr, absolute):
+        """Per-item maximum of |x| (``absolute``: amplitude_to_db) or of max(x, 0) (power_to_db on real input, which stays signed)."""
+        _check(self.lib.lra_item_max_exec(self.handle, c_void_p(x_ptr), batch, per_item, dtype_code(dtype), int(bool(absolute)), c_void_p(out_ptr)))
 
     def to_db_exec(self, x_ptr, out_ptr, batch, per_item, dtype, amplitude, amin, ref_scalar, ref_items_ptr, item_max_ptr, top_db):
         _check(self.lib.lra_to_db_exec(self.handle, c_void_p(x_ptr), c_void_p(out_ptr), batch, per_item, dtype_code(dtype), int(bool(amplitude)), float(amin), float(ref_scalar),

@@ -1838,7 +1838,9 @@ int lra_istft_exec_host(lra_istft_plan* p, const void* D_host, int64_t batch, in
 }
 
 // ---- decibel scaling and MFCC (lra_post.h) -------------------------------------------------------------------------
-int lra_item_absmax_exec(lra_ctx* ctx, const void* x, int64_t batch, int64_t per_item, int dtype, void* out_max) {
+int lra_item_absmax_exec(lra_ctx* ctx, const void* x, int64_t batch, int64_t per_item, int dtype, void* out_max) { return lra_item_max_exec(ctx, x, batch, per_item, dtype, 1, out_max); }
+
+int lra_item_max_exec(lra_ctx* ctx, const void* x, int64_t batch, int64_t per_item, int dtype, int absolute, void* out_max) {
     LRA_BIND(ctx);
     if (batch <= 0) return LRA_OK;
     if (!x || !out_max) return fail(LRA_EINVAL, "null data pointer");
@@ -1846,10 +1848,14 @@ int lra_item_absmax_exec(lra_ctx* ctx, const void* x, int64_t batch, int64_t per
     const int chunks = post_chunks(batch, per_item, ctx->n_cu);
     if (batch * chunks > 0x7fffffffLL) return fail(LRA_EINVAL, "too many items");
     LRA_HIP(hipMemsetAsync(out_max, 0, (size_t)batch * real_bytes(dtype), ctx->stream));
-    if (dtype == LRA_F64)
-        hipLaunchKernelGGL(item_absmax_kernel<double>, dim3((unsigned)(batch * chunks)), dim3(256), 0, ctx->stream, (const double*)x, (long long)per_item, chunks, (unsigned long long*)out_max);
-    else
-        hipLaunchKernelGGL(item_absmax_kernel<float>, dim3((unsigned)(batch * chunks)), dim3(256), 0, ctx->stream, (const float*)x, (long long)per_item, chunks, (unsigned int*)out_max);
+    const dim3 grid((unsigned)(batch * chunks)), block(256);
+    if (dtype == LRA_F64) {
+        if (absolute) hipLaunchKernelGGL((item_absmax_kernel<double, true>), grid, block, 0, ctx->stream, (const double*)x, (long long)per_item, chunks, (unsigned long long*)out_max);
+        else hipLaunchKernelGGL((item_absmax_kernel<double, false>), grid, block, 0, ctx->stream, (const double*)x, (long long)per_item, chunks, (unsigned long long*)out_max);
+    } else {
+        if (absolute) hipLaunchKernelGGL((item_absmax_kernel<float, true>), grid, block, 0, ctx->stream, (const float*)x, (long long)per_item, chunks, (unsigned int*)out_max);
+        else hipLaunchKernelGGL((item_absmax_kernel<float, false>), grid, block, 0, ctx->stream, (const float*)x, (long long)per_item, chunks, (unsigned int*)out_max);
+    }
     LRA_HIP(hipGetLastError());
     return LRA_OK;
 }

@@ -178,6 +178,28 @@ template <class T> LRA_HD cx<T> axpy_pi(T k, cx<T> u, cx<T> acc) {
 // acc + k u, k real
 template <class T> LRA_HD cx<T> axpy(T k, cx<T> u, cx<T> acc) { return mk<T>(acc.x + k * u.x, acc.y + k * u.y); }
 
+// Per-lane select under a mask that is held in an SGPR pair: c ? a : b as v_cndmask_b32_e64 (VOP3).  hipcc emits the VOP2 form with
+// the implicit VCC operand for most selects, and on gfx950 a v_cndmask_b32_e32 issued directly behind another one stalls the
+// SIMD's vector pipe for ~16 cycles (scripts/valu_probe2.hip: 9.7 ns per instruction back to back at one or two waves per SIMD
+// against 2.0 ns for the VOP3 form and 1.1 ns when another VALU instruction sits in between) -- the lane-0 selects of the
+// mirrored split come in pairs (real / imaginary half), i.e. every second one paid that.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LRA_NO_SEL_ASM)
+#define LRA_SEL_ASM 1
+using LaneMask = unsigned long long;
+__device__ __forceinline__ LaneMask lane_mask(bool c) { return __builtin_amdgcn_ballot_w64(c); }
+__device__ __forceinline__ float sel_mask(LaneMask m, bool, float a, float b) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+__device__ __forceinline__ double sel_mask(LaneMask, bool c, double a, double b) { return c ? a : b; }
+#else
+using LaneMask = bool;
+LRA_HD LaneMask lane_mask(bool c) { return c; }
+template <class T> LRA_HD T sel_mask(LaneMask, bool c, T a, T b) { return c ? a : b; }
+#endif
+template <class T> LRA_HD cx<T> sel_mask(LaneMask m, bool c, cx<T> a, cx<T> b) { return mk<T>(sel_mask(m, c, a.x, b.x), sel_mask(m, c, a.y, b.y)); }
+
 // pad modes for centred framing (np.pad modes the reference forwards, core/spectrum.py:287)
 enum PadMode : int { PAD_CONSTANT = 0, PAD_REFLECT = 1, PAD_EDGE = 2, PAD_SYMMETRIC = 3 };
 
@@ -278,7 +300,23 @@ template <class V> inline void stream_store16(V* p, V v) { *p = v; }
 struct Lds {
     char* base;
 };
-template <class V> LRA_HD V lds_ld(Lds l, int byte_off) { return *reinterpret_cast<const V*>(l.base + byte_off); }
+// LRA_LDS_NOMERGE (experiment): 8-byte LDS reads are issued as volatile loads, which keeps hipcc from fusing neighbouring pairs
+// into ds_read2_b64 / ds_read2st64_b64.  /opt/skills/guides/MI355X_MICROARCH.md (LDS table) prices ds_read2_b64 at 8 LDS cycles per
+// wave-instruction against 2 for ds_read_b64, i.e. the fused form at HALF the rate of the two reads it replaces.
+#ifndef LRA_LDS_NOMERGE
+#define LRA_LDS_NOMERGE 0
+#endif
+template <class V> LRA_HD V lds_ld(Lds l, int byte_off) {
+#if LRA_LDS_NOMERGE
+    if constexpr (sizeof(V) == 8) {
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        // (explicit LDS address space: address-space inference leaves volatile accesses alone, and a flat volatile load is no DS op)
+        const f2v t = *(const volatile __attribute__((address_space(3))) f2v*)(l.base + byte_off);
+        return __builtin_bit_cast(V, t);
+    }
+#endif
+    return *reinterpret_cast<const V*>(l.base + byte_off);
+}
 template <class V> LRA_HD void lds_st(Lds l, int byte_off, V v) { *reinterpret_cast<V*>(l.base + byte_off) = v; }
 LRA_HD Lds lds_sub(Lds l, int byte_off) { Lds r; r.base = l.base + byte_off; return r; }
 

@@ -789,9 +789,10 @@ template <class Cfg> LRA_HD void mel2_combine(const StftArgs<typename Cfg::real>
 // Shared region (per workgroup): w[(M+1) + pads] pairs | addr[2 pmax][n_mels] ints.
 // Per slot: the frame area is reused as the running-sum area rs[R][TF] pairs (+ zero slot, + bin M/2's slot).
 constexpr int MELR_PMAX = 16;  // longest piece list supported (the host falls back to OUT_MEL2 beyond); the lists are stored with their actual length
-// the weight pairs are stored with one pad pair per run of R/2 (index i -> i + i / (R/2)): a thread reads ITS run, so
-// lanes are R/2 + 1 pairs apart -- an odd number of 8-byte slots, i.e. conflict-free instead of 16 lanes per bank
-template <class Cfg> LRA_HD int melr_w_slot(int i) { return i + i / (Cfg::R / 2); }
+// the weight pairs are stored with two pad pairs per run of R/2 (index i -> i + 2 (i / (R/2))): a thread reads ITS run, so lanes
+// are R/2 + 2 pairs = 80 bytes apart -- every run starts on a 16-byte boundary (two pairs per ds_read_b128) and the 16 lanes of
+// a read group start 20 dwords apart, i.e. on 16 distinct 4-bank groups: conflict-free for 8- and 16-byte reads alike
+template <class Cfg> LRA_HD int melr_w_slot(int i) { return i + 2 * (i / (Cfg::R / 2)); }
 template <class Cfg> LRA_HD int melr_keep_off() { return ((melr_w_slot<Cfg>(Cfg::M) + 1) * 2 * (int)sizeof(typename Cfg::real) + 15) / 16 * 16; }
 template <class Cfg> LRA_HD int melr_addr_off() { return melr_keep_off<Cfg>(); }  // (the restart factors live in registers only, melr_hoist)
 // the address table is needed in LDS only for lists longer than the hoisted prefix or more than two bands per thread
@@ -849,7 +850,7 @@ template <class Cfg, int PM> LRA_HD void melr_split_accumulate(const StftArgs<ty
         }
         const T pk = spec_power<T, PM>(xk, a.power), pm = spec_power<T, PM>(xm, a.power);
         // (slot of pair i: i + i / BPL; both halves start on a run boundary, so the thread's pairs are base + j)
-        const C wk = lds_ld<C>(sh, ((BPL + 1) * tf + j) * (int)sizeof(C)), wm = lds_ld<C>(sh, ((BPL + 1) * (TF + tf) + j) * (int)sizeof(C));
+        const C wk = lds_ld<C>(sh, ((BPL + 2) * tf + j) * (int)sizeof(C)), wm = lds_ld<C>(sh, ((BPL + 2) * (TF + tf) + j) * (int)sizeof(C));
         ab[j] = mk<T>(wk.x * pk, wk.y * pk);
         ab[BPL + j] = mk<T>(wm.x * pm, wm.y * pm);
     }

@@ -167,29 +167,15 @@ template <class Cfg, int HD> LRA_HD void v2_shift(Regs2<Cfg, HD>& rg) {
     }
 }
 
-// window and pass-0 butterflies: registers only (raw x window -> v), in two halves for the LRA_V2_EARLY_PASS0 placements
-template <class Cfg, int HD> LRA_HD void v2_pass0_window(bool live, Regs2<Cfg, HD>& rg) {
-    using T = typename Cfg::real;
-    LRA_UNROLL
-    for (int e = 0; e < Cfg::R; ++e) rg.v[e] = live ? mk<T>(rg.raw[e].x * rg.win2[e].x, rg.raw[e].y * rg.win2[e].y) : mk<T>((T)0, (T)0);
-}
-template <class Cfg, int HD> LRA_HD void v2_pass0_dft(Regs2<Cfg, HD>& rg) {
-    using T = typename Cfg::real;
-    constexpr int r0 = Regs2<Cfg, HD>::r0, nb0 = Regs2<Cfg, HD>::nb0;
-    LRA_UNROLL
-    for (int i = 0; i < nb0; ++i) Dft<r0, T>::run(rg.v + i * r0);
-}
-template <class Cfg, int HD> LRA_HD void v2_pass0_arith(bool live, Regs2<Cfg, HD>& rg) {
-    v2_pass0_window<Cfg, HD>(live, rg);
-    v2_pass0_dft<Cfg, HD>(rg);
-}
-
 // phase: window, pass-0 butterflies, first LDS write of the frame
 template <class Cfg, int HD> LRA_HD void v2_pass0(bool live, int tf, Regs2<Cfg, HD>& rg, Lds fr) {
     using T = typename Cfg::real;
     constexpr int r0 = Regs2<Cfg, HD>::r0, nb0 = Regs2<Cfg, HD>::nb0;
+    // (a frame beyond n_frames is transformed like any other -- its ring holds finite stale samples and nothing of it is stored;
+    // zeroing it under `live` cost 12 selects per frame, ten of them back to back: see sel_mask in lra_common.h)
+    (void)live;
     LRA_UNROLL
-    for (int e = 0; e < Cfg::R; ++e) rg.v[e] = live ? mk<T>(rg.raw[e].x * rg.win2[e].x, rg.raw[e].y * rg.win2[e].y) : mk<T>((T)0, (T)0);
+    for (int e = 0; e < Cfg::R; ++e) rg.v[e] = mk<T>(rg.raw[e].x * rg.win2[e].x, rg.raw[e].y * rg.win2[e].y);
     LRA_UNROLL
     for (int i = 0; i < nb0; ++i) Dft<r0, T>::run(rg.v + i * r0);
     pass_write<Cfg, 0>(rg.v, fr, tf);
@@ -208,7 +194,6 @@ template <class Cfg, int HD> LRA_HD void v2_last_read(Regs2<Cfg, HD>& rg, Lds fr
     }
 }
 
-template <class C> LRA_HD C v2_sel(bool c, C a, C b) { return c ? a : b; }
 
 // staged complex epilogue (v2_store_row below): 16-byte pieces, and where a row starts relative to them
 template <class T> struct alignas(16) V4 {
@@ -234,6 +219,7 @@ LRA_HD void v2_last_split_store(const StftArgs<typename Cfg::real>& a, int clip,
     const C* A = rg.v;       // A[j] = Z[tf + j s]          (lane 0: Z[j s])
     const C* B = rg.v + r;   // B[j] = Z[(s - tf) + j s]    (lane 0: Z[s/2 + j s])
     const bool l0 = tf == 0;
+    const LaneMask l0m = lane_mask(l0);
     const int tfh = v2_tf_hi<Cfg>(tf);
     const long long row = ((long long)clip * a.n_frames + frame) * (M + 1);
     C* __restrict__ const D = MODE == OUT_COMPLEX ? a.D + row : nullptr;
@@ -254,18 +240,18 @@ LRA_HD void v2_last_split_store(const StftArgs<typename Cfg::real>& a, int clip,
     for (int q = 0; q < r; ++q) {
         // pair slot q.  Lanes 1..: (A[q], B[r-1-q]) = (Z[k], Z[M-k]), k = tf + q s.  Lane 0: q < r/2: (A[q], A[r-q]), k = q s;
         // q >= r/2: (B[q - r/2], B[3r/2 - 1 - q]), k = s/2 + (q - r/2) s; slot 0 of lane 0 is the DC / Nyquist pair.
-        const C zk = q >= r / 2 ? v2_sel(l0, B[q - r / 2], A[q]) : A[q];
+        const C zk = q >= r / 2 ? sel_mask(l0m, l0, B[q - r / 2], A[q]) : A[q];
         C zm;
         if (q == 0) zm = B[r - 1];
-        else if (q < r / 2) zm = v2_sel(l0, A[r - q], B[r - 1 - q]);
-        else zm = v2_sel(l0, B[3 * r / 2 - 1 - q], B[r - 1 - q]);
+        else if (q < r / 2) zm = sel_mask(l0m, l0, A[r - q], B[r - 1 - q]);
+        else zm = sel_mask(l0m, l0, B[3 * r / 2 - 1 - q], B[r - 1 - q]);
         C xk, xm;
         split_pair<T>(zk, zm, rg.twr[q], xk, xm);
         if (q == 0) {
             const C z0 = A[0];  // Z is pre-halved (see split_pair)
             const C dc = mk<T>((T)2 * (z0.x + z0.y), (T)0), ny = mk<T>((T)2 * (z0.x - z0.y), (T)0);
-            xk = v2_sel(l0, dc, xk);
-            xm = v2_sel(l0, ny, xm);
+            xk = sel_mask(l0m, l0, dc, xk);
+            xm = sel_mask(l0m, l0, ny, xm);
             if (l0 && valid && a.nonfinite_flag && !(std::fabs(dc.x) <= std::numeric_limits<T>::max())) LRA_ATOMIC_OR(a.nonfinite_flag, 1u);
         }
         const int k = (q < r / 2 ? tf : tfh) + q * s;
@@ -347,21 +333,41 @@ template <class Cfg, int HD> LRA_HD void v2_mel_runs_read(Regs2<Cfg, HD>& rg, Ld
     rg.pw_extra = lds_ld<T>(pwr, (tf == 0 ? v2_pw_index(Cfg::M) : 0) * (int)sizeof(T));  // consumed by thread 0 only
 }
 
+// same phase: this thread's 2 x 8 weight pairs (wA, wB) from the workgroup's table -> the butterfly registers (dead between the split
+// and the next frame's window multiply), two pairs per 16-byte read.  They depend on nothing in the frame: issued here, behind the
+// run reads, their latency is covered by the same wait instead of opening the accumulate phase with a second LDS round trip.
+template <class Cfg, int HD> LRA_HD void v2_mel_weights_read(Regs2<Cfg, HD>& rg, Lds sh, int tf) {
+    using T = typename Cfg::real;
+    constexpr int BPL = Cfg::R / 2, TF = Cfg::TF;
+    LRA_UNROLL
+    for (int run = 0; run < 2; ++run) {
+        LRA_UNROLL
+        for (int j = 0; j < BPL; j += 2) {
+            const V4<T> w2 = lds_ld<V4<T>>(sh, ((BPL + 2) * (run * TF + tf) + j) * 2 * (int)sizeof(T));
+            rg.v[run * BPL + j] = mk<T>(w2.a, w2.b);
+            rg.v[run * BPL + j + 1] = mk<T>(w2.c, w2.d);
+        }
+    }
+}
+
 // phase: (wA, wB) x power, running sums along both runs (restart factors in registers) -> rs[jj][tf] (as melr_split_accumulate)
 template <class Cfg, int HD> LRA_HD void v2_mel_accumulate(const StftArgs<typename Cfg::real>& a, int tf, Regs2<Cfg, HD>& rg, Lds rs, Lds sh) {
     using T = typename Cfg::real;
     using C = typename Cfg::cplx;
     constexpr int BPL = Cfg::R / 2, TF = Cfg::TF;
+    // The 16 weight pairs were read in the previous phase (v2_mel_weights_read: rg.v).  (Round 2 read weight j + 1 behind the store
+    // of running sum j; the compiler must keep that order -- it cannot see that `sh` and `rs` never overlap -- and the frame ran 16
+    // dependent LDS round trips here, each behind an s_waitcnt lgkmcnt(0): 0.664 -> 0.635 ms for the 256 x 30 s batch once batched.)
+    const C* w = rg.v;
     LRA_UNROLL
     for (int run = 0; run < 2; ++run) {
         C acc = mk<T>((T)0, (T)0);
         LRA_UNROLL
         for (int j = 0; j < BPL; ++j) {
             const int jj = run * BPL + j;
-            const C w = lds_ld<C>(sh, ((BPL + 1) * (run * TF + tf) + j) * (int)sizeof(C));
             const T p = rg.pw[jj], keep = rg.keep[jj];
-            acc = mk<T>(acc.x * keep + w.x * p, acc.y * keep + w.y * p);
-            lds_st<C>(rs, (jj * TF + tf) * (int)sizeof(C), acc);
+            acc = mk<T>(acc.x * keep + w[jj].x * p, acc.y * keep + w[jj].y * p);
+            lds_st<C>(rs, (jj * (TF + 1) + tf) * (int)sizeof(C), acc);  // pitch TF + 1: lra_mel.h, mel_runs_pitch
         }
     }
     if (tf == 0) {
@@ -378,7 +384,8 @@ template <class Cfg> constexpr int stft2_slot_bytes() { return Cfg::FRAME_BYTES;
 template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2(const StftArgs<typename Cfg::real>& a_in, const int blk, Lds lds) {
     static_assert(v2_cfg_ok<Cfg>(), "configuration has no mirrored last pass");
     static_assert(MODE == OUT_COMPLEX || MODE == OUT_POWER || MODE == OUT_MELR, "epilogues of the second-generation kernel");
-    static_assert(MODE != OUT_MELR || (melr_fits<Cfg>() && v2_pw_bytes<Cfg>() <= Cfg::FRAME_BYTES), "mel epilogue: running sums and power row live in the frame area");
+    static_assert(MODE != OUT_MELR || (melr_fits<Cfg>() && v2_pw_bytes<Cfg>() <= Cfg::FRAME_BYTES && (Cfg::R * (Cfg::TF + 1) + 2) * 2 * (int)sizeof(typename Cfg::real) <= Cfg::FRAME_BYTES),
+                  "mel epilogue: running sums (pitch TF + 1) and power row live in the frame area");
     StftArgs<typename Cfg::real> a = a_in;
     using RG = Regs2<Cfg, HD>;
     const int clip = blk / a.wg_per_clip;
@@ -394,35 +401,6 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
 #define LRA_V2_STAGED 0
 #endif
     constexpr bool STAGED = MODE == OUT_COMPLEX && LRA_V2_STAGED && sizeof(typename Cfg::real) == 4 && (Cfg::M + 3) * (int)sizeof(typename Cfg::cplx) <= SB;
-    // Mel epilogue, experiment (default off): window + pass-0 butterflies of frame t + 1 are register-only work
-    // and the butterfly registers are dead once the power row is written, so they are issued inside the epilogue of frame t to
-    // fill its LDS round trips -- 1: after the run reads, 2: after the running sums' stores, 3: after the band combine's reads
-    // are consumed (i.e. only ahead of the next frame's LDS write), 4: window multiply in phase 1 and butterflies in phase 3; the
-    // frame loop then opens with the LDS write alone.
-#ifndef LRA_V2_EARLY_PASS0
-#define LRA_V2_EARLY_PASS0 0
-#endif
-    constexpr int EARLY_AT = MODE == OUT_MELR ? LRA_V2_EARLY_PASS0 : 0;
-    constexpr bool EARLY = EARLY_AT != 0;
-    static_assert(EARLY_AT >= 0 && EARLY_AT <= 4, "LRA_V2_EARLY_PASS0: 0 (off), the epilogue phase 1..3 that carries the next frame's pass 0, or 4 (split over phases 1 and 3)");
-    // (4: ring shift, prefetch and window multiply after the run reads = phase 1, the butterflies after the band combine = phase 3)
-#define LRA_EARLY_NEXT_PASS0(at)                                                                                   \
-    if (EARLY_AT == 4 && (at == 1 || at == 3) && it + 1 < iters) {                                                  \
-        const int slot_e = slot_of<Cfg>(tid), tf_e = lane_of<Cfg>(tid), next_e = f_first + slot_e * iters + it + 1; \
-        if (at == 1) {                                                                                             \
-            v2_shift<Cfg, HD>(LRA_R(rg));                                                                          \
-            if (it + 2 < iters) v2_issue_loads<Cfg, HD>(a, clip, next_e + 1, tf_e, LRA_R(rg));                      \
-            v2_pass0_window<Cfg, HD>(next_e < a.n_frames, LRA_R(rg));                                              \
-        } else {                                                                                                   \
-            v2_pass0_dft<Cfg, HD>(LRA_R(rg));                                                                      \
-        }                                                                                                          \
-    }                                                                                                              \
-    if (EARLY_AT == at && it + 1 < iters) {                                                                        \
-        const int slot_e = slot_of<Cfg>(tid), tf_e = lane_of<Cfg>(tid), next_e = f_first + slot_e * iters + it + 1; \
-        v2_shift<Cfg, HD>(LRA_R(rg));                                  /* the pairs loaded one frame ago */        \
-        if (it + 2 < iters) v2_issue_loads<Cfg, HD>(a, clip, next_e + 1, tf_e, LRA_R(rg));                          \
-        v2_pass0_arith<Cfg, HD>(next_e < a.n_frames, LRA_R(rg));                                                   \
-    }
     LRA_REGS(RG, rg, Cfg::NT);
     LRA_PHASE(Cfg::NT, tid) {
         const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
@@ -432,24 +410,15 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
             melr_tables_to_lds<Cfg>(a, tid, lds_sub(lds, a.shared_off));
             melr_hoist<Cfg>(a, tf, LRA_R(rg), slot * SB);  // (addresses relative to the workgroup's LDS, not to the slot)
         }
-        if (EARLY) {
-            const int frame0 = f_first + slot * iters;
-            if (iters > 1) v2_issue_loads<Cfg, HD>(a, clip, frame0 + 1, tf, LRA_R(rg));
-            v2_pass0_arith<Cfg, HD>(frame0 < a.n_frames, LRA_R(rg));
-        }
     } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC && MODE != OUT_MELR)  // the shared mel tables need a workgroup barrier, once
     for (int it = 0; it < iters; ++it) {
         if (f_first + it >= a.n_frames) break;  // slot 0 has the smallest frame index: uniform exit
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
             RG& r = LRA_R(rg);
-            if (EARLY) {
-                pass_write<Cfg, 0>(r.v, lds_sub(lds, slot * SB), tf);                   // the butterflies ran during the previous frame's epilogue
-            } else {
-                if (it > 0) v2_shift<Cfg, HD>(r);                                       // consumes the pairs loaded during the previous frame
-                if (it + 1 < iters) v2_issue_loads<Cfg, HD>(a, clip, frame + 1, tf, r);  // ... and starts the next batch, BEFORE this frame's stores
-                v2_pass0<Cfg, HD>(frame < a.n_frames, tf, r, lds_sub(lds, slot * SB));
-            }
+            if (it > 0) v2_shift<Cfg, HD>(r);                                       // consumes the pairs loaded during the previous frame
+            if (it + 1 < iters) v2_issue_loads<Cfg, HD>(a, clip, frame + 1, tf, r);  // ... and starts the next batch, BEFORE this frame's stores
+            v2_pass0<Cfg, HD>(frame < a.n_frames, tf, r, lds_sub(lds, slot * SB));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
 #define LRA_MID_PASS2(p)                                                                                                  \
         if (Cfg::P - 1 > p) {                                                                                             \
@@ -480,24 +449,33 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
         if (MODE == OUT_MELR) {
             // power row -> runs in registers; then (only then: the running sums reuse the row's bytes) weights, running sums
             // -> rs; then every band adds its piece totals (melr_combine, shared with the first-generation kernel)
+            // LRA_MEL_ABLATE = n (timing experiments, scripts/ab_run.sh): the last n of the three epilogue phases sit behind a
+            // condition that is never true at run time, so the code, its registers and everything upstream stay as they are
+#ifndef LRA_MEL_ABLATE
+#define LRA_MEL_ABLATE 0
+#endif
+            const bool ablate_never = LRA_MEL_ABLATE > 0 && a.power == (typename Cfg::real)12345.678;
+            if (LRA_MEL_ABLATE < 3 || ablate_never) {
             LRA_PHASE(Cfg::NT, tid) {
                 v2_mel_runs_read<Cfg, HD>(LRA_R(rg), lds_sub(lds, slot_of<Cfg>(tid) * SB), lane_of<Cfg>(tid));
-                LRA_EARLY_NEXT_PASS0(1)
+                v2_mel_weights_read<Cfg, HD>(LRA_R(rg), lds_sub(lds, a.shared_off), lane_of<Cfg>(tid));
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+            }
+            if (LRA_MEL_ABLATE < 2 || ablate_never) {
             LRA_PHASE(Cfg::NT, tid) {
                 v2_mel_accumulate<Cfg, HD>(a, lane_of<Cfg>(tid), LRA_R(rg), lds_sub(lds, slot_of<Cfg>(tid) * SB), lds_sub(lds, a.shared_off));
-                LRA_EARLY_NEXT_PASS0(2)
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+            }
+            if (LRA_MEL_ABLATE < 1 || ablate_never) {
             LRA_PHASE(Cfg::NT, tid) {
                 const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
                 const Lds sl = lds_sub(lds, slot * SB);
                 if (frame < a.n_frames)
                     melr_combine<Cfg>(a, clip, frame, tf, it, 1, it + 1 == iters || frame + 1 >= a.n_frames, LRA_R(rg), lds_sub(lds, a.shared_off), sl, sl, lds);
-                LRA_EARLY_NEXT_PASS0(3)
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+            }
         }
     }
-#undef LRA_EARLY_NEXT_PASS0
 }
 
 }  // namespace lra

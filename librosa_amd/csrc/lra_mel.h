@@ -157,7 +157,10 @@ template <class T> struct MelRuns {
 
 // layout 0 (first-generation kernels): run A = bins bpl t + j, run B = bins M - bpl t - j (mirrored), extra bin M/2;
 // layout 1 (second-generation kernel, which reads its runs from a power row in LDS): run A = bins bpl t + j, run B = bins
-// M/2 + bpl t + j (both ascending), extra bin M; the weight table is then in plain bin order.
+// M/2 + bpl t + j (both ascending), extra bin M; the weight table is then in plain bin order.  Layout 1 also stores the running
+// sums with a pitch of TF + 1 pairs per register slot: with a pitch of TF all 2 bpl sums of one thread share one pair of LDS banks,
+// and the bands of the low mel range -- whose pieces all come from the first few threads -- gathered them with multi-way conflicts.
+inline int mel_runs_pitch(int tf_count, int layout) { return layout == 1 ? tf_count + 1 : tf_count; }
 template <class T> inline MelRuns<T> build_mel_runs(const TwoSlope<T>& ts, int tf_count, int bpl, int pmax, int min_len, int layout = 0) {
     MelRuns<T> mr;
     mr.tf = tf_count;
@@ -165,7 +168,8 @@ template <class T> inline MelRuns<T> build_mel_runs(const TwoSlope<T>& ts, int t
     mr.pmax = pmax;
     const int M = ts.n_bins - 1;
     if (!ts.ok || bpl < 1 || 2 * bpl * tf_count != M || pmax < 1) return mr;
-    const int half = M / 2, slots = 2 * bpl * tf_count, pair_bytes = 2 * (int)sizeof(T);
+    const int pitch = mel_runs_pitch(tf_count, layout);
+    const int half = M / 2, slots = 2 * bpl * pitch, pair_bytes = 2 * (int)sizeof(T);
     mr.zero_addr = slots * pair_bytes;
     mr.mid_addr = (slots + 1) * pair_bytes;
     if (mr.mid_addr + pair_bytes > 65535) return mr;
@@ -202,7 +206,7 @@ template <class T> inline MelRuns<T> build_mel_runs(const TwoSlope<T>& ts, int t
                     if (j > 0 && cur >= 0) {  // the previous slot closed a piece of segment cur
                         const int pj = jj - 1;
                         int lo = bin_of(t, pj), hi = lo;
-                        pieces.push_back({cur, (pj * tf_count + t) * pair_bytes, 0});
+                        pieces.push_back({cur, (pj * pitch + t) * pair_bytes, 0});
                         (void)lo; (void)hi;
                     }
                     cur = seg >= 0 ? seg : -2;
@@ -210,14 +214,14 @@ template <class T> inline MelRuns<T> build_mel_runs(const TwoSlope<T>& ts, int t
                     cur = seg;  // first weighted bin of a stretch that began with unweighted bins
                 }
             }
-            if (cur >= 0) pieces.push_back({cur, ((run * bpl + bpl - 1) * tf_count + t) * pair_bytes, 0});
+            if (cur >= 0) pieces.push_back({cur, ((run * bpl + bpl - 1) * pitch + t) * pair_bytes, 0});
         }
     }
     if (ts.owner[extra_bin] >= 0) pieces.push_back({ts.owner[extra_bin], mr.mid_addr, 0});
     // lowest bin of each piece (for ordering): recompute from the address
     for (auto& pc : pieces) {
         if (pc.addr == mr.mid_addr) { pc.lowbin = extra_bin; continue; }
-        const int slot = pc.addr / pair_bytes, jj = slot / tf_count, t = slot % tf_count;
+        const int slot = pc.addr / pair_bytes, jj = slot / pitch, t = slot % pitch;
         pc.lowbin = bin_of(t, jj);  // run A: the last (highest) bin; run B: the last slot is the LOWEST bin -- either orders pieces consistently
     }
     std::vector<std::vector<Piece>> by_seg((size_t)ts.n_mels + 1);

@@ -27,7 +27,10 @@ template <> struct MaxBits<double> {
     static __device__ type bits(double v) { return (unsigned long long)__double_as_longlong(v); }
 };
 
-template <class T> __global__ __launch_bounds__(256) void item_absmax_kernel(const T* __restrict__ x, long long per_item, int chunks_per_item, typename MaxBits<T>::type* __restrict__ out) {
+// ABS: max |x| (amplitude_to_db takes np.abs of every input, core/spectrum.py:2011); otherwise max(0, max x): power_to_db leaves real
+// input signed (:1855-1859), and everything downstream takes max(amin, .) of the maximum with amin > 0, so clamping it at zero is
+// exact and keeps the bit-pattern ordering of the combine.
+template <class T, bool ABS> __global__ __launch_bounds__(256) void item_absmax_kernel(const T* __restrict__ x, long long per_item, int chunks_per_item, typename MaxBits<T>::type* __restrict__ out) {
     const long long item = blockIdx.x / chunks_per_item;
     const int chunk = blockIdx.x % chunks_per_item;
     const T* __restrict__ xi = x + item * per_item;
@@ -35,7 +38,7 @@ template <class T> __global__ __launch_bounds__(256) void item_absmax_kernel(con
     const long long lo = chunk * per_chunk, hi = lo + per_chunk < per_item ? lo + per_chunk : per_item;
     T m = (T)0;
     for (long long i = lo + threadIdx.x; i < hi; i += 256) {
-        const T v = xi[i] < (T)0 ? -xi[i] : xi[i];
+        const T v = xi[i] < (T)0 ? (ABS ? -xi[i] : (T)0) : xi[i];
         m = v > m ? v : m;  // NaN never wins: the reference's np.max would propagate it, but NaN power is rejected upstream
     }
     __shared__ T red[256];
@@ -87,7 +90,7 @@ template <class T, bool AMP> __global__ __launch_bounds__(256) void to_db_kernel
     T* __restrict__ oi = out + item * per_item;
     for (long long i = lo + threadIdx.x; i < hi; i += 256) {
         T v = xi[i];
-        v = AMP ? v * v : (v < (T)0 ? -v : v);
+        if (AMP) v = v * v;  // (power_to_db does NOT take |x| of real input: negative values floor at amin, core/spectrum.py:1855-1873)
         const T db = db_of<T>(v, d.amin, ref_db);
         oi[i] = db > floor_db ? db : floor_db;
     }
@@ -125,7 +128,6 @@ __global__ __launch_bounds__(256) void dct_rows_kernel(const T* __restrict__ S, 
     for (int m = 0; m < n_in; ++m) {
         T v = s[(long long)m * n_frames];
         if (DB) {
-            v = v < (T)0 ? -v : v;
             const T db = db_of<T>(v, d.amin, ref_db);
             v = db > floor_db ? db : floor_db;
         }

@@ -64,9 +64,12 @@ def _stage(y):
 
 def _hpss_parts(y, which, kernel_size, power, mask, margin, n_fft, hop_length, win_length, window, center, pad_mode):
     yd, staged = _stage(y)
-    D = spectrum.stft(yd, n_fft=n_fft, hop_length=hop_length, win_length=win_length, window=window, center=center, pad_mode=pad_mode, check_finite=not staged)
+    # The reference accepts `window` and then passes it to NEITHER transform (effects.py:161-183): analysis, synthesis and the
+    # window-sum-square normalisation all run with the default window.  Same here (forwarding it to the forward transform only
+    # would analyse with one window and synthesise with another, which matches neither the reference nor a consistent pair).
+    del window
+    D = spectrum.stft(yd, n_fft=n_fft, hop_length=hop_length, win_length=win_length, center=center, pad_mode=pad_mode, check_finite=not staged)
     parts = decompose.hpss(D, kernel_size=kernel_size, power=power, mask=mask, margin=margin)
-    # the reference inverts WITHOUT passing `window` on (effects.py:161-183): the inverse always uses its default window
     ikw = dict(dtype=_arrays.numpy_dtype_of(y), n_fft=n_fft, hop_length=hop_length, win_length=win_length, center=center, length=y.shape[-1])
     if mask:  # the reference then inverts the (real-valued) masks themselves; irfft takes them as spectra with zero phase
         cplx = np.dtype(np.complex128) if _arrays.numpy_dtype_of(D) == np.complex128 else np.dtype(np.complex64)

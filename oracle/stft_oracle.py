@@ -671,8 +671,10 @@ def hpss(S, *, kernel_size=31, power=2.0, mask=False, margin=1.0):
 
 
 def effects_hpss(y, *, kernel_size=31, power=2.0, mask=False, margin=1.0, n_fft=2048, hop_length=None, win_length=None, window="hann", center=True, pad_mode="constant"):
-    """``librosa/effects.py:70-185``: stft -> decompose.hpss -> two istft (which are called WITHOUT ``window``, as in the reference)."""
-    D = stft(y, n_fft=n_fft, hop_length=hop_length, win_length=win_length, window=window, center=center, pad_mode=pad_mode)
+    """``librosa/effects.py:70-185``: stft -> decompose.hpss -> two istft.  ``window`` is accepted and passed to NONE of the three
+    transforms (``:161-183``), exactly as the reference does: all of them run with the default window."""
+    del window
+    D = stft(y, n_fft=n_fft, hop_length=hop_length, win_length=win_length, center=center, pad_mode=pad_mode)
     Dh, Dp = hpss(D, kernel_size=kernel_size, power=power, mask=mask, margin=margin)
     ikw = dict(dtype=y.dtype, n_fft=n_fft, hop_length=hop_length, win_length=win_length, center=center, length=y.shape[-1])
     return istft(Dh, **ikw), istft(Dp, **ikw)

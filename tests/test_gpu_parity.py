@@ -1305,6 +1305,9 @@ def _hpss_golden_body(L):
     assert h.shape == y.shape and h.dtype == y.dtype and np.abs(h - g["effects_h"]).max() <= 1e-4 * scale and np.abs(p - g["effects_p"]).max() <= 1e-4 * scale
     assert np.abs(L.effects.harmonic(y[0]) - g["effects_harmonic_default"]).max() <= 1e-4 * scale
     assert np.abs(L.effects.percussive(y[0], kernel_size=9, n_fft=1024, hop_length=256) - g["effects_percussive_k9"]).max() <= 1e-4 * scale
+    # `window` is accepted and ignored by all three transforms, as in the reference (effects.py:161-183)
+    hw, pw_ = L.effects.hpss(y, n_fft=512, margin=(1.0, 2.0), window="hamming")
+    assert np.array_equal(hw, h) and np.array_equal(pw_, p)
     ht, pt = L.effects.hpss(torch.from_numpy(y).cuda(), n_fft=512, margin=(1.0, 2.0))
     assert isinstance(ht, torch.Tensor) and ht.is_cuda and np.array_equal(ht.cpu().numpy(), h) and np.array_equal(pt.cpu().numpy(), p)
     for bad in (dict(margin=0.5), dict(margin=(1.0, 0.9)), dict(power=0), dict(kernel_size=0)):

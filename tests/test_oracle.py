@@ -407,3 +407,16 @@ def test_hpss_oracle_known_answers():
             O.hpss(S, margin=m)
     Hm, Pm = O.hpss(S, margin=(1.0, 4.0))
     assert np.all(Hm + Pm <= S * (1 + 1e-6))     # wider margins leave a residual
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="/root/reference not present (GPU box)")
+def test_hpss_oracle_live_reference_ignores_window():
+    """effects.hpss accepts `window` and passes it to none of its three transforms (effects.py:161-183): a non-default window changes
+    nothing in the reference, and therefore nothing in the restatement (the shim used to forward it to the forward stft)."""
+    L = ref_shim.load_reference()
+    y = golden_cases.make_signal("mix", 6000, 7, (), "float32")
+    rh, rp = L.effects.hpss(y, n_fft=512, window="hamming")
+    dh, dp = L.effects.hpss(y, n_fft=512)
+    assert np.array_equal(rh, dh) and np.array_equal(rp, dp)
+    oh, op = O.effects_hpss(y, n_fft=512, window="hamming")
+    assert np.array_equal(oh, rh) and np.array_equal(op, rp)
