@@ -349,7 +349,7 @@ def istft(stft_matrix, *, hop_length=None, win_length=None, n_fft=None, window="
         else:
             if Dt.flags["C_CONTIGUOUS"] and Dt.dtype == cplx:
                 # NumPy in, NumPy out with the spectrum already frame-major (what stft returns): the native host pipeline
-                yh = out if (out is not None and out.dtype == real and out.flags["C_CONTIGUOUS"]) else np.empty((batch, int(expected)), dtype=real)
+                yh = out if (out is not None and out.dtype == real and out.flags["C_CONTIGUOUS"] and out.flags["WRITEABLE"]) else np.empty((batch, int(expected)), dtype=real)
                 ctx.istft_exec_host(plan, Dt.ctypes.data, batch, n_total, n_used, wss.ctypes.data, yh.ctypes.data, int(expected), int(expected))
                 if yh is out:
                     return out
@@ -784,6 +784,8 @@ def _to_db(S, ref, amin, top_db, axes, amplitude, name):
         raise ParameterError("amin must be strictly positive")
     if top_db is not None and top_db < 0:
         raise ParameterError("top_db must be non-negative")
+    if not callable(ref) and ((ref.ndim if is_torch_tensor(ref) else np.ndim(ref)) > 0):
+        return _to_db_array_ref(S, ref, amin, top_db, axes, amplitude, name)
     S, real = _magnitude_and_dtype(S, name)
     scalar_in = S.ndim == 0
     red = _db_axes(S.ndim, axes)
@@ -799,7 +801,10 @@ def _to_db(S, ref, amin, top_db, axes, amplitude, name):
         else:
             # any other reduction runs on the host exactly as the reference calls it (core/spectrum.py:1861-1869); device
             # tensors are copied down for it (a slow path: prefer ref=np.max or a number)
-            host = np.abs(S.detach().cpu().numpy()) if is_torch_tensor(S) else np.abs(S)
+            # (power_to_db hands real input to `ref` as it is, amplitude_to_db its modulus: core/spectrum.py:1855-1869, 2011-2022)
+            host = S.detach().cpu().numpy() if is_torch_tensor(S) else S
+            if amplitude:
+                host = np.abs(host)
             try:
                 rv = ref(host, axis=(red if S.ndim else None), keepdims=True)
             except TypeError as exc:
@@ -816,7 +821,7 @@ def _to_db(S, ref, amin, top_db, axes, amplitude, name):
         max_ptr = None
         if device_max_as_ref or top_db is not None:
             max_ptr = sess.scratch(batch * real.itemsize)
-            ctx.item_absmax_exec(x_ptr, batch, per_item, real, max_ptr)
+            ctx.item_max_exec(x_ptr, batch, per_item, real, max_ptr, absolute=amplitude)  # power_to_db: real input stays signed
         ref_ptr = max_ptr if device_max_as_ref else (sess.input_raw(_as_like(sess, ref_items_host), real) if ref_items_host is not None else None)
         ctx.to_db_exec(x_ptr, out_ptr, batch, per_item, real, amplitude, amin * amin if amplitude else amin, ref_scalar, ref_ptr, max_ptr, top_db)
         out = sess.result(handle)
@@ -824,6 +829,43 @@ def _to_db(S, ref, amin, top_db, axes, amplitude, name):
         sess.close()
     out = restore(out)
     return out[()] if scalar_in and not is_torch_tensor(out) else out
+
+
+def _to_db_array_ref(S, ref, amin, top_db, axes, amplitude, name):
+    """Array-valued ``ref`` (anything that broadcasts against ``S``, e.g. one reference per channel; ``core/spectrum.py:1867-1875``):
+    the scaling runs on the device with ``ref = 1``, the broadcast subtraction and the ``top_db`` floor on the result."""
+    if top_db is not None and top_db < 0:
+        raise ParameterError("top_db must be non-negative")
+    base = _to_db(S, 1.0, amin, None, axes, amplitude, name)  # 10 log10(max(A, mag)) - 10 log10(max(A, 1))
+    A = amin * amin if amplitude else amin
+    red = _db_axes(base.ndim, axes)
+    # |ref| (squared for amplitudes) and its logarithm in ref's OWN precision, as the reference evaluates them (:1869-1875)
+    rv = np.abs(ref.detach().cpu().numpy() if is_torch_tensor(ref) else np.asarray(ref))
+    rv = rv * rv if amplitude else rv
+    if is_torch_tensor(base):
+        torch = _arrays._torch()
+        ref_db = torch.as_tensor(np.asarray(10.0 * np.log10(np.maximum(A, rv)), dtype=np.float64), device=base.device)
+        try:
+            out = ((base.to(torch.float64) + 10.0 * np.log10(max(A, 1.0))) - ref_db).to(base.dtype)
+        except RuntimeError as exc:
+            raise ParameterError(f"ref of shape {tuple(rv.shape)} does not broadcast against the input of shape {tuple(base.shape)}") from exc
+        if tuple(out.shape) != tuple(base.shape):
+            raise ParameterError(f"ref of shape {tuple(rv.shape)} does not broadcast against the input of shape {tuple(base.shape)}")
+        if top_db is not None and red:
+            out = torch.maximum(out, out.amax(dim=red, keepdim=True) - top_db)
+        return out
+    out = np.array(base, copy=True)
+    try:
+        fits = np.broadcast_shapes(out.shape, np.shape(rv)) == out.shape
+    except ValueError:
+        fits = False
+    if not fits:
+        raise ParameterError(f"ref of shape {np.shape(rv)} does not broadcast against the input of shape {out.shape}")
+    out += 10.0 * np.log10(max(A, 1.0))
+    out -= 10.0 * np.log10(np.maximum(A, rv))  # in place: the result keeps the input's precision, as the reference's `log_spec -= ...` does
+    if top_db is not None:
+        out = np.maximum(out, out.max(axis=red if out.ndim else None, keepdims=True) - top_db)
+    return out
 
 
 def power_to_db(S, *, ref=1.0, amin=1e-10, top_db=80.0, axes="auto"):
@@ -842,6 +884,13 @@ def amplitude_to_db(S, *, ref=1.0, amin=1e-5, top_db=80.0, axes="auto"):
 
 
 def _from_db(S_db, ref, amplitude):
+    if is_torch_tensor(ref) or np.ndim(ref) > 0:  # array-valued ref: broadcast on the result (core/spectrum.py:1925, 2082)
+        p = _from_db(S_db, 1.0, False)
+        if is_torch_tensor(p) and not is_torch_tensor(ref):
+            ref = _arrays._torch().as_tensor(np.asarray(ref), device=p.device)
+        elif not is_torch_tensor(p) and is_torch_tensor(ref):
+            ref = ref.detach().cpu().numpy()
+        return (ref ** 2 * p) ** 0.5 if amplitude else ref * p
     x = S_db if is_torch_tensor(S_db) else np.asarray(S_db)
     scalar_in = x.ndim == 0
     real = np.dtype(np.float32) if _arrays.numpy_dtype_of(x) == np.float32 else np.dtype(np.float64)

@@ -1203,6 +1203,16 @@ int host_pipeline(lra_ctx* ctx, int64_t batch, size_t in_item, size_t in_stride,
         (void)hipStreamSynchronize(compute);
         (void)hipStreamSynchronize(hp->s_out);
     }
+    // A stage is at least one whole item, so one very long clip (an hour of audio: 0.3 GB in, 2.5 GB of spectrum out) sizes the
+    // two pinned + two device slots far beyond pipe_chunk_mb.  Such slots do not outlive the call: only staging of up to four
+    // nominal stages per direction persists in the context (what a streaming caller reuses block after block).
+    const size_t keep_cap = (size_t)4 * ((size_t)ctx->opt_pipe_chunk_mb << 20);
+    if (hp->in_cap > keep_cap || hp->out_cap > keep_cap) {
+        (void)hipStreamSynchronize(hp->s_in);
+        (void)hipStreamSynchronize(compute);
+        (void)hipStreamSynchronize(hp->s_out);
+        hp->release_buffers(hp->in_cap > keep_cap, hp->out_cap > keep_cap);
+    }
     return rc;
 }
 

@@ -1484,7 +1484,10 @@ template <class Cfg, int HC> LRA_HD void istft_last_ola_rows(const IstftArgs<typ
     using T = typename Cfg::real;
     using C = typename Cfg::cplx;
     constexpr int p = Cfg::P - 1, lr = Cfg::logr(p), r = 1 << lr, nb = Cfg::R >> lr;
-    constexpr int R = Cfg::R, TF = Cfg::TF, CH = R < 8 ? R : 8;
+    // float: ONE chunk -- all carry pairs are read before the butterflies below (their latency hides behind ~100 packed instructions),
+    // the frame is added, everything is written.  (In chunks of 8 the second chunk's reads sat behind the first chunk's writes -- the
+    // compiler cannot reorder LDS accesses it cannot tell apart -- i.e. two more dependent LDS round trips per frame.)
+    constexpr int R = Cfg::R, TF = Cfg::TF, CH = sizeof(T) == 4 ? R : (R < 8 ? R : 8);
     constexpr int hc = HC, clc = R - hc;
     static_assert((1 << Cfg::logs(p)) == nb * TF, "last-pass output stride must be nb rows");
     const C* __restrict__ ws2 = reinterpret_cast<const C*>(a.win_scaled);
@@ -1492,12 +1495,17 @@ template <class Cfg, int HC> LRA_HD void istft_last_ola_rows(const IstftArgs<typ
     const C zero = mk<T>((T)0, (T)0);
     const int rbase = tf * (int)sizeof(C);
     const int wbase = (tf - hc * TF) * (int)sizeof(C);  // pair c lands on pair c - hc
+    C cv0[CH];
+    if (CH == R) {
+        LRA_UNROLL
+        for (int q = 0; q < CH; ++q) cv0[q] = q < clc ? lds_ld<C>(carry, rbase + q * TF * (int)sizeof(C)) : zero;
+    }
     pass_dft<Cfg, p>(rg, tf, a.tw);
     LRA_UNROLL
     for (int c0 = 0; c0 < R; c0 += CH) {
         C cv[CH];
         LRA_UNROLL
-        for (int q = 0; q < CH; ++q) cv[q] = (c0 + q) < clc ? lds_ld<C>(carry, rbase + (c0 + q) * TF * (int)sizeof(C)) : zero;
+        for (int q = 0; q < CH; ++q) cv[q] = CH == R ? cv0[q] : ((c0 + q) < clc ? lds_ld<C>(carry, rbase + (c0 + q) * TF * (int)sizeof(C)) : zero);
         LRA_UNROLL
         for (int q = 0; q < CH; ++q) {
             const int c = c0 + q, i = c % nb, j = c / nb;
@@ -1534,11 +1542,32 @@ template <class Cfg> LRA_HD IstftRowWin<Cfg> istft_row_window(const IstftArgs<ty
     w.hi = in_strip ? (int)hi : w.lo;  // empty window when the frame is outside the strip
     return w;
 }
-template <class Cfg, int HC> LRA_HD void istft_wss_rows(const IstftArgs<typename Cfg::real>& a, int t, bool in_strip, int tf, FftRegs<Cfg>& rg) {
+// The usual frame: its whole hop block lies inside the output and is stored by this slot, and the block starts on an 8-byte
+// boundary (even hop, even clip stride).  Wave-uniform, so the fast paths below are behind ONE scalar branch: unconditional 8-byte
+// loads / stores of whole sample pairs.  (Per-sample bound tests compiled to a dozen exec-mask branches and 4-byte accesses per frame.)
+// Uniform only where a slot is one or more whole waves (TF >= 64); narrower slots take the same paths under a per-lane condition.
+template <class Cfg, int HC> LRA_HD bool istft_rows_interior(const IstftArgs<typename Cfg::real>& a, long long clip, int t, bool in_strip) {
+    using T = typename Cfg::real;
+    const long long s_first = (long long)t * a.hop - a.drop;  // output index of the block's first sample (thread 0, pair 0)
+    const bool inside = in_strip && s_first >= 0 && s_first + 2 * HC * Cfg::TF <= a.out_len;
+    const bool aligned = ((reinterpret_cast<size_t>(a.y + clip * a.y_stride + s_first) | reinterpret_cast<size_t>(a.wss + s_first)) & (2 * sizeof(T) - 1)) == 0;
+    return inside && aligned;
+}
+template <class Cfg, int HC> LRA_HD void istft_wss_rows(const IstftArgs<typename Cfg::real>& a, long long clip, int t, bool in_strip, int tf, FftRegs<Cfg>& rg) {
     using T = typename Cfg::real;
     constexpr int TF = Cfg::TF;
     const IstftRowWin<Cfg> w = istft_row_window<Cfg>(a, t, in_strip, tf);
     const T* __restrict__ wb = a.wss + w.s0;
+    const bool interior = istft_rows_interior<Cfg, HC>(a, clip, t, in_strip);
+    if (Cfg::TF >= 64 ? (bool)LRA_UNIFORM(interior) : interior) {  // (a slot narrower than a wave shares it with other slots: per-lane there)
+        LRA_UNROLL
+        for (int c = 0; c < HC; ++c) {
+            const cx<T> p2 = *reinterpret_cast<const cx<T>*>(wb + 2 * c * TF);
+            rg.wv[2 * c] = p2.x;
+            rg.wv[2 * c + 1] = p2.y;
+        }
+        return;
+    }
     LRA_UNROLL
     for (int i = 0; i < 2 * HC; ++i) {
         const int off = 2 * (i >> 1) * TF + (i & 1);
@@ -1557,6 +1586,12 @@ template <class Cfg, int HC> LRA_HD void istft_flush_rows(const IstftArgs<typena
     for (int i = 0; i < 2 * HC; ++i) {
         val[i] = (rg.wv[i] > a.tiny) ? fast_div(rg.out[i], rg.wv[i]) : rg.out[i];
         LRA_KEEP(val[i]);
+    }
+    const bool interior = istft_rows_interior<Cfg, HC>(a, clip, t, in_strip);
+    if (Cfg::TF >= 64 ? (bool)LRA_UNIFORM(interior) : interior) {  // (a slot narrower than a wave shares it with other slots: per-lane there)
+        LRA_UNROLL
+        for (int c = 0; c < HC; ++c) *reinterpret_cast<cx<T>*>(yb + 2 * c * TF) = mk<T>(val[2 * c], val[2 * c + 1]);
+        return;
     }
     LRA_UNROLL
     for (int i = 0; i < 2 * HC; ++i) {
@@ -1678,16 +1713,29 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
             if constexpr (EARLY) istft_unsplit_pass0_write<Cfg>(tf, LRA_R(rg), lds_sub(lds, slot * SB));
             else if constexpr (MIR) istft_unsplit_pass0<Cfg>(tf, LRA_R(rg), lds_sub(lds, slot * SB));
             else istft_split_write<Cfg>(a, tf, LRA_R(rg), lds_sub(lds, slot * SB));
-            if (defer && j > 0 && s.active) {
+#ifndef LRA_ISTFT_ABLATE  // timing experiments (scripts/ab_run.sh): bit 0 = no spectrum loads in the frame loop, bit 1 = no output stores
+#define LRA_ISTFT_ABLATE 0
+#endif
+            const bool ablate_never = LRA_ISTFT_ABLATE != 0 && a.tiny == (T)12345.678;  // never true at run time
+#ifndef LRA_ISTFT_LOADS_FIRST
+#define LRA_ISTFT_LOADS_FIRST 1
+#endif
+            auto prefetch = [&]() {
+                if (!EARLY && j + 1 < steps && (!(LRA_ISTFT_ABLATE & 1) || ablate_never)) {
+                    if constexpr (MIR) istft_spec_load_mir<Cfg>(a, s.clip, t + 1, s.active && t + 1 >= 0 && t + 1 < s.t1, tf, LRA_R(rg));
+                    else istft_spec_load<Cfg>(a, s.clip, t + 1, s.active && t + 1 >= 0 && t + 1 < s.t1, tf, LRA_R(rg));
+                }
+            };
+            // the next frame's spectrum loads go out BEFORE the held-back stores: vector-memory operations retire in order, so loads
+            // queued behind stores are only seen complete once those stores have been acknowledged
+            if (LRA_ISTFT_LOADS_FIRST) prefetch();
+            if (defer && j > 0 && s.active && (!(LRA_ISTFT_ABLATE & 2) || ablate_never)) {
                 if constexpr (rows) istft_flush_rows<Cfg, HC>(a, s.clip, t - 1, t - 1 >= s.t0 && (s.last || t - 1 < s.t1), tf, LRA_R(rg));
                 else istft_flush_out<Cfg>(a, s.clip, t - 1, s.write_lo, s.write_hi, tf, LRA_R(rg));
             }
-            if (!EARLY && j + 1 < steps) {
-                if constexpr (MIR) istft_spec_load_mir<Cfg>(a, s.clip, t + 1, s.active && t + 1 >= 0 && t + 1 < s.t1, tf, LRA_R(rg));
-                else istft_spec_load<Cfg>(a, s.clip, t + 1, s.active && t + 1 >= 0 && t + 1 < s.t1, tf, LRA_R(rg));
-            }
+            if (!LRA_ISTFT_LOADS_FIRST) prefetch();
             if constexpr (rows) {  // for the flush of THIS frame, one iteration from now
-                if (s.active) istft_wss_rows<Cfg, HC>(a, t, t >= s.t0 && (s.last || t < s.t1), tf, LRA_R(rg));
+                if (s.active) istft_wss_rows<Cfg, HC>(a, s.clip, t, t >= s.t0 && (s.last || t < s.t1), tf, LRA_R(rg));
             }
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         // pass 0 (no twiddles) reads from LDS here, unlike the forward kernel (unless it was fused into the Hermitian step)

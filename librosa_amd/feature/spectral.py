@@ -88,7 +88,7 @@ def mfcc(*, y=None, sr=22050, S=None, n_mfcc=20, dct_type=2, norm="ortho", lifte
         tables["n_out"] = n_out
         ctx = sess.ctx
         max_ptr = sess.scratch(batch * real.itemsize)
-        ctx.item_absmax_exec(mel_ptr, batch, n_mels * n_frames, real, max_ptr)  # power_to_db's top_db = 80 (defaults, :2001)
+        ctx.item_max_exec(mel_ptr, batch, n_mels * n_frames, real, max_ptr, absolute=False)  # power_to_db's top_db = 80 (defaults, :2001)
         out_ptr, handle = sess.output((batch, n_out, n_frames), real)
         ctx.dct_exec(mel_ptr, out_ptr, batch, n_mels, n_out, n_frames, real, sess.input_raw(_spectrum._as_like(sess, basis), real),
                      sess.input_raw(_spectrum._as_like(sess, lift), real), fuse_db=True, amin=1e-10, ref_scalar=1.0, item_max_ptr=max_ptr, top_db=80.0)

@@ -96,38 +96,52 @@ def dtype_c2r(d, *, default=np.float32):
     return np.dtype(table.get(dt, default))
 
 
-def normalize(S, *, norm=np.inf, axis=0, threshold=None):
-    """Scale ``S`` to unit ``norm`` along ``axis`` -- the part of ``librosa.util.normalize``
-    (``librosa/util/utils.py:796-1025``) this path reaches: ``filters.mel(norm=<number>)`` (``filters.py:238-239``)
-    and ``window_sumsquare(norm=...)`` (``filters.py:1325-1327``), both with the default ``fill=None``.
+def normalize(S, *, norm=np.inf, axis=0, threshold=None, fill=None):
+    """Scale ``S`` to unit ``norm`` along ``axis``: ``librosa.util.normalize`` (``librosa/util/utils.py:796-1025``).  On this path it is
+    reached from ``filters.mel(norm=<number>)`` (``filters.py:238-239``) and ``window_sumsquare(norm=...)`` (``filters.py:1325-1327``),
+    both with the default ``fill=None``.
 
-    ``norm``: ``None`` (no scaling), ``+-inf`` (max / min magnitude), ``0`` (number of non-zeros) or ``p > 0``
-    (the l_p norm).  Slices whose norm is below ``threshold`` (default: ``tiny`` of the dtype) are left unscaled.
+    ``norm``: ``None`` (no scaling), ``+-inf`` (max / min magnitude), ``0`` (number of non-zeros) or ``p > 0`` (the l_p norm).
+    Slices whose norm is below ``threshold`` (default: ``tiny`` of the dtype) are left unscaled (``fill=None``), set to the constant
+    that has unit norm (``fill=True``: 1 for the max / min norms, ``n ** (-1 / p)`` for l_p; undefined for ``norm=0``) or set to zero
+    (``fill=False``).
     """
-    if norm is None:
-        return S
     if threshold is None:
         threshold = tiny(S)
     elif threshold <= 0:
         raise ParameterError(f"threshold={threshold} must be strictly positive")
+    if not (fill is None or fill is True or fill is False):
+        raise ParameterError(f"fill={fill} must be None or boolean")
     S = np.asarray(S)
     if not np.isfinite(S).all():
         raise ParameterError("Input must be finite")
+    if norm is None:
+        return S
     magnitude = np.abs(S).astype(float)
     reduce_kw = dict(axis=axis, keepdims=True)
-    if isinstance(norm, (int, float, np.number)) and np.isposinf(norm):
+    is_number = isinstance(norm, (int, float, np.number))
+    unit_fill = 1.0  # the constant slice of unit norm (max / min norms)
+    if is_number and np.isposinf(norm):
         scale = magnitude.max(**reduce_kw)
-    elif isinstance(norm, (int, float, np.number)) and np.isneginf(norm):
+    elif is_number and np.isneginf(norm):
         scale = magnitude.min(**reduce_kw)
-    elif isinstance(norm, (int, float, np.number)) and norm == 0:
+    elif is_number and norm == 0:
+        if fill is True:
+            raise ParameterError("Cannot normalize with norm=0 and fill=True")
         scale = np.count_nonzero(magnitude, **reduce_kw).astype(magnitude.dtype)
-    elif isinstance(norm, (int, float, np.number)) and norm > 0:
+    elif is_number and norm > 0:
         scale = np.sum(magnitude**norm, **reduce_kw) ** (1.0 / norm)
+        unit_fill = float(magnitude.size if axis is None else magnitude.shape[axis]) ** (-1.0 / norm)
     else:
         raise ParameterError(f"Unsupported norm: {norm!r}")
-    scale = np.where(scale < threshold, 1.0, scale)
+    small = scale < threshold
     out = np.empty_like(S)
-    out[...] = S / scale
+    if fill is None:
+        out[...] = S / np.where(small, 1.0, scale)
+    elif fill:
+        out[...] = np.where(np.broadcast_to(small, S.shape), unit_fill, S / np.where(small, 1.0, scale))
+    else:
+        out[...] = np.where(np.broadcast_to(small, S.shape), 0, S / np.where(small, 1.0, scale))
     return out
 
 

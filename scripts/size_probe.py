@@ -39,8 +39,11 @@ elif what == "mel":
     fn = lambda: ctx.melspectrogram_exec(pl, mp, y.data_ptr(), batch, n, n, 2.0, Mo.data_ptr())
 else:
     fn = lambda: ctx.stft_exec(pl, y.data_ptr(), batch, n, n, D.data_ptr())
-for _ in range(5): fn()
-torch.cuda.synchronize()
+import time
+t_end = time.time() + float(os.environ.get("PROBE_PREWARM_S", "0.4"))  # an idle MI355X runs its first ~0.2 s of work at reduced clocks
+while time.time() < t_end:
+    for _ in range(20): fn()
+    torch.cuda.synchronize()
 best = 1e9
 for rep in range(3):
     e0, e1 = ctx.event(), ctx.event(); e0.record()

@@ -560,6 +560,28 @@ def test_db_golden(L):
     assert abs(float(L.power_to_db(np.float32(0.5))) - float(O.power_to_db(np.float32(0.5)))) <= DB_TOL
     v = np.abs(np.random.default_rng(0).standard_normal(1000)) ** 2
     assert np.abs(L.power_to_db(v, ref=np.max) - O.power_to_db(v, ref=np.max)).max() <= 1e-10
+    # real input stays SIGNED in power_to_db (negative values floor at amin; ref / top_db from the signed maximum); amplitude_to_db takes
+    # the modulus; array-valued ref broadcasts (core/spectrum.py:1855-1881, 2011-2037)
+    import torch
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((3, 20, 30)).astype(np.float32)
+    neg = -np.abs(X) - 1.0
+    refc = np.array([0.5, 2.0, 1e-12])[:, None, None]
+    for Xi in (X, neg, X.astype(np.float64)):
+        tol = DB_TOL if Xi.dtype == np.float32 else 1e-10
+        for kw in (dict(), dict(ref=np.max), dict(ref=np.max, top_db=30.0), dict(top_db=None), dict(ref=np.median), dict(ref=refc), dict(ref=refc.astype(np.float32), top_db=None)):
+            got, want = L.power_to_db(Xi, **kw), O.power_to_db(Xi, **kw)
+            assert got.shape == want.shape and got.dtype == want.dtype and np.abs(got - want).max() <= tol, (kw, np.abs(got - want).max())
+            dev = L.power_to_db(torch.from_numpy(Xi).cuda(), **kw)
+            assert dev.is_cuda and np.abs(dev.cpu().numpy() - want).max() <= tol, kw
+        for kw in (dict(), dict(ref=np.max), dict(ref=refc, top_db=40.0)):
+            got, want = L.amplitude_to_db(Xi, **kw), O.amplitude_to_db(Xi, **kw)
+            assert got.dtype == want.dtype and np.abs(got - want).max() <= tol, kw
+    dbv = (rng.standard_normal((3, 4, 5)) * 10).astype(np.float32)
+    assert np.all(np.abs(L.db_to_power(dbv, ref=refc) - O.db_to_power(dbv, ref=refc)) <= 2e-6 * np.abs(O.db_to_power(dbv, ref=refc)))
+    assert np.all(np.abs(L.db_to_amplitude(dbv, ref=refc) - O.db_to_amplitude(dbv, ref=refc)) <= 2e-6 * np.abs(O.db_to_amplitude(dbv, ref=refc)))
+    with pytest.raises(L.ParameterError):
+        L.power_to_db(X, ref=np.ones((7, 1, 1)))
     with pytest.raises(L.ParameterError):
         L.power_to_db(M, amin=0)
     with pytest.raises(L.ParameterError):

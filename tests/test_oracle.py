@@ -420,3 +420,58 @@ def test_hpss_oracle_live_reference_ignores_window():
     assert np.array_equal(rh, dh) and np.array_equal(rp, dp)
     oh, op = O.effects_hpss(y, n_fft=512, window="hamming")
     assert np.array_equal(oh, rh) and np.array_equal(op, rp)
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="/root/reference not present (GPU box)")
+def test_db_oracle_live_reference_signed_and_array_ref():
+    """power_to_db leaves REAL input signed (negative values floor at amin; ref / top_db from the signed maximum), amplitude_to_db takes
+    the modulus; `ref` may be an array that broadcasts against S (core/spectrum.py:1855-1881, 2011-2037).  Restatement == reference."""
+    L = ref_shim.load_reference()
+    rng = np.random.default_rng(5)
+    S = rng.standard_normal((3, 20, 30)).astype(np.float32)            # e.g. a difference of spectrograms: both signs
+    neg = -np.abs(S) - 1.0                                             # every value negative
+    refc = np.array([0.5, 2.0, 1e-12])[:, None, None]
+    for X in (S, neg, S.astype(np.float64)):
+        for kw in (dict(), dict(ref=np.max), dict(ref=np.max, top_db=30.0), dict(top_db=None), dict(ref=np.median), dict(ref=refc), dict(ref=refc.astype(np.float32), top_db=None)):
+            a, b = L.power_to_db(X, **kw), O.power_to_db(X, **kw)
+            assert a.dtype == b.dtype and np.array_equal(a, b), kw
+        for kw in (dict(), dict(ref=np.max), dict(ref=refc, top_db=40.0)):
+            a, b = L.amplitude_to_db(X, **kw), O.amplitude_to_db(X, **kw)
+            assert a.dtype == b.dtype and np.array_equal(a, b), kw
+    db = rng.standard_normal((3, 4, 5)).astype(np.float32) * 10
+    for r in (refc, np.float32(2.0)):
+        assert np.array_equal(L.db_to_power(db, ref=r), O.db_to_power(db, ref=r)) and np.array_equal(L.db_to_amplitude(db, ref=r), O.db_to_amplitude(db, ref=r))
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="/root/reference not present (GPU box)")
+def test_normalize_matches_the_live_reference():
+    """util.normalize incl. ``fill`` (None / True / False) and ``threshold``: bit-equal to librosa.util.normalize (util/utils.py:796-1025) on
+    real / complex input, every norm kind and axis, error cases alike (the keyword had been dropped)."""
+    import warnings
+    from librosa_amd.util import utils as U
+    R = ref_shim.load_reference()
+    rng = np.random.default_rng(0)
+    S = rng.standard_normal((5, 7))
+    S[:, 2] = 0
+    S[1] *= 1e-320
+    Sc = S + 1j * rng.standard_normal((5, 7))
+    Sc[:, 2] = 0
+    for X in (S, Sc, S.astype(np.float32)):
+        for norm in (np.inf, -np.inf, 0, 1, 2, 0.5, None, "bad"):
+            for axis in (0, -1, None):
+                for fill in (None, True, False, 3):
+                    for thr in (None, 0.5, -1.0):
+                        res = []
+                        for fn in (R.util.normalize, U.normalize):
+                            try:
+                                with warnings.catch_warnings():
+                                    warnings.simplefilter("ignore")
+                                    res.append(fn(X, norm=norm, axis=axis, fill=fill, threshold=thr))
+                            except Exception as exc:  # noqa: BLE001 -- both sides must raise the same kind
+                                res.append(type(exc).__name__)
+                        a, b = res
+                        assert isinstance(a, str) == isinstance(b, str), (norm, axis, fill, thr, a, b)
+                        if isinstance(a, str):
+                            assert a == b == "ParameterError", (norm, axis, fill, thr, a, b)
+                        else:
+                            assert a.dtype == b.dtype and np.array_equal(a, b, equal_nan=True), (norm, axis, fill, thr)
