@@ -118,6 +118,29 @@ def _padded_window(window, win_length, n_fft):
     return util.pad_center(np.asarray(filters.get_window(window, win_length, fftbins=True), dtype=np.float64), size=n_fft)
 
 
+@functools.lru_cache(maxsize=32)
+def _istft_wss_cached(window, n_frames, win_length, n_fft, hop, center, expected, out_dtype, real):
+    wss = filters.window_sumsquare(window=window, n_frames=n_frames, win_length=win_length, n_fft=n_fft, hop_length=hop, dtype=np.dtype(out_dtype))
+    wss = np.ascontiguousarray(util.fix_length(wss[(n_fft // 2 if center else 0) :], size=expected), dtype=np.dtype(real))
+    wss.setflags(write=False)
+    return wss
+
+
+def _istft_wss(window, n_frames, win_length, n_fft, hop, center, expected, out_dtype, real):
+    """The inverse transform's window sum-square envelope, computed on the host in the output precision exactly as the reference does
+    (``core/spectrum.py:606-620``: ``window_sumsquare`` -> drop the centre padding -> ``fix_length``), and the key under which a context
+    may keep its device copy (None for window specifications that cannot be hashed).  The envelope depends on the arguments only; its
+    O(n_frames x n_fft) fill loop is 2-8 ms on a host core, which dwarfed the 0.1 ms kernel of a 32-clip device-resident call."""
+    args = (int(n_frames), int(win_length), int(n_fft), int(hop), bool(center), int(expected), np.dtype(out_dtype).str, np.dtype(real).str)
+    if isinstance(window, (str, tuple, float, int)):
+        try:
+            return _istft_wss_cached(window, *args), ("istft_wss", window) + args
+        except TypeError:
+            pass
+    wss = filters.window_sumsquare(window=window, n_frames=n_frames, win_length=win_length, n_fft=n_fft, hop_length=int(hop), dtype=out_dtype)
+    return np.ascontiguousarray(util.fix_length(wss[(n_fft // 2 if center else 0) :], size=int(expected)), dtype=real), None
+
+
 def _finite_check_covers_input(n, n_fft, hop, center):
     """True when every input sample lies in some frame, so the kernels' DC-bin flag sees it."""
     if hop > n_fft:
@@ -326,9 +349,7 @@ def istft(stft_matrix, *, hop_length=None, win_length=None, n_fft=None, window="
         if not np.allclose(out.shape, shape):
             raise ParameterError(f"Shape mismatch for provided output array out.shape={out.shape} != {list(shape)}")
     # window sum-square on the host, in the output precision, exactly as the reference (:606-620)
-    wss = filters.window_sumsquare(window=window, n_frames=n_frames, win_length=win_length, n_fft=n_fft, hop_length=int(hop_length), dtype=out_dtype)
-    wss = util.fix_length(wss[(n_fft // 2 if center else 0) :], size=int(expected))
-    wss = np.ascontiguousarray(wss, dtype=real)
+    wss, wss_key = _istft_wss(window, n_frames, win_length, n_fft, int(hop_length), center, expected, out_dtype, real)
     n_bins = 1 + n_fft // 2
     sess = _arrays.Session(D)
     try:
@@ -364,7 +385,7 @@ def istft(stft_matrix, *, hop_length=None, win_length=None, n_fft=None, window="
                 src_ptr = sess.input_raw(np.ascontiguousarray(D, dtype=cplx), cplx)
                 d_ptr = sess.scratch(batch * n_total * n_bins * cplx.itemsize)
                 _transpose_batched(ctx, src_ptr, d_ptr, batch, n_bins, n_total, cplx.itemsize)
-        wss_ptr = sess.input_raw(_as_like(sess, wss), real)
+        wss_ptr = ctx.device_table(wss_key, lambda: wss) if (wss_key is not None and wss.nbytes <= (64 << 20)) else sess.input_raw(_as_like(sess, wss), real)
         y_ptr, handle = sess.output((batch, int(expected)), real)
         ctx.istft_exec(plan, d_ptr, batch, n_total * n_bins, n_bins, n_used, wss_ptr, y_ptr, int(expected), int(expected))
         y = sess.result(handle)
@@ -495,8 +516,7 @@ def griffinlim(S, *, n_iter=32, hop_length=None, win_length=None, n_fft=None, wi
     rebuilt_frames = 1 + (expected + (2 * (n_fft // 2) if center else 0) - n_fft) // hop
     if rebuilt_frames != n_total:
         raise ParameterError(f"the signal of length {expected} rebuilt from S has {rebuilt_frames} frames, S has {n_total}: could not iterate")
-    wss = filters.window_sumsquare(window=window, n_frames=n_frames, win_length=win_length, n_fft=n_fft, hop_length=hop, dtype=out_dtype)
-    wss = np.ascontiguousarray(util.fix_length(wss[(n_fft // 2 if center else 0) :], size=expected), dtype=real)
+    wss, wss_key = _istft_wss(window, n_frames, win_length, n_fft, hop, center, expected, out_dtype, real)
     lead = tuple(S.shape[:-2])
     batch = int(np.prod(lead, dtype=np.int64)) if lead else 1
     # the uniform draws come from the host generator in the reference's order (S.shape, C order, :2834) so that a seed
@@ -514,7 +534,7 @@ def griffinlim(S, *, n_iter=32, hop_length=None, win_length=None, n_fft=None, wi
         angles = sess.scratch(count * cplx.itemsize)
         rebuilt = sess.scratch(count * cplx.itemsize)
         tprev = sess.scratch(count * cplx.itemsize)
-        wss_ptr = sess.input_raw(_as_like(sess, wss), real)
+        wss_ptr = ctx.device_table(wss_key, lambda: wss) if (wss_key is not None and wss.nbytes <= (64 << 20)) else sess.input_raw(_as_like(sess, wss), real)
         y_ptr, handle = sess.output((batch, expected), real)
         coef = momentum / (1 + momentum)
         check = ctx.stft_is_fused(splan) and _finite_check_covers_input(expected, n_fft, hop, center)

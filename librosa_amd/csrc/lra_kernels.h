@@ -1275,7 +1275,7 @@ template <class Cfg> LRA_HD void istft_spec_load_mir(const IstftArgs<typename Cf
     rg.xmid = X[M / 2];
 }
 
-// The two halves of istft_unsplit_pass0 below, for the LRA_ISTFT_EARLY experiment: the register-only part (pairs -> conj Z' in
+// The two halves of istft_unsplit_pass0 below: the register-only part (pairs -> conj Z' in
 // first-pass order, first-pass butterflies) and the first LDS write of the frame.
 template <class Cfg> LRA_HD void istft_unsplit_pass0_arith(int tf, FftRegs<Cfg>& rg) {
     using T = typename Cfg::real;
@@ -1672,13 +1672,6 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
     const int steps = a.warm_frames + a.strip_frames + (has_last ? a.drain_steps : 0);
     const bool defer = ROWS || 4 * a.hop <= Cfg::N;  // finished samples per hop fit the hold-back registers
     constexpr bool rows = ROWS;
-    // Experiment (default off): the Hermitian step + first-pass butterflies of frame t + 1 are register-only work on
-    // the prefetched spectrum; issued at the end of frame t's overlap-add phase (whose butterfly registers are dead by then) they fill
-    // that phase's LDS round trips, and the frame loop opens with the LDS write alone.  The prefetch of frame t + 2 follows them.
-#ifndef LRA_ISTFT_EARLY
-#define LRA_ISTFT_EARLY 0
-#endif
-    constexpr bool EARLY = LRA_ISTFT_EARLY && ROWS && MIR;
     LRA_TICK_DECL;  // (the pass macro shared with the forward kernel ticks; the inverse kernel does not report)
     LRA_REGS(FftRegs<Cfg>, rg, Cfg::NT);
     // the slot's strip (64-bit divisions) is worked out once, from the un-laundered thread index
@@ -1697,10 +1690,6 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
         const int t = s.t0 - a.warm_frames;
         if constexpr (MIR) istft_spec_load_mir<Cfg>(a, s.clip, t, s.active && t >= 0 && t < s.t1, tf, LRA_R(rg));
         else istft_spec_load<Cfg>(a, s.clip, t, s.active && t >= 0 && t < s.t1, tf, LRA_R(rg));
-        if constexpr (EARLY) {
-            if (steps > 0) istft_unsplit_pass0_arith<Cfg>(tf, LRA_R(rg));
-            if (steps > 1) istft_spec_load_mir<Cfg>(a, s.clip, t + 1, s.active && t + 1 >= 0 && t + 1 < s.t1, tf, LRA_R(rg));
-        }
     } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
     for (int j = 0; j < steps; ++j) {
         if (!Cfg::HOIST) { LRA_LAUNDER(a.win_scaled); LRA_LAUNDER(a.tw); LRA_LAUNDER(a.twr); }
@@ -1710,8 +1699,7 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
             const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
             const IstftSlot<Cfg> s = LRA_R(sl);
             const int t = s.t0 - a.warm_frames + j;
-            if constexpr (EARLY) istft_unsplit_pass0_write<Cfg>(tf, LRA_R(rg), lds_sub(lds, slot * SB));
-            else if constexpr (MIR) istft_unsplit_pass0<Cfg>(tf, LRA_R(rg), lds_sub(lds, slot * SB));
+            if constexpr (MIR) istft_unsplit_pass0<Cfg>(tf, LRA_R(rg), lds_sub(lds, slot * SB));
             else istft_split_write<Cfg>(a, tf, LRA_R(rg), lds_sub(lds, slot * SB));
 #ifndef LRA_ISTFT_ABLATE  // timing experiments (scripts/ab_run.sh): bit 0 = no spectrum loads in the frame loop, bit 1 = no output stores
 #define LRA_ISTFT_ABLATE 0
@@ -1721,7 +1709,7 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
 #define LRA_ISTFT_LOADS_FIRST 1
 #endif
             auto prefetch = [&]() {
-                if (!EARLY && j + 1 < steps && (!(LRA_ISTFT_ABLATE & 1) || ablate_never)) {
+                if (j + 1 < steps && (!(LRA_ISTFT_ABLATE & 1) || ablate_never)) {
                     if constexpr (MIR) istft_spec_load_mir<Cfg>(a, s.clip, t + 1, s.active && t + 1 >= 0 && t + 1 < s.t1, tf, LRA_R(rg));
                     else istft_spec_load<Cfg>(a, s.clip, t + 1, s.active && t + 1 >= 0 && t + 1 < s.t1, tf, LRA_R(rg));
                 }
@@ -1759,10 +1747,6 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
                 const IstftSlot<Cfg> s = LRA_R(sl);
                 const int t = s.t0 - a.warm_frames + j;
                 if (s.active) istft_last_ola_rows<Cfg, HC>(a, t >= 0 && t < s.t1, tf, LRA_R(rg), lds_sub(lds, slot * SB));
-                if constexpr (EARLY) {
-                    if (j + 1 < steps) istft_unsplit_pass0_arith<Cfg>(tf, LRA_R(rg));   // frame t + 1, prefetched one iteration ago
-                    if (j + 2 < steps) istft_spec_load_mir<Cfg>(a, s.clip, t + 2, s.active && t + 2 >= 0 && t + 2 < s.t1, tf, LRA_R(rg));
-                }
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
             continue;
         }
