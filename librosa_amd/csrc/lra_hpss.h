@@ -76,6 +76,15 @@ __device__ __forceinline__ long long hpss_reflect(long long i, long long n) {
     return i < n ? i : period - 1 - i;
 }
 
+// compare-exchange as v_min / v_max (2 issue cycles each).  Spelled `a < b ? a : b` / `a < b ? b : a` it compiled to v_cmp + two
+// v_cndmask_b32_e32 back to back -- and on gfx950 a VOP2 select directly behind another stalls the SIMD's vector pipe ~16 cycles
+// (profiles/r03_experiments.md): 382 exchanges per element spent most of the kernel's time in that stall.  The windows hold
+// magnitudes (and +inf in unused slots): no NaN, no negative zero, so min / max select exactly the values the comparisons would.
+__device__ __forceinline__ float hpss_min(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ float hpss_max(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double hpss_min(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ double hpss_max(double a, double b) { return __builtin_fmax(a, b); }
+
 // Batcher's odd-even merge sort over CAP register slots (CAP a power of two; every index is a compile-time constant after unrolling)
 template <class T, int CAP> __device__ __forceinline__ void hpss_sort(T (&a)[CAP]) {
 #pragma unroll
@@ -87,8 +96,8 @@ template <class T, int CAP> __device__ __forceinline__ void hpss_sort(T (&a)[CAP
 #pragma unroll
                 for (int i = 0; i < k; ++i)
                     if (i + j + k < CAP && (i + j) / (2 * p) == (i + j + k) / (2 * p)) {
-                        const T lo = a[i + j] < a[i + j + k] ? a[i + j] : a[i + j + k];
-                        const T hi = a[i + j] < a[i + j + k] ? a[i + j + k] : a[i + j];
+                        const T lo = hpss_min(a[i + j], a[i + j + k]);
+                        const T hi = hpss_max(a[i + j], a[i + j + k]);
                         a[i + j] = lo;
                         a[i + j + k] = hi;
                     }
@@ -98,8 +107,19 @@ template <class T, int CAP> __device__ __forceinline__ void hpss_sort(T (&a)[CAP
 template <class T, int CAP> __device__ __forceinline__ T hpss_median(const T* __restrict__ base, long long first, long long n, long long stride, int win) {
     if constexpr (CAP > 0) {
         T a[CAP];
+        if (first >= 0 && first + win <= n) {
+            // the window lies inside the axis (all but the first / last win / 2 positions): a walking pointer, no index fold -- the
+            // reflect() of the general path is a 64-bit modulo per tap (~30 instructions), which was most of the kernel's work
+            const T* __restrict__ p = base + first * stride;
 #pragma unroll
-        for (int j = 0; j < CAP; ++j) a[j] = j < win ? base[hpss_reflect(first + j, n) * stride] : HpssLimits<T>::inf();
+            for (int j = 0; j < CAP; ++j) {
+                a[j] = j < win ? *p : HpssLimits<T>::inf();
+                if (j + 1 < win) p += stride;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CAP; ++j) a[j] = j < win ? base[hpss_reflect(first + j, n) * stride] : HpssLimits<T>::inf();
+        }
         hpss_sort<T, CAP>(a);
         T v = a[0];
 #pragma unroll
