@@ -438,14 +438,15 @@ template <class Cfg> LRA_HD void stft_direct_pass0(const StftArgs<typename Cfg::
     using C = typename Cfg::cplx;
     constexpr int lr = Cfg::logr(0), r = 1 << lr, nb = Cfg::R >> lr, sin = Cfg::M >> lr;
     const C* __restrict__ win2 = reinterpret_cast<const C*>(a.win);
-    const bool live = frame < a.n_frames;
+    // (a frame beyond n_frames is transformed like any other -- finite stale samples, nothing of it is stored: no zeroing selects,
+    // which hipcc emits as back-to-back VOP2 v_cndmask pairs; see sel_mask in lra_common.h)
     LRA_UNROLL
     for (int i = 0; i < nb; ++i) {
         LRA_UNROLL
         for (int j = 0; j < r; ++j) {
             const C w = Cfg::HOIST ? rg.win2[i * r + j] : win2[tf + i * Cfg::TF + j * sin];
             const C x = rg.nxt[i * r + j];
-            rg.v[i * r + j] = live ? mk<T>(x.x * w.x, x.y * w.y) : mk<T>((T)0, (T)0);
+            rg.v[i * r + j] = mk<T>(x.x * w.x, x.y * w.y);
         }
     }
     if (more) stft_direct_fetch<Cfg>(a, clip, frame + 1, tf, rg);
@@ -534,11 +535,10 @@ template <class Cfg, int HD> LRA_HD void regring_pass0(const StftArgs<typename C
         }
     }
     if (more) regring_issue<Cfg, HD>(a, clip, frame + 1, tf, rg);
-    const bool live = frame < a.n_frames;
     LRA_UNROLL
-    for (int e = 0; e < Cfg::R; ++e) {
+    for (int e = 0; e < Cfg::R; ++e) {  // (no zeroing of frames beyond n_frames: see stft_direct_pass0)
         const C w = Cfg::HOIST ? rg.win2[e] : win2[RR::q_of(tf, e)];
-        rg.v[e] = live ? mk<T>(rg.raw[e].x * w.x, rg.raw[e].y * w.y) : mk<T>((T)0, (T)0);
+        rg.v[e] = mk<T>(rg.raw[e].x * w.x, rg.raw[e].y * w.y);
     }
     pass_dft<Cfg, 0>(rg, tf, a.tw);
     pass_write<Cfg, 0>(rg.v, fr, tf);
