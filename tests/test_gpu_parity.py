@@ -83,7 +83,17 @@ def test_extreme_sizes(L, n_fft, hop):
         assert _mel_close(M, O.melspectrogram(y=y, n_fft=n_fft, hop_length=hop, n_mels=32))
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
+def _sweep_seeds():
+    """1, 2, 3 in the suite; LRA_SWEEP_SEEDS="4-40" (a range or a comma list) widens the sweep for a one-off stress run."""
+    extra = os.environ.get("LRA_SWEEP_SEEDS", "")
+    seeds = [1, 2, 3]
+    for part in filter(None, extra.split(",")):
+        lo, _, hi = part.partition("-")
+        seeds += list(range(int(lo), int(hi or lo) + 1))
+    return seeds
+
+
+@pytest.mark.parametrize("seed", _sweep_seeds())
 def test_random_configurations(L, seed):
     """Seeded sweep over (n_fft power of two or not, hop aligned or not or beyond n_fft, dtype, center, pad mode,
     win_length, 1-D / 2-D input): stft, istft and melspectrogram against the oracle.  The inverse is compared where
