@@ -10,7 +10,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "hostsim", "hostsim.cpp")
-# LRA_HOSTSIM_DEFINES="-DLRA_V2_EARLY_PASS0=1 ...": simulate a kernel experiment (compile-time flag) in its own library
+# LRA_HOSTSIM_DEFINES="-DLRA_MEL_ABLATE=1 ...": simulate a kernel experiment (compile-time flag) in its own library
 EXTRA_DEFINES = os.environ.get("LRA_HOSTSIM_DEFINES", "").split()
 _TAG = "".join(c if c.isalnum() else "_" for c in "".join(EXTRA_DEFINES))
 SO = os.path.join(HERE, "hostsim", f"_hostsim{_TAG}.so")
