@@ -27,6 +27,16 @@
 #define LRA_UNROLL _Pragma("unroll")
 #endif
 
+// branch-probability hints: hipcc's block placement then keeps the rare paths (np.pad folds at a clip's edges, the non-finite flag,
+// piece lists beyond the hoisted prefix) out of the frame loop's fall-through chain
+#ifndef LRA_NO_EXPECT
+#define LRA_LIKELY(x) __builtin_expect(!!(x), 1)
+#define LRA_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#else
+#define LRA_LIKELY(x) (x)
+#define LRA_UNLIKELY(x) (x)
+#endif
+
 namespace lra {
 
 // ----------------------------------------------------------------------------- complex helpers

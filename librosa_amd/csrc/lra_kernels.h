@@ -921,7 +921,7 @@ template <class Cfg, class RG> LRA_HD void melr_combine(const StftArgs<typename 
             T acc = (T)0;
             LRA_UNROLL
             for (int q = 0; q < PH; ++q) acc += x[b][h * PH + q];
-            if (more) {
+            if (LRA_UNLIKELY(more)) {
                 for (int q = PH; q < a.melr_pmax; ++q)
                     acc += lds_ld<T>(rs, lds_ld<int>(sh, melr_addr_off<Cfg>() + ((h * a.melr_pmax + q) * a.n_mels + m) * (int)sizeof(int)));
             }

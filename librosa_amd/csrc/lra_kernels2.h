@@ -118,9 +118,9 @@ template <class Cfg, int HD> LRA_HD void v2_issue_loads(const StftArgs<typename 
     const T* __restrict__ yb = a.y + (long long)clip * a.y_stride;
     const long long p0 = (long long)next * a.hop;               // padded position of the frame's first sample
     const long long g0 = p0 + (Cfg::N - a.hop) - a.pad;         // clip position of the first NEW sample
-    if (g0 >= 0 && g0 + a.hop <= a.n) {
+    if (LRA_LIKELY(g0 >= 0 && g0 + a.hop <= a.n)) {
         const T* __restrict__ src = yb + (p0 - a.pad) + 2 * tf;  // this thread's pair 0 of the frame (only the new pairs are dereferenced)
-        if ((reinterpret_cast<size_t>(src) & (2 * sizeof(T) - 1)) == 0) {
+        if (LRA_LIKELY((reinterpret_cast<size_t>(src) & (2 * sizeof(T) - 1)) == 0)) {
             LRA_UNROLL
             for (int n = 0; n < RG::NEW; ++n) {
                 const int e = RG::elem_of_new(n);
@@ -252,7 +252,7 @@ LRA_HD void v2_last_split_store(const StftArgs<typename Cfg::real>& a, int clip,
             const C dc = mk<T>((T)2 * (z0.x + z0.y), (T)0), ny = mk<T>((T)2 * (z0.x - z0.y), (T)0);
             xk = sel_mask(l0m, l0, dc, xk);
             xm = sel_mask(l0m, l0, ny, xm);
-            if (l0 && valid && a.nonfinite_flag && !(std::fabs(dc.x) <= std::numeric_limits<T>::max())) LRA_ATOMIC_OR(a.nonfinite_flag, 1u);
+            if (LRA_UNLIKELY(l0 && valid && a.nonfinite_flag && !(std::fabs(dc.x) <= std::numeric_limits<T>::max()))) LRA_ATOMIC_OR(a.nonfinite_flag, 1u);
         }
         const int k = (q < r / 2 ? tf : tfh) + q * s;
         if (MODE == OUT_MELR) {
