@@ -1407,3 +1407,94 @@ def test_hpss_golden():
 
 def test_hpss_reference_properties_and_full_size():
     _run_isolated("_hpss_properties_body")
+
+
+# ---- seeded sweep of the SURVEY 8(f) rows against the oracle (shapes, axes, parameters drawn at random) -------------------------------
+@pytest.mark.parametrize("seed", _sweep_seeds())
+def test_random_rows_sweep(L, seed):
+    """dB conversions, MFCC, PCEN, phase vocoder, harmonic / percussive separation and the constant-Q transform on randomly drawn shapes
+    and parameters, NumPy arrays and device tensors, each against the oracle's restatement of the reference with the row's own
+    tolerance (the goldens pin the oracle; this pins the device paths away from the golden shapes)."""
+    import torch
+
+    import cqt_oracle as CQ
+
+    rng = np.random.default_rng(1000 + seed)
+    bad = []
+
+    def dev(x):
+        return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(6):
+            lead = tuple(int(v) for v in rng.integers(1, 4, size=int(rng.integers(0, 3))))
+            bands, frames = int(rng.integers(8, 140)), int(rng.integers(5, 300))
+            f64 = bool(rng.random() < 0.3)
+            S = (rng.standard_normal(lead + (bands, frames)) ** 2 * float(10.0 ** rng.uniform(-6, 3))).astype(np.float64 if f64 else np.float32)
+            tol = 1e-10 if f64 else DB_TOL
+            # decibel conversions
+            kw = dict(ref=[1.0, np.max, np.median, float(rng.uniform(0.1, 5))][int(rng.integers(0, 4))], top_db=[80.0, None, float(rng.uniform(5, 60))][int(rng.integers(0, 3))],
+                      amin=float(10.0 ** rng.uniform(-12, -4)))
+            for fn in ("power_to_db", "amplitude_to_db"):
+                want = getattr(O, fn)(S, **kw)
+                # float32: both logarithm terms carry a few ulps of THEIR magnitude (device log10f vs NumPy's), and 10 log10 of a squared
+                # amplitude reaches -200 dB while the difference of the two terms stays small: the bar scales with the larger term
+                mag = np.square(np.abs(S).astype(np.float64)) if fn == "amplitude_to_db" else np.abs(S).astype(np.float64)
+                terms = float(np.abs(10.0 * np.log10(np.maximum(kw["amin"] ** (2 if fn == "amplitude_to_db" else 1), mag))).max())
+                tol_fn = tol if f64 else max(tol, 6e-7 * terms)
+                for got in (getattr(L, fn)(S, **kw), getattr(L, fn)(dev(S), **kw).cpu().numpy()):
+                    if got.shape != want.shape or got.dtype != want.dtype or not np.abs(got - want).max() <= tol_fn:
+                        bad.append((fn, S.shape, S.dtype.name, str(kw), float(np.abs(got - want).max())))
+            # MFCC from a dB spectrogram
+            if bands >= 13:
+                mk = dict(n_mfcc=int(rng.integers(2, min(bands, 40))), dct_type=int(rng.integers(1, 4)), norm=[None, "ortho"][int(rng.integers(0, 2))], lifter=[0, 22][int(rng.integers(0, 2))])
+                if not (mk["dct_type"] == 1 and mk["norm"] == "ortho" and bands < 2):
+                    Sdb = O.power_to_db(S)
+                    want = O.mfcc(S=Sdb, **mk)
+                    # (float32 sums of up to 140 dB values, times the lifter: unnormalised transforms reach 1e4, so the bar scales with the largest coefficient)
+                    ok = lambda a: a.shape == want.shape and (_mfcc_close(a, want) or np.abs(a - want).max() <= (1e-12 if f64 else 2e-6) * np.abs(want).max())
+                    got = L.feature.mfcc(S=Sdb, **mk)
+                    if not ok(got) or (not f64 and not ok(L.feature.mfcc(S=dev(Sdb), **mk).cpu().numpy())):
+                        bad.append(("mfcc", S.shape, S.dtype.name, str(mk), float(np.abs(got - want).max() / np.abs(want).max())))
+            # PCEN (general / power == 0 / max-filtered reference, block-wise state)
+            pk = dict(gain=float(rng.uniform(0.5, 1.0)), bias=float(rng.choice([2.0, 1.0, 0.5])), power=float(rng.choice([0.5, 0.0, 0.25, 1.0])), time_constant=float(rng.uniform(0.05, 0.6)),
+                      eps=float(10.0 ** rng.uniform(-8, -4)), max_size=int(rng.choice([1, 1, 3])), hop_length=int(rng.choice([256, 512])))
+            if pk["max_size"] > 1 and S.ndim != 2:
+                pk["max_axis"] = -2  # (the reference asks for the band axis explicitly beyond two dimensions, core/spectrum.py:2624-2632)
+            want = O.pcen(S, **pk)
+            for got in (L.pcen(S, **pk), L.pcen(dev(S), **pk).cpu().numpy()):
+                if not _pcen_close(got, want):
+                    bad.append(("pcen", S.shape, S.dtype.name, str(pk), float(np.max(np.abs(got - want) / np.abs(want).clip(1e-300)))))
+            # phase vocoder and separation on a random complex spectrogram
+            bins = int(rng.choice([33, 65, 129, 257]))
+            T = int(rng.integers(12, 160))
+            D = (rng.standard_normal(lead[:1] + (bins, T)) + 1j * rng.standard_normal(lead[:1] + (bins, T))).astype(np.complex128 if f64 else np.complex64)
+            rate = float(rng.choice([0.5, 0.8, 1.0, 1.3, 2.0]))
+            want = O.phase_vocoder(D, rate=rate)
+            for got in (L.phase_vocoder(D, rate=rate), L.phase_vocoder(dev(D), rate=rate).cpu().numpy()):
+                if not _pv_close(got, want):
+                    bad.append(("phase_vocoder", D.shape, D.dtype.name, rate))
+            hk = dict(kernel_size=[31, (int(rng.integers(3, 40)), int(rng.integers(3, 40))), int(rng.integers(2, 24))][int(rng.integers(0, 3))], power=float(rng.choice([2.0, 1.0, 0.5, np.inf])),
+                      margin=[1.0, (1.0, float(rng.uniform(1.0, 4.0)))][int(rng.integers(0, 2))], mask=bool(rng.random() < 0.3))
+            X = np.abs(D) if rng.random() < 0.3 else D
+            want = O.hpss(X, **hk)
+            for got in (L.decompose.hpss(X, **hk), tuple(t.cpu().numpy() for t in L.decompose.hpss(dev(X), **hk))):
+                if not all(_hpss_close(a, b, 1e-12 if f64 else 1e-5) for a, b in zip(got, want)):
+                    bad.append(("hpss", X.shape, X.dtype.name, str(hk)))
+        # constant-Q / variable-Q transform of a short random signal (polyphase decimator: the pinned resampler)
+        n = int(rng.integers(9000, 30000))
+        y = (rng.standard_normal((2, n)) if rng.random() < 0.5 else rng.standard_normal(n)).astype(np.float32)
+        ck = dict(sr=22050, hop_length=int(rng.choice([64, 128, 256, 512])), n_bins=int(rng.choice([24, 36, 48, 60])), bins_per_octave=int(rng.choice([12, 12, 24])), res_type="polyphase",
+                  scale=bool(rng.random() < 0.8))
+        ck["n_bins"] = max(ck["bins_per_octave"], ck["n_bins"] // ck["bins_per_octave"] * ck["bins_per_octave"])
+        try:
+            want = CQ.cqt(y, **ck)
+        except Exception:  # noqa: BLE001 -- the reference rejects this combination (e.g. the hop does not divide the octave count)
+            want = None
+        if want is not None:
+            for got in (L.cqt(y, **ck), L.cqt(dev(y), **ck).cpu().numpy()):
+                if not _cqt_close(got, want):
+                    bad.append(("cqt", y.shape, str(ck), float(np.abs(got - want).max() / np.abs(want).max())))
+    assert not bad, bad[:6]
+
