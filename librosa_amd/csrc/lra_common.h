@@ -304,6 +304,12 @@ template <class V> inline void stream_store16(V* p, V v) { *p = v; }
 #define LRA_PHASE_END_SYNC(WAVE) } ::lra::sim::state().barrier(WAVE);
 #define LRA_REGS(Type, name, NT) std::vector<Type> name##_all(NT)
 #define LRA_R(name) name##_all[tid]
+// exchange of `name`.v[first .. first + 8) between lane l < 32 and lane l + 32 of every wave64 (a phase of its own); `active` must be
+// the same for both lanes of a pair: an inactive pair keeps its values
+#define LRA_HALF_SWAP8(name, tid, first, active)                                                                  \
+    if ((tid & 63) < 32 && (active)) {                                                                            \
+        for (int m_ = 0; m_ < 8; ++m_) std::swap(name##_all[tid].v[(first) + m_], name##_all[tid + 32].v[(first) + m_]); \
+    }
 
 #else  // device build
 
@@ -412,6 +418,24 @@ __device__ __forceinline__ int phase_tid() {
 #define LRA_PHASE_END_SYNC(WAVE) } ::lra::phase_sync<(WAVE)>();
 #define LRA_REGS(Type, name, NT) Type name
 #define LRA_R(name) name
+// v[0 .. 8) of lane l < 32 <-> v[0 .. 8) of lane l + 32, in place: v_permlane32_swap_b32 with one register on both sides swaps the
+// register's two halves (scripts/permlane_probe.hip: so it does, and lanes switched off in EXEC keep their values together with
+// their partners).  Raw instructions are invisible to hipcc's hazard recogniser, hence the wait states on both sides.
+__device__ __forceinline__ void half_swap8(cx<float>* v, bool active) {
+    if (active) {
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_permlane32_swap_b32 %0, %0\n\tv_permlane32_swap_b32 %1, %1\n\tv_permlane32_swap_b32 %2, %2\n\tv_permlane32_swap_b32 %3, %3\n\t"
+            "v_permlane32_swap_b32 %4, %4\n\tv_permlane32_swap_b32 %5, %5\n\tv_permlane32_swap_b32 %6, %6\n\tv_permlane32_swap_b32 %7, %7\n\t"
+            "v_permlane32_swap_b32 %8, %8\n\tv_permlane32_swap_b32 %9, %9\n\tv_permlane32_swap_b32 %10, %10\n\tv_permlane32_swap_b32 %11, %11\n\t"
+            "v_permlane32_swap_b32 %12, %12\n\tv_permlane32_swap_b32 %13, %13\n\tv_permlane32_swap_b32 %14, %14\n\tv_permlane32_swap_b32 %15, %15\n\t"
+            "s_nop 1"
+            : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[2].x), "+v"(v[2].y), "+v"(v[3].x), "+v"(v[3].y),
+              "+v"(v[4].x), "+v"(v[4].y), "+v"(v[5].x), "+v"(v[5].y), "+v"(v[6].x), "+v"(v[6].y), "+v"(v[7].x), "+v"(v[7].y));
+    }
+}
+__device__ __forceinline__ void half_swap8(cx<double>*, bool) {}  // (no double-precision configuration uses it)
+#define LRA_HALF_SWAP8(name, tid, first, active) ::lra::half_swap8(LRA_R(name).v + (first), (active))
 
 #endif
 

@@ -56,9 +56,21 @@ inline int log2_exact(int v) {
 // Calls f.template operator()<Cfg>() for the configuration of (T, logm, variant); returns false if
 // unsupported.
 template <class T, class F> inline bool dispatch_logm(int logm, int variant, F&& f) {
-#ifdef LRA_PROBE_ONLY  // development builds (scripts/gpu_probe.py): n_fft = 2048 f32 only, compiles in seconds
-    if (logm != 10 || sizeof(T) != 4) return false;
+#ifdef LRA_PROBE_ONLY  // development builds (scripts/probe_build.sh): one f32 size only (n_fft = 2048 unless -DLRA_PROBE_LOGM=..), compiles in seconds
+#ifndef LRA_PROBE_LOGM
+#define LRA_PROBE_LOGM 10
 #endif
+    if (logm != LRA_PROBE_LOGM || sizeof(T) != 4) return false;
+#endif
+#if defined(LRA_PROBE_ONLY) && defined(LRA_PROBE_CFG)  // e.g. -DLRA_PROBE_LOGM=12 "-DLRA_PROBE_CFG=FftCfg<12,4,T,64,4,false>"
+    (void)variant;
+    f.template operator()<LRA_PROBE_CFG>();
+    return true;
+#elif defined(LRA_PROBE_ONLY) && LRA_PROBE_LOGM != 10
+    (void)variant;
+    f.template operator()<typename CfgSel<T, LRA_PROBE_LOGM, 0>::type>();
+    return true;
+#else
     switch (logm) {
 #define LRA_CASE(L) \
     case L: f.template operator()<typename CfgSel<T, L, 0>::type>(); return true;
@@ -81,6 +93,7 @@ template <class T, class F> inline bool dispatch_logm(int logm, int variant, F&&
 #endif
         default: return false;
     }
+#endif
 }
 
 // workgroup configuration of the two-slope mel kernel: its filter tables are shared across the slots of a

@@ -655,6 +655,97 @@ template <class Cfg, int MODE, int PM> LRA_HD void stft_split_store(const StftAr
     }
 }
 
+// ---- last pass mirrored across the halves of a wave (complex / power epilogues without an LDS ring; n_fft = 8192) -------------------
+// The second-generation kernel's idea (lra_kernels2.h: Z[k] and Z[M-k] come out of the last pass in ONE thread, so the split step
+// needs no LDS round trip) for a last pass of ONE radix-16 butterfly per thread, where the mirror s - b of butterfly b cannot sit in
+// the same thread.  It sits in the same WAVE instead: lane l < 32 of wave w takes butterfly pi = 32 w + l, lane l + 32 takes s - pi
+// (s = M / 16 = TF), and after the pass the two lanes exchange their upper eight outputs (v_permlane32_swap_b32, half_swap8): lane
+// (b) then holds Z[b + j s], j < 8, and in v[15 - j] their mirrors Z[(s - b) + (15 - j) s] = Z[M - (b + j s)].  Pair pi = 0 is the
+// two self-mirrored butterflies 0 and s/2 (thread 0 and thread 32): those two lanes stay out of the exchange; butterfly s/2 pairs
+// j with 15 - j by itself, butterfly 0 pairs j with 16 - j, which thread 0 absorbs by acting as b = s with its registers shifted
+// by one (eight lane-0 selects; its slot 7 is X[M/2], its v[0] gives X[0] and X[M]).
+// Per frame and thread: 16 LDS writes + 16 reads and two workgroup barriers less than the split through LDS, for 16 swaps.
+#ifndef LRA_MIRROR_TWR_BASE
+#define LRA_MIRROR_TWR_BASE 1
+#endif
+template <class Cfg> constexpr bool mirror32_cfg_ok() {
+    constexpr int pl = Cfg::P - 1;
+    return Cfg::P >= 2 && Cfg::R == 16 && Cfg::HOIST && sizeof(typename Cfg::real) == 4 && Cfg::logr(pl) == 4 && Cfg::TF % 64 == 0 && Cfg::TF == (Cfg::M >> 4) &&
+           Cfg::TF == Cfg::NT && affine_tf<Cfg>();
+}
+template <class Cfg> LRA_HD int mirror32_bfly(int tf) {
+    const int pi = (tf >> 6) * 32 + (tf & 31);
+    return (tf & 32) == 0 ? pi : (pi == 0 ? Cfg::TF / 2 : Cfg::TF - pi);
+}
+// first bin of the thread's eight pair slots (slot q: bins kb + q s and M - kb - q s)
+template <class Cfg> LRA_HD int mirror32_kbase(int tf) { return tf == 0 ? Cfg::TF : mirror32_bfly<Cfg>(tf); }
+template <class Cfg> LRA_HD bool mirror32_swaps(int tf) { return tf != 0 && tf != 32; }
+
+// prologue: the last pass's twiddles of butterfly mirror32_bfly(tf) and the split twiddles of the thread's pair slots replace
+// what hoist_tables loaded for butterfly tf
+template <class Cfg> LRA_HD void mirror32_hoist(FftRegs<Cfg>& rg, int tf, const typename Cfg::cplx* __restrict__ tw, const typename Cfg::cplx* __restrict__ twr) {
+    if constexpr (mirror32_cfg_ok<Cfg>()) {
+        load_pass_twiddles<Cfg, Cfg::P - 1>(rg.treg, mirror32_bfly<Cfg>(tf), tw);
+        const int kb = mirror32_kbase<Cfg>(tf);
+        LRA_UNROLL
+        for (int q = 0; q < (LRA_MIRROR_TWR_BASE ? 1 : Cfg::R / 2); ++q) rg.twr[q] = twr[kb + q * Cfg::TF];
+    }
+}
+// split twiddle of pair slot q: W_N^(kb + q s) = W_N^kb W_32^q (s = N / 32).  Only W_N^kb is kept in registers -- with all eight the
+// kernel needs 182 VGPRs, two workgroups per CU instead of three; seven complex products per frame are the cheaper side.
+template <class Cfg> LRA_HD typename Cfg::cplx mirror32_twr(const FftRegs<Cfg>& rg, int q) {
+    using T = typename Cfg::real;
+    if (!LRA_MIRROR_TWR_BASE) return rg.twr[q];
+    constexpr double c32[8] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708, 0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173, 0.19509032201612826785};
+    if (q == 0) return rg.twr[0];
+    const cx<T> c = mk<T>((T)c32[q], (T)-c32[8 - q]);  // exp(-2 pi i q / 32): cos = c32[q], sin = c32[8 - q]
+    return cmul_f(rg.twr[0], c, cmul_p(rg.twr[0], c));
+}
+
+// split + store from the exchanged butterfly registers
+template <class Cfg, int MODE, int PM> LRA_HD void mirror32_split_store(const StftArgs<typename Cfg::real>& a, int clip, int frame, bool valid, int tf, FftRegs<Cfg>& rg) {
+    using T = typename Cfg::real;
+    using C = typename Cfg::cplx;
+    constexpr int M = Cfg::M, S = Cfg::TF;
+    const bool l0 = tf == 0;
+    const LaneMask l0m = lane_mask(l0);
+    const long long row = ((long long)clip * a.n_frames + frame) * (M + 1);
+    const int kb = mirror32_kbase<Cfg>(tf);
+    C* __restrict__ const Dk = MODE == OUT_COMPLEX ? a.D + row + kb : nullptr;
+    C* __restrict__ const Dm = MODE == OUT_COMPLEX ? a.D + row + (M - kb) : nullptr;
+    T* __restrict__ const Sk = MODE == OUT_POWER ? a.S + row + kb : nullptr;
+    T* __restrict__ const Sm = MODE == OUT_POWER ? a.S + row + (M - kb) : nullptr;
+    LRA_UNROLL
+    for (int q = 0; q < Cfg::R / 2; ++q) {
+        const C zk = sel_mask(l0m, l0, rg.v[q + 1], rg.v[q]);
+        C xk, xm;
+        split_pair<T>(zk, rg.v[Cfg::R - 1 - q], mirror32_twr<Cfg>(rg, q), xk, xm);
+        const bool both = q + 1 < Cfg::R / 2 || !l0;  // thread 0's last slot is the single bin M/2
+        if (q + 1 == Cfg::R / 2) xk = sel_mask(l0m, l0, mk<T>((T)2 * rg.v[Cfg::R / 2].x, (T)-2 * rg.v[Cfg::R / 2].y), xk);  // X[M/2] = conj(Z[M/2]), Z pre-halved
+        if (MODE == OUT_COMPLEX) {
+            if (valid) {
+                stream_store(&Dk[q * S], xk);
+                if (both) stream_store(&Dm[-q * S], xm);
+            }
+        } else {
+            const T pk = spec_power<T, PM>(xk, a.power), pm = spec_power<T, PM>(xm, a.power);
+            if (valid) {
+                Sk[q * S] = pk;
+                if (both) Sm[-q * S] = pm;
+            }
+        }
+    }
+    if (l0) {  // X[0], X[M] from Z[0]
+        const C z0 = rg.v[0];
+        const C x0 = mk<T>((T)2 * (z0.x + z0.y), (T)0), xn = mk<T>((T)2 * (z0.x - z0.y), (T)0);
+        if (valid && a.nonfinite_flag && !(std::fabs(x0.x) <= std::numeric_limits<T>::max())) LRA_ATOMIC_OR(a.nonfinite_flag, 1u);
+        if (valid) {
+            if (MODE == OUT_COMPLEX) { a.D[row] = x0; a.D[row + M] = xn; }
+            else { a.S[row] = spec_power<T, PM>(x0, a.power); a.S[row + M] = spec_power<T, PM>(xn, a.power); }
+        }
+    }
+}
+
 // ---- phase: banded mel reduce of ONE frame (its power spectrum sits in the slot's frame area) ----
 // Thread tf of the slot owns mel rows tf, tf+TF, ...; results go to the slot's staging tile
 // stage[m][it] so that the flush after the frame loop writes rows of `iters` consecutive frames.
@@ -977,8 +1068,9 @@ template <class Cfg, class RG> LRA_HD void melr_combine(const StftArgs<typename 
     }
 }
 
-#define LRA_MID_PASS(Cfg, p, rg, lds, tw, slot_bytes)                                                     \
-    if (Cfg::P > p) {                                                                                     \
+#define LRA_MID_PASS(Cfg, p, rg, lds, tw, slot_bytes) LRA_MID_PASS_TO(Cfg, Cfg::P, p, rg, lds, tw, slot_bytes)
+#define LRA_MID_PASS_TO(Cfg, END, p, rg, lds, tw, slot_bytes)                                             \
+    if (END > p) {                                                                                        \
         LRA_PHASE(Cfg::NT, tid) {                                                                         \
             pass_read<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(rg).v, lds_sub(lds, (slot_of<Cfg>(tid)) * (slot_bytes)), lane_of<Cfg>(tid)); \
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)                                                              \
@@ -1038,9 +1130,25 @@ template <class Cfg, int MODE, int PM = POW_TWO, int RAM = 0> LRA_HD void stft_b
 #define LRA_PF_EARLY 1
 #endif
     constexpr bool PF_EARLY = !LATE_PF && LRA_PF_EARLY;
+    // Complex / power epilogues: the split step works on registers and writes HBM only, so the frame needs ONE workgroup barrier
+    // behind its split reads ("every wave has read the frame area"), and that one sits behind the stores: a wave that waits there
+    // has its row already in flight.  (Frames of more than one wave only; 7 -> 6 barriers per frame at n_fft = 8192.)
+#ifndef LRA_SPLIT_ONE_BARRIER
+#define LRA_SPLIT_ONE_BARRIER 1
+#endif
+    constexpr bool SPLIT_NO_LDS = LRA_SPLIT_ONE_BARRIER && (MODE == OUT_COMPLEX || MODE == OUT_POWER);
+    // ... and where the last pass is one radix-16 butterfly per thread (n_fft = 8192), the split step's LDS round trip goes as well
+#ifndef LRA_MIRROR32
+#define LRA_MIRROR32 1
+#endif
+    // (measured per ring form on the 256 x 30 s batch, n_fft = 8192, profiles/r03_experiments.md section 8: hop = n_fft / 16 -1 %, n_fft / 2 -9 %;
+    // n_fft / 4 unchanged, n_fft / 8 and direct framing +3 ... +6 % -- those keep the split through LDS)
+    constexpr bool MIRROR = LRA_MIRROR32 && (RAM == 3 || RAM == 6 || LRA_MIRROR32 > 1) && mirror32_cfg_ok<Cfg>();
+    constexpr int MID_END = Cfg::P - (MIRROR ? 1 : 0);  // passes 1 .. MID_END - 1 go through LRA_MID_PASS
     LRA_REGS(FftRegs<Cfg>, rg, Cfg::NT);
     LRA_PHASE(Cfg::NT, tid) {
         hoist_tables<Cfg>(LRA_R(rg), lane_of<Cfg>(tid), a.win, a.tw, a.twr, false, MODE == OUT_MELR);
+        if (MIRROR) mirror32_hoist<Cfg>(LRA_R(rg), lane_of<Cfg>(tid), a.tw, a.twr);
         if (MODE == OUT_MEL2) mel2_tables_to_lds<Cfg>(a, tid, lds_sub(lds, a.shared_off));
         if (MODE == OUT_MELR) {
             melr_tables_to_lds<Cfg>(a, tid, lds_sub(lds, a.shared_off));
@@ -1078,10 +1186,29 @@ template <class Cfg, int MODE, int PM = POW_TWO, int RAM = 0> LRA_HD void stft_b
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         LRA_TICK(1);
 #if LRA_ABLATE != 2
-        LRA_MID_PASS(Cfg, 1, rg, lds, a.tw, slot_bytes)
-        LRA_MID_PASS(Cfg, 2, rg, lds, a.tw, slot_bytes)
-        LRA_MID_PASS(Cfg, 3, rg, lds, a.tw, slot_bytes)
+        LRA_MID_PASS_TO(Cfg, MID_END, 1, rg, lds, a.tw, slot_bytes)
+        LRA_MID_PASS_TO(Cfg, MID_END, 2, rg, lds, a.tw, slot_bytes)
+        LRA_MID_PASS_TO(Cfg, MID_END, 3, rg, lds, a.tw, slot_bytes)
 #endif
+        if constexpr (MIRROR) {
+            // last pass (butterfly mirror32_bfly), exchange across the wave's halves, split + stores from the registers; the ONE
+            // workgroup barrier ("every wave has read the frame area") sits behind the stores
+            LRA_PHASE(Cfg::NT, tid) {
+                const int tf = lane_of<Cfg>(tid);
+                pass_read<Cfg, Cfg::P - 1>(LRA_R(rg).v, lds_sub(lds, slot_of<Cfg>(tid) * slot_bytes), mirror32_bfly<Cfg>(tf));
+                pass_twiddle_dft_reg<Cfg, Cfg::P - 1>(LRA_R(rg).v, LRA_R(rg).treg);
+            } LRA_PHASE_END_SYNC(true)
+            LRA_PHASE(Cfg::NT, tid) {
+                LRA_HALF_SWAP8(rg, tid, Cfg::R / 2, mirror32_swaps<Cfg>(lane_of<Cfg>(tid)));
+            } LRA_PHASE_END_SYNC(true)
+            LRA_PHASE(Cfg::NT, tid) {
+                const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
+                mirror32_split_store<Cfg, MODE, PM>(a, clip, frame, frame < a.n_frames, tf, LRA_R(rg));
+            } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+            LRA_TICK(10);
+            done = it + 1;
+            continue;
+        }
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
             const Lds sl = lds_sub(lds, slot * slot_bytes);
@@ -1094,7 +1221,7 @@ template <class Cfg, int MODE, int PM = POW_TWO, int RAM = 0> LRA_HD void stft_b
 #endif
             if (DEFER && tile > 1 && it > 0 && it % tile == 0)  // the tile that frame it-1 completed
                 mel_flush_tile<Cfg>(a, clip, f_first + slot * iters, it - 1, tile, tf, lds_sub(sl, stft_tile_off<Cfg>()));
-        } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+        } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC || SPLIT_NO_LDS)
         LRA_TICK(8);
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;

@@ -435,7 +435,7 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
 #undef LRA_MID_PASS2
         LRA_PHASE(Cfg::NT, tid) {
             v2_last_read<Cfg, HD>(LRA_R(rg), lds_sub(lds, slot_of<Cfg>(tid) * SB), lane_of<Cfg>(tid));
-        } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+        } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC || (LRA_SPLIT_ONE_BARRIER && MODE != OUT_MELR && !STAGED))  // (registers -> HBM next: see stft_block)
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
             v2_last_split_store<Cfg, HD, MODE, PM, STAGED>(a, clip, frame, frame < a.n_frames, tf, LRA_R(rg), lds_sub(lds, slot * SB));

@@ -39,6 +39,11 @@ elif what == "mel":
     fn = lambda: ctx.melspectrogram_exec(pl, mp, y.data_ptr(), batch, n, n, 2.0, Mo.data_ptr())
 else:
     fn = lambda: ctx.stft_exec(pl, y.data_ptr(), batch, n, n, D.data_ptr())
+if os.environ.get("PROBE_CHECK"):  # the kernel under test against torch.stft in float64 on two clips (probe builds of sizes the parity cases skip)
+    got = L.stft(y[:2], n_fft=n_fft, hop_length=hop)
+    want = torch.stft(y[:2].double(), n_fft, hop_length=hop, window=torch.from_numpy(w.astype(np.float64)).to(dev), center=True, pad_mode="constant", return_complex=True)
+    err = float((got.to(torch.complex128) - want).abs().max() / want.abs().max())
+    print(f"check n_fft {n_fft} hop {hop}: max |diff| / max |want| = {err:.3g} {'ok' if err < 2e-6 else 'MISMATCH'}", flush=True)
 import time
 t_end = time.time() + float(os.environ.get("PROBE_PREWARM_S", "0.4"))  # an idle MI355X runs its first ~0.2 s of work at reduced clocks
 while time.time() < t_end:

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -180,6 +181,31 @@ int main(int argc, char** argv) {
         printf("%-9s W=%d iters=%3d ldspad=%3dK remap=%d nt=%d read=%d delay=%4d : %.4f ms  %.0f GB/s\n", names[c.mode], c.W, c.iters, c.lds_pad / 1024, c.remap, c.nt, c.read, c.delay, ms, by / ms / 1e6);
         fflush(stdout);
     };
+    if (argc > 1 && argv[1][0] == 'p') {  // "power [seconds] [memset]": the best strip form (or a plain hipMemset of the output) in a loop, for rocm-smi sampling from a second shell
+        const double secs = argc > 2 ? atof(argv[2]) : 8.0;
+        const bool ms_only = argc > 3;
+        const Cfg c{0, 1, 162, (160 * 1024 / 12) & ~255, 1, 0, 1, 0};
+        hipEvent_t a, b;
+        hipEventCreate(&a); hipEventCreate(&b);
+        hipEventRecord(a);
+        float total = 0.f, last = 0.f;
+        while (total < secs * 1e3f) {
+            if (ms_only) {
+                hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+                hipEventRecord(e0);
+                for (int r = 0; r < 8; ++r) hipMemsetAsync(out, 0, (size_t)batch * rows * ROWB, 0);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                hipEventElapsedTime(&last, e0, e1); last /= 8;
+                hipEventDestroy(e0); hipEventDestroy(e1);
+            } else {
+                last = run(out, in, c, batch, rows);
+            }
+            hipEventRecord(b); hipEventSynchronize(b);
+            hipEventElapsedTime(&total, a, b);
+        }
+        printf("%s: %.4f ms  %.0f GB/s\n", ms_only ? "hipMemsetAsync of the output" : "strip W=1 iters=162 12 waves/CU remap=1 read=1", last, (ms_only ? bytes_w : bytes_rw) / last / 1e6);
+        return 0;
+    }
     if (argc > 1) {  // "conc": the two store forms against resident waves per CU, rows per strip and a little compute between rows
         for (int mode : {0, 3})
             for (int nt : {0, 1}) {

@@ -52,8 +52,9 @@ def _tol(dtype):
         (2048, 2048, True, "edge", 2, np.float32, 30001, 0),   # direct framing, one wave per frame
         (8192, 8192, True, "reflect", 2, np.float32, 70000, 0),  # direct framing, four waves per frame
         (128, 1000, True, "symmetric", 4, np.float32, 9000, 0),
-        (8192, 512, True, "reflect", 3, np.float32, 30001, 0),   # register ring, HD = 16 (one new pair per thread and frame), four waves per frame
+        (8192, 512, True, "reflect", 3, np.float32, 30001, 0),   # register ring, HD = 16 (one new pair per thread and frame), four waves per frame; mirrored last pass
         (8192, 2048, False, "constant", 2, np.float32, 40000, 0),  # HD = 4
+        (8192, 4096, True, "reflect", 2, np.float32, 50001, 0),    # HD = 2: last pass mirrored across the halves of a wave (as HD = 16)
         (16384, 8192, True, "edge", 2, np.float32, 60001, 0),    # HD = 2, eight waves per frame
         (512, 512, True, "reflect", 3, np.float64, 9000, 0),
         (512, 100, False, "constant", 4, np.float32, 3000, 0),
