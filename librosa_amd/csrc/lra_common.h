@@ -299,6 +299,7 @@ inline Lds lds_sub(Lds l, int byte_off) { Lds r; r.base = l.base + byte_off; ret
 template <class T> inline T fast_div(T x, T w) { return x / w; }
 template <class V> inline void stream_store(V* p, V v) { *p = v; }
 template <class V> inline void stream_store16(V* p, V v) { *p = v; }
+template <class V> inline V stream_load(const V* p) { return *p; }
 #define LRA_PHASE(NT, tid) for (int tid = 0; tid < (NT); ++tid) { ::lra::sim::state().cur_tid = tid;
 #define LRA_PHASE_END } ::lra::sim::state().barrier();
 #define LRA_PHASE_END_SYNC(WAVE) } ::lra::sim::state().barrier(WAVE);
@@ -367,6 +368,19 @@ template <class V> __device__ __forceinline__ void stream_store(V* p, V v) {
 #else
     *p = v;
 #endif
+}
+// Input that is read once: optionally a non-temporal load (experiment, LRA_NT_LOAD)
+#ifndef LRA_NT_LOAD
+#define LRA_NT_LOAD 0
+#endif
+template <class V> __device__ __forceinline__ V stream_load(const V* p) {
+#if LRA_NT_LOAD
+    if constexpr (sizeof(V) == 8) {
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(V, __builtin_nontemporal_load(reinterpret_cast<const f2v*>(p)));
+    }
+#endif
+    return *p;
 }
 // 16-byte piece of a row that is written once, whole 16-byte pieces only, neighbours back to back: non-temporal
 // (measured on the store stream of the STFT: +8 % alone, +16 % with the XCD-aware workgroup map)

@@ -1396,8 +1396,8 @@ template <class Cfg> LRA_HD void istft_spec_load_mir(const IstftArgs<typename Cf
     LRA_UNROLL
     for (int q = 0; q < r0; ++q) {
         const C* __restrict__ Xq = q < r0 / 2 ? Xlo : Xhi;
-        rg.xk[q] = Xq[q * s];
-        rg.xm[q] = X[M - (q < r0 / 2 ? tf : mir_tf_hi<Cfg>(tf)) - q * s];
+        rg.xk[q] = stream_load(&Xq[q * s]);
+        rg.xm[q] = stream_load(&X[M - (q < r0 / 2 ? tf : mir_tf_hi<Cfg>(tf)) - q * s]);
     }
     rg.xmid = X[M / 2];
 }
