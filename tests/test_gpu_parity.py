@@ -533,6 +533,22 @@ def test_multi_resolution_stack(L, full_batch):
         assert _stft_close(o[3].cpu().numpy(), O.stft(yi, n_fft=n, hop_length=512))
 
 
+@pytest.mark.parametrize("hop", [512, 1024, 2048, 4096, 8192])
+def test_large_frame_ring_forms(L, hop):
+    """n_fft = 8192 (four waves per frame) over every register-ring form and direct framing -- hop = n_fft / 16 and n_fft / 2 run the last pass
+    mirrored across the halves of a wave (lra_kernels.h, mirror32_*), the others split through LDS -- complex, magnitude, power and general-power
+    epilogues, odd lengths, two channels, reflect and zero padding, uncentred: against the oracle with the golden cases' bar."""
+    rng = np.random.default_rng(8192 + hop)
+    for n, center, pad_mode in ((70001, True, "reflect"), (41234, True, "constant"), (52345, False, "constant")):
+        y = rng.standard_normal((2, n)).astype(np.float32)
+        kw = dict(n_fft=8192, hop_length=hop, center=center, pad_mode=pad_mode)
+        assert _stft_close(L.stft(y, **kw), O.stft(y, **kw)), (hop, n, center, pad_mode)
+        for power in (1.0, 2.0, 1.5):
+            S, _ = L.core.spectrum._spectrogram(y=y, power=power, **kw)
+            Sr, _ = O.spectrogram(y=y, power=power, **kw)
+            assert np.abs(S - Sr).max() <= 8e-6 * np.abs(Sr).max(), (hop, n, center, pad_mode, power)
+
+
 # ---------------------------------------------------------------------------------------------------
 # 5. decibel scaling and MFCC (SURVEY.md 8f ranks 1, 2)
 # ---------------------------------------------------------------------------------------------------
