@@ -182,6 +182,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cqt", action="store_true", help="skip the CQT-lite (config 5) side measurement")
     ap.add_argument("--no-side", action="store_true", help="skip every side measurement (profiling runs)")
+    ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power / clock samples (profiling runs: they loop the kernels for seconds)")
     ap.add_argument("--gather-chunks", type=int, default=4, help="pieces the shard travels in during the `gathered` measurement (N>1)")
     ap.add_argument("--variant", type=int, default=None)
     ap.add_argument("--iters", type=int, default=None)
@@ -331,6 +332,49 @@ def main():
                                               "stft2_kernel<n_fft=2048, OUT_COMPLEX> (librosa.stft, complex64 out)"))
         measure("roofline_istft", lambda: roof(lambda: ctx.istft_exec(iplan, Dp, batch, n_frames * n_bins, n_bins, n_frames, wss.data_ptr(), yrec.data_ptr(), n, n), BYTES_PER_FRAME_STFT,
                                                "istft_kernel<n_fft=2048> (librosa.istft: c2r FFT + window + overlap-add + wss normalise)"))
+        def board_power():
+            """Socket power and shader clock reported by rocm-smi while each of the three kernels runs in a loop (a second thread keeps the queue full):
+            the complex STFT runs at the board's power limit with the clock lowered, profiles/r03_experiments.md section 9."""
+            import re
+            import shutil
+            import subprocess
+            import threading
+
+            smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+            if not os.path.exists(smi):
+                return {"error": "rocm-smi not found"}
+
+            def parse(txt):
+                pw = re.search(r"Power \(W\):\s*([0-9.]+)", txt)
+                ck = re.search(r"sclk clock level:\s*\S+\s*\((\d+)Mhz\)", txt)
+                return {"socket_power_w": float(pw.group(1)) if pw else None, "sclk_mhz": int(ck.group(1)) if ck else None}
+
+            def sample(fn):
+                stop = threading.Event()
+
+                def feed():
+                    while not stop.is_set():
+                        for _ in range(200):
+                            fn()
+                        torch.cuda.synchronize(device)
+
+                th = threading.Thread(target=feed, daemon=True)
+                th.start()
+                try:
+                    time.sleep(2.5)  # (the power controller takes a second or two to settle on a clock)
+                    txt = subprocess.run([smi, "--showpower", "--showclocks"], capture_output=True, text=True, timeout=30).stdout
+                finally:
+                    stop.set()
+                    th.join(timeout=30)
+                    torch.cuda.synchronize(device)
+                return parse(txt)
+
+            return {"mel": sample(step_mel), "stft": sample(lambda: ctx.stft_exec(plan, yp, batch, n, n, Dp)),
+                    "istft": sample(lambda: ctx.istft_exec(iplan, Dp, batch, n_frames * n_bins, n_bins, n_frames, wss.data_ptr(), yrec.data_ptr(), n, n)),
+                    "what": "rocm-smi --showpower --showclocks sampled once, 2.5 s into a loop of the kernel (MI355X board limit: 1400 W; shader clock at most 2400 MHz)"}
+
+        if not args.no_power:
+            measure("board_power", board_power)
         try:
             err = (y[:8] - yrec[:8]).double().pow(2).sum(dim=1)
             snr_db = float((10 * torch.log10(y[:8].double().pow(2).sum(dim=1) / err)).min().item())

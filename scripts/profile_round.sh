@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $R/bench.py --no-cpu-baseline --no-cqt"
+BENCH="python $R/bench.py --no-cpu-baseline --no-cqt --no-power"
 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o r -- $BENCH --steps 20 --warmup 5 > "$OUT/stats.log" 2>&1
 timeout 240 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$OUT/fetch" -o r -- $BENCH --steps 3 --warmup 1 > "$OUT/fetch.log" 2>&1
 timeout 240 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$OUT/write" -o r -- $BENCH --steps 3 --warmup 1 > "$OUT/write.log" 2>&1
