@@ -300,6 +300,7 @@ template <class T> inline T fast_div(T x, T w) { return x / w; }
 template <class V> inline void stream_store(V* p, V v) { *p = v; }
 template <class V> inline void stream_store16(V* p, V v) { *p = v; }
 template <class V> inline V stream_load(const V* p) { return *p; }
+template <class T> inline void store4_unaligned(T* p, T a, T b, T c, T d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
 #define LRA_PHASE(NT, tid) for (int tid = 0; tid < (NT); ++tid) { ::lra::sim::state().cur_tid = tid;
 #define LRA_PHASE_END } ::lra::sim::state().barrier();
 #define LRA_PHASE_END_SYNC(WAVE) } ::lra::sim::state().barrier(WAVE);
@@ -368,6 +369,18 @@ template <class V> __device__ __forceinline__ void stream_store(V* p, V v) {
 #else
     *p = v;
 #endif
+}
+// four consecutive words as ONE store where the element type allows it (global_store_dwordx4; the pointer need only be element-aligned:
+// the hardware takes unaligned vector stores, and the type says so to the compiler)
+template <class T> __device__ __forceinline__ void store4_unaligned(T* p, T a, T b, T c, T d) {
+    if constexpr (sizeof(T) == 4) {
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        f4u v;
+        v.x = a; v.y = b; v.z = c; v.w = d;
+        *reinterpret_cast<f4u*>(p) = v;
+    } else {
+        p[0] = a; p[1] = b; p[2] = c; p[3] = d;
+    }
 }
 // Input that is read once: optionally a non-temporal load (experiment, LRA_NT_LOAD)
 #ifndef LRA_NT_LOAD

@@ -985,6 +985,42 @@ template <class Cfg, class RG> LRA_HD void melr_hoist(const StftArgs<typename Cf
     }
 }
 
+// ---- the register tile of the run-ordered mel epilogue: slot of a frame, and the burst that stores a band's tile ------------------
+// The tile position is tied to the ABSOLUTE element index in the output (row starts are n_frames elements apart, not a multiple of
+// MT), so that every full burst is one aligned MT x sizeof(T) = 32-byte piece: unaligned 32-byte bursts each dirtied two HBM sectors
+// (306 MB written per launch for 169 MB of output).  A slot's first and last bursts are partial.
+#ifndef LRA_MEL_ALIGNED_BURSTS
+#define LRA_MEL_ALIGNED_BURSTS 1
+#endif
+#ifndef LRA_MEL_BURST16  // a whole tile as two 16-byte stores instead of eight predicated 4-byte ones
+#define LRA_MEL_BURST16 1
+#endif
+template <class Cfg, class RG> LRA_HD int melr_tile_slot(const StftArgs<typename Cfg::real>& a, int clip, int frame, int it, int b, long long row0) {
+    constexpr int MT = RG::MELR_TILE;
+    if (!LRA_MEL_ALIGNED_BURSTS) return it & (MT - 1);
+    // rows start 0 or 16 bytes into a 32-byte piece, alternating with the band's parity: with bands 2 tf and 2 tf + 1
+    // per thread the phase is (clip, frame, b) only -- scalar, so the tile select and the flush branch stay scalar
+    // (a per-lane phase made the flush run twice per MT frames under half masks: +2.8 % kernel time)
+    if ((a.n_frames & 3) == 0 && Cfg::TF >= 64) return (int)(((long long)clip * a.n_mels * a.n_frames + (long long)b * a.n_frames + frame) & (MT - 1));
+    return (int)((row0 + frame) & (MT - 1));
+}
+// stores slots max(0, s8 - it) .. s8 of band slot b's tile (the frames this slot has produced so far); a whole tile leaves as two 16-byte stores
+template <class Cfg, class RG> LRA_HD void melr_burst(const StftArgs<typename Cfg::real>& a, long long row0, int frame, int s8, int it, int b, RG& rg) {
+    using T = typename Cfg::real;
+    constexpr int MT = RG::MELR_TILE;
+    T* __restrict__ row = a.Mel + (row0 + frame - s8);
+    if constexpr (sizeof(T) == 4 && MT == 8) {
+        if (LRA_MEL_BURST16 && s8 == MT - 1 && it >= MT - 1) {
+            store4_unaligned(row, rg.mt[b][0], rg.mt[b][1], rg.mt[b][2], rg.mt[b][3]);
+            store4_unaligned(row + 4, rg.mt[b][4], rg.mt[b][5], rg.mt[b][6], rg.mt[b][7]);
+            return;
+        }
+    }
+    LRA_UNROLL
+    for (int k = 0; k < MT; ++k)
+        if (k <= s8 && k >= s8 - it) row[k] = rg.mt[b][k];
+}
+
 // phase: mel[m] = sum of the B totals of segment m's pieces + sum of the A totals of segment m+1's pieces
 // (ascending bins).  Bands tf and tf + TF use the hoisted address lists; longer lists / further bands read
 // theirs from the shared table.
@@ -1020,35 +1056,15 @@ template <class Cfg, class RG> LRA_HD void melr_combine(const StftArgs<typename 
         }
         const T v = part[0] + part[1];
         if (tile == 1) {
-            // Register tile: the last MT frames of this band's row, stored as one burst.  The tile position is tied to the
-            // ABSOLUTE element index in the output (row starts are n_frames elements apart, not a multiple of MT), so that every
-            // full burst is one aligned MT x sizeof(T) = 32-byte piece: unaligned 32-byte bursts each dirtied two HBM sectors
-            // (306 MB written per launch for 169 MB of output).  A slot's first and last bursts are partial.
+            // Register tile: the last MT frames of this band's row, stored as one burst (melr_tile_slot, melr_burst)
             constexpr int MT = RG::MELR_TILE;
-#ifndef LRA_MEL_ALIGNED_BURSTS
-#define LRA_MEL_ALIGNED_BURSTS 1
-#endif
             const long long row0 = ((long long)clip * a.n_mels + m) * a.n_frames;  // element index of this band's row in the output
-            int s8;
-            if (!LRA_MEL_ALIGNED_BURSTS) {
-                s8 = it & (MT - 1);
-            } else if ((a.n_frames & 3) == 0 && Cfg::TF >= 64) {
-                // rows start 0 or 16 bytes into a 32-byte piece, alternating with the band's parity: with bands 2 tf and 2 tf + 1
-                // per thread the phase is (clip, frame, b) only -- scalar, so the tile select and the flush branch stay scalar
-                // (a per-lane phase made the flush run twice per MT frames under half masks: +2.8 % kernel time)
-                s8 = (int)(((long long)clip * a.n_mels * a.n_frames + (long long)b * a.n_frames + frame) & (MT - 1));
-            } else {
-                s8 = (int)((row0 + frame) & (MT - 1));
-            }
+            const int s8 = melr_tile_slot<Cfg, RG>(a, clip, frame, it, b, row0);
             LRA_UNROLL
-            for (int k = 0; k < MT; ++k)
-                if (k == s8) rg.mt[b][k] = v;
-            if (s8 == MT - 1 || last_of_slot) {
-                T* __restrict__ row = a.Mel + (row0 + frame - s8);
-                LRA_UNROLL
-                for (int k = 0; k < MT; ++k)
-                    if (k <= s8 && k >= s8 - it) row[k] = rg.mt[b][k];  // (only the frames this slot has produced so far)
-            }
+            for (int k = 0; k < MT; ++k) rg.mt[b][k] = k == s8 ? v : rg.mt[b][k];  // (a select per slot: a conditional store here ends up as an indexed store to scratch memory)
+            // (issued one frame later, behind the next frame's sample loads and a whole frame ahead of the loop top's s_waitcnt vmcnt(0), the
+            // bursts are 1-2 % SLOWER: profiles/r03_experiments.md section 11)
+            if (last_of_slot || s8 == MT - 1) melr_burst<Cfg, RG>(a, row0, frame, s8, it, b, rg);
         } else {
             lds_st<T>(stage, (m * tile + (it % tile)) * (int)sizeof(T), v);
         }
