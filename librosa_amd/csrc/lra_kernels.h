@@ -1842,6 +1842,12 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
             const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
             const IstftSlot<Cfg> s = LRA_R(sl);
             const int t = s.t0 - a.warm_frames + j;
+#if defined(__HIP_DEVICE_COMPILE__) && defined(LRA_ISTFT_ABLATE)
+            if constexpr ((LRA_ISTFT_ABLATE & 4) != 0 && sizeof(T) == 4) {  // (the experiment's load targets stay allocated while their loads are in flight)
+                LRA_UNROLL
+                for (int q = 0; q < Cfg::R; ++q) { LRA_KEEP(LRA_R(rg).nxt[q].x); LRA_KEEP(LRA_R(rg).nxt[q].y); }
+            }
+#endif
             if constexpr (MIR) istft_unsplit_pass0<Cfg>(tf, LRA_R(rg), lds_sub(lds, slot * SB));
             else istft_split_write<Cfg>(a, tf, LRA_R(rg), lds_sub(lds, slot * SB));
 #ifndef LRA_ISTFT_ABLATE  // timing experiments (scripts/ab_run.sh): bit 0 = no spectrum loads in the frame loop, bit 1 = no output stores
@@ -1866,8 +1872,26 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
             }
             if (!LRA_ISTFT_LOADS_FIRST) prefetch();
             if constexpr (rows) {  // for the flush of THIS frame, one iteration from now
-                if (s.active) istft_wss_rows<Cfg, HC>(a, s.clip, t, t >= s.t0 && (s.last || t < s.t1), tf, LRA_R(rg));
+                if (s.active && (!(LRA_ISTFT_ABLATE & 8) || ablate_never)) istft_wss_rows<Cfg, HC>(a, s.clip, t, t >= s.t0 && (s.last || t < s.t1), tf, LRA_R(rg));
             }
+#if defined(__HIP_DEVICE_COMPILE__) && (LRA_ISTFT_ABLATE & 4)
+            // experiment: the next frame's spectrum is read (16 loads the compiler does not know about, into registers nothing else uses) and never
+            // waited for -- what the read traffic costs the arithmetic when nothing waits on it
+            if constexpr (MIR && sizeof(T) == 4) {
+                if (j + 1 < steps && s.active && t + 1 >= 0 && t + 1 < s.t1) {
+                    const typename Cfg::cplx* X = a.D + s.clip * a.d_batch_stride + (long long)(t + 1) * a.d_frame_stride;
+                    LRA_UNROLL
+                    for (int q = 0; q < Cfg::R / 2; ++q) {
+                        const typename Cfg::cplx* pk = X + tf + q * 2 * Cfg::TF;
+                        const typename Cfg::cplx* pm = X + Cfg::M - tf - q * 2 * Cfg::TF;
+                        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(LRA_R(rg).nxt[2 * q]) : "v"(pk));
+                        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(LRA_R(rg).nxt[2 * q + 1]) : "v"(pm));
+                    }
+                }
+                LRA_UNROLL
+                for (int q = 0; q < Cfg::R; ++q) { LRA_KEEP(LRA_R(rg).nxt[q].x); LRA_KEEP(LRA_R(rg).nxt[q].y); }
+            }
+#endif
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         // pass 0 (no twiddles) reads from LDS here, unlike the forward kernel (unless it was fused into the Hermitian step)
         if (Cfg::P > 1 && !MIR) {
