@@ -43,13 +43,15 @@ def counters(sub):
     if not os.path.exists(path):
         return agg
     rows = list(csv.DictReader(open(path)))
-    # a kernel is also launched on other batches (autotune probes, the 64-clip NumPy end-to-end key): keep the launches
-    # with the most frequent grid only, i.e. the 256-clip batch of the timed step every per-launch figure refers to
+    # a kernel is also launched on other batches (autotune probes, the 64-clip NumPy end-to-end key, the 32-clip Griffin-Lim loop -- which
+    # outnumbers everything else): keep the launches with the grid that most of the kernel's TIME goes to, i.e. the 256-clip batch of the
+    # timed step every per-launch figure refers to
     grids = collections.defaultdict(collections.Counter)
     for r in rows:
-        grids[r["Kernel_Name"]][int(r["Grid_Size"])] += 1
+        grids[r["Kernel_Name"]][int(r["Grid_Size"])] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    timed = {k: v.most_common(1)[0][0] for k, v in grids.items()}  # the grid most of the kernel's time goes to
     for r in rows:
-        if int(r["Grid_Size"]) != grids[r["Kernel_Name"]].most_common(1)[0][0]:
+        if int(r["Grid_Size"]) != timed[r["Kernel_Name"]]:
             continue
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         agg[r["Kernel_Name"]]["_dur_ns"].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
@@ -106,6 +108,23 @@ if os.path.exists(stats_csv):
     rows = list(csv.DictReader(open(stats_csv)))[:6]
     for r in rows:
         lines.append(f"| {short(r['Name'])} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['MinNs']) / 1e3:.1f} | {float(r['MaxNs']) / 1e3:.1f} | {r['Percentage']} |")
+    lines.append("")
+# the same trace restricted to the timed 256-clip batch (the grid most of the kernel's time goes to): these are the averages the bench line's launch_ms must agree with
+trace_csv = os.path.join(src, "stats", "r_kernel_trace.csv")
+if os.path.exists(trace_csv):
+    rows = list(csv.DictReader(open(trace_csv)))
+    grids = collections.defaultdict(collections.Counter)
+    for r in rows:
+        grids[r["Kernel_Name"]][int(r["Grid_Size_X"])] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    durs = collections.defaultdict(list)
+    for r in rows:
+        k = r["Kernel_Name"]
+        if ("stft" in k) and int(r["Grid_Size_X"]) == grids[k].most_common(1)[0][0]:
+            durs[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    lines += ["## launches of the timed batch only (the grid most of the kernel's time goes to), from the same trace", "", "| kernel | launches | avg (us) | median (us) | min (us) |", "|---|---|---|---|---|"]
+    for k, v in sorted(durs.items(), key=lambda kv: -sum(kv[1]))[:6]:
+        v2 = sorted(v)
+        lines.append(f"| {short(k)} | {len(v)} | {mean(v) / 1e3:.1f} | {v2[len(v2) // 2] / 1e3:.1f} | {v2[0] / 1e3:.1f} |")
     lines.append("")
 lines += ["## HBM traffic per launch (FETCH_SIZE / WRITE_SIZE, separate passes)", "", f"calibration on torch clamp_ over the 677.4 MB batch: {calib}", "",
           "| kernel | FETCH raw (MB) | WRITE raw (MB) | FETCH calibrated (MB) | WRITE calibrated (MB) |", "|---|---|---|---|---|"]
