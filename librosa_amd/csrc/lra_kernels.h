@@ -154,6 +154,7 @@ template <class Cfg> struct FftRegs {
     static constexpr int MELR_TILE = 8;
     typename Cfg::real mt[2][MELR_TILE];
     typename Cfg::real wv[NPFX];  // ISTFT (row-aligned): window sum-square values of the held-back samples, loaded a frame ahead
+    typename Cfg::cplx cry[Cfg::R];  // ISTFT (row-aligned, istft_reg_carry): the overlap-add carry, pair c of this thread's R - HC rows that outlive a frame
     static constexpr int NH = Cfg::HOIST ? 1 : 0;
     typename Cfg::cplx win2[NH * Cfg::R + 1 - NH];       // window pairs in pass-0 register order
     typename Cfg::cplx treg[NH * Cfg::TREG_TOTAL + 1 - NH];
@@ -1318,7 +1319,15 @@ template <class T> struct IstftArgs {
 
 // per slot: frame area + double-buffered carry of N reals (>= N - hop for any hop >= 1)
 // HC > 0 (row-aligned): one in-place carry of the R - HC rows that outlive a frame, (R - HC) TF sample pairs
-template <class Cfg, int HC = 0> constexpr int istft_carry_reals() { return HC > 0 ? (Cfg::R - HC) * Cfg::TF * 2 : 2 * Cfg::N; }
+// Row-aligned hops shift a thread's carry pairs onto ITS OWN pairs (istft_last_ola_rows), so the carry is thread-private: where the
+// register budget allows (the ascending-radix float configuration: n_fft = 2048) it lives in R - HC register pairs instead of LDS --
+// 2 (R - HC) LDS instructions per frame and thread less (24 of 54 at hop = n_fft / 4), for no instruction more: the frame's sums ARE
+// the next frame's carry, one hop of rows down.
+#ifndef LRA_ISTFT_REG_CARRY
+#define LRA_ISTFT_REG_CARRY 1
+#endif
+template <class Cfg, int HC> constexpr bool istft_reg_carry() { return LRA_ISTFT_REG_CARRY && HC > 0 && Cfg::REV && Cfg::HOIST && sizeof(typename Cfg::real) == 4 && Cfg::R == 16; }
+template <class Cfg, int HC = 0> constexpr int istft_carry_reals() { return istft_reg_carry<Cfg, HC>() ? 0 : (HC > 0 ? (Cfg::R - HC) * Cfg::TF * 2 : 2 * Cfg::N); }
 template <class Cfg, int HC = 0> constexpr int istft_slot_bytes() { return Cfg::FRAME_BYTES + ((istft_carry_reals<Cfg, HC>() * (int)sizeof(typename Cfg::real) + 15) / 16) * 16; }
 template <class Cfg, int HC = 0> constexpr int istft_lds_bytes() { return Cfg::FPB * istft_slot_bytes<Cfg, HC>(); }
 
@@ -1638,10 +1647,12 @@ template <class Cfg, int HC> LRA_HD void istft_last_ola_rows(const IstftArgs<typ
     const C zero = mk<T>((T)0, (T)0);
     const int rbase = tf * (int)sizeof(C);
     const int wbase = (tf - hc * TF) * (int)sizeof(C);  // pair c lands on pair c - hc
+    constexpr bool REGC = istft_reg_carry<Cfg, HC>();
+    static_assert(!REGC || CH == R, "register carry: one chunk");
     C cv0[CH];
     if (CH == R) {
         LRA_UNROLL
-        for (int q = 0; q < CH; ++q) cv0[q] = q < clc ? lds_ld<C>(carry, rbase + q * TF * (int)sizeof(C)) : zero;
+        for (int q = 0; q < CH; ++q) cv0[q] = q < clc ? (REGC ? rg.cry[q] : lds_ld<C>(carry, rbase + q * TF * (int)sizeof(C))) : zero;
     }
     pass_dft<Cfg, p>(rg, tf, a.tw);
     LRA_UNROLL
@@ -1657,6 +1668,8 @@ template <class Cfg, int HC> LRA_HD void istft_last_ola_rows(const IstftArgs<typ
             const C val = contribute ? mk<T>(cv[q].x + z.x * w.x, cv[q].y - z.y * w.y) : cv[q];
             if (c < hc) {
                 if (2 * c + 1 < FftRegs<Cfg>::NPFX) { rg.out[2 * c] = val.x; rg.out[2 * c + 1] = val.y; }
+            } else if (REGC) {
+                rg.cry[c - hc] = val;
             } else {
                 lds_st<C>(carry, wbase + c * TF * (int)sizeof(C), val);
             }
@@ -1828,6 +1841,10 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
         }
         const Lds c0 = lds_sub(lds, slot * SB + Cfg::FRAME_BYTES);
         for (int u = tf; u < (HC > 0 ? istft_carry_reals<Cfg, HC>() : Cfg::N); u += Cfg::TF) lds_st<T>(c0, u * (int)sizeof(T), (T)0);
+        if constexpr (istft_reg_carry<Cfg, HC>()) {
+            LRA_UNROLL
+            for (int q = 0; q < Cfg::R; ++q) LRA_R(rg).cry[q] = mk<T>((T)0, (T)0);
+        }
         LRA_R(sl) = istft_slot<Cfg>(a, blk, slot_of<Cfg>(LRA_RAW_TID(tid)));
         const IstftSlot<Cfg> s = LRA_R(sl);
         const int t = s.t0 - a.warm_frames;
