@@ -142,6 +142,53 @@ def test_random_configurations(L, seed):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("seed", [s + 100 for s in _sweep_seeds()] + [110, 111, 112, 113, 114])
+def test_random_configurations_wide(L, seed):
+    """The argument space around the first sweep (the generator of tests/test_oracle.py::test_oracle_vs_live_reference_wide, which pins the oracle on
+    exactly these draws): named / tuple / array windows, win_length, symmetric padding, float64, 1-D to 3-D input, hops beyond the frame,
+    mel scale / norm / band-edge options -- drop-in against oracle."""
+    import warnings
+
+    rng = np.random.default_rng(seed)
+    n_fft = int(rng.choice([64, 200, 256, 512, 1000, 1024, 2048, 4096]))
+    hop = int(rng.choice([n_fft // 4, n_fft // 2, n_fft // 3, n_fft, max(1, n_fft // 8), n_fft + 17]))
+    dtype = np.float64 if rng.random() < 0.3 else np.float32
+    center = bool(rng.random() < 0.7)
+    pad_mode = str(rng.choice(["constant", "reflect", "edge", "symmetric"]))
+    win_length = None if rng.random() < 0.6 else int(rng.integers(n_fft // 2, n_fft))
+    wl = win_length or n_fft
+    window = [lambda: "hann", lambda: "hamming", lambda: "blackmanharris", lambda: ("tukey", 0.25), lambda: ("kaiser", 4.0), lambda: rng.random(wl) + 0.1][int(rng.integers(0, 6))]()
+    n = int(rng.integers(max(n_fft, 2 * hop) + 5, 5 * n_fft + 3000))
+    shape = [(n,), (2, n), (2, 3, n)][int(rng.integers(0, 3))]
+    y = rng.standard_normal(shape).astype(dtype)
+    kw = dict(n_fft=n_fft, hop_length=hop, win_length=win_length, window=window, center=center, pad_mode=pad_mode)
+    f32 = dtype == np.float32
+    tag = (seed, n_fft, hop, np.dtype(dtype).name, center, pad_mode, win_length, str(window)[:20], shape)
+    D, ref = L.stft(y, **kw), O.stft(y, **kw)
+    assert D.dtype == ref.dtype and D.shape == ref.shape, tag
+    assert np.abs(D - ref).max() <= (4e-6 if f32 else 1e-12) * np.abs(ref).max(), tag
+    ikw = dict(hop_length=hop, win_length=win_length, n_fft=n_fft, window=window, center=center)
+    try:
+        yr = O.istft(ref, **ikw)
+    except Exception:
+        yr = None
+    if yr is not None:
+        yy = L.istft(D, **ikw)
+        wss = O.window_sumsquare(window=window, n_frames=ref.shape[-1], win_length=win_length, n_fft=n_fft, hop_length=hop, dtype=np.float64)
+        wss = wss[(n_fft // 2 if center else 0):]
+        wss = np.pad(wss, (0, max(0, yr.shape[-1] - len(wss))))[: yr.shape[-1]]
+        assert yy.shape == yr.shape and yy.dtype == yr.dtype, tag
+        assert _istft_close(yy, yr, wss.astype(yr.dtype)), tag + (float(np.abs(yy - yr).max()),)
+    if n_fft >= 200:
+        mk = dict(kw, sr=22050, n_mels=int(rng.choice([13, 40, 80, 128])), power=float(rng.choice([1.0, 2.0, 1.5])), htk=bool(rng.random() < 0.3),
+                  norm=[None, "slaney", 1, np.inf][int(rng.integers(0, 4))], fmin=float(rng.choice([0.0, 50.0])), fmax=[None, 8000.0][int(rng.integers(0, 2))])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            M, Mr = L.feature.melspectrogram(y=y, **mk), O.melspectrogram(y=y, **mk)
+        assert M.dtype == Mr.dtype and M.shape == Mr.shape, tag
+        assert np.abs(M - Mr).max() <= (2e-5 if f32 else 1e-11) * Mr.max(), tag
+
+
 def test_threads_share_a_context(L):
     """Several Python threads calling the drop-in concurrently (ctypes releases the GIL): public calls serialise on a
     per-context lock, so stream selection, the sticky non-finite flag and plan scratch buffers cannot interleave."""

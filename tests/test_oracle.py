@@ -222,6 +222,54 @@ def test_oracle_vs_live_reference(seed):
     assert np.array_equal(wss0, O.window_sumsquare(window="hann", n_frames=17, hop_length=hop, n_fft=n_fft))
 
 
+@pytest.mark.skipif(not ref_shim.available(), reason="/root/reference not present (GPU box)")
+@pytest.mark.parametrize("seed", range(100, 116))
+def test_oracle_vs_live_reference_wide(seed):
+    """The same comparison over the rest of the argument space the path takes: float64 audio, uncentred framing, win_length < n_fft, other windows
+    (names, tuples, arrays), np.pad's symmetric mode, power 1 / 2 / 1.5, HTK mel scale, norm=None, fmin / fmax, 1-D and 3-D input."""
+    librosa = ref_shim.load_reference()
+    rng = np.random.default_rng(seed)
+    n_fft = int(rng.choice([64, 200, 256, 512, 1000, 1024, 2048, 4096]))
+    hop = int(rng.choice([n_fft // 4, n_fft // 2, n_fft // 3, n_fft, max(1, n_fft // 8), n_fft + 17]))
+    dtype = np.float64 if rng.random() < 0.3 else np.float32
+    center = bool(rng.random() < 0.7)
+    pad_mode = str(rng.choice(["constant", "reflect", "edge", "symmetric"]))
+    win_length = None if rng.random() < 0.6 else int(rng.integers(n_fft // 2, n_fft))
+    wl = win_length or n_fft
+    window = [lambda: "hann", lambda: "hamming", lambda: "blackmanharris", lambda: ("tukey", 0.25), lambda: ("kaiser", 4.0), lambda: rng.random(wl) + 0.1][int(rng.integers(0, 6))]()
+    n = int(rng.integers(max(n_fft, 2 * hop) + 5, 5 * n_fft + 3000))
+    shape = [(n,), (2, n), (2, 3, n)][int(rng.integers(0, 3))]
+    y = rng.standard_normal(shape).astype(dtype)
+    kw = dict(n_fft=n_fft, hop_length=hop, win_length=win_length, window=window, center=center, pad_mode=pad_mode)
+    tol = 1e-6 if dtype == np.float32 else 1e-13
+    D0, D1 = librosa.stft(y, **kw), O.stft(y, **kw)
+    assert D0.dtype == D1.dtype and D0.shape == D1.shape
+    assert np.abs(D0 - D1).max() <= tol * np.abs(D0).max()
+    ikw = dict(hop_length=hop, win_length=win_length, n_fft=n_fft, window=window, center=center)
+    try:
+        y0 = librosa.istft(D0, **ikw)
+    except Exception:
+        y0 = None  # the reference rejects the combination
+    if y0 is not None:
+        y1 = O.istft(D0, **ikw)
+        assert y0.shape == y1.shape and y0.dtype == y1.dtype
+        # (hops beyond the window leave samples with a tiny window sum-square: compare where the division is well conditioned)
+        wss = librosa.filters.window_sumsquare(window=window, n_frames=D0.shape[-1], win_length=win_length, n_fft=n_fft, hop_length=hop, dtype=np.float64)
+        wss = wss[(n_fft // 2 if center else 0):]
+        wss = np.pad(wss, (0, max(0, y0.shape[-1] - len(wss))))[: y0.shape[-1]]
+        ok = wss > 1e-3 * wss.max()
+        assert np.abs(y0 - y1)[..., ok].max() <= (2e-5 if dtype == np.float32 else 1e-12) * max(np.abs(y0)[..., ok].max(), 1e-30)
+    if n_fft >= 200:
+        mk = dict(kw, sr=22050, n_mels=int(rng.choice([13, 40, 80, 128])), power=float(rng.choice([1.0, 2.0, 1.5])), htk=bool(rng.random() < 0.3),
+                  norm=[None, "slaney", 1, np.inf][int(rng.integers(0, 4))], fmin=float(rng.choice([0.0, 50.0])), fmax=[None, 8000.0][int(rng.integers(0, 2))])
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # (empty filters at small n_fft / many bands: both sides warn)
+            M0, M1 = librosa.feature.melspectrogram(y=y, **mk), O.melspectrogram(y=y, **mk)
+        assert M0.dtype == M1.dtype and M0.shape == M1.shape
+        np.testing.assert_allclose(M0, M1, rtol=2e-5 if dtype == np.float32 else 1e-11, atol=(1e-6 if dtype == np.float32 else 1e-13) * M0.max())
+
+
 def test_db_and_mfcc_oracle_matches_reference_goldens():
     """the restated power_to_db / amplitude_to_db / db_to_* / mfcc against outputs of the unmodified
     reference (tests/golden/db_mfcc.npz, oracle/make_golden.py::make_db_mfcc)."""
