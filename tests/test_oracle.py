@@ -422,6 +422,46 @@ def test_cqt_oracle_live_reference():
         assert np.array_equal(CQ.vqt(y, sr=22050, res_type=rt, gamma=None), L.vqt(y, sr=22050, res_type=rt))
 
 
+@pytest.mark.skipif(not ref_shim.available(), reason="/root/reference not present (GPU box)")
+@pytest.mark.parametrize("seed", range(200, 212))
+def test_db_mfcc_vocoder_oracle_vs_live_reference_wide(seed):
+    """Seeded draws over the arguments of the 8(f) rows that are plain functions of a spectrogram: power_to_db / amplitude_to_db and their inverses
+    (ref scalar / callable, amin, top_db), mfcc (DCT types 1-3, norm, lifter, from audio and from S), phase_vocoder (rates either side of one)
+    and effects.time_stretch -- oracle against the unmodified reference, bit for bit where the arithmetic is NumPy's own."""
+    librosa = ref_shim.load_reference()
+    rng = np.random.default_rng(seed)
+    S = (rng.random((2, int(rng.integers(8, 96)), int(rng.integers(5, 80)))) ** 4 * 10 ** rng.uniform(-6, 3)).astype(np.float32 if rng.random() < 0.7 else np.float64)
+    ref = [1.0, 0.37, np.max, np.median][int(rng.integers(0, 4))]
+    kw = dict(ref=ref, amin=float(10 ** rng.uniform(-12, -4)), top_db=[None, 80.0, 35.5][int(rng.integers(0, 3))])
+    for name in ("power_to_db", "amplitude_to_db"):
+        a, b = getattr(librosa, name)(S, **kw), getattr(O, name)(S, **kw)
+        assert a.dtype == b.dtype and np.array_equal(a, b), (name, seed)
+    dbv = O.power_to_db(S, **kw)
+    rs = 1.0 if callable(ref) else ref
+    assert np.array_equal(librosa.db_to_power(dbv, ref=rs), O.db_to_power(dbv, ref=rs))
+    assert np.array_equal(librosa.db_to_amplitude(dbv, ref=rs), O.db_to_amplitude(dbv, ref=rs))
+    mk = dict(n_mfcc=int(rng.integers(5, 30)), dct_type=int(rng.integers(1, 4)), norm=[None, "ortho"][int(rng.integers(0, 2))], lifter=float(rng.choice([0, 0, 22, 7.5])))
+    if mk["dct_type"] == 1 and mk["norm"] == "ortho" and S.shape[-2] < 2:
+        mk["norm"] = None
+    Sdb = O.power_to_db(S)
+    a, b = librosa.feature.mfcc(S=Sdb, **mk), O.mfcc(S=Sdb, **mk)
+    assert a.dtype == b.dtype and a.shape == b.shape and np.allclose(a, b, rtol=1e-6, atol=1e-6 * np.abs(a).max()), ("mfcc S", seed, mk)
+    y = rng.standard_normal(int(rng.integers(3000, 9000))).astype(np.float32)
+    a = librosa.feature.mfcc(y=y, sr=22050, n_fft=512, hop_length=128, n_mels=40, **mk)
+    b = O.mfcc(y=y, sr=22050, n_fft=512, hop_length=128, n_mels=40, **mk)
+    assert a.shape == b.shape and np.allclose(a, b, rtol=1e-4, atol=2e-4 * np.abs(a).max()), ("mfcc y", seed, mk)
+    D = librosa.stft(y, n_fft=256, hop_length=64)
+    rate = float(rng.choice([0.5, 0.8, 1.0, 1.37, 2.0, 3.1]))
+    a, b = librosa.phase_vocoder(D, rate=rate), O.phase_vocoder(D, rate=rate)
+    assert a.shape == b.shape and a.dtype == b.dtype and np.abs(a - b).max() <= 2e-5 * np.abs(a).max(), ("vocoder", seed, rate)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", FutureWarning)  # (the reference's time_stretch passes deprecated arguments to its own phase_vocoder)
+        a = librosa.effects.time_stretch(y, rate=rate, n_fft=256, hop_length=64)
+    b = O.time_stretch(y, rate=rate, n_fft=256, hop_length=64)
+    assert a.shape == b.shape and np.abs(a - b).max() <= 5e-5 * max(np.abs(a).max(), 1e-30), ("time_stretch", seed, rate)
+
+
 # ---- harmonic / percussive separation (SURVEY.md 8f rank 3) ----------------------------------------------------------------------------
 def test_hpss_oracle_matches_reference_golden():
     """librosa.decompose.hpss (decompose.py:470-528) with util.softmask and magphase, and the effects.hpss / harmonic / percussive chains
