@@ -3,7 +3,7 @@
 #   scripts/power_probe.sh n_fft hop what [seconds]
 cd "$(dirname "$0")/.."
 nf=$1; hop=$2; what=$3; secs=${4:-8}
-PROBE_PREWARM_S=$secs timeout 120 python scripts/size_probe.py $nf $hop 30 $what > /tmp/pp_$$.log 2>&1 &
+PROBE_PREWARM_S=$secs timeout 300 python scripts/size_probe.py $nf $hop 30 $what > /tmp/pp_$$.log 2>&1 &
 pid=$!
 sleep 4   # (import + set-up)
 for i in 1 2 3 4; do
