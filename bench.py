@@ -4,6 +4,7 @@
     python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        # no launcher around it: starts the N ranks itself (the command above), refuses when fewer devices are visible
 
 A "step" is one pass of the hot path -- feature.melspectrogram (fused framing + window + FFT + |X|^2 + two-slope mel,
 one kernel launch) -- over one batch of synthetic 22.05 kHz clips already resident in HBM.  Workload:
@@ -27,8 +28,11 @@ Extra keys on the JSON line (rank 0):
   power_to_db / mfcc  the SURVEY 8(f) consumers on the same batch (device tensors)
   pcen_cqt        pcen on the mel batch; the true constant-Q transform (84 bins) of 64 clips, device tensors
   cqt_lite        BASELINE configs[4]: STFTs at n_fft 512 / 2048 / 8192 over the same batch (N=1 only)
-  cpu_baseline    the NumPy/scipy.fft oracle (a port of the reference path) on this box's host cores, rank 0 at N=1 only, on
-                  a bounded sample of the same workload (one core); cpu_baseline_all_cores = one independent process per core
+  stream_ceiling  the forward / inverse access streams WITHOUT arithmetic (lra_probe_stream), same box, batch and clock ramp: what the
+                  transforms' rates are to be read against (`transform_over_stream`)
+  cpu_baseline    the reference's own CPU path (unmodified librosa through oracle/ref_shim.py, packed for the GPU box by oracle/make_ref.py:
+                  kind "reference") with the NumPy port beside it, on this box's host cores, rank 0 at N=1 only, on a bounded sample of the
+                  same workload (one core); cpu_baseline_all_cores = one independent process per core
 """
 from __future__ import annotations
 
@@ -88,54 +92,84 @@ def _host_versions():
     return v
 
 
-def cpu_baseline(seconds=12.0, parity_clip=None):
-    """Oracle (NumPy restatement of the reference path, oracle/stft_oracle.py) timed on this host, 1 core.
-
-    ``parity_clip = (y_host, M_gpu_host)``: the same leg also checks the timed kernel's output for that clip."""
+def _load_reference():
+    """The UNMODIFIED reference package through oracle/ref_shim.py: from /root/reference where it exists (the build container), else from
+    the archive oracle/_ref/librosa_ref.zip that __graft_entry__.build() packs there (oracle/make_ref.py) and that travels with the
+    repository snapshot.  None when neither exists: the baseline then falls back to the NumPy port and says so."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import stft_oracle as O
+    try:
+        import ref_shim
 
+        if not ref_shim.available():
+            return None
+        return ref_shim.load_reference()
+    except Exception:  # pragma: no cover
+        return None
+
+
+def _limit_blas():
     import contextlib
 
     try:
         from threadpoolctl import threadpool_limits
 
-        limiter = threadpool_limits(limits=1)
+        return threadpool_limits(limits=1)
     except Exception:  # pragma: no cover
-        limiter = contextlib.nullcontext()
+        return contextlib.nullcontext()
+
+
+def _time_mel(fn, y, seconds):
+    fn(y[0])  # warm (tables, imports)
+    frames = clips = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        frames += fn(y[clips % len(y)]).shape[-1]
+        clips += 1
+    return frames, clips, time.perf_counter() - t0
+
+
+def cpu_baseline(seconds=10.0, parity_clip=None):
+    """The reference's own CPU path (librosa.feature.melspectrogram: core/spectrum.py:57-391, feature/spectral.py:2022-2161) timed on this
+    host, 1 core: `kind` = "reference" when the reference package is available (see _load_reference), with the NumPy port
+    (oracle/stft_oracle.py) timed beside it; "port" alone otherwise.
+
+    ``parity_clip = (y_host, M_gpu_host)``: the same leg also checks the timed kernel's output for that clip."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import stft_oracle as O
+
+    ref = _load_reference()
     y = O.config_input(4, n=SR * CLIP_SECONDS)
-    O.melspectrogram(y=y[0], sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS)  # warm
-    frames = 0
-    clips = 0
-    with limiter:
-        t0 = time.perf_counter()
-        while time.perf_counter() - t0 < seconds:
-            M = O.melspectrogram(y=y[clips % 4], sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS)
-            frames += M.shape[-1]
-            clips += 1
-    dt = time.perf_counter() - t0
-    out = {
-        "value": frames / dt,
-        "unit": "frames/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"{clips} clips x {CLIP_SECONDS} s melspectrogram (n_fft={N_FFT} hop={HOP} n_mels={N_MELS}) in {dt:.1f} s, "
-                  f"1 process, BLAS limited to 1 thread",
-        "host": _host_versions(),
-    }
-    # the port against the reference itself, measured where the reference tree exists (the build container), committed
-    try:
-        ratio = json.load(open(os.path.join(ROOT, "profiles", "cpu_port_vs_reference.json")))
-        out["port_vs_reference"] = ratio
-    except Exception:
-        pass
+    kw = dict(sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS)
+    with _limit_blas():
+        pf, pc, pdt = _time_mel(lambda c: O.melspectrogram(y=c, **kw), y, seconds if ref is None else seconds / 2)
+        if ref is not None:
+            rf, rc, rdt = _time_mel(lambda c: ref.feature.melspectrogram(y=c, **kw), y, seconds)
+    port = {"value": pf / pdt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{pc} clips x {CLIP_SECONDS} s melspectrogram in {pdt:.1f} s, oracle/stft_oracle.py, 1 process, BLAS limited to 1 thread"}
+    if ref is not None:
+        out = {"value": rf / rdt, "unit": "frames/s", "cores": 1, "kind": "reference",
+               "sample": f"{rc} clips x {CLIP_SECONDS} s through the unmodified librosa.feature.melspectrogram (n_fft={N_FFT} hop={HOP} n_mels={N_MELS}) in {rdt:.1f} s, "
+                         f"1 process, BLAS limited to 1 thread, numba stubbed (plain NumPy bodies; affects istft / window_sumsquare only, not this path)",
+               "reference_root": "oracle/_ref/librosa_ref.zip (packed by oracle/make_ref.py)" if not os.path.isdir("/root/reference") else "/root/reference",
+               "port": port, "port_vs_reference": port["value"] / (rf / rdt)}
+    else:
+        out = port
+        try:  # the port against the reference, measured where the reference tree exists (the build container), committed
+            out["port_vs_reference"] = json.load(open(os.path.join(ROOT, "profiles", "cpu_port_vs_reference.json")))
+        except Exception:
+            pass
+    out["host"] = _host_versions()
     parity = None
     if parity_clip is not None:
         yh, Mg = parity_clip
-        Mref = O.melspectrogram(y=yh, sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS)
+        Mref = O.melspectrogram(y=yh, **kw)
         rel = np.abs(Mg - Mref) / np.abs(Mref)
         parity = {"mel_max_rel_err": float(rel.max()), "mel_max_abs_err_over_max": float(np.abs(Mg - Mref).max() / Mref.max()), "bar": 1e-4,
-                  "sample": "clip 0 of the timed batch (downloaded), all 128 x 1292 values, pure relative error |d| / |ref|"}
+                  "sample": "clip 0 of the timed batch (downloaded), all 128 x 1292 values, pure relative error |d| / |ref| against the oracle"}
+        if ref is not None:
+            Mr = ref.feature.melspectrogram(y=yh, **kw)
+            parity["mel_max_rel_err_vs_reference"] = float((np.abs(Mg - Mr) / np.abs(Mr)).max())
+            parity["oracle_equals_reference"] = bool(np.array_equal(Mr, Mref))
     return out, parity
 
 
@@ -144,19 +178,12 @@ def _cpu_worker(seconds):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import stft_oracle as O
 
-    try:
-        from threadpoolctl import threadpool_limits
-
-        threadpool_limits(limits=1)
-    except Exception:  # pragma: no cover
-        pass
+    ref = _load_reference()
     y = O.config_input(2, n=SR * CLIP_SECONDS)
-    O.melspectrogram(y=y[0], sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS)
-    frames, clips, t0 = 0, 0, time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        frames += O.melspectrogram(y=y[clips % 2], sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS).shape[-1]
-        clips += 1
-    return frames, time.perf_counter() - t0
+    kw = dict(sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS)
+    with _limit_blas():
+        frames, _, dt = _time_mel((lambda c: ref.feature.melspectrogram(y=c, **kw)) if ref is not None else (lambda c: O.melspectrogram(y=c, **kw)), y, seconds)
+    return frames, dt, ref is not None
 
 
 def cpu_baseline_all_cores(seconds=8.0, max_procs=64):
@@ -168,8 +195,66 @@ def cpu_baseline_all_cores(seconds=8.0, max_procs=64):
     procs = max(1, min(os.cpu_count() or 1, max_procs))
     with ProcessPoolExecutor(max_workers=procs, mp_context=mp.get_context("spawn")) as pool:
         res = list(pool.map(_cpu_worker, [seconds] * procs))
-    return {"value": sum(f / dt for f, dt in res), "unit": "frames/s", "cores": procs, "kind": "port",
+    kind = "reference" if all(r[2] for r in res) else "port"
+    return {"value": sum(f / dt for f, dt, _ in res), "unit": "frames/s", "cores": procs, "kind": kind,
             "sample": f"{procs} independent processes x {seconds:.0f} s of 30 s-clip melspectrograms (n_fft={N_FFT} hop={HOP} n_mels={N_MELS}), 1 BLAS thread each; host has {os.cpu_count()} logical cores"}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here, the way the driver's multi-GPU command does
+    (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...), and pass its
+    exit code on.  Fails loudly when the node shows fewer than N devices (LRA_BENCH_BACKEND=gloo: ranks share devices, the CPU test)."""
+    import socket
+    import subprocess
+
+    backend = os.environ.get("LRA_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        import torch
+
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            sys.exit(f"bench.py --gpus {args.gpus}: only {have} ROCm device(s) visible on this node; refusing to report n_gpus={args.gpus}")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, LRA_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def dry_run(args, torch, world, rank):
+    """--dry-run: everything around the step (see the flag's help).  No kernel, no library, no GPU; never a measurement."""
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+    batch = args.batch if args.batch else (256 if world == 1 else 512)
+    n_frames = 1 + SR * CLIP_SECONDS // HOP
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001)
+    wall = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        tw = torch.tensor([wall], dtype=torch.float64)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+    if rank == 0:
+        print(json.dumps({"metric": "STFT+mel frames/sec (n_fft=2048 hop=512)", "value": None, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "dry-run (no kernel executed, not a measurement)",
+                          "config": {"workload": "dry run of the launch / barrier / reduction control flow", "clips_per_gpu": batch, "frames_per_step_per_gpu": batch * n_frames,
+                                     "self_launched": bool(os.environ.get("LRA_BENCH_SELF_LAUNCHED"))}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -184,19 +269,30 @@ def main():
     ap.add_argument("--no-side", action="store_true", help="skip every side measurement (profiling runs)")
     ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power / clock samples (profiling runs: they loop the kernels for seconds)")
     ap.add_argument("--gather-chunks", type=int, default=4, help="pieces the shard travels in during the `gathered` measurement (N>1)")
+    ap.add_argument("--dry-run", action="store_true", help="control-flow check without a GPU (tests/test_distributed_cpu.py): launch, rendezvous, barriers, max over ranks and "
+                                                            "the JSON line with the step replaced by a 1 ms host sleep; `value` is null and `data` says so")
     ap.add_argument("--variant", type=int, default=None)
     ap.add_argument("--iters", type=int, default=None)
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)  # (does not return)
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.exit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: one rank per GPU, the two must agree")
 
     import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run:
+        return dry_run(args, torch, world, rank)
 
     import librosa_amd as L
     from librosa_amd import filters
     from librosa_amd.distributed import ShardedGather, chunk_ranges
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a ROCm device (no CPU fallback)"
     # LRA_BENCH_BACKEND=gloo: control-flow check of the N > 1 path on a box with fewer GPUs than ranks (ranks then share devices)
     backend = os.environ.get("LRA_BENCH_BACKEND", "nccl")
@@ -321,17 +417,43 @@ def main():
         wss = torch.from_numpy(wss_host).to(device)
         yrec = torch.empty((batch, n), dtype=torch.float32, device=device)
 
-        def roof(fn, bytes_per_frame, kernel):
+        def roof(fn, bytes_per_frame, kernel, read_bytes):
             _, e = timed(fn, args.steps, args.warmup, collective=False, ramp_ms=args.prewarm_ms / 2)
             s = e / args.steps
             ach = frames_per_step * bytes_per_frame / s / 1e9
             return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                    "bytes_per_frame": bytes_per_frame, "launch_ms": s * 1e3, "frames_per_s_single_gpu": frames_per_step / s}
+                    "bytes_per_frame": bytes_per_frame, "launch_ms": s * 1e3, "frames_per_s_single_gpu": frames_per_step / s,
+                    # the north star words its bar as "HBM-read roofline": the compulsory READ bytes alone, next to the write side
+                    "read_bytes_per_frame": read_bytes, "read_frac": frames_per_step * read_bytes / s / 1e9 / HBM_PEAK_GBS,
+                    "write_frac": frames_per_step * (bytes_per_frame - read_bytes) / s / 1e9 / HBM_PEAK_GBS,
+                    "call_ms": s * 1e3, "launches_per_call": 1}
 
-        measure("roofline_stft", lambda: roof(lambda: ctx.stft_exec(plan, yp, batch, n, n, Dp), BYTES_PER_FRAME_STFT,
-                                              "stft2_kernel<n_fft=2048, OUT_COMPLEX> (librosa.stft, complex64 out)"))
-        measure("roofline_istft", lambda: roof(lambda: ctx.istft_exec(iplan, Dp, batch, n_frames * n_bins, n_bins, n_frames, wss.data_ptr(), yrec.data_ptr(), n, n), BYTES_PER_FRAME_STFT,
-                                               "istft_kernel<n_fft=2048> (librosa.istft: c2r FFT + window + overlap-add + wss normalise)"))
+        step_stft = lambda: ctx.stft_exec(plan, yp, batch, n, n, Dp)
+        step_istft = lambda: ctx.istft_exec(iplan, Dp, batch, n_frames * n_bins, n_bins, n_frames, wss.data_ptr(), yrec.data_ptr(), n, n)
+        measure("roofline_stft", lambda: roof(step_stft, BYTES_PER_FRAME_STFT, "stft2_kernel<n_fft=2048, OUT_COMPLEX> (librosa.stft, complex64 out)", HOP * 4))
+        measure("roofline_istft", lambda: roof(step_istft, BYTES_PER_FRAME_STFT, "istft_kernel<n_fft=2048> (librosa.istft: c2r FFT + window + overlap-add + wss normalise)", n_bins * 8))
+        if "roofline_istft" in side and "error" not in side["roofline_istft"]:
+            side["roofline_istft"]["call_note"] = ("lra_istft_exec = ONE launch since round 4: the kernel stores every sample it covers and the wrapper zeroes only what no frame reaches "
+                                                   "(nothing here); round 3's call carried an 85 us hipMemsetAsync of the whole output (677 MB)")
+
+        def stream_ceiling():
+            """The same access streams WITHOUT arithmetic (lra_probe_stream, csrc/lra_probe.h): what this mix of PCM reads and 8-byte-aligned 8 200-byte row
+            writes reaches on THIS box at the forward kernel's residency -- the figure the transform's own rate is to be read against."""
+            out = {}
+            for key, direction, src, dst in (("forward", 0, yp, Dp), ("inverse", 1, Dp, yrec.data_ptr())):
+                fn = lambda: ctx.probe_stream(direction, src, dst, batch, n_frames, N_FFT, HOP, n, 162, 12)
+                _, e = timed(fn, args.steps, args.warmup, collective=False, ramp_ms=args.prewarm_ms / 2)
+                per = e / args.steps
+                ach = frames_per_step * BYTES_PER_FRAME_STFT / per / 1e9
+                out[key] = {"launch_ms": per * 1e3, "achieved": ach, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+            for key, rk in (("forward", "roofline_stft"), ("inverse", "roofline_istft")):
+                if rk in side and "error" not in side[rk]:
+                    out[key]["transform_over_stream"] = side[rk]["achieved"] / out[key]["achieved"]
+            out["what"] = ("stream_probe_kernel: one wave64 per strip of 162 rows, per row 2 048 B of PCM and one 8 200-byte row (16 x dwordx2 + the middle bin, the kernels' own order), "
+                           "next row's loads ahead of this row's stores, 12 waves per CU, no FFT, no LDS traffic; same batch, same clock ramp, same HIP-event timing as roofline_stft / _istft")
+            return out
+
+        measure("stream_ceiling", stream_ceiling)
         def board_power():
             """Socket power and shader clock reported by rocm-smi while each of the three kernels runs in a loop (a second thread keeps the queue full):
             the complex STFT runs at the board's power limit with the clock lowered, profiles/r03_experiments.md section 9."""
@@ -369,8 +491,8 @@ def main():
                     torch.cuda.synchronize(device)
                 return parse(txt)
 
-            return {"mel": sample(step_mel), "stft": sample(lambda: ctx.stft_exec(plan, yp, batch, n, n, Dp)),
-                    "istft": sample(lambda: ctx.istft_exec(iplan, Dp, batch, n_frames * n_bins, n_bins, n_frames, wss.data_ptr(), yrec.data_ptr(), n, n)),
+            return {"mel": sample(step_mel), "stft": sample(step_stft), "istft": sample(step_istft),
+                    "stream_forward": sample(lambda: ctx.probe_stream(0, yp, Dp, batch, n_frames, N_FFT, HOP, n, 162, 12)),
                     "what": "rocm-smi --showpower --showclocks sampled once, 2.5 s into a loop of the kernel (MI355X board limit: 1400 W; shader clock at most 2400 MHz)"}
 
         if not args.no_power:
@@ -508,8 +630,26 @@ def main():
                     parts[str(nf)] = {"ms": per * 1e3, "GBps": bytes_n / per / 1e9}
                     total_s += per
                     del Dn
-                return {"workload": f"3 STFTs n_fft=512/2048/8192, hop=512, batch={batch} x {CLIP_SECONDS} s (BASELINE config 5)", "per_n_fft": parts, "ms_total": total_s * 1e3,
-                        "frame_triples_per_s": frames_per_step / total_s}
+                out = {"workload": f"3 STFTs n_fft=512/2048/8192, hop=512, batch={batch} x {CLIP_SECONDS} s (BASELINE config 5)", "per_n_fft": parts, "ms_total": total_s * 1e3,
+                       "frame_triples_per_s": frames_per_step / total_s, "frac_of_hbm": frames_per_step * (HOP * 4 + (257 + 1025 + 4097) * 8) / total_s / 1e9 / HBM_PEAK_GBS}
+                # secondary variant: each transform at librosa's default hop = n_fft // 4 (core/spectrum.py:235-236): 128 / 512 / 2048
+                parts4, total4, bytes4 = {}, 0.0, 0
+                for nf in (512, 2048, 8192):
+                    hp = nf // 4
+                    w = np.asarray(filters.get_window("hann", nf, fftbins=True), dtype=np.float32)
+                    pl = plan if nf == N_FFT else ctx.stft_plan(nf, hp, w, True, "constant", np.float32)
+                    T_nf = ctx.stft_num_frames(pl, n)
+                    Dn = torch.empty((batch, T_nf, nf // 2 + 1), dtype=torch.complex64, device=device)
+                    _, ev_n = timed(lambda: ctx.stft_exec(pl, yp, batch, n, n, Dn.data_ptr()), max(3, args.steps // 2), 2, collective=False, ramp_ms=args.prewarm_ms / 4)
+                    per = ev_n / max(3, args.steps // 2)
+                    bytes_n = batch * T_nf * ((nf // 2 + 1) * 8 + hp * 4)
+                    parts4[str(nf)] = {"hop": hp, "frames_per_clip": int(T_nf), "ms": per * 1e3, "GBps": bytes_n / per / 1e9}
+                    total4 += per
+                    bytes4 += bytes_n
+                    del Dn
+                out["default_hop_variant"] = {"workload": "the same three transforms at hop = n_fft // 4 (128 / 512 / 2048)", "per_n_fft": parts4, "ms_total": total4 * 1e3,
+                                              "GBps": bytes4 / total4 / 1e9, "frac_of_hbm": bytes4 / total4 / 1e9 / HBM_PEAK_GBS}
+                return out
 
             measure("cqt_lite", cqt_lite)
         del D
@@ -536,10 +676,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"feature.melspectrogram, {split}, @ 22.05 kHz, n_fft={N_FFT} hop={HOP} n_mels={N_MELS}, inputs resident in HBM, outputs left sharded "
                                    f"(`gathered`: all-gathered)", "frames_per_step_per_gpu": frames_per_step, "clips_per_gpu": batch, "prewarm_ms": args.prewarm_ms,
-                       "parallelism": f"clips sharded over {world} GPU(s), no collective on the data path", "device": ctx.device_name()},
+                       "parallelism": f"clips sharded over {world} GPU(s), one process per GPU, no collective on the data path", "device": ctx.device_name(),
+                       "self_launched": bool(os.environ.get("LRA_BENCH_SELF_LAUNCHED"))},
             "roofline": {"bound": "hbm", "kernel": "stft2_kernel<n_fft=2048, OUT_MELR> (fused melspectrogram)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_frame": BYTES_PER_FRAME_MEL,
                          "launch_ms": launch_s * 1e3, "frames_per_s_single_gpu": frames_per_step / launch_s,
+                         "limited_by": "valu/lds issue, not HBM: the declared bound of this kernel is roofline_valu (f32 vector peak); the HBM figure is kept because BASELINE's metric asks for it",
                          "note": "this kernel sits on the LDS / VALU side of the ridge (~65 kFLOP and ~500 LDS cycles per 2 560 B); see roofline_stft for the HBM-bound kernel"},
             "repeats": {"ms_per_step_min": min(rep), "ms_per_step_median": statistics.median(rep), "ms_per_step_all": rep, "what": "5 more repeats of the timed region (HIP events, no collectives)"},
         }
@@ -555,8 +697,8 @@ def main():
                                    "note": "n_fft=2048 f32 fused mel: 0 = second-generation core, one wave64 per frame; 4 = first generation, two waves per frame; chosen by timing both on the first call "
                                            "(ctx option autotune); stft / |X|^p always run the second-generation kernel"}
         if "roofline_stft" in line and "error" not in line["roofline_stft"]:
-            line["roofline_stft"]["achievable_note"] = ("the same stream without arithmetic (scripts/storepat2.hip: 2 048 B read + 8 200 B written per row) reaches 5.0-5.5 TB/s at the kernel's "
-                                                        "residency on this chip (profiles/r02_store_stream.md)")
+            line["roofline_stft"]["achievable_note"] = ("the same stream without arithmetic is measured in this line: stream_ceiling.forward (lra_probe_stream); rounds 2-3 saw 5.0-5.55 TB/s "
+                                                        "over the pool's boxes (profiles/r02_store_stream.md)")
         # HBM bytes per launch measured with rocprofv3 PMC passes (scripts/profile_round.sh), when committed
         try:
             prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json"))
@@ -571,6 +713,7 @@ def main():
                         _, kname, v = max(cands, key=lambda c: c[0])
                         line[key]["traffic"] = v["hbm_bytes"]
                         line[key]["traffic_source"] = f"profiles/{prof[-1]} ({kname})"
+                        line[key]["traffic_box"] = "profile"  # measured under rocprofv3 on the builder's box, not on the box this line was timed on
         except Exception:
             pass
         if world == 1 and not args.no_cpu_baseline:

@@ -267,6 +267,16 @@ int lra_comm_init(lra_ctx* ctx, int rank, int n_ranks, const void* id, lra_comm*
 int lra_comm_allgather(lra_comm* comm, const void* send_dev, void* recv_dev, size_t bytes_per_rank);
 void lra_comm_destroy(lra_comm* comm);
 
+/* ---- measurement aid (no reference counterpart): the transform's access stream without its arithmetic ------------------
+ * direction 0: per row read `hop` float32 of PCM and write one row of n_fft/2 + 1 complex64 (the shape of the array
+ * librosa/core/spectrum.py:356 allocates); direction 1: read a row, write `hop` samples (the columns :598 reads).  Same
+ * decomposition as the fused kernels (one wave64 per strip of `strip_rows` consecutive rows, 8-byte pieces, next row's loads
+ * ahead of this row's stores), `waves_per_cu` resident waves per CU (0 = 12, the forward kernel's residency).  bench.py
+ * reports it as `stream_ceiling`: what this mix of reads and 8-byte-aligned row writes reaches on the chip at hand
+ * (SURVEY.md 8d prices the kernels against 8 TB/s).  n_fft in {256, 512, ..., 2048}, hop a multiple of 128. */
+int lra_probe_stream(lra_ctx* ctx, int direction, const void* in, void* out, int64_t batch, int64_t rows_per_clip, int n_fft, int hop, int64_t clip_samples,
+                     int strip_rows, int waves_per_cu);
+
 /* ---- layout helper: dst[b][c][r] = src[b][r][c], elem_bytes in {4, 8, 16} ------------------ */
 int lra_transpose(lra_ctx* ctx, const void* src, void* dst, int64_t batch, int64_t rows, int64_t cols, int elem_bytes);
 

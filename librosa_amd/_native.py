@@ -68,6 +68,7 @@ SIGNATURES = {
     "lra_istft_plan_destroy": (None, [c_void_p]),
     "lra_istft_exec": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64]),
     "lra_transpose": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int]),
+    "lra_probe_stream": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int64, c_int, c_int]),
     "lra_item_absmax_exec": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "lra_item_max_exec": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     "lra_to_db_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_int, c_double]),
@@ -223,7 +224,7 @@ class Context:
         self._istft_plans = collections.OrderedDict()
         self._mel_plans = collections.OrderedDict()
         self._mel_by_id = {}
-        self._tables = collections.OrderedDict()
+        self._tables = {}  # pool name -> OrderedDict (see device_table)
         self._lock = threading.RLock()
         self.call_lock = threading.RLock()  # held by _arrays.Session for the duration of one public call
 
@@ -261,23 +262,36 @@ class Context:
         return Event(self)
 
     PLAN_CACHE_SIZE = 48
-    TABLE_CACHE_SIZE = 512
+    # device tables live in two LRU pools, each bounded by entries AND bytes: "small" (DCT bases, lifters, CQT bases, decimator taps: a few
+    # KB each) and "large" (istft / griffinlim window sum-square envelopes: one float per output sample, a new key per (n_frames, length)).
+    # Separate pools so that a stream of variable-length inverse transforms can neither pin gigabytes of HBM nor push the small tables out.
+    TABLE_POOLS = {"small": (512, 64 << 20), "large": (8, 128 << 20)}
 
-    def device_table(self, key, build):
-        """Device pointer of a small read-only table kept under ``key`` for the life of the context (LRU-bounded); ``build()`` returns
-        the host array on a miss.  The upload is synchronous, so the table is usable from any stream of the device afterwards."""
+    def device_table(self, key, build, pool="small"):
+        """Device pointer of a read-only table kept under ``key`` (LRU, bounded per pool by entry count and by bytes); ``build()`` returns the
+        host array on a miss.  The upload is synchronous, so the table is usable from any stream of the device afterwards.  A table larger than
+        a quarter of its pool's byte budget is not worth caching: callers check ``table_cacheable`` and upload per call instead."""
+        max_entries, max_bytes = self.TABLE_POOLS[pool]
         with self._lock:
-            buf = self._tables.get(key)
+            tables = self._tables.setdefault(pool, collections.OrderedDict())
+            buf = tables.get(key)
             if buf is not None:
-                self._tables.move_to_end(key)
+                tables.move_to_end(key)
                 return buf.ptr
             host = np.ascontiguousarray(build())
             buf = DeviceBuffer(self, max(host.nbytes, 16)).upload(host)
-            self._tables[key] = buf
-            while len(self._tables) > self.TABLE_CACHE_SIZE:
-                _, old = self._tables.popitem(last=False)
+            tables[key] = buf
+            while len(tables) > 1 and (len(tables) > max_entries or sum(b.nbytes for b in tables.values()) > max_bytes):
+                _, old = tables.popitem(last=False)
                 old.free()
             return buf.ptr
+
+    def table_cacheable(self, nbytes, pool="small"):
+        return int(nbytes) <= self.TABLE_POOLS[pool][1] // 4
+
+    def table_bytes(self, pool=None):
+        with self._lock:
+            return sum(b.nbytes for name, t in self._tables.items() if pool in (None, name) for b in t.values())
 
     def _cached_plan(self, cache, key, create, destroy):
         """LRU lookup; on overflow the oldest plan is destroyed (hipFree synchronises with the device first)."""
@@ -434,6 +448,10 @@ class Context:
         _check(self.lib.lra_griffinlim_update(self.handle, c_void_p(rebuilt_ptr), c_void_p(tprev_ptr) if tprev_ptr else None, c_void_p(s_ptr), c_void_p(angles_ptr), count, dtype_code(dtype),
                                               float(coef), float(eps), int(bool(normalize))))
 
+    def probe_stream(self, direction, in_ptr, out_ptr, batch, rows_per_clip, n_fft, hop, clip_samples, strip_rows=0, waves_per_cu=0):
+        """The transform's access stream without its arithmetic (measurement aid; ``include/librosa_amd.h``)."""
+        _check(self.lib.lra_probe_stream(self.handle, int(direction), c_void_p(in_ptr), c_void_p(out_ptr), batch, rows_per_clip, n_fft, hop, clip_samples, strip_rows, waves_per_cu))
+
     def transpose(self, src_ptr, dst_ptr, batch, rows, cols, elem_bytes):
         _check(self.lib.lra_transpose(self.handle, c_void_p(src_ptr), c_void_p(dst_ptr), batch, rows, cols, elem_bytes))
 
@@ -476,6 +494,29 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+def host_devices():
+    """Devices the NumPy drop-in spreads the clips of one call over, inside ONE process (a thread, a context and a host pipeline per
+    device; ctypes releases the GIL during native calls).  ``LRA_DEVICES`` = comma-separated device indices, or ``all`` (default: every
+    visible device); ``LRA_DEVICES=0`` keeps everything on one device.  Under a one-process-per-GPU launcher (``LOCAL_RANK`` /
+    ``WORLD_SIZE`` / ``LIBROSA_AMD_DEVICE`` set) the process owns exactly its own device unless ``LRA_DEVICES`` says otherwise."""
+    n = device_count()
+    if n <= 0:
+        return [0]
+    spec = os.environ.get("LRA_DEVICES", "").strip().lower()
+    if spec in ("", "all"):
+        if "LOCAL_RANK" in os.environ or "LIBROSA_AMD_DEVICE" in os.environ or int(os.environ.get("WORLD_SIZE", "1") or 1) > 1:
+            return [get_context().device]
+        return list(range(n))
+    try:
+        devs = [int(t) for t in spec.split(",") if t.strip()]
+    except ValueError:
+        raise ParameterError(f"LRA_DEVICES={spec!r}: expected comma-separated device indices or 'all'")
+    bad = [d for d in devs if not 0 <= d < n]
+    if bad:
+        raise ParameterError(f"LRA_DEVICES names device(s) {bad}, but {n} device(s) are visible")
+    return devs or [0]
 
 
 def get_context(device=None):

@@ -12,7 +12,9 @@ Extensions beyond the reference (which only accepts ``np.ndarray``):
 """
 from __future__ import annotations
 
+import collections
 import functools
+import threading
 import warnings
 
 import numpy as np
@@ -118,12 +120,51 @@ def _padded_window(window, win_length, n_fft):
     return util.pad_center(np.asarray(filters.get_window(window, win_length, fftbins=True), dtype=np.float64), size=n_fft)
 
 
-@functools.lru_cache(maxsize=32)
+class _ByteBoundedLRU:
+    """Memo of host arrays bounded by entry count AND by bytes (a window sum-square envelope has one value per output sample: an
+    entry-count bound alone let 32 hour-long envelopes hold ~10 GB of RAM).  Arrays above a quarter of the budget are not kept."""
+
+    def __init__(self, max_entries, max_bytes):
+        self.max_entries, self.max_bytes = int(max_entries), int(max_bytes)
+        self._d = collections.OrderedDict()
+        self._lock = threading.Lock()
+
+    def get(self, key, build):
+        with self._lock:
+            hit = self._d.get(key)
+            if hit is not None:
+                self._d.move_to_end(key)
+                return hit
+        val = build()
+        if val.nbytes <= self.max_bytes // 4:
+            with self._lock:
+                self._d[key] = val
+                while len(self._d) > 1 and (len(self._d) > self.max_entries or sum(v.nbytes for v in self._d.values()) > self.max_bytes):
+                    self._d.popitem(last=False)
+        return val
+
+    def nbytes(self):
+        with self._lock:
+            return sum(v.nbytes for v in self._d.values())
+
+    def clear(self):
+        with self._lock:
+            self._d.clear()
+
+
+_WSS_CACHE = _ByteBoundedLRU(max_entries=8, max_bytes=128 << 20)
+
+
 def _istft_wss_cached(window, n_frames, win_length, n_fft, hop, center, expected, out_dtype, real):
-    wss = filters.window_sumsquare(window=window, n_frames=n_frames, win_length=win_length, n_fft=n_fft, hop_length=hop, dtype=np.dtype(out_dtype))
-    wss = np.ascontiguousarray(util.fix_length(wss[(n_fft // 2 if center else 0) :], size=expected), dtype=np.dtype(real))
-    wss.setflags(write=False)
-    return wss
+    def build():
+        wss = filters.window_sumsquare(window=window, n_frames=n_frames, win_length=win_length, n_fft=n_fft, hop_length=hop, dtype=np.dtype(out_dtype))
+        wss = np.ascontiguousarray(util.fix_length(wss[(n_fft // 2 if center else 0) :], size=expected), dtype=np.dtype(real))
+        wss.setflags(write=False)
+        return wss
+
+    key = (window, n_frames, win_length, n_fft, hop, center, expected, out_dtype, real)
+    hash(key)  # (an unhashable window specification raises TypeError here: the caller computes without the memo)
+    return _WSS_CACHE.get(key, build)
 
 
 def _istft_wss(window, n_frames, win_length, n_fft, hop, center, expected, out_dtype, real):
@@ -139,6 +180,59 @@ def _istft_wss(window, n_frames, win_length, n_fft, hop, center, expected, out_d
             pass
     wss = filters.window_sumsquare(window=window, n_frames=n_frames, win_length=win_length, n_fft=n_fft, hop_length=int(hop), dtype=out_dtype)
     return np.ascontiguousarray(util.fix_length(wss[(n_fft // 2 if center else 0) :], size=int(expected)), dtype=real), None
+
+
+# Clips are independent (the reference asserts batch == per item, tests/test_multichannel.py:96-111), so a NumPy batch splits into
+# contiguous clip ranges with nothing exchanged between them: one range per visible device, each through that device's own context and
+# native host pipeline, from its own thread.  Below this much host data per device the extra contexts are not worth waking up.
+_MULTI_DEVICE_MIN_BYTES = 8 << 20
+
+
+def _sharded_host_exec(sess, batch, nbytes, run):
+    """``run(ctx, b, e)`` pushes clips ``[b, e)`` through ``ctx``'s host pipeline (plans are looked up per context) and returns its
+    non-finite flag.  With one device -- or a small job -- this is ``run(sess.ctx, 0, batch)``.  With several (``_native.host_devices()``,
+    env ``LRA_DEVICES``) device i takes ``shard_range(batch, i, n)``: the calling thread serves the session's own device, one thread per
+    further device serves the rest; the first exception is re-raised after every thread has finished."""
+    from .. import _native
+    from ..distributed import shard_range
+
+    devs = _native.host_devices()
+    if len(devs) <= 1 or batch < 2 * len(devs) or nbytes < _MULTI_DEVICE_MIN_BYTES * len(devs):
+        return run(sess.ctx, 0, batch)
+    by_dev = collections.OrderedDict()
+    for i, d in enumerate(devs):
+        b, e = shard_range(batch, i, len(devs))
+        if e > b:
+            by_dev.setdefault(d, []).append((b, e))
+    flags, errors = [], []
+
+    def serve(ctx, ranges, lock):
+        try:
+            if lock:
+                ctx.call_lock.acquire()
+            try:
+                if lock:
+                    ctx.use_own_stream()
+                for b, e in ranges:
+                    flags.append(bool(run(ctx, b, e)))
+            finally:
+                if lock:
+                    ctx.call_lock.release()
+        except BaseException as exc:  # noqa: BLE001 - re-raised on the calling thread
+            errors.append(exc)
+
+    threads = []
+    mine = by_dev.pop(sess.ctx.device, [])
+    for d, ranges in by_dev.items():
+        th = threading.Thread(target=serve, args=(_native.get_context(d), ranges, True), name=f"lra-dev{d}", daemon=True)
+        th.start()
+        threads.append(th)
+    serve(sess.ctx, mine, False)  # (the session already holds this context's lock and selected its stream)
+    for th in threads:
+        th.join()
+    if errors:
+        raise errors[0]
+    return any(flags)
 
 
 def _finite_check_covers_input(n, n_fft, hop, center):
@@ -195,7 +289,7 @@ def _run_stft_family(kind, y, *, n_fft, hop_length, win_length, window, center, 
             # NumPy in, NumPy out: the native host pipeline (chunked, overlapped staging; include/librosa_amd.h)
             a = np.ascontiguousarray(y, dtype=real).reshape(-1, n)
             batch = a.shape[0]
-            mel_plan, target, stride = None, None, 0
+            target, stride = None, 0
             if kind == "stft":
                 cdt = np.dtype(util.dtype_r2c(real))
                 if out is not None:
@@ -207,9 +301,18 @@ def _run_stft_family(kind, y, *, n_fft, hop_length, win_length, window, center, 
                 host = np.empty((batch, n_frames, n_bins), dtype=real)
             else:
                 n_mels = int(mel_basis.shape[0])
-                mel_plan = ctx.mel_plan(np.ascontiguousarray(mel_basis, dtype=real))
+                basis = np.ascontiguousarray(mel_basis, dtype=real)
                 host = np.empty((batch, n_mels, n_frames), dtype=real)
-            flagged = ctx.stft_exec_host(plan, mel_plan, {"stft": 0, "power": 1, "mel": 2}[kind], a.ctypes.data, batch, n, n, power, host.ctypes.data, stride)
+            win = fft_window.astype(real)
+            item_out = stride * real.itemsize if stride else host[0].size * host.itemsize  # bytes between the results of consecutive clips (`stride` counts reals)
+
+            def run(c, b, e):
+                pl = plan if c is ctx else c.stft_plan(n_fft, hop, win, center, pad_mode, real)
+                mp = c.mel_plan(basis) if kind == "mel" else None
+                return c.stft_exec_host(pl, mp, {"stft": 0, "power": 1, "mel": 2}[kind], a.ctypes.data + b * n * a.itemsize, e - b, n, n, power,
+                                        host.ctypes.data + b * item_out, stride)
+
+            flagged = _sharded_host_exec(sess, batch, a.nbytes + host.nbytes, run)
             if flagged:  # util.valid_audio's scan (util/utils.py:305), done by the staging threads on the samples they copy
                 raise ParameterError("Audio buffer is not finite everywhere")
             if kind == "mel":
@@ -371,7 +474,15 @@ def istft(stft_matrix, *, hop_length=None, win_length=None, n_fft=None, window="
             if Dt.flags["C_CONTIGUOUS"] and Dt.dtype == cplx:
                 # NumPy in, NumPy out with the spectrum already frame-major (what stft returns): the native host pipeline
                 yh = out if (out is not None and out.dtype == real and out.flags["C_CONTIGUOUS"] and out.flags["WRITEABLE"]) else np.empty((batch, int(expected)), dtype=real)
-                ctx.istft_exec_host(plan, Dt.ctypes.data, batch, n_total, n_used, wss.ctypes.data, yh.ctypes.data, int(expected), int(expected))
+                win = ifft_window.astype(real)
+                d_item = n_total * n_bins * cplx.itemsize
+
+                def run(c, b, e):
+                    pl = plan if c is ctx else c.istft_plan(n_fft, int(hop_length), win, bool(center), real)
+                    c.istft_exec_host(pl, Dt.ctypes.data + b * d_item, e - b, n_total, n_used, wss.ctypes.data, yh.ctypes.data + b * int(expected) * real.itemsize, int(expected), int(expected))
+                    return False
+
+                _sharded_host_exec(sess, batch, Dt.nbytes + yh.nbytes, run)
                 if yh is out:
                     return out
                 y = _arrays.cast(yh.reshape(shape), out_dtype)
@@ -385,7 +496,7 @@ def istft(stft_matrix, *, hop_length=None, win_length=None, n_fft=None, window="
                 src_ptr = sess.input_raw(np.ascontiguousarray(D, dtype=cplx), cplx)
                 d_ptr = sess.scratch(batch * n_total * n_bins * cplx.itemsize)
                 _transpose_batched(ctx, src_ptr, d_ptr, batch, n_bins, n_total, cplx.itemsize)
-        wss_ptr = ctx.device_table(wss_key, lambda: wss) if (wss_key is not None and wss.nbytes <= (64 << 20)) else sess.input_raw(_as_like(sess, wss), real)
+        wss_ptr = ctx.device_table(wss_key, lambda: wss, pool="large") if (wss_key is not None and ctx.table_cacheable(wss.nbytes, "large")) else sess.input_raw(_as_like(sess, wss), real)
         y_ptr, handle = sess.output((batch, int(expected)), real)
         ctx.istft_exec(plan, d_ptr, batch, n_total * n_bins, n_bins, n_used, wss_ptr, y_ptr, int(expected), int(expected))
         y = sess.result(handle)
@@ -534,7 +645,7 @@ def griffinlim(S, *, n_iter=32, hop_length=None, win_length=None, n_fft=None, wi
         angles = sess.scratch(count * cplx.itemsize)
         rebuilt = sess.scratch(count * cplx.itemsize)
         tprev = sess.scratch(count * cplx.itemsize)
-        wss_ptr = ctx.device_table(wss_key, lambda: wss) if (wss_key is not None and wss.nbytes <= (64 << 20)) else sess.input_raw(_as_like(sess, wss), real)
+        wss_ptr = ctx.device_table(wss_key, lambda: wss, pool="large") if (wss_key is not None and ctx.table_cacheable(wss.nbytes, "large")) else sess.input_raw(_as_like(sess, wss), real)
         y_ptr, handle = sess.output((batch, expected), real)
         coef = momentum / (1 + momentum)
         check = ctx.stft_is_fused(splan) and _finite_check_covers_input(expected, n_fft, hop, center)
@@ -778,19 +889,20 @@ def _as_items(x, red_axes):
     return xp, batch, per_item, restore
 
 
-def _magnitude_and_dtype(S, name):
-    """abs() of complex input with the reference's warning; the real dtype the device computes in (f32 stays f32, everything else f64)."""
+def _magnitude_and_dtype(S, name, stacklevel=3):
+    """abs() of complex input with the reference's warning (attributed to the caller of the public function: ``stacklevel`` counts from
+    here); the real dtype the device computes in (f32 stays f32, everything else f64)."""
     if is_torch_tensor(S):
         if S.is_complex():
             warnings.warn(f"{name} was called on complex input so phase information will be discarded. To suppress this warning, "
-                          f"call {name}(np.abs(D){'**2' if name == 'power_to_db' else ''}) instead.", stacklevel=3)
+                          f"call {name}(np.abs(D){'**2' if name == 'power_to_db' else ''}) instead.", stacklevel=stacklevel)
             S = S.abs()
         real = np.dtype(np.float32) if _arrays.numpy_dtype_of(S) == np.float32 else np.dtype(np.float64)
         return S, real
     S = np.asarray(S)
     if np.issubdtype(S.dtype, np.complexfloating):
         warnings.warn(f"{name} was called on complex input so phase information will be discarded. To suppress this warning, "
-                      f"call {name}(np.abs(D){'**2' if name == 'power_to_db' else ''}) instead.", stacklevel=3)
+                      f"call {name}(np.abs(D){'**2' if name == 'power_to_db' else ''}) instead.", stacklevel=stacklevel)
         S = np.abs(S)
     real = np.dtype(np.float32) if S.dtype == np.float32 else np.dtype(np.float64)
     return S, real
@@ -856,6 +968,7 @@ def _to_db_array_ref(S, ref, amin, top_db, axes, amplitude, name):
     the scaling runs on the device with ``ref = 1``, the broadcast subtraction and the ``top_db`` floor on the result."""
     if top_db is not None and top_db < 0:
         raise ParameterError("top_db must be non-negative")
+    S, _ = _magnitude_and_dtype(S, name, stacklevel=4)  # the complex-input warning, once, attributed to the public function's caller
     base = _to_db(S, 1.0, amin, None, axes, amplitude, name)  # 10 log10(max(A, mag)) - 10 log10(max(A, 1))
     A = amin * amin if amplitude else amin
     red = _db_axes(base.ndim, axes)
@@ -881,7 +994,8 @@ def _to_db_array_ref(S, ref, amin, top_db, axes, amplitude, name):
         fits = False
     if not fits:
         raise ParameterError(f"ref of shape {np.shape(rv)} does not broadcast against the input of shape {out.shape}")
-    out += 10.0 * np.log10(max(A, 1.0))
+    if A > 1.0:  # (otherwise the device pass subtracted log10(1) = 0: nothing to put back, no extra rounding)
+        out += 10.0 * np.log10(A)
     out -= 10.0 * np.log10(np.maximum(A, rv))  # in place: the result keeps the input's precision, as the reference's `log_spec -= ...` does
     if top_db is not None:
         out = np.maximum(out, out.max(axis=red if out.ndim else None, keepdims=True) - top_db)

@@ -60,6 +60,14 @@ template <class T> LRA_HD cx<T> cmul_mi(cx<T> a) { return mk<T>(a.y, -a.x); }
 // halves with v_mov (28 % of the FFT phases' VALU instructions were such moves), so the asymmetric
 // forms are spelled out here.  The plain C++ bodies are the definition (used for double, for the host
 // pass and by the CPU simulator); the asm is the same arithmetic, IEEE-identical per lane.
+// The inline assembly below (v_pk_*_f32 with op_sel / neg modifiers, v_cndmask_b32_e64 under a 64-bit ballot, v_permlane32_swap_b32 with
+// hand-placed s_nop hazards) is gfx950 wave64 code and nothing else: a build for any other target must fail here, not miscompile.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "librosa_amd kernels are written for gfx950 (MI355X, CDNA4) only: build with --offload-arch=gfx950"
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && defined(__AMDGCN_WAVEFRONT_SIZE) && __AMDGCN_WAVEFRONT_SIZE != 64
+#error "librosa_amd kernels assume 64-wide wavefronts"
+#endif
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(LRA_NO_PK_ASM)
 #define LRA_PK_ASM 1
 namespace pk {

@@ -79,7 +79,10 @@ __device__ __forceinline__ long long hpss_reflect(long long i, long long n) {
 // compare-exchange as v_min / v_max (2 issue cycles each).  Spelled `a < b ? a : b` / `a < b ? b : a` it compiled to v_cmp + two
 // v_cndmask_b32_e32 back to back -- and on gfx950 a VOP2 select directly behind another stalls the SIMD's vector pipe ~16 cycles
 // (profiles/r03_experiments.md): 382 exchanges per element spent most of the kernel's time in that stall.  The windows hold
-// magnitudes (and +inf in unused slots): no NaN, no negative zero, so min / max select exactly the values the comparisons would.
+// magnitudes (and +inf in unused slots): no negative zero, so min / max select exactly the values the comparisons would -- FOR FINITE INPUT.
+// Non-finite input is outside the contract: v_min / v_max return the other operand for a NaN, so a NaN bin is skipped by the medians
+// around it (scipy's median_filter would carry it through); the NumPy entry point rejects such input (decompose.py), a device tensor is
+// the caller's responsibility like the non-negativity of a real S.
 __device__ __forceinline__ float hpss_min(float a, float b) { return __builtin_fminf(a, b); }
 __device__ __forceinline__ float hpss_max(float a, float b) { return __builtin_fmaxf(a, b); }
 __device__ __forceinline__ double hpss_min(double a, double b) { return __builtin_fmin(a, b); }

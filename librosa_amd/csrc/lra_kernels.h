@@ -439,8 +439,8 @@ template <class Cfg> LRA_HD void stft_direct_pass0(const StftArgs<typename Cfg::
     using C = typename Cfg::cplx;
     constexpr int lr = Cfg::logr(0), r = 1 << lr, nb = Cfg::R >> lr, sin = Cfg::M >> lr;
     const C* __restrict__ win2 = reinterpret_cast<const C*>(a.win);
-    // (a frame beyond n_frames is transformed like any other -- finite stale samples, nothing of it is stored: no zeroing selects,
-    // which hipcc emits as back-to-back VOP2 v_cndmask pairs; see sel_mask in lra_common.h)
+    // (a frame beyond n_frames is transformed like any other -- stale or zero samples (the prologue zero-fills rg.nxt), nothing of it is
+    // stored: no zeroing selects, which hipcc emits as back-to-back VOP2 v_cndmask pairs; see sel_mask in lra_common.h)
     LRA_UNROLL
     for (int i = 0; i < nb; ++i) {
         LRA_UNROLL
@@ -1174,6 +1174,12 @@ template <class Cfg, int MODE, int PM = POW_TWO, int RAM = 0> LRA_HD void stft_b
     } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC && MODE != OUT_MEL2 && MODE != OUT_MELR)  // the shared tables need a workgroup barrier, once
     LRA_PHASE(Cfg::NT, tid) {
         const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
+        if (RHD > 1 || DIRECT) {
+            // prefetch registers of a slot whose frames lie past the clip are never loaded (the fetches return early): defined zeros, once,
+            // outside the frame loop -- such frames are transformed like any other and nothing of them is stored
+            LRA_UNROLL
+            for (int e = 0; e < Cfg::R; ++e) LRA_R(rg).nxt[e] = mk<typename Cfg::real>((typename Cfg::real)0, (typename Cfg::real)0);
+        }
         if (RHD > 1) {
             regring_fill<Cfg, RHD>(a, clip, f_first + slot * iters, tf, LRA_R(rg));
         } else if (DIRECT) {
@@ -1306,7 +1312,7 @@ template <class T> struct IstftArgs {
     const cx<T>* twr;
     const T* wss;               // [out_len] window sum-square already sliced/fixed to the output
     T tiny;
-    T* y;                       // [batch][out_len], pre-zeroed by the host wrapper
+    T* y;                       // [batch][out_len]; the kernel writes every sample below istft_written_end(), the host wrapper zeroes the rest
     long long y_stride;
     long long out_len;
     long long batch;
@@ -1316,6 +1322,16 @@ template <class T> struct IstftArgs {
     int drain_steps;            // extra steps the last strip of a clip runs to flush the carry
     int n_blocks, xcd_chunk;    // launch geometry, see xcd_block
 };
+
+// First output sample of a clip that NO step of the fused kernel stores: the strips of a clip walk frames 0 .. n_used - 1 and the last
+// strip runs drain_steps more, each step finalising one hop block of padded positions [t hop, (t + 1) hop) -- gaps between frames
+// (hop > n_fft) included, they leave as the zero carry -- so samples [0, min(out_len, end)) are all written and the host wrapper
+// only zeroes [end, out_len): the part of `length` beyond the frames' reach (core/spectrum.py:553-555, 606-624), normally nothing.
+LRA_HD long long istft_written_end(int n_fft, int hop, long long n_used, int drop) {
+    const long long drain = n_fft > hop ? (n_fft - hop + hop - 1) / hop : 0;
+    const long long end = (n_used + drain) * (long long)hop - drop;
+    return end < 0 ? 0 : end;
+}
 
 // per slot: frame area + double-buffered carry of N reals (>= N - hop for any hop >= 1)
 // HC > 0 (row-aligned): one in-place carry of the R - HC rows that outlive a frame, (R - HC) TF sample pairs

@@ -171,7 +171,7 @@ template <class Cfg, int HD> LRA_HD void v2_shift(Regs2<Cfg, HD>& rg) {
 template <class Cfg, int HD> LRA_HD void v2_pass0(bool live, int tf, Regs2<Cfg, HD>& rg, Lds fr) {
     using T = typename Cfg::real;
     constexpr int r0 = Regs2<Cfg, HD>::r0, nb0 = Regs2<Cfg, HD>::nb0;
-    // (a frame beyond n_frames is transformed like any other -- its ring holds finite stale samples and nothing of it is stored;
+    // (a frame beyond n_frames is transformed like any other -- its ring holds stale samples or the prologue's zeros and nothing of it is stored;
     // zeroing it under `live` cost 12 selects per frame, ten of them back to back: see sel_mask in lra_common.h)
     (void)live;
     LRA_UNROLL
@@ -406,6 +406,9 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
         const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
         v2_hoist<Cfg, HD>(LRA_R(rg), tf, a.win, a.tw, a.twr);
         v2_fill<Cfg, HD>(a, clip, f_first + slot * iters, tf, LRA_R(rg));
+        // (v2_issue_loads returns early for frames past the clip: the prefetch registers then keep these zeros or an earlier frame's samples)
+        LRA_UNROLL
+        for (int e = 0; e < RG::NEW; ++e) LRA_R(rg).pf[e] = mk<typename Cfg::real>((typename Cfg::real)0, (typename Cfg::real)0);
         if (MODE == OUT_MELR) {
             melr_tables_to_lds<Cfg>(a, tid, lds_sub(lds, a.shared_off));
             melr_hoist<Cfg>(a, tf, LRA_R(rg), slot * SB);  // (addresses relative to the workgroup's LDS, not to the slot)

@@ -23,7 +23,9 @@ def hpss(S, *, kernel_size=31, power=2.0, mask=False, margin=1.0):
     are exactly the ones ``scipy.ndimage.median_filter`` selects), the two soft masks and the masked spectrogram with the input's
     phase.  ``S`` is ``(..., n_bins, n_frames)``, complex or non-negative real, a NumPy array or a device tensor (device tensors are
     returned for device input; the output of ``librosa_amd.stft`` is consumed and produced without a transpose).  Integer input is
-    taken as float32.  For device tensors the non-negativity of a real ``S`` is the caller's responsibility.
+    taken as float32.  For device tensors the non-negativity of a real ``S`` is the caller's responsibility, and so is its finiteness:
+    the selection network works on ``min`` / ``max``, which skip a NaN operand where scipy's filter would carry it through, so a NumPy
+    ``S`` with non-finite entries is rejected here (``ParameterError``) instead of being separated into finite, wrong medians.
     """
     win_harm, win_perc = _pair(kernel_size)
     margin_harm, margin_perc = _pair(margin)
@@ -41,6 +43,8 @@ def hpss(S, *, kernel_size=31, power=2.0, mask=False, margin=1.0):
         raise ParameterError(f"S must have at least 2 dimensions, given shape={tuple(S.shape)}")
     in_dtype = _arrays.numpy_dtype_of(S)
     is_complex = in_dtype.kind == "c"
+    if not on_device and in_dtype.kind in "fc" and not np.isfinite(S).all():
+        raise ParameterError("S is not finite everywhere")   # (see the docstring: the device medians would skip NaN entries)
     if is_complex:
         cplx = np.dtype(in_dtype)
         real = np.dtype(np.float64) if cplx == np.complex128 else np.dtype(np.float32)

@@ -13,10 +13,11 @@ patches the *environment*:
   memory only, the PEP 695 ``type X = ...`` aliases and ``def f[T](...)`` generics that Python
   3.10 cannot parse (all affected runtime modules use ``from __future__ import annotations``).
 
-It is only usable where ``/root/reference`` exists (the build container).  It does not exist on
-the GPU box, so nothing in ``-m gpu`` tests, ``smoke()`` or ``bench.py`` imports this; they use
-the committed fixtures under ``tests/golden/`` (made by ``oracle/make_golden.py``) and the NumPy
-restatement in ``oracle/stft_oracle.py``.
+``/root/reference`` exists only in the build container.  On the GPU box the same files are available as the
+archive ``oracle/_ref/librosa_ref.zip`` (a git-ignored build product of ``oracle/make_ref.py``), which this module
+unpacks into a temporary directory; only ``bench.py``'s ``cpu_baseline`` leg uses that (the reference itself timed on
+the GPU box's host cores).  The ``-m gpu`` tests and ``smoke()`` use the committed fixtures under ``tests/golden/``
+(made by ``oracle/make_golden.py``) and the NumPy restatement in ``oracle/stft_oracle.py``.
 """
 from __future__ import annotations
 
@@ -32,7 +33,29 @@ import sys
 import tempfile
 import types
 
-REFERENCE_ROOT = os.environ.get("LIBROSA_REFERENCE_ROOT", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+PACKED = os.path.join(HERE, "_ref", "librosa_ref.zip")  # built by oracle/make_ref.py where /root/reference exists; travels to the GPU box
+
+
+def _reference_root():
+    """LIBROSA_REFERENCE_ROOT, else /root/reference, else the packed copy of the same files unpacked into a temporary directory."""
+    env = os.environ.get("LIBROSA_REFERENCE_ROOT")
+    if env:
+        return env
+    if os.path.isfile("/root/reference/librosa/__init__.py") or not os.path.isfile(PACKED):
+        return "/root/reference"
+    import atexit
+    import shutil
+    import zipfile
+
+    d = tempfile.mkdtemp(prefix="lra_ref_")
+    atexit.register(shutil.rmtree, d, ignore_errors=True)
+    with zipfile.ZipFile(PACKED) as z:
+        z.extractall(d)
+    return d
+
+
+REFERENCE_ROOT = _reference_root()
 
 
 def available() -> bool:

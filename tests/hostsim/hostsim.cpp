@@ -244,5 +244,6 @@ int hostsim_istft_f64(int n_fft, const double* D, long long batch, int n_frames_
     return run_istft<double>(n_fft, D, batch, n_frames_total, n_used, hop, center, win_scaled, wss, tiny, y, out_len, strip_groups, variant, diag);
 }
 long long hostsim_pad_index(long long g, long long n, int mode) { return pad_index(g, n, mode); }
+long long hostsim_istft_written_end(int n_fft, int hop, long long n_used, int drop) { return istft_written_end(n_fft, hop, n_used, drop); }
 #endif
 }

@@ -124,7 +124,12 @@ def istft(D, n_fft, hop, win, wss, out_len, n_used, center=True, strip_groups=4,
     assert bins == n_fft // 2 + 1
     ws = np.ascontiguousarray(np.asarray(win, dtype=np.float64) / n_fft, dtype=rt)
     wss = np.ascontiguousarray(wss, dtype=rt)
-    y = np.zeros((batch, out_len), dtype=rt)
+    # the buffer arrives full of NaN and only what the host wrapper clears (lra_api.hip, istft_run: samples from istft_written_end() on)
+    # is zeroed: every other sample must be stored by the kernel body itself
+    y = np.full((batch, out_len), np.nan, dtype=rt)
+    lib().hostsim_istft_written_end.restype = ctypes.c_longlong
+    end = lib().hostsim_istft_written_end(ctypes.c_int(n_fft), ctypes.c_int(hop), ctypes.c_longlong(n_used), ctypes.c_int(n_fft // 2 if center else 0))
+    y[:, min(int(end), out_len):] = 0
     diag = np.zeros(12, np.int64)
     fn = lib().hostsim_istft_f64 if f64 else lib().hostsim_istft_f32
     rc = fn(ctypes.c_int(n_fft), _p(D), ctypes.c_longlong(batch), ctypes.c_int(T), ctypes.c_int(n_used), ctypes.c_int(hop), ctypes.c_int(int(center)),

@@ -256,3 +256,119 @@ def test_cqt_and_pcen_argument_errors_before_any_device_work():
         L.pcen(np.arange(100), max_size=3)          # :2510-2513
     with pytest.raises(L.ParameterError):
         L.pcen(np.ones((3, 4, 5)), max_size=3)      # 3-d input needs max_axis (:2502-2507 passes it)
+
+
+# ---- in-process multi-device sharding of a NumPy batch (core/spectrum.py::_sharded_host_exec) and its bounded memos -----------------
+class _FakeCtx:
+    def __init__(self, device):
+        import threading
+
+        self.device = device
+        self.call_lock = threading.RLock()
+        self.streams = 0
+
+    def use_own_stream(self):
+        self.streams += 1
+
+
+class _FakeSess:
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+
+def _fake_devices(monkeypatch, devs):
+    from librosa_amd import _native
+
+    ctxs = {d: _FakeCtx(d) for d in set(devs) | {0}}
+    monkeypatch.setattr(_native, "host_devices", lambda: list(devs))
+    monkeypatch.setattr(_native, "get_context", lambda device=None: ctxs[0 if device is None else device])
+    return ctxs
+
+
+@pytest.mark.parametrize("devs,batch", [([0, 1, 2, 3, 4, 5, 6, 7], 4096), ([0, 1, 2], 10), ([0, 0], 7), ([3, 1], 5), ([0], 9)])
+def test_numpy_batches_shard_over_devices_without_gaps_or_overlap(monkeypatch, devs, batch):
+    """Every clip is served exactly once, by the context of the device its range belongs to (clip i of B on device i * n // B up to the
+    balanced remainder: distributed.shard_range), the session's own device on the calling thread, the others on their own threads under
+    their contexts' locks.  Reference property kept: batch == per item (tests/test_multichannel.py:96-111)."""
+    import threading
+
+    ctxs = _fake_devices(monkeypatch, devs)
+    served = np.zeros(batch, np.int32)
+    by_dev = {}
+    who = {}
+
+    def run(ctx, b, e):
+        served[b:e] += 1
+        by_dev.setdefault(ctx.device, []).append((b, e))
+        who[ctx.device] = threading.current_thread().name
+        return b == 0  # (one shard reports a non-finite sample)
+
+    flagged = spectrum._sharded_host_exec(_FakeSess(ctxs[0]), batch, 1 << 40, run)
+    assert np.array_equal(served, np.ones(batch, np.int32))
+    assert flagged is True
+    if len(devs) > 1:
+        assert sorted(by_dev) == sorted(set(devs))
+        sizes = sorted(e - b for r in by_dev.values() for b, e in r)
+        assert sizes[-1] - sizes[0] <= 1 and len(sizes) == len(devs)
+        for d in set(devs) - {0}:
+            assert who[d] == f"lra-dev{d}" and ctxs[d].streams == 1   # its own thread, its own stream, under its lock
+        if 0 in devs:
+            assert who[0] == threading.current_thread().name and ctxs[0].streams == 0
+    else:
+        assert by_dev == {0: [(0, batch)]}
+
+
+def test_small_jobs_stay_on_one_device_and_errors_surface(monkeypatch):
+    ctxs = _fake_devices(monkeypatch, [0, 1])
+    calls = []
+    spectrum._sharded_host_exec(_FakeSess(ctxs[0]), 64, 1 << 20, lambda c, b, e: calls.append((c.device, b, e)))   # 1 MB: not worth a second context
+    spectrum._sharded_host_exec(_FakeSess(ctxs[0]), 3, 1 << 40, lambda c, b, e: calls.append((c.device, b, e)))    # fewer than two clips per device
+    assert calls == [(0, 0, 64), (0, 0, 3)]
+
+    def boom(c, b, e):
+        if c.device == 1:
+            raise L.ParameterError("Audio buffer is not finite everywhere")
+        return False
+
+    with pytest.raises(L.ParameterError):
+        spectrum._sharded_host_exec(_FakeSess(ctxs[0]), 64, 1 << 40, boom)
+    assert ctxs[1].call_lock.acquire(blocking=False)  # released on the error path
+
+
+def test_host_devices_env(monkeypatch):
+    from librosa_amd import _native
+
+    monkeypatch.setattr(_native, "device_count", lambda: 4)
+    for k in ("LOCAL_RANK", "WORLD_SIZE", "LIBROSA_AMD_DEVICE", "LRA_DEVICES"):
+        monkeypatch.delenv(k, raising=False)
+    assert _native.host_devices() == [0, 1, 2, 3]
+    monkeypatch.setenv("LRA_DEVICES", "0")
+    assert _native.host_devices() == [0]
+    monkeypatch.setenv("LRA_DEVICES", "2, 3")
+    assert _native.host_devices() == [2, 3]
+    monkeypatch.setenv("LRA_DEVICES", "7")
+    with pytest.raises(L.ParameterError):
+        _native.host_devices()
+    monkeypatch.setenv("LRA_DEVICES", "all")
+    assert _native.host_devices() == [0, 1, 2, 3]
+
+
+def test_window_sumsquare_memo_is_bounded_by_bytes():
+    """every distinct (n_frames, length) is a new envelope of one value per output sample; the memo holds at most 8 of them and
+    at most 128 MB, and never an array above a quarter of that."""
+    lru = spectrum._ByteBoundedLRU(max_entries=3, max_bytes=4000)
+    made = []
+
+    def build(n):
+        made.append(n)
+        return np.zeros(n, np.float32)
+
+    for n in (100, 200, 100, 150, 120):      # 400 + 800 + 600 + 480 bytes, three entries at most
+        lru.get(n, lambda n=n: build(n))
+    assert made == [100, 200, 150, 120] and lru.nbytes() <= 4000 and len(lru._d) == 3
+    big = lru.get("big", lambda: np.zeros(2000, np.float32))   # 8 000 bytes > budget / 4: returned, not kept
+    assert big.nbytes == 8000 and "big" not in lru._d
+    for n in range(300, 320):
+        lru.get(n, lambda n=n: build(n))
+    assert lru.nbytes() <= 4000 and len(lru._d) <= 3
+    assert spectrum._WSS_CACHE.max_entries == 8 and spectrum._WSS_CACHE.max_bytes == 128 << 20
