@@ -414,7 +414,9 @@ def main():
         iplan = ctx.istft_plan(N_FFT, HOP, window, True, np.float32)
         wss_host = filters.window_sumsquare(window="hann", n_frames=n_frames, n_fft=N_FFT, hop_length=HOP, dtype=np.float32)[N_FFT // 2 :]
         wss_host = np.ascontiguousarray(np.pad(wss_host, (0, max(0, n - len(wss_host))))[:n], dtype=np.float32)
-        wss = torch.from_numpy(wss_host).to(device)
+        from librosa_amd.core.spectrum import wss_to_norm
+
+        wss = torch.from_numpy(wss_to_norm(wss_host)).to(device)  # the factor form the public istft hands to the kernels (1 / wss where wss > tiny)
         yrec = torch.empty((batch, n), dtype=torch.float32, device=device)
 
         def roof(fn, bytes_per_frame, kernel, read_bytes):
@@ -429,11 +431,11 @@ def main():
                     "call_ms": s * 1e3, "launches_per_call": 1}
 
         step_stft = lambda: ctx.stft_exec(plan, yp, batch, n, n, Dp)
-        step_istft = lambda: ctx.istft_exec(iplan, Dp, batch, n_frames * n_bins, n_bins, n_frames, wss.data_ptr(), yrec.data_ptr(), n, n)
+        step_istft = lambda: ctx.istft_exec_norm(iplan, Dp, batch, n_frames * n_bins, n_bins, n_frames, wss.data_ptr(), yrec.data_ptr(), n, n)
         measure("roofline_stft", lambda: roof(step_stft, BYTES_PER_FRAME_STFT, "stft2_kernel<n_fft=2048, OUT_COMPLEX> (librosa.stft, complex64 out)", HOP * 4))
         measure("roofline_istft", lambda: roof(step_istft, BYTES_PER_FRAME_STFT, "istft_kernel<n_fft=2048> (librosa.istft: c2r FFT + window + overlap-add + wss normalise)", n_bins * 8))
         if "roofline_istft" in side and "error" not in side["roofline_istft"]:
-            side["roofline_istft"]["call_note"] = ("lra_istft_exec = ONE launch since round 4: the kernel stores every sample it covers and the wrapper zeroes only what no frame reaches "
+            side["roofline_istft"]["call_note"] = ("lra_istft_exec_norm (what librosa_amd.istft calls) = ONE launch since round 4: the kernel stores every sample it covers and the wrapper zeroes only what no frame reaches "
                                                    "(nothing here); round 3's call carried an 85 us hipMemsetAsync of the whole output (677 MB)")
 
         def stream_ceiling():

@@ -155,6 +155,13 @@ void lra_istft_plan_destroy(lra_istft_plan* plan);
 int lra_istft_exec(lra_istft_plan* plan, const void* D, int64_t batch, int64_t d_batch_stride, int64_t d_frame_stride, int64_t n_used,
                    const void* wss, void* y, int64_t out_len, int64_t y_stride);
 
+/* The same transform with the normalisation handed over as FACTORS: norm[s] = 1 / wss[s] where wss[s] > tiny, else 1 (device, [out_len]) --
+ * the form the fused kernels consume (y = ola * norm: core/spectrum.py:622-624 as a multiplication, within 1 ulp of the division).  A caller
+ * that keeps the envelope of a (window, hop, length) combination around (the Python shim memoises it per context) builds the factors once;
+ * lra_istft_exec derives them from `wss` with one small launch per call. */
+int lra_istft_exec_norm(lra_istft_plan* plan, const void* D, int64_t batch, int64_t d_batch_stride, int64_t d_frame_stride, int64_t n_used,
+                        const void* norm, void* y, int64_t out_len, int64_t y_stride);
+
 /* Host-buffer form (librosa.istft on np.ndarrays): D_host [batch][n_frames][n_bins] complex, packed, pageable; wss_host
  * [out_len] reals; y_host [batch] rows of out_len reals, y_stride apart.  Same staged, overlapped transfer as
  * lra_stft_exec_host. */

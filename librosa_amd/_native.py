@@ -67,6 +67,7 @@ SIGNATURES = {
     "lra_istft_plan_create": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, POINTER(c_void_p)]),
     "lra_istft_plan_destroy": (None, [c_void_p]),
     "lra_istft_exec": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64]),
+    "lra_istft_exec_norm": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64]),
     "lra_transpose": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int]),
     "lra_probe_stream": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int64, c_int, c_int]),
     "lra_item_absmax_exec": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
@@ -389,6 +390,10 @@ class Context:
 
     def mel_apply_exec(self, mel_plan, s_ptr, batch, n_frames, batch_stride, bin_stride, frame_stride, out_ptr):
         _check(self.lib.lra_mel_apply_exec(mel_plan, c_void_p(s_ptr), batch, n_frames, batch_stride, bin_stride, frame_stride, c_void_p(out_ptr)))
+
+    def istft_exec_norm(self, plan, d_ptr, batch, d_batch_stride, d_frame_stride, n_used, norm_ptr, y_ptr, out_len, y_stride):
+        """``istft_exec`` with the normalisation given as factors (``1 / wss`` where ``wss > tiny``, else 1; ``spectrum.wss_to_norm``)."""
+        _check(self.lib.lra_istft_exec_norm(plan, c_void_p(d_ptr), batch, d_batch_stride, d_frame_stride, n_used, c_void_p(norm_ptr), c_void_p(y_ptr), out_len, y_stride))
 
     def istft_exec(self, plan, d_ptr, batch, d_batch_stride, d_frame_stride, n_used, wss_ptr, y_ptr, out_len, y_stride):
         _check(self.lib.lra_istft_exec(plan, c_void_p(d_ptr), batch, d_batch_stride, d_frame_stride, n_used, c_void_p(wss_ptr), c_void_p(y_ptr), out_len, y_stride))

@@ -235,6 +235,24 @@ def _sharded_host_exec(sess, batch, nbytes, run):
     return any(flags)
 
 
+def wss_to_norm(wss):
+    """Window sum-square envelope -> the factors the inverse kernels multiply by: ``1 / wss`` where ``wss > tiny(wss)``, else 1 -- the
+    reference's ``y[approx_nonzero_indices] /= ifft_window_sum[approx_nonzero_indices]`` (``core/spectrum.py:622-624``) as a product, in the
+    envelope's own precision (each factor correctly rounded; the product is within 1 ulp of the division)."""
+    wss = np.asarray(wss)
+    one = wss.dtype.type(1)
+    with np.errstate(divide="ignore", over="ignore"):
+        return np.where(wss > util.tiny(wss), one / wss, one).astype(wss.dtype, copy=False)
+
+
+def _device_norm(sess, wss, wss_key, real):
+    """Device pointer of the normalisation factors of ``wss`` (memoised per context under the envelope's key, in the byte-bounded pool)."""
+    ctx = sess.ctx
+    if wss_key is not None and ctx.table_cacheable(wss.nbytes, "large"):
+        return ctx.device_table(("norm",) + tuple(wss_key), lambda: wss_to_norm(wss), pool="large")
+    return sess.input_raw(_as_like(sess, wss_to_norm(wss)), real)
+
+
 def _finite_check_covers_input(n, n_fft, hop, center):
     """True when every input sample lies in some frame, so the kernels' DC-bin flag sees it."""
     if hop > n_fft:
@@ -496,9 +514,9 @@ def istft(stft_matrix, *, hop_length=None, win_length=None, n_fft=None, window="
                 src_ptr = sess.input_raw(np.ascontiguousarray(D, dtype=cplx), cplx)
                 d_ptr = sess.scratch(batch * n_total * n_bins * cplx.itemsize)
                 _transpose_batched(ctx, src_ptr, d_ptr, batch, n_bins, n_total, cplx.itemsize)
-        wss_ptr = ctx.device_table(wss_key, lambda: wss, pool="large") if (wss_key is not None and ctx.table_cacheable(wss.nbytes, "large")) else sess.input_raw(_as_like(sess, wss), real)
+        norm_ptr = _device_norm(sess, wss, wss_key, real)
         y_ptr, handle = sess.output((batch, int(expected)), real)
-        ctx.istft_exec(plan, d_ptr, batch, n_total * n_bins, n_bins, n_used, wss_ptr, y_ptr, int(expected), int(expected))
+        ctx.istft_exec_norm(plan, d_ptr, batch, n_total * n_bins, n_bins, n_used, norm_ptr, y_ptr, int(expected), int(expected))
         y = sess.result(handle)
     finally:
         sess.close()
@@ -645,7 +663,7 @@ def griffinlim(S, *, n_iter=32, hop_length=None, win_length=None, n_fft=None, wi
         angles = sess.scratch(count * cplx.itemsize)
         rebuilt = sess.scratch(count * cplx.itemsize)
         tprev = sess.scratch(count * cplx.itemsize)
-        wss_ptr = ctx.device_table(wss_key, lambda: wss, pool="large") if (wss_key is not None and ctx.table_cacheable(wss.nbytes, "large")) else sess.input_raw(_as_like(sess, wss), real)
+        norm_ptr = _device_norm(sess, wss, wss_key, real)
         y_ptr, handle = sess.output((batch, expected), real)
         coef = momentum / (1 + momentum)
         check = ctx.stft_is_fused(splan) and _finite_check_covers_input(expected, n_fft, hop, center)
@@ -662,12 +680,12 @@ def griffinlim(S, *, n_iter=32, hop_length=None, win_length=None, n_fft=None, wi
         ctx.griffinlim_init(u_t, s_ptr, angles, count, real)
         have_prev = False
         for _ in range(int(n_iter)):
-            ctx.istft_exec(iplan, angles, batch, n_total * n_bins, n_bins, n_used, wss_ptr, y_ptr, expected, expected)   # :2850
+            ctx.istft_exec_norm(iplan, angles, batch, n_total * n_bins, n_bins, n_used, norm_ptr, y_ptr, expected, expected)   # :2850
             ctx.stft_exec(splan, y_ptr, batch, expected, expected, rebuilt)                                                # :2863
             ctx.griffinlim_update(rebuilt, tprev if have_prev else None, s_ptr, angles, count, real, coef, eps)            # :2875-2880
             rebuilt, tprev = tprev, rebuilt                                                                                # :2882
             have_prev = True
-        ctx.istft_exec(iplan, angles, batch, n_total * n_bins, n_bins, n_used, wss_ptr, y_ptr, expected, expected)       # :2885
+        ctx.istft_exec_norm(iplan, angles, batch, n_total * n_bins, n_bins, n_used, norm_ptr, y_ptr, expected, expected)       # :2885
         if check and ctx.nonfinite_read():
             raise ParameterError("Audio buffer is not finite everywhere")
         y = sess.result(handle)

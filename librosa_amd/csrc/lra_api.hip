@@ -268,6 +268,7 @@ struct lra_istft_plan {
     void* d_twr = nullptr;
     FftPlanCache fft;
     Scratch spec, frames;
+    Scratch norm;  // lra_istft_exec: 1 / wss of the call's envelope (the kernels multiply; see istft_run)
 };
 
 namespace {
@@ -659,8 +660,17 @@ __global__ void spec_pack_kernel(const cx<T>* __restrict__ D, long long d_batch_
 }
 
 // gather overlap-add: y[clip][s] = sum_t ws[s' - tH] * x[f(clip,t)][s' - tH] (increasing t), / wss
+// window sum-square envelope -> per-sample normalisation factor: 1 / wss where wss > tiny, else 1 (core/spectrum.py:622-624 as a product)
+template <class T> __global__ void wss_to_norm_kernel(const T* __restrict__ wss, T tinyv, T* __restrict__ nrm, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const T w = wss[i];
+        nrm[i] = w > tinyv ? (T)1 / w : (T)1;
+    }
+}
+
 template <class T>
-__global__ void ola_gather_kernel(const T* __restrict__ x, int N, int hop, int n_used, int drop, const T* __restrict__ ws, const T* __restrict__ wss,
+__global__ void ola_gather_kernel(const T* __restrict__ x, int N, int hop, int n_used, int drop, const T* __restrict__ ws, const T* __restrict__ wss, int wss_is_norm,
                                   T tinyv, long long clip0, long long clips, T* __restrict__ y, long long y_stride, long long out_len) {
     const long long chunks = (out_len + 255) / 256;
     const long long c = blockIdx.x / chunks;
@@ -677,7 +687,7 @@ __global__ void ola_gather_kernel(const T* __restrict__ x, int N, int hop, int n
         acc += ws[off] * x[(c * n_used + t) * N + off];
     }
     const T w = wss[s];
-    y[(clip0 + c) * y_stride + s] = (w > tinyv) ? acc / w : acc;
+    y[(clip0 + c) * y_stride + s] = wss_is_norm ? acc * w : ((w > tinyv) ? acc / w : acc);
 }
 
 template <class E> __global__ void transpose_kernel(const E* __restrict__ src, E* __restrict__ dst, long long rows, long long cols) {
@@ -933,7 +943,9 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
 }
 
 template <class T>
-int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_stride, int64_t d_frame_stride, int64_t n_used, const void* wss, void* y,
+// `wss`: the window sum-square envelope of the output samples (wss_is_norm == 0, lra_istft_exec) or the normalisation factors made of it
+// (1 / wss where wss > tiny, else 1: lra_istft_exec_norm, what the fused kernels consume).
+int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_stride, int64_t d_frame_stride, int64_t n_used, const void* wss, int wss_is_norm, void* y,
               int64_t out_len, int64_t y_stride) {
     LRA_BIND(p->ctx);
     lra_ctx* ctx = p->ctx;
@@ -959,6 +971,13 @@ int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_s
     if (d_frame_stride < bins) return fail(LRA_EINVAL, "d_frame_stride smaller than n_bins");
     const T tinyv = sizeof(T) == 8 ? (T)2.2250738585072014e-308 : (T)1.17549435e-38f;
     if (p->pow2) {
+        const void* nrm = wss;
+        if (!wss_is_norm) {  // one tiny launch per call (out_len values); callers that keep the envelope around pass the factors themselves
+            LRA_TRY(p->norm.ensure((size_t)out_len * sizeof(T)));
+            hipLaunchKernelGGL(wss_to_norm_kernel<T>, dim3((unsigned)((out_len + 255) / 256)), dim3(256), 0, ctx->stream, (const T*)wss, tinyv, (T*)p->norm.p, (long long)out_len);
+            LRA_HIP(hipGetLastError());
+            nrm = p->norm.p;
+        }
         IstftLaunch<T> L;
         L.a = IstftArgs<T>();
         L.a.D = (const cx<T>*)D;
@@ -969,7 +988,7 @@ int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_s
         L.a.drop = p->center ? N / 2 : 0;
         L.a.win_scaled = (const T*)p->d_win_scaled;
         L.a.twr = (const cx<T>*)p->d_twr;
-        L.a.wss = (const T*)wss;
+        L.a.wss = (const T*)nrm;
         L.a.tiny = tinyv;
         L.a.y = (T*)y;
         L.a.y_stride = y_stride;
@@ -1019,7 +1038,7 @@ int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_s
                                    (char*)p->frames.p, (size_t)N * sizeof(T)));
         const long long ochunks = (out_len + 255) / 256;
         hipLaunchKernelGGL(ola_gather_kernel<T>, dim3((unsigned)(clips * ochunks)), dim3(256), 0, ctx->stream, (const T*)p->frames.p, N, p->hop, (int)n_used,
-                           p->center ? N / 2 : 0, (const T*)p->d_win_scaled, (const T*)wss, tinyv, c0, clips, (T*)y, (long long)y_stride, (long long)out_len);
+                           p->center ? N / 2 : 0, (const T*)p->d_win_scaled, (const T*)wss, wss_is_norm, tinyv, c0, clips, (T*)y, (long long)y_stride, (long long)out_len);
         LRA_HIP(hipGetLastError());
     }
     return scratch_release(p->fft, ctx->stream);
@@ -1823,8 +1842,15 @@ void lra_istft_plan_destroy(lra_istft_plan* p) {
 int lra_istft_exec(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_stride, int64_t d_frame_stride, int64_t n_used, const void* wss,
                    void* y, int64_t out_len, int64_t y_stride) {
     if (!p) return fail(LRA_EINVAL, "null plan");
-    return p->dtype == LRA_F64 ? istft_run<double>(p, D, batch, d_batch_stride, d_frame_stride, n_used, wss, y, out_len, y_stride)
-                               : istft_run<float>(p, D, batch, d_batch_stride, d_frame_stride, n_used, wss, y, out_len, y_stride);
+    return p->dtype == LRA_F64 ? istft_run<double>(p, D, batch, d_batch_stride, d_frame_stride, n_used, wss, 0, y, out_len, y_stride)
+                               : istft_run<float>(p, D, batch, d_batch_stride, d_frame_stride, n_used, wss, 0, y, out_len, y_stride);
+}
+
+int lra_istft_exec_norm(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_stride, int64_t d_frame_stride, int64_t n_used, const void* norm,
+                   void* y, int64_t out_len, int64_t y_stride) {
+    if (!p) return fail(LRA_EINVAL, "null plan");
+    return p->dtype == LRA_F64 ? istft_run<double>(p, D, batch, d_batch_stride, d_frame_stride, n_used, norm, 1, y, out_len, y_stride)
+                               : istft_run<float>(p, D, batch, d_batch_stride, d_frame_stride, n_used, norm, 1, y, out_len, y_stride);
 }
 
 int lra_istft_exec_host(lra_istft_plan* p, const void* D_host, int64_t batch, int64_t n_frames, int64_t n_used, const void* wss_host, void* y_host, int64_t out_len,
@@ -1851,8 +1877,8 @@ int lra_istft_exec_host(lra_istft_plan* p, const void* D_host, int64_t batch, in
     LRA_HIP(hipMemcpyAsync(hp->dev_aux, wss_host, out_item, hipMemcpyHostToDevice, ctx->stream));
     return host_pipeline(ctx, batch, in_item, in_item, out_item, (size_t)y_stride * es, (const char*)D_host, (char*)y_host, 0, nullptr,
                          [&](void* d_in, void* d_out, int64_t, int64_t nb) -> int {
-                             return p->dtype == LRA_F64 ? istft_run<double>(p, d_in, nb, n_frames * n_bins, n_bins, n_used, hp->dev_aux, d_out, out_len, out_len)
-                                                        : istft_run<float>(p, d_in, nb, n_frames * n_bins, n_bins, n_used, hp->dev_aux, d_out, out_len, out_len);
+                             return p->dtype == LRA_F64 ? istft_run<double>(p, d_in, nb, n_frames * n_bins, n_bins, n_used, hp->dev_aux, 0, d_out, out_len, out_len)
+                                                        : istft_run<float>(p, d_in, nb, n_frames * n_bins, n_bins, n_used, hp->dev_aux, 0, d_out, out_len, out_len);
                          });
 }
 

@@ -195,6 +195,24 @@ template <class T> LRA_HD cx<T> axpy_pi(T k, cx<T> u, cx<T> acc) {
 }
 // acc + k u, k real
 template <class T> LRA_HD cx<T> axpy(T k, cx<T> u, cx<T> acc) { return mk<T>(acc.x + k * u.x, acc.y + k * u.y); }
+// acc + (z.x w.x, -z.y w.y): the inverse transform's window multiply of a conjugated value fused with the overlap-add, ONE instruction
+// (hipcc builds it from two packed FMAs on re-paired halves: seven v_mov per pair)
+template <class T> LRA_HD cx<T> fma_conj_win(cx<T> z, cx<T> w, cx<T> acc) {
+#ifdef LRA_PK_ASM
+    if constexpr (sizeof(T) == 4) return pk::c(pk::fma<0, 1, 0, 1, 0, 1>(pk::v(z), pk::v(w), pk::v(acc)));
+#endif
+    return mk<T>(acc.x + z.x * w.x, acc.y - z.y * w.y);
+}
+// element-wise product of two pairs
+template <class T> LRA_HD cx<T> pmul(cx<T> a, cx<T> b) { return mk<T>(a.x * b.x, a.y * b.y); }
+// Keeps hipcc from merging the tail of one arm of a branch with the other arm's (SimplifyCFG sinks "common" loads / stores behind the join
+// and selects their ADDRESSES per arm: the fast path's four 8-byte accesses with immediate offsets became eight 4-byte accesses through
+// seven 64-bit address computations).  An inline-asm statement is never sunk, and the scan for sinkable code stops at it.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LRA_ARM_END(tag) asm volatile("; arm " tag)
+#else
+#define LRA_ARM_END(tag) ((void)0)
+#endif
 
 // Per-lane select under a mask that is held in an SGPR pair: c ? a : b as v_cndmask_b32_e64 (VOP3).  hipcc emits the VOP2 form with
 // the implicit VCC operand for most selects, and on gfx950 a v_cndmask_b32_e32 issued directly behind another one stalls the

@@ -1310,7 +1310,8 @@ template <class T> struct IstftArgs {
     const T* win_scaled;        // [N] window / N
     const cx<T>* tw;
     const cx<T>* twr;
-    const T* wss;               // [out_len] window sum-square already sliced/fixed to the output
+    const T* wss;               // [out_len] NORMALISATION FACTORS of the output samples: 1 / wss[s] where the window sum-square (already sliced / fixed to the
+                                // output) exceeds `tiny`, else 1 (core/spectrum.py:606-624 as a multiplication; the host wrapper builds the table: lra_api.hip)
     T tiny;
     T* y;                       // [batch][out_len]; the kernel writes every sample below istft_written_end(), the host wrapper zeroes the rest
     long long y_stride;
@@ -1562,8 +1563,7 @@ template <class Cfg> LRA_HD void istft_store_sample(const IstftArgs<typename Cfg
     using T = typename Cfg::real;
     const long long s = sp - a.drop;
     if (sp >= write_lo && sp < write_hi && s >= 0 && s < a.out_len) {
-        const T w = a.wss[s];
-        a.y[clip * a.y_stride + s] = (w > a.tiny) ? val / w : val;
+        a.y[clip * a.y_stride + s] = val * a.wss[s];
     }
 }
 
@@ -1665,6 +1665,11 @@ template <class Cfg, int HC> LRA_HD void istft_last_ola_rows(const IstftArgs<typ
     const int wbase = (tf - hc * TF) * (int)sizeof(C);  // pair c lands on pair c - hc
     constexpr bool REGC = istft_reg_carry<Cfg, HC>();
     static_assert(!REGC || CH == R, "register carry: one chunk");
+    // A frame that adds nothing (warm-up before the clip, drain behind it, an inactive slot's) was LOADED as an all-zero spectrum
+    // (istft_spec_load / _mir under the same condition as `contribute`), so its transform is exactly zero and `carry + frame` is the
+    // carry: no `contribute ? sum : carry` select per value (2 R v_cndmask per frame), and no second arm -- as a scalar branch around two
+    // bodies hipcc resolved the carry's PHIs with 48 v_mov per frame behind the join.
+    (void)contribute;
     C cv0[CH];
     if (CH == R) {
         LRA_UNROLL
@@ -1681,7 +1686,7 @@ template <class Cfg, int HC> LRA_HD void istft_last_ola_rows(const IstftArgs<typ
             const int c = c0 + q, i = c % nb, j = c / nb;
             const C z = rg.v[i * r + j];  // = conj(z'[pos]); x[2 pos] = Re z', x[2 pos + 1] = Im z'
             const C w = Cfg::HOIST ? rg.win2[i * r + j] : ws2[last_pass_pos<Cfg>(tf, i, j)];
-            const C val = contribute ? mk<T>(cv[q].x + z.x * w.x, cv[q].y - z.y * w.y) : cv[q];
+            const C val = fma_conj_win(z, w, cv[q]);  // (cv.x + z.x w.x, cv.y - z.y w.y): one packed FMA
             if (c < hc) {
                 if (2 * c + 1 < FftRegs<Cfg>::NPFX) { rg.out[2 * c] = val.x; rg.out[2 * c + 1] = val.y; }
             } else if (REGC) {
@@ -1738,6 +1743,7 @@ template <class Cfg, int HC> LRA_HD void istft_wss_rows(const IstftArgs<typename
             rg.wv[2 * c] = p2.x;
             rg.wv[2 * c + 1] = p2.y;
         }
+        LRA_ARM_END("wss rows: interior frame");
         return;
     }
     LRA_UNROLL
@@ -1751,18 +1757,23 @@ template <class Cfg, int HC> LRA_HD void istft_flush_rows(const IstftArgs<typena
     constexpr int TF = Cfg::TF;
     const IstftRowWin<Cfg> w = istft_row_window<Cfg>(a, t, in_strip, tf);
     T* __restrict__ yb = a.y + clip * a.y_stride + w.s0;
-    // normalise unconditionally (every load is consumed on every control path; see istft_flush_out).  The
-    // quotient is x * rcp(w): within 1 ulp of the reference's division (core/spectrum.py:624).
+    // normalise unconditionally (every load is consumed on every control path; see istft_flush_out): a multiplication by the
+    // host-built factor 1 / wss (1 where the envelope is tiny), within 1 ulp of the reference's division (core/spectrum.py:624) -- one
+    // packed multiply per sample pair instead of v_rcp + v_mul + v_cmp + v_cndmask per sample
     T val[2 * HC];
     LRA_UNROLL
-    for (int i = 0; i < 2 * HC; ++i) {
-        val[i] = (rg.wv[i] > a.tiny) ? fast_div(rg.out[i], rg.wv[i]) : rg.out[i];
-        LRA_KEEP(val[i]);
+    for (int c = 0; c < HC; ++c) {
+        const cx<T> pr = pmul(mk<T>(rg.out[2 * c], rg.out[2 * c + 1]), mk<T>(rg.wv[2 * c], rg.wv[2 * c + 1]));
+        val[2 * c] = pr.x;
+        val[2 * c + 1] = pr.y;
+        LRA_KEEP(val[2 * c]);
+        LRA_KEEP(val[2 * c + 1]);
     }
     const bool interior = istft_rows_interior<Cfg, HC>(a, clip, t, in_strip);
     if (Cfg::TF >= 64 ? (bool)LRA_UNIFORM(interior) : interior) {  // (a slot narrower than a wave shares it with other slots: per-lane there)
         LRA_UNROLL
         for (int c = 0; c < HC; ++c) *reinterpret_cast<cx<T>*>(yb + 2 * c * TF) = mk<T>(val[2 * c], val[2 * c + 1]);
+        LRA_ARM_END("flush rows: interior frame");
         return;
     }
     LRA_UNROLL
@@ -1796,7 +1807,7 @@ template <class Cfg> LRA_HD void istft_flush_out(const IstftArgs<typename Cfg::r
     T val[NPF];
     LRA_UNROLL
     for (int c = 0; c < NPF; ++c) {
-        val[c] = (w[c] > a.tiny) ? rg.out[c] / w[c] : rg.out[c];
+        val[c] = rg.out[c] * w[c];
         LRA_KEEP(val[c]);
     }
     LRA_UNROLL

@@ -167,6 +167,111 @@ template <class Cfg, int HD> LRA_HD void v2_shift(Regs2<Cfg, HD>& rg) {
     }
 }
 
+// The register ring WITHOUT the shift (LRA_V2_ROTATE): the R pairs stay where they are and the frame's VIEW of them rotates.  Logical
+// pass-0 row j of the slot's frame number `it` lives in physical row (j + SJ it) mod r0, so the only data that moves per frame are the
+// SJ new rows per butterfly (R / HD pairs: 4 at hop = n_fft / 4) from their landing registers into the rows the previous frame read
+// first; the window multiply picks its operands by the rotation, which is wave-uniform (a scalar switch with HD arms of R packed
+// multiplies each -- the rest of the frame is rotation-free).  v2_shift moved all R pairs every frame: 16 v_mov_b64 at n_fft = 2048
+// (+ the copies hipcc adds at the loop's back edge), 3.4 % of the kernel by ablation (profiles/r03_experiments.md section 1).
+#ifndef LRA_V2_ROTATE
+#define LRA_V2_ROTATE 1
+#endif
+// The C++ spelling of the rotating view (what the host simulator runs, and the definition of the assembly below).
+template <class Cfg, int HD> LRA_HD void v2_window_rotating_ref(int it, Regs2<Cfg, HD>& rg) {
+    using T = typename Cfg::real;
+    using RG = Regs2<Cfg, HD>;
+    constexpr int r0 = RG::r0, nb0 = RG::nb0, SJ = RG::SJ;
+    const int rot = it & (HD - 1);
+    for (int i = 0; i < nb0; ++i) {
+        if (it > 0)
+            for (int m = 0; m < SJ; ++m) rg.raw[i * r0 + (SJ * ((rot + HD - 1) % HD) + m) % r0] = rg.pf[i * SJ + m];
+        for (int j = 0; j < r0; ++j) {
+            const typename Cfg::cplx x = rg.raw[i * r0 + (j + SJ * rot) % r0], w = rg.win2[i * r0 + j];
+            rg.v[i * r0 + j] = mk<T>(x.x * w.x, x.y * w.y);
+        }
+    }
+}
+template <class Cfg, int HD> constexpr bool v2_rotate_asm_ok() {
+    return LRA_V2_ROTATE && HD == 4 && Regs2<Cfg, HD>::r0 == 16 && Regs2<Cfg, HD>::nb0 == 1 && sizeof(typename Cfg::real) == 4;
+}
+#if defined(LRA_PK_ASM)
+// One residue class of rows (c, c + 4, c + 8, c + 12: the rows a frame's hop of four rows maps onto each other), n_fft / hop = 4, sixteen rows:
+// v[c + 4 u] = P[c + 4 ((u + rot) mod 4)] * win[c + 4 u], the new pair `pf` going into P[c + 4 ((rot + 3) mod 4)] (and straight into the
+// product of logical row c + 12).  The rotation is wave-uniform (SGPR): a scalar switch INSIDE the block, so that the ring's sixteen register
+// pairs are tied operands of straight-line code as far as hipcc is concerned -- they never move and never pass through a PHI.  (Written as a
+// C++ switch hipcc either turned the ring into a run-time-indexed array in scratch memory or copied 12-16 pairs per frame between the arms.)
+__device__ __forceinline__ void v2_rot_class(pk::f2& p0, pk::f2& p1, pk::f2& p2, pk::f2& p3, pk::f2 pf, pk::f2 w0, pk::f2 w1, pk::f2 w2, pk::f2 w3, pk::f2& v0, pk::f2& v1,
+                                              pk::f2& v2, pk::f2& v3, int rot, int ins) {
+    asm("s_cmp_lg_u32 %13, 0\n\t"
+        "s_cbranch_scc1 .Lrot1_%=\n\t"
+        "s_cmp_eq_u32 %14, 0\n\t"
+        "s_cbranch_scc1 .Lrot0_%=\n\t"
+        "v_mov_b64 %7, %8\n"
+        ".Lrot0_%=:\n\t"
+        "v_pk_mul_f32 %0, %4, %9\n\t"
+        "v_pk_mul_f32 %1, %5, %10\n\t"
+        "v_pk_mul_f32 %2, %6, %11\n\t"
+        "v_pk_mul_f32 %3, %7, %12\n\t"
+        "s_branch .Lrotend_%=\n"
+        ".Lrot1_%=:\n\t"
+        "s_cmp_lg_u32 %13, 1\n\t"
+        "s_cbranch_scc1 .Lrot2_%=\n\t"
+        "v_pk_mul_f32 %0, %5, %9\n\t"
+        "v_pk_mul_f32 %1, %6, %10\n\t"
+        "v_pk_mul_f32 %2, %7, %11\n\t"
+        "v_pk_mul_f32 %3, %8, %12\n\t"
+        "v_mov_b64 %4, %8\n\t"
+        "s_branch .Lrotend_%=\n"
+        ".Lrot2_%=:\n\t"
+        "s_cmp_lg_u32 %13, 2\n\t"
+        "s_cbranch_scc1 .Lrot3_%=\n\t"
+        "v_pk_mul_f32 %0, %6, %9\n\t"
+        "v_pk_mul_f32 %1, %7, %10\n\t"
+        "v_pk_mul_f32 %2, %4, %11\n\t"
+        "v_pk_mul_f32 %3, %8, %12\n\t"
+        "v_mov_b64 %5, %8\n\t"
+        "s_branch .Lrotend_%=\n"
+        ".Lrot3_%=:\n\t"
+        "v_pk_mul_f32 %0, %7, %9\n\t"
+        "v_pk_mul_f32 %1, %4, %10\n\t"
+        "v_pk_mul_f32 %2, %5, %11\n\t"
+        "v_pk_mul_f32 %3, %8, %12\n\t"
+        "v_mov_b64 %6, %8\n"
+        ".Lrotend_%=:\n\t"
+        "s_nop 0"
+        : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3)
+        : "v"(pf), "v"(w0), "v"(w1), "v"(w2), "v"(w3), "s"(rot), "s"(ins)
+        : "scc");
+}
+#endif
+// `it` is the slot's frame counter (wave-uniform: every slot of the workgroup is at the same count)
+template <class Cfg, int HD> LRA_HD void v2_window_rotating(int it, Regs2<Cfg, HD>& rg) {
+#if defined(LRA_PK_ASM)
+    if constexpr (v2_rotate_asm_ok<Cfg, HD>()) {
+        const int rot = it & 3, ins = it;  // `ins`: zero for the slot's first frame, whose ring v2_fill loaded whole (the loop counter is scalar already)
+        pk::f2 p[16], o[16];
+        LRA_UNROLL
+        for (int e = 0; e < 16; ++e) p[e] = pk::v(rg.raw[e]);
+        LRA_UNROLL
+        for (int c = 0; c < 4; ++c)
+            v2_rot_class(p[c], p[c + 4], p[c + 8], p[c + 12], pk::v(rg.pf[c]), pk::v(rg.win2[c]), pk::v(rg.win2[c + 4]), pk::v(rg.win2[c + 8]), pk::v(rg.win2[c + 12]), o[c],
+                         o[c + 4], o[c + 8], o[c + 12], rot, ins);
+        LRA_UNROLL
+        for (int e = 0; e < 16; ++e) { rg.raw[e] = pk::c(p[e]); rg.v[e] = pk::c(o[e]); }
+        return;
+    }
+#endif
+    v2_window_rotating_ref<Cfg, HD>(it, rg);
+}
+// pass-0 butterflies on the windowed frame, first LDS write of the frame (second half of v2_pass0)
+template <class Cfg, int HD> LRA_HD void v2_pass0_dft(int tf, Regs2<Cfg, HD>& rg, Lds fr) {
+    using T = typename Cfg::real;
+    constexpr int r0 = Regs2<Cfg, HD>::r0, nb0 = Regs2<Cfg, HD>::nb0;
+    LRA_UNROLL
+    for (int i = 0; i < nb0; ++i) Dft<r0, T>::run(rg.v + i * r0);
+    pass_write<Cfg, 0>(rg.v, fr, tf);
+}
+
 // phase: window, pass-0 butterflies, first LDS write of the frame
 template <class Cfg, int HD> LRA_HD void v2_pass0(bool live, int tf, Regs2<Cfg, HD>& rg, Lds fr) {
     using T = typename Cfg::real;
@@ -406,6 +511,12 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
         const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
         v2_hoist<Cfg, HD>(LRA_R(rg), tf, a.win, a.tw, a.twr);
         v2_fill<Cfg, HD>(a, clip, f_first + slot * iters, tf, LRA_R(rg));
+        if constexpr (v2_rotate_asm_ok<Cfg, HD>()) {
+            // the fill's loads are waited for HERE, once: the frame loop's first consumer of the ring is an asm block whose operands are the ring
+            // itself, and a wait placed there is a wait in every iteration (s_waitcnt vmcnt(0) at the loop's top: for the frame's fresh stores too)
+            LRA_UNROLL
+            for (int e = 0; e < Cfg::R; ++e) { LRA_KEEP(LRA_R(rg).raw[e].x); LRA_KEEP(LRA_R(rg).raw[e].y); }
+        }
         // (v2_issue_loads returns early for frames past the clip: the prefetch registers then keep these zeros or an earlier frame's samples)
         LRA_UNROLL
         for (int e = 0; e < RG::NEW; ++e) LRA_R(rg).pf[e] = mk<typename Cfg::real>((typename Cfg::real)0, (typename Cfg::real)0);
@@ -419,9 +530,15 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
             RG& r = LRA_R(rg);
-            if (it > 0) v2_shift<Cfg, HD>(r);                                       // consumes the pairs loaded during the previous frame
-            if (it + 1 < iters) v2_issue_loads<Cfg, HD>(a, clip, frame + 1, tf, r);  // ... and starts the next batch, BEFORE this frame's stores
-            v2_pass0<Cfg, HD>(frame < a.n_frames, tf, r, lds_sub(lds, slot * SB));
+            if (v2_rotate_asm_ok<Cfg, HD>()) {
+                v2_window_rotating<Cfg, HD>(it, r);                                      // consumes the pairs loaded during the previous frame (4 moves, not 16)
+                if (it + 1 < iters) v2_issue_loads<Cfg, HD>(a, clip, frame + 1, tf, r);  // ... and starts the next batch, BEFORE this frame's stores
+                v2_pass0_dft<Cfg, HD>(tf, r, lds_sub(lds, slot * SB));
+            } else {
+                if (it > 0) v2_shift<Cfg, HD>(r);                                       // consumes the pairs loaded during the previous frame
+                if (it + 1 < iters) v2_issue_loads<Cfg, HD>(a, clip, frame + 1, tf, r);  // ... and starts the next batch, BEFORE this frame's stores
+                v2_pass0<Cfg, HD>(frame < a.n_frames, tf, r, lds_sub(lds, slot * SB));
+            }
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
 #define LRA_MID_PASS2(p)                                                                                                  \
         if (Cfg::P - 1 > p) {                                                                                             \

@@ -27,11 +27,14 @@ D = torch.empty((batch, T, bins), dtype=torch.complex64, device=dev)
 if what == "istft":
     ip = ctx.istft_plan(n_fft, hop, w, True, np.float32)
     ww = filters.window_sumsquare(window="hann", n_frames=T, n_fft=n_fft, hop_length=hop, dtype=np.float32)[n_fft // 2:]
-    ww = torch.from_numpy(np.ascontiguousarray(np.pad(ww, (0, max(0, n - len(ww))))[:n], dtype=np.float32)).to(dev)
+    from librosa_amd.core.spectrum import wss_to_norm
+    if not hasattr(ctx, "istft_exec_norm"):  # (older probe builds)
+        ctx.istft_exec_norm, wss_to_norm = ctx.istft_exec, (lambda w: w)
+    ww = torch.from_numpy(wss_to_norm(np.ascontiguousarray(np.pad(ww, (0, max(0, n - len(ww))))[:n], dtype=np.float32))).to(dev)
     yr = torch.empty((batch, n), dtype=torch.float32, device=dev)
     ctx.stft_exec(pl, y.data_ptr(), batch, n, n, D.data_ptr())
     apply_opts()  # (inverse-only kernel variants: after the forward transform that makes the input)
-    fn = lambda: ctx.istft_exec(ip, D.data_ptr(), batch, T * bins, bins, T, ww.data_ptr(), yr.data_ptr(), n, n)
+    fn = lambda: ctx.istft_exec_norm(ip, D.data_ptr(), batch, T * bins, bins, T, ww.data_ptr(), yr.data_ptr(), n, n)
 elif what == "mel":
     n_mels = int(os.environ.get("PROBE_MELS", "128"))
     mp = ctx.mel_plan(filters.mel(sr=22050, n_fft=n_fft, n_mels=n_mels))

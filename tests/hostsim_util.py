@@ -123,7 +123,10 @@ def istft(D, n_fft, hop, win, wss, out_len, n_used, center=True, strip_groups=4,
     batch, T, bins = D.shape
     assert bins == n_fft // 2 + 1
     ws = np.ascontiguousarray(np.asarray(win, dtype=np.float64) / n_fft, dtype=rt)
-    wss = np.ascontiguousarray(wss, dtype=rt)
+    # the kernel bodies multiply by the normalisation factors the host wrapper makes of the envelope (lra_api.hip, wss_to_norm_kernel)
+    wss = np.asarray(wss, dtype=rt)
+    with np.errstate(divide="ignore", over="ignore"):
+        wss = np.ascontiguousarray(np.where(wss > np.finfo(rt).tiny, rt(1) / wss, rt(1)), dtype=rt)
     # the buffer arrives full of NaN and only what the host wrapper clears (lra_api.hip, istft_run: samples from istft_written_end() on)
     # is zeroed: every other sample must be stored by the kernel body itself
     y = np.full((batch, out_len), np.nan, dtype=rt)
