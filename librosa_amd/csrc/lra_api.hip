@@ -527,7 +527,7 @@ template <class T> struct IstftLaunch {
             const long long conc = (long long)n_cu * (per_cu > 0 ? per_cu : 1);
             double best_fill = -1.0;
             sf = 64;
-            for (int cand = 160; cand >= 32; --cand) {
+            for (int cand = 176; cand >= 32; --cand) {  // (up to 1292 / 8 = 162 frames for the 30 s clips of BASELINE: one round of strips, 1.9 % of warm-up reads)
                 const int spc = (a.n_used + cand - 1) / cand;
                 const int fr = (a.n_used + spc - 1) / spc;  // equal shares
                 const double rounds = (double)((batch * spc + FPB - 1) / FPB) / (double)conc;

@@ -236,6 +236,16 @@ template <class T> LRA_HD T sel_mask(LaneMask, bool c, T a, T b) { return c ? a 
 #endif
 template <class T> LRA_HD cx<T> sel_mask(LaneMask m, bool c, cx<T> a, cx<T> b) { return mk<T>(sel_mask(m, c, a.x, b.x), sel_mask(m, c, a.y, b.y)); }
 
+// Pitch (in (A, B) pairs) of the run-ordered mel epilogue's running-sum area, register slot to register slot (lra_mel.h builds the piece
+// addresses with it, the kernels store with it).  Layout 0: first-generation kernels, pitch TF.  Layout 1 (second generation):
+// Round 4 reads the piece totals as whole (A, B) pairs (ds_read_b64: 64 banks; a 4-byte read of one half of an 8-byte slot can only ever
+// land on 16 of its 32 banks, a built-in 2-way conflict), for which the plain pitch TF models best (scripts/lds_model.py: 57 LDS cycles per
+// frame for the 16 reads against 90 with 4-byte reads at pitch TF + 1).
+#ifndef LRA_MEL_RS_PITCH_EXTRA
+#define LRA_MEL_RS_PITCH_EXTRA 0
+#endif
+LRA_HD int mel_runs_pitch(int tf_count, int layout) { return layout == 1 ? tf_count + LRA_MEL_RS_PITCH_EXTRA : tf_count; }
+
 // pad modes for centred framing (np.pad modes the reference forwards, core/spectrum.py:287)
 enum PadMode : int { PAD_CONSTANT = 0, PAD_REFLECT = 1, PAD_EDGE = 2, PAD_SYMMETRIC = 3 };
 

@@ -967,6 +967,9 @@ template <class Cfg, int PM> LRA_HD void melr_split_accumulate(const StftArgs<ty
     }
 }
 
+#ifndef LRA_MEL_PAIR_READS
+#define LRA_MEL_PAIR_READS 1
+#endif
 // prologue: per-thread constants of the run-ordered epilogue -> registers (restart factors; the first MELR_PHOIST
 // entries of both piece lists of mel bands tf and tf + TF)
 // `base`: byte offset added to every hoisted address (the second-generation kernel passes its slot's offset, so that the 16
@@ -981,7 +984,11 @@ template <class Cfg, class RG> LRA_HD void melr_hoist(const StftArgs<typename Cf
         LRA_UNROLL
         for (int h = 0; h < 2; ++h) {
             LRA_UNROLL
-            for (int q = 0; q < PH; ++q) rg.mad[b][h * PH + q] = base + (m < a.n_mels ? a.melr_addr[(h * a.melr_pmax + q) * a.n_mels + m] : a.melr_zero);
+            for (int q = 0; q < PH; ++q) {
+                const int ad = base + (m < a.n_mels ? a.melr_addr[(h * a.melr_pmax + q) * a.n_mels + m] : a.melr_zero);
+                // (the table addresses the B half of a pair for list 0; melr_combine reads whole pairs: keep the pair's address)
+                rg.mad[b][h * PH + q] = (LRA_MEL_PAIR_READS && sizeof(typename Cfg::real) == 4) ? (ad & ~(2 * (int)sizeof(typename Cfg::real) - 1)) : ad;
+            }
         }
     }
 }
@@ -1031,11 +1038,21 @@ template <class Cfg, class RG> LRA_HD void melr_combine(const StftArgs<typename 
     using T = typename Cfg::real;
     constexpr int PH = RG::MELR_PHOIST, TF = Cfg::TF;
     const bool more = a.melr_pmax > PH;  // uniform
+    // The hoisted piece totals are read as whole (A, B) pairs and the wanted half is picked in registers (list h = 0: the B totals of
+    // segment m, h = 1: the A totals of segment m + 1): an 8-byte read spreads 32 lanes over 64 banks, a 4-byte read of one half of
+    // 8-byte slots over 16 -- a built-in 2-way conflict that was a third of the epilogue's LDS cycles (scripts/lds_model.py).
     T x[2][2 * PH];
     LRA_UNROLL
     for (int b = 0; b < 2; ++b) {
         LRA_UNROLL
-        for (int q = 0; q < 2 * PH; ++q) x[b][q] = lds_ld<T>(rs_hoisted, rg.mad[b][q]);
+        for (int q = 0; q < 2 * PH; ++q) {
+            if constexpr (LRA_MEL_PAIR_READS && sizeof(T) == 4) {
+                const cx<T> pr = lds_ld<cx<T>>(rs_hoisted, rg.mad[b][q]);  // (melr_hoist keeps the pair's address)
+                x[b][q] = q < PH ? pr.y : pr.x;
+            } else {
+                x[b][q] = lds_ld<T>(rs_hoisted, rg.mad[b][q]);
+            }
+        }
     }
     LRA_UNROLL
     for (int b = 0; b < 2; ++b) {

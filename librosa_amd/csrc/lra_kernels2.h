@@ -309,9 +309,22 @@ template <class Cfg> LRA_HD int v2_row_shift(const StftArgs<typename Cfg::real>&
     return (int)(reinterpret_cast<size_t>(a.D + row) & (2 * sizeof(typename Cfg::real)));  // 0 or sizeof(cplx): the row starts on / half-way into a 16-byte piece
 }
 
-// OUT_MELR: float index of bin k in the power row: runs of 8 bins, 12 floats (48 bytes) apart
-LRA_HD int v2_pw_index(int k) { return (k >> 3) * 12 + (k & 7); }
-template <class Cfg> constexpr int v2_pw_bytes() { return ((Cfg::M >> 3) * 12 + 4) * (int)sizeof(typename Cfg::real); }
+// OUT_MELR: float index of bin k in the power row.  Runs of 8 bins back to back, the two 16-byte halves of a run swapped where bit 7 of the
+// bin is set: the butterfly-order writes (lanes = 32 consecutive bins, ds_write_b32) then stay within a handful of distinct banks per
+// lane group, and the run reads (ds_read_b128, thread tf takes run tf: sixteen lanes 32 bytes apart) find the halves of neighbouring
+// lane groups on disjoint bank quarters.  scripts/lds_model.py: 36 + 16 LDS cycles per frame for the 16 writes + 4 reads against 64 + 16
+// for the round-3 layout (runs 48 bytes apart, every 32-lane write 2-way conflicted).  Linear over steps of 256 bins: idx(k + 256) = idx(k) + 256.
+#ifndef LRA_MEL_PW_SWZ
+#define LRA_MEL_PW_SWZ 1
+#endif
+// (the swizzled form needs pair slots a whole number of 128-bin blocks apart: n_fft >= 2048 at sixteen points per thread; smaller frames keep the padded runs)
+template <class Cfg> constexpr bool v2_pw_swz() { return LRA_MEL_PW_SWZ && (2 * Cfg::TF) % 128 == 0; }
+template <bool SWZ> LRA_HD int v2_pw_index_t(int k) {
+    if (SWZ) return (k >> 3) * 8 + ((((k >> 2) ^ (k >> 7)) & 1) << 2) + (k & 3);
+    return (k >> 3) * 12 + (k & 7);
+}
+template <class Cfg> LRA_HD int v2_pw_index(int k) { return v2_pw_index_t<v2_pw_swz<Cfg>()>(k); }
+template <class Cfg> constexpr int v2_pw_bytes() { return (v2_pw_swz<Cfg>() ? Cfg::M + 8 : (Cfg::M >> 3) * 12 + 4) * (int)sizeof(typename Cfg::real); }
 
 // phase: last-pass butterflies, Hermitian split in registers, epilogue (complex spectrum or |X|^power) to HBM
 template <class Cfg, int HD, int MODE, int PM, bool STAGED>
@@ -333,13 +346,17 @@ LRA_HD void v2_last_split_store(const StftArgs<typename Cfg::real>& a, int clip,
     // OUT_MELR: byte addresses of the power-row slots of this thread's four bin families (k = tf + q s and M - k, with lane 0's
     // alternative bases), pinned in registers: left to itself hipcc re-derives (k >> 3) * 12 + (k & 7) for each of the 16 stores
     // (4 VALU instructions each) rather than keep four values live
-    int pwk_lo = 0, pwk_hi = 0, pwm_lo = 0, pwm_hi = 0;
+    // ([family][parity of the pair slot]: the swizzled row is linear over steps of TWO slots (256 bins), so each family has two bases)
+    int pwk[2][2] = {{0, 0}, {0, 0}}, pwm[2][2] = {{0, 0}, {0, 0}};
     if (MODE == OUT_MELR) {
-        pwk_lo = v2_pw_index(tf) * (int)sizeof(T);
-        pwk_hi = v2_pw_index(tfh) * (int)sizeof(T);
-        pwm_lo = v2_pw_index(M - tf) * (int)sizeof(T);
-        pwm_hi = v2_pw_index(M - tfh) * (int)sizeof(T);
-        LRA_KEEP(pwk_lo); LRA_KEEP(pwk_hi); LRA_KEEP(pwm_lo); LRA_KEEP(pwm_hi);
+        LRA_UNROLL
+        for (int par = 0; par < 2; ++par) {
+            pwk[0][par] = v2_pw_index<Cfg>(tf + par * s) * (int)sizeof(T);
+            pwk[1][par] = v2_pw_index<Cfg>(tfh + par * s) * (int)sizeof(T);
+            pwm[0][par] = v2_pw_index<Cfg>(M - tf - par * s) * (int)sizeof(T);
+            pwm[1][par] = v2_pw_index<Cfg>(M - tfh - par * s) * (int)sizeof(T);
+            LRA_KEEP(pwk[0][par]); LRA_KEEP(pwk[1][par]); LRA_KEEP(pwm[0][par]); LRA_KEEP(pwm[1][par]);
+        }
     }
     LRA_UNROLL
     for (int q = 0; q < r; ++q) {
@@ -363,8 +380,13 @@ LRA_HD void v2_last_split_store(const StftArgs<typename Cfg::real>& a, int clip,
         if (MODE == OUT_MELR) {
             // power row -> LDS (the frame area is free: every Z is in registers), bin k at float (k / 8) 12 + k % 8: runs of 8
             // bins 48 bytes apart, so that the 16-byte run reads of v2_mel_runs_read hit disjoint banks.  Per-thread bases + immediates.
-            lds_st<T>(stage, (q < r / 2 ? pwk_lo : pwk_hi) + 24 * q * (s / 16) * (int)sizeof(T), spec_power<T, PM>(xk, a.power));
-            lds_st<T>(stage, (q < r / 2 ? pwm_lo : pwm_hi) - 24 * q * (s / 16) * (int)sizeof(T), spec_power<T, PM>(xm, a.power));
+            if (v2_pw_swz<Cfg>()) {
+                lds_st<T>(stage, pwk[q < r / 2 ? 0 : 1][q & 1] + (q >> 1) * 2 * s * (int)sizeof(T), spec_power<T, PM>(xk, a.power));
+                lds_st<T>(stage, pwm[q < r / 2 ? 0 : 1][q & 1] - (q >> 1) * 2 * s * (int)sizeof(T), spec_power<T, PM>(xm, a.power));
+            } else {
+                lds_st<T>(stage, pwk[q < r / 2 ? 0 : 1][0] + 24 * q * (s / 16) * (int)sizeof(T), spec_power<T, PM>(xk, a.power));
+                lds_st<T>(stage, pwm[q < r / 2 ? 0 : 1][0] - 24 * q * (s / 16) * (int)sizeof(T), spec_power<T, PM>(xm, a.power));
+            }
         } else if (MODE == OUT_COMPLEX && STAGED) {
             // the row goes to LDS in bin order (the frame area is free: every Z is in registers), shifted so that LDS and
             // global addresses agree modulo 16; v2_store_row then writes it as aligned 16-byte pieces.  Of the two bins that
@@ -387,7 +409,7 @@ LRA_HD void v2_last_split_store(const StftArgs<typename Cfg::real>& a, int clip,
     const C zmid = A[r / 2];
     const C xmid = mk<T>((T)2 * zmid.x, (T)-2 * zmid.y);
     if (MODE == OUT_MELR) {
-        if (l0) lds_st<T>(stage, v2_pw_index(M / 2) * (int)sizeof(T), spec_power<T, PM>(xmid, a.power));
+        if (l0) lds_st<T>(stage, v2_pw_index<Cfg>(M / 2) * (int)sizeof(T), spec_power<T, PM>(xmid, a.power));
     } else if (MODE == OUT_COMPLEX && STAGED) {
         if (l0) lds_st<C>(stage, sh + (M / 2) * (int)sizeof(C), xmid);
     } else if (l0 && valid) {
@@ -430,12 +452,12 @@ template <class Cfg, int HD> LRA_HD void v2_mel_runs_read(Regs2<Cfg, HD>& rg, Ld
     static_assert(BPL == 8, "runs of 8 bins");
     LRA_UNROLL
     for (int run = 0; run < 2; ++run) {
-        const int base = 12 * (run * Cfg::TF + tf) * (int)sizeof(T);
-        const V4<T> lo = lds_ld<V4<T>>(pwr, base), hi = lds_ld<V4<T>>(pwr, base + 16);
+        const int first = 8 * (run * Cfg::TF + tf);  // first bin of the run (padded layout: 12 (run TF + tf) floats, the second half 16 bytes on)
+        const V4<T> lo = lds_ld<V4<T>>(pwr, v2_pw_index<Cfg>(first) * (int)sizeof(T)), hi = lds_ld<V4<T>>(pwr, v2_pw_index<Cfg>(first + 4) * (int)sizeof(T));
         T* d = rg.pw + run * BPL;
         d[0] = lo.a; d[1] = lo.b; d[2] = lo.c; d[3] = lo.d; d[4] = hi.a; d[5] = hi.b; d[6] = hi.c; d[7] = hi.d;
     }
-    rg.pw_extra = lds_ld<T>(pwr, (tf == 0 ? v2_pw_index(Cfg::M) : 0) * (int)sizeof(T));  // consumed by thread 0 only
+    rg.pw_extra = lds_ld<T>(pwr, (tf == 0 ? v2_pw_index<Cfg>(Cfg::M) : 0) * (int)sizeof(T));  // consumed by thread 0 only
 }
 
 // same phase: this thread's 2 x 8 weight pairs (wA, wB) from the workgroup's table -> the butterfly registers (dead between the split
@@ -472,7 +494,7 @@ template <class Cfg, int HD> LRA_HD void v2_mel_accumulate(const StftArgs<typena
             const int jj = run * BPL + j;
             const T p = rg.pw[jj], keep = rg.keep[jj];
             acc = mk<T>(acc.x * keep + w[jj].x * p, acc.y * keep + w[jj].y * p);
-            lds_st<C>(rs, (jj * (TF + 1) + tf) * (int)sizeof(C), acc);  // pitch TF + 1: lra_mel.h, mel_runs_pitch
+            lds_st<C>(rs, (jj * mel_runs_pitch(TF, 1) + tf) * (int)sizeof(C), acc);  // (pitch: lra_mel.h, mel_runs_pitch)
         }
     }
     if (tf == 0) {
@@ -489,7 +511,7 @@ template <class Cfg> constexpr int stft2_slot_bytes() { return Cfg::FRAME_BYTES;
 template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2(const StftArgs<typename Cfg::real>& a_in, const int blk, Lds lds) {
     static_assert(v2_cfg_ok<Cfg>(), "configuration has no mirrored last pass");
     static_assert(MODE == OUT_COMPLEX || MODE == OUT_POWER || MODE == OUT_MELR, "epilogues of the second-generation kernel");
-    static_assert(MODE != OUT_MELR || (melr_fits<Cfg>() && v2_pw_bytes<Cfg>() <= Cfg::FRAME_BYTES && (Cfg::R * (Cfg::TF + 1) + 2) * 2 * (int)sizeof(typename Cfg::real) <= Cfg::FRAME_BYTES),
+    static_assert(MODE != OUT_MELR || (melr_fits<Cfg>() && v2_pw_bytes<Cfg>() <= Cfg::FRAME_BYTES && (Cfg::R * (Cfg::TF + LRA_MEL_RS_PITCH_EXTRA) + 2) * 2 * (int)sizeof(typename Cfg::real) <= Cfg::FRAME_BYTES),
                   "mel epilogue: running sums (pitch TF + 1) and power row live in the frame area");
     StftArgs<typename Cfg::real> a = a_in;
     using RG = Regs2<Cfg, HD>;
@@ -511,7 +533,7 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
         const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
         v2_hoist<Cfg, HD>(LRA_R(rg), tf, a.win, a.tw, a.twr);
         v2_fill<Cfg, HD>(a, clip, f_first + slot * iters, tf, LRA_R(rg));
-        if constexpr (v2_rotate_asm_ok<Cfg, HD>()) {
+        if constexpr (v2_rotate_asm_ok<Cfg, HD>() && MODE != OUT_MELR) {
             // the fill's loads are waited for HERE, once: the frame loop's first consumer of the ring is an asm block whose operands are the ring
             // itself, and a wait placed there is a wait in every iteration (s_waitcnt vmcnt(0) at the loop's top: for the frame's fresh stores too)
             LRA_UNROLL
@@ -530,7 +552,9 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
             RG& r = LRA_R(rg);
-            if (v2_rotate_asm_ok<Cfg, HD>()) {
+            // (measured, profiles/r04_experiments.md: 21 vector instructions per frame fewer and the same time for the complex / power
+            // epilogues; 1 % SLOWER with the mel epilogue, whose issue-bound loop pays for the switches' taken branches -- it keeps the shift)
+            if (v2_rotate_asm_ok<Cfg, HD>() && MODE != OUT_MELR) {
                 v2_window_rotating<Cfg, HD>(it, r);                                      // consumes the pairs loaded during the previous frame (4 moves, not 16)
                 if (it + 1 < iters) v2_issue_loads<Cfg, HD>(a, clip, frame + 1, tf, r);  // ... and starts the next batch, BEFORE this frame's stores
                 v2_pass0_dft<Cfg, HD>(tf, r, lds_sub(lds, slot * SB));

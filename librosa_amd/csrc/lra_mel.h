@@ -20,6 +20,8 @@
 #include <algorithm>
 #include <vector>
 
+#include "lra_common.h"
+
 namespace lra {
 
 template <class T> struct TwoSlope {
@@ -160,7 +162,7 @@ template <class T> struct MelRuns {
 // M/2 + bpl t + j (both ascending), extra bin M; the weight table is then in plain bin order.  Layout 1 also stores the running
 // sums with a pitch of TF + 1 pairs per register slot: with a pitch of TF all 2 bpl sums of one thread share one pair of LDS banks,
 // and the bands of the low mel range -- whose pieces all come from the first few threads -- gathered them with multi-way conflicts.
-inline int mel_runs_pitch(int tf_count, int layout) { return layout == 1 ? tf_count + 1 : tf_count; }
+// (mel_runs_pitch: lra_common.h -- the kernels and this table builder share it)
 template <class T> inline MelRuns<T> build_mel_runs(const TwoSlope<T>& ts, int tf_count, int bpl, int pmax, int min_len, int layout = 0) {
     MelRuns<T> mr;
     mr.tf = tf_count;
