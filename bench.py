@@ -616,6 +616,18 @@ def main():
             return out
 
         measure("pcen_cqt", pcen_and_cqt)
+
+        def hpss_key():
+            nb = min(32, batch)
+            Dh = L.stft(y[:nb], n_fft=N_FFT, hop_length=HOP)  # (the layout decompose.hpss consumes without a transpose)
+            fn = lambda: L.decompose.hpss(Dh)
+            _, e = timed(fn, 5, 2, collective=False, ramp_ms=args.prewarm_ms / 4)
+            per = e / 5
+            return {"clips": nb, "ms_per_call": per * 1e3, "GBps_algorithmic": 3 * Dh.numel() * 8 / per / 1e9,
+                    "what": "decompose.hpss(<device stft>, kernel_size=31): |D|, both running medians (sorting networks in registers), soft masks, two masked spectra: "
+                            "one complex64 spectrogram read, two written"}
+
+        measure("hpss", hpss_key)
         # BASELINE config 5 (CQT-lite): three STFTs at n_fft = 512 / 2048 / 8192 over the same batch, shared hop 512
         if not args.no_cqt:
             def cqt_lite():

@@ -126,6 +126,28 @@ if os.path.exists(trace_csv):
         v2 = sorted(v)
         lines.append(f"| {short(k)} | {len(v)} | {mean(v) / 1e3:.1f} | {v2[len(v2) // 2] / 1e3:.1f} | {v2[0] / 1e3:.1f} |")
     lines.append("")
+    # the kernels of the SURVEY 8(f) rows and the stream probe, same trace: every launch of the grid most of their time goes to
+    other = collections.defaultdict(list)
+    FRAMES = 256 * 1292
+    known_bytes = {"pcen_kernel": ("256 x 128 x 1292 values, 4 B read + 8 B written", 256 * 128 * 1292 * 12),
+                   "hpss_kernel": ("32 x 1292 x 1025 bins: |D| (4 B) + D (8 B) read, two spectra (16 B) written", 32 * 1292 * 1025 * 28),
+                   "stream_probe_kernel<0>": ("forward stream, 10 248 B per row", FRAMES * 10248), "stream_probe_kernel<1>": ("inverse stream, 10 248 B per row", FRAMES * 10248),
+                   "to_db_kernel": ("256 x 128 x 1292 values read and written", 256 * 128 * 1292 * 8)}
+    for r in rows:
+        k = r["Kernel_Name"]
+        if any(n in k for n in ("pcen_kernel", "hpss_kernel", "magnitude_kernel", "cqt_project_kernel", "fir_decimate", "stream_probe_kernel", "to_db_kernel", "dct_rows_kernel",
+                                "item_absmax_kernel", "griffinlim_update_kernel", "phase_vocoder_kernel", "wss_to_norm_kernel", "fillBuffer")):
+            if int(r["Grid_Size_X"]) == grids[k].most_common(1)[0][0]:
+                other[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    if other:
+        lines += ["## other kernels of the path (SURVEY 8f rows, the stream probe; launches of the grid most of each kernel's time goes to)", "",
+                  "| kernel | launches | avg (us) | algorithmic bytes per launch | GB/s | % of 8 TB/s |", "|---|---|---|---|---|---|"]
+        for k, v in sorted(other.items(), key=lambda kv: -sum(kv[1])):
+            name = k.split("(")[0][-70:]
+            kb = next((val for key, val in known_bytes.items() if key in k.replace("lra::", "")), None)
+            avg = mean(v)
+            lines.append(f"| {name} | {len(v)} | {avg / 1e3:.1f} | {kb[0] if kb else '-'} | {(kb[1] / avg) if kb else 0:.0f} | {(kb[1] / avg / 80) if kb else 0:.1f} |" if kb else f"| {name} | {len(v)} | {avg / 1e3:.1f} | - | - | - |")
+        lines.append("")
 lines += ["## HBM traffic per launch (FETCH_SIZE / WRITE_SIZE, separate passes)", "", f"calibration on torch clamp_ over the 677.4 MB batch: {calib}", "",
           "| kernel | FETCH raw (MB) | WRITE raw (MB) | FETCH calibrated (MB) | WRITE calibrated (MB) |", "|---|---|---|---|---|"]
 for k, v in sorted(traffic["kernels"].items()):
@@ -142,5 +164,20 @@ for sub in ("sq1", "sq2"):
         if "stft_kernel" in k or "stft2_kernel" in k:
             lines.append(f"| {short(k)} | " + " | ".join(f"{mean(v[c]):.4g}" if c in v else "-" for c in keys) + " |")
     lines.append("")
+# derived per-frame figures of the three BASELINE kernels (330 752 frames per launch): vector instructions, LDS instructions, bank-conflict share
+sq1, sq2 = counters("sq1"), counters("sq2")
+der = []
+for k in sq1:
+    if not ("stft2_kernel" in k or "istft_kernel" in k) or "Li10ELi4Ef" not in k and "10, 4, float" not in k:
+        continue
+    a, b = sq1[k], sq2.get(k, {})
+    g = lambda d, c: mean(d[c]) if c in d else float("nan")
+    frames = 256 * 1292
+    der.append(f"| {short(k)} | {g(a, 'SQ_INSTS_VALU') / frames:.0f} | {g(b, 'SQ_INSTS_LDS') / frames:.1f} | {g(b, 'SQ_LDS_BANK_CONFLICT') / max(g(b, 'SQ_LDS_IDX_ACTIVE'), 1):.3f} | "
+               f"{g(a, 'SQ_WAIT_INST_ANY') / max(g(a, 'SQ_WAVE_CYCLES'), 1):.2f} | {g(a, 'SQ_ACTIVE_INST_VALU') / max(g(a, 'SQ_WAVE_CYCLES'), 1):.2f} | {mean(a.get('_vgpr', [0])):.0f} |")
+if der:
+    lines += ["## derived, per frame (330 752 frames per launch of the timed batch)", "",
+              "| kernel | VALU instructions / frame | LDS instructions / frame | LDS bank-conflict cycles / LDS active cycles | SQ_WAIT_INST_ANY / wave cycles | VALU active / wave cycles | VGPRs (granules x 2?) |",
+              "|---|---|---|---|---|---|---|"] + der + [""]
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
