@@ -628,6 +628,32 @@ def main():
                             "one complex64 spectrogram read, two written"}
 
         measure("hpss", hpss_key)
+
+        def mixed_radix():
+            """n_fft = 400, hop 160, 80 mels at 16 kHz (the front end of Whisper-style speech models) over 256 x 30 s: ONE fused launch (csrc/lra_mixed.h) against the
+            framing + rocFFT + transpose + banded-product path it replaces (ctx option mixed = 0)."""
+            sr2, nf, hp, nm = 16000, 400, 160, 80
+            n2 = sr2 * CLIP_SECONDS
+            y2 = y[:, :n2].contiguous()
+            out = {}
+            for key, opt in (("fused", 1), ("rocfft_path", 0)):
+                ctx.set_option("mixed", opt)
+                try:
+                    fn = lambda: L.feature.melspectrogram(y=y2, sr=sr2, n_fft=nf, hop_length=hp, n_mels=nm, check_finite=False)
+                    T2 = int(fn().shape[-1])
+                    _, e = timed(fn, 5, 2, collective=False, ramp_ms=args.prewarm_ms / 4)
+                    per = e / 5
+                    fs = lambda: L.stft(y2, n_fft=nf, hop_length=hp, check_finite=False)
+                    _, e2 = timed(fs, 5, 2, collective=False, ramp_ms=args.prewarm_ms / 4)
+                    per2 = e2 / 5
+                    out[key] = {"mel_ms": per * 1e3, "mel_frames_per_s": batch * T2 / per, "mel_GBps_algorithmic": batch * T2 * (hp * 4 + nm * 4) / per / 1e9,
+                                "stft_ms": per2 * 1e3, "stft_GBps_algorithmic": batch * T2 * (hp * 4 + (nf // 2 + 1) * 8) / per2 / 1e9}
+                finally:
+                    ctx.set_option("mixed", 1)
+            out["workload"] = f"feature.melspectrogram / stft, n_fft=400 hop=160 n_mels=80 @ 16 kHz, {batch} clips x {CLIP_SECONDS} s (device tensors, public drop-in)"
+            return out
+
+        measure("mixed_radix_400", mixed_radix)
         # BASELINE config 5 (CQT-lite): three STFTs at n_fft = 512 / 2048 / 8192 over the same batch, shared hop 512
         if not args.no_cqt:
             def cqt_lite():

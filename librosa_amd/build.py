@@ -57,6 +57,7 @@ def build(force=False, verbose=True, extra_flags=(), out=OUT):
     os.makedirs(OBJ, exist_ok=True)
     tag = "_" + str(abs(hash(tuple(extra_flags))) % 10**8) if extra_flags else ""
     jobs = [([hipcc, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, "lra_api.hip"), "-o", os.path.join(OBJ, f"api{tag}.o")])]
+    jobs.append([hipcc, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, "lra_mixed_inst.hip"), "-o", os.path.join(OBJ, f"mixed{tag}.o")])
     for g in range(n_groups()):
         jobs.append([hipcc, *FLAGS, *extra_flags, f"-DLRA_INST_GROUP={g}", "-c", os.path.join(CSRC, "lra_inst.hip"), "-o", os.path.join(OBJ, f"inst{tag}_{g}.o")])
 

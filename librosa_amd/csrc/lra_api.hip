@@ -31,6 +31,7 @@
 #include "lra_cqt.h"
 #include "lra_hpss.h"
 #include "lra_probe.h"
+#include "lra_mixed_launch.h"
 
 using namespace lra;
 
@@ -76,6 +77,7 @@ struct lra_ctx {
     int opt_generic_mel = 0;         // force the generic banded mel path (tests)
     int opt_lds_pad = 0;             // extra dynamic LDS per workgroup (occupancy experiments)
     int opt_v2 = 1;                  // second-generation forward kernel where it applies (lra_kernels2.h)
+    int opt_mixed = 1;               // fused mixed-radix forward kernel for the listed non-power-of-two frame lengths (lra_mixed.h); 0: rocFFT path
     int opt_direct = 1;              // direct framing (no ring) for hop >= n_fft
     int opt_xcd_remap = 1;           // workgroup -> work item map that keeps neighbouring strips on one XCD (lra_kernels.h, xcd_block)
     unsigned int* d_flag = nullptr;  // non-finite input flag (device)
@@ -226,6 +228,9 @@ struct lra_stft_plan {
     void* d_twr = nullptr;
     FftPlanCache fft;
     Scratch frames, spec;
+    // mixed-radix fused path (lra_mixed.h): W_M^t (M entries) and W_N^k (M + 1 entries); null when n_fft is not in its size list
+    void* d_mtw = nullptr;
+    void* d_mtwn = nullptr;
 };
 
 struct lra_mel_plan {
@@ -907,6 +912,44 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
         }
         return launch(variant);
     }
+    // listed non-power-of-two frame lengths: one fused launch (lra_mixed.h)
+    if (p->d_mtw && ctx->opt_mixed) {
+        mixed::Args<T> a = mixed::Args<T>();
+        a.y = (const T*)y;
+        a.y_stride = y_stride;
+        a.n = n;
+        a.n_frames = (int)n_frames;
+        a.hop = p->hop;
+        a.pad = p->center ? p->n_fft / 2 : 0;
+        a.pad_mode = p->pad_mode;
+        a.win = (const T*)p->d_win;
+        a.tw_m = (const mixed::cpx<T>*)p->d_mtw;
+        a.tw_n = (const mixed::cpx<T>*)p->d_mtwn;
+        a.power_mode = power_mode_of(power);
+        a.power = (T)power;
+        const int F = mixed::frames_per_group_of(p->n_fft, (int)sizeof(T));
+        a.groups_per_clip = (int)((n_frames + F - 1) / F);
+        int mm = mixed::MIXED_COMPLEX;
+        if (mode == OUT_COMPLEX) {
+            a.D = (mixed::cpx<T>*)out;
+        } else if (mode == OUT_POWER) {
+            a.S = (T*)out;
+            mm = mixed::MIXED_POWER;
+        } else {
+            a.Mel = (T*)out;
+            a.mel_c0 = mel->d_c0;
+            a.mel_len = mel->d_len;
+            a.mel_off = mel->d_off;
+            a.mel_val = (const T*)mel->d_val;
+            a.n_mels = mel->n_mels;
+            mm = mixed::MIXED_MEL;
+        }
+        hipError_t e;
+        if constexpr (sizeof(T) == 8) e = mixed::launch_f64(p->n_fft, mm, a, batch, ctx->stream);
+        else e = mixed::launch_f32(p->n_fft, mm, a, batch, ctx->stream);
+        if (e != hipSuccess) return fail(LRA_EHIP, std::string("mixed-radix stft kernel launch: ") + hipGetErrorString(e));
+        return LRA_OK;
+    }
     // general path
     LRA_TRY(scratch_acquire(p->fft, ctx->stream));
     if (mode == OUT_COMPLEX) {
@@ -1401,6 +1444,7 @@ int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value) {
     else if (!std::strcmp(key, "xcd_remap")) ctx->opt_xcd_remap = value != 0;
     else if (!std::strcmp(key, "v2")) ctx->opt_v2 = value != 0;
     else if (!std::strcmp(key, "direct")) ctx->opt_direct = value != 0;
+    else if (!std::strcmp(key, "mixed")) ctx->opt_mixed = value != 0;
     else if (!std::strcmp(key, "autotune")) ctx->opt_autotune = value != 0;
     else if (!std::strcmp(key, "mel_runs")) ctx->opt_mel_runs = value != 0;
     else if (!std::strcmp(key, "variant")) ctx->opt_variant = (value >= 0 && value < kNumVariants) ? value : -1;
@@ -1533,6 +1577,23 @@ int lra_stft_plan_create(lra_ctx* ctx, int n_fft, int hop_length, const void* wi
     } else {
         rc = upload(&p->d_win, window_host, (size_t)n_fft * real_bytes(dtype));
     }
+    if (rc == LRA_OK && !p->pow2 && mixed::in_size_list(n_fft)) {
+        const int M = n_fft / 2;
+        const double two_pi = 6.283185307179586476925286766559;
+        if (dtype == LRA_F64) {
+            std::vector<cx<double>> t1(M), t2(M + 1);
+            for (int t = 0; t < M; ++t) t1[t] = mk<double>(std::cos(-two_pi * t / M), std::sin(-two_pi * t / M));
+            for (int k = 0; k <= M; ++k) t2[k] = mk<double>(std::cos(-two_pi * k / n_fft), std::sin(-two_pi * k / n_fft));
+            rc = upload(&p->d_mtw, t1.data(), t1.size() * sizeof(cx<double>));
+            if (rc == LRA_OK) rc = upload(&p->d_mtwn, t2.data(), t2.size() * sizeof(cx<double>));
+        } else {
+            std::vector<cx<float>> t1(M), t2(M + 1);
+            for (int t = 0; t < M; ++t) t1[t] = mk<float>((float)std::cos(-two_pi * t / M), (float)std::sin(-two_pi * t / M));
+            for (int k = 0; k <= M; ++k) t2[k] = mk<float>((float)std::cos(-two_pi * k / n_fft), (float)std::sin(-two_pi * k / n_fft));
+            rc = upload(&p->d_mtw, t1.data(), t1.size() * sizeof(cx<float>));
+            if (rc == LRA_OK) rc = upload(&p->d_mtwn, t2.data(), t2.size() * sizeof(cx<float>));
+        }
+    }
     if (rc == LRA_OK && p->pow2) {
         p->logm = log2_exact(n_fft) - 1;
         rc = dtype == LRA_F64 ? build_tables<double>(p->logm, p->d_tw, &p->d_twr) : build_tables<float>(p->logm, p->d_tw, &p->d_twr);
@@ -1552,6 +1613,8 @@ void lra_stft_plan_destroy(lra_stft_plan* p) {
     for (int v = 0; v < kNumVariants; ++v)
         if (p->d_tw[v]) (void)hipFree(p->d_tw[v]);
     if (p->d_twr) (void)hipFree(p->d_twr);
+    if (p->d_mtw) (void)hipFree(p->d_mtw);
+    if (p->d_mtwn) (void)hipFree(p->d_mtwn);
     delete p;
 }
 

@@ -1,0 +1,300 @@
+// lra_mixed.h -- fused forward transform for frame lengths that are not powers of two: n_fft = 2 M with M = 2^a 3^b 5^c
+// (400 = the 25 ms frame of 16 kHz speech front ends, 320, 480, 640, 800, 960, 1200, 1600, ...).
+//
+// Reference semantics: librosa/core/spectrum.py:57-391 (stft: centre padding :287, framing :330-350, window multiply + rfft of the
+// frames :380-390), :2920-3015 (_spectrogram: |X|^power), librosa/feature/spectral.py:2158-2160 (melspectrogram: basis . |X|^power).
+//
+// Round 3 served these sizes through frame_window_kernel -> rocFFT -> power_transpose_kernel -> mel_apply_kernel: the 4 x overlapped
+// frames were materialised in HBM (0.9-1.1 TB/s of algorithmic traffic).  Here ONE launch reads the PCM, transforms in LDS and writes
+// the complex spectrum, |X|^p or the mel bands; nothing else touches HBM.
+//
+// Structure (deliberately different from the power-of-two kernels, whose one-wave-per-frame register tiling has no counterpart for
+// M = 200): a workgroup of 256 threads owns F consecutive frames of one clip at a time, resident in LDS as M complex points each
+// (z[n] = x[2n] + i x[2n+1] times the window pair: the usual even/odd packing), and every stage hands its work items -- butterflies,
+// split bins, mel bands -- to the threads by a flat index, so no stage cares how M factors against the wave size.  Stages, separated
+// by workgroup barriers: (1) frame load + window (np.pad index fold for centred frames at the clip's edges), (2) one Stockham pass per
+// radix in {8, 5, 4, 3, 2} ping-ponging between two LDS buffers, twiddles W_M^t from an LDS table, (3) Hermitian split with W_N^k and the
+// epilogue.  All index arithmetic is on compile-time constants (N is a template parameter): divisions are multiplications.
+//
+// Self-contained (threadIdx / __shared__ / __syncthreads only): the whole kernel also runs in tests/hostsim/postsim.cpp, one OS thread
+// per lane, against the oracle.
+#pragma once
+
+#ifndef LRA_POSTSIM
+#include <hip/hip_runtime.h>
+#endif
+
+namespace lra {
+namespace mixed {
+
+template <class T> struct alignas(2 * sizeof(T)) cpx {
+    T x, y;
+};
+template <class T> __device__ __forceinline__ cpx<T> mkc(T x, T y) { cpx<T> r; r.x = x; r.y = y; return r; }
+template <class T> __device__ __forceinline__ cpx<T> add(cpx<T> a, cpx<T> b) { return mkc<T>(a.x + b.x, a.y + b.y); }
+template <class T> __device__ __forceinline__ cpx<T> sub(cpx<T> a, cpx<T> b) { return mkc<T>(a.x - b.x, a.y - b.y); }
+template <class T> __device__ __forceinline__ cpx<T> mul(cpx<T> a, cpx<T> b) { return mkc<T>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+template <class T> __device__ __forceinline__ cpx<T> mul_mi(cpx<T> a) { return mkc<T>(a.y, -a.x); }  // a * (-i)
+template <class T> __device__ __forceinline__ cpx<T> scale(cpx<T> a, T k) { return mkc<T>(a.x * k, a.y * k); }
+
+// ---- factorisation of M (compile time) ---------------------------------------------------------------------------------------
+struct Radices {
+    int r[12];
+    int n;
+};
+constexpr Radices factor(int M) {
+    Radices f{};
+    f.n = 0;
+    // radix-8 passes first, then one 4 or 2 for what is left of the power of two, then the fives and threes
+    while (M % 8 == 0) { f.r[f.n++] = 8; M /= 8; }
+    if (M % 4 == 0) { f.r[f.n++] = 4; M /= 4; }
+    if (M % 2 == 0) { f.r[f.n++] = 2; M /= 2; }
+    while (M % 5 == 0) { f.r[f.n++] = 5; M /= 5; }
+    while (M % 3 == 0) { f.r[f.n++] = 3; M /= 3; }
+    if (M != 1) f.n = 0;  // another prime: not served here
+    return f;
+}
+constexpr bool supported(int N) { return N >= 12 && N % 2 == 0 && N / 2 <= 4096 && factor(N / 2).n > 0; }
+constexpr int stride_before(const Radices& f, int p) {
+    int s = 1;
+    for (int q = 0; q < p; ++q) s *= f.r[q];
+    return s;
+}
+// frames per workgroup: two ping-pong buffers of M complex points per frame + the W_M table in ~24 KB, i.e. six or seven workgroups per
+// CU: every stage ends in a workgroup barrier and starts with loads, so what hides the latencies is OTHER workgroups in other stages.
+// Measured on the MI355X, n_fft 400 / hop 160 / 80 mels, 256 x 30 s (profiles/r04_experiments.md section 5): 16 frames per workgroup (51 KB,
+// three workgroups per CU) 1.39 ms, 12: 1.16, 8: 1.08, 6: 0.94, 4: 0.99; 64- or 128-thread workgroups 1.45-2.5 ms.
+#ifndef LRA_MIXED_FMAX
+#define LRA_MIXED_FMAX 8
+#endif
+#ifndef LRA_MIXED_LDS_KB
+#define LRA_MIXED_LDS_KB 24
+#endif
+template <class T, int N> constexpr int frames_per_group() {
+    constexpr int M = N / 2;
+    int f = (int)((LRA_MIXED_LDS_KB * 1024 - M * 2 * (int)sizeof(T)) / (2 * M * 2 * (int)sizeof(T)));
+    return f < 1 ? 1 : (f > LRA_MIXED_FMAX ? LRA_MIXED_FMAX : f);
+}
+template <class T, int N> constexpr int lds_bytes() { return (2 * frames_per_group<T, N>() * (N / 2) + N / 2) * 2 * (int)sizeof(T); }
+
+enum { MIXED_COMPLEX = 0, MIXED_POWER = 1, MIXED_MEL = 2 };
+#ifndef LRA_MIXED_NT
+#define LRA_MIXED_NT 256
+#endif
+constexpr int NT = LRA_MIXED_NT;  // threads per workgroup
+
+template <class T> struct Args {
+    const T* y;            // [batch][y_stride]
+    long long y_stride, n;
+    int n_frames, hop, pad, pad_mode;  // pad = n_fft / 2 when centred; pad_mode: 0 constant, 1 reflect, 2 edge, 3 symmetric (np.pad)
+    const T* win;          // [N] window padded to n_fft (NOT halved)
+    const cpx<T>* tw_m;    // [M]     W_M^t = exp(-2 pi i t / M)
+    const cpx<T>* tw_n;    // [M + 1] W_N^k = exp(-2 pi i k / N)
+    cpx<T>* D;             // MIXED_COMPLEX: [batch][n_frames][M + 1]
+    T* S;                  // MIXED_POWER:   [batch][n_frames][M + 1]
+    T* Mel;                // MIXED_MEL:     [batch][n_mels][n_frames]
+    int power_mode;        // 1: |X|, 2: |X|^2, 0: |X|^power
+    T power;
+    const int* mel_c0;     // band m covers bins [c0, c0 + len), weights mel_val[off + i]
+    const int* mel_len;
+    const int* mel_off;
+    const T* mel_val;
+    int n_mels;
+    int groups_per_clip;   // ceil(n_frames / F)
+};
+
+// sample g of a clip of n samples under np.pad's modes; matches lra::pad_index (lra_common.h) and np.pad incl. repeated reflection
+template <class T> __device__ __forceinline__ T fetch(const T* __restrict__ yb, long long g, long long n, int mode) {
+    if (g >= 0 && g < n) return yb[g];
+    if (n <= 0 || mode == 0) return (T)0;
+    if (mode == 2 || n == 1) return yb[g < 0 ? 0 : n - 1];
+    const long long lo = mode == 1 ? 0 : -1, hi = mode == 1 ? 2 * (n - 1) : 2 * n - 1;
+    while (g < 0 || g >= n) g = g < 0 ? lo - g : hi - g;
+    return yb[g];
+}
+
+// ---- small forward DFTs, natural order in and out ---------------------------------------------------------------------------------
+template <int R, class T> struct Dft;
+template <class T> struct Dft<2, T> {
+    static __device__ __forceinline__ void run(cpx<T>* v) {
+        const cpx<T> a = v[0], b = v[1];
+        v[0] = add(a, b);
+        v[1] = sub(a, b);
+    }
+};
+template <class T> struct Dft<3, T> {
+    static __device__ __forceinline__ void run(cpx<T>* v) {
+        const T s = (T)0.86602540378443864676;  // sin(2 pi / 3)
+        const cpx<T> t1 = add(v[1], v[2]), d = scale(mul_mi(sub(v[1], v[2])), s);  // -i s (b - c)
+        const cpx<T> m = mkc<T>(v[0].x - (T)0.5 * t1.x, v[0].y - (T)0.5 * t1.y);
+        v[0] = add(v[0], t1);
+        v[1] = add(m, d);
+        v[2] = sub(m, d);
+    }
+};
+template <class T> struct Dft<4, T> {
+    static __device__ __forceinline__ void run(cpx<T>* v) {
+        const cpx<T> a = add(v[0], v[2]), b = sub(v[0], v[2]), c = add(v[1], v[3]), d = mul_mi(sub(v[1], v[3]));
+        v[0] = add(a, c);
+        v[1] = add(b, d);
+        v[2] = sub(a, c);
+        v[3] = sub(b, d);
+    }
+};
+template <class T> struct Dft<5, T> {
+    static __device__ __forceinline__ void run(cpx<T>* v) {
+        const T c1 = (T)0.30901699437494742410, c2 = (T)-0.80901699437494742410;  // cos(2 pi / 5), cos(4 pi / 5)
+        const T s1 = (T)0.95105651629515357212, s2 = (T)0.58778525229247312917;   // sin(2 pi / 5), sin(4 pi / 5)
+        const cpx<T> t1 = add(v[1], v[4]), t2 = add(v[2], v[3]), t3 = sub(v[1], v[4]), t4 = sub(v[2], v[3]);
+        const cpx<T> m1 = mkc<T>(v[0].x + c1 * t1.x + c2 * t2.x, v[0].y + c1 * t1.y + c2 * t2.y);
+        const cpx<T> m2 = mkc<T>(v[0].x + c2 * t1.x + c1 * t2.x, v[0].y + c2 * t1.y + c1 * t2.y);
+        const cpx<T> n1 = mul_mi(mkc<T>(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y));  // -i (s1 t3 + s2 t4)
+        const cpx<T> n2 = mul_mi(mkc<T>(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y));  // -i (s2 t3 - s1 t4)
+        v[0] = add(v[0], add(t1, t2));
+        v[1] = add(m1, n1);
+        v[4] = sub(m1, n1);
+        v[2] = add(m2, n2);
+        v[3] = sub(m2, n2);
+    }
+};
+template <class T> struct Dft<8, T> {
+    static __device__ __forceinline__ void run(cpx<T>* v) {
+        const T h = (T)0.70710678118654752440;
+        cpx<T> e[4] = {v[0], v[2], v[4], v[6]}, o[4] = {v[1], v[3], v[5], v[7]};
+        Dft<4, T>::run(e);
+        Dft<4, T>::run(o);
+        const cpx<T> o1 = scale(mkc<T>(o[1].x + o[1].y, o[1].y - o[1].x), h);   // o1 * W8^1 = o1 (1 - i) / sqrt 2
+        const cpx<T> o2 = mul_mi(o[2]);                                          // o2 * W8^2 = -i o2
+        const cpx<T> o3 = scale(mkc<T>(o[3].y - o[3].x, -(o[3].x + o[3].y)), h);  // o3 * W8^3 = o3 (-1 - i) / sqrt 2
+        v[0] = add(e[0], o[0]); v[4] = sub(e[0], o[0]);
+        v[1] = add(e[1], o1);   v[5] = sub(e[1], o1);
+        v[2] = add(e[2], o2);   v[6] = sub(e[2], o2);
+        v[3] = add(e[3], o3);   v[7] = sub(e[3], o3);
+    }
+};
+
+#ifdef LRA_POSTSIM
+#define LRA_MIXED_DYN_LDS(ptr) char* ptr = reinterpret_cast<char*>(g_postsim_dyn_lds)
+#else
+#define LRA_MIXED_DYN_LDS(ptr) extern __shared__ __align__(16) char lra_mixed_dyn_lds[]; char* ptr = lra_mixed_dyn_lds
+#endif
+
+// One Stockham pass of radix R over the F frames in `src` (stride S = product of the earlier radices): butterfly b of a frame reads
+// src[b + j M / R], multiplies input j by W_{S R}^{(b mod S) j} = W_M^{(b mod S) j M / (S R)} and writes output j to
+// dst[(b - b mod S) R + (b mod S) + j S].  Work items (frame, butterfly) are dealt to the threads by a flat index.
+template <class T, int N, int R, int S, int F> __device__ __forceinline__ void pass(const cpx<T>* src, cpx<T>* dst, const cpx<T>* twm, int frames) {
+    constexpr int M = N / 2, NB = M / R, TWS = M / (S * R);
+    for (int w = (int)threadIdx.x; w < frames * NB; w += NT) {
+        const int f = w / NB, b = w - f * NB, k = b % S;
+        const cpx<T>* s = src + f * M + b;
+        cpx<T> v[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) v[j] = s[j * NB];
+        if (S > 1) {
+#pragma unroll
+            for (int j = 1; j < R; ++j) v[j] = mul(v[j], twm[k * j * TWS]);
+        }
+        Dft<R, T>::run(v);
+        cpx<T>* d = dst + f * M + (b - k) * R + k;
+#pragma unroll
+        for (int j = 0; j < R; ++j) d[j * S] = v[j];
+    }
+}
+
+// the passes of factor(M), unrolled at compile time; returns (through the pointer swap) the buffer that holds the result
+template <class T, int N, int P, int F> struct Passes {
+    static __device__ __forceinline__ void run(cpx<T>*& a, cpx<T>*& b, const cpx<T>* twm, int frames) {
+        constexpr Radices f = factor(N / 2);
+        if constexpr (P < f.n) {
+            pass<T, N, f.r[P], stride_before(f, P), F>(a, b, twm, frames);
+            __syncthreads();
+            cpx<T>* t = a; a = b; b = t;
+            Passes<T, N, P + 1, F>::run(a, b, twm, frames);
+        }
+    }
+};
+
+template <class T> __device__ __forceinline__ T spec_pow(cpx<T> x, int mode, T p) {
+    const T m2 = x.x * x.x + x.y * x.y;
+    if (mode == 2) return m2;
+    const T m = sqrt(m2);
+    if (mode == 1) return m;
+    return pow(m, p);
+}
+
+// grid = batch * groups_per_clip workgroups of NT threads; dynamic LDS = lds_bytes<T, N>()
+template <class T, int N, int MODE> __global__ __launch_bounds__(NT) void mixed_stft_kernel(Args<T> a) {
+    constexpr int M = N / 2, F = frames_per_group<T, N>();
+    LRA_MIXED_DYN_LDS(lds);
+    cpx<T>* buf0 = reinterpret_cast<cpx<T>*>(lds);
+    cpx<T>* buf1 = buf0 + F * M;
+    cpx<T>* twm = buf1 + F * M;
+    const int clip = (int)(blockIdx.x / (unsigned)a.groups_per_clip), group = (int)(blockIdx.x % (unsigned)a.groups_per_clip);
+    const int f0 = group * F;
+    const int frames = a.n_frames - f0 < F ? a.n_frames - f0 : F;
+    const T* __restrict__ yb = a.y + (long long)clip * a.y_stride;
+    // (1) W_M table -> LDS; frames -> buf0 as window-multiplied sample pairs
+    for (int t = (int)threadIdx.x; t < M; t += NT) twm[t] = a.tw_m[t];
+    const cpx<T>* __restrict__ win2 = reinterpret_cast<const cpx<T>*>(a.win);
+    for (int w = (int)threadIdx.x; w < frames * M; w += NT) {
+        const int f = w / M, i = w - f * M;
+        const long long g = (long long)(f0 + f) * a.hop - a.pad + 2 * i;  // clip position of the pair's first sample
+        cpx<T> x;
+        if (g >= 0 && g + 1 < a.n) {
+            x = mkc<T>(yb[g], yb[g + 1]);
+        } else {
+            x = mkc<T>(fetch<T>(yb, g, a.n, a.pad_mode), fetch<T>(yb, g + 1, a.n, a.pad_mode));
+        }
+        const cpx<T> wv = win2[i];
+        buf0[w] = mkc<T>(x.x * wv.x, x.y * wv.y);
+    }
+    __syncthreads();
+    // (2) M-point complex FFT of every frame
+    cpx<T>* src = buf0;
+    cpx<T>* dst = buf1;
+    Passes<T, N, 0, F>::run(src, dst, twm, frames);
+    // (3) Hermitian split.  With E = (Z[k] + conj Z[M-k]) / 2, O = (Z[k] - conj Z[M-k]) / 2 and P = W_N^k O:
+    //       X[k] = E - i P,   X[M-k] = conj(E) - i conj(P)      (W_N^{M-k} = -conj W_N^k),
+    // so one work item per pair (k, M - k), k = 0 .. M/2, reads its two points once and writes both bins (k = 0: the DC and Nyquist bins
+    // from Z[0]; k = M/2, M even: one self-paired bin).
+    T* prow = reinterpret_cast<T*>(dst);  // MIXED_MEL: the power rows go to the buffer the FFT no longer needs ((M + 1) values per frame <= 2 M)
+    constexpr int HP = M / 2 + 1;         // pairs per frame
+    for (int w = (int)threadIdx.x; w < frames * HP; w += NT) {
+        const int f = w / HP, k = w - f * HP;
+        const cpx<T> zk = src[f * M + k], zr = src[f * M + (k == 0 ? 0 : M - k)];
+        const cpx<T> e = mkc<T>((T)0.5 * (zk.x + zr.x), (T)0.5 * (zk.y - zr.y)), o = mkc<T>((T)0.5 * (zk.x - zr.x), (T)0.5 * (zk.y + zr.y));
+        const cpx<T> pw = mul(o, a.tw_n[k]);
+        cpx<T> xk = mkc<T>(e.x + pw.y, e.y - pw.x), xm = mkc<T>(e.x - pw.y, -e.y - pw.x);
+        if (k == 0) { xk.y = (T)0; xm.y = (T)0; }  // DC and Nyquist: purely real by construction (rounding leaves -0 / +0 differences otherwise)
+        const long long row = ((long long)clip * a.n_frames + f0 + f) * (M + 1);
+        const bool two = 2 * k != M;  // (k = M/2 pairs with itself: xk == xm up to the sign of zero)
+        if (MODE == MIXED_COMPLEX) {
+            a.D[row + k] = xk;
+            if (two) a.D[row + M - k] = xm;
+        } else if (MODE == MIXED_POWER) {
+            a.S[row + k] = spec_pow<T>(xk, a.power_mode, a.power);
+            if (two) a.S[row + M - k] = spec_pow<T>(xm, a.power_mode, a.power);
+        } else {
+            prow[f * (M + 1) + k] = spec_pow<T>(xk, a.power_mode, a.power);
+            if (two) prow[f * (M + 1) + M - k] = spec_pow<T>(xm, a.power_mode, a.power);
+        }
+    }
+    if (MODE == MIXED_MEL) {
+        __syncthreads();
+        // mel[m][f] = sum_i val[off_m + i] P[f][c0_m + i]: a work item per (band, frame), frames fastest -- the F frames of a band are
+        // consecutive in the output
+        for (int w = (int)threadIdx.x; w < a.n_mels * F; w += NT) {
+            const int m = w / F, f = w - m * F;
+            if (f >= frames) continue;
+            const int c0 = a.mel_c0[m], len = a.mel_len[m];
+            const T* __restrict__ val = a.mel_val + a.mel_off[m];
+            const T* p = prow + f * (M + 1) + c0;
+            T acc = (T)0;
+            for (int i = 0; i < len; ++i) acc += val[i] * p[i];
+            a.Mel[((long long)clip * a.n_mels + m) * a.n_frames + f0 + f] = acc;
+        }
+    }
+}
+
+}  // namespace mixed
+}  // namespace lra

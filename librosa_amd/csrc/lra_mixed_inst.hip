@@ -1,0 +1,51 @@
+// lra_mixed_inst.hip -- instances and launcher of the mixed-radix fused forward kernels (lra_mixed.h), a translation unit of its own so
+// that it compiles side by side with lra_api.hip and the power-of-two instance groups (librosa_amd/build.py).
+#include "lra_mixed.h"
+
+#include "lra_mixed_launch.h"
+
+namespace lra {
+namespace mixed {
+namespace {
+
+template <class T, int N> hipError_t launch_n(int mode, const Args<T>& a, long long batch, hipStream_t stream) {
+    constexpr int lds = lds_bytes<T, N>();
+    const long long grid = batch * a.groups_per_clip;
+    if (grid <= 0) return hipSuccess;
+    if (grid > 0x7ffffff0LL) return hipErrorInvalidConfiguration;
+    void (*kern)(Args<T>) = mode == MIXED_COMPLEX ? mixed_stft_kernel<T, N, MIXED_COMPLEX> : (mode == MIXED_POWER ? mixed_stft_kernel<T, N, MIXED_POWER> : mixed_stft_kernel<T, N, MIXED_MEL>);
+    if (lds > 65536) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, a);
+    return hipGetLastError();
+}
+
+template <class T> hipError_t launch_t(int n_fft, int mode, const Args<T>& a, long long batch, hipStream_t stream) {
+    switch (n_fft) {
+#define LRA_MIXED_CASE(N) \
+    case N: return launch_n<T, N>(mode, a, batch, stream);
+        LRA_MIXED_SIZES(LRA_MIXED_CASE)
+#undef LRA_MIXED_CASE
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+int frames_per_group_of(int n_fft, int elem_bytes) {
+    switch (n_fft) {
+#define LRA_MIXED_CASE(N) \
+    case N: return elem_bytes == 8 ? frames_per_group<double, N>() : frames_per_group<float, N>();
+        LRA_MIXED_SIZES(LRA_MIXED_CASE)
+#undef LRA_MIXED_CASE
+        default: return 0;
+    }
+}
+
+hipError_t launch_f32(int n_fft, int mode, const Args<float>& a, long long batch, hipStream_t stream) { return launch_t<float>(n_fft, mode, a, batch, stream); }
+hipError_t launch_f64(int n_fft, int mode, const Args<double>& a, long long batch, hipStream_t stream) { return launch_t<double>(n_fft, mode, a, batch, stream); }
+
+}  // namespace mixed
+}  // namespace lra

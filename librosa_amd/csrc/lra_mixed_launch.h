@@ -1,0 +1,29 @@
+// lra_mixed_launch.h -- what lra_api.hip sees of the mixed-radix kernels: the list of frame lengths they are instantiated for and the
+// launcher (defined in lra_mixed_inst.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "lra_mixed.h"
+
+// frame lengths n_fft = 2 M, M = 2^a 3^b 5^c, served by one fused launch (everything else that is not a power of two keeps the rocFFT
+// path): the 15 / 20 / 25 / 30 / 40 / 50 / 60 ms frames of 8, 16, 22.05 (rounded), 32 and 48 kHz front ends and their doubles
+#define LRA_MIXED_SIZES(X) X(160) X(200) X(240) X(320) X(400) X(480) X(640) X(800) X(960) X(1000) X(1200) X(1280) X(1440) X(1600) X(1920) X(2000) X(2400) X(3200) X(4800)
+
+namespace lra {
+namespace mixed {
+constexpr bool in_size_list(int n_fft) {
+#define LRA_MIXED_CASE(N) \
+    if (n_fft == N) return true;
+    LRA_MIXED_SIZES(LRA_MIXED_CASE)
+#undef LRA_MIXED_CASE
+    return false;
+}
+#define LRA_MIXED_CHECK(N) static_assert(supported(N), "n_fft = " #N ": n_fft / 2 must factor into 2, 3 and 5");
+LRA_MIXED_SIZES(LRA_MIXED_CHECK)
+#undef LRA_MIXED_CHECK
+int frames_per_group_of(int n_fft, int elem_bytes);
+hipError_t launch_f32(int n_fft, int mode, const Args<float>& a, long long batch, hipStream_t stream);
+hipError_t launch_f64(int n_fft, int mode, const Args<double>& a, long long batch, hipStream_t stream);
+}  // namespace mixed
+}  // namespace lra

@@ -6,7 +6,7 @@ mkdir -p $R/probe
 pids=()
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
-  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DLRA_PROBE_ONLY $flags $R/librosa_amd/csrc/lra_api.hip -o $R/probe/lib_$name.so \
+  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DLRA_PROBE_ONLY $flags $R/librosa_amd/csrc/lra_api.hip $R/librosa_amd/csrc/lra_mixed_inst.hip -o $R/probe/lib_$name.so \
       -L/opt/rocm/lib -lrocfft -Wl,-rpath,/opt/rocm/lib > /tmp/probe_$name.log 2>&1 || { echo "probe build $name FAILED"; grep -E "error" /tmp/probe_$name.log | head -5; } ) &
   pids+=($!)
 done

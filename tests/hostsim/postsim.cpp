@@ -55,6 +55,7 @@ alignas(16) static unsigned char g_postsim_dyn_lds[64 * 1024];  // the dynamic L
 #include "../../librosa_amd/csrc/lra_pcen.h"
 #include "../../librosa_amd/csrc/lra_cqt.h"
 #include "../../librosa_amd/csrc/lra_hpss.h"
+#include "../../librosa_amd/csrc/lra_mixed.h"
 
 namespace {
 template <class F> void run_grid(unsigned grid, unsigned block, F body) {
@@ -193,3 +194,52 @@ int postsim_hpss(const void* mag, const void* D, void* out_h, void* out_p, long 
     return 0;
 }
 }
+
+// ---- mixed-radix fused forward kernel (librosa_amd/csrc/lra_mixed.h), the launch of stft_run's mixed branch (lra_api.hip) ----------------------
+namespace {
+template <class T, int N> int sim_mixed(int mode, lra::mixed::Args<T> a, long long batch) {
+    using namespace lra::mixed;
+    constexpr int F = frames_per_group<T, N>();
+    static_assert(lds_bytes<T, N>() <= (int)sizeof(g_postsim_dyn_lds), "simulated LDS too small");
+    a.groups_per_clip = (a.n_frames + F - 1) / F;
+    const unsigned grid = (unsigned)(batch * a.groups_per_clip);
+    if (mode == MIXED_COMPLEX) run_grid(grid, NT, [=] { mixed_stft_kernel<T, N, MIXED_COMPLEX>(a); });
+    else if (mode == MIXED_POWER) run_grid(grid, NT, [=] { mixed_stft_kernel<T, N, MIXED_POWER>(a); });
+    else run_grid(grid, NT, [=] { mixed_stft_kernel<T, N, MIXED_MEL>(a); });
+    return 0;
+}
+template <class T> int sim_mixed_n(int n_fft, int mode, const lra::mixed::Args<T>& a, long long batch) {
+    switch (n_fft) {  // (a few of the product's sizes: every radix, one and several passes of each)
+        case 160: return sim_mixed<T, 160>(mode, a, batch);
+        case 240: return sim_mixed<T, 240>(mode, a, batch);
+        case 400: return sim_mixed<T, 400>(mode, a, batch);
+        case 480: return sim_mixed<T, 480>(mode, a, batch);
+        case 1000: return sim_mixed<T, 1000>(mode, a, batch);
+        case 1200: return sim_mixed<T, 1200>(mode, a, batch);
+        case 1280: return sim_mixed<T, 1280>(mode, a, batch);
+        default: return 1;
+    }
+}
+}  // namespace
+
+extern "C" int postsim_mixed_stft(int n_fft, int mode, int is_f64, const void* y, long long batch, long long n, int n_frames, int hop, int pad, int pad_mode, const void* win,
+                                  const void* tw_m, const void* tw_n, void* out, int power_mode, double power, const int* mel_c0, const int* mel_len, const int* mel_off,
+                                  const void* mel_val, int n_mels) {
+    auto fill = [&](auto& a, auto tag) {
+        using T = decltype(tag);
+        a.y = (const T*)y; a.y_stride = n; a.n = n; a.n_frames = n_frames; a.hop = hop; a.pad = pad; a.pad_mode = pad_mode;
+        a.win = (const T*)win; a.tw_m = (const lra::mixed::cpx<T>*)tw_m; a.tw_n = (const lra::mixed::cpx<T>*)tw_n;
+        a.D = (lra::mixed::cpx<T>*)out; a.S = (T*)out; a.Mel = (T*)out;
+        a.power_mode = power_mode; a.power = (T)power;
+        a.mel_c0 = mel_c0; a.mel_len = mel_len; a.mel_off = mel_off; a.mel_val = (const T*)mel_val; a.n_mels = n_mels;
+    };
+    if (is_f64) {
+        lra::mixed::Args<double> a = lra::mixed::Args<double>();
+        fill(a, double());
+        return sim_mixed_n<double>(n_fft, mode, a, batch);
+    }
+    lra::mixed::Args<float> a = lra::mixed::Args<float>();
+    fill(a, float());
+    return sim_mixed_n<float>(n_fft, mode, a, batch);
+}
+

@@ -150,7 +150,7 @@ _post = None
 def post_lib():
     global _post
     if _post is None:
-        deps = [POST_SRC] + [os.path.join(CSRC, h) for h in ("lra_pcen.h", "lra_cqt.h", "lra_hpss.h")]
+        deps = [POST_SRC] + [os.path.join(CSRC, h) for h in ("lra_pcen.h", "lra_cqt.h", "lra_hpss.h", "lra_mixed.h")]
         if not os.path.exists(POST_SO) or any(os.path.getmtime(d) > os.path.getmtime(POST_SO) for d in deps):
             subprocess.check_call(["g++", "-O1", "-std=c++17", "-w", "-fPIC", "-shared", "-pthread", POST_SRC, "-o", POST_SO])
         _post = ctypes.CDLL(POST_SO)
@@ -220,3 +220,39 @@ def hpss(D, *, win_harm=31, win_perc=31, power=2.0, margin_harm=1.0, margin_perc
     post_lib().postsim_hpss(_p(mag), _p(D) if cplx else None, _p(oh), _p(op), D.shape[0], D.shape[1], D.shape[2], int(win_harm), int(win_perc), float(power), float(margin_harm),
                             float(margin_perc), int(want_mask), int(real == np.float64))
     return oh, op
+
+
+def mixed_stft(y, n_fft, hop, window, *, mode="stft", center=True, pad_mode="constant", power=2.0, mel_basis=None):
+    """The fused mixed-radix forward kernel (csrc/lra_mixed.h) through the simulator, argument preparation as in lra_api.hip (stft_run / plan create).
+    y: (batch, n); returns (batch, n_frames, bins) complex / real for "stft" / "power", (batch, n_mels, n_frames) for "mel"."""
+    y = np.ascontiguousarray(y)
+    rt = y.dtype.type
+    ct = np.complex128 if y.dtype == np.float64 else np.complex64
+    batch, n = y.shape
+    M = n_fft // 2
+    pad = n_fft // 2 if center else 0
+    n_frames = 1 + (n + 2 * pad - n_fft) // hop
+    win = np.ascontiguousarray(window, dtype=rt)
+    t = np.arange(M, dtype=np.float64)
+    tw_m = np.ascontiguousarray(np.exp(-2j * np.pi * t / M).astype(ct))
+    tw_n = np.ascontiguousarray(np.exp(-2j * np.pi * np.arange(M + 1, dtype=np.float64) / n_fft).astype(ct))
+    code = {"stft": 0, "power": 1, "mel": 2}[mode]
+    c0 = ln = off = val = None
+    n_mels = 0
+    if mode == "mel":
+        c0, ln, off, val = mel_band(np.asarray(mel_basis, dtype=rt))
+        n_mels = mel_basis.shape[0]
+        out = np.full((batch, n_mels, n_frames), np.nan, dtype=rt)
+    elif mode == "power":
+        out = np.full((batch, n_frames, M + 1), np.nan, dtype=rt)
+    else:
+        out = np.full((batch, n_frames, M + 1), np.nan, dtype=ct)
+    pm = {"constant": 0, "reflect": 1, "edge": 2, "symmetric": 3}[pad_mode]
+    fn = post_lib().postsim_mixed_stft
+    c = ctypes
+    fn.argtypes = [c.c_int, c.c_int, c.c_int, c.c_void_p, c.c_longlong, c.c_longlong, c.c_int, c.c_int, c.c_int, c.c_int, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int, c.c_double,
+                   c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int]
+    rc = fn(n_fft, code, int(y.dtype == np.float64), _p(y), batch, n, n_frames, hop, pad, pm, _p(win), _p(tw_m), _p(tw_n), _p(out), 2 if power == 2.0 else (1 if power == 1.0 else 0), float(power),
+            _p(c0), _p(ln), _p(off), _p(val), n_mels)
+    assert rc == 0, f"n_fft={n_fft} is not among the simulator's mixed-radix sizes"
+    return out

@@ -1218,6 +1218,45 @@ def test_numpy_batch_shards_in_process(L, monkeypatch):
         L.stft(bad, n_fft=1024, hop_length=256)
 
 
+@pytest.mark.parametrize("n_fft,hop,sr,n_mels", [(400, 160, 16000, 80), (320, 160, 16000, 40), (480, 120, 48000, 64), (800, 200, 16000, 128), (960, 480, 48000, 80),
+                                                 (1200, 300, 48000, 128), (1600, 400, 16000, 80), (2400, 600, 48000, 128), (240, 80, 8000, 20), (4800, 1200, 48000, 128)])
+def test_mixed_radix_frames_fused(L, n_fft, hop, sr, n_mels):
+    """Frame lengths 2^a 3^b 5^c (400 / 160 = the 25 ms / 10 ms front end of 16 kHz speech models; reference sizes: tests/test_core.py:256-292) run ONE fused
+    launch (csrc/lra_mixed.h) instead of framing + rocFFT + transpose + banded product: stft, |X|^p and melspectrogram against the oracle, the pad modes,
+    float64, device tensors, and agreement with the rocFFT path they replace (ctx option "mixed")."""
+    import torch
+
+    rng = np.random.default_rng(n_fft + hop)
+    y = (0.1 * rng.standard_normal((3, 11 * n_fft + 17))).astype(np.float32)
+    ctx = L.get_context(0)
+    for center, pad_mode in ((True, "constant"), (True, "reflect"), (False, "constant")):
+        ref = O.stft(y, n_fft=n_fft, hop_length=hop, center=center, pad_mode=pad_mode)
+        D = L.stft(y, n_fft=n_fft, hop_length=hop, center=center, pad_mode=pad_mode)
+        assert D.shape == ref.shape and D.dtype == ref.dtype and _stft_close(D, ref), (center, pad_mode)
+    Mref = O.melspectrogram(y=y, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=n_mels)
+    M = L.feature.melspectrogram(y=y, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=n_mels)
+    assert M.shape == Mref.shape and _mel_close(M, Mref)
+    assert np.all(np.abs(M - Mref) <= 1e-4 * np.abs(Mref) + 1e-7 * Mref.max())
+    Mt = L.feature.melspectrogram(y=torch.from_numpy(y).cuda(), sr=sr, n_fft=n_fft, hop_length=hop, n_mels=n_mels).cpu().numpy()
+    assert np.array_equal(Mt, M)
+    S1 = L.feature.melspectrogram(y=y, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=n_mels, power=1.0)
+    assert _mel_close(S1, O.melspectrogram(y=y, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=n_mels, power=1.0))
+    y64 = y[:2].astype(np.float64)
+    assert _stft_close(L.stft(y64, n_fft=n_fft, hop_length=hop), O.stft(y64, n_fft=n_fft, hop_length=hop))
+    assert _mel_close(L.feature.melspectrogram(y=y64, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=n_mels), O.melspectrogram(y=y64, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=n_mels))
+    # the path it replaces, same inputs: both must satisfy the oracle, and each other to the same tolerance
+    try:
+        ctx.set_option("mixed", 0)
+        D0 = L.stft(y, n_fft=n_fft, hop_length=hop)
+        M0 = L.feature.melspectrogram(y=y, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=n_mels)
+    finally:
+        ctx.set_option("mixed", 1)
+    assert _stft_close(L.stft(y, n_fft=n_fft, hop_length=hop), D0) and _mel_close(M, M0)
+    # round trip through the (rocFFT) inverse
+    yh = L.istft(L.stft(y, n_fft=n_fft, hop_length=hop), hop_length=hop, n_fft=n_fft, length=y.shape[-1])
+    assert np.abs(yh - y).max() <= 2e-5
+
+
 def test_native_rccl_communicator(L):
     """lra_comm_* (RCCL bound at run time through the C ABI) at world size 1 -- all a one-GPU box can run: id, communicator on
     the context's device, an all-gather enqueued behind the kernel that produced its input."""

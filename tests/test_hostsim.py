@@ -717,3 +717,52 @@ def test_hpss_shims_through_simulator(monkeypatch):
         scale = np.abs(y).max()
         assert gh.shape == y.shape and gh.dtype == y.dtype and np.abs(gh - eh).max() <= 1e-5 * scale and np.abs(gp - ep).max() <= 1e-5 * scale, kw
         assert np.array_equal(effects.harmonic(y, **kw), gh) and np.array_equal(effects.percussive(y, **kw), gp)
+
+
+# ---- mixed-radix fused forward kernel (csrc/lra_mixed.h): the whole __global__ body on host threads against the oracle ---------------------------
+@pytest.mark.parametrize(
+    "n_fft,hop,n,center,pad_mode,dtype",
+    [
+        (400, 160, 4000, True, "constant", np.float32),    # 8 x 5 x 5: the 25 ms / 10 ms frames of 16 kHz front ends
+        (400, 160, 1900, True, "reflect", np.float32),
+        (400, 100, 2100, False, "constant", np.float32),
+        (240, 60, 1500, True, "edge", np.float32),         # 8 x 5 x 3
+        (160, 80, 1000, True, "symmetric", np.float32),    # 8 x 2 x 5
+        (480, 120, 2500, True, "constant", np.float64),    # 8 x 2 x 5 x 3, float64
+        (1000, 250, 5000, True, "reflect", np.float32),    # 4 x 5 x 5 x 5
+        (1200, 300, 6100, True, "constant", np.float32),   # 8 x 5 x 5 x 3: several frames per workgroup, a partial last group
+        (1280, 320, 5000, True, "constant", np.float32),   # 8 x 8 x 2 x 5
+    ],
+)
+def test_mixed_radix_stft_body(n_fft, hop, n, center, pad_mode, dtype):
+    """librosa/core/spectrum.py:57-391 for frame lengths 2^a 3^b 5^c through ONE fused launch: complex spectrum and |X|^2 against the oracle
+    (NaN-prefilled outputs: every element must be stored)."""
+    rng = np.random.default_rng(n_fft + hop)
+    y = rng.standard_normal((2, n)).astype(dtype)
+    win = O.get_window("hann", n_fft).astype(dtype)
+    ref = O.stft(y, n_fft=n_fft, hop_length=hop, center=center, pad_mode=pad_mode)
+    D = H.mixed_stft(y, n_fft, hop, win, mode="stft", center=center, pad_mode=pad_mode)
+    got = np.moveaxis(D, -1, -2)
+    assert got.shape == ref.shape and np.isfinite(D.view(dtype)).all()
+    scale = np.abs(ref).max()
+    tol = 1e-12 if dtype == np.float64 else 2e-6
+    assert np.abs(got - ref).max() <= tol * scale, np.abs(got - ref).max() / scale
+    assert np.all(got[:, 0].imag == 0) and np.all(got[:, -1].imag == 0)  # DC and Nyquist bins are exactly real, as pocketfft's are
+    S = np.moveaxis(H.mixed_stft(y, n_fft, hop, win, mode="power", center=center, pad_mode=pad_mode, power=2.0), -1, -2)
+    Sref = np.abs(ref) ** 2
+    assert np.all(np.abs(S - Sref) <= (1e-11 if dtype == np.float64 else 1e-5) * Sref.max())
+    S1 = np.moveaxis(H.mixed_stft(y[:1], n_fft, hop, win, mode="power", center=center, pad_mode=pad_mode, power=1.0), -1, -2)
+    assert np.all(np.abs(S1 - np.abs(ref[:1])) <= (1e-11 if dtype == np.float64 else 1e-5) * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("n_fft,hop,n_mels,sr,dtype", [(400, 160, 80, 16000, np.float32), (1200, 300, 64, 48000, np.float32), (240, 120, 20, 8000, np.float64)])
+def test_mixed_radix_mel_body(n_fft, hop, n_mels, sr, dtype):
+    """librosa/feature/spectral.py:2022-2161 through the same launch (banded basis from LDS power rows); the reference's float32 basis values."""
+    rng = np.random.default_rng(n_mels)
+    y = (0.1 * rng.standard_normal((2, 7 * n_fft + 13))).astype(dtype)
+    win = O.get_window("hann", n_fft).astype(dtype)
+    B = O.mel(sr=sr, n_fft=n_fft, n_mels=n_mels).astype(dtype)
+    ref = O.melspectrogram(y=y, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=n_mels)
+    got = H.mixed_stft(y, n_fft, hop, win, mode="mel", mel_basis=B)
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    assert np.all(np.abs(got - ref) <= (1e-11 if dtype == np.float64 else 1e-4) * np.abs(ref) + (1e-12 if dtype == np.float64 else 1e-6) * ref.max())
