@@ -646,8 +646,14 @@ def main():
                     fs = lambda: L.stft(y2, n_fft=nf, hop_length=hp, check_finite=False)
                     _, e2 = timed(fs, 5, 2, collective=False, ramp_ms=args.prewarm_ms / 4)
                     per2 = e2 / 5
+                    Dm = fs()
+                    fi = lambda: L.istft(Dm, hop_length=hp, n_fft=nf, length=n2)
+                    _, e3 = timed(fi, 5, 2, collective=False, ramp_ms=args.prewarm_ms / 4)
+                    per3 = e3 / 5
                     out[key] = {"mel_ms": per * 1e3, "mel_frames_per_s": batch * T2 / per, "mel_GBps_algorithmic": batch * T2 * (hp * 4 + nm * 4) / per / 1e9,
-                                "stft_ms": per2 * 1e3, "stft_GBps_algorithmic": batch * T2 * (hp * 4 + (nf // 2 + 1) * 8) / per2 / 1e9}
+                                "stft_ms": per2 * 1e3, "stft_GBps_algorithmic": batch * T2 * (hp * 4 + (nf // 2 + 1) * 8) / per2 / 1e9,
+                                "istft_ms": per3 * 1e3, "istft_GBps_algorithmic": batch * T2 * (hp * 4 + (nf // 2 + 1) * 8) / per3 / 1e9}
+                    del Dm
                 finally:
                     ctx.set_option("mixed", 1)
             out["workload"] = f"feature.melspectrogram / stft, n_fft=400 hop=160 n_mels=80 @ 16 kHz, {batch} clips x {CLIP_SECONDS} s (device tensors, public drop-in)"

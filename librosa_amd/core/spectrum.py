@@ -198,6 +198,11 @@ def _sharded_host_exec(sess, batch, nbytes, run):
 
     devs = _native.host_devices()
     if len(devs) <= 1 or batch < 2 * len(devs) or nbytes < _MULTI_DEVICE_MIN_BYTES * len(devs):
+        if len(devs) == 1 and devs[0] != sess.ctx.device:  # LRA_DEVICES names ONE device that is not the session's: the whole call goes there
+            ctx = _native.get_context(devs[0])
+            with ctx.call_lock:
+                ctx.use_own_stream()
+                return run(ctx, 0, batch)
         return run(sess.ctx, 0, batch)
     by_dev = collections.OrderedDict()
     for i, d in enumerate(devs):

@@ -274,6 +274,8 @@ struct lra_istft_plan {
     FftPlanCache fft;
     Scratch spec, frames;
     Scratch norm;  // lra_istft_exec: 1 / wss of the call's envelope (the kernels multiply; see istft_run)
+    void* d_mtw = nullptr;   // mixed-radix inverse (lra_mixed.h): W_M^t, W_N^k; null when n_fft is not in its size list
+    void* d_mtwn = nullptr;
 };
 
 namespace {
@@ -1065,6 +1067,43 @@ int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_s
         LRA_TRY(launch(variant));
         if (!too_big) return zero_from(istft_written_end(N, p->hop, n_used, p->center ? N / 2 : 0));
     }
+    // listed non-power-of-two frame lengths: one fused launch (lra_mixed.h, mixed_istft_kernel)
+    if (p->d_mtw && ctx->opt_mixed) {
+        const int fmax = mixed::inv_frames_max_of(N, (int)sizeof(T));
+        const int halo = (N + p->hop - 1) / p->hop - 1;
+        if (fmax - halo >= 1) {
+            const void* nrm = wss;
+            if (!wss_is_norm) {
+                LRA_TRY(p->norm.ensure((size_t)out_len * sizeof(T)));
+                hipLaunchKernelGGL(wss_to_norm_kernel<T>, dim3((unsigned)((out_len + 255) / 256)), dim3(256), 0, ctx->stream, (const T*)wss, tinyv, (T*)p->norm.p, (long long)out_len);
+                LRA_HIP(hipGetLastError());
+                nrm = p->norm.p;
+            }
+            mixed::InvArgs<T> a = mixed::InvArgs<T>();
+            a.D = (const mixed::cpx<T>*)D;
+            a.d_batch_stride = d_batch_stride;
+            a.d_frame_stride = d_frame_stride;
+            a.n_used = (int)n_used;
+            a.hop = p->hop;
+            a.drop = p->center ? N / 2 : 0;
+            a.win_scaled = (const T*)p->d_win_scaled;
+            a.tw_m = (const mixed::cpx<T>*)p->d_mtw;
+            a.tw_n = (const mixed::cpx<T>*)p->d_mtwn;
+            a.norm = (const T*)nrm;
+            a.y = (T*)y;
+            a.y_stride = y_stride;
+            a.out_len = out_len;
+            a.halo = halo;
+            a.group_hops = fmax - halo;
+            a.groups_per_clip = (int)((n_used + a.group_hops - 1) / a.group_hops);
+            hipError_t e;
+            if constexpr (sizeof(T) == 8) e = mixed::launch_inv_f64(N, a, batch, ctx->stream);
+            else e = mixed::launch_inv_f32(N, a, batch, ctx->stream);
+            if (e != hipSuccess) return fail(LRA_EHIP, std::string("mixed-radix istft kernel launch: ") + hipGetErrorString(e));
+            // the kernel stores every sample up to the last frame's end; beyond it (`length` past the frames' reach) the output is zero
+            return zero_from((n_used - 1) * (long long)p->hop + N - (p->center ? N / 2 : 0));
+        }
+    }
     // general path: pack -> rocFFT C2R -> gather overlap-add, one clip group at a time
     LRA_TRY(scratch_acquire(p->fft, ctx->stream));
     const long long group = general_clip_group(batch, n_used, N, sizeof(T));
@@ -1545,6 +1584,26 @@ int lra_event_elapsed_ms(lra_event* start, lra_event* stop, float* ms) {
 }
 
 // ---- STFT ---------------------------------------------------------------------------------------
+namespace {
+// twiddle tables of the mixed-radix kernels (lra_mixed.h): W_M^t, t < M, and W_N^k, k <= M, evaluated in double and rounded once
+int mixed_tables(int n_fft, int dtype, void** d_mtw, void** d_mtwn) {
+    const int M = n_fft / 2;
+    const double two_pi = 6.283185307179586476925286766559;
+    if (dtype == LRA_F64) {
+        std::vector<cx<double>> t1(M), t2(M + 1);
+        for (int t = 0; t < M; ++t) t1[t] = mk<double>(std::cos(-two_pi * t / M), std::sin(-two_pi * t / M));
+        for (int k = 0; k <= M; ++k) t2[k] = mk<double>(std::cos(-two_pi * k / n_fft), std::sin(-two_pi * k / n_fft));
+        LRA_TRY(upload(d_mtw, t1.data(), t1.size() * sizeof(cx<double>)));
+        return upload(d_mtwn, t2.data(), t2.size() * sizeof(cx<double>));
+    }
+    std::vector<cx<float>> t1(M), t2(M + 1);
+    for (int t = 0; t < M; ++t) t1[t] = mk<float>((float)std::cos(-two_pi * t / M), (float)std::sin(-two_pi * t / M));
+    for (int k = 0; k <= M; ++k) t2[k] = mk<float>((float)std::cos(-two_pi * k / n_fft), (float)std::sin(-two_pi * k / n_fft));
+    LRA_TRY(upload(d_mtw, t1.data(), t1.size() * sizeof(cx<float>)));
+    return upload(d_mtwn, t2.data(), t2.size() * sizeof(cx<float>));
+}
+}  // namespace
+
 int lra_stft_plan_create(lra_ctx* ctx, int n_fft, int hop_length, const void* window_host, int center, int pad_mode, int dtype, lra_stft_plan** out) {
     LRA_BIND(ctx);
     if (!out) return fail(LRA_EINVAL, "null out");
@@ -1577,23 +1636,7 @@ int lra_stft_plan_create(lra_ctx* ctx, int n_fft, int hop_length, const void* wi
     } else {
         rc = upload(&p->d_win, window_host, (size_t)n_fft * real_bytes(dtype));
     }
-    if (rc == LRA_OK && !p->pow2 && mixed::in_size_list(n_fft)) {
-        const int M = n_fft / 2;
-        const double two_pi = 6.283185307179586476925286766559;
-        if (dtype == LRA_F64) {
-            std::vector<cx<double>> t1(M), t2(M + 1);
-            for (int t = 0; t < M; ++t) t1[t] = mk<double>(std::cos(-two_pi * t / M), std::sin(-two_pi * t / M));
-            for (int k = 0; k <= M; ++k) t2[k] = mk<double>(std::cos(-two_pi * k / n_fft), std::sin(-two_pi * k / n_fft));
-            rc = upload(&p->d_mtw, t1.data(), t1.size() * sizeof(cx<double>));
-            if (rc == LRA_OK) rc = upload(&p->d_mtwn, t2.data(), t2.size() * sizeof(cx<double>));
-        } else {
-            std::vector<cx<float>> t1(M), t2(M + 1);
-            for (int t = 0; t < M; ++t) t1[t] = mk<float>((float)std::cos(-two_pi * t / M), (float)std::sin(-two_pi * t / M));
-            for (int k = 0; k <= M; ++k) t2[k] = mk<float>((float)std::cos(-two_pi * k / n_fft), (float)std::sin(-two_pi * k / n_fft));
-            rc = upload(&p->d_mtw, t1.data(), t1.size() * sizeof(cx<float>));
-            if (rc == LRA_OK) rc = upload(&p->d_mtwn, t2.data(), t2.size() * sizeof(cx<float>));
-        }
-    }
+    if (rc == LRA_OK && !p->pow2 && mixed::in_size_list(n_fft)) rc = mixed_tables(n_fft, dtype, &p->d_mtw, &p->d_mtwn);
     if (rc == LRA_OK && p->pow2) {
         p->logm = log2_exact(n_fft) - 1;
         rc = dtype == LRA_F64 ? build_tables<double>(p->logm, p->d_tw, &p->d_twr) : build_tables<float>(p->logm, p->d_tw, &p->d_twr);
@@ -1884,6 +1927,7 @@ int lra_istft_plan_create(lra_ctx* ctx, int n_fft, int hop_length, const void* w
         p->logm = log2_exact(n_fft) - 1;
         rc = dtype == LRA_F64 ? build_tables<double>(p->logm, p->d_tw, &p->d_twr) : build_tables<float>(p->logm, p->d_tw, &p->d_twr);
     }
+    if (rc == LRA_OK && !p->pow2 && mixed::in_size_list(n_fft)) rc = mixed_tables(n_fft, dtype, &p->d_mtw, &p->d_mtwn);
     if (rc != LRA_OK) {
         lra_istft_plan_destroy(p);
         return rc;
@@ -1899,6 +1943,8 @@ void lra_istft_plan_destroy(lra_istft_plan* p) {
     for (int v = 0; v < kNumVariants; ++v)
         if (p->d_tw[v]) (void)hipFree(p->d_tw[v]);
     if (p->d_twr) (void)hipFree(p->d_twr);
+    if (p->d_mtw) (void)hipFree(p->d_mtw);
+    if (p->d_mtwn) (void)hipFree(p->d_mtwn);
     delete p;
 }
 

@@ -296,5 +296,95 @@ template <class T, int N, int MODE> __global__ __launch_bounds__(NT) void mixed_
     }
 }
 
+// =====================================================================================================================================
+// Inverse: librosa/core/spectrum.py:394-626 (irfft of the columns :598, window, overlap-add in frame order :593-603 / :629-643,
+// division by the window sum-square :606-624) for the same frame lengths, one launch.
+//
+// A workgroup owns the output samples of G consecutive hops of one clip -- padded positions [g G hop, (g + 1) G hop), the clip's last
+// group also the tail up to the last frame's end -- and transforms every frame that reaches into them: its own G frames and the
+// ceil(N / hop) - 1 frames before (recomputed by the neighbouring group too: no carry between workgroups, no atomics).  Per frame:
+// Hermitian un-split of X[0 .. M] into conj Z' (pairs (k, M - k); the imaginary parts of X[0] and X[M] are ignored, as pocketfft's c2r
+// does), the forward passes above (FFT of the conjugate = conjugate of the inverse), window / N; the windowed frames stay in LDS as N
+// reals each.  Then every output sample gathers its <= ceil(N / hop) contributions in INCREASING frame order -- the reference's
+// accumulation order -- and is multiplied by its normalisation factor (1 / wss where wss > tiny, else 1: lra_api.hip builds the table).
+template <class T> struct InvArgs {
+    const cpx<T>* D;            // [batch][d_batch_stride]: frames d_frame_stride apart, M + 1 bins each
+    long long d_batch_stride, d_frame_stride;
+    int n_used, hop, drop;      // frames [0, n_used) contribute; drop = n_fft / 2 when centred
+    const T* win_scaled;        // [N] window / N
+    const cpx<T>* tw_m;         // [M]     W_M^t
+    const cpx<T>* tw_n;         // [M + 1] W_N^k
+    const T* norm;              // [out_len] normalisation factors
+    T* y;                       // [batch][y_stride]
+    long long y_stride, out_len;
+    int groups_per_clip, group_hops, halo;  // G = group_hops own frames per group, halo = ceil(N / hop) - 1 earlier frames
+};
+// frames resident per workgroup (own + halo) under the same LDS budget as the forward kernel
+template <class T, int N> constexpr int inv_frames_max() {
+    constexpr int M = N / 2;
+    int f = (int)((2 * LRA_MIXED_LDS_KB * 1024 - M * 2 * (int)sizeof(T)) / (2 * M * 2 * (int)sizeof(T)));
+    return f < 2 ? 2 : (f > 24 ? 24 : f);
+}
+template <class T, int N> constexpr int inv_lds_bytes() { return (2 * inv_frames_max<T, N>() * (N / 2) + N / 2) * 2 * (int)sizeof(T); }
+
+template <class T, int N> __global__ __launch_bounds__(NT) void mixed_istft_kernel(InvArgs<T> a) {
+    constexpr int M = N / 2, FMAX = inv_frames_max<T, N>(), HP = M / 2 + 1;
+    LRA_MIXED_DYN_LDS(lds);
+    cpx<T>* buf0 = reinterpret_cast<cpx<T>*>(lds);
+    cpx<T>* buf1 = buf0 + FMAX * M;
+    cpx<T>* twm = buf1 + FMAX * M;
+    const long long clip = (long long)(blockIdx.x / (unsigned)a.groups_per_clip);
+    const int group = (int)(blockIdx.x % (unsigned)a.groups_per_clip);
+    const bool last = group == a.groups_per_clip - 1;
+    const int t_own = group * a.group_hops;                      // first frame whose hop block this group finalises
+    const int t_first = t_own - a.halo < 0 ? 0 : t_own - a.halo;  // first frame transformed here
+    int t_end = t_own + a.group_hops;                             // one past the last frame transformed here
+    if (t_end > a.n_used || last) t_end = a.n_used;
+    const int frames = t_end - t_first;                           // <= group_hops + halo <= FMAX (host)
+    for (int t = (int)threadIdx.x; t < M; t += NT) twm[t] = a.tw_m[t];
+    // (1) Hermitian un-split: buf0[f][k] = conj Z'[k],  Z'[k] = E' + i O',  E' = X[k] + conj X[M-k],  O' = (X[k] - conj X[M-k]) conj W_N^k
+    for (int w = (int)threadIdx.x; w < frames * HP; w += NT) {
+        const int f = w / HP, k = w - f * HP;
+        const cpx<T>* __restrict__ X = a.D + clip * a.d_batch_stride + (long long)(t_first + f) * a.d_frame_stride;
+        cpx<T> xk = X[k], xm = X[M - k];
+        if (k == 0) { xk.y = (T)0; xm.y = (T)0; }
+        const cpx<T> e = mkc<T>(xk.x + xm.x, xk.y - xm.y), d = mkc<T>(xk.x - xm.x, xk.y + xm.y);
+        const cpx<T> wc = a.tw_n[k];
+        const cpx<T> o = mkc<T>(d.x * wc.x + d.y * wc.y, d.y * wc.x - d.x * wc.y);  // d * conj(w)
+        // conj Z'[k] = conj(E') - i conj(O') = (e.x - o.y, -e.y - o.x);  conj Z'[M-k] = E' - i O' = (e.x + o.y, e.y - o.x)
+        buf0[f * M + k] = mkc<T>(e.x - o.y, -e.y - o.x);
+        if (k > 0 && 2 * k != M) buf0[f * M + M - k] = mkc<T>(e.x + o.y, e.y - o.x);
+    }
+    __syncthreads();
+    // (2) forward passes: Y = FFT(conj Z') = conj(M z)
+    cpx<T>* src = buf0;
+    cpx<T>* dst = buf1;
+    Passes<T, N, 0, FMAX>::run(src, dst, twm, frames);
+    // (3) window / N in place: sample pair m of a frame = (Y.x ws[2m], -Y.y ws[2m+1])
+    const cpx<T>* __restrict__ ws2 = reinterpret_cast<const cpx<T>*>(a.win_scaled);
+    for (int w = (int)threadIdx.x; w < frames * M; w += NT) {
+        const int i = w % M;
+        const cpx<T> v = src[w], wv = ws2[i];
+        src[w] = mkc<T>(v.x * wv.x, -v.y * wv.y);
+    }
+    __syncthreads();
+    // (4) overlap-add by gathering, increasing frame order; padded position p, output index s = p - drop
+    const T* fr = reinterpret_cast<const T*>(src);  // frame f, sample u at fr[f * N + u]
+    const long long p0 = (long long)t_own * a.hop;
+    long long p1 = (long long)(t_own + a.group_hops) * a.hop;
+    if (last) p1 = (long long)(a.n_used - 1) * a.hop + N > p1 ? (long long)(a.n_used - 1) * a.hop + N : p1;  // the clip's tail: up to the last frame's end
+    for (long long p = p0 + (long long)threadIdx.x; p < p1; p += NT) {
+        const long long s = p - a.drop;
+        if (s < 0 || s >= a.out_len) continue;
+        long long tl = p - N + 1;
+        tl = tl <= 0 ? 0 : (tl + a.hop - 1) / a.hop;
+        long long th = p / a.hop;
+        if (th > a.n_used - 1) th = a.n_used - 1;
+        T acc = (T)0;
+        for (long long t = tl; t <= th; ++t) acc += fr[(t - t_first) * N + (p - t * a.hop)];
+        a.y[clip * a.y_stride + s] = acc * a.norm[s];
+    }
+}
+
 }  // namespace mixed
 }  // namespace lra

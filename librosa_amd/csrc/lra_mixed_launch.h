@@ -25,5 +25,8 @@ LRA_MIXED_SIZES(LRA_MIXED_CHECK)
 int frames_per_group_of(int n_fft, int elem_bytes);
 hipError_t launch_f32(int n_fft, int mode, const Args<float>& a, long long batch, hipStream_t stream);
 hipError_t launch_f64(int n_fft, int mode, const Args<double>& a, long long batch, hipStream_t stream);
+int inv_frames_max_of(int n_fft, int elem_bytes);  // frames (own + halo) the inverse kernel holds per workgroup
+hipError_t launch_inv_f32(int n_fft, const InvArgs<float>& a, long long batch, hipStream_t stream);
+hipError_t launch_inv_f64(int n_fft, const InvArgs<double>& a, long long batch, hipStream_t stream);
 }  // namespace mixed
 }  // namespace lra

@@ -243,3 +243,49 @@ extern "C" int postsim_mixed_stft(int n_fft, int mode, int is_f64, const void* y
     return sim_mixed_n<float>(n_fft, mode, a, batch);
 }
 
+namespace {
+template <class T, int N> int sim_mixed_inv(lra::mixed::InvArgs<T> a, long long batch) {
+    using namespace lra::mixed;
+    static_assert(inv_lds_bytes<T, N>() <= (int)sizeof(g_postsim_dyn_lds), "simulated LDS too small");
+    const int fmax = inv_frames_max<T, N>();
+    a.halo = (N + a.hop - 1) / a.hop - 1;
+    if (fmax - a.halo < 1) return 2;
+    a.group_hops = fmax - a.halo;
+    a.groups_per_clip = (a.n_used + a.group_hops - 1) / a.group_hops;
+    run_grid((unsigned)(batch * a.groups_per_clip), NT, [=] { mixed_istft_kernel<T, N>(a); });
+    return 0;
+}
+template <class T> int sim_mixed_inv_n(int n_fft, const lra::mixed::InvArgs<T>& a, long long batch) {
+    switch (n_fft) {
+        case 160: return sim_mixed_inv<T, 160>(a, batch);
+        case 240: return sim_mixed_inv<T, 240>(a, batch);
+        case 400: return sim_mixed_inv<T, 400>(a, batch);
+        case 480: return sim_mixed_inv<T, 480>(a, batch);
+        case 1000: return sim_mixed_inv<T, 1000>(a, batch);
+        case 1200: return sim_mixed_inv<T, 1200>(a, batch);
+        default: return 1;
+    }
+}
+}  // namespace
+
+// D: [batch][n_frames_total][M + 1]; norm: the normalisation factors (1 / wss where wss > tiny, else 1); y arrives as the caller filled it
+extern "C" int postsim_mixed_istft(int n_fft, int is_f64, const void* D, long long batch, int n_frames_total, int n_used, int hop, int drop, const void* win_scaled, const void* tw_m,
+                                   const void* tw_n, const void* norm, void* y, long long out_len) {
+    auto fill = [&](auto& a, auto tag) {
+        using T = decltype(tag);
+        const int M = n_fft / 2;
+        a.D = (const lra::mixed::cpx<T>*)D; a.d_frame_stride = M + 1; a.d_batch_stride = (long long)n_frames_total * (M + 1);
+        a.n_used = n_used; a.hop = hop; a.drop = drop; a.win_scaled = (const T*)win_scaled;
+        a.tw_m = (const lra::mixed::cpx<T>*)tw_m; a.tw_n = (const lra::mixed::cpx<T>*)tw_n; a.norm = (const T*)norm;
+        a.y = (T*)y; a.y_stride = out_len; a.out_len = out_len;
+    };
+    if (is_f64) {
+        lra::mixed::InvArgs<double> a = lra::mixed::InvArgs<double>();
+        fill(a, double());
+        return sim_mixed_inv_n<double>(n_fft, a, batch);
+    }
+    lra::mixed::InvArgs<float> a = lra::mixed::InvArgs<float>();
+    fill(a, float());
+    return sim_mixed_inv_n<float>(n_fft, a, batch);
+}
+

@@ -256,3 +256,30 @@ def mixed_stft(y, n_fft, hop, window, *, mode="stft", center=True, pad_mode="con
             _p(c0), _p(ln), _p(off), _p(val), n_mels)
     assert rc == 0, f"n_fft={n_fft} is not among the simulator's mixed-radix sizes"
     return out
+
+
+def mixed_istft(D, n_fft, hop, win, wss, out_len, n_used, center=True):
+    """The fused mixed-radix inverse kernel (csrc/lra_mixed.h) through the simulator; D: (batch, T, M + 1) complex, frame-major.  The output arrives full of NaN and
+    only what lra_api.hip's wrapper clears (samples past the last frame's end) is zeroed: every other sample must be stored by the kernel."""
+    D = np.ascontiguousarray(D)
+    f64 = D.dtype == np.complex128
+    rt = np.float64 if f64 else np.float32
+    ct = D.dtype
+    batch, T, bins = D.shape
+    M = n_fft // 2
+    assert bins == M + 1
+    ws = np.ascontiguousarray(np.asarray(win, dtype=np.float64) / n_fft, dtype=rt)
+    wss = np.asarray(wss, dtype=rt)
+    with np.errstate(divide="ignore", over="ignore"):
+        norm = np.ascontiguousarray(np.where(wss > np.finfo(rt).tiny, rt(1) / wss, rt(1)), dtype=rt)
+    tw_m = np.ascontiguousarray(np.exp(-2j * np.pi * np.arange(M, dtype=np.float64) / M).astype(ct))
+    tw_n = np.ascontiguousarray(np.exp(-2j * np.pi * np.arange(M + 1, dtype=np.float64) / n_fft).astype(ct))
+    drop = n_fft // 2 if center else 0
+    y = np.full((batch, out_len), np.nan, dtype=rt)
+    y[:, max(0, min(out_len, (n_used - 1) * hop + n_fft - drop)):] = 0
+    fn = post_lib().postsim_mixed_istft
+    c = ctypes
+    fn.argtypes = [c.c_int, c.c_int, c.c_void_p, c.c_longlong, c.c_int, c.c_int, c.c_int, c.c_int, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_longlong]
+    rc = fn(n_fft, int(f64), _p(D), batch, T, n_used, hop, drop, _p(ws), _p(tw_m), _p(tw_n), _p(norm), _p(y), out_len)
+    assert rc == 0, f"simulator: n_fft={n_fft} hop={hop} not served (rc {rc})"
+    return y

@@ -1148,7 +1148,11 @@ def test_istft_sixteenth_hop(L, n_fft, hop):
         (256, 300, True, 5000, (None, 5000, 7000), np.float32),                     # hop > n_fft: gaps between frames
         (256, 300, False, 5000, (None, 6500), np.float32),
         (8192, 512, True, 60000, (None, 70000), np.float32),                        # four waves per frame
-        (1000, 250, True, 20000, (None, 20000, 26000), np.float32),                 # rocFFT + gather path
+        (1000, 250, True, 20000, (None, 20000, 26000), np.float32),                 # mixed-radix fused inverse (4 x 5 x 5 x 5)
+        (400, 160, True, 30000, (None, 30000, 36000), np.float32),                  # ... 8 x 5 x 5: several groups per clip, halo frames
+        (400, 160, False, 30000, (None, 33000), np.float64),
+        (160, 200, True, 9000, (None, 12000), np.float32),                          # ... hop > n_fft
+        (1002, 250, True, 20000, (None, 20000, 26000), np.float32),                 # rocFFT + gather path (n_fft / 2 = 501 = 3 x 167)
         (2048, 512, True, 30000, (None, 36000), np.float64),
     ],
 )
@@ -1252,9 +1256,22 @@ def test_mixed_radix_frames_fused(L, n_fft, hop, sr, n_mels):
     finally:
         ctx.set_option("mixed", 1)
     assert _stft_close(L.stft(y, n_fft=n_fft, hop_length=hop), D0) and _mel_close(M, M0)
-    # round trip through the (rocFFT) inverse
-    yh = L.istft(L.stft(y, n_fft=n_fft, hop_length=hop), hop_length=hop, n_fft=n_fft, length=y.shape[-1])
+    # the fused inverse of the same frame lengths: round trip, the oracle with and without `length`, and the rocFFT path it replaces
+    Dfull = L.stft(y, n_fft=n_fft, hop_length=hop)
+    yh = L.istft(Dfull, hop_length=hop, n_fft=n_fft, length=y.shape[-1])
     assert np.abs(yh - y).max() <= 2e-5
+    Dref = O.stft(y, n_fft=n_fft, hop_length=hop)
+    for length in (None, y.shape[-1], y.shape[-1] - 3 * hop - 1, y.shape[-1] + 2 * n_fft):
+        ref = O.istft(Dref, hop_length=hop, n_fft=n_fft, length=length)
+        got = L.istft(Dref, hop_length=hop, n_fft=n_fft, length=length)
+        wss = _wss_for(dict(n_fft=n_fft, hop_length=hop), Dref.shape[-1], ref.shape[-1], length, np.float32)
+        assert got.shape == ref.shape and _istft_close(got, ref, wss), length
+    try:
+        ctx.set_option("mixed", 0)
+        y0 = L.istft(Dfull, hop_length=hop, n_fft=n_fft, length=y.shape[-1])
+    finally:
+        ctx.set_option("mixed", 1)
+    assert np.abs(y0 - yh).max() <= 2e-6 * max(1.0, np.abs(y).max())
 
 
 def test_native_rccl_communicator(L):

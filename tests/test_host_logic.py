@@ -325,6 +325,11 @@ def test_small_jobs_stay_on_one_device_and_errors_surface(monkeypatch):
     spectrum._sharded_host_exec(_FakeSess(ctxs[0]), 3, 1 << 40, lambda c, b, e: calls.append((c.device, b, e)))    # fewer than two clips per device
     assert calls == [(0, 0, 64), (0, 0, 3)]
 
+    ctxs2 = _fake_devices(monkeypatch, [1])   # one listed device that is not the session's own: everything goes there, under its lock and stream
+    spectrum._sharded_host_exec(_FakeSess(ctxs2[0]), 64, 1 << 40, lambda c, b, e: calls.append((c.device, b, e)))
+    assert calls[-1] == (1, 0, 64) and ctxs2[1].streams == 1
+    ctxs = _fake_devices(monkeypatch, [0, 1])
+
     def boom(c, b, e):
         if c.device == 1:
             raise L.ParameterError("Audio buffer is not finite everywhere")

@@ -766,3 +766,34 @@ def test_mixed_radix_mel_body(n_fft, hop, n_mels, sr, dtype):
     got = H.mixed_stft(y, n_fft, hop, win, mode="mel", mel_basis=B)
     assert got.shape == ref.shape and np.isfinite(got).all()
     assert np.all(np.abs(got - ref) <= (1e-11 if dtype == np.float64 else 1e-4) * np.abs(ref) + (1e-12 if dtype == np.float64 else 1e-6) * ref.max())
+
+
+@pytest.mark.parametrize(
+    "n_fft,hop,n,center,length,dtype",
+    [
+        (400, 160, 4000, True, "n", np.float32),
+        (400, 160, 4000, True, None, np.float32),
+        (400, 100, 3000, True, 2500, np.float32),
+        (400, 160, 3000, True, 4000, np.float32),     # length beyond the frames: zero tail from the wrapper
+        (400, 160, 3000, False, None, np.float32),
+        (240, 60, 2000, True, "n", np.float32),
+        (160, 200, 3000, True, None, np.float32),     # hop > n_fft: gaps between frames
+        (480, 120, 3000, True, "n", np.float64),
+        (1000, 250, 9000, True, "n", np.float32),     # several groups per clip with halo frames
+        (1200, 300, 7000, True, "n", np.float32),
+    ],
+)
+def test_mixed_radix_istft_body(n_fft, hop, n, center, length, dtype):
+    """librosa/core/spectrum.py:394-626 for frame lengths 2^a 3^b 5^c through ONE fused launch (un-split, inverse passes, window, gather overlap-add in frame
+    order, normalisation), NaN-prefilled output."""
+    rng = np.random.default_rng(n_fft + hop)
+    y = rng.standard_normal((2, n)).astype(dtype)
+    L_ = n if length == "n" else length
+    Dn, ref, wss, win, out_len, n_used = _istft_inputs(y, n_fft, hop, center, L_)
+    out = H.mixed_istft(Dn, n_fft, hop, win, wss, out_len, n_used, center=center)
+    assert out.shape == ref.shape and np.isfinite(out).all()
+    cond = 1.0 / np.sqrt(np.maximum(wss, np.finfo(np.float32).tiny))
+    tol = (4e-6 if dtype == np.float32 else 1e-13) * np.abs(ref).max() * np.maximum(1.0, cond)
+    well = wss > 1e-3 * wss.max()
+    assert np.all(np.abs(out - ref)[..., well] <= tol[well])
+    assert np.all(np.abs(out - ref)[..., ~well] <= 50 * tol[~well] + 1e-3)
