@@ -1071,7 +1071,7 @@ int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_s
     if (p->d_mtw && ctx->opt_mixed) {
         const int fmax = mixed::inv_frames_max_of(N, (int)sizeof(T));
         const int halo = (N + p->hop - 1) / p->hop - 1;
-        if (fmax - halo >= 1) {
+        if (fmax - halo >= 1 && fmax - halo >= 2 * halo) {  // (halo frames are recomputed by the neighbouring group: worth it while they are a third of the work at most)
             const void* nrm = wss;
             if (!wss_is_norm) {
                 LRA_TRY(p->norm.ensure((size_t)out_len * sizeof(T)));

@@ -319,10 +319,18 @@ template <class T> struct InvArgs {
     long long y_stride, out_len;
     int groups_per_clip, group_hops, halo;  // G = group_hops own frames per group, halo = ceil(N / hop) - 1 earlier frames
 };
-// frames resident per workgroup (own + halo) under the same LDS budget as the forward kernel
+// Frames resident per workgroup (own + halo).  The halo frames are recomputed work, so the group must be long against the halo (the host
+// takes this kernel only when own >= 2 halo, lra_api.hip), but LDS per workgroup is residency (measured, 400 / 160, 256 x 30 s: 24 KB 1.00 ms,
+// 32 KB 1.02, 48 KB 1.21, 64 KB 1.55; 800 / 200 at 64 KB: 2.89 ms against 2.79 for the rocFFT path): 24 KB, or 32 KB where that is what holds
+// nine frames (six own + the three halo frames of a 4 x overlap); larger frames fail the host's rule and keep the rocFFT path.
 template <class T, int N> constexpr int inv_frames_max() {
     constexpr int M = N / 2;
-    int f = (int)((2 * LRA_MIXED_LDS_KB * 1024 - M * 2 * (int)sizeof(T)) / (2 * M * 2 * (int)sizeof(T)));
+    constexpr int per_frame = 2 * M * 2 * (int)sizeof(T), table = M * 2 * (int)sizeof(T);
+    int f = 0;
+    for (int kb : {24, 32}) {
+        f = (kb * 1024 - table) / per_frame;
+        if (f >= 9) break;
+    }
     return f < 2 ? 2 : (f > 24 ? 24 : f);
 }
 template <class T, int N> constexpr int inv_lds_bytes() { return (2 * inv_frames_max<T, N>() * (N / 2) + N / 2) * 2 * (int)sizeof(T); }

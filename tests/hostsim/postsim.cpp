@@ -249,7 +249,7 @@ template <class T, int N> int sim_mixed_inv(lra::mixed::InvArgs<T> a, long long 
     static_assert(inv_lds_bytes<T, N>() <= (int)sizeof(g_postsim_dyn_lds), "simulated LDS too small");
     const int fmax = inv_frames_max<T, N>();
     a.halo = (N + a.hop - 1) / a.hop - 1;
-    if (fmax - a.halo < 1) return 2;
+    if (fmax - a.halo < 1) return 2;  // (the product also asks for own >= 2 halo: a performance rule; the simulator takes every shape that fits)
     a.group_hops = fmax - a.halo;
     a.groups_per_clip = (a.n_used + a.group_hops - 1) / a.group_hops;
     run_grid((unsigned)(batch * a.groups_per_clip), NT, [=] { mixed_istft_kernel<T, N>(a); });
