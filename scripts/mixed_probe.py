@@ -9,6 +9,7 @@ what = sys.argv[5] if len(sys.argv) > 5 else "mel"
 steps = int(sys.argv[6]) if len(sys.argv) > 6 else 10
 dev = torch.device("cuda", 0)
 ctx = L.get_context(0)
+ctx.set_option("mixed", int(os.environ.get("LRA_MIXED_OPT", "1")))
 y = bench.make_batch(torch, 256, sr * 30, 0, dev)
 fn = (lambda: L.feature.melspectrogram(y=y, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=n_mels, check_finite=False)) if what == "mel" else (lambda: L.stft(y, n_fft=n_fft, hop_length=hop, check_finite=False))
 T = int(fn().shape[-1])
