@@ -594,7 +594,8 @@ def main():
                 alg_bytes = nb * (n * 4 + 84 * n_frames * 8)  # PCM read once + the stacked complex64 result written once
                 out[key] = {"clips": nb, "ms_per_call": e / 5 * 1e3, "frames_per_s": nb * n_frames / (e / 5), "GBps_algorithmic": alg_bytes / (e / 5) / 1e9,
                             "what": f"librosa_amd.cqt(<device audio>, 84 bins, res_type={rt!r}): 7 octaves of rectangular-window STFT + sparse basis projection + FIR decimation, "
-                                    "device-resident (the constant-Q transform BASELINE config 5 approximates); 20 small launches: latency-, not bandwidth-bound"}
+                                    "device-resident (the constant-Q transform BASELINE config 5 approximates); round 4: one fused launch per octave (frames + transform + projection + stacking, "
+                                    "csrc/lra_mixed.h) and a register-blocked halving kernel: 13 launches"}
             # the same two rows through the oracle (port of the reference) on one host core, one clip each: a reported baseline
             try:
                 sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -246,6 +246,14 @@ int lra_fir_decimate_exec(lra_ctx* ctx, const void* x, void* out, int64_t batch,
 int lra_cqt_project_exec(lra_ctx* ctx, const void* D, void* out, const void* row_ptr, const void* col, const void* val, const void* sqrt_len, int64_t batch, int64_t frames_in, int n_bins,
                          int64_t n_frames, int n_total, int bin0, int row0, int n_rows, int dtype);
 
+/* One octave of the recursion in one launch (round 4): the rectangular-window STFT of centred frames (n_fft a power of two in [32, 4096]:
+ * lra_cqt_octave_supported; constantq.py:1197-1212), the sparse basis projection (:1213-1218), the length scaling (:1116-1118) and the stacking
+ * (:1168-1194) -- arguments as lra_cqt_project_exec, y [batch][y_stride] instead of D.  The frame spectra stay in LDS.  Raises the context's
+ * non-finite flag like the forward kernels (a frame's DC bin is non-finite iff one of its samples is). */
+int lra_cqt_octave_supported(int n_fft);
+int lra_cqt_octave_exec(lra_ctx* ctx, const void* y, int64_t batch, int64_t n, int64_t y_stride, int n_fft, int hop, int pad_mode, const void* row_ptr, const void* col, const void* val,
+                        const void* sqrt_len, void* out, int64_t n_frames, int n_total, int bin0, int row0, int n_rows, int dtype);
+
 /* ---- harmonic / percussive separation: librosa.decompose.hpss, librosa/decompose.py:371-528 (between the stft and the two istft of
  * librosa.effects.hpss / harmonic / percussive, librosa/effects.py:70-301) --------------------------------------------------------- */
 /* mag[i] = |D[i]| (np.abs of the complex spectrogram, core/spectrum.py:1347); D complex, mag real of `dtype`'s precision (device). */

@@ -87,6 +87,8 @@ SIGNATURES = {
     "lra_maxfilter_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_int]),
     "lra_fir_decimate_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_double, c_double, c_int]),
     "lra_cqt_project_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int64, c_int, c_int, c_int, c_int, c_int]),
+    "lra_cqt_octave_supported": (c_int, [c_int]),
+    "lra_cqt_octave_exec": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int]),
     "lra_magnitude_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int]),
     "lra_hpss_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_double, c_double, c_double, c_int, c_int]),
     "lra_dct_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_int, c_double, c_double, c_void_p, c_void_p, c_int, c_double]),
@@ -435,6 +437,14 @@ class Context:
     def cqt_project_exec(self, d_ptr, out_ptr, row_ptr, col_ptr, val_ptr, sqrt_len_ptr, batch, frames_in, n_bins, n_frames, n_total, bin0, row0, n_rows, dtype):
         _check(self.lib.lra_cqt_project_exec(self.handle, c_void_p(d_ptr), c_void_p(out_ptr), c_void_p(row_ptr), c_void_p(col_ptr), c_void_p(val_ptr), c_void_p(sqrt_len_ptr or None), batch,
                                              frames_in, int(n_bins), n_frames, int(n_total), int(bin0), int(row0), int(n_rows), dtype_code(dtype)))
+
+    def cqt_octave_supported(self, n_fft):
+        return bool(self.lib.lra_cqt_octave_supported(int(n_fft)))
+
+    def cqt_octave_exec(self, y_ptr, batch, n, y_stride, n_fft, hop, pad_mode, row_ptr, col_ptr, val_ptr, sqrt_len_ptr, out_ptr, n_frames, n_total, bin0, row0, n_rows, dtype):
+        """One constant-Q octave in one launch (``include/librosa_amd.h``): STFT with a rectangular window + sparse projection + scaling + stacking."""
+        _check(self.lib.lra_cqt_octave_exec(self.handle, c_void_p(y_ptr), batch, n, y_stride, n_fft, hop, PAD_MODES[pad_mode], c_void_p(row_ptr), c_void_p(col_ptr), c_void_p(val_ptr),
+                                            c_void_p(sqrt_len_ptr) if sqrt_len_ptr else None, c_void_p(out_ptr), n_frames, n_total, bin0, row0, n_rows, dtype_code(dtype)))
 
     def magnitude_exec(self, d_ptr, mag_ptr, count, dtype):
         _check(self.lib.lra_magnitude_exec(self.handle, c_void_p(d_ptr), c_void_p(mag_ptr), count, dtype_code(dtype)))

@@ -36,6 +36,11 @@ from ..util.utils import is_torch_tensor
 from .intervals import interval_frequencies
 from .spectrum import _DEVICE_PAD_MODES, _all_finite, _as_like
 
+# One launch per octave (csrc/lra_mixed.h, mixed_cqt_kernel: frames + rectangular-window transform + sparse projection + scaling + stacking, the
+# octave's spectra never leave LDS) where the octave's frame length is one the kernel is built for; False keeps the round-3 pair of launches
+# (forward kernel -> HBM -> cqt_project_kernel) everywhere.  A test / measurement switch.
+FUSED_OCTAVES = True
+
 __all__ = ["cqt", "vqt"]
 
 _C1_HZ = 440.0 * (2.0 ** ((24 - 69) / 12))  # note_to_hz("C1") (core/convert.py:573-620): MIDI note 24
@@ -224,18 +229,24 @@ def vqt(y, *, sr=22050, hop_length=512, fmin=None, n_bins=84, intervals="equal",
             ctx.fir_decimate_exec(y_ptr, nxt, batch, n, lens[0], taps_ptr, n_taps, factor, first, np.sqrt(1.0 / factor), 1.0 if scale else np.sqrt(factor), real)
             y_ptr = nxt
         out_ptr, handle = sess.output((batch, n_frames, n_bins), cplx)
-        d_bytes = max(f * (o["n_fft"] // 2 + 1) for f, o in zip(frames, octaves)) * batch * cplx.itemsize
-        d_ptr = sess.scratch(d_bytes)
+        d_ptr = None  # spectrum scratch of the unfused octaves (frame lengths beyond the fused kernel's), allocated on first need
         sqrt_len_ptr = table("sqrt_len", plan["sqrt_len"], np.float64) if plan["sqrt_len"] is not None else None
         half_taps = None
         for i, o in enumerate(octaves):
             n_fft, hop = o["n_fft"], o["hop"]
             if n_fft > lens[i]:   # the warning of the reference's stft (core/spectrum.py:267-271), once per octave it applies to
                 warnings.warn(f"n_fft={n_fft} is too large for input signal of length={lens[i]}", stacklevel=3)
-            splan = ctx.stft_plan(n_fft, hop, np.ones(n_fft, dtype=real), True, pad_mode, real)          # window="ones" (:1197)
-            ctx.stft_exec(splan, y_ptr, batch, lens[i], lens[i], d_ptr)
-            ctx.cqt_project_exec(d_ptr, out_ptr, table(f"row_ptr{i}", o["row_ptr"], np.int32), table(f"col{i}", o["col"], np.int32), table(f"val{i}", o["val"], cplx),
-                                 (sqrt_len_ptr + 8 * o["bin0"]) if sqrt_len_ptr else None, batch, frames[i], n_fft // 2 + 1, n_frames, n_bins, o["bin0"], o["row0"], o["n_rows"], real)
+            csr = (table(f"row_ptr{i}", o["row_ptr"], np.int32), table(f"col{i}", o["col"], np.int32), table(f"val{i}", o["val"], cplx))
+            scl = (sqrt_len_ptr + 8 * o["bin0"]) if sqrt_len_ptr else None
+            if FUSED_OCTAVES and ctx.cqt_octave_supported(n_fft):
+                # one launch per octave: frames, rectangular-window transform, projection, scaling and stacking; the octave's spectra stay in LDS
+                ctx.cqt_octave_exec(y_ptr, batch, lens[i], lens[i], n_fft, hop, pad_mode, csr[0], csr[1], csr[2], scl, out_ptr, n_frames, n_bins, o["bin0"], o["row0"], o["n_rows"], real)
+            else:
+                if d_ptr is None:
+                    d_ptr = sess.scratch(max(f * (oo["n_fft"] // 2 + 1) for f, oo in zip(frames, octaves)) * batch * cplx.itemsize)
+                splan = ctx.stft_plan(n_fft, hop, np.ones(n_fft, dtype=real), True, pad_mode, real)          # window="ones" (:1197)
+                ctx.stft_exec(splan, y_ptr, batch, lens[i], lens[i], d_ptr)
+                ctx.cqt_project_exec(d_ptr, out_ptr, csr[0], csr[1], csr[2], scl, batch, frames[i], n_fft // 2 + 1, n_frames, n_bins, o["bin0"], o["row0"], o["n_rows"], real)
             if o["halve"]:
                 if half_taps is None:
                     half_taps = decimator(2)

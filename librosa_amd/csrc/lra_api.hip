@@ -81,6 +81,7 @@ struct lra_ctx {
     int opt_direct = 1;              // direct framing (no ring) for hop >= n_fft
     int opt_xcd_remap = 1;           // workgroup -> work item map that keeps neighbouring strips on one XCD (lra_kernels.h, xcd_block)
     unsigned int* d_flag = nullptr;  // non-finite input flag (device)
+    std::map<std::pair<int, int>, std::pair<void*, void*>> cqt_tw;  // (n_fft, dtype) -> (W_M^t, W_N^k) of the fused constant-Q octave kernel (lra_mixed.h)
     std::string name;
     struct HostPipe* pipe = nullptr;  // staging of the host-buffer entry points (lra_stft_exec_host), created on first use
     int opt_pipe_chunk_mb = 128;      // bytes (in + out) one pipeline stage moves
@@ -1449,6 +1450,10 @@ void lra_ctx_destroy(lra_ctx* ctx) {
     delete ctx->pipe;
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
+    for (auto& kv : ctx->cqt_tw) {
+        if (kv.second.first) (void)hipFree(kv.second.first);
+        if (kv.second.second) (void)hipFree(kv.second.second);
+    }
     delete ctx;
 }
 
@@ -2168,10 +2173,26 @@ int lra_fir_decimate_exec(lra_ctx* ctx, const void* x, void* out, int64_t batch,
     if (n_in <= 0) return fail(LRA_EINVAL, "fir_decimate: empty input");
     if (!x || !out || !taps) return fail(LRA_EINVAL, "null data pointer");
     if (dtype != LRA_F32 && dtype != LRA_F64) return fail(LRA_EINVAL, "fir_decimate: dtype must be LRA_F32 or LRA_F64");
-    const long long blocks_per_clip = (n_out + 255) / 256;
-    if (blocks_per_clip * batch > 0x7fffffffLL) return fail(LRA_EINVAL, "fir_decimate: array too large for one launch");
     const size_t elem = dtype == LRA_F64 ? 8 : 4;
-    const size_t lds = ((size_t)255 * down + n_taps) * elem;  // the workgroup's input span
+    // four outputs per thread (four independent chains, a quarter of the workgroups) where the longer span still fits 32 KB of LDS and the job is big
+    const bool four = n_out >= 8192 && ((size_t)(1023 * (long long)down + n_taps)) * elem <= 32 * 1024;
+    const int opt = four ? 4 : 1;
+    const long long blocks_per_clip = (n_out + 256 * opt - 1) / (256 * opt);
+    if (blocks_per_clip * batch > 0x7fffffffLL) return fail(LRA_EINVAL, "fir_decimate: array too large for one launch");
+    if (four && down == 2 && n_taps >= 6) {  // the octave recursion's halving: four consecutive outputs per thread, padded span (fir_halve4_kernel)
+        const size_t span2 = (size_t)1023 * 2 + n_taps;
+        const size_t lds2 = (span2 + span2 / 8 + 1) * elem;
+        const unsigned grid2 = (unsigned)(blocks_per_clip * batch);
+        if (dtype == LRA_F64)
+            hipLaunchKernelGGL(fir_halve4_kernel<double>, dim3(grid2), dim3(256), lds2, ctx->stream, (const double*)x, (double*)out, (const double*)taps, (long long)n_in, (long long)n_out,
+                               (int)blocks_per_clip, n_taps, first, div, mul);
+        else
+            hipLaunchKernelGGL(fir_halve4_kernel<float>, dim3(grid2), dim3(256), lds2, ctx->stream, (const float*)x, (float*)out, (const float*)taps, (long long)n_in, (long long)n_out,
+                               (int)blocks_per_clip, n_taps, first, div, mul);
+        LRA_HIP(hipGetLastError());
+        return LRA_OK;
+    }
+    const size_t lds = ((size_t)(256 * opt - 1) * down + n_taps) * elem;  // the workgroup's input span
     if (lds > 64 * 1024) {  // span too long to stage: the direct kernel
         const long long count = (long long)batch * n_out;
         if ((count + 255) / 256 > 0x7fffffffLL) return fail(LRA_EINVAL, "fir_decimate: array too large for one launch");
@@ -2186,12 +2207,12 @@ int lra_fir_decimate_exec(lra_ctx* ctx, const void* x, void* out, int64_t batch,
         return LRA_OK;
     }
     const unsigned grid = (unsigned)(blocks_per_clip * batch);
-    if (dtype == LRA_F64)
-        hipLaunchKernelGGL(fir_decimate_kernel<double>, dim3(grid), dim3(256), lds, ctx->stream, (const double*)x, (double*)out, (const double*)taps, (long long)n_in, (long long)n_out,
-                           (int)blocks_per_clip, n_taps, down, first, div, mul);
-    else
-        hipLaunchKernelGGL(fir_decimate_kernel<float>, dim3(grid), dim3(256), lds, ctx->stream, (const float*)x, (float*)out, (const float*)taps, (long long)n_in, (long long)n_out,
-                           (int)blocks_per_clip, n_taps, down, first, div, mul);
+#define LRA_FIR(T, OPT)                                                                                                                                                            \
+    hipLaunchKernelGGL((fir_decimate_kernel<T, OPT>), dim3(grid), dim3(256), lds, ctx->stream, (const T*)x, (T*)out, (const T*)taps, (long long)n_in, (long long)n_out, (int)blocks_per_clip, \
+                       n_taps, down, first, div, mul)
+    if (dtype == LRA_F64) { if (four) LRA_FIR(double, 4); else LRA_FIR(double, 1); }
+    else { if (four) LRA_FIR(float, 4); else LRA_FIR(float, 1); }
+#undef LRA_FIR
     LRA_HIP(hipGetLastError());
     return LRA_OK;
 }
@@ -2214,6 +2235,45 @@ int lra_cqt_project_exec(lra_ctx* ctx, const void* D, void* out, const void* row
         hipLaunchKernelGGL(cqt_project_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, (const CqtCplx<float>*)D, (CqtCplx<float>*)out, (const int*)row_ptr, (const int*)col,
                            (const CqtCplx<float>*)val, (const double*)sqrt_len, (long long)batch, (long long)frames_in, n_bins, (long long)n_frames, n_total, bin0, row0, n_rows);
     LRA_HIP(hipGetLastError());
+    return LRA_OK;
+}
+
+int lra_cqt_octave_supported(int n_fft) { return mixed::in_cqt_size_list(n_fft) ? 1 : 0; }
+
+int lra_cqt_octave_exec(lra_ctx* ctx, const void* y, int64_t batch, int64_t n, int64_t y_stride, int n_fft, int hop, int pad_mode, const void* row_ptr, const void* col, const void* val,
+                        const void* sqrt_len, void* out, int64_t n_frames, int n_total, int bin0, int row0, int n_rows, int dtype) {
+    LRA_BIND(ctx);
+    if (!mixed::in_cqt_size_list(n_fft)) return fail(LRA_EINVAL, "cqt_octave: n_fft must be a power of two in [32, 4096] (see lra_cqt_octave_supported)");
+    if (hop < 1 || pad_mode < LRA_PAD_CONSTANT || pad_mode > LRA_PAD_SYMMETRIC) return fail(LRA_EINVAL, "cqt_octave: bad hop or pad mode");
+    if (n_total < 1 || bin0 < 0 || row0 < 0 || n_rows < 0 || bin0 + n_rows > n_total) return fail(LRA_EINVAL, "cqt_octave: the octave's rows must fit the stacked result");
+    if (dtype != LRA_F32 && dtype != LRA_F64) return fail(LRA_EINVAL, "cqt_octave: dtype must be LRA_F32 or LRA_F64");
+    if (batch <= 0 || n_frames <= 0 || n_rows == 0) return LRA_OK;
+    if (!y || !out || !row_ptr || !col || !val) return fail(LRA_EINVAL, "null data pointer");
+    if (n_frames > 1 + n / hop) return fail(LRA_EINVAL, "cqt_octave: more frames than the centred signal has");
+    if (n_frames > 0x7fffffffLL / 4) return fail(LRA_EINVAL, "too many frames per clip");
+    auto& tw = ctx->cqt_tw[std::make_pair(n_fft, dtype)];
+    if (!tw.first) LRA_TRY(mixed_tables(n_fft, dtype, &tw.first, &tw.second));
+    const int F = mixed::cqt_frames_per_group_of(n_fft, dtype == LRA_F64 ? 8 : 4);
+    auto fill = [&](auto& a, auto tag) {
+        using T = decltype(tag);
+        a.y = (const T*)y; a.y_stride = y_stride; a.n = n; a.hop = hop; a.pad = n_fft / 2; a.pad_mode = pad_mode;
+        a.tw_m = (const mixed::cpx<T>*)tw.first; a.tw_n = (const mixed::cpx<T>*)tw.second;
+        a.row_ptr = (const int*)row_ptr; a.col = (const int*)col; a.val = (const mixed::cpx<T>*)val; a.sqrt_len = (const double*)sqrt_len;
+        a.out = (mixed::cpx<T>*)out; a.n_frames = (int)n_frames; a.n_total = n_total; a.bin0 = bin0; a.row0 = row0; a.n_rows = n_rows;
+        a.groups_per_clip = (int)((n_frames + F - 1) / F);
+        a.nonfinite_flag = ctx->d_flag;
+    };
+    hipError_t e;
+    if (dtype == LRA_F64) {
+        mixed::CqtArgs<double> a = mixed::CqtArgs<double>();
+        fill(a, double());
+        e = mixed::launch_cqt_f64(n_fft, a, batch, ctx->stream);
+    } else {
+        mixed::CqtArgs<float> a = mixed::CqtArgs<float>();
+        fill(a, float());
+        e = mixed::launch_cqt_f32(n_fft, a, batch, ctx->stream);
+    }
+    if (e != hipSuccess) return fail(LRA_EHIP, std::string("cqt octave kernel launch: ") + hipGetErrorString(e));
     return LRA_OK;
 }
 

@@ -68,28 +68,108 @@ __global__ __launch_bounds__(256) void fir_decimate_direct_kernel(const T* __res
     T* name = reinterpret_cast<T*>(lra_dyn_lds_raw)
 #endif
 
-template <class T>
+// OPT outputs per thread, 256 apart: the same sums in the same order, OPT independent chains in flight per thread (the one-output form is a
+// chain of n_taps dependent LDS reads + multiply-adds, latency-bound) and a quarter as many workgroups.
+template <class T, int OPT>
 __global__ __launch_bounds__(256) void fir_decimate_kernel(const T* __restrict__ x, T* __restrict__ out, const T* __restrict__ h, long long n_in, long long n_out, int blocks_per_clip, int n_taps,
                                                            int down, int first, double div, double mul) {
     LRA_DYN_LDS(T, xs);
     const long long clip = blockIdx.x / blocks_per_clip;
-    const long long n0 = (long long)(blockIdx.x % blocks_per_clip) * 256;
+    const long long n0 = (long long)(blockIdx.x % blocks_per_clip) * (256 * OPT);
     const int t = threadIdx.x;
     const T* __restrict__ xc = x + clip * n_in;
     const long long base = (n0 + first) * (long long)down - (n_taps - 1);  // input index of xs[0]
-    const int span = 255 * down + n_taps;
+    const int span = (256 * OPT - 1) * down + n_taps;
     for (int s = t; s < span; s += 256) {
         const long long gi = base + s;
         xs[s] = (gi >= 0 && gi < n_in) ? xc[gi] : (T)0;
     }
     __syncthreads();
-    const T* __restrict__ w = xs + t * down;  // this output's window, oldest sample first
-    T acc = (T)0;
-    for (int j = 0; j < n_taps; ++j) acc = CqtOps<T>::madd(acc, w[j], h[n_taps - 1 - j]);
-    const long long n = n0 + t;
-    if (n < n_out) {
-        const T scaled = (T)((double)acc / div);
-        out[clip * n_out + n] = mul == 1.0 ? scaled : (T)((double)scaled * mul);  // `y *= sqrt(factor)` of the unscaled transform (constantq.py:1263-1264)
+    T acc[OPT];
+#pragma unroll
+    for (int q = 0; q < OPT; ++q) acc[q] = (T)0;
+    for (int j = 0; j < n_taps; ++j) {
+        const T hj = h[n_taps - 1 - j];
+#pragma unroll
+        for (int q = 0; q < OPT; ++q) acc[q] = CqtOps<T>::madd(acc[q], xs[(t + 256 * q) * down + j], hj);  // output n0 + t + 256 q: its window, oldest sample first
+    }
+#pragma unroll
+    for (int q = 0; q < OPT; ++q) {
+        const long long n = n0 + t + 256 * q;
+        if (n < n_out) {
+            const T scaled = (T)((double)acc[q] / div);
+            out[clip * n_out + n] = mul == 1.0 ? scaled : (T)((double)scaled * mul);  // `y *= sqrt(factor)` of the unscaled transform (constantq.py:1263-1264)
+        }
+    }
+}
+
+// Halving (down = 2: every step of the octave recursion), four CONSECUTIVE outputs per thread.  Output n takes inputs 2 (n + first) - k, so
+// neighbouring outputs share all but two of their n_taps inputs: a thread that walks its n_taps + 6 input samples once feeds each of them to up
+// to four running sums -- the same products added in the same (ascending-input) order per output, a quarter of the LDS reads.  The strided
+// form above is bound by exactly those reads (41 per output for the Kaiser half-band, 375 for this library's own design).  A thread's window
+// starts eight samples after its neighbour's; the staged span is laid out with one pad slot per eight samples (sample i at slot i + i / 8), so
+// that the lanes' reads of "their j-th sample" are nine slots apart: conflict-free, and the pad of the j-th sample is a scalar.
+template <class T>
+__global__ __launch_bounds__(256) void fir_halve4_kernel(const T* __restrict__ x, T* __restrict__ out, const T* __restrict__ h, long long n_in, long long n_out, int blocks_per_clip, int n_taps,
+                                                         int first, double div, double mul) {
+    LRA_DYN_LDS(T, xs);
+    const long long clip = blockIdx.x / blocks_per_clip;
+    const long long n0 = (long long)(blockIdx.x % blocks_per_clip) * 1024;
+    const int t = threadIdx.x;
+    const T* __restrict__ xc = x + clip * n_in;
+    const long long base = (n0 + first) * 2 - (n_taps - 1);  // input index of staged sample 0
+    const int span = 1023 * 2 + n_taps;
+    for (int s = t; s < span; s += 256) {
+        const long long gi = base + s;
+        xs[s + (s >> 3)] = (gi >= 0 && gi < n_in) ? xc[gi] : (T)0;
+    }
+    __syncthreads();
+    const T* __restrict__ w = xs + t * 9;  // this thread's window: sample j of it at w[j + j / 8]
+    T a0 = (T)0, a1 = (T)0, a2 = (T)0, a3 = (T)0;
+    const int walk = n_taps + 6;
+    auto edge = [&](int j) {  // the first and last six samples of the walk reach only some of the four outputs (position k = j - 2 q in output q's window)
+        const T v = w[j + (j >> 3)];
+        if (j < n_taps) a0 = CqtOps<T>::madd(a0, v, h[n_taps - 1 - j]);
+        if (j >= 2 && j - 2 < n_taps) a1 = CqtOps<T>::madd(a1, v, h[n_taps + 1 - j]);
+        if (j >= 4 && j - 4 < n_taps) a2 = CqtOps<T>::madd(a2, v, h[n_taps + 3 - j]);
+        if (j >= 6 && j - 6 < n_taps) a3 = CqtOps<T>::madd(a3, v, h[n_taps + 5 - j]);
+    };
+    int j = 0;
+    for (; j < 6 && j < walk; ++j) edge(j);
+    // every sample of the middle feeds all four sums; eight samples per trip with their fourteen taps fetched in one go (the tap index is the
+    // same for all lanes: scalar loads, and one dependent scalar load per sample was what the loop waited for)
+    for (; j + 8 <= n_taps; j += 8) {
+        const T* __restrict__ hp = h + (n_taps - 8 - j);  // taps of positions j + 7 (lowest index) ... j, + 6
+        T hh[14];
+#pragma unroll
+        for (int i = 0; i < 14; ++i) hh[i] = hp[i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int jj = j + u;
+            const T v = w[jj + (jj >> 3)];
+            a0 = CqtOps<T>::madd(a0, v, hh[7 - u]);
+            a1 = CqtOps<T>::madd(a1, v, hh[9 - u]);
+            a2 = CqtOps<T>::madd(a2, v, hh[11 - u]);
+            a3 = CqtOps<T>::madd(a3, v, hh[13 - u]);
+        }
+    }
+    for (; j < n_taps; ++j) {
+        const T v = w[j + (j >> 3)];
+        const int c = n_taps - 1 - j;
+        a0 = CqtOps<T>::madd(a0, v, h[c]);
+        a1 = CqtOps<T>::madd(a1, v, h[c + 2]);
+        a2 = CqtOps<T>::madd(a2, v, h[c + 4]);
+        a3 = CqtOps<T>::madd(a3, v, h[c + 6]);
+    }
+    for (; j < walk; ++j) edge(j);
+    const T acc[4] = {a0, a1, a2, a3};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long long n = n0 + (long long)t * 4 + q;
+        if (n < n_out) {
+            const T scaled = (T)((double)acc[q] / div);
+            out[clip * n_out + n] = mul == 1.0 ? scaled : (T)((double)scaled * mul);
+        }
     }
 }
 

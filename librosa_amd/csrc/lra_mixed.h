@@ -182,11 +182,12 @@ template <class T> struct Dft<8, T> {
 // One Stockham pass of radix R over the F frames in `src` (stride S = product of the earlier radices): butterfly b of a frame reads
 // src[b + j M / R], multiplies input j by W_{S R}^{(b mod S) j} = W_M^{(b mod S) j M / (S R)} and writes output j to
 // dst[(b - b mod S) R + (b mod S) + j S].  Work items (frame, butterfly) are dealt to the threads by a flat index.
-template <class T, int N, int R, int S, int F> __device__ __forceinline__ void pass(const cpx<T>* src, cpx<T>* dst, const cpx<T>* twm, int frames) {
+// PITCH: complex slots between consecutive frames of a buffer (M, or M + 1 where the epilogue wants whole spectra of M + 1 bins per frame)
+template <class T, int N, int R, int S, int F, int PITCH = N / 2> __device__ __forceinline__ void pass(const cpx<T>* src, cpx<T>* dst, const cpx<T>* twm, int frames) {
     constexpr int M = N / 2, NB = M / R, TWS = M / (S * R);
     for (int w = (int)threadIdx.x; w < frames * NB; w += NT) {
         const int f = w / NB, b = w - f * NB, k = b % S;
-        const cpx<T>* s = src + f * M + b;
+        const cpx<T>* s = src + f * PITCH + b;
         cpx<T> v[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) v[j] = s[j * NB];
@@ -195,21 +196,21 @@ template <class T, int N, int R, int S, int F> __device__ __forceinline__ void p
             for (int j = 1; j < R; ++j) v[j] = mul(v[j], twm[k * j * TWS]);
         }
         Dft<R, T>::run(v);
-        cpx<T>* d = dst + f * M + (b - k) * R + k;
+        cpx<T>* d = dst + f * PITCH + (b - k) * R + k;
 #pragma unroll
         for (int j = 0; j < R; ++j) d[j * S] = v[j];
     }
 }
 
 // the passes of factor(M), unrolled at compile time; returns (through the pointer swap) the buffer that holds the result
-template <class T, int N, int P, int F> struct Passes {
+template <class T, int N, int P, int F, int PITCH = N / 2> struct Passes {
     static __device__ __forceinline__ void run(cpx<T>*& a, cpx<T>*& b, const cpx<T>* twm, int frames) {
         constexpr Radices f = factor(N / 2);
         if constexpr (P < f.n) {
-            pass<T, N, f.r[P], stride_before(f, P), F>(a, b, twm, frames);
+            pass<T, N, f.r[P], stride_before(f, P), F, PITCH>(a, b, twm, frames);
             __syncthreads();
             cpx<T>* t = a; a = b; b = t;
-            Passes<T, N, P + 1, F>::run(a, b, twm, frames);
+            Passes<T, N, P + 1, F, PITCH>::run(a, b, twm, frames);
         }
     }
 };
@@ -293,6 +294,106 @@ template <class T, int N, int MODE> __global__ __launch_bounds__(NT) void mixed_
             for (int i = 0; i < len; ++i) acc += val[i] * p[i];
             a.Mel[((long long)clip * a.n_mels + m) * a.n_frames + f0 + f] = acc;
         }
+    }
+}
+
+// =====================================================================================================================================
+// One octave of the constant-Q / variable-Q recursion in ONE launch: librosa/core/constantq.py:1197-1223 (__cqt_response: stft with a
+// rectangular window, fft_basis.dot(D)), :1116-1118 (division by sqrt(filter length)), :1168-1194 (__trim_stack: the octave's rows of
+// the stacked result, frames beyond the common count dropped).  The frame transform is the kernel above (n_fft is a power of two here:
+// filters.wavelet pads to one); the spectrum of a frame never leaves LDS -- round 3 wrote it to HBM (85 MB per octave for 64 x 30 s
+// clips) and read it back in cqt_project_kernel.  The projection follows that kernel operation by operation: CSR rows walked in order,
+// one rounding per operation (no contraction), the scaling as a float64 multiplication by the reciprocal.
+template <class T> struct CqtArgs {
+    const T* y;
+    long long y_stride, n;
+    int hop, pad, pad_mode;
+    const cpx<T>* tw_m;
+    const cpx<T>* tw_n;
+    const int* row_ptr;        // CSR over the octave's filters; rows row0 .. row0 + n_rows - 1 are used
+    const int* col;
+    const cpx<T>* val;
+    const double* sqrt_len;    // [n_rows] or nullptr (scale=False)
+    cpx<T>* out;               // [batch][n_frames][n_total], this octave at columns bin0 ...
+    int n_frames, n_total, bin0, row0, n_rows;
+    int groups_per_clip;
+    unsigned int* nonfinite_flag;  // raised when a frame's DC bin is not finite (a non-finite sample in it), or nullptr
+};
+template <class T, int N> constexpr int cqt_frames_per_group() {
+    constexpr int MP = N / 2 + 1;
+    int f = (int)((LRA_MIXED_LDS_KB * 1024 - (N / 2) * 2 * (int)sizeof(T)) / (2 * MP * 2 * (int)sizeof(T)));
+    return f < 1 ? 1 : (f > LRA_MIXED_FMAX ? LRA_MIXED_FMAX : f);
+}
+// (Staging the octave's CSR entries in LDS -- 12 KB for up to 1024 of them -- was measured and is slower: 62.9 against 54.7 us per octave of 64 x 30 s clips;
+// the LDS it takes costs resident workgroups, which is what hides this kernel's latencies.)
+template <class T, int N> constexpr int cqt_lds_bytes() { return (2 * cqt_frames_per_group<T, N>() * (N / 2 + 1) + N / 2) * 2 * (int)sizeof(T); }
+
+#ifdef LRA_POSTSIM
+#define LRA_MIXED_FLAG_OR(ptr) (*(ptr) |= 1u)
+#else
+#define LRA_MIXED_FLAG_OR(ptr) atomicOr((ptr), 1u)
+#endif
+
+#pragma clang fp contract(off)
+template <class T> __device__ __forceinline__ cpx<T> cmadd_exact(cpx<T> acc, cpx<T> a, cpx<T> b) {  // acc + a b, as scipy.sparse's complex wrapper evaluates it
+    const T re = a.x * b.x - a.y * b.y;
+    const T im = a.x * b.y + a.y * b.x;
+    return mkc<T>(acc.x + re, acc.y + im);
+}
+#pragma clang fp contract(fast)
+
+template <class T, int N> __global__ __launch_bounds__(NT) void mixed_cqt_kernel(CqtArgs<T> a) {
+    constexpr int M = N / 2, MP = M + 1, F = cqt_frames_per_group<T, N>(), HP = M / 2 + 1;
+    LRA_MIXED_DYN_LDS(lds);
+    cpx<T>* buf0 = reinterpret_cast<cpx<T>*>(lds);
+    cpx<T>* buf1 = buf0 + F * MP;
+    cpx<T>* twm = buf1 + F * MP;
+    const int clip = (int)(blockIdx.x / (unsigned)a.groups_per_clip), group = (int)(blockIdx.x % (unsigned)a.groups_per_clip);
+    const int f0 = group * F;
+    const int frames = a.n_frames - f0 < F ? a.n_frames - f0 : F;
+    const T* __restrict__ yb = a.y + (long long)clip * a.y_stride;
+    for (int t = (int)threadIdx.x; t < M; t += NT) twm[t] = a.tw_m[t];
+    // frames -> buf0 (rectangular window: window="ones", constantq.py:1201)
+    for (int w = (int)threadIdx.x; w < frames * M; w += NT) {
+        const int f = w / M, i = w - f * M;
+        const long long g = (long long)(f0 + f) * a.hop - a.pad + 2 * i;
+        cpx<T> x;
+        if (g >= 0 && g + 1 < a.n) x = mkc<T>(yb[g], yb[g + 1]);
+        else x = mkc<T>(fetch<T>(yb, g, a.n, a.pad_mode), fetch<T>(yb, g + 1, a.n, a.pad_mode));
+        buf0[f * MP + i] = x;
+    }
+    __syncthreads();
+    cpx<T>* src = buf0;
+    cpx<T>* dst = buf1;
+    Passes<T, N, 0, F, MP>::run(src, dst, twm, frames);
+    // Hermitian split by pairs, whole spectra (M + 1 bins) -> dst
+    for (int w = (int)threadIdx.x; w < frames * HP; w += NT) {
+        const int f = w / HP, k = w - f * HP;
+        const cpx<T> zk = src[f * MP + k], zr = src[f * MP + (k == 0 ? 0 : M - k)];
+        const cpx<T> e = mkc<T>((T)0.5 * (zk.x + zr.x), (T)0.5 * (zk.y - zr.y)), o = mkc<T>((T)0.5 * (zk.x - zr.x), (T)0.5 * (zk.y + zr.y));
+        const cpx<T> pw = mul(o, a.tw_n[k]);
+        cpx<T> xk = mkc<T>(e.x + pw.y, e.y - pw.x), xm = mkc<T>(e.x - pw.y, -e.y - pw.x);
+        if (k == 0) {
+            xk.y = (T)0;
+            xm.y = (T)0;
+            if (a.nonfinite_flag && !(xk.x - xk.x == (T)0)) LRA_MIXED_FLAG_OR(a.nonfinite_flag);
+        }
+        dst[f * MP + k] = xk;
+        if (2 * k != M) dst[f * MP + M - k] = xm;
+    }
+    __syncthreads();
+    // projection: a work item per (frame, row), rows fastest (consecutive output elements)
+    for (int w = (int)threadIdx.x; w < frames * a.n_rows; w += NT) {
+        const int f = w / a.n_rows, r = w - f * a.n_rows;
+        const cpx<T>* d = dst + f * MP;
+        cpx<T> acc = mkc<T>((T)0, (T)0);
+        const int j1 = a.row_ptr[a.row0 + r + 1];
+        for (int j = a.row_ptr[a.row0 + r]; j < j1; ++j) acc = cmadd_exact(acc, a.val[j], d[a.col[j]]);
+        if (a.sqrt_len) {
+            const double scl = 1.0 / a.sqrt_len[r];
+            acc = mkc<T>((T)((double)acc.x * scl), (T)((double)acc.y * scl));
+        }
+        a.out[((long long)clip * a.n_frames + f0 + f) * a.n_total + a.bin0 + r] = acc;
     }
 }
 

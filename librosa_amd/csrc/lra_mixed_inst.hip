@@ -57,6 +57,40 @@ template <class T> hipError_t launch_inv_t(int n_fft, const InvArgs<T>& a, long 
     }
 }
 
+template <class T, int N> hipError_t launch_cqt_n(const CqtArgs<T>& a, long long batch, hipStream_t stream) {
+    constexpr int lds = cqt_lds_bytes<T, N>();
+    const long long grid = batch * a.groups_per_clip;
+    if (grid <= 0) return hipSuccess;
+    if (grid > 0x7ffffff0LL) return hipErrorInvalidConfiguration;
+    void (*kern)(CqtArgs<T>) = mixed_cqt_kernel<T, N>;
+    if (lds > 65536) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, a);
+    return hipGetLastError();
+}
+template <class T> hipError_t launch_cqt_t(int n_fft, const CqtArgs<T>& a, long long batch, hipStream_t stream) {
+    switch (n_fft) {
+#define LRA_MIXED_CASE(N) \
+    case N: return launch_cqt_n<T, N>(a, batch, stream);
+        LRA_CQT_SIZES(LRA_MIXED_CASE)
+#undef LRA_MIXED_CASE
+        default: return hipErrorInvalidValue;
+    }
+}
+int cqt_frames_per_group_of(int n_fft, int elem_bytes) {
+    switch (n_fft) {
+#define LRA_MIXED_CASE(N) \
+    case N: return elem_bytes == 8 ? cqt_frames_per_group<double, N>() : cqt_frames_per_group<float, N>();
+        LRA_CQT_SIZES(LRA_MIXED_CASE)
+#undef LRA_MIXED_CASE
+        default: return 0;
+    }
+}
+hipError_t launch_cqt_f32(int n_fft, const CqtArgs<float>& a, long long batch, hipStream_t stream) { return launch_cqt_t<float>(n_fft, a, batch, stream); }
+hipError_t launch_cqt_f64(int n_fft, const CqtArgs<double>& a, long long batch, hipStream_t stream) { return launch_cqt_t<double>(n_fft, a, batch, stream); }
+
 int inv_frames_max_of(int n_fft, int elem_bytes) {
     switch (n_fft) {
 #define LRA_MIXED_CASE(N) \

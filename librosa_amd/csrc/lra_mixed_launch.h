@@ -10,8 +10,18 @@
 // path): the 15 / 20 / 25 / 30 / 40 / 50 / 60 ms frames of 8, 16, 22.05 (rounded), 32 and 48 kHz front ends and their doubles
 #define LRA_MIXED_SIZES(X) X(160) X(200) X(240) X(320) X(400) X(480) X(640) X(800) X(960) X(1000) X(1200) X(1280) X(1440) X(1600) X(1920) X(2000) X(2400) X(3200) X(4800)
 
+// the constant-Q octave kernel's frame lengths (filters.wavelet pads every octave's filters to a power of two)
+#define LRA_CQT_SIZES(X) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048) X(4096)
+
 namespace lra {
 namespace mixed {
+constexpr bool in_cqt_size_list(int n_fft) {
+#define LRA_MIXED_CASE(N) \
+    if (n_fft == N) return true;
+    LRA_CQT_SIZES(LRA_MIXED_CASE)
+#undef LRA_MIXED_CASE
+    return false;
+}
 constexpr bool in_size_list(int n_fft) {
 #define LRA_MIXED_CASE(N) \
     if (n_fft == N) return true;
@@ -25,6 +35,9 @@ LRA_MIXED_SIZES(LRA_MIXED_CHECK)
 int frames_per_group_of(int n_fft, int elem_bytes);
 hipError_t launch_f32(int n_fft, int mode, const Args<float>& a, long long batch, hipStream_t stream);
 hipError_t launch_f64(int n_fft, int mode, const Args<double>& a, long long batch, hipStream_t stream);
+int cqt_frames_per_group_of(int n_fft, int elem_bytes);
+hipError_t launch_cqt_f32(int n_fft, const CqtArgs<float>& a, long long batch, hipStream_t stream);
+hipError_t launch_cqt_f64(int n_fft, const CqtArgs<double>& a, long long batch, hipStream_t stream);
 int inv_frames_max_of(int n_fft, int elem_bytes);  // frames (own + halo) the inverse kernel holds per workgroup
 hipError_t launch_inv_f32(int n_fft, const InvArgs<float>& a, long long batch, hipStream_t stream);
 hipError_t launch_inv_f64(int n_fft, const InvArgs<double>& a, long long batch, hipStream_t stream);

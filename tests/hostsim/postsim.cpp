@@ -50,7 +50,7 @@ using std::hypot;
 using std::pow;
 using std::sqrt;
 
-alignas(16) static unsigned char g_postsim_dyn_lds[64 * 1024];  // the dynamic LDS of the workgroup being run
+alignas(16) static unsigned char g_postsim_dyn_lds[160 * 1024];  // the dynamic LDS of the workgroup being run
 
 #include "../../librosa_amd/csrc/lra_pcen.h"
 #include "../../librosa_amd/csrc/lra_cqt.h"
@@ -134,8 +134,18 @@ int postsim_maxfilter(const void* S, void* out, long long outer, int n_bands, lo
 
 // the launches of lra_fir_decimate_exec / lra_cqt_project_exec (lra_api.hip)
 int postsim_fir_decimate(const void* x, void* out, long long batch, long long n_in, long long n_out, const void* taps, int n_taps, int down, int first, double div, double mul, int is_f64) {
-    const int blocks_per_clip = (int)((n_out + 255) / 256);
-    if ((size_t)(255 * down + n_taps) * (is_f64 ? 8 : 4) > sizeof(g_postsim_dyn_lds)) {  // as lra_fir_decimate_exec: the direct kernel
+    // (as lra_fir_decimate_exec, lra_api.hip: four outputs per thread for big jobs whose span fits, else one; the direct kernel for spans beyond the LDS)
+    const size_t elem = is_f64 ? 8 : 4;
+    const bool four = n_out >= 8192 && ((size_t)(1023 * (long long)down + n_taps)) * elem <= 32 * 1024;
+    const int opt = four ? 4 : 1;
+    const int blocks_per_clip = (int)((n_out + 256 * opt - 1) / (256 * opt));
+    if (four && down == 2 && n_taps >= 6) {
+        const unsigned grid2 = (unsigned)(blocks_per_clip * batch);
+        if (is_f64) run_grid(grid2, 256, [=] { lra::fir_halve4_kernel<double>((const double*)x, (double*)out, (const double*)taps, n_in, n_out, blocks_per_clip, n_taps, first, div, mul); });
+        else run_grid(grid2, 256, [=] { lra::fir_halve4_kernel<float>((const float*)x, (float*)out, (const float*)taps, n_in, n_out, blocks_per_clip, n_taps, first, div, mul); });
+        return 0;
+    }
+    if ((size_t)((256 * opt - 1) * down + n_taps) * elem > 64 * 1024) {
         const unsigned dgrid = (unsigned)((batch * n_out + 255) / 256);
         if (is_f64)
             run_grid_serial(dgrid, 256, [=] { lra::fir_decimate_direct_kernel<double>((const double*)x, (double*)out, (const double*)taps, batch, n_in, n_out, n_taps, down, first, div, mul); });
@@ -144,10 +154,10 @@ int postsim_fir_decimate(const void* x, void* out, long long batch, long long n_
         return 0;
     }
     const unsigned grid = (unsigned)(blocks_per_clip * batch);
-    if (is_f64)
-        run_grid(grid, 256, [=] { lra::fir_decimate_kernel<double>((const double*)x, (double*)out, (const double*)taps, n_in, n_out, blocks_per_clip, n_taps, down, first, div, mul); });
-    else
-        run_grid(grid, 256, [=] { lra::fir_decimate_kernel<float>((const float*)x, (float*)out, (const float*)taps, n_in, n_out, blocks_per_clip, n_taps, down, first, div, mul); });
+#define SIM_FIR(T, OPT) run_grid(grid, 256, [=] { lra::fir_decimate_kernel<T, OPT>((const T*)x, (T*)out, (const T*)taps, n_in, n_out, blocks_per_clip, n_taps, down, first, div, mul); })
+    if (is_f64) { if (four) SIM_FIR(double, 4); else SIM_FIR(double, 1); }
+    else { if (four) SIM_FIR(float, 4); else SIM_FIR(float, 1); }
+#undef SIM_FIR
     return 0;
 }
 
@@ -287,5 +297,49 @@ extern "C" int postsim_mixed_istft(int n_fft, int is_f64, const void* D, long lo
     lra::mixed::InvArgs<float> a = lra::mixed::InvArgs<float>();
     fill(a, float());
     return sim_mixed_inv_n<float>(n_fft, a, batch);
+}
+
+namespace {
+template <class T, int N> int sim_cqt_octave(lra::mixed::CqtArgs<T> a, long long batch) {
+    using namespace lra::mixed;
+    static_assert(cqt_lds_bytes<T, N>() <= (int)sizeof(g_postsim_dyn_lds), "simulated LDS too small");
+    constexpr int F = cqt_frames_per_group<T, N>();
+    a.groups_per_clip = (a.n_frames + F - 1) / F;
+    run_grid((unsigned)(batch * a.groups_per_clip), NT, [=] { mixed_cqt_kernel<T, N>(a); });
+    return 0;
+}
+template <class T> int sim_cqt_octave_n(int n_fft, const lra::mixed::CqtArgs<T>& a, long long batch) {
+    switch (n_fft) {
+        case 32: return sim_cqt_octave<T, 32>(a, batch);
+        case 64: return sim_cqt_octave<T, 64>(a, batch);
+        case 128: return sim_cqt_octave<T, 128>(a, batch);
+        case 256: return sim_cqt_octave<T, 256>(a, batch);
+        case 512: return sim_cqt_octave<T, 512>(a, batch);
+        case 1024: return sim_cqt_octave<T, 1024>(a, batch);
+        case 2048: return sim_cqt_octave<T, 2048>(a, batch);
+        default: return 1;
+    }
+}
+}  // namespace
+
+// the launch of lra_cqt_octave_exec (lra_api.hip); tw_m / tw_n: the twiddle tables the context builds per frame length
+extern "C" int postsim_cqt_octave(int n_fft, int is_f64, const void* y, long long batch, long long n, long long y_stride, int hop, int pad_mode, const void* tw_m, const void* tw_n,
+                                  const int* row_ptr, const int* col, const void* val, const double* sqrt_len, void* out, long long n_frames, int n_total, int bin0, int row0, int n_rows) {
+    auto fill = [&](auto& a, auto tag) {
+        using T = decltype(tag);
+        a.y = (const T*)y; a.y_stride = y_stride; a.n = n; a.hop = hop; a.pad = n_fft / 2; a.pad_mode = pad_mode;
+        a.tw_m = (const lra::mixed::cpx<T>*)tw_m; a.tw_n = (const lra::mixed::cpx<T>*)tw_n;
+        a.row_ptr = row_ptr; a.col = col; a.val = (const lra::mixed::cpx<T>*)val; a.sqrt_len = sqrt_len;
+        a.out = (lra::mixed::cpx<T>*)out; a.n_frames = (int)n_frames; a.n_total = n_total; a.bin0 = bin0; a.row0 = row0; a.n_rows = n_rows;
+        a.nonfinite_flag = nullptr;
+    };
+    if (is_f64) {
+        lra::mixed::CqtArgs<double> a = lra::mixed::CqtArgs<double>();
+        fill(a, double());
+        return sim_cqt_octave_n<double>(n_fft, a, batch);
+    }
+    lra::mixed::CqtArgs<float> a = lra::mixed::CqtArgs<float>();
+    fill(a, float());
+    return sim_cqt_octave_n<float>(n_fft, a, batch);
 }
 

@@ -343,6 +343,27 @@ class _SimCtx:
         H.post_lib().postsim_cqt_project(d_ptr, out_ptr, row_ptr, col_ptr, val_ptr, sqrt_len_ptr, batch, frames_in, int(n_bins), n_frames, int(n_total), int(bin0), int(row0), int(n_rows),
                                          int(np.dtype(dtype) == np.float64))
 
+    # the fused octave (lra_cqt_octave_exec): the whole kernel body of csrc/lra_mixed.h, mixed_cqt_kernel, through the simulator
+    fused_octaves = False  # (the bit-for-bit shim tests take the oracle's STFT; test_cqt_fused_octaves_through_simulator turns this on)
+
+    def cqt_octave_supported(self, n_fft):
+        return self.fused_octaves and int(n_fft) in (32, 64, 128, 256, 512, 1024, 2048)
+
+    def cqt_octave_exec(self, y_ptr, batch, n, y_stride, n_fft, hop, pad_mode, row_ptr, col_ptr, val_ptr, sqrt_len_ptr, out_ptr, n_frames, n_total, bin0, row0, n_rows, dtype):
+        import ctypes as c
+
+        f64 = np.dtype(dtype) == np.float64
+        ct = np.complex128 if f64 else np.complex64
+        M = int(n_fft) // 2
+        tw_m = np.ascontiguousarray(np.exp(-2j * np.pi * np.arange(M, dtype=np.float64) / M).astype(ct))
+        tw_n = np.ascontiguousarray(np.exp(-2j * np.pi * np.arange(M + 1, dtype=np.float64) / n_fft).astype(ct))
+        fn = H.post_lib().postsim_cqt_octave
+        fn.argtypes = [c.c_int, c.c_int, c.c_void_p, c.c_longlong, c.c_longlong, c.c_longlong, c.c_int, c.c_int, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p,
+                       c.c_longlong, c.c_int, c.c_int, c.c_int, c.c_int]
+        rc = fn(int(n_fft), int(f64), y_ptr, batch, n, y_stride, int(hop), {"constant": 0, "reflect": 1, "edge": 2, "symmetric": 3}[pad_mode], tw_m.ctypes.data, tw_n.ctypes.data, row_ptr, col_ptr,
+                val_ptr, sqrt_len_ptr, out_ptr, n_frames, int(n_total), int(bin0), int(row0), int(n_rows))
+        assert rc == 0
+
     def transpose(self, src_ptr, dst_ptr, batch, rows, cols, elem_bytes):
         """dst[b][c][r] = src[b][r][c] (lra_transpose)."""
         dt = {4: np.float32, 8: np.float64, 16: np.complex128}[int(elem_bytes)]
@@ -797,3 +818,32 @@ def test_mixed_radix_istft_body(n_fft, hop, n, center, length, dtype):
     well = wss > 1e-3 * wss.max()
     assert np.all(np.abs(out - ref)[..., well] <= tol[well])
     assert np.all(np.abs(out - ref)[..., ~well] <= 50 * tol[~well] + 1e-3)
+
+
+@pytest.mark.filterwarnings("ignore:n_fft=")
+def test_cqt_fused_octaves_through_simulator(monkeypatch):
+    """The one-launch octave (csrc/lra_mixed.h, mixed_cqt_kernel: frames, rectangular-window transform, sparse projection, scaling, stacking) run whole
+    by the simulator inside librosa_amd.cqt / vqt: the oracle's transform to float32 round-off (2e-5 of the peak, the device tests' bar), 1e-11 in float64,
+    for every octave schedule of the bit-for-bit test above (early downsampling, partial lowest octave, reflect padding, unscaled, one bin)."""
+    import cqt_oracle as CQ
+    import golden_cases
+    import librosa_amd
+    from librosa_amd import _arrays
+
+    monkeypatch.setattr(_arrays, "Session", _SimSession)
+    monkeypatch.setattr(_SimCtx, "fused_octaves", True)
+    calls = []
+    orig = _SimCtx.cqt_octave_exec
+    monkeypatch.setattr(_SimCtx, "cqt_octave_exec", lambda self, *a: (calls.append(a[4]), orig(self, *a))[1])
+    y = golden_cases.make_signal("mix", 22050, 3, None, "float32")
+    for kw in (dict(), dict(hop_length=256, n_bins=60), dict(n_bins=30, bins_per_octave=12), dict(scale=False, n_bins=24), dict(fmin=110.0, n_bins=36, tuning=0.2, norm=2),
+               dict(filter_scale=0.5, pad_mode="reflect", window="hamming", sparsity=0.05), dict(n_bins=1)):
+        got = librosa_amd.cqt(y, res_type="polyphase", **kw)
+        exp = CQ.cqt(y, res_type="polyphase", **kw)
+        assert got.shape == exp.shape and got.dtype == exp.dtype
+        assert np.abs(got - exp).max() <= 2e-5 * np.abs(exp).max(), (kw, np.abs(got - exp).max() / np.abs(exp).max())
+    assert calls and set(calls) <= {32, 64, 128, 256, 512, 1024, 2048}
+    y64 = golden_cases.make_signal("mix", 12000, 5, (2,), "float64")
+    got = librosa_amd.vqt(y64, res_type="polyphase", gamma=5.0, n_bins=36)
+    exp = CQ.vqt(y64, res_type="polyphase", gamma=5.0, n_bins=36)
+    assert got.dtype == np.complex128 and np.abs(got - exp).max() <= 1e-11 * np.abs(exp).max()
