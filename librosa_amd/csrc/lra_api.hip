@@ -77,6 +77,7 @@ struct lra_ctx {
     int opt_generic_mel = 0;         // force the generic banded mel path (tests)
     int opt_lds_pad = 0;             // extra dynamic LDS per workgroup (occupancy experiments)
     int opt_v2 = 1;                  // second-generation forward kernel where it applies (lra_kernels2.h)
+    int opt_hpss_tile = 1;           // hpss: a thread per 4 x 4 tile with shared sorted cores (hpss_tile_kernel); 0: a thread per element (A/B)
     int opt_mixed = 1;               // fused mixed-radix forward kernel for the listed non-power-of-two frame lengths (lra_mixed.h); 0: rocFFT path
     int opt_direct = 1;              // direct framing (no ring) for hop >= n_fft
     int opt_xcd_remap = 1;           // workgroup -> work item map that keeps neighbouring strips on one XCD (lra_kernels.h, xcd_block)
@@ -1379,15 +1380,29 @@ int rccl_fail(RcclApi* api, const char* what, int rc) {
 
 namespace {
 template <class T> void hpss_launch(lra_ctx* ctx, const void* mag, const void* D, void* out_h, void* out_p, const HpssArgs& a, unsigned grid) {
-    const int widest = a.win_harm > a.win_perc ? a.win_harm : a.win_perc;
-    int slots = widest <= 32 ? 32 : 0;
-    if constexpr (sizeof(T) == 4) slots = widest <= 32 ? 32 : (widest <= 64 ? 64 : 0);  // 64 float64 slots would not fit the register file: counting selection instead
-    if (slots == 32) {
+    const HpssPlan plan = hpss_plan(a, (int)sizeof(T));
+    // a thread per 4 x 4 tile, neighbouring windows sharing one sorted core (hpss_tile_kernel)
+    const unsigned tgrid = (unsigned)((hpss_tiles(a) + 255) / 256);
+    if (plan.tile_slots == 32 && plan.fixed_win && ctx->opt_hpss_tile) {
+        hipLaunchKernelGGL((hpss_tile_kernel<T, 32, kHpssFixedWin>), dim3(tgrid), dim3(256), 0, ctx->stream, (const T*)mag, (const HpssCplx<T>*)D, out_h, out_p, a);
+        return;
+    }
+    if (plan.tile_slots == 32 && ctx->opt_hpss_tile) {
+        hipLaunchKernelGGL((hpss_tile_kernel<T, 32, 0>), dim3(tgrid), dim3(256), 0, ctx->stream, (const T*)mag, (const HpssCplx<T>*)D, out_h, out_p, a);
+        return;
+    }
+    if constexpr (sizeof(T) == 4) {
+        if (plan.tile_slots == 64 && ctx->opt_hpss_tile) {
+            hipLaunchKernelGGL((hpss_tile_kernel<T, 64, 0>), dim3(tgrid), dim3(256), 0, ctx->stream, (const T*)mag, (const HpssCplx<T>*)D, out_h, out_p, a);
+            return;
+        }
+    }
+    if (plan.element_slots == 32) {
         hipLaunchKernelGGL((hpss_kernel<T, 32>), dim3(grid), dim3(256), 0, ctx->stream, (const T*)mag, (const HpssCplx<T>*)D, out_h, out_p, a);
         return;
     }
     if constexpr (sizeof(T) == 4) {
-        if (slots == 64) {
+        if (plan.element_slots == 64) {
             hipLaunchKernelGGL((hpss_kernel<T, 64>), dim3(grid), dim3(256), 0, ctx->stream, (const T*)mag, (const HpssCplx<T>*)D, out_h, out_p, a);
             return;
         }
@@ -1489,6 +1504,7 @@ int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value) {
     else if (!std::strcmp(key, "v2")) ctx->opt_v2 = value != 0;
     else if (!std::strcmp(key, "direct")) ctx->opt_direct = value != 0;
     else if (!std::strcmp(key, "mixed")) ctx->opt_mixed = value != 0;
+    else if (!std::strcmp(key, "hpss_tile")) ctx->opt_hpss_tile = value != 0;
     else if (!std::strcmp(key, "autotune")) ctx->opt_autotune = value != 0;
     else if (!std::strcmp(key, "mel_runs")) ctx->opt_mel_runs = value != 0;
     else if (!std::strcmp(key, "variant")) ctx->opt_variant = (value >= 0 && value < kNumVariants) ? value : -1;

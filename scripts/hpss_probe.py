@@ -16,6 +16,16 @@ def timeit(fn, n=5):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-for kw in (dict(), dict(kernel_size=(13, 31)), dict(kernel_size=63), dict(mask=True)):
+ctx = L.get_context(0)
+if len(sys.argv) > 2:   # counter passes: one call of each kernel
+    for tile in (1, 0):
+        ctx.set_option("hpss_tile", tile)
+        L.decompose.hpss(D, mask=True); L.decompose.hpss(D)
+    torch.cuda.synchronize()
+    sys.exit(0)
+for tile in (1, 0, 1, 0):
+  ctx.set_option("hpss_tile", tile)
+  for kw in (dict(), dict(kernel_size=(13, 31)), dict(kernel_size=63), dict(mask=True)):
+    print(f"tile={tile}", end=" ")
     print(f"decompose.hpss {clips} x 1025 x {D.shape[-1]} {kw}: {timeit(lambda: L.decompose.hpss(D, **kw)):.2f} ms", flush=True)
 print(f"effects.hpss {clips} clips x 30 s: {timeit(lambda: L.effects.hpss(y)):.2f} ms (stft {timeit(lambda: L.stft(y)):.2f} ms, istft {timeit(lambda: L.istft(D, length=y.shape[-1])):.2f} ms)", flush=True)

@@ -84,13 +84,28 @@ template <class F> void run_grid_serial(unsigned grid, unsigned block, F body) {
 
 namespace {
 template <class T> void sim_hpss(const void* mag, const void* D, void* out_h, void* out_p, const lra::HpssArgs& a, unsigned grid) {
-    const int widest = a.win_harm > a.win_perc ? a.win_harm : a.win_perc;  // the same selection as hpss_launch (lra_api.hip)
-    if (widest <= 32) {
+    const lra::HpssPlan plan = lra::hpss_plan(a, (int)sizeof(T));  // the same selection as hpss_launch (lra_api.hip)
+    const unsigned tgrid = (unsigned)((lra::hpss_tiles(a) + 255) / 256);
+    if (plan.tile_slots == 32 && plan.fixed_win) {
+        run_grid(tgrid, 256, [=] { lra::hpss_tile_kernel<T, 32, lra::kHpssFixedWin>((const T*)mag, (const lra::HpssCplx<T>*)D, out_h, out_p, a); });
+        return;
+    }
+    if (plan.tile_slots == 32) {
+        run_grid(tgrid, 256, [=] { lra::hpss_tile_kernel<T, 32, 0>((const T*)mag, (const lra::HpssCplx<T>*)D, out_h, out_p, a); });
+        return;
+    }
+    if constexpr (sizeof(T) == 4) {
+        if (plan.tile_slots == 64) {
+            run_grid(tgrid, 256, [=] { lra::hpss_tile_kernel<T, 64, 0>((const T*)mag, (const lra::HpssCplx<T>*)D, out_h, out_p, a); });
+            return;
+        }
+    }
+    if (plan.element_slots == 32) {
         run_grid_serial(grid, 256, [=] { lra::hpss_kernel<T, 32>((const T*)mag, (const lra::HpssCplx<T>*)D, out_h, out_p, a); });
         return;
     }
     if constexpr (sizeof(T) == 4) {
-        if (widest <= 64) {
+        if (plan.element_slots == 64) {
             run_grid_serial(grid, 256, [=] { lra::hpss_kernel<T, 64>((const T*)mag, (const lra::HpssCplx<T>*)D, out_h, out_p, a); });
             return;
         }

@@ -689,6 +689,25 @@ def test_hpss_body(dtype):
                     assert np.array_equal(g, e), kw
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_hpss_tile_kernel_windows(dtype):
+    """The 4 x 4-tile kernel's corners (lra_hpss.h, hpss_median_quad): shortest and longest windows of both network sizes, even windows,
+    axes of exactly win + 4 positions (every tile folds at both ends), axes that are not multiples of four, values with many ties --
+    real input, so bit for bit against the oracle."""
+    rng = np.random.default_rng(77)
+    cases = [(35, 35, 31, 31), (10, 11, 6, 7), (12, 37, 8, 33), (37, 10, 33, 6), (41, 23, 6, 18), (69, 12, 65, 7), (13, 70, 7, 65), (50, 45, 32, 33), (39, 38, 17, 31), (7, 9, 3, 3), (30, 30, 5, 9)]
+    for n_frames, n_bins, wh, wp in cases:
+        for ties in (False, True):
+            S = rng.random((2, n_bins, n_frames)).astype(dtype)
+            if ties:
+                S = np.round(S * 6).astype(dtype) / 4
+            St = np.ascontiguousarray(np.swapaxes(S, -1, -2))
+            exp = O.hpss(S, kernel_size=(wh, wp), mask=True, power=1.0)
+            got = H.hpss(St, win_harm=wh, win_perc=wp, power=1.0, margin_harm=1.0, margin_perc=1.0, want_mask=True)
+            for g, e in zip(got, exp):
+                assert np.array_equal(g, np.swapaxes(e, -1, -2).astype(g.dtype)), (n_frames, n_bins, wh, wp, ties)
+
+
 def test_hpss_shims_through_simulator(monkeypatch):
     """librosa_amd.decompose.hpss (layouts, dtypes, NumPy and tensor code paths, argument errors) and librosa_amd.effects.hpss / harmonic
     / percussive (with the two transforms supplied by the oracle) against the oracle's chain."""
