@@ -240,6 +240,20 @@ int lra_maxfilter_exec(lra_ctx* ctx, const void* S, void* out, int64_t outer, in
 int lra_fir_decimate_exec(lra_ctx* ctx, const void* x, void* out, int64_t batch, int64_t n_in, int64_t n_out, const void* taps, int n_taps, int down, int first, double div, double mul,
                           int dtype);
 
+/* librosa.resample(res_type="polyphase") for any rational ratio, librosa/core/audio.py:676-693 = scipy.signal.resample_poly(x, up, down):
+ * out[clip][n] = (sum_k x[clip][k] taps[(n + first) down - k up]) / div * mul over the real samples k under the filter (the
+ * zero-stuffed signal filtered and decimated: scipy's upfirdn, summed in its order).  taps = scipy's design times `up`, zero-prefixed;
+ * first = n_pre_remove; n_out = ceil(n_in up / down).  up == 1 is lra_fir_decimate_exec.  x, out, taps: real of `dtype` (device). */
+int lra_resample_poly_exec(lra_ctx* ctx, const void* x, void* out, int64_t batch, int64_t n_in, int64_t n_out, const void* taps, int n_taps, int up, int down, int first, double div,
+                           double mul, int dtype);
+
+/* librosa.resample(res_type="fft" / "scipy"), librosa/core/audio.py:672-675 = scipy.signal.resample(x, n_out) along the last axis for
+ * real x: out[clip] = irfft(Y, n_out) * (n_out / n_in) * gain, Y = the lower min(n_in, n_out) / 2 + 1 bins of rfft(x[clip]) (zero above),
+ * the shared Nyquist bin doubled when shortening / halved when lengthening an even length.  Whole-signal transforms (rocFFT, any
+ * length < 2^31; plans kept per length, least recently used evicted); gain: the caller's scaling (1 / sqrt(ratio) of
+ * resample(scale=True), :719-720).  x: [batch][n_in], out: [batch][n_out] real of `dtype` (device). */
+int lra_resample_fft_exec(lra_ctx* ctx, const void* x, void* out, int64_t batch, int64_t n_in, int64_t n_out, double gain, int dtype);
+
 /* out[clip][t][bin0 + r] = (sum_j val[j] D[clip][t][col[j]], j in row row0 + r of the CSR basis) / sqrt_len[r], 0 <= r < n_rows,
  * 0 <= t < n_frames.  D: [clip][frames_in][n_bins] complex (lra_stft_exec's layout), out: [clip][n_frames][n_total] complex, both of
  * `dtype`'s precision; row_ptr / col: int32, val: complex (device); sqrt_len: float64 [n_rows] (device) or NULL (scale=False). */

@@ -16,8 +16,8 @@ family, resampy's ``kaiser_*``, samplerate's ``sinc_*``) run this library's own 
 below 0.8 of the new Nyquist (``:1093``), inside every such filter's pass band, so the transforms agree to the resamplers'
 pass-band ripple -- 2.6e-3 of the peak against the reference's ``"polyphase"`` result, whose Kaiser-5 filter droops most; parity
 for this family is that tolerance statement, not pinned against soxr.  ``"fft"`` / ``"scipy"`` (whole-signal
-``scipy.signal.resample``, which also stretches time when a length is odd) and the non-band-limited ``"linear"`` /
-``"zero_order_hold"`` are not provided.
+``scipy.signal.resample``) run as two rocFFT transforms of the whole signal per halving (``lra_resample_fft_exec``), pinned against
+the reference like ``"polyphase"``.  The non-band-limited ``"linear"`` / ``"zero_order_hold"`` are not provided.
 """
 from __future__ import annotations
 
@@ -33,6 +33,7 @@ from .. import filters
 from ..util import utils as util
 from ..util.exceptions import ParameterError
 from ..util.utils import is_torch_tensor
+from .audio import _rational_filter
 from .intervals import interval_frequencies
 from .spectrum import _DEVICE_PAD_MODES, _all_finite, _as_like
 
@@ -46,7 +47,6 @@ __all__ = ["cqt", "vqt"]
 _C1_HZ = 440.0 * (2.0 ** ((24 - 69) / 12))  # note_to_hz("C1") (core/convert.py:573-620): MIDI note 24
 
 
-_FIR_LIKE = ("kaiser_best", "kaiser_fast", "sinc_best", "sinc_medium", "sinc_fastest")
 
 
 def _two_factors(x):
@@ -58,25 +58,13 @@ def _two_factors(x):
     return n
 
 
-@functools.lru_cache(maxsize=64)
 def _decimator(down, res_type, real):
-    """(taps incl. leading zeros, first output's offset) of the FIR that decimates by ``down`` (cached: treat the taps as read-only).
+    """(taps incl. leading zeros, first output's offset) of the FIR that decimates by ``down``: ``audio._rational_filter(1, down, ...)``
+    (``"polyphase"``: scipy's design, reproduced exactly; other names: the library's own band-limited design)."""
+    return _rational_filter(1, int(down), res_type, real)
 
-    ``"polyphase"``: ``scipy.signal.resample_poly(x, 1, down)``'s own design and alignment (its default Kaiser-5 window, 10 ``down``
-    taps each side, the zero prefix that centres the output grid).  Anything else: a Kaiser design with soxr-HQ's band edges."""
-    if not isinstance(res_type, str) or not (res_type == "polyphase" or res_type.startswith("soxr") or res_type in _FIR_LIKE):
-        raise ParameterError(f"res_type={res_type!r} is not provided by librosa_amd.vqt: use 'polyphase' (scipy's design, reproduced exactly) or a band-limited "
-                             "resampler name (soxr_*, kaiser_*, sinc_*: the library's own decimator)")
-    if res_type == "polyphase":
-        half = 10 * down
-        taps = scipy.signal.firwin(2 * half + 1, 1.0 / down, window=("kaiser", 5.0)).astype(real)
-        lead = down - half % down
-        return np.concatenate([np.zeros(lead, dtype=real), taps]), (half + lead) // down
-    width = 0.087 / down                      # transition: 0.913 .. 1.0 of the new Nyquist, in units of the old Nyquist
-    n_taps, beta = scipy.signal.kaiserord(125.0, width)
-    half = -(-(n_taps // 2) // down) * down   # half length rounded up to a multiple of `down`: integer output alignment without a prefix
-    taps = scipy.signal.firwin(2 * half + 1, (1.0 - 0.5 * 0.087) / down, window=("kaiser", beta)).astype(real)
-    return taps, half // down
+
+_SPECTRAL = ("fft", "scipy")   # scipy.signal.resample: whole-signal Fourier resampling (core/audio.py:672-675)
 
 
 def _auto_n_bins(sr, fmin, intervals, gamma, bins_per_octave, filter_scale, window):
@@ -184,7 +172,8 @@ def vqt(y, *, sr=22050, hop_length=512, fmin=None, n_bins=84, intervals="equal",
         n_bins = _auto_n_bins(float(sr), float(fmin), intervals, None if gamma is None else float(gamma), int(bins_per_octave), float(filter_scale), window)
     if not (isinstance(pad_mode, str) and pad_mode in _DEVICE_PAD_MODES):
         raise ParameterError(f"pad_mode={pad_mode!r} is not supported by librosa_amd.vqt")
-    _decimator(2, res_type, real)  # validates res_type (also when no octave needs a decimation)
+    if res_type not in _SPECTRAL:
+        _decimator(2, res_type, real)  # validates res_type (also when no octave needs a decimation)
     plan_key = (float(sr), int(hop_length), float(fmin), int(n_bins), intervals, None if gamma is None else float(gamma), int(bins_per_octave), float(filter_scale),
                 None if norm is None else float(norm), float(sparsity), window, bool(scale), cplx.str)
     try:
@@ -222,16 +211,22 @@ def vqt(y, *, sr=22050, hop_length=512, fmin=None, n_bins=84, intervals="equal",
             taps, first = _decimator(down, res_type, real)
             return ctx.device_table(("fir", down, res_type, real.str), lambda: taps), len(taps), first
 
+        def shorten(src, n_from, n_to, down, extra):
+            """audio.resample(orig_sr=down, target_sr=1, scale=True) of the (batch, n_from) signal at ``src`` into scratch; ``extra``: a factor on top."""
+            dst = sess.scratch(batch * n_to * real.itemsize)
+            if res_type in _SPECTRAL:
+                ctx.resample_fft_exec(src, dst, batch, n_from, n_to, np.sqrt(float(down)) * extra, real)
+            else:
+                taps_ptr, n_taps, first = decimator(down)
+                ctx.fir_decimate_exec(src, dst, batch, n_from, n_to, taps_ptr, n_taps, down, first, np.sqrt(1.0 / down), extra, real)
+            return dst
+
         if plan["early"]:
-            taps_ptr, n_taps, first = decimator(factor)
-            nxt = sess.scratch(batch * lens[0] * real.itemsize)
             # resample(scale=True) divides by sqrt(1 / factor); an unscaled transform multiplies by sqrt(factor) on top (:1254-1264)
-            ctx.fir_decimate_exec(y_ptr, nxt, batch, n, lens[0], taps_ptr, n_taps, factor, first, np.sqrt(1.0 / factor), 1.0 if scale else np.sqrt(factor), real)
-            y_ptr = nxt
+            y_ptr = shorten(y_ptr, n, lens[0], factor, 1.0 if scale else np.sqrt(factor))
         out_ptr, handle = sess.output((batch, n_frames, n_bins), cplx)
         d_ptr = None  # spectrum scratch of the unfused octaves (frame lengths beyond the fused kernel's), allocated on first need
         sqrt_len_ptr = table("sqrt_len", plan["sqrt_len"], np.float64) if plan["sqrt_len"] is not None else None
-        half_taps = None
         for i, o in enumerate(octaves):
             n_fft, hop = o["n_fft"], o["hop"]
             if n_fft > lens[i]:   # the warning of the reference's stft (core/spectrum.py:267-271), once per octave it applies to
@@ -248,11 +243,7 @@ def vqt(y, *, sr=22050, hop_length=512, fmin=None, n_bins=84, intervals="equal",
                 ctx.stft_exec(splan, y_ptr, batch, lens[i], lens[i], d_ptr)
                 ctx.cqt_project_exec(d_ptr, out_ptr, csr[0], csr[1], csr[2], scl, batch, frames[i], n_fft // 2 + 1, n_frames, n_bins, o["bin0"], o["row0"], o["n_rows"], real)
             if o["halve"]:
-                if half_taps is None:
-                    half_taps = decimator(2)
-                nxt = sess.scratch(batch * lens[i + 1] * real.itemsize)
-                ctx.fir_decimate_exec(y_ptr, nxt, batch, lens[i], lens[i + 1], half_taps[0], half_taps[1], 2, half_taps[2], np.sqrt(0.5), 1.0, real)
-                y_ptr = nxt
+                y_ptr = shorten(y_ptr, lens[i], lens[i + 1], 2, 1.0)
         if check and ctx.nonfinite_read() and not _all_finite(y):
             raise ParameterError("Audio buffer is not finite everywhere")
         res = sess.result(handle)

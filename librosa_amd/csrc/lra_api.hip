@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -85,6 +86,7 @@ struct lra_ctx {
     std::map<std::pair<int, int>, std::pair<void*, void*>> cqt_tw;  // (n_fft, dtype) -> (W_M^t, W_N^k) of the fused constant-Q octave kernel (lra_mixed.h)
     std::string name;
     struct HostPipe* pipe = nullptr;  // staging of the host-buffer entry points (lra_stft_exec_host), created on first use
+    struct ResampleFft* rs_fft = nullptr;  // whole-signal transforms of lra_resample_fft_exec, created on first use
     int opt_pipe_chunk_mb = 128;      // bytes (in + out) one pipeline stage moves
     int opt_pipe_threads = 8;         // host threads per staging copy
 };
@@ -715,6 +717,39 @@ template <class E> __global__ void transpose_kernel(const E* __restrict__ src, E
         if (r < rows && c < cols) d[c * rows + r] = tile[threadIdx.x][j];
     }
 }
+
+namespace {
+
+}  // namespace
+
+// Whole-signal rocFFT plans of the Fourier-domain resampler, one cache per (direction, precision, length), least recently used of
+// kMaxResampleLengths evicted (signals of many different lengths must not accumulate plans and work buffers), and the two spectra.
+constexpr size_t kMaxResampleLengths = 12;
+struct ResampleFft {
+    struct Entry {
+        int type, dtype;
+        long long n;
+        std::unique_ptr<FftPlanCache> cache;
+    };
+    std::vector<Entry> entries;  // most recently used last
+    Scratch spec_in, spec_out;
+    FftPlanCache order;  // cross-stream ordering of the two spectra (scratch_acquire / scratch_release)
+    FftPlanCache* get(int type, int dtype, long long n) {
+        for (size_t i = 0; i < entries.size(); ++i)
+            if (entries[i].type == type && entries[i].dtype == dtype && entries[i].n == n) {
+                Entry e = std::move(entries[i]);
+                entries.erase(entries.begin() + (long)i);
+                entries.push_back(std::move(e));
+                return entries.back().cache.get();
+            }
+        if (entries.size() >= kMaxResampleLengths) {
+            (void)hipDeviceSynchronize();  // the evicted plans may still have work in flight
+            entries.erase(entries.begin());
+        }
+        entries.push_back(Entry{type, dtype, n, std::make_unique<FftPlanCache>()});
+        return entries.back().cache.get();
+    }
+};
 
 namespace {
 
@@ -1463,6 +1498,7 @@ void lra_ctx_destroy(lra_ctx* ctx) {
     if (!ctx) return;
     DeviceGuard device_guard__(ctx->device);
     delete ctx->pipe;
+    delete ctx->rs_fft;
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
     for (auto& kv : ctx->cqt_tw) {
@@ -2231,6 +2267,83 @@ int lra_fir_decimate_exec(lra_ctx* ctx, const void* x, void* out, int64_t batch,
 #undef LRA_FIR
     LRA_HIP(hipGetLastError());
     return LRA_OK;
+}
+
+int lra_resample_poly_exec(lra_ctx* ctx, const void* x, void* out, int64_t batch, int64_t n_in, int64_t n_out, const void* taps, int n_taps, int up, int down, int first, double div, double mul,
+                           int dtype) {
+    if (up == 1) return lra_fir_decimate_exec(ctx, x, out, batch, n_in, n_out, taps, n_taps, down, first, div, mul, dtype);  // the staged decimators
+    LRA_BIND(ctx);
+    if (n_taps < 1 || up < 1 || down < 1 || first < 0 || !(div > 0)) return fail(LRA_EINVAL, "resample_poly: n_taps, up and down must be positive, first non-negative, div positive");
+    if (batch <= 0 || n_out <= 0) return LRA_OK;
+    if (n_in <= 0) return fail(LRA_EINVAL, "resample_poly: empty input");
+    if (!x || !out || !taps) return fail(LRA_EINVAL, "null data pointer");
+    if (dtype != LRA_F32 && dtype != LRA_F64) return fail(LRA_EINVAL, "resample_poly: dtype must be LRA_F32 or LRA_F64");
+    const long long count = (long long)batch * n_out;
+    if ((count + 255) / 256 > 0x7fffffffLL) return fail(LRA_EINVAL, "resample_poly: array too large for one launch");
+    const unsigned grid = (unsigned)((count + 255) / 256);
+    if (dtype == LRA_F64)
+        hipLaunchKernelGGL(resample_poly_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)x, (double*)out, (const double*)taps, (long long)batch, (long long)n_in,
+                           (long long)n_out, n_taps, up, down, first, div, mul);
+    else
+        hipLaunchKernelGGL(resample_poly_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)x, (float*)out, (const float*)taps, (long long)batch, (long long)n_in,
+                           (long long)n_out, n_taps, up, down, first, div, mul);
+    LRA_HIP(hipGetLastError());
+    return LRA_OK;
+}
+
+}  // extern "C"
+
+namespace {
+template <class T> int resample_fft_run(lra_ctx* ctx, const T* x, T* out, long long batch, long long n_in, long long n_out, double gain, int dtype) {
+    if (!ctx->rs_fft) ctx->rs_fft = new ResampleFft();
+    ResampleFft* rs = ctx->rs_fft;
+    const long long bins_in = n_in / 2 + 1, bins_out = n_out / 2 + 1;
+    // clips per pass: both spectra of a pass within ~1 GB
+    long long per_pass = (1LL << 30) / ((bins_in + bins_out) * (long long)sizeof(cx<T>));
+    if (per_pass < 1) per_pass = 1;
+    if (per_pass > batch) per_pass = batch;
+    LRA_TRY(rs->spec_in.ensure((size_t)per_pass * bins_in * sizeof(cx<T>)));
+    LRA_TRY(rs->spec_out.ensure((size_t)per_pass * bins_out * sizeof(cx<T>)));
+    const long long N = n_out < n_in ? n_out : n_in;
+    const long long n_copy = N / 2 + 1;
+    const long long shared = (N % 2 == 0 && n_in != n_out) ? N / 2 : -1;
+    const T factor = n_out < n_in ? (T)2 : (T)0.5;
+    const long long real_last = n_out % 2 == 0 ? n_out / 2 : -1;
+    FftPlanCache* fwd = rs->get((int)rocfft_transform_type_real_forward, dtype, n_in);
+    FftPlanCache* inv = rs->get((int)rocfft_transform_type_real_inverse, dtype, n_out);
+    LRA_TRY(scratch_acquire(rs->order, ctx->stream));
+    for (long long c0 = 0; c0 < batch; c0 += per_pass) {
+        const long long cnt = batch - c0 < per_pass ? batch - c0 : per_pass;
+        rocfft_plan plan;
+        LRA_TRY(get_rocfft_plan(*fwd, ctx, rocfft_transform_type_real_forward, dtype, (int)n_in, cnt, &plan));
+        void* ib[1] = {(void*)(x + c0 * n_in)};
+        void* ob[1] = {rs->spec_in.p};
+        LRA_FFT(rocfft_execute(plan, ib, ob, fwd->info));
+        const long long count = cnt * bins_out;
+        hipLaunchKernelGGL(resample_spectrum_kernel<T>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, (const CqtCplx<T>*)rs->spec_in.p, (CqtCplx<T>*)rs->spec_out.p, cnt,
+                           bins_in, bins_out, n_copy, shared, factor, real_last, (T)gain);
+        LRA_HIP(hipGetLastError());
+        LRA_TRY(get_rocfft_plan(*inv, ctx, rocfft_transform_type_real_inverse, dtype, (int)n_out, cnt, &plan));
+        void* ib2[1] = {rs->spec_out.p};
+        void* ob2[1] = {(void*)(out + c0 * n_out)};
+        LRA_FFT(rocfft_execute(plan, ib2, ob2, inv->info));
+    }
+    LRA_TRY(scratch_release(rs->order, ctx->stream));
+    return LRA_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int lra_resample_fft_exec(lra_ctx* ctx, const void* x, void* out, int64_t batch, int64_t n_in, int64_t n_out, double gain, int dtype) {
+    LRA_BIND(ctx);
+    if (batch <= 0 || n_out <= 0) return LRA_OK;
+    if (n_in <= 0) return fail(LRA_EINVAL, "resample_fft: empty input");
+    if (!x || !out) return fail(LRA_EINVAL, "null data pointer");
+    if (dtype != LRA_F32 && dtype != LRA_F64) return fail(LRA_EINVAL, "resample_fft: dtype must be LRA_F32 or LRA_F64");
+    if (n_in > 0x7fffffffLL || n_out > 0x7fffffffLL) return fail(LRA_EINVAL, "resample_fft: signal too long for one transform");
+    if (dtype == LRA_F64) return resample_fft_run<double>(ctx, (const double*)x, (double*)out, batch, n_in, n_out, gain / (double)n_in, dtype);
+    return resample_fft_run<float>(ctx, (const float*)x, (float*)out, batch, n_in, n_out, gain / (double)n_in, dtype);
 }
 
 int lra_cqt_project_exec(lra_ctx* ctx, const void* D, void* out, const void* row_ptr, const void* col, const void* val, const void* sqrt_len, int64_t batch, int64_t frames_in, int n_bins,

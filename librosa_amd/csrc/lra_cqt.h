@@ -57,6 +57,54 @@ __global__ __launch_bounds__(256) void fir_decimate_direct_kernel(const T* __res
     out[id] = mul == 1.0 ? scaled : (T)((double)scaled * mul);
 }
 
+// ---- general rational resampling, scipy.signal.resample_poly(x, up, down) (librosa.resample(res_type="polyphase"), core/audio.py:676-693):
+// the signal with up - 1 zeros between samples, filtered by h, every down-th sample kept (scipy's upfirdn).  Output n sits at position
+// (n + first) * down of the zero-stuffed signal; only the taps over real samples are summed, over ascending input index like upfirdn's
+// inner loop: out[n] = sum_k x[k] h[(n + first) down - k up].  ceil(n_taps / up) products per output (the filter has 20 max(up, down) + 1
+// taps: about 20 down / up + 1 of them), a thread per output, neighbouring threads' windows overlap (L1).
+template <class T>
+__global__ __launch_bounds__(256) void resample_poly_kernel(const T* __restrict__ x, T* __restrict__ out, const T* __restrict__ h, long long batch, long long n_in, long long n_out, int n_taps,
+                                                            int up, int down, int first, double div, double mul) {
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= batch * n_out) return;
+    const long long clip = id / n_out, n = id % n_out;
+    const T* __restrict__ xc = x + clip * n_in;
+    const long long top = (n + first) * (long long)down;  // position of tap 0 in the zero-stuffed signal
+    long long k_hi = top / up;                              // last real sample at or before it
+    long long k_lo = top - (n_taps - 1) <= 0 ? 0 : (top - (n_taps - 1) + up - 1) / up;
+    if (k_hi > n_in - 1) k_hi = n_in - 1;
+    T acc = (T)0;
+    for (long long k = k_lo; k <= k_hi; ++k) acc = CqtOps<T>::madd(acc, xc[k], h[top - k * up]);
+    const T scaled = (T)((double)acc / div);
+    out[id] = mul == 1.0 ? scaled : (T)((double)scaled * mul);
+}
+
+// ---- Fourier-domain resampling, scipy.signal.resample(x, num) for real x (librosa.resample(res_type="fft" / "scipy"), core/audio.py:672-675):
+// rfft, the lower min(num, Nx) / 2 + 1 bins copied (the rest zero), the shared Nyquist bin doubled when shortening / halved when
+// lengthening an even length, irfft, times num / Nx.  This kernel is the middle step: Y[clip][k] of bins_out bins from X[clip][k] of
+// bins_in; `gain` carries the normalisation of the unnormalised inverse transform (1 / Nx) and the caller's scaling.  The imaginary
+// parts of bin 0 and of the output's own Nyquist bin are cleared (irfft ignores them).
+template <class T>
+__global__ __launch_bounds__(256) void resample_spectrum_kernel(const CqtCplx<T>* __restrict__ X, CqtCplx<T>* __restrict__ Y, long long batch, long long bins_in, long long bins_out,
+                                                                long long n_copy, long long shared_nyquist, T nyquist_factor, long long real_last, T gain) {
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= batch * bins_out) return;
+    const long long clip = id / bins_out, k = id % bins_out;
+    CqtCplx<T> v;
+    v.x = v.y = (T)0;
+    if (k < n_copy) {
+        v = X[clip * bins_in + k];
+        if (k == shared_nyquist) {
+            v.x *= nyquist_factor;
+            v.y *= nyquist_factor;
+        }
+        if (k == 0 || k == real_last) v.y = (T)0;
+        v.x *= gain;
+        v.y *= gain;
+    }
+    Y[id] = v;
+}
+
 // A workgroup produces 256 consecutive outputs of one clip: their common input span (255 down + n_taps samples) is staged in LDS
 // once (zeros outside the signal: adding 0 * h leaves the running sum unchanged), every thread then walks its n_taps-long window of
 // it; the tap index is the same for all lanes in each step, so the taps come through the scalar cache.

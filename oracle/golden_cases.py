@@ -124,6 +124,28 @@ CQT_CASES = {
 }
 
 
+RESAMPLE_CASES = {
+    # name: (signal (kind, n, seed, channels, dtype), librosa.resample kwargs); the scipy-backed converters (the ones the reference runs here)
+    "fft_22050_8000": (("mix", 6000, 131, None, "float32"), dict(orig_sr=22050, target_sr=8000, res_type="fft")),
+    "fft_halve_even": (("mix", 5000, 132, (2,), "float32"), dict(orig_sr=2, target_sr=1, res_type="fft", scale=True)),
+    "fft_halve_odd": (("mix", 5001, 133, None, "float32"), dict(orig_sr=2, target_sr=1, res_type="scipy", scale=True)),
+    "fft_up_even_f64": (("mix", 3000, 134, None, "float64"), dict(orig_sr=8000, target_sr=22050, res_type="fft")),
+    "fft_up_double": (("chirp", 2048, 135, None, "float32"), dict(orig_sr=1, target_sr=2, res_type="fft", scale=True)),
+    "fft_prime_length": (("mix", 4099, 136, None, "float32"), dict(orig_sr=22050, target_sr=16000, res_type="scipy")),
+    "poly_22050_8000": (("mix", 6000, 137, None, "float32"), dict(orig_sr=22050, target_sr=8000, res_type="polyphase")),
+    "poly_up_f64_scale": (("mix", 3000, 138, (2,), "float64"), dict(orig_sr=16000, target_sr=22050, res_type="polyphase", scale=True)),
+    "poly_44100_22050": (("chirp", 9001, 139, None, "float32"), dict(orig_sr=44100, target_sr=22050, res_type="polyphase")),
+}
+
+CQT_FFT_CASES = {
+    # as CQT_CASES with the whole-signal Fourier resampler between the octaves (res_type in the kwargs)
+    "cqt_fft_default": ("cqt", ("mix", 33075, 141, None, "float32"), dict(res_type="fft")),
+    "cqt_scipy_early_downsample": ("cqt", ("chirp", 33075, 142, None, "float32"), dict(n_bins=24, res_type="scipy")),
+    "vqt_fft_stereo_odd": ("vqt", ("mix", 22051, 143, (2,), "float32"), dict(res_type="fft", hop_length=256, n_bins=60)),
+    "cqt_fft_f64": ("cqt", ("mix", 22050, 144, None, "float64"), dict(n_bins=48, bins_per_octave=24, fmin=220.0, res_type="fft")),
+}
+
+
 HPSS_CASES = {
     # name: decompose.hpss kwargs on D = stft(mix, n_fft=128, hop=100) (65, 61) complex64; "power_*": on |D|**2 (real input)
     "default": dict(),

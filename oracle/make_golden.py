@@ -92,6 +92,7 @@ def main():
     make_vocoder(librosa, meta)
     make_pcen(librosa, meta)
     make_cqt(librosa, meta)
+    make_resample(librosa, meta)
     make_hpss(librosa, meta)
 
 
@@ -147,6 +148,19 @@ def make_cqt(librosa, meta):
         store[name] = getattr(librosa, fn)(y, sr=golden_cases.SR, res_type="polyphase", **kw)
     np.savez_compressed(os.path.join(OUT, "cqt.npz"), params=json.dumps(dict(case="cqt", **meta)), **store)
     print("cqt done")
+
+
+def make_resample(librosa, meta):
+    """librosa.resample (core/audio.py:1002-1178) with the scipy-backed converters, and librosa.cqt / vqt with res_type="fft" / "scipy"."""
+    store = {}
+    for name, ((kind, n, seed, channels, dtype), kw) in golden_cases.RESAMPLE_CASES.items():
+        y = golden_cases.make_signal(kind, n, seed, channels, dtype)
+        store[name] = librosa.resample(y, **kw)
+    for name, (fn, (kind, n, seed, channels, dtype), kw) in golden_cases.CQT_FFT_CASES.items():
+        y = golden_cases.make_signal(kind, n, seed, channels, dtype)
+        store[name] = getattr(librosa, fn)(y, sr=golden_cases.SR, **kw)
+    np.savez_compressed(os.path.join(OUT, "resample.npz"), params=json.dumps(dict(case="resample", **meta)), **store)
+    print("resample done")
 
 
 def make_hpss(librosa, meta):
@@ -208,11 +222,11 @@ def make_db_mfcc(librosa, meta):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] in ("griffinlim", "vocoder", "pcen", "cqt", "hpss"):  # only this fixture (the others are unchanged)
+    if len(sys.argv) > 1 and sys.argv[1] in ("griffinlim", "vocoder", "pcen", "cqt", "hpss", "resample"):  # only this fixture (the others are unchanged)
         _librosa = ref_shim.load_reference()
         import scipy as _scipy
 
         _meta = dict(numpy=np.__version__, scipy=_scipy.__version__, reference_version=str(_librosa.__version__))
-        dict(griffinlim=make_griffinlim, vocoder=make_vocoder, pcen=make_pcen, cqt=make_cqt, hpss=make_hpss)[sys.argv[1]](_librosa, _meta)
+        dict(griffinlim=make_griffinlim, vocoder=make_vocoder, pcen=make_pcen, cqt=make_cqt, hpss=make_hpss, resample=make_resample)[sys.argv[1]](_librosa, _meta)
     else:
         main()

@@ -147,6 +147,18 @@ int postsim_maxfilter(const void* S, void* out, long long outer, int n_bands, lo
     return 0;
 }
 
+// the launch of lra_resample_poly_exec (lra_api.hip); up == 1 goes to the decimators below, as there
+int postsim_fir_decimate(const void* x, void* out, long long batch, long long n_in, long long n_out, const void* taps, int n_taps, int down, int first, double div, double mul, int is_f64);
+int postsim_resample_poly(const void* x, void* out, long long batch, long long n_in, long long n_out, const void* taps, int n_taps, int up, int down, int first, double div, double mul, int is_f64) {
+    if (up == 1) return postsim_fir_decimate(x, out, batch, n_in, n_out, taps, n_taps, down, first, div, mul, is_f64);
+    const unsigned grid = (unsigned)((batch * n_out + 255) / 256);
+    if (is_f64)
+        run_grid_serial(grid, 256, [=] { lra::resample_poly_kernel<double>((const double*)x, (double*)out, (const double*)taps, batch, n_in, n_out, n_taps, up, down, first, div, mul); });
+    else
+        run_grid_serial(grid, 256, [=] { lra::resample_poly_kernel<float>((const float*)x, (float*)out, (const float*)taps, batch, n_in, n_out, n_taps, up, down, first, div, mul); });
+    return 0;
+}
+
 // the launches of lra_fir_decimate_exec / lra_cqt_project_exec (lra_api.hip)
 int postsim_fir_decimate(const void* x, void* out, long long batch, long long n_in, long long n_out, const void* taps, int n_taps, int down, int first, double div, double mul, int is_f64) {
     // (as lra_fir_decimate_exec, lra_api.hip: four outputs per thread for big jobs whose span fits, else one; the direct kernel for spans beyond the LDS)

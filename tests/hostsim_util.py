@@ -158,6 +158,7 @@ def post_lib():
         _post.postsim_pcen.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_longlong, c.c_longlong, c.c_int] + [c.c_double] * 5 + [c.c_void_p, c.c_double, c.c_void_p]
         _post.postsim_maxfilter.argtypes = [c.c_void_p, c.c_void_p, c.c_longlong, c.c_int, c.c_longlong, c.c_int, c.c_int]
         _post.postsim_fir_decimate.argtypes = [c.c_void_p, c.c_void_p, c.c_longlong, c.c_longlong, c.c_longlong, c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_double, c.c_double, c.c_int]
+        _post.postsim_resample_poly.argtypes = [c.c_void_p, c.c_void_p, c.c_longlong, c.c_longlong, c.c_longlong, c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_int, c.c_double, c.c_double, c.c_int]
         _post.postsim_magnitude.argtypes = [c.c_void_p, c.c_void_p, c.c_longlong, c.c_int]
         _post.postsim_hpss.argtypes = [c.c_void_p] * 4 + [c.c_longlong, c.c_longlong, c.c_int, c.c_int, c.c_int, c.c_double, c.c_double, c.c_double, c.c_int, c.c_int]
         _post.postsim_cqt_project.argtypes = [c.c_void_p] * 6 + [c.c_longlong, c.c_longlong, c.c_int, c.c_longlong, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int]
@@ -190,6 +191,15 @@ def fir_decimate(x, taps, down, first, n_out, div=1.0, mul=1.0):
     taps = np.ascontiguousarray(taps, dtype=x.dtype)
     out = np.full((x.shape[0], n_out), np.nan, dtype=x.dtype)
     post_lib().postsim_fir_decimate(_p(x), _p(out), x.shape[0], x.shape[1], n_out, _p(taps), len(taps), int(down), int(first), float(div), float(mul), int(x.dtype == np.float64))
+    return out
+
+
+def resample_poly(x, taps, up, down, first, n_out, div=1.0, mul=1.0):
+    """x: (batch, n_in) -> (batch, n_out) through the kernel body of lra_resample_poly_exec."""
+    x = np.ascontiguousarray(x)
+    taps = np.ascontiguousarray(taps, dtype=x.dtype)
+    out = np.full((x.shape[0], n_out), np.nan, dtype=x.dtype)
+    post_lib().postsim_resample_poly(_p(x), _p(out), x.shape[0], x.shape[1], n_out, _p(taps), len(taps), int(up), int(down), int(first), float(div), float(mul), int(x.dtype == np.float64))
     return out
 
 

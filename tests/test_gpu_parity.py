@@ -1458,6 +1458,65 @@ def test_cqt_golden(L, name):
     assert isinstance(Ct, torch.Tensor) and Ct.is_cuda and np.array_equal(Ct.cpu().numpy(), C)
 
 
+@pytest.mark.parametrize("name", list(golden_cases.CQT_FFT_CASES))
+def test_cqt_fft_resampler_golden(L, name):
+    """res_type="fft" / "scipy": the octaves are resampled by whole-signal transforms (lra_resample_fft_exec: rocFFT both ways) --
+    against the unmodified reference's output.  float32 transforms of up to 33 075 points on both sides: 1e-4 of the peak."""
+    import torch
+
+    fn, (kind, n, seed, channels, dtype), kw = golden_cases.CQT_FFT_CASES[name]
+    g = np.load(os.path.join(GOLDEN_DIR, "resample.npz"))
+    y = golden_cases.make_signal(kind, n, seed, channels, dtype)
+    tol = 1e-10 if dtype == "float64" else 1e-4
+    with warnings.catch_warnings():
+        warnings.filterwarnings("ignore", message="n_fft=.*is too large")
+        C = getattr(L, fn)(y, sr=golden_cases.SR, **kw)
+        assert C.shape == g[name].shape and C.dtype == g[name].dtype and np.abs(C - g[name]).max() <= tol * np.abs(g[name]).max(), np.abs(C - g[name]).max() / np.abs(g[name]).max()
+        Ct = getattr(L, fn)(torch.from_numpy(y).cuda(), sr=golden_cases.SR, **kw)
+    assert isinstance(Ct, torch.Tensor) and Ct.is_cuda and np.array_equal(Ct.cpu().numpy(), C)
+
+
+@pytest.mark.parametrize("name", list(golden_cases.RESAMPLE_CASES))
+def test_resample_golden(L, name):
+    """librosa_amd.resample against the unmodified reference (tests/golden/resample.npz): the Fourier converter to float32 / float64
+    transform accuracy (1e-5 / 1e-12 of the peak), the polyphase converter bit for bit (scipy's taps, upfirdn's summation order)."""
+    import torch
+
+    (kind, n, seed, channels, dtype), kw = golden_cases.RESAMPLE_CASES[name]
+    g = np.load(os.path.join(GOLDEN_DIR, "resample.npz"))
+    y = golden_cases.make_signal(kind, n, seed, channels, dtype)
+    got = L.resample(y, **kw)
+    assert got.shape == g[name].shape and got.dtype == g[name].dtype
+    if kw["res_type"] == "polyphase":
+        assert np.array_equal(got, g[name])
+    else:
+        assert np.abs(got - g[name]).max() <= (1e-12 if dtype == "float64" else 1e-5) * np.abs(g[name]).max(), np.abs(got - g[name]).max() / np.abs(g[name]).max()
+    dev = L.resample(torch.from_numpy(y).cuda(), **kw)
+    assert isinstance(dev, torch.Tensor) and dev.is_cuda and np.array_equal(dev.cpu().numpy(), got)
+
+
+def test_resample_properties(L):
+    """Size-independent properties on a batch the oracle would not finish quickly: 64 clips x 30 s at 22 050 Hz -> 16 000 Hz -> back, all
+    three converter families; a band-limited signal survives the round trip, lengths are ceil(n * ratio), linearity, and the time axis
+    may be any axis."""
+    import torch
+
+    sr, n = 22050, 22050 * 30
+    t = torch.arange(n, device="cuda", dtype=torch.float64) / sr
+    f = torch.linspace(110.0, 3520.0, 64, device="cuda", dtype=torch.float64)[:, None]
+    y = (torch.sin(2 * np.pi * f * t) * torch.hann_window(n, device="cuda", dtype=torch.float64)).to(torch.float32)   # tones below 0.45 of the lower Nyquist, faded ends
+    for res_type, tol in (("fft", 1e-4), ("polyphase", 2e-2), ("soxr_hq", 1e-4)):
+        lo = L.resample(y, orig_sr=sr, target_sr=16000, res_type=res_type)
+        assert lo.shape == (64, int(np.ceil(n * 16000 / sr))) and bool(torch.isfinite(lo).all())
+        back = L.resample(lo, orig_sr=16000, target_sr=sr, res_type=res_type)
+        assert back.shape == y.shape
+        err = (back - y)[:, 2000:-2000].abs().max().item()
+        assert err <= tol, (res_type, err)
+        two = L.resample(2.0 * y[:4] + y[4:8], orig_sr=sr, target_sr=16000, res_type=res_type)
+        assert (two - (2.0 * lo[:4] + lo[4:8])).abs().max().item() <= 1e-5
+        assert torch.equal(L.resample(y[:3].T.contiguous(), orig_sr=sr, target_sr=16000, res_type=res_type, axis=0).T, lo[:3])
+
+
 def test_cqt_default_resampler_and_errors(L):
     """The default res_type (soxr_hq in the reference; here the library's own decimator with soxr-HQ's band edges) against the oracle's
     polyphase transform: the two differ by the resamplers' pass-band responses only (2.6e-3 of the peak measured on
@@ -1475,7 +1534,7 @@ def test_cqt_default_resampler_and_errors(L):
         tone = np.sin(2 * np.pi * f * np.arange(sr) / sr).astype(np.float32)
         mag = np.abs(L.cqt(tone, sr=sr))
         assert mag.shape == (84, 1 + sr // 512) and np.all(np.argmax(mag[:, 5:-5], axis=0) == midi - 24)
-    for bad in (dict(tuning=None), dict(fmin=20000.0), dict(n_bins=200), dict(pad_mode="wrap"), dict(hop_length=0), dict(res_type="fft"), dict(res_type="linear")):
+    for bad in (dict(tuning=None), dict(fmin=20000.0), dict(n_bins=200), dict(pad_mode="wrap"), dict(hop_length=0), dict(res_type="zero_order_hold"), dict(res_type="linear")):
         with pytest.raises(L.ParameterError):
             L.cqt(y, **bad)
     with pytest.raises(L.ParameterError):

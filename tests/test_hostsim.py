@@ -339,6 +339,9 @@ class _SimCtx:
     def fir_decimate_exec(self, x_ptr, out_ptr, batch, n_in, n_out, taps_ptr, n_taps, down, first, div, mul, dtype):
         H.post_lib().postsim_fir_decimate(x_ptr, out_ptr, batch, n_in, n_out, taps_ptr, int(n_taps), int(down), int(first), float(div), float(mul), int(np.dtype(dtype) == np.float64))
 
+    def resample_poly_exec(self, x_ptr, out_ptr, batch, n_in, n_out, taps_ptr, n_taps, up, down, first, div, mul, dtype):
+        H.post_lib().postsim_resample_poly(x_ptr, out_ptr, batch, n_in, n_out, taps_ptr, int(n_taps), int(up), int(down), int(first), float(div), float(mul), int(np.dtype(dtype) == np.float64))
+
     def cqt_project_exec(self, d_ptr, out_ptr, row_ptr, col_ptr, val_ptr, sqrt_len_ptr, batch, frames_in, n_bins, n_frames, n_total, bin0, row0, n_rows, dtype):
         H.post_lib().postsim_cqt_project(d_ptr, out_ptr, row_ptr, col_ptr, val_ptr, sqrt_len_ptr, batch, frames_in, int(n_bins), n_frames, int(n_total), int(bin0), int(row0), int(n_rows),
                                          int(np.dtype(dtype) == np.float64))
@@ -488,6 +491,59 @@ def test_fir_decimate_body_is_resample_poly(dtype, down, n):
 
     got = H.fir_decimate(x, taps, down, first, n_out, div=np.sqrt(1.0 / down))
     assert np.array_equal(got, CQ.resample(x, orig_sr=down, target_sr=1, res_type="polyphase", scale=True))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("up,down,n", [(2, 1, 300), (3, 2, 1000), (2, 3, 1001), (160, 441, 5000), (441, 160, 700), (320, 441, 4001), (1, 3, 777), (5, 4, 1)])
+def test_resample_poly_body_is_resample_poly(dtype, up, down, n):
+    """The general rational resampler with scipy's own design and alignment == scipy.signal.resample_poly(x, up, down), bit for bit
+    (same taps, same summation order, no contraction)."""
+    import scipy.signal
+    from librosa_amd.core.audio import _rational_filter
+
+    rng = np.random.default_rng(up * 7919 + down * 31 + n)
+    x = rng.standard_normal((2, n)).astype(dtype)
+    taps, first = _rational_filter(up, down, "polyphase", np.dtype(dtype))
+    n_out = -(-n * up // down)
+    got = H.resample_poly(x, taps, up, down, first, n_out)
+    exp = scipy.signal.resample_poly(x, up, down, axis=-1)
+    assert got.shape == exp.shape and np.array_equal(got, exp)
+
+
+def test_resample_through_simulator(monkeypatch):
+    """librosa_amd.resample(res_type="polyphase") -- axis handling, integer-rate check, fix / scale, dtype, errors -- through the simulator,
+    against the oracle's restatement of librosa.resample (bit-identical)."""
+    import cqt_oracle as CQ
+    import librosa_amd
+    from librosa_amd import _arrays
+    from librosa_amd.util.exceptions import ParameterError
+
+    monkeypatch.setattr(_arrays, "Session", _SimSession)
+    rng = np.random.default_rng(5)
+    y = rng.standard_normal((2, 3, 4000)).astype(np.float32)
+    for orig, target, kw in ((22050, 8000, {}), (22050, 16000, dict(scale=True)), (8000, 22050, {}), (44100, 22050, dict(scale=True)), (22050, 11025.0, {}), (3, 2, dict(fix=False))):
+        got = librosa_amd.resample(y, orig_sr=orig, target_sr=target, res_type="polyphase", **kw)
+        exp = CQ.resample(y, orig_sr=orig, target_sr=target, res_type="polyphase", **{k: v for k, v in kw.items() if k != "fix"})
+        assert got.dtype == exp.dtype and got.shape == exp.shape and np.array_equal(got, exp), (orig, target, kw)
+    yt = np.ascontiguousarray(np.moveaxis(y, -1, 0))                    # time first
+    got = librosa_amd.resample(yt, orig_sr=22050, target_sr=8000, res_type="polyphase", axis=0)
+    assert np.array_equal(np.moveaxis(got, 0, -1), CQ.resample(y, orig_sr=22050, target_sr=8000, res_type="polyphase"))
+    y64 = y[0, 0].astype(np.float64)
+    got = librosa_amd.resample(y64, orig_sr=4, target_sr=3, res_type="polyphase")
+    assert got.dtype == np.float64 and np.array_equal(got, CQ.resample(y64, orig_sr=4, target_sr=3, res_type="polyphase"))
+    assert librosa_amd.resample(y, orig_sr=8000, target_sr=8000) is y
+    tone = np.sin(0.07 * np.arange(4000)) + 0.5 * np.cos(0.31 * np.arange(4000))   # well inside both pass bands
+    for orig, target in ((2, 1), (3, 2), (2, 3)):                               # the library's own design: band-limited, same output grid
+        own = librosa_amd.resample(tone, orig_sr=orig, target_sr=target, res_type="soxr_hq")
+        ref = CQ.resample(tone, orig_sr=orig, target_sr=target, res_type="polyphase")
+        assert own.shape == ref.shape and np.abs(own - ref)[100:-100].max() < 5e-3, (orig, target)
+    for bad in (dict(orig_sr=22050.5, target_sr=8000, res_type="polyphase"), dict(orig_sr=22050, target_sr=8000, res_type="linear"), dict(orig_sr=-1, target_sr=8000, res_type="fft")):
+        with pytest.raises(ParameterError):
+            librosa_amd.resample(y, **bad)
+    with pytest.raises(ParameterError):
+        librosa_amd.resample(y.astype(np.int16), orig_sr=2, target_sr=1)
+    with pytest.raises(ParameterError):
+        librosa_amd.resample(np.array([1.0, np.nan]), orig_sr=2, target_sr=1)
 
 
 def test_own_decimator_design():

@@ -395,6 +395,25 @@ def test_cqt_oracle_matches_reference_golden(name):
     assert got.shape == g[name].shape and got.dtype == g[name].dtype and np.array_equal(got, g[name])
 
 
+@pytest.mark.parametrize("name", list(golden_cases.RESAMPLE_CASES))
+def test_resample_oracle_matches_reference_golden(name):
+    """librosa.resample (core/audio.py:1002-1178) restated for the scipy-backed converters vs the unmodified reference
+    (oracle/make_golden.py::make_resample): bit for bit."""
+    (kind, n, seed, channels, dtype), kw = golden_cases.RESAMPLE_CASES[name]
+    g = np.load(os.path.join(GOLDEN_DIR, "resample.npz"))
+    got = CQ.resample(golden_cases.make_signal(kind, n, seed, channels, dtype), **kw)
+    assert got.shape == g[name].shape and got.dtype == g[name].dtype and np.array_equal(got, g[name])
+
+
+@pytest.mark.parametrize("name", list(golden_cases.CQT_FFT_CASES))
+def test_cqt_fft_oracle_matches_reference_golden(name):
+    """The recursion with the whole-signal Fourier resampler between the octaves (res_type="fft" / "scipy"): bit for bit."""
+    fn, (kind, n, seed, channels, dtype), kw = golden_cases.CQT_FFT_CASES[name]
+    g = np.load(os.path.join(GOLDEN_DIR, "resample.npz"))
+    got = getattr(CQ, fn)(golden_cases.make_signal(kind, n, seed, channels, dtype), sr=golden_cases.SR, **kw)
+    assert got.shape == g[name].shape and got.dtype == g[name].dtype and np.array_equal(got, g[name])
+
+
 def test_cqt_oracle_known_answers():
     """What the reference's tests assert about the transform itself (tests/test_constantq.py: shape and dtype, the energy of a pure tone
     sits in its bin, an impulse gives a flat column) and about its tables (filters.wavelet_lengths vs constant_q lengths)."""
