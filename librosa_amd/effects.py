@@ -1,7 +1,8 @@
 """Time-domain effects built on the path: ``librosa/effects.py``.
 
 ``time_stretch`` is the reference's stft -> phase vocoder -> istft chain (``librosa/effects.py:464-484``) and ``hpss`` /
-``harmonic`` / ``percussive`` its stft -> ``decompose.hpss`` -> istft chain (``:70-301``), with every stage on the device: for a
+``harmonic`` / ``percussive`` its stft -> ``decompose.hpss`` -> istft chain (``:70-301``), ``pitch_shift`` = ``time_stretch`` + ``resample``
+(``:487-596``), with every stage on the device: for a
 device tensor nothing crosses PCIe, for an ``np.ndarray`` only the signal goes up and the result comes down.
 """
 from __future__ import annotations
@@ -10,11 +11,12 @@ import numpy as np
 
 from . import _arrays
 from . import decompose
+from .core import audio as _audio
 from .core import spectrum
 from .util.exceptions import ParameterError
-from .util.utils import is_torch_tensor
+from .util.utils import fix_length, is_positive_int, is_torch_tensor
 
-__all__ = ["time_stretch", "hpss", "harmonic", "percussive"]
+__all__ = ["time_stretch", "pitch_shift", "hpss", "harmonic", "percussive"]
 
 
 def time_stretch(y, *, rate, **kwargs):
@@ -45,6 +47,30 @@ def time_stretch(y, *, rate, **kwargs):
     ikw.pop("pad_mode", None)
     out = spectrum.istft(Ds, dtype=_arrays.numpy_dtype_of(y), length=len_stretch, **ikw)
     return out.cpu().numpy() if staged else out
+
+
+def pitch_shift(y, *, sr, n_steps, bins_per_octave=12, res_type="soxr_hq", scale=False, **kwargs):
+    """Shift the pitch of an audio series by ``n_steps`` steps; drop-in for ``librosa.effects.pitch_shift`` (``librosa/effects.py:487-596``):
+    ``time_stretch`` by ``2 ** (-n_steps / bins_per_octave)``, ``resample`` back from ``sr / rate`` to ``sr``, crop / pad to the input's
+    length -- one upload and one download for a NumPy ``y``.  The intermediate rate is not an integer, so of the scipy-backed converters
+    only ``res_type="fft"`` / ``"scipy"`` apply (``"polyphase"`` raises, as in the reference); the band-limited names (``soxr_*``, the
+    default, ``kaiser_*``, ``sinc_*``) take the Fourier converter too, which is band-limited by construction (parity unpinned: those
+    packages are not in the build image)."""
+    if not is_positive_int(bins_per_octave):
+        raise ParameterError(f"bins_per_octave={bins_per_octave} must be a positive integer.")
+    rate = 2.0 ** (-float(n_steps) / bins_per_octave)
+    yd, staged = _stage(y)
+    stretched = time_stretch(yd, rate=rate, **kwargs)
+    orig_sr = float(sr) / rate
+    if res_type != "polyphase" and not (int(orig_sr) == orig_sr and int(sr) == sr) and (res_type.startswith("soxr") or res_type in _audio._FIR_LIKE):
+        res_type = "fft"
+    shifted = _audio.resample(stretched, orig_sr=orig_sr, target_sr=sr, res_type=res_type, scale=scale)
+    n = int(y.shape[-1])
+    if is_torch_tensor(shifted):
+        m = int(shifted.shape[-1])
+        shifted = shifted[..., :n] if m >= n else _arrays._torch().nn.functional.pad(shifted, (0, n - m))
+        return shifted.cpu().numpy() if staged else shifted
+    return fix_length(shifted, size=n)
 
 
 def _stage(y):

@@ -137,6 +137,15 @@ RESAMPLE_CASES = {
     "poly_44100_22050": (("chirp", 9001, 139, None, "float32"), dict(orig_sr=44100, target_sr=22050, res_type="polyphase")),
 }
 
+PITCH_SHIFT_CASES = {
+    # name: (signal, librosa.effects.pitch_shift kwargs); sr = SR.  res_type="fft": the converter that accepts the non-integer intermediate rate
+    "shift_up_4": (("mix", 12000, 151, None, "float32"), dict(n_steps=4, res_type="fft")),
+    "shift_down_tritone_stereo": (("mix", 9000, 152, (2,), "float32"), dict(n_steps=-6, res_type="fft", n_fft=1024)),
+    # ("mix", not "chirp": the vocoder accumulates the phase differences of EVERY frame, so a bin's rounding-level phase while it is empty
+    # becomes its phase offset once the sweep reaches it -- the reference's own output for a pure chirp moves by O(1) with the last bit of the STFT)
+    "shift_quarter_tones_scale": (("mix", 8000, 153, None, "float32"), dict(n_steps=3, bins_per_octave=24, res_type="scipy", scale=True, n_fft=512, hop_length=128)),
+}
+
 CQT_FFT_CASES = {
     # as CQT_CASES with the whole-signal Fourier resampler between the octaves (res_type in the kwargs)
     "cqt_fft_default": ("cqt", ("mix", 33075, 141, None, "float32"), dict(res_type="fft")),

@@ -151,7 +151,8 @@ def make_cqt(librosa, meta):
 
 
 def make_resample(librosa, meta):
-    """librosa.resample (core/audio.py:1002-1178) with the scipy-backed converters, and librosa.cqt / vqt with res_type="fft" / "scipy"."""
+    """librosa.resample (core/audio.py:1002-1178) with the scipy-backed converters, librosa.cqt / vqt with res_type="fft" / "scipy", and
+    librosa.effects.pitch_shift (effects.py:487-596) through the Fourier converter."""
     store = {}
     for name, ((kind, n, seed, channels, dtype), kw) in golden_cases.RESAMPLE_CASES.items():
         y = golden_cases.make_signal(kind, n, seed, channels, dtype)
@@ -159,6 +160,9 @@ def make_resample(librosa, meta):
     for name, (fn, (kind, n, seed, channels, dtype), kw) in golden_cases.CQT_FFT_CASES.items():
         y = golden_cases.make_signal(kind, n, seed, channels, dtype)
         store[name] = getattr(librosa, fn)(y, sr=golden_cases.SR, **kw)
+    for name, ((kind, n, seed, channels, dtype), kw) in golden_cases.PITCH_SHIFT_CASES.items():
+        y = golden_cases.make_signal(kind, n, seed, channels, dtype)
+        store[name] = librosa.effects.pitch_shift(y, sr=golden_cases.SR, **kw)
     np.savez_compressed(os.path.join(OUT, "resample.npz"), params=json.dumps(dict(case="resample", **meta)), **store)
     print("resample done")
 

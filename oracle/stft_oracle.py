@@ -507,6 +507,18 @@ def time_stretch(y, *, rate, **kwargs):
     return istft(Ds, dtype=y.dtype, length=round(y.shape[-1] / rate), **ikw)
 
 
+def pitch_shift(y, *, sr, n_steps, bins_per_octave=12, res_type="fft", scale=False, **kwargs):
+    """``librosa/effects.py:573-596``: time_stretch by 2 ** (-n_steps / bins_per_octave), resample from sr / rate back to sr (the
+    scipy-backed converters: ``cqt_oracle.resample``), fix_length to the input's length."""
+    import cqt_oracle
+
+    if not (isinstance(bins_per_octave, (int, np.integer)) and bins_per_octave > 0):
+        raise ParameterError(f"bins_per_octave={bins_per_octave} must be a positive integer.")
+    rate = 2.0 ** (-float(n_steps) / bins_per_octave)
+    y_shift = cqt_oracle.resample(time_stretch(y, rate=rate, **kwargs), orig_sr=float(sr) / rate, target_sr=sr, res_type=res_type, scale=scale)
+    return fix_length(y_shift, y.shape[-1])
+
+
 # ----------------------------------------------------------------------------- SURVEY.md 8f rank 4: block feeder
 def stream_blocks(y, *, block_length, frame_length, hop_length, fill_value=None):
     """Blocks ``librosa.stream`` yields for an already decoded signal ``y`` ((n,) or (channels, n)), stated directly from

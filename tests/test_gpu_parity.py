@@ -1495,6 +1495,30 @@ def test_resample_golden(L, name):
     assert isinstance(dev, torch.Tensor) and dev.is_cuda and np.array_equal(dev.cpu().numpy(), got)
 
 
+@pytest.mark.parametrize("name", list(golden_cases.PITCH_SHIFT_CASES))
+def test_pitch_shift_golden(L, name):
+    """effects.pitch_shift = time_stretch + resample + fix_length, device-resident, against the unmodified reference: 2e-5 of the peak
+    (the phase vocoder's and the whole-signal transforms' float32 rounding); NumPy and tensor input give the same samples; polyphase
+    cannot take the non-integer intermediate rate (the reference's error)."""
+    import torch
+
+    (kind, n, seed, channels, dtype), kw = golden_cases.PITCH_SHIFT_CASES[name]
+    g = np.load(os.path.join(GOLDEN_DIR, "resample.npz"))
+    y = golden_cases.make_signal(kind, n, seed, channels, dtype)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = L.effects.pitch_shift(y, sr=golden_cases.SR, **kw)
+        dev = L.effects.pitch_shift(torch.from_numpy(y).cuda(), sr=golden_cases.SR, **kw)
+        own = L.effects.pitch_shift(y, sr=golden_cases.SR, **{**kw, "res_type": "soxr_hq"})
+    assert got.shape == g[name].shape and got.dtype == g[name].dtype and np.abs(got - g[name]).max() <= 2e-5 * np.abs(g[name]).max(), np.abs(got - g[name]).max() / np.abs(g[name]).max()
+    assert isinstance(dev, torch.Tensor) and dev.is_cuda and np.array_equal(dev.cpu().numpy(), got)
+    assert np.array_equal(own, got)   # the band-limited names take the Fourier converter for a non-integer rate
+    with pytest.raises(L.ParameterError):
+        L.effects.pitch_shift(y, sr=golden_cases.SR, n_steps=1, res_type="polyphase")
+    with pytest.raises(L.ParameterError):
+        L.effects.pitch_shift(y, sr=golden_cases.SR, n_steps=1, bins_per_octave=0)
+
+
 def test_resample_properties(L):
     """Size-independent properties on a batch the oracle would not finish quickly: 64 clips x 30 s at 22 050 Hz -> 16 000 Hz -> back, all
     three converter families; a band-limited signal survives the round trip, lengths are ceil(n * ratio), linearity, and the time axis

@@ -405,6 +405,17 @@ def test_resample_oracle_matches_reference_golden(name):
     assert got.shape == g[name].shape and got.dtype == g[name].dtype and np.array_equal(got, g[name])
 
 
+@pytest.mark.parametrize("name", list(golden_cases.PITCH_SHIFT_CASES))
+def test_pitch_shift_oracle_matches_reference_golden(name):
+    """librosa.effects.pitch_shift (effects.py:573-596) restated (time_stretch + resample + fix_length) vs the unmodified reference: bit for bit."""
+    (kind, n, seed, channels, dtype), kw = golden_cases.PITCH_SHIFT_CASES[name]
+    g = np.load(os.path.join(GOLDEN_DIR, "resample.npz"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = O.pitch_shift(golden_cases.make_signal(kind, n, seed, channels, dtype), sr=golden_cases.SR, **kw)
+    assert got.shape == g[name].shape and got.dtype == g[name].dtype and np.array_equal(got, g[name])
+
+
 @pytest.mark.parametrize("name", list(golden_cases.CQT_FFT_CASES))
 def test_cqt_fft_oracle_matches_reference_golden(name):
     """The recursion with the whole-signal Fourier resampler between the octaves (res_type="fft" / "scipy"): bit for bit."""
