@@ -68,6 +68,18 @@ void lra_ctx_destroy(lra_ctx* ctx);
 int lra_ctx_set_stream(lra_ctx* ctx, void* hip_stream);
 /* Go back to the context's own (non-blocking) stream. */
 int lra_ctx_use_own_stream(lra_ctx* ctx);
+/* A second stream of the context for work that may overlap the main chain (the constant-Q recursion: the octave transforms run beside
+ * the chain of halvings, librosa/core/constantq.py:1054-1099).  LRA_SIDE_FORK: calls from now on are enqueued on the side stream, behind
+ * everything enqueued on the main stream so far; LRA_SIDE_BACK: back to the main stream, which does NOT wait for the side stream;
+ * LRA_SIDE_JOIN (from the main stream): the main stream waits for everything enqueued on the side stream.  Buffers used on the side
+ * stream must stay alive until a join; LRA_SIDE_END = back (if forked) + join, for error paths.  The two directions use separate
+ * events (re-recording one event that the other stream still waits on let that wait slip on ROCm 7.0: a use-after-free in the
+ * caller's buffers).  lra_ctx_set_stream / lra_ctx_use_own_stream forget any fork. */
+#define LRA_SIDE_FORK 1
+#define LRA_SIDE_BACK 2
+#define LRA_SIDE_JOIN 3
+#define LRA_SIDE_END 4
+int lra_ctx_side(lra_ctx* ctx, int mode);
 int lra_ctx_sync(lra_ctx* ctx);
 /* Tuning knobs: "stft_iters" (frames per slot, 0 = auto), "istft_strip_groups" (frames per strip, 0 = auto),
    "variant" (-1 = auto), "autotune" (1/0). */

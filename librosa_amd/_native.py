@@ -37,6 +37,7 @@ SIGNATURES = {
     "lra_ctx_create": (c_int, [c_int, POINTER(c_void_p)]),
     "lra_ctx_destroy": (None, [c_void_p]),
     "lra_ctx_set_stream": (c_int, [c_void_p, c_void_p]),
+    "lra_ctx_side": (c_int, [c_void_p, c_int]),
     "lra_ctx_use_own_stream": (c_int, [c_void_p]),
     "lra_ctx_sync": (c_int, [c_void_p]),
     "lra_ctx_set_option": (c_int, [c_void_p, c_char_p, c_int]),
@@ -238,6 +239,12 @@ class Context:
         buf = ctypes.create_string_buffer(256)
         _check(self.lib.lra_ctx_device_name(self.handle, buf, 256))
         return buf.value.decode()
+
+    SIDE_FORK, SIDE_BACK, SIDE_JOIN, SIDE_END = 1, 2, 3, 4
+
+    def side(self, mode):
+        """A second stream of the context (``lra_ctx_side``): fork / back / join / end (= back if forked, then join)."""
+        _check(self.lib.lra_ctx_side(self.handle, int(mode)))
 
     def set_stream(self, stream_ptr):
         """Enqueue on this hipStream_t (0 / None = HIP's default stream, torch's usual current stream)."""

@@ -41,6 +41,8 @@ from .spectrum import _DEVICE_PAD_MODES, _all_finite, _as_like
 # octave's spectra never leave LDS) where the octave's frame length is one the kernel is built for; False keeps the round-3 pair of launches
 # (forward kernel -> HBM -> cqt_project_kernel) everywhere.  A test / measurement switch.
 FUSED_OCTAVES = True
+# The octave transforms on the context's side stream, beside the chain of halvings (lra_ctx_side); False: everything on one stream.
+OVERLAP_OCTAVES = True
 
 __all__ = ["cqt", "vqt"]
 
@@ -194,8 +196,10 @@ def vqt(y, *, sr=22050, hop_length=512, fmin=None, n_bins=84, intervals="equal",
     frames = [1 + ln // o["hop"] for ln, o in zip(lens, octaves)]
     n_frames = min(frames)
     sess = _arrays.Session(y if on_device else np.empty(0))
+    overlapped = False
     try:
         ctx = sess.ctx
+        overlapped = OVERLAP_OCTAVES
         y_ptr, batch, _, _ = sess.input_2d(y, real)
         check = on_device
         if check:
@@ -233,6 +237,10 @@ def vqt(y, *, sr=22050, hop_length=512, fmin=None, n_bins=84, intervals="equal",
                 warnings.warn(f"n_fft={n_fft} is too large for input signal of length={lens[i]}", stacklevel=3)
             csr = (table(f"row_ptr{i}", o["row_ptr"], np.int32), table(f"col{i}", o["col"], np.int32), table(f"val{i}", o["val"], cplx))
             scl = (sqrt_len_ptr + 8 * o["bin0"]) if sqrt_len_ptr else None
+            # The octave's transform goes to the context's side stream (behind the halving that made its signal), the halving for the next
+            # octave stays on the main stream: the two chains of small launches overlap instead of alternating (joined after the loop).
+            if OVERLAP_OCTAVES:
+                ctx.side(ctx.SIDE_FORK)
             if FUSED_OCTAVES and ctx.cqt_octave_supported(n_fft):
                 # one launch per octave: frames, rectangular-window transform, projection, scaling and stacking; the octave's spectra stay in LDS
                 ctx.cqt_octave_exec(y_ptr, batch, lens[i], lens[i], n_fft, hop, pad_mode, csr[0], csr[1], csr[2], scl, out_ptr, n_frames, n_bins, o["bin0"], o["row0"], o["n_rows"], real)
@@ -242,12 +250,19 @@ def vqt(y, *, sr=22050, hop_length=512, fmin=None, n_bins=84, intervals="equal",
                 splan = ctx.stft_plan(n_fft, hop, np.ones(n_fft, dtype=real), True, pad_mode, real)          # window="ones" (:1197)
                 ctx.stft_exec(splan, y_ptr, batch, lens[i], lens[i], d_ptr)
                 ctx.cqt_project_exec(d_ptr, out_ptr, csr[0], csr[1], csr[2], scl, batch, frames[i], n_fft // 2 + 1, n_frames, n_bins, o["bin0"], o["row0"], o["n_rows"], real)
+            if OVERLAP_OCTAVES:
+                ctx.side(ctx.SIDE_BACK)
             if o["halve"]:
                 y_ptr = shorten(y_ptr, lens[i], lens[i + 1], 2, 1.0)
+        if OVERLAP_OCTAVES:
+            ctx.side(ctx.SIDE_JOIN)
+            overlapped = False
         if check and ctx.nonfinite_read() and not _all_finite(y):
             raise ParameterError("Audio buffer is not finite everywhere")
         res = sess.result(handle)
     finally:
+        if overlapped:   # an error between fork and join: nothing of this call may still run when its buffers are released
+            ctx.side(ctx.SIDE_END)
         sess.close()
     return _arrays.swap_last_two(res.reshape(lead + (n_frames, n_bins)))
 

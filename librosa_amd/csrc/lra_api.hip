@@ -86,6 +86,10 @@ struct lra_ctx {
     std::map<std::pair<int, int>, std::pair<void*, void*>> cqt_tw;  // (n_fft, dtype) -> (W_M^t, W_N^k) of the fused constant-Q octave kernel (lra_mixed.h)
     std::string name;
     struct HostPipe* pipe = nullptr;  // staging of the host-buffer entry points (lra_stft_exec_host), created on first use
+    hipStream_t side_stream = nullptr;  // lra_ctx_side: a second stream for work that may overlap the main chain (created on first fork)
+    hipStream_t side_main = nullptr;    // the stream to return to
+    hipEvent_t side_event = nullptr, join_event = nullptr;  // fork: recorded on the main stream; join: recorded on the side stream
+    bool on_side = false, side_used = false;
     struct ResampleFft* rs_fft = nullptr;  // whole-signal transforms of lra_resample_fft_exec, created on first use
     int opt_pipe_chunk_mb = 128;      // bytes (in + out) one pipeline stage moves
     int opt_pipe_threads = 8;         // host threads per staging copy
@@ -1500,6 +1504,9 @@ void lra_ctx_destroy(lra_ctx* ctx) {
     delete ctx->pipe;
     delete ctx->rs_fft;
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    if (ctx->side_event) (void)hipEventDestroy(ctx->side_event);
+    if (ctx->join_event) (void)hipEventDestroy(ctx->join_event);
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
     for (auto& kv : ctx->cqt_tw) {
         if (kv.second.first) (void)hipFree(kv.second.first);
@@ -1511,13 +1518,50 @@ void lra_ctx_destroy(lra_ctx* ctx) {
 int lra_ctx_set_stream(lra_ctx* ctx, void* hip_stream) {
     if (!ctx) return fail(LRA_EINVAL, "null context");
     ctx->stream = (hipStream_t)hip_stream;  // NULL is HIP's default (null) stream, a valid choice
+    ctx->on_side = ctx->side_used = false;
     return LRA_OK;
 }
 
 int lra_ctx_use_own_stream(lra_ctx* ctx) {
     if (!ctx) return fail(LRA_EINVAL, "null context");
     ctx->stream = ctx->own_stream;
+    ctx->on_side = ctx->side_used = false;
     return LRA_OK;
+}
+
+int lra_ctx_side(lra_ctx* ctx, int mode) {
+    LRA_BIND(ctx);
+    if (mode == LRA_SIDE_FORK) {
+        if (ctx->on_side) return fail(LRA_EINVAL, "lra_ctx_side: already on the side stream");
+        if (!ctx->side_stream) LRA_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+        if (!ctx->side_event) LRA_HIP(hipEventCreateWithFlags(&ctx->side_event, hipEventDisableTiming));
+        LRA_HIP(hipEventRecord(ctx->side_event, ctx->stream));
+        LRA_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->side_event, 0));
+        ctx->side_main = ctx->stream;
+        ctx->stream = ctx->side_stream;
+        ctx->on_side = ctx->side_used = true;
+        return LRA_OK;
+    }
+    if (mode == LRA_SIDE_BACK) {
+        if (!ctx->on_side) return fail(LRA_EINVAL, "lra_ctx_side: not on the side stream");
+        ctx->stream = ctx->side_main;
+        ctx->on_side = false;
+        return LRA_OK;
+    }
+    if (mode == LRA_SIDE_END && ctx->on_side) {  // wherever the caller is (error paths): back, then join
+        ctx->stream = ctx->side_main;
+        ctx->on_side = false;
+    }
+    if (mode == LRA_SIDE_JOIN || mode == LRA_SIDE_END) {
+        if (ctx->on_side) return fail(LRA_EINVAL, "lra_ctx_side: join from the main stream (LRA_SIDE_BACK first)");
+        if (!ctx->side_used) return LRA_OK;
+        if (!ctx->join_event) LRA_HIP(hipEventCreateWithFlags(&ctx->join_event, hipEventDisableTiming));
+        LRA_HIP(hipEventRecord(ctx->join_event, ctx->side_stream));
+        LRA_HIP(hipStreamWaitEvent(ctx->stream, ctx->join_event, 0));
+        ctx->side_used = false;
+        return LRA_OK;
+    }
+    return fail(LRA_EINVAL, "lra_ctx_side: mode must be LRA_SIDE_FORK, LRA_SIDE_BACK, LRA_SIDE_JOIN or LRA_SIDE_END");
 }
 
 int lra_ctx_sync(lra_ctx* ctx) {

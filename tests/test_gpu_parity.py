@@ -1541,6 +1541,30 @@ def test_resample_properties(L):
         assert torch.equal(L.resample(y[:3].T.contiguous(), orig_sr=sr, target_sr=16000, res_type=res_type, axis=0).T, lo[:3])
 
 
+def test_cqt_side_stream_overlap(L):
+    """The octave transforms on the context's side stream beside the chain of halvings (lra_ctx_side) against everything on one stream:
+    bit-identical, over back-to-back calls without a synchronisation in between (buffers of one call are reused by the next: any ordering
+    hole shows up as a difference or a fault), device tensors and NumPy input, fused and two-launch octaves."""
+    import torch
+    from librosa_amd.core import constantq
+
+    y = torch.from_numpy(golden_cases.make_signal("mix", 22050 * 8, 31, (24,), "float32")).cuda()
+    try:
+        for fused in (True, False):
+            constantq.FUSED_OCTAVES = fused
+            constantq.OVERLAP_OCTAVES = False
+            ref = L.cqt(y, sr=22050)
+            constantq.OVERLAP_OCTAVES = True
+            for _ in range(6):
+                outs = [L.cqt(y, sr=22050) for _ in range(4)]
+                torch.cuda.synchronize()
+                assert all(torch.equal(o, ref) for o in outs), fused
+            yn = y[:3].cpu().numpy()
+            assert np.array_equal(L.cqt(yn, sr=22050), ref[:3].cpu().numpy())
+    finally:
+        constantq.FUSED_OCTAVES = constantq.OVERLAP_OCTAVES = True
+
+
 def test_cqt_default_resampler_and_errors(L):
     """The default res_type (soxr_hq in the reference; here the library's own decimator with soxr-HQ's band edges) against the oracle's
     polyphase transform: the two differ by the resamplers' pass-band responses only (2.6e-3 of the peak measured on

@@ -321,6 +321,11 @@ class _SimCtx:
             tables[key] = np.ascontiguousarray(build())
         return tables[key].ctypes.data
 
+    SIDE_FORK, SIDE_BACK, SIDE_JOIN, SIDE_END = 1, 2, 3, 4
+
+    def side(self, mode):
+        pass
+
     def nonfinite_reset(self):
         pass
 
