@@ -131,11 +131,14 @@ if os.path.exists(trace_csv):
     FRAMES = 256 * 1292
     known_bytes = {"pcen_kernel": ("256 x 128 x 1292 values, 4 B read + 8 B written", 256 * 128 * 1292 * 12),
                    "hpss_kernel": ("32 x 1292 x 1025 bins: |D| (4 B) + D (8 B) read, two spectra (16 B) written", 32 * 1292 * 1025 * 28),
+                   "hpss_tile_kernel": ("32 x 1292 x 1025 bins: |D| (4 B) + D (8 B) read, two spectra (16 B) written", 32 * 1292 * 1025 * 28),
+                   "magnitude_kernel": ("32 x 1292 x 1025 bins: D (8 B) read, |D| (4 B) written", 32 * 1292 * 1025 * 12),
+                   "mixed_cqt_kernel": ("one octave of 64 x 30 s: the octave's signal read once (<= 169 MB), 12 bins x frames written", 0),
                    "stream_probe_kernel<0>": ("forward stream, 10 248 B per row", FRAMES * 10248), "stream_probe_kernel<1>": ("inverse stream, 10 248 B per row", FRAMES * 10248),
                    "to_db_kernel": ("256 x 128 x 1292 values read and written", 256 * 128 * 1292 * 8)}
     for r in rows:
         k = r["Kernel_Name"]
-        if any(n in k for n in ("pcen_kernel", "hpss_kernel", "magnitude_kernel", "cqt_project_kernel", "fir_decimate", "stream_probe_kernel", "to_db_kernel", "dct_rows_kernel",
+        if any(n in k for n in ("pcen_kernel", "hpss_kernel", "hpss_tile_kernel", "mixed_cqt_kernel", "fir_halve4", "resample_", "mixed_stft_kernel", "mixed_istft_kernel", "magnitude_kernel", "cqt_project_kernel", "fir_decimate", "stream_probe_kernel", "to_db_kernel", "dct_rows_kernel",
                                 "item_absmax_kernel", "griffinlim_update_kernel", "phase_vocoder_kernel", "wss_to_norm_kernel", "fillBuffer")):
             if int(r["Grid_Size_X"]) == grids[k].most_common(1)[0][0]:
                 other[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
@@ -144,7 +147,7 @@ if os.path.exists(trace_csv):
                   "| kernel | launches | avg (us) | algorithmic bytes per launch | GB/s | % of 8 TB/s |", "|---|---|---|---|---|---|"]
         for k, v in sorted(other.items(), key=lambda kv: -sum(kv[1])):
             name = k.split("(")[0][-70:]
-            kb = next((val for key, val in known_bytes.items() if key in k.replace("lra::", "")), None)
+            kb = next((val for key, val in known_bytes.items() if key in k.replace("lra::", "") and val[1]), None)
             avg = mean(v)
             lines.append(f"| {name} | {len(v)} | {avg / 1e3:.1f} | {kb[0] if kb else '-'} | {(kb[1] / avg) if kb else 0:.0f} | {(kb[1] / avg / 80) if kb else 0:.1f} |" if kb else f"| {name} | {len(v)} | {avg / 1e3:.1f} | - | - | - |")
         lines.append("")
