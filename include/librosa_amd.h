@@ -266,6 +266,15 @@ int lra_resample_poly_exec(lra_ctx* ctx, const void* x, void* out, int64_t batch
  * resample(scale=True), :719-720).  x: [batch][n_in], out: [batch][n_out] real of `dtype` (device). */
 int lra_resample_fft_exec(lra_ctx* ctx, const void* x, void* out, int64_t batch, int64_t n_in, int64_t n_out, double gain, int dtype);
 
+/* Band-limited resampling by a rational ratio in the Fourier domain: the library's own converter behind librosa.resample's soxr_* /
+ * kaiser_* / sinc_* names (librosa/core/audio.py:1146-1170; packages that are not in the build image) when the ratio is not a plain
+ * decimation.  Each clip is zero-padded to fft_in samples, transformed, multiplied by the low-pass erfc((k - k_mid) / k_sigma) / 2 (bins of
+ * the forward transform), cut at the lower Nyquist, inverted at fft_out samples; out[clip] = the first n_out samples * gain * fft_out /
+ * fft_in.  The caller chooses fft_in = g down >= n_in + the filter's length and fft_out = g up (then the circular convolution is the linear
+ * one and the output grid is exact).  x: [batch][n_in], out: [batch][n_out] real of `dtype` (device). */
+int lra_resample_band_exec(lra_ctx* ctx, const void* x, void* out, int64_t batch, int64_t n_in, int64_t n_out, int64_t fft_in, int64_t fft_out, double k_mid, double k_sigma, double gain,
+                           int dtype);
+
 /* out[clip][t][bin0 + r] = (sum_j val[j] D[clip][t][col[j]], j in row row0 + r of the CSR basis) / sqrt_len[r], 0 <= r < n_rows,
  * 0 <= t < n_frames.  D: [clip][frames_in][n_bins] complex (lra_stft_exec's layout), out: [clip][n_frames][n_total] complex, both of
  * `dtype`'s precision; row_ptr / col: int32, val: complex (device); sqrt_len: float64 [n_rows] (device) or NULL (scale=False). */

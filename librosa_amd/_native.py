@@ -89,6 +89,7 @@ SIGNATURES = {
     "lra_fir_decimate_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_double, c_double, c_int]),
     "lra_resample_poly_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_double, c_double, c_int]),
     "lra_resample_fft_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_double, c_int]),
+    "lra_resample_band_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_double, c_double, c_double, c_int]),
     "lra_cqt_project_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int64, c_int, c_int, c_int, c_int, c_int]),
     "lra_cqt_octave_supported": (c_int, [c_int]),
     "lra_cqt_octave_exec": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int]),
@@ -449,6 +450,10 @@ class Context:
 
     def resample_fft_exec(self, x_ptr, out_ptr, batch, n_in, n_out, gain, dtype):
         _check(self.lib.lra_resample_fft_exec(self.handle, c_void_p(x_ptr), c_void_p(out_ptr), batch, n_in, n_out, float(gain), dtype_code(dtype)))
+
+    def resample_band_exec(self, x_ptr, out_ptr, batch, n_in, n_out, fft_in, fft_out, k_mid, k_sigma, gain, dtype):
+        _check(self.lib.lra_resample_band_exec(self.handle, c_void_p(x_ptr), c_void_p(out_ptr), batch, n_in, n_out, int(fft_in), int(fft_out), float(k_mid), float(k_sigma), float(gain),
+                                               dtype_code(dtype)))
 
     def cqt_project_exec(self, d_ptr, out_ptr, row_ptr, col_ptr, val_ptr, sqrt_len_ptr, batch, frames_in, n_bins, n_frames, n_total, bin0, row0, n_rows, dtype):
         _check(self.lib.lra_cqt_project_exec(self.handle, c_void_p(d_ptr), c_void_p(out_ptr), c_void_p(row_ptr), c_void_p(col_ptr), c_void_p(val_ptr), c_void_p(sqrt_len_ptr or None), batch,

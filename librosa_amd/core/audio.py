@@ -14,7 +14,8 @@ path through the standard library.  ``stream`` does not resample (``sr`` differe
 recursion.  ``res_type="fft"`` / ``"scipy"`` (whole-signal Fourier resampling, any ratio) and ``"polyphase"`` (scipy's Kaiser-5
 design, any integer rate pair) reproduce the reference's scipy-backed converters; the ``soxr_*`` / ``kaiser_*`` / ``sinc_*`` names --
 packages that are not in the build image, the reference cannot run them there either -- are served by this library's own
-band-limited polyphase design (pass band to 0.913 of the lower Nyquist, 125 dB: soxr-HQ's band edges), parity unpinned.
+band-limited design (pass band to 0.913 of the lower Nyquist, 125 dB at it: soxr-HQ's band edges; a polyphase FIR for plain decimations,
+the same response applied in the Fourier domain to zero-padded clips for every other ratio), parity unpinned.
 """
 from __future__ import annotations
 
@@ -62,6 +63,31 @@ def _rational_filter(up, down, res_type, real):
     return np.concatenate([np.zeros(lead, dtype=real), taps]), (half + lead) // down
 
 
+def _smooth_at_least(n):
+    """Smallest integer >= n whose prime factors are 2, 3, 5, 7 (transform lengths rocFFT has radix kernels for)."""
+    n = max(int(n), 1)
+    while True:
+        m = n
+        for p in (2, 3, 5, 7):
+            while m % p == 0:
+                m //= p
+        if m == 1:
+            return n
+        n += 1
+
+
+def _band_plan(n_in, up, down):
+    """Transform lengths and roll-off of the Fourier form of the library's own band-limited converter (``lra_resample_band_exec``):
+    low-pass ``erfc((f - 0.9565 f_c) / sigma) / 2`` with ``f_c`` the lower Nyquist and ``sigma = 0.0435 f_c / 3.5`` -- 1 - 6e-7 at
+    0.913 f_c, 6e-7 (-125 dB) at f_c, soxr-HQ's band edges -- whose impulse response has a Gaussian envelope ``exp(-(pi sigma t)^2)``:
+    below 1e-8 after ``110 / f_c`` input samples, the zero padding that makes the circular convolution the linear one."""
+    f_c = 0.5 * min(1.0, up / down)            # cycles per input sample
+    pad = int(np.ceil(110.0 / f_c)) + 16
+    g = _smooth_at_least(-(-(n_in + pad) // down))
+    fft_in, fft_out = g * down, g * up
+    return fft_in, fft_out, 0.9565 * f_c * fft_in, 0.0435 * f_c * fft_in / 3.5
+
+
 def resample(y, *, orig_sr, target_sr, res_type="soxr_hq", fix=True, scale=False, axis=-1, **kwargs):
     """Resample a time series from ``orig_sr`` to ``target_sr``; drop-in for ``librosa.resample`` (``librosa/core/audio.py:1002-1178``).
 
@@ -97,7 +123,10 @@ def resample(y, *, orig_sr, target_sr, res_type="soxr_hq", fix=True, scale=False
             raise ParameterError(f"res_type={res_type!r} needs integer-valued sampling rates in librosa_amd (use res_type='fft' for arbitrary ratios)")
         g = math.gcd(int(orig_sr), int(target_sr))
         up, down = int(target_sr) // g, int(orig_sr) // g
-        taps, first = _rational_filter(up, down, res_type, real)
+        # the library's own design: a plain decimation runs the staged FIR decimators; any other ratio would need ~20 max(up, down) / up
+        # x 12 products per output (258 at 22 050 -> 16 000 Hz) and runs in the Fourier domain instead (same band edges, see _band_plan)
+        banded = res_type != "polyphase" and up != 1
+        taps, first = _rational_filter(1 if banded else up, down, res_type, real)   # (validates res_type)
         n_out = -(-n_in * up // down)
     else:
         n_out = n_samples
@@ -110,6 +139,9 @@ def resample(y, *, orig_sr, target_sr, res_type="soxr_hq", fix=True, scale=False
         out_ptr, handle = sess.output((batch, n_out), real)
         if spectral:
             ctx.resample_fft_exec(x_ptr, out_ptr, batch, n_in, n_out, 1.0 / np.sqrt(ratio) if scale else 1.0, real)
+        elif banded:
+            fft_in, fft_out, k_mid, k_sigma = _band_plan(n_in, up, down)
+            ctx.resample_band_exec(x_ptr, out_ptr, batch, n_in, n_out, fft_in, fft_out, k_mid, k_sigma, 1.0 / np.sqrt(ratio) if scale else 1.0, real)
         else:
             taps_ptr = ctx.device_table(("fir", up, down, res_type, real.str), lambda: taps)
             ctx.resample_poly_exec(x_ptr, out_ptr, batch, n_in, n_out, taps_ptr, len(taps), up, down, first, np.sqrt(ratio) if scale else 1.0, 1.0, real)

@@ -737,6 +737,7 @@ struct ResampleFft {
     };
     std::vector<Entry> entries;  // most recently used last
     Scratch spec_in, spec_out;
+    Scratch time_in, time_out;  // padded clips / uncropped results of the band-limited form
     FftPlanCache order;  // cross-stream ordering of the two spectra (scratch_acquire / scratch_release)
     FftPlanCache* get(int type, int dtype, long long n) {
         for (size_t i = 0; i < entries.size(); ++i)
@@ -2338,6 +2339,46 @@ int lra_resample_poly_exec(lra_ctx* ctx, const void* x, void* out, int64_t batch
 }  // extern "C"
 
 namespace {
+// the band-limited form (resample_shaped_spectrum_kernel): clips padded to fft_in, shaped, inverted at fft_out, the first n_out samples kept
+template <class T>
+int resample_shaped_run(lra_ctx* ctx, const T* x, T* out, long long batch, long long n_in, long long n_out, long long fft_in, long long fft_out, double k_mid, double k_sigma, double gain, int dtype) {
+    if (!ctx->rs_fft) ctx->rs_fft = new ResampleFft();
+    ResampleFft* rs = ctx->rs_fft;
+    const long long bins_in = fft_in / 2 + 1, bins_out = fft_out / 2 + 1;
+    long long per_pass = (1LL << 30) / ((bins_in + bins_out) * (long long)sizeof(cx<T>) + (fft_in + fft_out) * (long long)sizeof(T));
+    if (per_pass < 1) per_pass = 1;
+    if (per_pass > batch) per_pass = batch;
+    LRA_TRY(scratch_acquire(rs->order, ctx->stream));
+    LRA_TRY(rs->spec_in.ensure((size_t)per_pass * bins_in * sizeof(cx<T>)));
+    LRA_TRY(rs->spec_out.ensure((size_t)per_pass * bins_out * sizeof(cx<T>)));
+    LRA_TRY(rs->time_in.ensure((size_t)per_pass * fft_in * sizeof(T)));
+    LRA_TRY(rs->time_out.ensure((size_t)per_pass * fft_out * sizeof(T)));
+    const long long n_copy = (fft_out < fft_in ? fft_out : fft_in) / 2 + 1;
+    const long long real_last = fft_out % 2 == 0 ? fft_out / 2 : -1;
+    FftPlanCache* fwd = rs->get((int)rocfft_transform_type_real_forward, dtype, fft_in);
+    FftPlanCache* inv = rs->get((int)rocfft_transform_type_real_inverse, dtype, fft_out);
+    auto blocks = [](long long count) { return dim3((unsigned)((count + 255) / 256)); };
+    for (long long c0 = 0; c0 < batch; c0 += per_pass) {
+        const long long cnt = batch - c0 < per_pass ? batch - c0 : per_pass;
+        hipLaunchKernelGGL(repitch_rows_kernel<T>, blocks(cnt * fft_in), dim3(256), 0, ctx->stream, x + c0 * n_in, (T*)rs->time_in.p, cnt, n_in, n_in, fft_in);
+        rocfft_plan plan;
+        LRA_TRY(get_rocfft_plan(*fwd, ctx, rocfft_transform_type_real_forward, dtype, (int)fft_in, cnt, &plan));
+        void* ib[1] = {rs->time_in.p};
+        void* ob[1] = {rs->spec_in.p};
+        LRA_FFT(rocfft_execute(plan, ib, ob, fwd->info));
+        hipLaunchKernelGGL(resample_shaped_spectrum_kernel<T>, blocks(cnt * bins_out), dim3(256), 0, ctx->stream, (const CqtCplx<T>*)rs->spec_in.p, (CqtCplx<T>*)rs->spec_out.p, cnt, bins_in,
+                           bins_out, n_copy, real_last, k_mid, 1.0 / k_sigma, (T)gain);
+        LRA_TRY(get_rocfft_plan(*inv, ctx, rocfft_transform_type_real_inverse, dtype, (int)fft_out, cnt, &plan));
+        void* ib2[1] = {rs->spec_out.p};
+        void* ob2[1] = {rs->time_out.p};
+        LRA_FFT(rocfft_execute(plan, ib2, ob2, inv->info));
+        hipLaunchKernelGGL(repitch_rows_kernel<T>, blocks(cnt * n_out), dim3(256), 0, ctx->stream, (const T*)rs->time_out.p, out + c0 * n_out, cnt, n_out, fft_out, n_out);
+        LRA_HIP(hipGetLastError());
+    }
+    LRA_TRY(scratch_release(rs->order, ctx->stream));
+    return LRA_OK;
+}
+
 template <class T> int resample_fft_run(lra_ctx* ctx, const T* x, T* out, long long batch, long long n_in, long long n_out, double gain, int dtype) {
     if (!ctx->rs_fft) ctx->rs_fft = new ResampleFft();
     ResampleFft* rs = ctx->rs_fft;
@@ -2378,6 +2419,19 @@ template <class T> int resample_fft_run(lra_ctx* ctx, const T* x, T* out, long l
 }  // namespace
 
 extern "C" {
+
+int lra_resample_band_exec(lra_ctx* ctx, const void* x, void* out, int64_t batch, int64_t n_in, int64_t n_out, int64_t fft_in, int64_t fft_out, double k_mid, double k_sigma, double gain,
+                           int dtype) {
+    LRA_BIND(ctx);
+    if (batch <= 0 || n_out <= 0) return LRA_OK;
+    if (n_in <= 0) return fail(LRA_EINVAL, "resample_band: empty input");
+    if (!x || !out) return fail(LRA_EINVAL, "null data pointer");
+    if (dtype != LRA_F32 && dtype != LRA_F64) return fail(LRA_EINVAL, "resample_band: dtype must be LRA_F32 or LRA_F64");
+    if (fft_in < n_in || fft_out < n_out || fft_in > 0x7fffffffLL || fft_out > 0x7fffffffLL) return fail(LRA_EINVAL, "resample_band: transform lengths must cover the signals and stay below 2^31");
+    if (!(k_sigma > 0) || !(k_mid > 0)) return fail(LRA_EINVAL, "resample_band: the roll-off needs a positive centre and width");
+    if (dtype == LRA_F64) return resample_shaped_run<double>(ctx, (const double*)x, (double*)out, batch, n_in, n_out, fft_in, fft_out, k_mid, k_sigma, gain / (double)fft_in, dtype);
+    return resample_shaped_run<float>(ctx, (const float*)x, (float*)out, batch, n_in, n_out, fft_in, fft_out, k_mid, k_sigma, gain / (double)fft_in, dtype);
+}
 
 int lra_resample_fft_exec(lra_ctx* ctx, const void* x, void* out, int64_t batch, int64_t n_in, int64_t n_out, double gain, int dtype) {
     LRA_BIND(ctx);

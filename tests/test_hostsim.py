@@ -354,6 +354,18 @@ class _SimCtx:
         x = self._view(x_ptr, (batch, n_in), dtype)
         self._view(out_ptr, (batch, n_out), dtype)[...] = (scipy.signal.resample(x, n_out, axis=-1) * gain).astype(dtype)
 
+    def resample_band_exec(self, x_ptr, out_ptr, batch, n_in, n_out, fft_in, fft_out, k_mid, k_sigma, gain, dtype):
+        # (rocFFT's transforms on the device: NumPy's here; the roll-off as resample_shaped_spectrum_kernel applies it)
+        import scipy.special
+
+        x = self._view(x_ptr, (batch, n_in), dtype)
+        X = np.fft.rfft(x.astype(np.float64), n=fft_in, axis=-1)
+        n_copy = min(fft_in, fft_out) // 2 + 1
+        Y = np.zeros((batch, fft_out // 2 + 1), dtype=np.complex128)
+        Y[:, :n_copy] = X[:, :n_copy] * (0.5 * scipy.special.erfc((np.arange(n_copy) - k_mid) / k_sigma))
+        y = np.fft.irfft(Y, n=fft_out, axis=-1) * (fft_out / fft_in) * gain
+        self._view(out_ptr, (batch, n_out), dtype)[...] = y[:, :n_out].astype(dtype)
+
     def cqt_project_exec(self, d_ptr, out_ptr, row_ptr, col_ptr, val_ptr, sqrt_len_ptr, batch, frames_in, n_bins, n_frames, n_total, bin0, row0, n_rows, dtype):
         H.post_lib().postsim_cqt_project(d_ptr, out_ptr, row_ptr, col_ptr, val_ptr, sqrt_len_ptr, batch, frames_in, int(n_bins), n_frames, int(n_total), int(bin0), int(row0), int(n_rows),
                                          int(np.dtype(dtype) == np.float64))
