@@ -1758,6 +1758,31 @@ def test_hpss_reference_properties_and_full_size():
     _run_isolated("_hpss_properties_body")
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_hpss_tile_kernel_windows_device(L, dtype):
+    """hpss_tile_kernel on the device, the simulator's corner list (tests/test_hostsim.py::test_hpss_tile_kernel_windows): shortest and
+    longest windows of both network sizes (run-time window and the compile-time 31), even windows, axes of exactly win + 4, ragged
+    tiles, heavy ties, plus windows the element kernel keeps -- real input, so BIT FOR BIT against the oracle; and the element kernel
+    (context option hpss_tile = 0) gives the same bits."""
+    rng = np.random.default_rng(78)
+    cases = [(35, 35, 31, 31), (10, 11, 6, 7), (12, 37, 8, 33), (37, 10, 33, 6), (41, 23, 6, 18), (69, 12, 65, 7), (13, 70, 7, 65), (50, 45, 32, 33), (39, 38, 17, 31), (7, 9, 3, 3),
+             (30, 30, 5, 9), (300, 257, 31, 31), (131, 1025, 31, 17)]
+    ctx = L.get_context(0)
+    for n_frames, n_bins, wh, wp in cases:
+        for ties in (False, True):
+            S = rng.random((2, n_bins, n_frames)).astype(dtype)
+            if ties:
+                S = np.round(S * 6).astype(dtype) / 4
+            exp = O.hpss(S, kernel_size=(wh, wp), mask=True, power=1.0)
+            got = L.decompose.hpss(S, kernel_size=(wh, wp), mask=True, power=1.0)
+            assert all(np.array_equal(g, e) and g.dtype == e.dtype for g, e in zip(got, exp)), (n_frames, n_bins, wh, wp, ties)
+            try:
+                ctx.set_option("hpss_tile", 0)
+                assert all(np.array_equal(g, e) for g, e in zip(L.decompose.hpss(S, kernel_size=(wh, wp), mask=True, power=1.0), exp)), (n_frames, n_bins, wh, wp, ties, "element kernel")
+            finally:
+                ctx.set_option("hpss_tile", 1)
+
+
 # ---- seeded sweep of the SURVEY 8(f) rows against the oracle (shapes, axes, parameters drawn at random) -------------------------------
 @pytest.mark.parametrize("seed", _sweep_seeds())
 def test_random_rows_sweep(L, seed):
