@@ -79,6 +79,7 @@ struct lra_ctx {
     int opt_lds_pad = 0;             // extra dynamic LDS per workgroup (occupancy experiments)
     int opt_v2 = 1;                  // second-generation forward kernel where it applies (lra_kernels2.h)
     int opt_hpss_tile = 1;           // hpss: a thread per 4 x 4 tile with shared sorted cores (hpss_tile_kernel); 0: a thread per element (A/B)
+    int opt_mixed_inv_pow2 = 1;      // inverse, n_fft = 256 / 512 / 1024 with a hop outside n_fft / {2, 4, 8, 16}: the fused gather kernel of lra_mixed.h (0: istft_kernel's general mode)
     int opt_mixed = 1;               // fused mixed-radix forward kernel for the listed non-power-of-two frame lengths (lra_mixed.h); 0: rocFFT path
     int opt_direct = 1;              // direct framing (no ring) for hop >= n_fft
     int opt_xcd_remap = 1;           // workgroup -> work item map that keeps neighbouring strips on one XCD (lra_kernels.h, xcd_block)
@@ -1057,6 +1058,54 @@ int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_s
     if (!D) return fail(LRA_EINVAL, "null spectrum pointer");
     if (d_frame_stride < bins) return fail(LRA_EINVAL, "d_frame_stride smaller than n_bins");
     const T tinyv = sizeof(T) == 8 ? (T)2.2250738585072014e-308 : (T)1.17549435e-38f;
+    // listed non-power-of-two frame lengths -- and powers of two up to 1024 whose hop is not n_fft / {2, 4, 8, 16} (the register-tiled kernel
+    // below serves those hops through its general overlap-add mode: measured slower) -- : one fused launch (lra_mixed.h, mixed_istft_kernel)
+    auto run_mixed = [&](bool* done) -> int {
+        *done = false;
+        if (p->d_mtw && ctx->opt_mixed) {
+            const int fmax = mixed::inv_frames_max_of(N, (int)sizeof(T));
+            const int halo = (N + p->hop - 1) / p->hop - 1;
+            if (fmax - halo >= 1 && fmax - halo >= 2 * halo) {  // (halo frames are recomputed by the neighbouring group: worth it while they are a third of the work at most)
+                const void* nrm = wss;
+                if (!wss_is_norm) {
+                    LRA_TRY(p->norm.ensure((size_t)out_len * sizeof(T)));
+                    hipLaunchKernelGGL(wss_to_norm_kernel<T>, dim3((unsigned)((out_len + 255) / 256)), dim3(256), 0, ctx->stream, (const T*)wss, tinyv, (T*)p->norm.p, (long long)out_len);
+                    LRA_HIP(hipGetLastError());
+                    nrm = p->norm.p;
+                }
+                mixed::InvArgs<T> a = mixed::InvArgs<T>();
+                a.D = (const mixed::cpx<T>*)D;
+                a.d_batch_stride = d_batch_stride;
+                a.d_frame_stride = d_frame_stride;
+                a.n_used = (int)n_used;
+                a.hop = p->hop;
+                a.drop = p->center ? N / 2 : 0;
+                a.win_scaled = (const T*)p->d_win_scaled;
+                a.tw_m = (const mixed::cpx<T>*)p->d_mtw;
+                a.tw_n = (const mixed::cpx<T>*)p->d_mtwn;
+                a.norm = (const T*)nrm;
+                a.y = (T*)y;
+                a.y_stride = y_stride;
+                a.out_len = out_len;
+                a.halo = halo;
+                a.group_hops = fmax - halo;
+                a.groups_per_clip = (int)((n_used + a.group_hops - 1) / a.group_hops);
+                hipError_t e;
+                if constexpr (sizeof(T) == 8) e = mixed::launch_inv_f64(N, a, batch, ctx->stream);
+                else e = mixed::launch_inv_f32(N, a, batch, ctx->stream);
+                if (e != hipSuccess) return fail(LRA_EHIP, std::string("mixed-radix istft kernel launch: ") + hipGetErrorString(e));
+                // the kernel stores every sample up to the last frame's end; beyond it (`length` past the frames' reach) the output is zero
+                *done = true;
+                return zero_from((n_used - 1) * (long long)p->hop + N - (p->center ? N / 2 : 0));
+            }
+        }
+        return LRA_OK;
+    };
+    if (p->pow2 && ctx->opt_mixed_inv_pow2 && p->d_mtw && p->hop * 2 != N && p->hop * 4 != N && p->hop * 8 != N && p->hop * 16 != N && p->hop < N) {
+        bool done = false;
+        LRA_TRY(run_mixed(&done));
+        if (done) return LRA_OK;
+    }
     if (p->pow2) {
         const void* nrm = wss;
         if (!wss_is_norm) {  // one tiny launch per call (out_len values); callers that keep the envelope around pass the factors themselves
@@ -1109,42 +1158,10 @@ int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_s
         LRA_TRY(launch(variant));
         if (!too_big) return zero_from(istft_written_end(N, p->hop, n_used, p->center ? N / 2 : 0));
     }
-    // listed non-power-of-two frame lengths: one fused launch (lra_mixed.h, mixed_istft_kernel)
-    if (p->d_mtw && ctx->opt_mixed) {
-        const int fmax = mixed::inv_frames_max_of(N, (int)sizeof(T));
-        const int halo = (N + p->hop - 1) / p->hop - 1;
-        if (fmax - halo >= 1 && fmax - halo >= 2 * halo) {  // (halo frames are recomputed by the neighbouring group: worth it while they are a third of the work at most)
-            const void* nrm = wss;
-            if (!wss_is_norm) {
-                LRA_TRY(p->norm.ensure((size_t)out_len * sizeof(T)));
-                hipLaunchKernelGGL(wss_to_norm_kernel<T>, dim3((unsigned)((out_len + 255) / 256)), dim3(256), 0, ctx->stream, (const T*)wss, tinyv, (T*)p->norm.p, (long long)out_len);
-                LRA_HIP(hipGetLastError());
-                nrm = p->norm.p;
-            }
-            mixed::InvArgs<T> a = mixed::InvArgs<T>();
-            a.D = (const mixed::cpx<T>*)D;
-            a.d_batch_stride = d_batch_stride;
-            a.d_frame_stride = d_frame_stride;
-            a.n_used = (int)n_used;
-            a.hop = p->hop;
-            a.drop = p->center ? N / 2 : 0;
-            a.win_scaled = (const T*)p->d_win_scaled;
-            a.tw_m = (const mixed::cpx<T>*)p->d_mtw;
-            a.tw_n = (const mixed::cpx<T>*)p->d_mtwn;
-            a.norm = (const T*)nrm;
-            a.y = (T*)y;
-            a.y_stride = y_stride;
-            a.out_len = out_len;
-            a.halo = halo;
-            a.group_hops = fmax - halo;
-            a.groups_per_clip = (int)((n_used + a.group_hops - 1) / a.group_hops);
-            hipError_t e;
-            if constexpr (sizeof(T) == 8) e = mixed::launch_inv_f64(N, a, batch, ctx->stream);
-            else e = mixed::launch_inv_f32(N, a, batch, ctx->stream);
-            if (e != hipSuccess) return fail(LRA_EHIP, std::string("mixed-radix istft kernel launch: ") + hipGetErrorString(e));
-            // the kernel stores every sample up to the last frame's end; beyond it (`length` past the frames' reach) the output is zero
-            return zero_from((n_used - 1) * (long long)p->hop + N - (p->center ? N / 2 : 0));
-        }
+    if (!p->pow2) {
+        bool done = false;
+        LRA_TRY(run_mixed(&done));
+        if (done) return LRA_OK;
     }
     // general path: pack -> rocFFT C2R -> gather overlap-add, one clip group at a time
     LRA_TRY(scratch_acquire(p->fft, ctx->stream));
@@ -1586,6 +1603,7 @@ int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value) {
     else if (!std::strcmp(key, "direct")) ctx->opt_direct = value != 0;
     else if (!std::strcmp(key, "mixed")) ctx->opt_mixed = value != 0;
     else if (!std::strcmp(key, "hpss_tile")) ctx->opt_hpss_tile = value != 0;
+    else if (!std::strcmp(key, "mixed_inv_pow2")) ctx->opt_mixed_inv_pow2 = value != 0;
     else if (!std::strcmp(key, "autotune")) ctx->opt_autotune = value != 0;
     else if (!std::strcmp(key, "mel_runs")) ctx->opt_mel_runs = value != 0;
     else if (!std::strcmp(key, "variant")) ctx->opt_variant = (value >= 0 && value < kNumVariants) ? value : -1;
@@ -2029,7 +2047,7 @@ int lra_istft_plan_create(lra_ctx* ctx, int n_fft, int hop_length, const void* w
         p->logm = log2_exact(n_fft) - 1;
         rc = dtype == LRA_F64 ? build_tables<double>(p->logm, p->d_tw, &p->d_twr) : build_tables<float>(p->logm, p->d_tw, &p->d_twr);
     }
-    if (rc == LRA_OK && !p->pow2 && mixed::in_size_list(n_fft)) rc = mixed_tables(n_fft, dtype, &p->d_mtw, &p->d_mtwn);
+    if (rc == LRA_OK && ((!p->pow2 && mixed::in_size_list(n_fft)) || (p->pow2 && mixed::in_inv_pow2_list(n_fft)))) rc = mixed_tables(n_fft, dtype, &p->d_mtw, &p->d_mtwn);
     if (rc != LRA_OK) {
         lra_istft_plan_destroy(p);
         return rc;

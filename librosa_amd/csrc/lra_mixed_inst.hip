@@ -52,6 +52,7 @@ template <class T> hipError_t launch_inv_t(int n_fft, const InvArgs<T>& a, long 
 #define LRA_MIXED_CASE(N) \
     case N: return launch_inv_n<T, N>(a, batch, stream);
         LRA_MIXED_SIZES(LRA_MIXED_CASE)
+        LRA_MIXED_INV_POW2(LRA_MIXED_CASE)
 #undef LRA_MIXED_CASE
         default: return hipErrorInvalidValue;
     }
@@ -96,6 +97,7 @@ int inv_frames_max_of(int n_fft, int elem_bytes) {
 #define LRA_MIXED_CASE(N) \
     case N: return elem_bytes == 8 ? inv_frames_max<double, N>() : inv_frames_max<float, N>();
         LRA_MIXED_SIZES(LRA_MIXED_CASE)
+        LRA_MIXED_INV_POW2(LRA_MIXED_CASE)
 #undef LRA_MIXED_CASE
         default: return 0;
     }

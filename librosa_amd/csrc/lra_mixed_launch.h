@@ -10,6 +10,11 @@
 // path): the 15 / 20 / 25 / 30 / 40 / 50 / 60 ms frames of 8, 16, 22.05 (rounded), 32 and 48 kHz front ends and their doubles
 #define LRA_MIXED_SIZES(X) X(160) X(200) X(240) X(320) X(400) X(480) X(640) X(800) X(960) X(1000) X(1200) X(1280) X(1440) X(1600) X(1920) X(2000) X(2400) X(3200) X(4800)
 
+// INVERSE only: power-of-two frame lengths whose hop does not divide them the way the register-tiled inverse wants (n_fft / {2, 4, 8, 16}) --
+// n_fft = 512 with hop 160 (25 ms windows padded to 512 at 16 kHz), 1024 with 441, ... -- take the fused gather kernel of this file instead of
+// spec_pack + rocFFT + overlap-add (larger frames hold too few frames per workgroup for it: lra_api.hip's own / halo rule)
+#define LRA_MIXED_INV_POW2(X) X(256) X(512) X(1024)
+
 // the constant-Q octave kernel's frame lengths (filters.wavelet pads every octave's filters to a power of two)
 #define LRA_CQT_SIZES(X) X(32) X(64) X(128) X(256) X(512) X(1024) X(2048) X(4096)
 
@@ -29,8 +34,16 @@ constexpr bool in_size_list(int n_fft) {
 #undef LRA_MIXED_CASE
     return false;
 }
+constexpr bool in_inv_pow2_list(int n_fft) {
+#define LRA_MIXED_CASE(N) \
+    if (n_fft == N) return true;
+    LRA_MIXED_INV_POW2(LRA_MIXED_CASE)
+#undef LRA_MIXED_CASE
+    return false;
+}
 #define LRA_MIXED_CHECK(N) static_assert(supported(N), "n_fft = " #N ": n_fft / 2 must factor into 2, 3 and 5");
 LRA_MIXED_SIZES(LRA_MIXED_CHECK)
+LRA_MIXED_INV_POW2(LRA_MIXED_CHECK)
 #undef LRA_MIXED_CHECK
 int frames_per_group_of(int n_fft, int elem_bytes);
 hipError_t launch_f32(int n_fft, int mode, const Args<float>& a, long long batch, hipStream_t stream);

@@ -7,6 +7,7 @@ import bench, librosa_amd as L
 n_fft, hop, sr = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (400, 160, 16000)))
 dev = torch.device("cuda", 0)
 L.get_context(0).set_option("mixed", int(os.environ.get("LRA_MIXED_OPT", "1")))
+L.get_context(0).set_option("mixed_inv_pow2", int(os.environ.get("LRA_MIXED_INV_POW2", "1")))   # powers of two with an unaligned hop: fused gather kernel (1) / istft_kernel's general mode (0)
 y = bench.make_batch(torch, 256, sr * 30, 0, dev)
 D = L.stft(y, n_fft=n_fft, hop_length=hop, check_finite=False)
 fn = lambda: L.istft(D, hop_length=hop, n_fft=n_fft, length=y.shape[-1])

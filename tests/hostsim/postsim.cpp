@@ -300,6 +300,9 @@ template <class T> int sim_mixed_inv_n(int n_fft, const lra::mixed::InvArgs<T>& 
         case 480: return sim_mixed_inv<T, 480>(a, batch);
         case 1000: return sim_mixed_inv<T, 1000>(a, batch);
         case 1200: return sim_mixed_inv<T, 1200>(a, batch);
+        case 256: return sim_mixed_inv<T, 256>(a, batch);   // LRA_MIXED_INV_POW2: powers of two with a hop the register-tiled inverse does not take
+        case 512: return sim_mixed_inv<T, 512>(a, batch);
+        case 1024: return sim_mixed_inv<T, 1024>(a, batch);
         default: return 1;
     }
 }

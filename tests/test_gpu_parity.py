@@ -1152,6 +1152,10 @@ def test_istft_sixteenth_hop(L, n_fft, hop):
         (400, 160, True, 30000, (None, 30000, 36000), np.float32),                  # ... 8 x 5 x 5: several groups per clip, halo frames
         (400, 160, False, 30000, (None, 33000), np.float64),
         (160, 200, True, 9000, (None, 12000), np.float32),                          # ... hop > n_fft
+        (512, 200, True, 30000, (None, 30000, 36000), np.float32),                  # ... powers of two with a hop outside n_fft / {2, 4, 8, 16}: the same gather kernel
+        (256, 100, False, 20000, (None, 23000), np.float64),
+        (256, 80, True, 20000, (None, 20000), np.float32),
+        (512, 160, True, 30000, (None, 33000), np.float32),                         # (own frames < 2 x halo: stays with the register-tiled kernel's general mode)
         (1002, 250, True, 20000, (None, 20000, 26000), np.float32),                 # rocFFT + gather path (n_fft / 2 = 501 = 3 x 167)
         (2048, 512, True, 30000, (None, 36000), np.float64),
     ],

@@ -915,6 +915,10 @@ def test_mixed_radix_mel_body(n_fft, hop, n_mels, sr, dtype):
         (480, 240, 3000, True, "n", np.float64),      # (larger frames hold three per workgroup: the fused form needs hop >= n_fft / 2 there)
         (1000, 500, 9000, True, "n", np.float32),     # several groups per clip with a halo frame
         (1200, 600, 7000, True, "n", np.float32),
+        (512, 160, 5000, True, "n", np.float32),      # powers of two with a hop outside n_fft / {2, 4, 8, 16}: the same kernel (LRA_MIXED_INV_POW2)
+        (512, 200, 4100, False, 4000, np.float64),
+        (256, 100, 3000, True, 3300, np.float32),
+        (1024, 441, 9000, True, "n", np.float32),
     ],
 )
 def test_mixed_radix_istft_body(n_fft, hop, n, center, length, dtype):
