@@ -214,6 +214,22 @@ template <class T> LRA_HD cx<T> pmul(cx<T> a, cx<T> b) { return mk<T>(a.x * b.x,
 #define LRA_ARM_END(tag) ((void)0)
 #endif
 
+// Wave priority at the phase boundaries of the frame loops (s_setprio; P < 0: no instruction; nothing in the host simulator).  With two
+// waves per SIMD the issue arbiter otherwise serves the older wave first whatever it is doing; a wave in its transform passes (dense
+// vector work) ahead of one in its epilogue (short dependent LDS round trips) is worth 5-6 % of the fused mel kernel
+// (profiles/r04_experiments.md 10).
+template <int P> LRA_HD void lra_setprio() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (P >= 0) __builtin_amdgcn_s_setprio(P);
+#endif
+}
+#ifndef LRA_I_PRIO_A
+#define LRA_I_PRIO_A -1
+#endif
+#ifndef LRA_I_PRIO_B
+#define LRA_I_PRIO_B -1
+#endif
+
 // Per-lane select under a mask that is held in an SGPR pair: c ? a : b as v_cndmask_b32_e64 (VOP3).  hipcc emits the VOP2 form with
 // the implicit VCC operand for most selects, and on gfx950 a v_cndmask_b32_e32 issued directly behind another one stalls the
 // SIMD's vector pipe for ~16 cycles (scripts/valu_probe2.hip: 9.7 ns per instruction back to back at one or two waves per SIMD

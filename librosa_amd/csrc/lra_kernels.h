@@ -1897,6 +1897,7 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
     } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
     for (int j = 0; j < steps; ++j) {
         if (!Cfg::HOIST) { LRA_LAUNDER(a.win_scaled); LRA_LAUNDER(a.tw); LRA_LAUNDER(a.twr); }
+        lra_setprio<LRA_I_PRIO_A>();   // wave priority per phase (s_setprio, -1 = none): A = un-split + loads + held-back stores, B = the passes + overlap-add
         // (a) split the prefetched spectrum of frame j into LDS, (b) only now issue the held-back output
         // stores of frame j-1, (c) start the prefetch of frame j+1: the wait in (a) never covers (b)
         LRA_PHASE(Cfg::NT, tid) {
@@ -1954,6 +1955,7 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
             }
 #endif
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+        lra_setprio<LRA_I_PRIO_B>();
         // pass 0 (no twiddles) reads from LDS here, unlike the forward kernel (unless it was fused into the Hermitian step)
         if (Cfg::P > 1 && !MIR) {
             LRA_PHASE(Cfg::NT, tid) {

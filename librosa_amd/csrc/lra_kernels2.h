@@ -42,6 +42,37 @@ template <class Cfg> LRA_HD int v2_hop_divisor(int hop) {
     return 0;
 }
 
+// s_setprio at the phase boundaries of the frame loop (see there; lra_common.h, lra_setprio).  Mel kernel: A = window + transform passes (A1: the
+// passes apart from pass 0), S = un-split + power row, B / B2 / B3 = the epilogue's run read / accumulate / band combine; complex / power kernels:
+// CA = transform, CS = un-split + stores.  -1: no instruction.  Measured on the 256 x 30 s batch (same box, alternating; product without: 0.604 ms):
+// 3 / 2 / 0 / combine 1: 0.564-0.568; 3 / 2 / 0: 0.570-0.574; 3 / 2 / 1: 0.570; 3 / 3 / 0: 0.573-0.576; 2 / 3 / 0: 0.578; 3 / 0 / 0: 0.603; the
+// reverse order (0 / - / 3): 0.583-0.587.  The store-bound complex kernel: CA 3 / CS 0 0.744 against 0.747 (left alone), the reverse 0.757.
+#ifndef LRA_V2_PRIO_A
+#define LRA_V2_PRIO_A 3
+#endif
+#ifndef LRA_V2_PRIO_S
+#define LRA_V2_PRIO_S 2
+#endif
+#ifndef LRA_V2_PRIO_B
+#define LRA_V2_PRIO_B 0
+#endif
+#ifndef LRA_V2_PRIO_B2
+#define LRA_V2_PRIO_B2 -1
+#endif
+#ifndef LRA_V2_PRIO_B3
+#define LRA_V2_PRIO_B3 1
+#endif
+#ifndef LRA_V2_PRIO_A1
+#define LRA_V2_PRIO_A1 -1
+#endif
+#ifndef LRA_V2_PRIO_CA
+#define LRA_V2_PRIO_CA -1
+#endif
+#ifndef LRA_V2_PRIO_CS
+#define LRA_V2_PRIO_CS -1
+#endif
+template <int P> LRA_HD void v2_setprio() { lra_setprio<P>(); }
+
 template <class Cfg, int HD> struct Regs2 {
     using C = typename Cfg::cplx;
     static constexpr int R = Cfg::R;
@@ -549,6 +580,9 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
     } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC && MODE != OUT_MELR)  // the shared mel tables need a workgroup barrier, once
     for (int it = 0; it < iters; ++it) {
         if (f_first + it >= a.n_frames) break;  // slot 0 has the smallest frame index: uniform exit
+        // Wave priority per phase (s_setprio; LRA_V2_PRIO_A: window + transform passes, _S: un-split + stores / power row, _B: mel epilogue;
+        // -1 = leave alone).  profiles/r04_experiments.md 10.
+        v2_setprio<MODE == OUT_MELR ? LRA_V2_PRIO_A : LRA_V2_PRIO_CA>();
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
             RG& r = LRA_R(rg);
@@ -564,6 +598,7 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
                 v2_pass0<Cfg, HD>(frame < a.n_frames, tf, r, lds_sub(lds, slot * SB));
             }
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+        if (MODE == OUT_MELR) v2_setprio<LRA_V2_PRIO_A1>();   // (middle + last passes apart from window / pass 0)
 #define LRA_MID_PASS2(p)                                                                                                  \
         if (Cfg::P - 1 > p) {                                                                                             \
             LRA_PHASE(Cfg::NT, tid) {                                                                                     \
@@ -580,6 +615,7 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
         LRA_PHASE(Cfg::NT, tid) {
             v2_last_read<Cfg, HD>(LRA_R(rg), lds_sub(lds, slot_of<Cfg>(tid) * SB), lane_of<Cfg>(tid));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC || (LRA_SPLIT_ONE_BARRIER && MODE != OUT_MELR && !STAGED))  // (registers -> HBM next: see stft_block)
+        v2_setprio<MODE == OUT_MELR ? LRA_V2_PRIO_S : LRA_V2_PRIO_CS>();
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
             v2_last_split_store<Cfg, HD, MODE, PM, STAGED>(a, clip, frame, frame < a.n_frames, tf, LRA_R(rg), lds_sub(lds, slot * SB));
@@ -591,6 +627,7 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         }
         if (MODE == OUT_MELR) {
+            v2_setprio<LRA_V2_PRIO_B>();
             // power row -> runs in registers; then (only then: the running sums reuse the row's bytes) weights, running sums
             // -> rs; then every band adds its piece totals (melr_combine, shared with the first-generation kernel)
             // LRA_MEL_ABLATE = n (timing experiments, scripts/ab_run.sh): the last n of the three epilogue phases sit behind a
@@ -605,11 +642,13 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
                 v2_mel_weights_read<Cfg, HD>(LRA_R(rg), lds_sub(lds, a.shared_off), lane_of<Cfg>(tid));
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
             }
+            v2_setprio<LRA_V2_PRIO_B2>();
             if (LRA_MEL_ABLATE < 2 || ablate_never) {
             LRA_PHASE(Cfg::NT, tid) {
                 v2_mel_accumulate<Cfg, HD>(a, lane_of<Cfg>(tid), LRA_R(rg), lds_sub(lds, slot_of<Cfg>(tid) * SB), lds_sub(lds, a.shared_off));
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
             }
+            v2_setprio<LRA_V2_PRIO_B3>();
             if (LRA_MEL_ABLATE < 1 || ablate_never) {
             LRA_PHASE(Cfg::NT, tid) {
                 const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
