@@ -24,6 +24,25 @@
 #include <hip/hip_runtime.h>
 #endif
 
+// wave priority per stage (s_setprio; experiment switch, profiles/r04_experiments.md 10): L = frame loads, P = passes, S = split, E = mel reduce; -1 = none
+#ifndef LRA_MIXED_PRIO_L
+#define LRA_MIXED_PRIO_L -1
+#endif
+#ifndef LRA_MIXED_PRIO_P
+#define LRA_MIXED_PRIO_P -1
+#endif
+#ifndef LRA_MIXED_PRIO_S
+#define LRA_MIXED_PRIO_S -1
+#endif
+#ifndef LRA_MIXED_PRIO_E
+#define LRA_MIXED_PRIO_E -1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LRA_MIXED_SETPRIO(p) do { if ((p) >= 0) __builtin_amdgcn_s_setprio((p) >= 0 ? (p) : 0); } while (0)
+#else
+#define LRA_MIXED_SETPRIO(p) ((void)0)
+#endif
+
 namespace lra {
 namespace mixed {
 
@@ -235,6 +254,7 @@ template <class T, int N, int MODE> __global__ __launch_bounds__(NT) void mixed_
     const int frames = a.n_frames - f0 < F ? a.n_frames - f0 : F;
     const T* __restrict__ yb = a.y + (long long)clip * a.y_stride;
     // (1) W_M table -> LDS; frames -> buf0 as window-multiplied sample pairs
+    LRA_MIXED_SETPRIO(LRA_MIXED_PRIO_L);
     for (int t = (int)threadIdx.x; t < M; t += NT) twm[t] = a.tw_m[t];
     const cpx<T>* __restrict__ win2 = reinterpret_cast<const cpx<T>*>(a.win);
     for (int w = (int)threadIdx.x; w < frames * M; w += NT) {
@@ -251,9 +271,11 @@ template <class T, int N, int MODE> __global__ __launch_bounds__(NT) void mixed_
     }
     __syncthreads();
     // (2) M-point complex FFT of every frame
+    LRA_MIXED_SETPRIO(LRA_MIXED_PRIO_P);
     cpx<T>* src = buf0;
     cpx<T>* dst = buf1;
     Passes<T, N, 0, F>::run(src, dst, twm, frames);
+    LRA_MIXED_SETPRIO(LRA_MIXED_PRIO_S);
     // (3) Hermitian split.  With E = (Z[k] + conj Z[M-k]) / 2, O = (Z[k] - conj Z[M-k]) / 2 and P = W_N^k O:
     //       X[k] = E - i P,   X[M-k] = conj(E) - i conj(P)      (W_N^{M-k} = -conj W_N^k),
     // so one work item per pair (k, M - k), k = 0 .. M/2, reads its two points once and writes both bins (k = 0: the DC and Nyquist bins
@@ -282,6 +304,7 @@ template <class T, int N, int MODE> __global__ __launch_bounds__(NT) void mixed_
     }
     if (MODE == MIXED_MEL) {
         __syncthreads();
+        LRA_MIXED_SETPRIO(LRA_MIXED_PRIO_E);
         // mel[m][f] = sum_i val[off_m + i] P[f][c0_m + i]: a work item per (band, frame), frames fastest -- the F frames of a band are
         // consecutive in the output
         for (int w = (int)threadIdx.x; w < a.n_mels * F; w += NT) {
