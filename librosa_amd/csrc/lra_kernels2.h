@@ -42,6 +42,9 @@ template <class Cfg> LRA_HD int v2_hop_divisor(int hop) {
     return 0;
 }
 
+#ifndef LRA_V2_ROTATE_MEL
+#define LRA_V2_ROTATE_MEL 0  // the rotating register ring for the mel epilogue too (measured +1 % without wave priorities, see the frame loop)
+#endif
 // s_setprio at the phase boundaries of the frame loop (see there; lra_common.h, lra_setprio).  Mel kernel: A = window + transform passes (A1: the
 // passes apart from pass 0), S = un-split + power row, B / B2 / B3 = the epilogue's run read / accumulate / band combine; complex / power kernels:
 // CA = transform, CS = un-split + stores.  -1: no instruction.  Measured on the 256 x 30 s batch (same box, alternating; product without: 0.604 ms):
@@ -588,7 +591,7 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
             RG& r = LRA_R(rg);
             // (measured, profiles/r04_experiments.md: 21 vector instructions per frame fewer and the same time for the complex / power
             // epilogues; 1 % SLOWER with the mel epilogue, whose issue-bound loop pays for the switches' taken branches -- it keeps the shift)
-            if (v2_rotate_asm_ok<Cfg, HD>() && MODE != OUT_MELR) {
+            if (v2_rotate_asm_ok<Cfg, HD>() && (MODE != OUT_MELR || LRA_V2_ROTATE_MEL)) {
                 v2_window_rotating<Cfg, HD>(it, r);                                      // consumes the pairs loaded during the previous frame (4 moves, not 16)
                 if (it + 1 < iters) v2_issue_loads<Cfg, HD>(a, clip, frame + 1, tf, r);  // ... and starts the next batch, BEFORE this frame's stores
                 v2_pass0_dft<Cfg, HD>(tf, r, lds_sub(lds, slot * SB));
