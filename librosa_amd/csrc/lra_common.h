@@ -223,6 +223,16 @@ template <int P> LRA_HD void lra_setprio() {
     if constexpr (P >= 0) __builtin_amdgcn_s_setprio(P);
 #endif
 }
+#ifndef LRA_V1_PRIO_A   // first-generation forward kernel, mel epilogue (stft_block): transform 3 / split + accumulate 0 / band combine 1 (n_fft 512, 80 mels, 256 x 30 s:
+                        // hop 128 0.994 -> 0.946 ms, hop 160 0.849 -> 0.821 ms; profiles/r04_experiments.md 10)
+#define LRA_V1_PRIO_A 3
+#endif
+#ifndef LRA_V1_PRIO_B
+#define LRA_V1_PRIO_B 0
+#endif
+#ifndef LRA_V1_PRIO_B3
+#define LRA_V1_PRIO_B3 1
+#endif
 #ifndef LRA_I_PRIO_A
 #define LRA_I_PRIO_A -1
 #endif

@@ -1212,6 +1212,7 @@ template <class Cfg, int MODE, int PM = POW_TWO, int RAM = 0> LRA_HD void stft_b
         if (f_first + it >= a.n_frames) break;  // slot 0 has the smallest frame index: uniform exit
         LRA_TICK(0);
         if (!Cfg::HOIST) { LRA_LAUNDER(a.win); LRA_LAUNDER(a.tw); LRA_LAUNDER(a.twr); }
+        if (MODE == OUT_MELR) lra_setprio<LRA_V1_PRIO_A>();  // wave priority per phase, as in stft2_kernel (lra_kernels2.h): transform / split / epilogue / band combine
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
             const Lds sl = lds_sub(lds, slot * slot_bytes);
@@ -1263,6 +1264,7 @@ template <class Cfg, int MODE, int PM = POW_TWO, int RAM = 0> LRA_HD void stft_b
                 mel_flush_tile<Cfg>(a, clip, f_first + slot * iters, it - 1, tile, tf, lds_sub(sl, stft_tile_off<Cfg>()));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC || SPLIT_NO_LDS)
         LRA_TICK(8);
+        if (MODE == OUT_MELR) lra_setprio<LRA_V1_PRIO_B>();
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
             if constexpr (MODE == OUT_MELR) melr_split_accumulate<Cfg, PM>(a, frame < a.n_frames, tf, LRA_R(rg), lds_sub(lds, slot * slot_bytes), lds_sub(lds, a.shared_off));
@@ -1278,6 +1280,7 @@ template <class Cfg, int MODE, int PM = POW_TWO, int RAM = 0> LRA_HD void stft_b
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         }
         if (MODE == OUT_MEL || MODE == OUT_MELR) {
+            if (MODE == OUT_MELR) lra_setprio<LRA_V1_PRIO_B3>();
             LRA_PHASE(Cfg::NT, tid) {
                 const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
                 const Lds sl = lds_sub(lds, slot * slot_bytes);
