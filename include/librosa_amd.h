@@ -294,6 +294,11 @@ int lra_cqt_octave_exec(lra_ctx* ctx, const void* y, int64_t batch, int64_t n, i
 /* mag[i] = |D[i]| (np.abs of the complex spectrogram, core/spectrum.py:1347); D complex, mag real of `dtype`'s precision (device). */
 int lra_magnitude_exec(lra_ctx* ctx, const void* D, void* mag, int64_t count, int dtype);
 
+/* librosa.magphase, librosa/core/spectrum.py:1296-1361: mag[i] = |D[i]| ** power, phase[i] = D[i] / |D[i]| (1 + 0j where |D[i]| = 0; real and
+ * imaginary parts divided separately, :1353-1357).  D: complex (is_complex != 0) or real of `dtype`'s precision; mag real, phase complex
+ * (device).  The exponent as NumPy evaluates a scalar one (1, 2, 0.5, -1, 0: copy, square, sqrt, reciprocal, ones; else pow). */
+int lra_magphase_exec(lra_ctx* ctx, const void* D, int is_complex, void* mag, void* phase, int64_t count, double power, int dtype);
+
 /* mag: [clip][frame][bin] real (device; |D|, or any non-negative real spectrogram S).  One pass: harm / perc = medians over win_harm
  * frames / win_perc bins (scipy.ndimage.median_filter, mode="reflect", :499-510), the two soft masks (util.softmask with `power`,
  * margins, split_zeros = both margins 1, :512-520; power = inf: hard masks), and

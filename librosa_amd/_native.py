@@ -94,6 +94,7 @@ SIGNATURES = {
     "lra_cqt_octave_supported": (c_int, [c_int]),
     "lra_cqt_octave_exec": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int]),
     "lra_magnitude_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int]),
+    "lra_magphase_exec": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_double, c_int]),
     "lra_hpss_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_double, c_double, c_double, c_int, c_int]),
     "lra_dct_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int, c_void_p, c_void_p, c_int, c_double, c_double, c_void_p, c_void_p, c_int, c_double]),
 }
@@ -469,6 +470,9 @@ class Context:
 
     def magnitude_exec(self, d_ptr, mag_ptr, count, dtype):
         _check(self.lib.lra_magnitude_exec(self.handle, c_void_p(d_ptr), c_void_p(mag_ptr), count, dtype_code(dtype)))
+
+    def magphase_exec(self, d_ptr, is_complex, mag_ptr, phase_ptr, count, power, dtype):
+        _check(self.lib.lra_magphase_exec(self.handle, c_void_p(d_ptr), int(bool(is_complex)), c_void_p(mag_ptr), c_void_p(phase_ptr), count, float(power), dtype_code(dtype)))
 
     def hpss_exec(self, mag_ptr, d_ptr, out_h_ptr, out_p_ptr, batch, n_frames, n_bins, win_harm, win_perc, power, margin_harm, margin_perc, want_mask, dtype):
         _check(self.lib.lra_hpss_exec(self.handle, c_void_p(mag_ptr), c_void_p(d_ptr or None), c_void_p(out_h_ptr), c_void_p(out_p_ptr), batch, n_frames, int(n_bins), int(win_harm), int(win_perc),

@@ -25,7 +25,7 @@ from ..util import utils as util
 from ..util.exceptions import ParameterError
 from ..util.utils import is_torch_tensor
 
-__all__ = ["stft", "istft", "_spectrogram", "griffinlim", "phase_vocoder", "power_to_db", "amplitude_to_db", "db_to_power", "db_to_amplitude"]
+__all__ = ["stft", "istft", "_spectrogram", "magphase", "griffinlim", "phase_vocoder", "power_to_db", "amplitude_to_db", "db_to_power", "db_to_amplitude"]
 
 # np.pad modes that do not depend only on edge values: rejected exactly as the reference does
 _REJECTED_PAD_MODES = ("wrap", "maximum", "mean", "median", "minimum")
@@ -702,6 +702,43 @@ def griffinlim(S, *, n_iter=32, hop_length=None, win_length=None, n_fft=None, wi
 # ---------------------------------------------------------------------------------------------------
 # phase vocoder: librosa/core/spectrum.py:1364-1519
 # ---------------------------------------------------------------------------------------------------
+def magphase(D, *, power=1):
+    """Separate a spectrogram into magnitude and phase; drop-in for ``librosa.magphase`` (``librosa/core/spectrum.py:1296-1361``):
+    ``S = |D| ** power``, ``P = D / |D|`` with ``1 + 0j`` where ``|D| = 0`` (real and imaginary parts divided separately, as the reference does
+    for the sake of denormals), so that ``D = S * P`` for ``power = 1``.  ``D``: complex or real, a NumPy array or a device tensor (returned in
+    kind), any shape; one elementwise launch (``lra_magphase_exec``)."""
+    on_device = is_torch_tensor(D)
+    if not on_device:
+        D = np.asarray(D)
+    in_dtype = _arrays.numpy_dtype_of(D)
+    is_complex = in_dtype.kind == "c"
+    wide = in_dtype in (np.dtype(np.complex128), np.dtype(np.float64))
+    real = np.dtype(np.float64) if wide else np.dtype(np.float32)
+    cplx = np.dtype(np.complex128) if wide else np.dtype(np.complex64)
+    shape = tuple(int(v) for v in D.shape)
+    count = int(np.prod(shape, dtype=np.int64)) if shape else 1
+    if count == 0:
+        mag, phase = np.zeros(shape, dtype=real), np.zeros(shape, dtype=cplx)
+        if on_device:
+            torch = _arrays._torch()
+            return torch.from_numpy(mag).to(D.device), torch.from_numpy(phase).to(D.device)
+        return mag, phase
+    sess = _arrays.Session(D if on_device else np.empty(0))
+    try:
+        ctx = sess.ctx
+        if on_device:
+            d_ptr = sess.input_raw(D.reshape(-1), cplx if is_complex else real)
+        else:
+            d_ptr = sess.input_raw(np.ascontiguousarray(D, dtype=cplx if is_complex else real).reshape(-1), cplx if is_complex else real)
+        m_ptr, m_handle = sess.output((count,), real)
+        p_ptr, p_handle = sess.output((count,), cplx)
+        ctx.magphase_exec(d_ptr, is_complex, m_ptr, p_ptr, count, float(power), real)
+        mag, phase = sess.result(m_handle), sess.result(p_handle)
+    finally:
+        sess.close()
+    return mag.reshape(shape), phase.reshape(shape)
+
+
 def phase_vocoder(D, *, rate=None, t_out=None, kind="linear", hop_length=_DEPRECATED, n_fft=_DEPRECATED):
     """Phase vocoder; drop-in for ``librosa.phase_vocoder`` (``librosa/core/spectrum.py:1364-1519``).
 

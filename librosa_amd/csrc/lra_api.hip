@@ -2537,6 +2537,21 @@ int lra_magnitude_exec(lra_ctx* ctx, const void* D, void* mag, int64_t count, in
     return LRA_OK;
 }
 
+int lra_magphase_exec(lra_ctx* ctx, const void* D, int is_complex, void* mag, void* phase, int64_t count, double power, int dtype) {
+    LRA_BIND(ctx);
+    if (count <= 0) return LRA_OK;
+    if (!D || !mag || !phase) return fail(LRA_EINVAL, "null data pointer");
+    if (dtype != LRA_F32 && dtype != LRA_F64) return fail(LRA_EINVAL, "magphase: dtype must be LRA_F32 or LRA_F64");
+    if ((count + 255) / 256 > 0x7fffffffLL) return fail(LRA_EINVAL, "magphase: array too large for one launch");
+    const unsigned grid = (unsigned)((count + 255) / 256);
+    if (dtype == LRA_F64)
+        hipLaunchKernelGGL(magphase_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream, D, is_complex ? 1 : 0, (double*)mag, (HpssCplx<double>*)phase, (long long)count, power);
+    else
+        hipLaunchKernelGGL(magphase_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, D, is_complex ? 1 : 0, (float*)mag, (HpssCplx<float>*)phase, (long long)count, (float)power);
+    LRA_HIP(hipGetLastError());
+    return LRA_OK;
+}
+
 int lra_hpss_exec(lra_ctx* ctx, const void* mag, const void* D, void* out_h, void* out_p, int64_t batch, int64_t n_frames, int n_bins, int win_harm, int win_perc, double power,
                   double margin_harm, double margin_perc, int want_mask, int dtype) {
     LRA_BIND(ctx);

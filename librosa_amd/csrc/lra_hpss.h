@@ -85,6 +85,41 @@ template <class T> struct HpssOps {
 };
 template <> __device__ __forceinline__ float HpssOps<float>::mag(float a, float b) { return (float)sqrt((double)a * (double)a + (double)b * (double)b); }
 template <> __device__ __forceinline__ double HpssOps<double>::mag(double a, double b) { return hypot(a, b); }
+// librosa.magphase (core/spectrum.py:1296-1361): mag = |D| ** power, phase = D / |D| with 1 + 0j where |D| = 0 (real and imaginary parts
+// divided separately, as the reference does for the sake of denormals).  D complex, or real (its imaginary part is zero).  x ** power as
+// NumPy evaluates a scalar exponent on an array: 1, 2, 0.5, -1, 0 take its fast paths (copy, square, sqrt, reciprocal, ones), else pow.
+template <class T> __device__ __forceinline__ T magphase_pow(T m, T power) {
+    if (power == (T)1) return m;
+    if (power == (T)2) return m * m;
+    if (power == (T)0.5) return sizeof(T) == 4 ? (T)sqrtf((float)m) : (T)sqrt((double)m);
+    if (power == (T)-1) return (T)1 / m;
+    if (power == (T)0) return (T)1;
+    return sizeof(T) == 4 ? (T)powf((float)m, (float)power) : (T)pow((double)m, (double)power);
+}
+template <class T>
+__global__ __launch_bounds__(256) void magphase_kernel(const void* __restrict__ D, int is_complex, T* __restrict__ mag, HpssCplx<T>* __restrict__ phase, long long count, T power) {
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= count) return;
+    T re, im, m;
+    if (is_complex) {
+        const HpssCplx<T> d = ((const HpssCplx<T>*)D)[id];
+        re = d.x;
+        im = d.y;
+        m = HpssOps<T>::mag(re, im);
+    } else {
+        re = ((const T*)D)[id];
+        im = (T)0;
+        m = re < (T)0 ? -re : re;   // np.abs of a real: the sign bit cleared (-0.0 -> 0.0)
+        if (m == (T)0) m = (T)0;
+    }
+    const T z = m == (T)0 ? (T)1 : (T)0;
+    const T nz = HpssOps<T>::add(m, z);
+    HpssCplx<T> ph;
+    ph.x = HpssOps<T>::add(HpssOps<T>::div(re, nz), z);
+    ph.y = HpssOps<T>::div(im, nz);
+    phase[id] = ph;
+    mag[id] = magphase_pow<T>(m, power);
+}
 #pragma clang fp contract(fast)
 
 template <class T> __global__ __launch_bounds__(256) void magnitude_kernel(const HpssCplx<T>* __restrict__ D, T* __restrict__ mag, long long count) {

@@ -212,6 +212,13 @@ int postsim_magnitude(const void* D, void* mag, long long count, int is_f64) {
     return 0;
 }
 
+int postsim_magphase(const void* D, int is_complex, void* mag, void* phase, long long count, double power, int is_f64) {
+    const unsigned grid = (unsigned)((count + 255) / 256);
+    if (is_f64) run_grid_serial(grid, 256, [=] { lra::magphase_kernel<double>(D, is_complex, (double*)mag, (lra::HpssCplx<double>*)phase, count, power); });
+    else run_grid_serial(grid, 256, [=] { lra::magphase_kernel<float>(D, is_complex, (float*)mag, (lra::HpssCplx<float>*)phase, count, (float)power); });
+    return 0;
+}
+
 int postsim_hpss(const void* mag, const void* D, void* out_h, void* out_p, long long batch, long long n_frames, int n_bins, int win_harm, int win_perc, double power, double margin_harm,
                  double margin_perc, int want_mask, int is_f64) {
     lra::HpssArgs a;

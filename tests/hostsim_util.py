@@ -160,6 +160,7 @@ def post_lib():
         _post.postsim_fir_decimate.argtypes = [c.c_void_p, c.c_void_p, c.c_longlong, c.c_longlong, c.c_longlong, c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_double, c.c_double, c.c_int]
         _post.postsim_resample_poly.argtypes = [c.c_void_p, c.c_void_p, c.c_longlong, c.c_longlong, c.c_longlong, c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_int, c.c_double, c.c_double, c.c_int]
         _post.postsim_magnitude.argtypes = [c.c_void_p, c.c_void_p, c.c_longlong, c.c_int]
+        _post.postsim_magphase.argtypes = [c.c_void_p, c.c_int, c.c_void_p, c.c_void_p, c.c_longlong, c.c_double, c.c_int]
         _post.postsim_hpss.argtypes = [c.c_void_p] * 4 + [c.c_longlong, c.c_longlong, c.c_int, c.c_int, c.c_int, c.c_double, c.c_double, c.c_double, c.c_int, c.c_int]
         _post.postsim_cqt_project.argtypes = [c.c_void_p] * 6 + [c.c_longlong, c.c_longlong, c.c_int, c.c_longlong, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int]
     return _post

@@ -1551,6 +1551,36 @@ def test_resample_band_limited_converter(L, orig, target, n, dtype):
     assert a.shape == b.shape and np.abs(a - b).max() <= 2e-3, np.abs(a - b).max()   # (Kaiser-5's own pass-band droop)
 
 
+def test_magphase_reference_cases(L):
+    """librosa.magphase (core/spectrum.py:1296-1361) on the device: the reference's own tests (tests/test_core.py:756-804: dtype propagation,
+    zeros -> 1 + 0j, denormals, real input with signed zeros) and a spectrogram against the oracle (|D| to the last bit: an exactly rounded
+    sum / the device's hypot here, NumPy's hypot there); device tensors and NumPy arrays give the same bits."""
+    import torch
+
+    y = golden_cases.make_signal("mix", 22050, 61, None, "float32")
+    D = L.stft(y)
+    S, P = L.magphase(D)
+    assert S.dtype == y.dtype and P.dtype == D.dtype and np.allclose(np.abs(P), 1.0) and np.allclose(S * P, D)          # test_magphase
+    eS, eP = O.magphase(D)
+    assert np.abs(S - eS).max() <= 2.5e-7 * np.abs(eS).max() and np.abs(P - eP).max() <= 3e-7   # (measured: 1.19e-7 = one float32 ulp of the largest |D|, 1.8e-7)
+    St, Pt = L.magphase(torch.from_numpy(D).cuda())
+    assert isinstance(St, torch.Tensor) and St.is_cuda and np.array_equal(St.cpu().numpy(), S) and np.array_equal(Pt.cpu().numpy(), P)
+    Z = np.zeros((128, 128), dtype=np.complex64)                                                                    # test_magphase_zero
+    S, P = L.magphase(Z)
+    assert S.dtype == np.float32 and P.dtype == np.complex64 and np.all(S == 0) and np.all(P == 1 + 0j)
+    Dn = 1.0e-42j * np.ones((128, 128), dtype=np.complex64)                                                         # test_magphase_denormalized
+    S, P = L.magphase(Dn)
+    assert S.dtype == np.float32 and P.dtype == np.complex64 and np.allclose(S, 1.0e-42) and np.allclose(P, 0 + 1j)
+    R = np.array([[-1.0, -0.0], [0.0, 1.0]], dtype=np.float64)                                                      # test_magphase_real
+    S, P = L.magphase(R)
+    assert S.dtype == np.float64 and P.dtype == np.complex128 and np.array_equal(S, [[1.0, 0.0], [0.0, 1.0]])
+    assert np.allclose([[P[0, 0], P[0, 1] ** 2], [P[1, 0], P[1, 1]]], [[-1 + 0j, 1 + 0j], [1 + 0j, 1 + 0j]])
+    D64 = D.astype(np.complex128)
+    for power in (2, 0.5, 3.5):
+        got, exp = L.magphase(D64, power=power), O.magphase(D64, power=power)
+        assert got[0].dtype == np.float64 and np.allclose(got[0], exp[0], rtol=1e-13, atol=0) and np.abs(got[1] - exp[1]).max() <= 1e-15
+
+
 def test_resample_properties(L):
     """Size-independent properties on a batch the oracle would not finish quickly: 64 clips x 30 s at 22 050 Hz -> 16 000 Hz -> back, all
     three converter families; a band-limited signal survives the round trip, lengths are ceil(n * ratio), linearity, and the time axis

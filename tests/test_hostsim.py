@@ -400,6 +400,9 @@ class _SimCtx:
     def magnitude_exec(self, d_ptr, mag_ptr, count, dtype):
         H.post_lib().postsim_magnitude(d_ptr, mag_ptr, count, int(np.dtype(dtype) == np.float64))
 
+    def magphase_exec(self, d_ptr, is_complex, mag_ptr, phase_ptr, count, power, dtype):
+        H.post_lib().postsim_magphase(d_ptr, int(bool(is_complex)), mag_ptr, phase_ptr, count, float(power), int(np.dtype(dtype) == np.float64))
+
     def hpss_exec(self, mag_ptr, d_ptr, out_h_ptr, out_p_ptr, batch, n_frames, n_bins, win_harm, win_perc, power, margin_harm, margin_perc, want_mask, dtype):
         H.post_lib().postsim_hpss(mag_ptr, d_ptr, out_h_ptr, out_p_ptr, batch, n_frames, int(n_bins), int(win_harm), int(win_perc), float(power), float(margin_harm), float(margin_perc),
                                   int(bool(want_mask)), int(np.dtype(dtype) == np.float64))
@@ -767,6 +770,47 @@ def test_hpss_body(dtype):
                     assert np.abs(g - e).max() <= eps * max(np.abs(e).max(), 1e-30), kw
                 else:
                     assert np.array_equal(g, e), kw
+
+
+def test_magphase_through_simulator(monkeypatch):
+    """librosa_amd.magphase (core/spectrum.py:1296-1361) with the kernel body on the host: the reference's own test cases (tests/test_core.py:756-804:
+    dtypes, zeros -> phase 1 + 0j, denormals, real input with signed zeros) and random spectra against the oracle -- real input bit for bit, |D| of a complex
+    value to the last bit (an exactly rounded sum / this libm's hypot here, NumPy's hypot there), every NumPy fast-path exponent."""
+    import torch
+
+    import librosa_amd
+    from librosa_amd import _arrays
+
+    real_session = _arrays.Session
+    monkeypatch.setattr(_arrays, "Session", _SimSession)
+    rng = np.random.default_rng(12)
+    D = (rng.standard_normal((3, 17, 9)) + 1j * rng.standard_normal((3, 17, 9))).astype(np.complex64)
+    D[0, :3] = 0
+    S, P = librosa_amd.magphase(D)
+    eS, eP = O.magphase(D)
+    assert S.dtype == np.float32 and P.dtype == np.complex64 and S.shape == D.shape
+    assert np.abs(S - eS).max() <= 1e-7 * np.abs(eS).max() and np.abs(P - eP).max() <= 2e-7 and np.allclose(np.abs(P), 1.0) and np.allclose(S * P, D, atol=1e-6)
+    assert np.all(P[0, :3] == 1 + 0j) and np.all(S[0, :3] == 0)
+    D64 = D.astype(np.complex128)
+    for power in (1, 2, 0.5, -1, 0, 3.5):
+        with np.errstate(divide="ignore"):
+            got, exp = librosa_amd.magphase(D64, power=power), O.magphase(D64, power=power)
+        assert got[0].dtype == np.float64 and got[1].dtype == np.complex128
+        assert np.abs(got[1] - exp[1]).max() <= 5e-16 and np.allclose(got[0], exp[0], rtol=1e-14 if power == 3.5 else 2e-15, atol=0), power   # (|D|: this libm's hypot / NumPy's)
+    R = np.array([[-1.0, -0.0], [0.0, 1.0]], dtype=np.float64)                       # test_magphase_real
+    S, P = librosa_amd.magphase(R)
+    assert S.dtype == np.float64 and P.dtype == np.complex128 and np.array_equal(S, [[1.0, 0.0], [0.0, 1.0]]) and np.array_equal(P, [[-1, 1], [1, 1]])
+    assert all(np.array_equal(g, e) for g, e in zip(librosa_amd.magphase(R.astype(np.float32), power=2), O.magphase(R.astype(np.float32), power=2)))
+    Dn = 1.0e-42j * np.ones((4, 4), dtype=np.complex64)                              # test_magphase_denormalized
+    S, P = librosa_amd.magphase(Dn)
+    assert np.allclose(S, 1.0e-42) and np.allclose(P, 0 + 1j)
+    Z = np.zeros((5, 5), dtype=np.complex64)                                          # test_magphase_zero
+    S, P = librosa_amd.magphase(Z)
+    assert np.all(S == 0) and np.all(P == 1 + 0j)
+    assert librosa_amd.magphase(np.zeros((0, 4), dtype=np.complex64))[1].shape == (0, 4)
+    monkeypatch.setattr(_arrays, "Session", _sim_torch_session(real_session))         # tensor code path (CPU tensors)
+    St, Pt = librosa_amd.magphase(torch.from_numpy(D64), power=2)
+    assert isinstance(St, torch.Tensor) and np.allclose(St.numpy(), O.magphase(D64, power=2)[0], rtol=1e-15, atol=0) and np.abs(Pt.numpy() - O.magphase(D64)[1]).max() <= 5e-16
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
