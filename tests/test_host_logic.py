@@ -377,3 +377,46 @@ def test_window_sumsquare_memo_is_bounded_by_bytes():
         lru.get(n, lambda n=n: build(n))
     assert lru.nbytes() <= 4000 and len(lru._d) <= 3
     assert spectrum._WSS_CACHE.max_entries == 8 and spectrum._WSS_CACHE.max_bytes == 128 << 20
+
+
+def test_resample_plans_and_filters():
+    """Host side of librosa_amd.resample: 7-smooth transform lengths, the Fourier form's padding / output grid, the polyphase filter
+    (scipy's design and alignment) and argument errors raised before any device work."""
+    import math
+
+    import scipy.signal
+
+    from librosa_amd.core.audio import _band_plan, _rational_filter, _smooth_at_least
+
+    for n in (1, 2, 11, 97, 1501, 65537):
+        m = _smooth_at_least(n)
+        r = m
+        for p in (2, 3, 5, 7):
+            while r % p == 0:
+                r //= p
+        assert m >= n and r == 1 and all(any(k % p for p in (2, 3, 5, 7)) or k < n for k in range(n, m))   # the smallest such number
+    for n_in, up, down in ((661500, 320, 441), (9000, 441, 320), (5000, 160, 147), (4096, 2, 3)):
+        fft_in, fft_out, k_mid, k_sigma = _band_plan(n_in, up, down)
+        f_c = 0.5 * min(1.0, up / down)
+        assert fft_in % down == 0 and fft_out == fft_in // down * up and fft_in >= n_in + 110 / f_c      # exact output grid, linear convolution
+        assert fft_out >= -(-n_in * up // down)
+        assert abs(k_mid / fft_in - 0.9565 * f_c) < 1e-12 and abs((k_mid + 3.5 * k_sigma) / fft_in - f_c) < 1e-12   # -125 dB at the lower Nyquist
+    for up, down in ((1, 2), (3, 2), (160, 441), (441, 160)):
+        for real in (np.dtype(np.float32), np.dtype(np.float64)):
+            taps, first = _rational_filter(up, down, "polyphase", real)
+            half = 10 * max(up, down)
+            ref = scipy.signal.firwin(2 * half + 1, 1.0 / max(up, down), window=("kaiser", 5.0)).astype(real) * real.type(up)
+            lead = down - half % down
+            assert taps.dtype == real and len(taps) == lead + 2 * half + 1 and not taps[:lead].any() and np.array_equal(taps[lead:], ref) and first == (half + lead) // down
+    y = np.zeros(100, dtype=np.float32)
+    for bad in (dict(orig_sr=22050.5, target_sr=8000, res_type="polyphase"), dict(orig_sr=22050.5, target_sr=8000, res_type="soxr_hq"), dict(orig_sr=2, target_sr=1, res_type="linear"),
+                dict(orig_sr=0, target_sr=1, res_type="fft")):
+        with pytest.raises(L.ParameterError):
+            L.resample(y, **bad)
+    with pytest.raises(L.ParameterError):
+        L.resample(np.zeros(10, dtype=np.int32), orig_sr=2, target_sr=1)
+    assert L.resample(y, orig_sr=16000, target_sr=16000) is y
+    with pytest.raises(L.ParameterError):
+        L.effects.pitch_shift(y, sr=22050, n_steps=1, bins_per_octave=-3)
+    assert math.gcd(320, 441) == 1
+
