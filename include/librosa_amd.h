@@ -127,6 +127,13 @@ int lra_stft_num_frames(const lra_stft_plan* plan, int64_t n, int64_t* n_frames)
 int lra_stft_exec(lra_stft_plan* plan, const void* y, int64_t batch, int64_t n, int64_t y_stride, void* D);
 /* S[batch][n_frames][n_bins] = |stft|**power  (_spectrogram, core/spectrum.py:3000-3013). */
 int lra_spectrogram_exec(lra_stft_plan* plan, const void* y, int64_t batch, int64_t n, int64_t y_stride, double power, void* S);
+/* The same two results with the rows of consecutive frames `out_frame_stride` ELEMENTS apart (>= n_bins; 0 = n_bins = the calls above):
+ * kind 0 = lra_stft_exec, kind 1 = lra_spectrogram_exec.  The array librosa.stft returns is itself a strided view -- (..., n_bins, n_frames)
+ * over storage whose fastest axis is the bin axis (core/spectrum.py:356, order="F") -- so a caller may pad each frame's row to a whole
+ * number of 128-byte cache lines (1040 complex64 for n_fft = 2048) and present out[..., :n_bins] transposed: every wave-wide store of the
+ * kernels then covers whole lines (round 5, profiles/r05_pitch.md).  Only the elements [0, n_bins) of a row are written.  Fused power-of-two
+ * plans only (lra_stft_plan_is_fused); LRA_EINVAL otherwise. */
+int lra_stft_exec_strided(lra_stft_plan* plan, int kind, const void* y, int64_t batch, int64_t n, int64_t y_stride, double power, void* out, int64_t out_frame_stride);
 
 /* Host-buffer form of the three forward calls (what librosa.stft / _spectrogram / feature.melspectrogram take: NumPy arrays,
  * core/spectrum.py:57-391, :2920-3015, feature/spectral.py:2145-2160).  y_host: [batch] rows of n reals, y_stride elements
@@ -331,6 +338,11 @@ void lra_comm_destroy(lra_comm* comm);
  * (SURVEY.md 8d prices the kernels against 8 TB/s).  n_fft in {256, 512, ..., 2048}, hop a multiple of 128. */
 int lra_probe_stream(lra_ctx* ctx, int direction, const void* in, void* out, int64_t batch, int64_t rows_per_clip, int n_fft, int hop, int64_t clip_samples,
                      int strip_rows, int waves_per_cu);
+/* ... with the rows `row_pitch_bytes` apart (0 = packed: (n_fft/2 + 1) * 8; a multiple of 8) and the row side moved in pieces of
+ * `piece_bytes`: 8 = the kernels' own butterfly order (bins k ascending from one base, M - k descending from the other), 16 = wave-wide
+ * 1 KiB pieces in address order + bin M (needs a pitch that is a multiple of 16). */
+int lra_probe_stream_pitched(lra_ctx* ctx, int direction, const void* in, void* out, int64_t batch, int64_t rows_per_clip, int n_fft, int hop, int64_t clip_samples,
+                             int strip_rows, int waves_per_cu, int64_t row_pitch_bytes, int piece_bytes);
 
 /* ---- layout helper: dst[b][c][r] = src[b][r][c], elem_bytes in {4, 8, 16} ------------------ */
 int lra_transpose(lra_ctx* ctx, const void* src, void* dst, int64_t batch, int64_t rows, int64_t cols, int elem_bytes);

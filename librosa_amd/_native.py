@@ -71,6 +71,8 @@ SIGNATURES = {
     "lra_istft_exec_norm": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64]),
     "lra_transpose": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int]),
     "lra_probe_stream": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int64, c_int, c_int]),
+    "lra_probe_stream_pitched": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int64, c_int, c_int, c_int64, c_int]),
+    "lra_stft_exec_strided": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p, c_int64]),
     "lra_item_absmax_exec": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "lra_item_max_exec": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     "lra_to_db_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_double, c_double, c_void_p, c_void_p, c_int, c_double]),
@@ -389,6 +391,10 @@ class Context:
     def spectrogram_exec(self, plan, y_ptr, batch, n, y_stride, power, out_ptr):
         _check(self.lib.lra_spectrogram_exec(plan, c_void_p(y_ptr), batch, n, y_stride, float(power), c_void_p(out_ptr)))
 
+    def stft_exec_strided(self, plan, kind, y_ptr, batch, n, y_stride, power, out_ptr, out_frame_stride):
+        """kind 0 = complex spectrum, 1 = ``|X|**power``, rows ``out_frame_stride`` elements apart (fused power-of-two plans; ``include/librosa_amd.h``)."""
+        _check(self.lib.lra_stft_exec_strided(plan, int(kind), c_void_p(y_ptr), batch, n, y_stride, float(power), c_void_p(out_ptr), int(out_frame_stride)))
+
     def melspectrogram_exec(self, plan, mel_plan, y_ptr, batch, n, y_stride, power, out_ptr):
         _check(self.lib.lra_melspectrogram_exec(plan, mel_plan, c_void_p(y_ptr), batch, n, y_stride, float(power), c_void_p(out_ptr)))
 
@@ -488,9 +494,10 @@ class Context:
         _check(self.lib.lra_griffinlim_update(self.handle, c_void_p(rebuilt_ptr), c_void_p(tprev_ptr) if tprev_ptr else None, c_void_p(s_ptr), c_void_p(angles_ptr), count, dtype_code(dtype),
                                               float(coef), float(eps), int(bool(normalize))))
 
-    def probe_stream(self, direction, in_ptr, out_ptr, batch, rows_per_clip, n_fft, hop, clip_samples, strip_rows=0, waves_per_cu=0):
+    def probe_stream(self, direction, in_ptr, out_ptr, batch, rows_per_clip, n_fft, hop, clip_samples, strip_rows=0, waves_per_cu=0, row_pitch_bytes=0, piece_bytes=8):
         """The transform's access stream without its arithmetic (measurement aid; ``include/librosa_amd.h``)."""
-        _check(self.lib.lra_probe_stream(self.handle, int(direction), c_void_p(in_ptr), c_void_p(out_ptr), batch, rows_per_clip, n_fft, hop, clip_samples, strip_rows, waves_per_cu))
+        _check(self.lib.lra_probe_stream_pitched(self.handle, int(direction), c_void_p(in_ptr), c_void_p(out_ptr), batch, rows_per_clip, n_fft, hop, clip_samples, strip_rows, waves_per_cu,
+                                                 int(row_pitch_bytes), int(piece_bytes)))
 
     def transpose(self, src_ptr, dst_ptr, batch, rows, cols, elem_bytes):
         _check(self.lib.lra_transpose(self.handle, c_void_p(src_ptr), c_void_p(dst_ptr), batch, rows, cols, elem_bytes))

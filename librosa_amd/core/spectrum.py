@@ -13,6 +13,7 @@ Extensions beyond the reference (which only accepts ``np.ndarray``):
 from __future__ import annotations
 
 import collections
+import os
 import functools
 import threading
 import warnings
@@ -258,6 +259,44 @@ def _device_norm(sess, wss, wss_key, real):
     return sess.input_raw(_as_like(sess, wss_to_norm(wss)), real)
 
 
+# Rows of the device-resident complex / power result are padded to whole 128-byte cache lines (LRA_ROW_ALIGN bytes; 0 = packed): every wave-wide
+# store of the kernels then covers whole lines instead of straddling five (profiles/r05_pitch.md: the 2048 / 512 transform 0.747 -> 0.658 ms
+# on the same box).  What the caller sees is unchanged in shape, dtype and values: ``(..., n_bins, n_frames)`` with the bin axis fastest -- the
+# reference's own result is such a strided view (order="F", core/spectrum.py:356) -- only ``stride(-1)`` is ``row_pitch`` instead of ``n_bins``.
+ROW_ALIGN_BYTES = int(os.environ.get("LRA_ROW_ALIGN", "128") or 0)
+_ROW_ALIGN_MIN_ROW_BYTES = 4096   # measured: rows of 2 056 B (n_fft = 512) gain nothing or lose, 4 104 B (n_fft = 1024) and longer gain 7-17 %
+
+
+def row_pitch(n_bins, itemsize, align=None):
+    """Elements between the rows of consecutive frames in a device-resident result of ``stft`` / ``_spectrogram``."""
+    align = ROW_ALIGN_BYTES if align is None else int(align)
+    if align <= 0 or n_bins * itemsize < _ROW_ALIGN_MIN_ROW_BYTES or align % itemsize:
+        return int(n_bins)
+    per = align // itemsize
+    return int((n_bins + per - 1) // per * per)
+
+
+def _frame_major_strides(xt, n_bins):
+    """(batch stride, frame stride) in elements when the tensor ``xt`` of shape (..., n_frames, n_bins) can be walked as [batch][frame][bin] in
+    place -- bins contiguous, frames a fixed distance >= n_bins apart, the leading axes collapsing into one -- else None."""
+    if xt.ndim < 2 or xt.shape[-1] != n_bins or (n_bins > 1 and xt.stride(-1) != 1):
+        return None
+    fs = int(xt.stride(-2)) if xt.shape[-2] > 1 else int(n_bins)
+    if fs < n_bins:
+        return None
+    bs = fs * int(xt.shape[-2])
+    if xt.ndim > 2:
+        lead = [(int(sz), int(st)) for sz, st in zip(xt.shape[:-2], xt.stride()[:-2]) if sz > 1]
+        if lead:
+            bs = lead[-1][1]
+            if bs < fs * int(xt.shape[-2]):
+                return None
+            for (sz0, st0), (sz1, st1) in zip(lead[:-1], lead[1:]):
+                if st0 != st1 * sz1:
+                    return None
+    return bs, fs
+
+
 def _finite_check_covers_input(n, n_fft, hop, center):
     """True when every input sample lies in some frame, so the kernels' DC-bin flag sees it."""
     if hop > n_fft:
@@ -268,7 +307,8 @@ def _finite_check_covers_input(n, n_fft, hop, center):
     return covered_hi >= (n + (n_fft // 2 if center else 0))
 
 
-def _run_stft_family(kind, y, *, n_fft, hop_length, win_length, window, center, pad_mode, dtype=None, power=1.0, mel_basis=None, check_finite=True, post=None, out=None):
+def _run_stft_family(kind, y, *, n_fft, hop_length, win_length, window, center, pad_mode, dtype=None, power=1.0, mel_basis=None, check_finite=True, post=None, out=None,
+                     row_align=None):
     """kind in {"stft", "power", "mel"}.  Returns the result laid out like the reference's.
 
     ``post(sess, mel_ptr, batch, n_mels, n_frames, real) -> (handle, rows)`` (mel only) chains further device work on the mel
@@ -347,12 +387,21 @@ def _run_stft_family(kind, y, *, n_fft, hop_length, win_length, window, center, 
             res = _arrays.swap_last_two(host.reshape(lead + (n_frames, n_bins)))
             return _arrays.cast(res, out_dtype) if kind == "stft" else res
         y_ptr, batch, _, y_stride = sess.input_2d(y, real)
+        pitch = n_bins
+        if kind != "mel" and sess.is_torch and fused:  # device-resident result: rows padded to whole cache lines behind the view (see row_pitch)
+            pitch = row_pitch(n_bins, np.dtype(util.dtype_r2c(real) if kind == "stft" else real).itemsize, row_align)
         if kind == "stft":
-            ptr, handle = sess.output((batch, n_frames, n_bins), util.dtype_r2c(real))
-            ctx.stft_exec(plan, y_ptr, batch, n, y_stride, ptr)
+            ptr, handle = sess.output((batch, n_frames, pitch), util.dtype_r2c(real))
+            if pitch == n_bins:
+                ctx.stft_exec(plan, y_ptr, batch, n, y_stride, ptr)
+            else:
+                ctx.stft_exec_strided(plan, 0, y_ptr, batch, n, y_stride, 1.0, ptr, pitch)
         elif kind == "power":
-            ptr, handle = sess.output((batch, n_frames, n_bins), real)
-            ctx.spectrogram_exec(plan, y_ptr, batch, n, y_stride, power, ptr)
+            ptr, handle = sess.output((batch, n_frames, pitch), real)
+            if pitch == n_bins:
+                ctx.spectrogram_exec(plan, y_ptr, batch, n, y_stride, power, ptr)
+            else:
+                ctx.stft_exec_strided(plan, 1, y_ptr, batch, n, y_stride, power, ptr, pitch)
         else:
             n_mels = int(mel_basis.shape[0])
             mel_plan = ctx.mel_plan(np.ascontiguousarray(mel_basis, dtype=real))
@@ -370,6 +419,8 @@ def _run_stft_family(kind, y, *, n_fft, hop_length, win_length, window, center, 
         sess.close()
     if kind == "mel":
         return res.reshape(lead + (n_mels, n_frames))
+    if pitch != n_bins:
+        res = res.view(lead + (n_frames, pitch))[..., :n_bins]  # the padding stays behind the view
     res = _arrays.swap_last_two(res.reshape(lead + (n_frames, n_bins)))  # (..., n_bins, n_frames) view
     if kind == "stft":
         res = _arrays.cast(res, out_dtype)
@@ -377,7 +428,7 @@ def _run_stft_family(kind, y, *, n_fft, hop_length, win_length, window, center, 
 
 
 def stft(y, *, n_fft=2048, hop_length=None, win_length=None, window="hann", center=True, dtype=None, pad_mode="constant", out=None,
-         check_finite=True):
+         check_finite=True, row_align=None):
     """Short-time Fourier transform; drop-in for ``librosa.stft`` (``librosa/core/spectrum.py:57-391``).
 
     Returns ``D[..., f, t]`` of shape ``(..., 1 + n_fft//2, n_frames)``, complex64 for float32 audio and
@@ -387,11 +438,15 @@ def stft(y, *, n_fft=2048, hop_length=None, win_length=None, window="hann", cent
 
     ``out`` (numpy only): a pre-allocated complex array with matching leading shape and at least
     ``n_frames`` columns; the same object (or ``out[..., :n_frames]``) is returned (``:355-367``).
+
+    Device tensors (extension): each frame's row of the result starts on a 128-byte boundary (``row_align`` bytes, default
+    ``LRA_ROW_ALIGN`` = 128; 0 = packed rows) -- ``stride(-1)`` of the returned view is then ``row_pitch(n_bins, itemsize)`` rather
+    than ``n_bins``; shape, dtype and values are the same, ``.contiguous()`` compacts, and ``istft`` reads the view in place.
     """
     if out is not None and is_torch_tensor(y):
         raise ParameterError("out= is only supported for numpy inputs")
     return _run_stft_family("stft", y, n_fft=n_fft, hop_length=hop_length, win_length=win_length, window=window, center=center, pad_mode=pad_mode,
-                            dtype=dtype if out is None else (dtype or util.dtype_r2c(_arrays.numpy_dtype_of(y))), check_finite=check_finite, out=out)
+                            dtype=dtype if out is None else (dtype or util.dtype_r2c(_arrays.numpy_dtype_of(y))), check_finite=check_finite, out=out, row_align=row_align)
 
 
 def _spectrogram(*, y=None, S=None, n_fft=2048, hop_length=512, power=1, win_length=None, window="hann", center=True, pad_mode="constant"):
@@ -484,9 +539,12 @@ def istft(stft_matrix, *, hop_length=None, win_length=None, n_fft=None, window="
         batch = int(np.prod(lead, dtype=np.int64)) if lead else 1
         # bring the spectrum into the device layout [batch][frame][bin]
         Dt = _arrays.swap_last_two(D)  # (..., T, bins)
+        d_batch_stride, d_frame_stride = n_total * n_bins, n_bins
         if sess.is_torch:
-            if Dt.is_contiguous() and Dt.dtype == _arrays.torch_dtype(cplx):
+            strides = _frame_major_strides(Dt, n_bins) if Dt.dtype == _arrays.torch_dtype(cplx) else None
+            if strides is not None:  # what stft returns (rows possibly padded, see row_pitch), or any frame-major view: read in place
                 d_ptr = Dt.data_ptr()
+                d_batch_stride, d_frame_stride = strides
                 sess._keep.append(Dt)
             else:
                 src = D.to(_arrays.torch_dtype(cplx)).contiguous()
@@ -521,7 +579,7 @@ def istft(stft_matrix, *, hop_length=None, win_length=None, n_fft=None, window="
                 _transpose_batched(ctx, src_ptr, d_ptr, batch, n_bins, n_total, cplx.itemsize)
         norm_ptr = _device_norm(sess, wss, wss_key, real)
         y_ptr, handle = sess.output((batch, int(expected)), real)
-        ctx.istft_exec_norm(plan, d_ptr, batch, n_total * n_bins, n_bins, n_used, norm_ptr, y_ptr, int(expected), int(expected))
+        ctx.istft_exec_norm(plan, d_ptr, batch, d_batch_stride, d_frame_stride, n_used, norm_ptr, y_ptr, int(expected), int(expected))
         y = sess.result(handle)
     finally:
         sess.close()
@@ -580,7 +638,9 @@ def _to_frame_major(sess, x, batch, rows, cols, dtype):
     dtype = np.dtype(dtype)
     if sess.is_torch:
         xt = _arrays.swap_last_two(x)
-        if xt.is_contiguous() and xt.dtype == _arrays.torch_dtype(dtype):
+        if xt.dtype == _arrays.torch_dtype(dtype) and (xt.is_contiguous() or (xt.ndim >= 2 and xt.stride(-1) == 1 and xt.stride(-2) >= xt.shape[-1])):
+            # frame-major already: in place, or -- rows padded behind the view (stft's device result, row_pitch) -- one compaction pass
+            xt = xt.contiguous()
             sess._keep.append(xt)
             return xt.data_ptr()
         src = x.to(_arrays.torch_dtype(dtype)).contiguous()

@@ -881,7 +881,7 @@ template <class F> int autotune_variant(lra_ctx* ctx, F&& launch, int* tuned) {
 }
 
 template <class T>
-int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n, int64_t y_stride, double power, lra_mel_plan* mel, void* out) {
+int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n, int64_t y_stride, double power, lra_mel_plan* mel, void* out, int64_t row_pitch = 0) {
     LRA_BIND(p->ctx);
     int64_t n_frames = 0;
     LRA_TRY(lra_stft_num_frames(p, n, &n_frames));
@@ -891,6 +891,9 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
     if (n_frames > 0x7fffffffLL / 4) return fail(LRA_EINVAL, "too many frames per clip");
     lra_ctx* ctx = p->ctx;
     const int bins = p->n_fft / 2 + 1;
+    if (row_pitch <= 0) row_pitch = bins;
+    if (row_pitch != bins && (!p->pow2 || row_pitch < bins || (mode != OUT_COMPLEX && mode != OUT_POWER)))
+        return fail(LRA_EINVAL, "a row pitch other than n_bins is served by the fused power-of-two kernels only (complex / power results), and must be at least n_bins");
     if (mode == OUT_MEL) {
         if (!mel) return fail(LRA_EINVAL, "null mel plan");
         if (mel->n_bins != bins) return fail(LRA_EINVAL, "mel basis has " + std::to_string(mel->n_bins) + " bins, stft has " + std::to_string(bins));
@@ -903,6 +906,7 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
         L.a.y_stride = y_stride;
         L.a.n = n;
         L.a.n_frames = (int)n_frames;
+        L.a.row_pitch = row_pitch;
         L.a.hop = p->hop;
         L.a.pad = p->center ? p->n_fft / 2 : 0;
         L.a.pad_mode = p->pad_mode;
@@ -1814,6 +1818,14 @@ int lra_spectrogram_exec(lra_stft_plan* p, const void* y, int64_t batch, int64_t
                                : stft_run<float>(p, OUT_POWER, y, batch, n, y_stride, power, nullptr, S);
 }
 
+int lra_stft_exec_strided(lra_stft_plan* p, int kind, const void* y, int64_t batch, int64_t n, int64_t y_stride, double power, void* out, int64_t out_frame_stride) {
+    if (!p) return fail(LRA_EINVAL, "null plan");
+    if (kind != 0 && kind != 1) return fail(LRA_EINVAL, "kind must be 0 (complex) or 1 (|X|^power)");
+    const int mode = kind == 0 ? OUT_COMPLEX : OUT_POWER;
+    return p->dtype == LRA_F64 ? stft_run<double>(p, mode, y, batch, n, y_stride, kind ? power : 1.0, nullptr, out, out_frame_stride)
+                               : stft_run<float>(p, mode, y, batch, n, y_stride, kind ? power : 1.0, nullptr, out, out_frame_stride);
+}
+
 // ---- mel ----------------------------------------------------------------------------------------
 int lra_mel_plan_create(lra_ctx* ctx, int n_mels, int n_bins, const void* basis_host, int dtype, lra_mel_plan** out) {
     LRA_BIND(ctx);
@@ -2662,6 +2674,11 @@ void lra_comm_destroy(lra_comm* comm) {
 
 int lra_probe_stream(lra_ctx* ctx, int direction, const void* in, void* out, int64_t batch, int64_t rows_per_clip, int n_fft, int hop, int64_t clip_samples, int strip_rows,
                      int waves_per_cu) {
+    return lra_probe_stream_pitched(ctx, direction, in, out, batch, rows_per_clip, n_fft, hop, clip_samples, strip_rows, waves_per_cu, 0, 8);
+}
+
+int lra_probe_stream_pitched(lra_ctx* ctx, int direction, const void* in, void* out, int64_t batch, int64_t rows_per_clip, int n_fft, int hop, int64_t clip_samples,
+                             int strip_rows, int waves_per_cu, int64_t row_pitch_bytes, int piece_bytes) {
     LRA_BIND(ctx);
     if (batch <= 0 || rows_per_clip <= 0) return LRA_OK;
     if (!in || !out) return fail(LRA_EINVAL, "null data pointer");
@@ -2678,6 +2695,10 @@ int lra_probe_stream(lra_ctx* ctx, int direction, const void* in, void* out, int
     a.strip_rows = strip_rows > 0 ? strip_rows : 162;
     a.n_clips = (int)batch;
     a.bins = M + 1;
+    a.row_pitch = row_pitch_bytes > 0 ? row_pitch_bytes : (long long)(M + 1) * 8;
+    if (a.row_pitch < (long long)(M + 1) * 8 || a.row_pitch % 8 != 0) return fail(LRA_EINVAL, "probe: row pitch must be a multiple of 8 bytes, at least one row");
+    if (piece_bytes != 8 && piece_bytes != 16) return fail(LRA_EINVAL, "probe: pieces of 8 or 16 bytes");
+    if (piece_bytes == 16 && (a.row_pitch % 16 != 0 || ((size_t)(direction == 0 ? out : in) & 15))) return fail(LRA_EINVAL, "probe: 16-byte pieces need 16-byte aligned rows");
     a.hop_bytes = hop * 4;
     const long long pcm_rows = clip_samples / hop;
     a.pcm_rows = (int)(pcm_rows < rows_per_clip ? pcm_rows : rows_per_clip);
@@ -2687,7 +2708,8 @@ int lra_probe_stream(lra_ctx* ctx, int direction, const void* in, void* out, int
     a.xcd_chunk = ctx->opt_xcd_remap ? (int)(grid / 8) : 0;
     const int wpc = waves_per_cu > 0 ? waves_per_cu : 12;
     const int lds = wpc >= 32 ? 0 : ((160 * 1024 / wpc) & ~255);  // one wave per workgroup: the LDS pad bounds the resident waves per CU
-    auto kern = direction == 0 ? stream_probe_kernel<0> : stream_probe_kernel<1>;
+    auto kern = direction == 0 ? (piece_bytes == 16 ? stream_probe_kernel<0, true> : stream_probe_kernel<0, false>)
+                               : (piece_bytes == 16 ? stream_probe_kernel<1, true> : stream_probe_kernel<1, false>);
     if (lds > 65536) LRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, ctx->stream, a);
     LRA_HIP(hipGetLastError());

@@ -78,8 +78,10 @@ template <class T> struct StftArgs {
     int slot_bytes;     // LDS bytes per frame slot (frame area + PCM ring + mel staging tile)
     int mel_tile;       // frames staged per mel row before a flush
     // outputs (one of)
-    cx<T>* D;  // [batch][T][M+1]
-    T* S;      // [batch][T][M+1]
+    cx<T>* D;  // [batch][T][row_pitch], M + 1 bins of each row used
+    T* S;      // [batch][T][row_pitch]
+    long long row_pitch;  // ELEMENTS between the rows of consecutive frames: M + 1 = packed (the layout core/spectrum.py:356 allocates); larger = rows padded so that
+                          // each starts on a cache-line boundary, the caller presenting the result as a strided view (lra_stft_exec_strided)
     T* Mel;    // [batch][n_mels][T]
     int power_mode;
     T power;
@@ -586,7 +588,7 @@ template <class Cfg, int MODE, int PM> LRA_HD void stft_split_store(const StftAr
     using T = typename Cfg::real;
     using C = typename Cfg::cplx;
     constexpr int M = Cfg::M;
-    const long long row = ((long long)clip * a.n_frames + frame) * (M + 1);
+    const long long row = ((long long)clip * a.n_frames + frame) * a.row_pitch;
     // bins k = tf + i TF ascend from one per-thread pointer, the mirrored bins M - k descend from another:
     // two 64-bit bases per frame and immediate offsets for all R stores
     C* __restrict__ const Dk = MODE == OUT_COMPLEX ? a.D + row + tf : nullptr;
@@ -710,7 +712,7 @@ template <class Cfg, int MODE, int PM> LRA_HD void mirror32_split_store(const St
     constexpr int M = Cfg::M, S = Cfg::TF;
     const bool l0 = tf == 0;
     const LaneMask l0m = lane_mask(l0);
-    const long long row = ((long long)clip * a.n_frames + frame) * (M + 1);
+    const long long row = ((long long)clip * a.n_frames + frame) * a.row_pitch;
     const int kb = mirror32_kbase<Cfg>(tf);
     C* __restrict__ const Dk = MODE == OUT_COMPLEX ? a.D + row + kb : nullptr;
     C* __restrict__ const Dm = MODE == OUT_COMPLEX ? a.D + row + (M - kb) : nullptr;

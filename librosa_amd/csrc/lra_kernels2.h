@@ -50,6 +50,9 @@ template <class Cfg> LRA_HD int v2_hop_divisor(int hop) {
 // CA = transform, CS = un-split + stores.  -1: no instruction.  Measured on the 256 x 30 s batch (same box, alternating; product without: 0.604 ms):
 // 3 / 2 / 0 / combine 1: 0.564-0.568; 3 / 2 / 0: 0.570-0.574; 3 / 2 / 1: 0.570; 3 / 3 / 0: 0.573-0.576; 2 / 3 / 0: 0.578; 3 / 0 / 0: 0.603; the
 // reverse order (0 / - / 3): 0.583-0.587.  The store-bound complex kernel: CA 3 / CS 0 0.744 against 0.747 (left alone), the reverse 0.757.
+#ifndef LRA_V2_STAGGER_ALL
+#define LRA_V2_STAGGER_ALL 0
+#endif
 #ifndef LRA_V2_PRIO_A
 #define LRA_V2_PRIO_A 3
 #endif
@@ -339,7 +342,7 @@ template <class T> struct alignas(16) V4 {
     T a, b, c, d;
 };
 template <class Cfg> LRA_HD int v2_row_shift(const StftArgs<typename Cfg::real>& a, int clip, int frame) {
-    const long long row = ((long long)clip * a.n_frames + frame) * (Cfg::M + 1);
+    const long long row = ((long long)clip * a.n_frames + frame) * a.row_pitch;
     return (int)(reinterpret_cast<size_t>(a.D + row) & (2 * sizeof(typename Cfg::real)));  // 0 or sizeof(cplx): the row starts on / half-way into a 16-byte piece
 }
 
@@ -373,7 +376,7 @@ LRA_HD void v2_last_split_store(const StftArgs<typename Cfg::real>& a, int clip,
     const bool l0 = tf == 0;
     const LaneMask l0m = lane_mask(l0);
     const int tfh = v2_tf_hi<Cfg>(tf);
-    const long long row = ((long long)clip * a.n_frames + frame) * (M + 1);
+    const long long row = ((long long)clip * a.n_frames + frame) * a.row_pitch;
     C* __restrict__ const D = MODE == OUT_COMPLEX ? a.D + row : nullptr;
     T* __restrict__ const S = MODE == OUT_POWER ? a.S + row : nullptr;
     const int sh = (MODE == OUT_COMPLEX && STAGED) ? v2_row_shift<Cfg>(a, clip, frame) : 0;
@@ -462,7 +465,7 @@ template <class Cfg> LRA_HD void v2_store_row(const StftArgs<typename Cfg::real>
     constexpr int M = Cfg::M, PIECES = M / (2 * Cfg::TF);
     static_assert(sizeof(T) == 4, "16-byte pieces of complex64");
     if (!valid) return;
-    const long long row = ((long long)clip * a.n_frames + frame) * (M + 1);
+    const long long row = ((long long)clip * a.n_frames + frame) * a.row_pitch;
     const int sh = v2_row_shift<Cfg>(a, clip, frame);
     char* __restrict__ const g = reinterpret_cast<char*>(a.D + row) + sh + 16 * tf;  // first aligned piece of this thread
     V4<T> w[PIECES];
@@ -581,6 +584,15 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
             melr_hoist<Cfg>(a, tf, LRA_R(rg), slot * SB);  // (addresses relative to the workgroup's LDS, not to the slot)
         }
     } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC && MODE != OUT_MELR)  // the shared mel tables need a workgroup barrier, once
+#if defined(LRA_V2_STAGGER) && !defined(LRA_HOSTSIM)
+    // experiment (round 5): the two waves that share a SIMD start LRA_V2_STAGGER x 64 cycles apart -- the wave in an odd
+    // hardware wave slot sleeps before its first frame (HW_ID bits 3:0 = wave slot within the SIMD) -- instead of drifting there over the first frames
+    if (MODE == OUT_MELR || LRA_V2_STAGGER_ALL) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        if (hw & 1u) __builtin_amdgcn_s_sleep(LRA_V2_STAGGER);
+    }
+#endif
     for (int it = 0; it < iters; ++it) {
         if (f_first + it >= a.n_frames) break;  // slot 0 has the smallest frame index: uniform exit
         // Wave priority per phase (s_setprio; LRA_V2_PRIO_A: window + transform passes, _S: un-split + stores / power row, _B: mel epilogue;

@@ -28,11 +28,15 @@ struct ProbeArgs {
     int bins;                // complex64 per row (n_fft / 2 + 1)
     int hop_bytes;           // PCM bytes per row (hop * 4)
     int xcd_chunk;           // > 0: block b -> (b % 8) * xcd_chunk + b / 8
+    long long row_pitch;     // bytes between consecutive rows (bins * 8 = packed; round 5: a multiple of 128 puts every row on a cache-line boundary)
 };
 
 // DIR 0: forward stream (read hop_bytes, write one row); DIR 1: inverse stream (read one row, write hop_bytes).
 // One wave per workgroup; R8 = 8-byte pieces per lane on the PCM side (hop_bytes / 512), at most 8.
-template <int DIR> __global__ __launch_bounds__(64) void stream_probe_kernel(ProbeArgs a) {
+// P16 (round 5, needs a row pitch that is a multiple of 16): the row side moves as M / 128 wave-wide 16-byte pieces of 1 KiB each in
+// address order + bin M as lane 0's 8-byte tail (global_store_dwordx4 / global_load_dwordx4) instead of the kernels' 2 x M / 128
+// 8-byte pieces in butterfly order -- what a transform could do after exchanging neighbouring bins between lane pairs.
+template <int DIR, bool P16> __global__ __launch_bounds__(64) void stream_probe_kernel(ProbeArgs a) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     extern __shared__ char probe_pad[];  // (residency bound only)
     const int lane = threadIdx.x;
@@ -45,7 +49,8 @@ template <int DIR> __global__ __launch_bounds__(64) void stream_probe_kernel(Pro
     const int M = a.bins - 1;                 // bins k and M - k pair up, bin M / 2 is lane 0's extra piece
     const int pieces = M / 128;                // 8-byte pieces per lane on each side (8 at n_fft = 2048); the host checks M % 128 == 0, M <= 1024
     const int pcm8 = a.hop_bytes / 512;        // 8-byte pieces per lane of the PCM side (4 at hop 512)
-    const long long row_bytes = (long long)a.bins * 8;
+    const long long row_bytes = a.row_pitch;
+    typedef float f4 __attribute__((ext_vector_type(4)));
     f2 v = {(float)lane, (float)b};
     if (DIR == 0) {
         f2 cur[8], nx[8];
@@ -62,12 +67,21 @@ template <int DIR> __global__ __launch_bounds__(64) void stream_probe_kernel(Pro
             }
             v.x += cur[0].x + cur[7].y;
             f2* rp = reinterpret_cast<f2*>(a.out + (clip * a.rows_per_clip + row) * row_bytes);
-            f2* pk = rp + lane;
-            f2* pm = rp + (M - lane);
+            if (P16) {
+                f4* p4 = reinterpret_cast<f4*>(rp) + lane;
+                const f4 w = {v.x, v.y, v.x, v.y};
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (i < pieces) { pk[i * 64] = v; pm[-i * 64] = v; }  // bins lane + 64 i < M / 2 and their mirrors M - lane - 64 i > M / 2
-            if (lane == 0) rp[M / 2] = v;
+                for (int i = 0; i < 8; ++i)
+                    if (i < pieces) p4[i * 64] = w;
+                if (lane == 0) rp[M] = v;
+            } else {
+                f2* pk = rp + lane;
+                f2* pm = rp + (M - lane);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (i < pieces) { pk[i * 64] = v; pm[-i * 64] = v; }  // bins lane + 64 i < M / 2 and their mirrors M - lane - 64 i > M / 2
+                if (lane == 0) rp[M / 2] = v;
+            }
             for (int c = 0; c < 8; ++c) cur[c] = nx[c];
         }
     } else {
@@ -80,12 +94,20 @@ template <int DIR> __global__ __launch_bounds__(64) void stream_probe_kernel(Pro
             for (int c = 0; c < 17; ++c) nx[c] = cur[c];
             if (row + 1 < a.rows_per_clip) {
                 const f2* rp = reinterpret_cast<const f2*>(a.in + (clip * a.rows_per_clip + row + 1) * row_bytes);
-                const f2* pk = rp + lane;
-                const f2* pm = rp + (M - lane);
+                if (P16) {
+                    const f4* p4 = reinterpret_cast<const f4*>(rp) + lane;
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    if (i < pieces) { nx[2 * i] = pk[i * 64]; nx[2 * i + 1] = pm[-i * 64]; }
-                nx[16] = rp[M / 2];
+                    for (int i = 0; i < 8; ++i)
+                        if (i < pieces) { const f4 w = p4[i * 64]; nx[2 * i] = f2{w.x, w.y}; nx[2 * i + 1] = f2{w.z, w.w}; }
+                    nx[16] = rp[M];
+                } else {
+                    const f2* pk = rp + lane;
+                    const f2* pm = rp + (M - lane);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (i < pieces) { nx[2 * i] = pk[i * 64]; nx[2 * i + 1] = pm[-i * 64]; }
+                    nx[16] = rp[M / 2];
+                }
             }
 #pragma unroll
             for (int c = 0; c < 17; ++c) { acc.x += cur[c].x; acc.y += cur[c].y; }

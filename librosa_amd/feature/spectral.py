@@ -142,7 +142,13 @@ def _apply_mel(S, mel_basis):
         mel_plan = ctx.mel_plan(np.ascontiguousarray(mel_basis, dtype=real))
         St = _arrays.swap_last_two(S)
         native = St.is_contiguous() if is_torch_tensor(S) else St.flags["C_CONTIGUOUS"]
-        if native and n_frames > 1:
+        padded = _spectrum._frame_major_strides(St, n_bins) if (is_torch_tensor(S) and not native and St.dtype == _arrays.torch_dtype(real)) else None
+        if padded is not None and n_frames > 1:
+            # the device layout with each frame's row padded to whole cache lines (what _spectrogram returns for device tensors): read in place
+            sess._keep.append(St)
+            s_ptr = St.data_ptr()
+            strides = (padded[0], 1, padded[1])
+        elif native and n_frames > 1:
             # a view of the device layout [b][t][f] (what our own _spectrogram returns)
             s_ptr = sess.input_raw(St, real)
             strides = (n_frames * n_bins, 1, n_bins)  # batch, bin, frame

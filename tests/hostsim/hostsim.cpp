@@ -187,6 +187,8 @@ int run_stft(int n_fft, int mode, const T* y, long long n, long long batch, int 
     s.a.y = y; s.a.y_stride = n; s.a.n = n; s.a.n_frames = n_frames; s.a.hop = hop; s.a.pad = center ? n_fft / 2 : 0; s.a.pad_mode = pad_mode;
     s.a.win = win; s.a.frames_per_wg = iters_per_wg;
     s.a.D = (cx<T>*)out; s.a.S = (T*)out; s.a.Mel = (T*)out;
+    // rows of the complex / power result: packed, or (LRA_SIM_ROW_PAD = extra elements per row; the test reads the padded buffer) padded
+    s.a.row_pitch = n_fft / 2 + 1 + (std::getenv("LRA_SIM_ROW_PAD") ? std::atoi(std::getenv("LRA_SIM_ROW_PAD")) : 0);
     s.a.power_mode = power_mode; s.a.power = (T)power;
     s.a.mel_c0 = mel_c0; s.a.mel_len = mel_len; s.a.mel_off = mel_off; s.a.mel_val = mel_val; s.a.n_mels = n_mels;
     s.mode = mode; s.blocks = batch; s.diag = diag; s.dense_basis = dense_basis;

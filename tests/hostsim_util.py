@@ -78,9 +78,10 @@ def mel_band(B):
     return c0, ln, off, np.ascontiguousarray(val)
 
 
-def stft(y, n_fft, hop, win, center=True, pad_mode="constant", mode=0, iters_per_wg=1, power=2.0, mel_basis=None, variant=0):
+def stft(y, n_fft, hop, win, center=True, pad_mode="constant", mode=0, iters_per_wg=1, power=2.0, mel_basis=None, variant=0, row_pad=0):
     """y: (batch, n) f32/f64.  mode 0 -> complex (batch, T, M+1); 1 -> power; 2 / 3 / 4 -> mel (batch, n_mels, T)
-    through the generic banded path / the two-slope path / its run-ordered form."""
+    through the generic banded path / the two-slope path / its run-ordered form.
+    row_pad (modes 0 / 1): rows `M + 1 + row_pad` elements apart (StftArgs::row_pitch); the whole padded buffer comes back, NaN where nothing was stored."""
     y = np.ascontiguousarray(y)
     assert y.ndim == 2
     f64 = y.dtype == np.float64
@@ -95,16 +96,21 @@ def stft(y, n_fft, hop, win, center=True, pad_mode="constant", mode=0, iters_per
     c0 = ln = off = val = dense = None
     n_mels = 0
     if mode == 0:
-        out = np.full((batch, n_frames, M + 1), np.nan, dtype=np.complex128 if f64 else np.complex64)
+        out = np.full((batch, n_frames, M + 1 + row_pad), np.nan, dtype=np.complex128 if f64 else np.complex64)
     elif mode == 1:
-        out = np.full((batch, n_frames, M + 1), np.nan, dtype=y.dtype)
+        out = np.full((batch, n_frames, M + 1 + row_pad), np.nan, dtype=y.dtype)
     else:
+        assert row_pad == 0
         dense = np.ascontiguousarray(mel_basis, dtype=y.dtype)
         c0, ln, off, val = mel_band(dense)
         n_mels = mel_basis.shape[0]
         out = np.full((batch, n_mels, n_frames), np.nan, dtype=y.dtype)
     diag = np.zeros(12, np.int64)
     fn = lib().hostsim_stft_f64 if f64 else lib().hostsim_stft_f32
+    if row_pad:
+        os.environ["LRA_SIM_ROW_PAD"] = str(int(row_pad))
+    else:
+        os.environ.pop("LRA_SIM_ROW_PAD", None)
     rc = fn(ctypes.c_int(n_fft), ctypes.c_int(mode), _p(y), ctypes.c_longlong(n), ctypes.c_longlong(batch), ctypes.c_int(n_frames),
             ctypes.c_int(hop), ctypes.c_int(int(center)), ctypes.c_int(PAD_MODES[pad_mode]), _p(win), ctypes.c_int(iters_per_wg), _p(out),
             ctypes.c_int(pm), ctypes.c_double(power), _p(c0), _p(ln), _p(off), _p(val), ctypes.c_int(n_mels), ctypes.c_int(variant), _p(dense), _p(diag))

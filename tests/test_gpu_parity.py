@@ -480,6 +480,61 @@ def test_torch_device_tensors(L):
         L.stft(bad, n_fft=1023, hop_length=512)  # general (rocFFT) path: explicit device scan
 
 
+@pytest.mark.parametrize("name", ["stft_n2048_h512_1s", "stft_n1024_blackmanharris", "stft_n4096_h512", "stft_stereo_n1024", "stft_f64_n2048", "stft_n512_reflect"])
+def test_padded_row_view_against_goldens(L, name):
+    """Round 5: a device-resident stft result has each frame's row on a 128-byte boundary behind the (..., n_bins, n_frames) view
+    (core/spectrum.py:356 allocates a strided view too).  Strides as documented, values = the reference's golden, bit-equal to the packed
+    form, nothing written into the padding, istft / _spectrogram / the other consumers take the view as it is."""
+    import torch
+
+    from librosa_amd.core import spectrum as SP
+
+    case = golden_cases.CASES[name]
+    g = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))
+    skw = dict(case["stft"])
+    n_fft = skw["n_fft"]
+    n_bins = 1 + n_fft // 2
+    y = g["y"]
+    yt = torch.from_numpy(np.ascontiguousarray(y)).cuda()
+    csize = 16 if y.dtype == np.float64 else 8
+    old = SP._arrays.POISON_OUTPUTS
+    SP._arrays.POISON_OUTPUTS = True  # results start as NaN bit patterns: whatever the kernels leave alone stays NaN
+    try:
+        D = L.stft(yt, **skw)
+        Dp = L.stft(yt, row_align=0, **skw)
+    finally:
+        SP._arrays.POISON_OUTPUTS = old
+    pitch = SP.row_pitch(n_bins, csize)
+    assert (pitch * csize) % 128 == 0 or pitch == n_bins
+    assert (pitch > n_bins) == (n_bins * csize >= 4096)
+    assert tuple(D.shape) == g["D"].shape == tuple(Dp.shape)
+    assert D.stride(-2) == 1 and D.stride(-1) == pitch and Dp.stride(-1) == n_bins
+    assert torch.equal(D, Dp)
+    assert _stft_close(D.cpu().numpy(), g["D"])
+    if pitch > n_bins:  # the padding behind the view is still the poison pattern
+        assert D.data_ptr() % 128 == 0
+        n_frames = D.shape[-1]
+        base = torch.as_strided(D, (D.numel() // (n_bins * n_frames), n_frames, pitch), (n_frames * pitch, pitch, 1))
+        assert bool(torch.isnan(torch.view_as_real(base[..., n_bins:])).all())
+        assert not bool(torch.isnan(torch.view_as_real(base[..., :n_bins])).any())
+    hop = skw.get("hop_length") or (skw.get("win_length") or n_fft) // 4
+    ikw = {k: v for k, v in skw.items() if k in ("hop_length", "win_length", "n_fft", "window", "center")}
+    ya, yb = L.istft(D, length=y.shape[-1], **ikw), L.istft(Dp, length=y.shape[-1], **ikw)
+    assert torch.equal(ya, yb)
+    assert torch.equal(L.istft(D.contiguous(), length=y.shape[-1], **ikw), ya)  # (a C-ordered copy goes through the transposing path)
+    assert np.abs(ya.cpu().numpy() - y).max() < (1e-10 if y.dtype == np.float64 else 5e-5)
+    S, _ = L._spectrogram(y=yt, power=2, **{**{k: v for k, v in skw.items() if k != "dtype"}, "hop_length": hop})
+    assert S.stride(-2) == 1 and S.stride(-1) == SP.row_pitch(n_bins, csize // 2)
+    P = np.abs(g["D"].astype(np.complex128)) ** 2
+    assert np.all(np.abs(S.cpu().numpy() - P) <= 1e-4 * P + 1e-5 * P.max())
+    mag, ph = L.magphase(D)
+    mag2, ph2 = L.magphase(Dp)
+    assert torch.equal(mag, mag2) and torch.equal(ph, ph2)
+    M1 = L.feature.melspectrogram(S=S, sr=22050, n_mels=40)
+    M2 = L.feature.melspectrogram(S=S.contiguous(), sr=22050, n_mels=40)
+    assert torch.allclose(M1, M2, rtol=1e-5, atol=0)
+
+
 def test_tuning_variants_agree(L):
     """The tuning variants of the n_fft=2048 kernels must agree with the oracle and each other."""
     import torch

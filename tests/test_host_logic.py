@@ -420,3 +420,26 @@ def test_resample_plans_and_filters():
         L.effects.pitch_shift(y, sr=22050, n_steps=1, bins_per_octave=-3)
     assert math.gcd(320, 441) == 1
 
+
+
+def test_row_pitch_and_frame_major_strides():
+    """Round 5: the padded row pitch of device-resident results and the stride test that lets `istft` / `melspectrogram(S=...)` read such a view in place."""
+    import torch
+
+    from librosa_amd.core import spectrum as SP
+
+    assert SP.row_pitch(1025, 8, 128) == 1040 and SP.row_pitch(1025, 4, 128) == 1056 and SP.row_pitch(1025, 16, 128) == 1032
+    assert SP.row_pitch(4097, 8, 128) == 4112 and SP.row_pitch(513, 8, 128) == 528
+    assert SP.row_pitch(257, 8, 128) == 257          # rows under 4 KiB stay packed (measured: no gain)
+    assert SP.row_pitch(1025, 8, 0) == 1025 and SP.row_pitch(1024, 8, 128) == 1024
+    buf = torch.zeros((6, 7, 1040), dtype=torch.complex64)
+    view = buf[..., :1025]
+    assert SP._frame_major_strides(view, 1025) == (7 * 1040, 1040)
+    assert SP._frame_major_strides(view.view(2, 3, 7, 1040)[..., :1025] if False else buf.view(2, 3, 7, 1040)[..., :1025], 1025) == (7 * 1040, 1040)
+    assert SP._frame_major_strides(buf[::2, :, :1025], 1025) == (2 * 7 * 1040, 1040)   # clips further apart: still one batch stride
+    assert SP._frame_major_strides(buf.view(2, 3, 7, 1040)[:, ::2, :, :1025], 1025) is None   # leading axes that do not collapse
+    assert SP._frame_major_strides(torch.zeros((3, 7, 1025), dtype=torch.complex64), 1025) == (7 * 1025, 1025)
+    assert SP._frame_major_strides(torch.zeros((3, 1025, 7), dtype=torch.complex64).transpose(-1, -2).transpose(-1, -2), 7) == (1025 * 7, 7)
+    assert SP._frame_major_strides(torch.zeros((3, 1025, 7), dtype=torch.complex64).transpose(-1, -2), 1025) is None  # bin axis not contiguous
+    assert SP._frame_major_strides(buf[:, :, ::2][..., :300], 300) is None
+    assert SP._frame_major_strides(buf[0, :, :1025], 1025) == (7 * 1040, 1040)   # no leading axis

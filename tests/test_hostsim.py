@@ -123,6 +123,25 @@ def test_stft_body_second_generation(n_fft, hop, center, pad_mode, iters, n, pow
         assert np.abs(out - S).max() <= 4e-6 * S.max()
 
 
+@pytest.mark.parametrize("n_fft,hop,row_pad,mode,dtype", [(2048, 512, 15, 0, np.float32), (2048, 512, 31, 1, np.float32), (1024, 256, 15, 0, np.float32), (8192, 512, 15, 0, np.float32),
+                                                      (512, 512, 15, 0, np.float32), (256, 64, 7, 1, np.float32), (2048, 512, 7, 0, np.float64), (4096, 1024, 15, 0, np.float32)])
+def test_stft_body_padded_rows(n_fft, hop, row_pad, mode, dtype):
+    """StftArgs::row_pitch (round 5): rows of the complex / power result `M + 1 + row_pad` elements apart -- every kernel family (second generation,
+    first generation with the LDS ring, direct framing, the register ring of the large frames) stores the same values as with packed rows
+    and writes nothing into the padding."""
+    rng = np.random.default_rng(n_fft + hop + row_pad)
+    y = rng.standard_normal((2, 3 * n_fft + 777)).astype(dtype)
+    win = O.get_window("hann", n_fft)
+    packed, d0 = H.stft(y, n_fft, hop, win, iters_per_wg=3, mode=mode)
+    padded, d1 = H.stft(y, n_fft, hop, win, iters_per_wg=3, mode=mode, row_pad=row_pad)
+    _check_diag(d0)
+    _check_diag(d1)
+    bins = n_fft // 2 + 1
+    assert padded.shape == packed.shape[:-1] + (bins + row_pad,)
+    assert np.array_equal(padded[..., :bins], packed) and not np.isnan(packed).any()
+    assert np.isnan(padded[..., bins:]).all()
+
+
 @pytest.mark.parametrize("n_fft,hop,power,n_mels,dtype,variant", [(2048, 512, 2.0, 128, np.float32, 0), (2048, 512, 2.0, 128, np.float32, 1), (2048, 512, 2.0, 128, np.float32, 4), (1024, 256, 1.0, 40, np.float32, 0),
                                                           (512, 128, 1.5, 20, np.float32, 0), (2048, 512, 2.0, 64, np.float64, 0)])
 def test_power_and_mel_body(n_fft, hop, power, n_mels, dtype, variant):
