@@ -259,12 +259,15 @@ def _device_norm(sess, wss, wss_key, real):
     return sess.input_raw(_as_like(sess, wss_to_norm(wss)), real)
 
 
-# Rows of the device-resident complex / power result are padded to whole 128-byte cache lines (LRA_ROW_ALIGN bytes; 0 = packed): every wave-wide
-# store of the kernels then covers whole lines instead of straddling five (profiles/r05_pitch.md: the 2048 / 512 transform 0.747 -> 0.658 ms
-# on the same box).  What the caller sees is unchanged in shape, dtype and values: ``(..., n_bins, n_frames)`` with the bin axis fastest -- the
-# reference's own result is such a strided view (order="F", core/spectrum.py:356) -- only ``stride(-1)`` is ``row_pitch`` instead of ``n_bins``.
-ROW_ALIGN_BYTES = int(os.environ.get("LRA_ROW_ALIGN", "128") or 0)
-_ROW_ALIGN_MIN_ROW_BYTES = 4096   # measured: rows of 2 056 B (n_fft = 512) gain nothing or lose, 4 104 B (n_fft = 1024) and longer gain 7-17 %
+# Optional (LRA_ROW_ALIGN bytes, default 0 = packed; per call: stft(..., row_align=128)): the rows of a device-resident complex / power result padded
+# to whole 128-byte cache lines behind the (..., n_bins, n_frames) view -- the reference's own result is such a strided view (order="F",
+# core/spectrum.py:356), only stride(-1) becomes row_pitch instead of n_bins.  VERDICT r04 proposed it as the way to a faster store stream; measured
+# in round 5 it is NOT one: on the same allocation the padded layout is 1-6 % SLOWER than packed rows (0.661 vs 0.647, 0.777 vs 0.745 ms for the
+# 2048 / 512 transform), and what first looked like a 13 % gain was the placement of the output allocation, which moves the same kernel between
+# 0.633 and 0.745 ms inside one process (profiles/r05_pitch.md).  Kept as an option (istft, melspectrogram(S=...) and the frame-major consumers
+# take such views in place); off by default.
+ROW_ALIGN_BYTES = int(os.environ.get("LRA_ROW_ALIGN", "0") or 0)
+_ROW_ALIGN_MIN_ROW_BYTES = 4096   # rows shorter than this are never padded
 
 
 def row_pitch(n_bins, itemsize, align=None):
@@ -439,9 +442,10 @@ def stft(y, *, n_fft=2048, hop_length=None, win_length=None, window="hann", cent
     ``out`` (numpy only): a pre-allocated complex array with matching leading shape and at least
     ``n_frames`` columns; the same object (or ``out[..., :n_frames]``) is returned (``:355-367``).
 
-    Device tensors (extension): each frame's row of the result starts on a 128-byte boundary (``row_align`` bytes, default
-    ``LRA_ROW_ALIGN`` = 128; 0 = packed rows) -- ``stride(-1)`` of the returned view is then ``row_pitch(n_bins, itemsize)`` rather
-    than ``n_bins``; shape, dtype and values are the same, ``.contiguous()`` compacts, and ``istft`` reads the view in place.
+    Device tensors (extension): ``row_align=128`` (default ``LRA_ROW_ALIGN`` = 0: packed rows) starts each frame's row of the result on a
+    128-byte boundary -- ``stride(-1)`` of the returned view is then ``row_pitch(n_bins, itemsize, 128)`` rather than ``n_bins``; shape, dtype
+    and values are the same, ``.contiguous()`` compacts, and ``istft`` reads the view in place.  Measured in round 5: no faster than packed rows
+    (``profiles/r05_pitch.md``), hence off by default.
     """
     if out is not None and is_torch_tensor(y):
         raise ParameterError("out= is only supported for numpy inputs")

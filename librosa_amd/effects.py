@@ -40,7 +40,7 @@ def time_stretch(y, *, rate, **kwargs):
                 raise ParameterError("Audio buffer is not finite everywhere")
             yd = torch.from_numpy(np.ascontiguousarray(y)).to(f"cuda:{_arrays._native.get_context().device}")
     staged = is_torch_tensor(yd) and not on_device
-    D = spectrum.stft(yd, check_finite=not staged, **({"row_align": 0} if is_torch_tensor(yd) else {}), **kwargs)  # (packed rows: the vocoder walks the buffer as it is)
+    D = spectrum.stft(yd, check_finite=not staged, row_align=0, **kwargs)  # (packed rows: the vocoder walks the buffer as it is)
     Ds = spectrum.phase_vocoder(D, rate=rate, hop_length=kwargs.get("hop_length"), n_fft=kwargs.get("n_fft"))
     len_stretch = round(y.shape[-1] / rate)
     ikw = dict(kwargs)
@@ -95,7 +95,7 @@ def _hpss_parts(y, which, kernel_size, power, mask, margin, n_fft, hop_length, w
     # would analyse with one window and synthesise with another, which matches neither the reference nor a consistent pair).
     del window
     D = spectrum.stft(yd, n_fft=n_fft, hop_length=hop_length, win_length=win_length, center=center, pad_mode=pad_mode, check_finite=not staged,
-                      **({"row_align": 0} if is_torch_tensor(yd) else {}))  # (packed rows: the separation kernel walks the buffer as it is)
+                      row_align=0)  # (packed rows: the separation kernel walks the buffer as it is)
     parts = decompose.hpss(D, kernel_size=kernel_size, power=power, mask=mask, margin=margin)
     ikw = dict(dtype=_arrays.numpy_dtype_of(y), n_fft=n_fft, hop_length=hop_length, win_length=win_length, center=center, length=y.shape[-1])
     if mask:  # the reference then inverts the (real-valued) masks themselves; irfft takes them as spectra with zero phase

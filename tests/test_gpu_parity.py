@@ -481,10 +481,11 @@ def test_torch_device_tensors(L):
 
 
 @pytest.mark.parametrize("name", ["stft_n2048_h512_1s", "stft_n1024_blackmanharris", "stft_n4096_h512", "stft_stereo_n1024", "stft_f64_n2048", "stft_n512_reflect"])
-def test_padded_row_view_against_goldens(L, name):
-    """Round 5: a device-resident stft result has each frame's row on a 128-byte boundary behind the (..., n_bins, n_frames) view
-    (core/spectrum.py:356 allocates a strided view too).  Strides as documented, values = the reference's golden, bit-equal to the packed
-    form, nothing written into the padding, istft / _spectrogram / the other consumers take the view as it is."""
+def test_padded_row_view_against_goldens(L, name, monkeypatch):
+    """Round 5 (optional layout, LRA_ROW_ALIGN / row_align=128): a device-resident stft result with each frame's row on a 128-byte boundary
+    behind the (..., n_bins, n_frames) view (core/spectrum.py:356 allocates a strided view too).  Strides as documented, values = the
+    reference's golden, bit-equal to the packed form, nothing written into the padding, istft / _spectrogram / the other consumers take
+    the view as it is."""
     import torch
 
     from librosa_amd.core import spectrum as SP
@@ -497,13 +498,12 @@ def test_padded_row_view_against_goldens(L, name):
     y = g["y"]
     yt = torch.from_numpy(np.ascontiguousarray(y)).cuda()
     csize = 16 if y.dtype == np.float64 else 8
-    old = SP._arrays.POISON_OUTPUTS
-    SP._arrays.POISON_OUTPUTS = True  # results start as NaN bit patterns: whatever the kernels leave alone stays NaN
-    try:
-        D = L.stft(yt, **skw)
-        Dp = L.stft(yt, row_align=0, **skw)
-    finally:
-        SP._arrays.POISON_OUTPUTS = old
+    assert L.stft(yt, **skw).stride(-1) == (n_bins if SP.ROW_ALIGN_BYTES == 0 else SP.row_pitch(n_bins, csize))  # the default: packed rows
+    monkeypatch.setattr(SP, "ROW_ALIGN_BYTES", 128)        # the module-wide switch (env LRA_ROW_ALIGN); row_align= overrides it per call
+    monkeypatch.setattr(SP._arrays, "POISON_OUTPUTS", True)  # results start as NaN bit patterns: whatever the kernels leave alone stays NaN
+    D = L.stft(yt, **skw)
+    Dp = L.stft(yt, row_align=0, **skw)
+    monkeypatch.setattr(SP._arrays, "POISON_OUTPUTS", False)
     pitch = SP.row_pitch(n_bins, csize)
     assert (pitch * csize) % 128 == 0 or pitch == n_bins
     assert (pitch > n_bins) == (n_bins * csize >= 4096)
