@@ -257,6 +257,70 @@ def dry_run(args, torch, world, rank):
         dist.destroy_process_group()
 
 
+def compact_line(line):
+    """The stdout line: the contract's keys, `roofline` with the path's other fractions folded in (`roofline.path`), `cpu_baseline`, and one number per side
+    measurement -- prose and per-repeat lists stay in the full record (stderr / --detail; the keys are described in this file's docstring and DESIGN.md 6)."""
+    def get(d, *keys, default=None):
+        for k in keys:
+            if not isinstance(d, dict) or k not in d:
+                return default
+            d = d[k]
+        return d
+
+    def r(x, nd=4):
+        return round(x, nd) if isinstance(x, float) else x
+
+    out = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if k in line}
+    cfg = line.get("config", {})
+    out["config"] = {"workload": f"feature.melspectrogram, {cfg.get('clips_per_gpu')} clips x {CLIP_SECONDS} s per GPU @ 22.05 kHz, n_fft={N_FFT} hop={HOP} n_mels={N_MELS}, "
+                                 f"{'BASELINE configs[1]' if line.get('n_gpus') == 1 else 'BASELINE configs[2] split, clip i on GPU i // ' + str(cfg.get('clips_per_gpu'))}, inputs resident in HBM",
+                     "clips_per_gpu": cfg.get("clips_per_gpu"), "frames_per_step_per_gpu": cfg.get("frames_per_step_per_gpu"), "prewarm_ms": cfg.get("prewarm_ms"),
+                     "parallelism": f"clips sharded over {line.get('n_gpus')} GPU(s), no data-path collective", "device": cfg.get("device")}
+    rf = line.get("roofline", {})
+    roof = {k: r(rf.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_box", "bytes_per_frame", "launch_ms") if k in rf}
+    roof["valu_frac"] = r(get(line, "roofline_valu", "frac"))
+    path = {"stft_frac": get(line, "roofline_stft", "frac"), "stft_ms": get(line, "roofline_stft", "launch_ms"), "istft_frac": get(line, "roofline_istft", "frac"),
+            "istft_ms": get(line, "roofline_istft", "launch_ms"), "stream_forward_frac": get(line, "stream_ceiling", "forward", "frac"),
+            "stream_inverse_frac": get(line, "stream_ceiling", "inverse", "frac"), "cqt_lite_frac": get(line, "cqt_lite", "frac_of_hbm"), "cqt_lite_ms": get(line, "cqt_lite", "ms_total"),
+            "stft_frac_best_placement": get(line, "placement", "stft_frac_best"), "stft_frac_worst_placement": get(line, "placement", "stft_frac_worst"),
+            "istft_frac_best_placement": get(line, "placement", "istft_frac_best"), "placements": get(line, "placement", "allocations"),
+            "stft_traffic": get(line, "roofline_stft", "traffic"), "istft_traffic": get(line, "roofline_istft", "traffic")}
+    roof["path"] = {k: r(v) for k, v in path.items() if v is not None}
+    out["roofline"] = roof
+    cb = line.get("cpu_baseline")
+    if isinstance(cb, dict):
+        out["cpu_baseline"] = {k: r(cb.get(k), 1) for k in ("value", "unit", "cores", "kind") if k in cb}
+        out["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
+        if get(line, "cpu_baseline_all_cores", "value") is not None:
+            out["cpu_baseline"]["all_cores_value"] = r(get(line, "cpu_baseline_all_cores", "value"), 1)
+            out["cpu_baseline"]["all_cores"] = get(line, "cpu_baseline_all_cores", "cores")
+        out["cpu_baseline"]["cpu_model"] = get(cb, "host", "cpu_model") or get(line, "cpu_baseline", "cpu_model")
+    par = line.get("parity")
+    if isinstance(par, dict):
+        out["parity"] = {k: par[k] for k in ("mel_max_rel_err_vs_reference", "mel_max_rel_err", "oracle_equals_reference", "bar") if k in par}
+        out["parity"]["round_trip_snr_db_min"] = r(get(line, "roofline_istft", "round_trip_snr_db_min"), 1)
+    if "scaling_base" in line:
+        out["scaling_base"] = {k: r(v) for k, v in line["scaling_base"].items()} if isinstance(line["scaling_base"], dict) else line["scaling_base"]
+    if "gathered" in line and isinstance(line["gathered"], dict):
+        out["gathered"] = {k: r(line["gathered"].get(k)) for k in ("value", "unit", "ms_per_step", "chunks", "bytes_per_rank", "backend", "own_rows_match", "full_matches_unsharded", "error") if k in line["gathered"]}
+    out["repeats"] = {"ms_per_step_min": r(get(line, "repeats", "ms_per_step_min")), "ms_per_step_median": r(get(line, "repeats", "ms_per_step_median"))}
+    side = {"dropin_torch_ms": get(line, "dropin_torch", "ms_per_call"), "numpy_mel_ms_64clips": get(line, "end_to_end_numpy", "melspectrogram", "ms"),
+            "numpy_stft_ms_64clips": get(line, "end_to_end_numpy", "stft", "ms"), "power_to_db_ms": get(line, "power_to_db", "ms_per_call"), "mfcc_ms": get(line, "mfcc", "ms_per_call"),
+            "griffinlim_ms_per_iter_32clips": get(line, "griffinlim", "ms_per_iteration"), "griffinlim_ms_setup": get(line, "griffinlim", "ms_setup"),
+            "cqt_polyphase_ms_64clips": get(line, "pcen_cqt", "cqt_polyphase", "ms_per_call"), "cqt_default_ms_64clips": get(line, "pcen_cqt", "cqt_default", "ms_per_call"),
+            "pcen_ms": get(line, "pcen_cqt", "pcen", "ms_per_call"), "hpss_ms_32clips": get(line, "hpss", "ms_per_call"), "mixed_400_mel_ms": get(line, "mixed_radix_400", "fused", "mel_ms"),
+            "mixed_400_stft_ms": get(line, "mixed_radix_400", "fused", "stft_ms"), "cqt_lite_512_ms": get(line, "cqt_lite", "per_n_fft", "512", "ms"),
+            "cqt_lite_8192_ms": get(line, "cqt_lite", "per_n_fft", "8192", "ms"), "cqt_lite_default_hop_ms": get(line, "cqt_lite", "default_hop_variant", "ms_total"),
+            "stft_power_w": get(line, "board_power", "stft", "socket_power_w"), "stft_sclk_mhz": get(line, "board_power", "stft", "sclk_mhz"),
+            "mel_power_w": get(line, "board_power", "mel", "socket_power_w"), "mel_variant": get(line, "kernel_variants", "melspectrogram")}
+    out["side"] = {k: r(v) for k, v in side.items() if v is not None}
+    errs = [k for k, v in line.items() if isinstance(v, dict) and "error" in v]
+    if errs:
+        out["side_errors"] = errs
+    out["detail"] = "full record: stderr of this run (and --detail / gpurun_out/bench_detail.json); keys: bench.py docstring, DESIGN.md 6"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -268,6 +332,8 @@ def main():
     ap.add_argument("--no-cqt", action="store_true", help="skip the CQT-lite (config 5) side measurement")
     ap.add_argument("--no-side", action="store_true", help="skip every side measurement (profiling runs)")
     ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power / clock samples (profiling runs: they loop the kernels for seconds)")
+    ap.add_argument("--placements", type=int, default=5, help="allocations of the 2.7 GB spectrum the complex STFT / ISTFT side figures are sampled over (median reported, best / worst beside it)")
+    ap.add_argument("--detail", default=None, help="file the full (long) measurement record goes to; default gpurun_out/bench_detail.json when that directory exists; it always goes to stderr too")
     ap.add_argument("--gather-chunks", type=int, default=4, help="pieces the shard travels in during the `gathered` measurement (N>1)")
     ap.add_argument("--dry-run", action="store_true", help="control-flow check without a GPU (tests/test_distributed_cpu.py): launch, rendezvous, barriers, max over ranks and "
                                                             "the JSON line with the step replaced by a 1 ms host sleep; `value` is null and `data` says so")
@@ -400,17 +466,32 @@ def main():
         g_wall = float(tw.item())
         full = step_gathered()
         ok = bool(torch.equal(full[rank * batch : (rank + 1) * batch], M))
+        # ... and the rows that came from elsewhere: every rank recomputes its neighbour's shard from that shard's own (seeded) input -- the
+        # gathered tensor must equal the unsharded call clip for clip (the reference's batch == per item property, tests/test_multichannel.py:96-111)
+        other = (rank + 1) % world
+        y_o = make_batch(torch, batch, n, other * batch, device)
+        M_o = torch.empty_like(M)
+        ctx.melspectrogram_exec(plan, mel_plan, y_o.data_ptr(), batch, n, n, 2.0, M_o.data_ptr())
+        ok_other = bool(torch.equal(full[other * batch : (other + 1) * batch], M_o))
+        del y_o, M_o
+        tf = torch.tensor([int(ok), int(ok_other)], dtype=torch.int32, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(tf, op=dist.ReduceOp.MIN)
+        ok, ok_other = bool(tf[0].item()), bool(tf[1].item())
         side["gathered"] = {"value": frames_per_step * world * g_steps / g_wall, "unit": "frames/s", "ms_per_step": g_wall / g_steps * 1e3, "steps": g_steps, "chunks": len(pieces),
-                            "bytes_per_rank": batch * N_MELS * n_frames * 4, "backend": backend, "own_rows_match": ok,
+                            "bytes_per_rank": batch * N_MELS * n_frames * 4, "backend": backend, "own_rows_match": ok, "full_matches_unsharded": ok_other,
                             "what": "every rank holds the full (N x clips, 128, frames) mel tensor; the shard is computed and all-gathered in chunks of clips (librosa_amd.distributed.ShardedGather)"}
         del full
 
     # ---- single-GPU side measurements (their timing helpers contain no collectives) -------------------------------------------
     snr_db = None
     if world == 1 and not args.no_side:
-        D = torch.empty((batch, n_frames, N_FFT // 2 + 1), dtype=torch.complex64, device=device)
-        Dp = D.data_ptr()
+        # The complex spectrum is 2.7 GB, and WHERE that allocation lands moves the store-bound transform between 0.63 and 0.75 ms inside one process
+        # (profiles/r05_pitch.md): one allocation is a draw.  Several are made, the transform is timed on each, and everything below runs on the
+        # MEDIAN one; best / worst are reported beside it (`placement`).
         n_bins = N_FFT // 2 + 1
+        D_cands = [torch.empty((batch, n_frames, n_bins), dtype=torch.complex64, device=device) for _ in range(max(1, args.placements))]
+        D = D_cands[0]
+        Dp = D.data_ptr()
         iplan = ctx.istft_plan(N_FFT, HOP, window, True, np.float32)
         wss_host = filters.window_sumsquare(window="hann", n_frames=n_frames, n_fft=N_FFT, hop_length=HOP, dtype=np.float32)[N_FFT // 2 :]
         wss_host = np.ascontiguousarray(np.pad(wss_host, (0, max(0, n - len(wss_host))))[:n], dtype=np.float32)
@@ -430,6 +511,28 @@ def main():
                     "write_frac": frames_per_step * (bytes_per_frame - read_bytes) / s / 1e9 / HBM_PEAK_GBS,
                     "call_ms": s * 1e3, "launches_per_call": 1}
 
+        placement = None
+        if len(D_cands) > 1:
+            try:
+                ms_f, ms_i = [], []
+                for Dc in D_cands:
+                    p = Dc.data_ptr()
+                    _, e = timed(lambda: ctx.stft_exec(plan, yp, batch, n, n, p), 10, 3, collective=False, ramp_ms=args.prewarm_ms / 4)
+                    ms_f.append(e / 10 * 1e3)
+                    _, e = timed(lambda: ctx.istft_exec_norm(iplan, p, batch, n_frames * n_bins, n_bins, n_frames, wss.data_ptr(), yrec.data_ptr(), n, n), 10, 3, collective=False)
+                    ms_i.append(e / 10 * 1e3)
+                order = sorted(range(len(D_cands)), key=lambda i: ms_f[i])
+                pick = order[len(order) // 2]
+                D = D_cands[pick]
+                Dp = D.data_ptr()
+                to_frac = lambda ms: frames_per_step * BYTES_PER_FRAME_STFT / (ms / 1e3) / 1e9 / HBM_PEAK_GBS
+                placement = {"allocations": len(D_cands), "picked": "median by stft time", "stft_ms": ms_f, "istft_ms": ms_i, "stft_frac_best": to_frac(min(ms_f)), "stft_frac_worst": to_frac(max(ms_f)),
+                             "istft_frac_best": to_frac(min(ms_i)), "istft_frac_worst": to_frac(max(ms_i))}
+            except Exception as exc:  # pragma: no cover
+                placement = {"error": repr(exc)}
+        D_cands = [D]  # (the others go back to the allocator)
+        if placement is not None:
+            side["placement"] = placement
         step_stft = lambda: ctx.stft_exec(plan, yp, batch, n, n, Dp)
         step_istft = lambda: ctx.istft_exec_norm(iplan, Dp, batch, n_frames * n_bins, n_bins, n_frames, wss.data_ptr(), yrec.data_ptr(), n, n)
         measure("roofline_stft", lambda: roof(step_stft, BYTES_PER_FRAME_STFT, "stft2_kernel<n_fft=2048, OUT_COMPLEX> (librosa.stft, complex64 out)", HOP * 4))
@@ -516,6 +619,19 @@ def main():
                     "what": "librosa_amd.feature.melspectrogram(y=<device tensor>): argument validation, plan-cache lookup, per-context lock, output allocation + the kernel"}
 
         measure("dropin_torch", public_torch)
+
+        def scaling_base():
+            """The N = 1 figure at the per-GPU work of the N > 1 runs (512 clips = BASELINE configs[2]'s split), so that a 1 -> 8 curve compares equal per-GPU work."""
+            b2 = 512
+            y2 = make_batch(torch, b2, n, 0, device)
+            M2 = torch.empty((b2, N_MELS, n_frames), dtype=torch.float32, device=device)
+            fn = lambda: ctx.melspectrogram_exec(plan, mel_plan, y2.data_ptr(), b2, n, n, 2.0, M2.data_ptr())
+            _, e = timed(fn, args.steps, args.warmup, collective=False, ramp_ms=args.prewarm_ms / 2)
+            per = e / args.steps
+            return {"clips_per_gpu": b2, "value": b2 * n_frames / per, "unit": "frames/s", "ms_per_step": per * 1e3}
+
+        if batch != 512:
+            measure("scaling_base", scaling_base)
 
         def public_numpy():
             nb = 64  # a quarter of the batch: 169 MB up, 42 MB down
@@ -725,7 +841,7 @@ def main():
                                    f"(`gathered`: all-gathered)", "frames_per_step_per_gpu": frames_per_step, "clips_per_gpu": batch, "prewarm_ms": args.prewarm_ms,
                        "parallelism": f"clips sharded over {world} GPU(s), one process per GPU, no collective on the data path", "device": ctx.device_name(),
                        "self_launched": bool(os.environ.get("LRA_BENCH_SELF_LAUNCHED"))},
-            "roofline": {"bound": "hbm", "kernel": "stft2_kernel<n_fft=2048, OUT_MELR> (fused melspectrogram)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "valu/lds", "kernel": "stft2_kernel<n_fft=2048, OUT_MELR> (fused melspectrogram)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_frame": BYTES_PER_FRAME_MEL,
                          "launch_ms": launch_s * 1e3, "frames_per_s_single_gpu": frames_per_step / launch_s,
                          "limited_by": "valu/lds issue, not HBM: the declared bound of this kernel is roofline_valu (f32 vector peak); the HBM figure is kept because BASELINE's metric asks for it",
@@ -775,7 +891,17 @@ def main():
                 line["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
             except Exception as exc:  # the single-core object above is the contract; this one is informative
                 line["cpu_baseline_all_cores"] = {"error": repr(exc)}
-        print(json.dumps(line), flush=True)
+        # ONE short line on stdout (the driver's record keeps it whole); the full record goes to stderr and, where it can, to a file
+        full = json.dumps(line)
+        print(full, file=sys.stderr, flush=True)
+        detail = args.detail or (os.path.join(ROOT, "gpurun_out", "bench_detail.json") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else None)
+        if detail:
+            try:
+                with open(detail, "w") as fh:
+                    fh.write(full + "\n")
+            except OSError:
+                pass
+        print(json.dumps(compact_line(line)), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -73,7 +73,8 @@ int lra_ctx_use_own_stream(lra_ctx* ctx);
  * everything enqueued on the main stream so far; LRA_SIDE_BACK: back to the main stream, which does NOT wait for the side stream;
  * LRA_SIDE_JOIN (from the main stream): the main stream waits for everything enqueued on the side stream.  Buffers used on the side
  * stream must stay alive until a join; LRA_SIDE_END = back (if forked) + join, for error paths.  The two directions use separate
- * events (re-recording one event that the other stream still waits on let that wait slip on ROCm 7.0: a use-after-free in the
+ * events, and every fork its own event out of a ring whose slots are reused only once the side stream is past its wait on them
+ * (re-recording one event that the other stream still waits on let that wait slip on ROCm 7.0: a use-after-free in the
  * caller's buffers).  lra_ctx_set_stream / lra_ctx_use_own_stream forget any fork. */
 #define LRA_SIDE_FORK 1
 #define LRA_SIDE_BACK 2

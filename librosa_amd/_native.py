@@ -545,16 +545,17 @@ class Comm:
 
 def host_devices():
     """Devices the NumPy drop-in spreads the clips of one call over, inside ONE process (a thread, a context and a host pipeline per
-    device; ctypes releases the GIL during native calls).  ``LRA_DEVICES`` = comma-separated device indices, or ``all`` (default: every
-    visible device); ``LRA_DEVICES=0`` keeps everything on one device.  Under a one-process-per-GPU launcher (``LOCAL_RANK`` /
-    ``WORLD_SIZE`` / ``LIBROSA_AMD_DEVICE`` set) the process owns exactly its own device unless ``LRA_DEVICES`` says otherwise."""
+    device; ctypes releases the GIL during native calls).  Opt-in (a plain NumPy call must not wake contexts on every GPU of
+    the node, least of all under a one-process-per-GPU launcher that this library does not know -- SLURM, MPI, a multiprocessing pool):
+    by default a call stays on the process's own device (``get_context()``: ``LIBROSA_AMD_DEVICE`` / ``LOCAL_RANK``, else 0);
+    ``LRA_DEVICES=all`` = every visible device, ``LRA_DEVICES=0,2`` = those."""
     n = device_count()
     if n <= 0:
         return [0]
     spec = os.environ.get("LRA_DEVICES", "").strip().lower()
-    if spec in ("", "all"):
-        if "LOCAL_RANK" in os.environ or "LIBROSA_AMD_DEVICE" in os.environ or int(os.environ.get("WORLD_SIZE", "1") or 1) > 1:
-            return [get_context().device]
+    if spec == "":
+        return [get_context().device]
+    if spec == "all":
         return list(range(n))
     try:
         devs = [int(t) for t in spec.split(",") if t.strip()]

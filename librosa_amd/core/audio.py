@@ -37,6 +37,13 @@ __all__ = ["stream", "resample"]
 _FIR_LIKE = ("kaiser_best", "kaiser_fast", "sinc_best", "sinc_medium", "sinc_fastest")   # (not "linear" / "zero_order_hold": those are not band-limited)
 
 
+def _check_fir_res_type(res_type):
+    """Names served by the FIR / band-limited converters; anything else is an error (cheap: no filter is designed)."""
+    if not isinstance(res_type, str) or not (res_type == "polyphase" or res_type.startswith("soxr") or res_type in _FIR_LIKE):
+        raise ParameterError(f"res_type={res_type!r} is not provided by librosa_amd: use 'fft' / 'scipy' / 'polyphase' (scipy's converters, reproduced) or a "
+                             "band-limited resampler name (soxr_*, kaiser_*, sinc_*: the library's own polyphase design)")
+
+
 @functools.lru_cache(maxsize=64)
 def _rational_filter(up, down, res_type, real):
     """(taps incl. leading zeros, first output's offset) of the FIR behind a resampling by ``up / down`` (coprime; cached: treat the
@@ -45,9 +52,7 @@ def _rational_filter(up, down, res_type, real):
     ``"polyphase"``: ``scipy.signal.resample_poly(x, up, down)``'s own design and alignment (its default Kaiser-5 window, 10
     ``max(up, down)`` taps each side, scaled by ``up``, the zero prefix that centres the output grid).  Anything else: a Kaiser
     design with soxr-HQ's band edges."""
-    if not isinstance(res_type, str) or not (res_type == "polyphase" or res_type.startswith("soxr") or res_type in _FIR_LIKE):
-        raise ParameterError(f"res_type={res_type!r} is not provided by librosa_amd: use 'fft' / 'scipy' / 'polyphase' (scipy's converters, reproduced) or a "
-                             "band-limited resampler name (soxr_*, kaiser_*, sinc_*: the library's own polyphase design)")
+    _check_fir_res_type(res_type)
     rate = max(up, down)
     if res_type == "polyphase":
         half = 10 * rate
@@ -126,7 +131,9 @@ def resample(y, *, orig_sr, target_sr, res_type="soxr_hq", fix=True, scale=False
         # the library's own design: a plain decimation runs the staged FIR decimators; any other ratio would need ~20 max(up, down) / up
         # x 12 products per output (258 at 22 050 -> 16 000 Hz) and runs in the Fourier domain instead (same band edges, see _band_plan)
         banded = res_type != "polyphase" and up != 1
-        taps, first = _rational_filter(1 if banded else up, down, res_type, real)   # (validates res_type)
+        _check_fir_res_type(res_type)
+        if not banded:  # (the Fourier form designs no FIR: a filter for e.g. 22 050 -> 22 051 Hz would have millions of taps -- ADVICE r04)
+            taps, first = _rational_filter(up, down, res_type, real)
         n_out = -(-n_in * up // down)
     else:
         n_out = n_samples
@@ -151,6 +158,8 @@ def resample(y, *, orig_sr, target_sr, res_type="soxr_hq", fix=True, scale=False
     res = res.reshape(lead + (n_out,))
     if fix and n_out != n_samples:
         if on_device:
+            if kwargs:  # (np.pad's keywords have no counterpart here; the reference passes them to util.fix_length, core/audio.py:1170)
+                raise ParameterError(f"fix_length keyword arguments {sorted(kwargs)} are only supported for numpy inputs")
             torch = _arrays._torch()
             res = res[..., :n_samples] if n_out > n_samples else torch.nn.functional.pad(res, (0, n_samples - n_out))
         else:

@@ -355,6 +355,11 @@ def _run_stft_family(kind, y, *, n_fft, hop_length, win_length, window, center, 
             # NumPy in, NumPy out: the native host pipeline (chunked, overlapped staging; include/librosa_amd.h)
             a = np.ascontiguousarray(y, dtype=real).reshape(-1, n)
             batch = a.shape[0]
+            if batch == 0:  # no clips (y.shape == (0, n)): the reference returns an empty array of the result's shape and dtype
+                if kind == "mel":
+                    return np.empty(lead + (int(mel_basis.shape[0]), n_frames), dtype=real)
+                empty = np.empty(lead + (n_bins, n_frames), dtype=out_dtype if kind == "stft" else real)
+                return out[..., :n_frames] if out is not None else empty
             target, stride = None, 0
             if kind == "stft":
                 cdt = np.dtype(util.dtype_r2c(real))

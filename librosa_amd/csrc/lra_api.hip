@@ -89,7 +89,15 @@ struct lra_ctx {
     struct HostPipe* pipe = nullptr;  // staging of the host-buffer entry points (lra_stft_exec_host), created on first use
     hipStream_t side_stream = nullptr;  // lra_ctx_side: a second stream for work that may overlap the main chain (created on first fork)
     hipStream_t side_main = nullptr;    // the stream to return to
-    hipEvent_t side_event = nullptr, join_event = nullptr;  // fork: recorded on the main stream; join: recorded on the side stream
+    // fork: an event recorded on the main stream, waited for by the side stream; join: recorded on the side stream, waited for by the main one.
+    // Every fork takes the NEXT event of a ring (a constant-Q call forks once per octave): an event is never re-recorded while the side stream may
+    // still hold an unconsumed wait on its previous record -- `side_passed[i]`, recorded on the side stream right behind that wait, is synchronised
+    // before slot i is used again (it has normally completed long before).  ADVICE r04: one re-recorded event let such a wait slip on ROCm 7.0.
+    static constexpr int kForkRing = 16;
+    hipEvent_t fork_event[kForkRing] = {}, side_passed[kForkRing] = {};
+    bool fork_used[kForkRing] = {};
+    int fork_next = 0;
+    hipEvent_t join_event = nullptr;
     bool on_side = false, side_used = false;
     struct ResampleFft* rs_fft = nullptr;  // whole-signal transforms of lra_resample_fft_exec, created on first use
     int opt_pipe_chunk_mb = 128;      // bytes (in + out) one pipeline stage moves
@@ -740,6 +748,19 @@ struct ResampleFft {
     Scratch spec_in, spec_out;
     Scratch time_in, time_out;  // padded clips / uncropped results of the band-limited form
     FftPlanCache order;  // cross-stream ordering of the two spectra (scratch_acquire / scratch_release)
+    // the four buffers only ever grew (up to ~1 GB per pass each way), so one large call pinned ~2 GB of HBM for the context's lifetime.
+    // A call that leaves more than kKeepBytes behind waits for its own work and gives the memory back (such a call ran for milliseconds anyway).
+    static constexpr size_t kKeepBytes = 256u << 20;
+    int trim(hipStream_t stream) {
+        if (spec_in.bytes + spec_out.bytes + time_in.bytes + time_out.bytes <= kKeepBytes) return LRA_OK;
+        LRA_HIP(hipStreamSynchronize(stream));
+        for (Scratch* sc : {&spec_in, &spec_out, &time_in, &time_out}) {
+            if (sc->p) (void)hipFree(sc->p);
+            sc->p = nullptr;
+            sc->bytes = 0;
+        }
+        return LRA_OK;
+    }
     FftPlanCache* get(int type, int dtype, long long n) {
         for (size_t i = 0; i < entries.size(); ++i)
             if (entries[i].type == type && entries[i].dtype == dtype && entries[i].n == n) {
@@ -1527,7 +1548,10 @@ void lra_ctx_destroy(lra_ctx* ctx) {
     delete ctx->rs_fft;
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
-    if (ctx->side_event) (void)hipEventDestroy(ctx->side_event);
+    for (int i = 0; i < lra_ctx::kForkRing; ++i) {
+        if (ctx->fork_event[i]) (void)hipEventDestroy(ctx->fork_event[i]);
+        if (ctx->side_passed[i]) (void)hipEventDestroy(ctx->side_passed[i]);
+    }
     if (ctx->join_event) (void)hipEventDestroy(ctx->join_event);
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
     for (auto& kv : ctx->cqt_tw) {
@@ -1556,9 +1580,15 @@ int lra_ctx_side(lra_ctx* ctx, int mode) {
     if (mode == LRA_SIDE_FORK) {
         if (ctx->on_side) return fail(LRA_EINVAL, "lra_ctx_side: already on the side stream");
         if (!ctx->side_stream) LRA_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
-        if (!ctx->side_event) LRA_HIP(hipEventCreateWithFlags(&ctx->side_event, hipEventDisableTiming));
-        LRA_HIP(hipEventRecord(ctx->side_event, ctx->stream));
-        LRA_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->side_event, 0));
+        const int slot = ctx->fork_next;
+        ctx->fork_next = (slot + 1) % lra_ctx::kForkRing;
+        if (!ctx->fork_event[slot]) LRA_HIP(hipEventCreateWithFlags(&ctx->fork_event[slot], hipEventDisableTiming));
+        if (!ctx->side_passed[slot]) LRA_HIP(hipEventCreateWithFlags(&ctx->side_passed[slot], hipEventDisableTiming));
+        if (ctx->fork_used[slot]) LRA_HIP(hipEventSynchronize(ctx->side_passed[slot]));  // the side stream is past its wait on this slot's previous record
+        LRA_HIP(hipEventRecord(ctx->fork_event[slot], ctx->stream));
+        LRA_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->fork_event[slot], 0));
+        LRA_HIP(hipEventRecord(ctx->side_passed[slot], ctx->side_stream));
+        ctx->fork_used[slot] = true;
         ctx->side_main = ctx->stream;
         ctx->stream = ctx->side_stream;
         ctx->on_side = ctx->side_used = true;
@@ -2406,7 +2436,9 @@ int resample_shaped_run(lra_ctx* ctx, const T* x, T* out, long long batch, long 
         LRA_HIP(hipGetLastError());
     }
     LRA_TRY(scratch_release(rs->order, ctx->stream));
-    return LRA_OK;
+    LRA_TRY(scratch_release(*fwd, ctx->stream));  // (an evicted plan is destroyed behind its last use: get_rocfft_plan)
+    LRA_TRY(scratch_release(*inv, ctx->stream));
+    return rs->trim(ctx->stream);
 }
 
 template <class T> int resample_fft_run(lra_ctx* ctx, const T* x, T* out, long long batch, long long n_in, long long n_out, double gain, int dtype) {
@@ -2444,7 +2476,9 @@ template <class T> int resample_fft_run(lra_ctx* ctx, const T* x, T* out, long l
         LRA_FFT(rocfft_execute(plan, ib2, ob2, inv->info));
     }
     LRA_TRY(scratch_release(rs->order, ctx->stream));
-    return LRA_OK;
+    LRA_TRY(scratch_release(*fwd, ctx->stream));
+    LRA_TRY(scratch_release(*inv, ctx->stream));
+    return rs->trim(ctx->stream);
 }
 }  // namespace
 

@@ -1275,6 +1275,15 @@ def test_numpy_batch_shards_in_process(L, monkeypatch):
     out = np.swapaxes(np.zeros((5, D1.shape[-1] + 3, 513), dtype=np.complex64), -1, -2)   # laid out like stft's own result, three spare columns
     got = L.stft(y, n_fft=1024, hop_length=256, out=out)
     assert np.array_equal(got, D1) and np.shares_memory(got, out)
+    # three ranges of unequal length (7 clips -> 3 + 2 + 2), all on device 0
+    y7 = golden_cases.make_signal("noise", 20000, 12, (7,))
+    monkeypatch.setenv("LRA_DEVICES", "0")
+    M7 = L.feature.melspectrogram(y=y7, sr=22050, n_fft=1024, hop_length=256, n_mels=40)
+    monkeypatch.setenv("LRA_DEVICES", "0,0,0")
+    del served[:]
+    assert np.array_equal(M7, L.feature.melspectrogram(y=y7, sr=22050, n_fft=1024, hop_length=256, n_mels=40))
+    assert sorted(e - b for _, b, e in served) == [2, 2, 3]
+    monkeypatch.setenv("LRA_DEVICES", ",".join(str(i % n_dev) for i in range(2)) if n_dev < 2 else "all")
     bad = y.copy()
     bad[4, 17] = np.nan   # a non-finite sample in the LAST range must still raise
     with pytest.raises(L.ParameterError):
@@ -1331,6 +1340,29 @@ def test_mixed_radix_frames_fused(L, n_fft, hop, sr, n_mels):
     finally:
         ctx.set_option("mixed", 1)
     assert np.abs(y0 - yh).max() <= 2e-6 * max(1.0, np.abs(y).max())
+
+
+def test_bench_two_ranks_with_real_kernels():
+    """the N > 1 path of bench.py with REAL kernels -- two ranks (gloo for the rendezvous / barriers / gather, both on device 0 of the
+    1-GPU box, which bench.py allows under LRA_BENCH_BACKEND=gloo), configs[2]'s split shape at a smaller per-rank batch: one JSON line with n_gpus = 2,
+    the chunked gather's own rows AND the neighbour's rows equal to the unsharded computation."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LRA_DEVICES")}
+    env.update(LRA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "48", "--prewarm-ms", "50", "--gather-chunks", "3"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert len(lines[0]) <= 4096
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and line["config"]["clips_per_gpu"] == 48
+    g = line["gathered"]
+    assert g["own_rows_match"] is True and g["full_matches_unsharded"] is True and g["backend"] == "gloo" and g["chunks"] == 3
 
 
 def test_native_rccl_communicator(L):
@@ -1680,6 +1712,25 @@ def test_cqt_side_stream_overlap(L):
             assert np.array_equal(L.cqt(yn, sr=22050), ref[:3].cpu().numpy())
     finally:
         constantq.FUSED_OCTAVES = constantq.OVERLAP_OCTAVES = True
+
+
+def test_cqt_many_short_octaves_fork_ring(L, monkeypatch):
+    """every octave forks the side stream; each fork now takes its own event out of a ring (16 slots, reused only once the side
+    stream is past its wait).  Many short calls with many octaves -- several times round the ring, poisoned outputs, no synchronisation in
+    between -- must stay bit-identical to the one-stream order."""
+    import torch
+    from librosa_amd import _arrays
+    from librosa_amd.core import constantq
+
+    y = torch.from_numpy(golden_cases.make_signal("mix", 16384, 5, (3,), "float32")).cuda()
+    kw = dict(sr=22050, hop_length=128, n_bins=8 * 12, bins_per_octave=12, fmin=32.7, res_type="polyphase")
+    monkeypatch.setattr(constantq, "OVERLAP_OCTAVES", False)
+    ref = L.cqt(y, **kw)
+    monkeypatch.setattr(constantq, "OVERLAP_OCTAVES", True)
+    monkeypatch.setattr(_arrays, "POISON_OUTPUTS", True)
+    outs = [L.cqt(y, **kw) for _ in range(40)]   # 8 octaves x 40 calls = 20 times round the ring
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, ref) for o in outs)
 
 
 def test_cqt_default_resampler_and_errors(L):

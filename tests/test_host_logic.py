@@ -346,7 +346,14 @@ def test_host_devices_env(monkeypatch):
     monkeypatch.setattr(_native, "device_count", lambda: 4)
     for k in ("LOCAL_RANK", "WORLD_SIZE", "LIBROSA_AMD_DEVICE", "LRA_DEVICES"):
         monkeypatch.delenv(k, raising=False)
-    assert _native.host_devices() == [0, 1, 2, 3]
+
+    class _Ctx:
+        device = 0
+
+    monkeypatch.setattr(_native, "get_context", lambda device=None: _Ctx())
+    assert _native.host_devices() == [0]          # opt-in: a plain call stays on the process's own device
+    _Ctx.device = 2
+    assert _native.host_devices() == [2]
     monkeypatch.setenv("LRA_DEVICES", "0")
     assert _native.host_devices() == [0]
     monkeypatch.setenv("LRA_DEVICES", "2, 3")
