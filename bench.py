@@ -691,7 +691,7 @@ def main():
             return {"clips": nb, "ms_per_iteration": per_iter * 1e3, "frames_per_s_per_iteration": nb * n_frames / per_iter, "ms_32_iterations": (ta + (32 - it_a) * per_iter) * 1e3,
                     "ms_setup": (ta - it_a * per_iter) * 1e3, "finite": bool(torch.isfinite(yr).all()),
                     "what": "librosa_amd.griffinlim(<device |stft|>): per iteration istft + stft + phase update, all device-resident (difference of a 132- and a 4-iteration call, minima of three runs each); "
-                            "ms_setup = host-drawn uniform phases (the reference's rng stream: 42 M float64 draws for 32 clips) + their upload + the final istft"}
+                            "ms_setup = the initial phases (round 5: the reference's own PCG64 stream drawn on the device bit for bit, csrc/lra_rng.h; rounds 1-4 drew 42 M float64 on the host: 92 ms) + the final istft"}
 
         measure("griffinlim", griffinlim_key)
 

@@ -226,6 +226,15 @@ int lra_griffinlim_update(lra_ctx* ctx, const void* rebuilt, const void* tprev, 
  * caller's rng.random(S.shape), so that a seed reproduces the reference's stream), in the element order of S / angles. */
 int lra_griffinlim_init(lra_ctx* ctx, const void* u, const void* S, void* angles, int64_t count, int dtype);
 
+/* NumPy's default generator on the device (round 5): PCG64 = PCG XSL RR 128/64 with O(log n) jump-ahead per thread, integer arithmetic only, so
+ * the stream is np.random.default_rng's bit for bit.  state4 (host) = {state_hi, state_lo, inc_hi, inc_lo}: the two 128-bit integers of
+ * Generator.bit_generator.state["state"].  out[i] (device, float64) = draw number offset + i, i.e. rng.random(offset + count)[offset:]. */
+int lra_pcg64_random_exec(lra_ctx* ctx, const uint64_t* state4, uint64_t offset, void* out, int64_t count);
+/* lra_griffinlim_init with the draws made in place: angles = S * exp(2 pi i u), u = rng.random((batch, n_bins, n_frames)) in THAT element order
+ * (the reference's `rng.random(size=S.shape)`, librosa/core/spectrum.py:2832-2847), S / angles in the device layout [batch][frame][bin].
+ * The caller advances its host generator by batch * n_bins * n_frames draws (bit_generator.advance) to leave it where the reference would. */
+int lra_griffinlim_init_pcg64(lra_ctx* ctx, const uint64_t* state4, const void* S, void* angles, int64_t batch, int n_bins, int64_t n_frames, int dtype);
+
 /* ---- phase vocoder: librosa.phase_vocoder, librosa/core/spectrum.py:1364-1519 (effects.time_stretch, effects.py:464-484) ---- */
 /* D: [batch][n_frames][n_bins] complex (device), out: [batch][n_out][n_bins]; t_out_host: n_out fractional input frame times in
  * [0, n_frames) (np.arange(0, n_frames, rate) for a constant rate, :1488).  Phase: running sum of the phase differences of the

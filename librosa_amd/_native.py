@@ -71,6 +71,8 @@ SIGNATURES = {
     "lra_istft_exec_norm": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64]),
     "lra_transpose": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int]),
     "lra_probe_stream": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int64, c_int, c_int]),
+    "lra_pcg64_random_exec": (c_int, [c_void_p, POINTER(ctypes.c_uint64), ctypes.c_uint64, c_void_p, c_int64]),
+    "lra_griffinlim_init_pcg64": (c_int, [c_void_p, POINTER(ctypes.c_uint64), c_void_p, c_void_p, c_int64, c_int, c_int64, c_int]),
     "lra_probe_stream_pitched": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int64, c_int, c_int, c_int64, c_int]),
     "lra_stft_exec_strided": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p, c_int64]),
     "lra_item_absmax_exec": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
@@ -489,6 +491,18 @@ class Context:
 
     def griffinlim_init(self, u_ptr, s_ptr, angles_ptr, count, dtype):
         _check(self.lib.lra_griffinlim_init(self.handle, c_void_p(u_ptr), c_void_p(s_ptr), c_void_p(angles_ptr), count, dtype_code(dtype)))
+
+    @staticmethod
+    def _pcg64_state4(state, inc):
+        m = (1 << 64) - 1
+        return (ctypes.c_uint64 * 4)((int(state) >> 64) & m, int(state) & m, (int(inc) >> 64) & m, int(inc) & m)
+
+    def pcg64_random_exec(self, state, inc, offset, out_ptr, count):
+        """``np.random.Generator(PCG64)`` with the 128-bit ``state`` / ``inc`` of its ``bit_generator.state["state"]``: draws ``offset .. offset + count`` of ``random()`` (float64, device)."""
+        _check(self.lib.lra_pcg64_random_exec(self.handle, self._pcg64_state4(state, inc), int(offset), c_void_p(out_ptr), int(count)))
+
+    def griffinlim_init_pcg64(self, state, inc, s_ptr, angles_ptr, batch, n_bins, n_frames, dtype):
+        _check(self.lib.lra_griffinlim_init_pcg64(self.handle, self._pcg64_state4(state, inc), c_void_p(s_ptr), c_void_p(angles_ptr), int(batch), int(n_bins), int(n_frames), dtype_code(dtype)))
 
     def griffinlim_update(self, rebuilt_ptr, tprev_ptr, s_ptr, angles_ptr, count, dtype, coef, eps, normalize=True):
         _check(self.lib.lra_griffinlim_update(self.handle, c_void_p(rebuilt_ptr), c_void_p(tprev_ptr) if tprev_ptr else None, c_void_p(s_ptr), c_void_p(angles_ptr), count, dtype_code(dtype),

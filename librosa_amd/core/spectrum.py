@@ -632,6 +632,10 @@ def _transpose_batched(ctx, src_ptr, dst_ptr, batch, rows, cols, elem_bytes):
 # ---------------------------------------------------------------------------------------------------
 # Griffin-Lim: librosa/core/spectrum.py:2669-2917
 # ---------------------------------------------------------------------------------------------------
+# griffinlim(init="random") with NumPy's default generator: draw on the device (lra_rng.h) instead of on the host; False = always draw on the host
+DEVICE_RNG = True
+
+
 class _Deprecated:
     """Sentinel for the reference's deprecated ``random_state`` keyword (``util/deprecation.py``)."""
 
@@ -724,7 +728,15 @@ def griffinlim(S, *, n_iter=32, hop_length=None, win_length=None, n_fft=None, wi
     batch = int(np.prod(lead, dtype=np.int64)) if lead else 1
     # the uniform draws come from the host generator in the reference's order (S.shape, C order, :2834) so that a seed
     # reproduces its stream; the float64 phasor itself is evaluated on the device
-    draws = rng.random(size=tuple(S.shape)) if init == "random" else None
+    # ... unless the generator is NumPy's default one (PCG64: default_rng(seed), or rng=None): its stream is reproduced bit for bit on the device
+    # (csrc/lra_rng.h) from the generator's state, and the host generator is advanced past the draws -- 92 ms of host work for 32 clips otherwise
+    pcg = None
+    if init == "random" and isinstance(rng, np.random.Generator) and DEVICE_RNG:
+        st = rng.bit_generator.state
+        if st.get("bit_generator") == "PCG64" and int(np.prod(S.shape, dtype=np.int64)) > 0:
+            pcg = (int(st["state"]["state"]), int(st["state"]["inc"]))
+            rng.bit_generator.advance(int(np.prod(S.shape, dtype=np.int64)))
+    draws = rng.random(size=tuple(S.shape)) if (init == "random" and pcg is None) else None
     sess = _arrays.Session(S)
     try:
         ctx = sess.ctx
@@ -745,13 +757,16 @@ def griffinlim(S, *, n_iter=32, hop_length=None, win_length=None, n_fft=None, wi
             ctx.nonfinite_reset()
         # angles = S exp(2 pi i u)  (:2834, :2847); the draws travel in S's layout and are transposed on the device.
         # init=None is u = 0: angles = S (1 + 0i)  (:2837)
-        u_t = sess.scratch(count * 8)
-        if draws is not None:
-            up = sess.input_raw(_as_like(sess, draws.reshape(batch, n_bins, n_total)), np.float64)
-            _transpose_batched(ctx, up, u_t, batch, n_bins, n_total, 8)
+        if pcg is not None:
+            ctx.griffinlim_init_pcg64(pcg[0], pcg[1], s_ptr, angles, batch, n_bins, n_total, real)
         else:
-            ctx.memset(u_t, 0, count * 8)
-        ctx.griffinlim_init(u_t, s_ptr, angles, count, real)
+            u_t = sess.scratch(count * 8)
+            if draws is not None:
+                up = sess.input_raw(_as_like(sess, draws.reshape(batch, n_bins, n_total)), np.float64)
+                _transpose_batched(ctx, up, u_t, batch, n_bins, n_total, 8)
+            else:
+                ctx.memset(u_t, 0, count * 8)
+            ctx.griffinlim_init(u_t, s_ptr, angles, count, real)
         have_prev = False
         for _ in range(int(n_iter)):
             ctx.istft_exec_norm(iplan, angles, batch, n_total * n_bins, n_bins, n_used, norm_ptr, y_ptr, expected, expected)   # :2850

@@ -32,6 +32,7 @@
 #include "lra_cqt.h"
 #include "lra_hpss.h"
 #include "lra_probe.h"
+#include "lra_rng.h"
 #include "lra_mixed_launch.h"
 
 using namespace lra;
@@ -2224,6 +2225,41 @@ int lra_griffinlim_init(lra_ctx* ctx, const void* u, const void* S, void* angles
     if (grid > 64LL * ctx->n_cu) grid = 64LL * ctx->n_cu;
     if (dtype == LRA_F64) hipLaunchKernelGGL((griffinlim_init_kernel<double>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const double*)u, (const double*)S, (Cplx2<double>*)angles, (long long)count);
     else hipLaunchKernelGGL((griffinlim_init_kernel<float>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const double*)u, (const float*)S, (Cplx2<float>*)angles, (long long)count);
+    LRA_HIP(hipGetLastError());
+    return LRA_OK;
+}
+
+int lra_pcg64_random_exec(lra_ctx* ctx, const uint64_t* state4, uint64_t offset, void* out, int64_t count) {
+    LRA_BIND(ctx);
+    if (count <= 0) return LRA_OK;
+    if (!state4 || !out) return fail(LRA_EINVAL, "null argument");
+    const rng::Pcg64 g{state4[0], state4[1], state4[2], state4[3]};
+    const long long runs = (count + rng::kRunLength - 1) / rng::kRunLength;
+    const long long grid = (runs + 255) / 256;
+    if (grid > 0x7ffffff0LL) return fail(LRA_EINVAL, "too many draws for one call");
+    hipLaunchKernelGGL(rng::pcg64_uniform_kernel, dim3((unsigned)grid), dim3(256), 0, ctx->stream, g, offset, (double*)out, (long long)count);
+    LRA_HIP(hipGetLastError());
+    return LRA_OK;
+}
+
+int lra_griffinlim_init_pcg64(lra_ctx* ctx, const uint64_t* state4, const void* S, void* angles, int64_t batch, int n_bins, int64_t n_frames, int dtype) {
+    LRA_BIND(ctx);
+    if (batch <= 0 || n_bins <= 0 || n_frames <= 0) return LRA_OK;
+    if (!state4 || !S || !angles) return fail(LRA_EINVAL, "null argument");
+    const rng::Pcg64 g{state4[0], state4[1], state4[2], state4[3]};
+    // a thread owns `seg` consecutive frames of one (clip, bin) row: long enough that the jump-ahead (~2 x 27 128-bit products) is a small part of it,
+    // short enough that the grid fills the chip (>= ~8 workgroups per CU where the job is that large)
+    const int bin_blocks = (n_bins + 255) / 256;
+    int seg = 256;
+    while (seg > 32 && batch * bin_blocks * ((n_frames + seg - 1) / seg) < 8LL * ctx->n_cu) seg /= 2;
+    const long long grid = batch * bin_blocks * ((n_frames + seg - 1) / seg);
+    if (grid > 0x7ffffff0LL) return fail(LRA_EINVAL, "griffinlim init: grid too large");
+    if (dtype == LRA_F64)
+        hipLaunchKernelGGL((rng::griffinlim_init_pcg64_kernel<double>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, g, (const double*)S, (rng::RngCplx<double>*)angles, (long long)batch, n_bins,
+                           (long long)n_frames, seg, bin_blocks);
+    else
+        hipLaunchKernelGGL((rng::griffinlim_init_pcg64_kernel<float>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, g, (const float*)S, (rng::RngCplx<float>*)angles, (long long)batch, n_bins,
+                           (long long)n_frames, seg, bin_blocks);
     LRA_HIP(hipGetLastError());
     return LRA_OK;
 }

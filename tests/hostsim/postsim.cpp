@@ -56,6 +56,7 @@ alignas(16) static unsigned char g_postsim_dyn_lds[160 * 1024];  // the dynamic 
 #include "../../librosa_amd/csrc/lra_cqt.h"
 #include "../../librosa_amd/csrc/lra_hpss.h"
 #include "../../librosa_amd/csrc/lra_mixed.h"
+#include "../../librosa_amd/csrc/lra_rng.h"
 
 namespace {
 template <class F> void run_grid(unsigned grid, unsigned block, F body) {
@@ -209,6 +210,23 @@ int postsim_magnitude(const void* D, void* mag, long long count, int is_f64) {
     const unsigned grid = (unsigned)((count + 255) / 256);
     if (is_f64) run_grid_serial(grid, 256, [=] { lra::magnitude_kernel<double>((const lra::HpssCplx<double>*)D, (double*)mag, count); });
     else run_grid_serial(grid, 256, [=] { lra::magnitude_kernel<float>((const lra::HpssCplx<float>*)D, (float*)mag, count); });
+    return 0;
+}
+
+// the launches of lra_pcg64_random_exec / lra_griffinlim_init_pcg64 (lra_api.hip), same argument preparation
+int postsim_pcg64_random(const unsigned long long* state4, unsigned long long offset, double* out, long long count) {
+    const lra::rng::Pcg64 g{state4[0], state4[1], state4[2], state4[3]};
+    const long long runs = (count + lra::rng::kRunLength - 1) / lra::rng::kRunLength;
+    run_grid_serial((unsigned)((runs + 255) / 256), 256, [=] { lra::rng::pcg64_uniform_kernel(g, offset, out, count); });
+    return 0;
+}
+
+int postsim_griffinlim_init_pcg64(const unsigned long long* state4, const void* S, void* angles, long long batch, int n_bins, long long n_frames, int seg, int is_f64) {
+    const lra::rng::Pcg64 g{state4[0], state4[1], state4[2], state4[3]};
+    const int bin_blocks = (n_bins + 255) / 256;
+    const unsigned grid = (unsigned)(batch * bin_blocks * ((n_frames + seg - 1) / seg));
+    if (is_f64) run_grid_serial(grid, 256, [=] { lra::rng::griffinlim_init_pcg64_kernel<double>(g, (const double*)S, (lra::rng::RngCplx<double>*)angles, batch, n_bins, n_frames, seg, bin_blocks); });
+    else run_grid_serial(grid, 256, [=] { lra::rng::griffinlim_init_pcg64_kernel<float>(g, (const float*)S, (lra::rng::RngCplx<float>*)angles, batch, n_bins, n_frames, seg, bin_blocks); });
     return 0;
 }
 

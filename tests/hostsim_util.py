@@ -156,7 +156,7 @@ _post = None
 def post_lib():
     global _post
     if _post is None:
-        deps = [POST_SRC] + [os.path.join(CSRC, h) for h in ("lra_pcen.h", "lra_cqt.h", "lra_hpss.h", "lra_mixed.h")]
+        deps = [POST_SRC] + [os.path.join(CSRC, h) for h in ("lra_pcen.h", "lra_cqt.h", "lra_hpss.h", "lra_mixed.h", "lra_rng.h")]
         if not os.path.exists(POST_SO) or any(os.path.getmtime(d) > os.path.getmtime(POST_SO) for d in deps):
             subprocess.check_call(["g++", "-O1", "-std=c++17", "-w", "-fPIC", "-shared", "-pthread", POST_SRC, "-o", POST_SO])
         _post = ctypes.CDLL(POST_SO)
@@ -170,6 +170,35 @@ def post_lib():
         _post.postsim_hpss.argtypes = [c.c_void_p] * 4 + [c.c_longlong, c.c_longlong, c.c_int, c.c_int, c.c_int, c.c_double, c.c_double, c.c_double, c.c_int, c.c_int]
         _post.postsim_cqt_project.argtypes = [c.c_void_p] * 6 + [c.c_longlong, c.c_longlong, c.c_int, c.c_longlong, c.c_int, c.c_int, c.c_int, c.c_int, c.c_int]
     return _post
+
+
+def _pcg64_state4(rng):
+    st = rng.bit_generator.state
+    assert st["bit_generator"] == "PCG64"
+    state, inc, m = int(st["state"]["state"]), int(st["state"]["inc"]), (1 << 64) - 1
+    return np.array([(state >> 64) & m, state & m, (inc >> 64) & m, inc & m], dtype=np.uint64)
+
+
+def pcg64_random(rng, offset, count):
+    """Draws ``offset .. offset + count`` of ``rng.random()`` (the generator itself is left alone) through the kernel body of lra_pcg64_random_exec."""
+    out = np.full(count, np.nan)
+    fn = post_lib().postsim_pcg64_random
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_ulonglong, ctypes.c_void_p, ctypes.c_longlong]
+    st = _pcg64_state4(rng)
+    fn(_p(st), int(offset), _p(out), int(count))
+    return out
+
+
+def griffinlim_init_pcg64(rng, S_frame_major, seg=256):
+    """S: (batch, n_frames, n_bins) real, the device layout -> angles (same layout, complex) = S exp(2 pi i u) with u = rng.random((batch, n_bins, n_frames))."""
+    S = np.ascontiguousarray(S_frame_major)
+    batch, n_frames, n_bins = S.shape
+    out = np.full(S.shape, np.nan, dtype=np.complex128 if S.dtype == np.float64 else np.complex64)
+    fn = post_lib().postsim_griffinlim_init_pcg64
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_int]
+    st = _pcg64_state4(rng)
+    fn(_p(st), _p(S), _p(out), batch, n_bins, n_frames, int(seg), int(S.dtype == np.float64))
+    return out
 
 
 def pcen(S, *, b, gain, bias, power, eps, zi_scalar, ref=None, zi=None, want_zf=False):

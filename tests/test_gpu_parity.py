@@ -953,6 +953,42 @@ def test_griffinlim_reference_matrix(L, n_fft, center, use_length, pad_mode, ini
         assert np.abs(y_rec - ref)[well].max() <= (1e-4 if init == "random" else 2e-3) * np.abs(ref).max()
 
 
+def test_pcg64_device_stream_is_numpys(L):
+    """csrc/lra_rng.h on the device: draws offset .. offset + count of np.random.default_rng(seed).random(), bit for bit (integer arithmetic + one exact
+    conversion), for several seeds / sizes / jump-ahead offsets; then griffinlim with device-drawn phases against the host-drawn path (same values, and
+    the caller's generator left in the same state)."""
+    import torch
+    from librosa_amd.core import spectrum as SP
+
+    ctx = L.get_context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    for seed in (0, 7, 440, 2**64 + 3):
+        for offset, count in ((0, 1), (0, 1000), (5, 129), (123457, 4096), (2**33 + 1, 777), (0, 3_000_001)):
+            g = np.random.default_rng(seed)
+            st = g.bit_generator.state["state"]
+            out = torch.empty(count, dtype=torch.float64, device="cuda")
+            ctx.pcg64_random_exec(st["state"], st["inc"], offset, out.data_ptr(), count)
+            g.bit_generator.advance(offset)
+            assert np.array_equal(out.cpu().numpy(), g.random(count)), (seed, offset, count)
+    y = golden_cases.make_signal("mix", 22050, 3, (2,), "float32")
+    S = np.abs(L.stft(y, n_fft=1024, hop_length=256))
+    for dtype in (np.float32, np.float64):
+        g1, g2 = np.random.default_rng(99), np.random.default_rng(99)
+        a = L.griffinlim(S.astype(dtype), n_iter=3, hop_length=256, rng=g1)
+        old = SP.DEVICE_RNG
+        SP.DEVICE_RNG = False
+        try:
+            b = L.griffinlim(S.astype(dtype), n_iter=3, hop_length=256, rng=g2)
+        finally:
+            SP.DEVICE_RNG = old
+        assert np.array_equal(a, b)
+        assert g1.bit_generator.state == g2.bit_generator.state and g1.random() == g2.random()
+    # other bit generators and RandomState keep the host path
+    r1 = L.griffinlim(S, n_iter=2, hop_length=256, rng=np.random.Generator(np.random.Philox(5)))
+    r2 = L.griffinlim(S, n_iter=2, hop_length=256, rng=np.random.Generator(np.random.Philox(5)))
+    assert np.array_equal(r1, r2) and np.isfinite(r1).all()
+
+
 def test_griffinlim_arguments(L):
     """tests/test_core.py:2643-2711: dtype, momentum, rng state, deprecated random_state, error paths."""
     import torch

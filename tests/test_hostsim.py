@@ -290,6 +290,42 @@ def test_power_epilogue_without_lds_ring(n_fft, hop, power, iters, n, monkeypatc
 
 
 # ---- PCEN kernels (librosa_amd/csrc/lra_pcen.h) on host threads ----------------------------------------------------------------
+@pytest.mark.parametrize("seed", [0, 1, 440, 2**63 + 12345, None])
+def test_pcg64_stream_is_numpys(seed):
+    """csrc/lra_rng.h (round 5): the device generator IS np.random.default_rng's PCG64 -- integer arithmetic, so bit for bit --
+    for several seeds, sizes that end inside a thread's run, and offsets (jump-ahead) from 0 to beyond 2^32."""
+    mk = lambda: np.random.default_rng(seed if seed is not None else np.random.SeedSequence(987654321))
+    for count in (1, 127, 128, 129, 5000):
+        assert np.array_equal(H.pcg64_random(mk(), 0, count), mk().random(count))
+    for offset in (1, 127, 128, 1000003, 2**32 + 17):
+        want = mk()
+        want.bit_generator.advance(offset)
+        assert np.array_equal(H.pcg64_random(mk(), offset, 300), want.random(300))
+    # a generator that has already been used: its state says where it is
+    g = mk()
+    g.random(77)
+    g.integers(0, 10, size=5)
+    st = g.bit_generator.state
+    want = np.random.Generator(np.random.PCG64())
+    want.bit_generator.state = st
+    assert np.array_equal(H.pcg64_random(g, 0, 1000), want.random(1000))
+
+
+@pytest.mark.parametrize("dtype,batch,n_bins,n_frames,seg", [(np.float32, 2, 129, 37, 16), (np.float64, 1, 513, 9, 256), (np.float32, 3, 300, 70, 32)])
+def test_griffinlim_init_pcg64_body(dtype, batch, n_bins, n_frames, seg):
+    """angles = S exp(2 pi i u) with u drawn on the device in the reference's order (rng.random(S.shape), S = (clip, bin, frame)) into the frame-major layout:
+    the same values as the host-drawn path (float64 phasor, one rounding)."""
+    rng = np.random.default_rng(2024)
+    S = np.abs(np.random.default_rng(5).standard_normal((batch, n_bins, n_frames))).astype(dtype)
+    got = H.griffinlim_init_pcg64(rng, np.ascontiguousarray(np.swapaxes(S, -1, -2)), seg=seg)
+    u = np.random.default_rng(2024).random(S.shape)
+    a = 2 * np.pi * u
+    want = (np.cos(a).astype(dtype) * S) + 1j * (np.sin(a).astype(dtype) * S)
+    want = np.swapaxes(want, -1, -2).astype(got.dtype)
+    assert np.abs(got - want).max() <= (1e-15 if dtype == np.float64 else 2e-7) * np.abs(want).max()
+    assert np.array_equal(got.real == 0, want.real == 0)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("rows,n", [(1, 1), (5, 63), (16, 64), (17, 65), (40, 200)])
 def test_pcen_body(dtype, rows, n):
