@@ -309,7 +309,7 @@ def compact_line(line):
             "griffinlim_ms_per_iter_32clips": get(line, "griffinlim", "ms_per_iteration"), "griffinlim_ms_setup": get(line, "griffinlim", "ms_setup"),
             "cqt_polyphase_ms_64clips": get(line, "pcen_cqt", "cqt_polyphase", "ms_per_call"), "cqt_default_ms_64clips": get(line, "pcen_cqt", "cqt_default", "ms_per_call"),
             "pcen_ms": get(line, "pcen_cqt", "pcen", "ms_per_call"), "hpss_ms_32clips": get(line, "hpss", "ms_per_call"), "mixed_400_mel_ms": get(line, "mixed_radix_400", "fused", "mel_ms"),
-            "mixed_400_stft_ms": get(line, "mixed_radix_400", "fused", "stft_ms"), "cqt_lite_512_ms": get(line, "cqt_lite", "per_n_fft", "512", "ms"),
+            "mixed_400_stft_ms": get(line, "mixed_radix_400", "fused", "stft_ms"), "speech_512_mel_ms": get(line, "speech_512", "mel_ms"), "cqt_lite_512_ms": get(line, "cqt_lite", "per_n_fft", "512", "ms"),
             "cqt_lite_8192_ms": get(line, "cqt_lite", "per_n_fft", "8192", "ms"), "cqt_lite_default_hop_ms": get(line, "cqt_lite", "default_hop_variant", "ms_total"),
             "stft_power_w": get(line, "board_power", "stft", "socket_power_w"), "stft_sclk_mhz": get(line, "board_power", "stft", "sclk_mhz"),
             "mel_power_w": get(line, "board_power", "mel", "socket_power_w"), "mel_variant": get(line, "kernel_variants", "melspectrogram")}
@@ -777,6 +777,18 @@ def main():
             return out
 
         measure("mixed_radix_400", mixed_radix)
+
+        def speech_512():
+            """n_fft = 512, hop 160, 80 mels at 16 kHz (32 ms frames every 10 ms): small frames share a wave (16 threads per frame), four bands per thread since round 5."""
+            sr2, nf, hp, nm = 16000, 512, 160, 80
+            y2 = y[:, : sr2 * CLIP_SECONDS].contiguous()
+            fn = lambda: L.feature.melspectrogram(y=y2, sr=sr2, n_fft=nf, hop_length=hp, n_mels=nm, check_finite=False)
+            T2 = int(fn().shape[-1])
+            _, e = timed(fn, 5, 2, collective=False, ramp_ms=args.prewarm_ms / 4)
+            per = e / 5
+            return {"mel_ms": per * 1e3, "mel_frames_per_s": batch * T2 / per, "workload": f"feature.melspectrogram n_fft=512 hop=160 n_mels=80 @ 16 kHz, {batch} clips x {CLIP_SECONDS} s"}
+
+        measure("speech_512", speech_512)
         # BASELINE config 5 (CQT-lite): three STFTs at n_fft = 512 / 2048 / 8192 over the same batch, shared hop 512
         if not args.no_cqt:
             def cqt_lite():

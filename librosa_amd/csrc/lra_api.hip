@@ -1912,7 +1912,7 @@ int lra_mel_plan_create(lra_ctx* ctx, int n_mels, int n_bins, const void* basis_
                     p->n_pieces[pi] = mp.n_pieces;
                 }
                 if (rc == LRA_OK && (n_bins - 1) % 16 == 0) {
-                    MelRuns<double> mr = build_mel_runs<double>(ts, (n_bins - 1) / 16, 8, MELR_PMAX, 4);
+                    MelRuns<double> mr = build_mel_runs<double>(ts, (n_bins - 1) / 16, 8, MELR_PMAX, melr_ph_of_tf((n_bins - 1) / 16));  // (min list length = the hoisted prefix)
                     if (mr.ok) {
                         rc = upload(&p->d_melr_w, mr.w.data(), mr.w.size() * sizeof(double));
                         if (rc == LRA_OK) rc = upload(&p->d_melr_keep, mr.keep.data(), mr.keep.size() * sizeof(double));
@@ -1950,7 +1950,7 @@ int lra_mel_plan_create(lra_ctx* ctx, int n_mels, int n_bins, const void* basis_
                     p->n_pieces[pi] = mp.n_pieces;
                 }
                 if (rc == LRA_OK && (n_bins - 1) % 16 == 0) {
-                    MelRuns<float> mr = build_mel_runs<float>(ts, (n_bins - 1) / 16, 8, MELR_PMAX, 4);
+                    MelRuns<float> mr = build_mel_runs<float>(ts, (n_bins - 1) / 16, 8, MELR_PMAX, melr_ph_of_tf((n_bins - 1) / 16));  // (min list length = the hoisted prefix)
                     if (mr.ok) {
                         rc = upload(&p->d_melr_w, mr.w.data(), mr.w.size() * sizeof(float));
                         if (rc == LRA_OK) rc = upload(&p->d_melr_keep, mr.keep.data(), mr.keep.size() * sizeof(float));

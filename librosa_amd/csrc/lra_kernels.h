@@ -129,6 +129,25 @@ template <class Cfg> LRA_HD int slot_of(int tid) {
 }
 template <class Cfg> LRA_HD int lane_of(int tid) { return (int)((unsigned)tid % (unsigned)Cfg::TF); }
 
+// OUT_MELR register budget per thread: NB mel bands (NB tf .. NB tf + NB - 1), the first PH entries of each band's two piece lists, and the last
+// TILE frames' values of each band.  One wave per frame (TF >= 64) serves 128 bands with two per thread; small frames share a wave (TF = 32 at
+// n_fft 1024, 16 at 512) and their threads take 4 / 8 bands each -- round 5: with two, 96 of 128 bands of an n_fft = 512 frame went through the
+// table path (two dependent LDS reads per piece, one 4-byte store per band and frame): 1.84 ms against 0.31 ms for the transform itself.  Their
+// pair segments are a few bins wide, so two hoisted pieces per list cover them (longer lists take the rest from the table).
+#ifndef LRA_MELR_NB_SMALL
+#define LRA_MELR_NB_SMALL 4  // bands per thread where TF <= 16 (8 was measured: the n_fft = 512 kernel then needs 276 VGPRs, and 20 spilled registers cost more than the table path)
+#endif
+#ifndef LRA_MELR_PH_SMALL
+#define LRA_MELR_PH_SMALL 3  // hoisted pieces per list there (same box, n_fft 512 / hop 128 / 80 bands: 2 -> 0.85, 3 -> 0.75, 4 -> 0.77 ms; two bands x four pieces before: 0.95)
+#endif
+// (TF = 32, n_fft = 1024: four bands per thread with two hoisted pieces measured 0.79 against 0.83 ms at 128 bands but 0.78 against 0.68 ms at 80, whose
+// wider segments need the longer hoisted lists: it keeps two bands per thread)
+constexpr int melr_nb_of_tf(int tf) { return tf >= 32 ? 2 : LRA_MELR_NB_SMALL; }
+constexpr int melr_ph_of_tf(int tf) { return tf >= 32 ? 4 : LRA_MELR_PH_SMALL; }  // (also the minimum list length the host builds: lra_api.hip)
+template <class Cfg> constexpr int melr_nb() { return melr_nb_of_tf(Cfg::TF); }
+template <class Cfg> constexpr int melr_ph() { return melr_ph_of_tf(Cfg::TF); }
+template <class Cfg> constexpr int melr_tile_frames() { return melr_nb<Cfg>() == 2 ? 8 : 4; }  // (NB x TILE = 16 registers, or 32 at eight bands per thread)
+
 template <class Cfg> struct FftRegs {
     typename Cfg::cplx v[Cfg::R];
     typename Cfg::cplx mid;
@@ -147,14 +166,14 @@ template <class Cfg> struct FftRegs {
     typename Cfg::cplx xk[Cfg::R / 2 > 0 ? Cfg::R / 2 : 1], xm[Cfg::R / 2 > 0 ? Cfg::R / 2 : 1], xmid;
     typename Cfg::real out[NPFX];  // ISTFT hold-back (hop <= n_fft/2 in the row-aligned kernels, <= n_fft/4 otherwise)
     // OUT_MELR: this thread's restart factors and the first MELR_PHOIST entries of the piece lists of its (up to two) mel bands
-    static constexpr int MELR_PHOIST = 4;
+    static constexpr int MELR_PHOIST = melr_ph<Cfg>(), MELR_NB = melr_nb<Cfg>();
     typename Cfg::real keep[Cfg::R];
-    int mad[2][2 * MELR_PHOIST];
+    int mad[MELR_NB][2 * MELR_PHOIST];
     // ... and the last MELR_TILE frames' values of those two bands: stored as one burst per band every MELR_TILE
     // frames, so that the L2 merges them into whole 32-byte sectors (single 4-byte stores 5 us apart do not merge:
     // 865 MB of HBM writes per launch for 169 MB of output)
-    static constexpr int MELR_TILE = 8;
-    typename Cfg::real mt[2][MELR_TILE];
+    static constexpr int MELR_TILE = melr_tile_frames<Cfg>();
+    typename Cfg::real mt[MELR_NB][MELR_TILE];
     typename Cfg::real wv[NPFX];  // ISTFT (row-aligned): window sum-square values of the held-back samples, loaded a frame ahead
     typename Cfg::cplx cry[Cfg::R];  // ISTFT (row-aligned, istft_reg_carry): the overlap-add carry, pair c of this thread's R - HC rows that outlive a frame
     static constexpr int NH = Cfg::HOIST ? 1 : 0;
@@ -890,8 +909,8 @@ template <class Cfg> LRA_HD int melr_w_slot(int i) { return i + 2 * (i / (Cfg::R
 template <class Cfg> LRA_HD int melr_keep_off() { return ((melr_w_slot<Cfg>(Cfg::M) + 1) * 2 * (int)sizeof(typename Cfg::real) + 15) / 16 * 16; }
 template <class Cfg> LRA_HD int melr_addr_off() { return melr_keep_off<Cfg>(); }  // (the restart factors live in registers only, melr_hoist)
 // the address table is needed in LDS only for lists longer than the hoisted prefix or more than two bands per thread
-constexpr int MELR_PHOIST_N = 4;  // piece-list entries per band kept in registers (FftRegs / Regs2 ::MELR_PHOIST)
-template <class Cfg> LRA_HD bool melr_needs_table(int n_mels, int pmax) { return pmax > MELR_PHOIST_N || n_mels > 2 * Cfg::TF; }
+constexpr int MELR_PHOIST_N = 4;  // piece-list entries per band kept in registers at two bands per thread (melr_ph)
+template <class Cfg> LRA_HD bool melr_needs_table(int n_mels, int pmax) { return pmax > melr_ph<Cfg>() || n_mels > melr_nb<Cfg>() * Cfg::TF; }
 template <class Cfg> LRA_HD int melr_shared_bytes(int n_mels, int pmax) {
     return ((melr_addr_off<Cfg>() + (melr_needs_table<Cfg>(n_mels, pmax) ? n_mels * 2 * pmax * (int)sizeof(int) : 0) + 15) / 16) * 16;
 }
@@ -981,8 +1000,8 @@ template <class Cfg, class RG> LRA_HD void melr_hoist(const StftArgs<typename Cf
     LRA_UNROLL
     for (int jj = 0; jj < Cfg::R; ++jj) rg.keep[jj] = a.melr_keep[jj * Cfg::TF + tf];
     LRA_UNROLL
-    for (int b = 0; b < 2; ++b) {
-        const int m = 2 * tf + b;  // bands 2 tf and 2 tf + 1 (see melr_combine)
+    for (int b = 0; b < RG::MELR_NB; ++b) {
+        const int m = RG::MELR_NB * tf + b;  // bands NB tf .. NB tf + NB - 1 (see melr_combine)
         LRA_UNROLL
         for (int h = 0; h < 2; ++h) {
             LRA_UNROLL
@@ -1019,10 +1038,10 @@ template <class Cfg, class RG> LRA_HD void melr_burst(const StftArgs<typename Cf
     using T = typename Cfg::real;
     constexpr int MT = RG::MELR_TILE;
     T* __restrict__ row = a.Mel + (row0 + frame - s8);
-    if constexpr (sizeof(T) == 4 && MT == 8) {
+    if constexpr (sizeof(T) == 4 && (MT == 8 || MT == 4)) {
         if (LRA_MEL_BURST16 && s8 == MT - 1 && it >= MT - 1) {
             store4_unaligned(row, rg.mt[b][0], rg.mt[b][1], rg.mt[b][2], rg.mt[b][3]);
-            store4_unaligned(row + 4, rg.mt[b][4], rg.mt[b][5], rg.mt[b][6], rg.mt[b][7]);
+            if constexpr (MT == 8) store4_unaligned(row + 4, rg.mt[b][4], rg.mt[b][5], rg.mt[b][6], rg.mt[b][7]);
             return;
         }
     }
@@ -1038,29 +1057,33 @@ template <class Cfg, class RG> LRA_HD void melr_burst(const StftArgs<typename Cf
 template <class Cfg, class RG> LRA_HD void melr_combine(const StftArgs<typename Cfg::real>& a, int clip, int frame, int tf, int it, int tile, bool last_of_slot, RG& rg, Lds sh,
                                                         Lds rs, Lds stage, Lds rs_hoisted) {
     using T = typename Cfg::real;
-    constexpr int PH = RG::MELR_PHOIST, TF = Cfg::TF;
+    constexpr int PH = RG::MELR_PHOIST, TF = Cfg::TF, NB = RG::MELR_NB;
     const bool more = a.melr_pmax > PH;  // uniform
     // The hoisted piece totals are read as whole (A, B) pairs and the wanted half is picked in registers (list h = 0: the B totals of
     // segment m, h = 1: the A totals of segment m + 1): an 8-byte read spreads 32 lanes over 64 banks, a 4-byte read of one half of
     // 8-byte slots over 16 -- a built-in 2-way conflict that was a third of the epilogue's LDS cycles (scripts/lds_model.py).
-    T x[2][2 * PH];
+    // (sixteen reads in flight at a time: the bands are taken in groups of GB, so that eight bands per thread do not keep 32 totals live at once)
+    constexpr int GB = NB * 2 * PH > 16 ? 16 / (2 * PH) : NB;
+    T x[NB][2 * PH];
     LRA_UNROLL
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < NB; ++b) {
+      if (b % GB == 0) {
         LRA_UNROLL
-        for (int q = 0; q < 2 * PH; ++q) {
-            if constexpr (LRA_MEL_PAIR_READS && sizeof(T) == 4) {
-                const cx<T> pr = lds_ld<cx<T>>(rs_hoisted, rg.mad[b][q]);  // (melr_hoist keeps the pair's address)
-                x[b][q] = q < PH ? pr.y : pr.x;
-            } else {
-                x[b][q] = lds_ld<T>(rs_hoisted, rg.mad[b][q]);
+        for (int bb = b; bb < b + GB; ++bb) {
+            LRA_UNROLL
+            for (int q = 0; q < 2 * PH; ++q) {
+                if constexpr (LRA_MEL_PAIR_READS && sizeof(T) == 4) {
+                    const cx<T> pr = lds_ld<cx<T>>(rs_hoisted, rg.mad[bb][q]);  // (melr_hoist keeps the pair's address)
+                    x[bb][q] = q < PH ? pr.y : pr.x;
+                } else {
+                    x[bb][q] = lds_ld<T>(rs_hoisted, rg.mad[bb][q]);
+                }
             }
         }
-    }
-    LRA_UNROLL
-    for (int b = 0; b < 2; ++b) {
-        // Bands 2 tf and 2 tf + 1: a thread's first band is even and its second odd for EVERY lane, which makes the burst phase
-        // below one value per wave and band slot wherever rows start 0 or 16 bytes into a 32-byte piece (n_frames a multiple of 4).
-        const int m = 2 * tf + b;
+      }
+        // Bands NB tf .. NB tf + NB - 1.  (NB = 2: a thread's first band is even and its second odd for EVERY lane, which makes the burst phase
+        // below one value per wave and band slot wherever rows start 0 or 16 bytes into a 32-byte piece -- n_frames a multiple of 4.)
+        const int m = NB * tf + b;
         if (m >= a.n_mels) break;
         T part[2];
         LRA_UNROLL
@@ -1089,7 +1112,7 @@ template <class Cfg, class RG> LRA_HD void melr_combine(const StftArgs<typename 
             lds_st<T>(stage, (m * tile + (it % tile)) * (int)sizeof(T), v);
         }
     }
-    for (int m = tf + 2 * TF; m < a.n_mels; m += TF) {  // more than two bands per thread: everything from the table
+    for (int m = tf + NB * TF; m < a.n_mels; m += TF) {  // more than NB bands per thread: everything from the table
         T part[2];
         LRA_UNROLL
         for (int h = 0; h < 2; ++h) {

@@ -95,11 +95,11 @@ template <class Cfg, int HD> struct Regs2 {
     // OUT_MELR (run-ordered two-slope mel epilogue, lra_mel.h layout 1): this thread's two runs of R/2 power values, the
     // restart factors of its running sums, the first MELR_PHOIST piece addresses of its two mel bands and the last
     // MELR_TILE frames' values of those bands (stored as one burst per band, see FftRegs)
-    static constexpr int MELR_PHOIST = MELR_PHOIST_N, MELR_TILE = 8;
+    static constexpr int MELR_PHOIST = melr_ph<Cfg>(), MELR_TILE = melr_tile_frames<Cfg>(), MELR_NB = melr_nb<Cfg>();  // (two bands per thread at one wave per frame; see FftRegs)
     typename Cfg::real pw[R], pw_extra;
     typename Cfg::real keep[R];
-    int mad[2][2 * MELR_PHOIST];
-    typename Cfg::real mt[2][MELR_TILE];
+    int mad[MELR_NB][2 * MELR_PHOIST];
+    typename Cfg::real mt[MELR_NB][MELR_TILE];
     // complex index (within a frame) of pass-0 register element e
     static LRA_HD int q_of(int tf, int e) { return tf + (e / r0) * Cfg::TF + (e % r0) * sin0; }
     // pass-0 register element of new pair n

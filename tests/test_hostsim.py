@@ -173,7 +173,10 @@ def test_power_and_mel_body(n_fft, hop, power, n_mels, dtype, variant):
 
 
 @pytest.mark.parametrize("n_fft,hop,power,n_mels,iters,n,v2", [(2048, 512, 2.0, 128, 3, 9000, 1), (2048, 512, 1.0, 128, 9, 30000, 1), (2048, 512, 2.0, 40, 4, 9000, 1), (2048, 1024, 2.0, 128, 3, 9000, 1),
-                                                               (2048, 256, 1.6, 64, 5, 9000, 1), (1024, 256, 2.0, 40, 6, 9000, 1), (2048, 512, 2.0, 128, 3, 9000, 0), (1024, 256, 1.0, 40, 3, 9000, 0)])
+                                                               (2048, 256, 1.6, 64, 5, 9000, 1), (1024, 256, 2.0, 40, 6, 9000, 1), (2048, 512, 2.0, 128, 3, 9000, 0), (1024, 256, 1.0, 40, 3, 9000, 0),
+                                                               # round 5: 4 / 8 bands per thread where frames share a wave (TF = 32 / 16 / 8), 4-frame output tiles at TF <= 16
+                                                               (512, 128, 2.0, 128, 9, 5000, 0), (512, 128, 2.0, 80, 5, 5000, 0), (512, 160, 1.0, 40, 7, 5000, 0), (1024, 256, 2.0, 128, 9, 9000, 0),
+                                                               (256, 64, 2.0, 64, 11, 3000, 0), (256, 64, 2.0, 128, 6, 3000, 0), (512, 512, 2.0, 128, 4, 6000, 0)])
 def test_mel_body_run_ordered_both_generations(n_fft, hop, power, n_mels, iters, n, v2, monkeypatch):
     """OUT_MELR on the second-generation core (power row in LDS, lra_kernels2.h) and on the first-generation one."""
     if not v2:
