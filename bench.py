@@ -307,7 +307,7 @@ def compact_line(line):
     side = {"dropin_torch_ms": get(line, "dropin_torch", "ms_per_call"), "numpy_mel_ms_64clips": get(line, "end_to_end_numpy", "melspectrogram", "ms"),
             "numpy_stft_ms_64clips": get(line, "end_to_end_numpy", "stft", "ms"), "power_to_db_ms": get(line, "power_to_db", "ms_per_call"), "mfcc_ms": get(line, "mfcc", "ms_per_call"),
             "griffinlim_ms_per_iter_32clips": get(line, "griffinlim", "ms_per_iteration"), "griffinlim_ms_setup": get(line, "griffinlim", "ms_setup"),
-            "cqt_polyphase_ms_64clips": get(line, "pcen_cqt", "cqt_polyphase", "ms_per_call"), "cqt_default_ms_64clips": get(line, "pcen_cqt", "cqt_default", "ms_per_call"),
+            "cqt_polyphase_ms_64clips": get(line, "pcen_cqt", "cqt_polyphase", "ms_per_call"), "cqt_default_ms_64clips": get(line, "pcen_cqt", "cqt_default", "ms_per_call"), "cqt_polyphase_nocheck_ms_64clips": get(line, "pcen_cqt", "cqt_polyphase_nocheck", "ms_per_call"),
             "pcen_ms": get(line, "pcen_cqt", "pcen", "ms_per_call"), "hpss_ms_32clips": get(line, "hpss", "ms_per_call"), "mixed_400_mel_ms": get(line, "mixed_radix_400", "fused", "mel_ms"),
             "mixed_400_stft_ms": get(line, "mixed_radix_400", "fused", "stft_ms"), "speech_512_mel_ms": get(line, "speech_512", "mel_ms"), "cqt_lite_512_ms": get(line, "cqt_lite", "per_n_fft", "512", "ms"),
             "cqt_lite_8192_ms": get(line, "cqt_lite", "per_n_fft", "8192", "ms"), "cqt_lite_default_hop_ms": get(line, "cqt_lite", "default_hop_variant", "ms_total"),
@@ -331,6 +331,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cqt", action="store_true", help="skip the CQT-lite (config 5) side measurement")
     ap.add_argument("--no-side", action="store_true", help="skip every side measurement (profiling runs)")
+    ap.add_argument("--no-scaling-base", action="store_true", help="skip the N = 1 run at 512 clips (profiling runs: it launches the headline kernel on another grid)")
     ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power / clock samples (profiling runs: they loop the kernels for seconds)")
     ap.add_argument("--placements", type=int, default=5, help="allocations of the 2.7 GB spectrum the complex STFT / ISTFT side figures are sampled over (median reported, best / worst beside it)")
     ap.add_argument("--detail", default=None, help="file the full (long) measurement record goes to; default gpurun_out/bench_detail.json when that directory exists; it always goes to stderr too")
@@ -438,10 +439,11 @@ def main():
     rep = [timed(step_mel, args.steps, 0, collective=False)[1] / args.steps * 1e3 for _ in range(5)]
 
     side = {}
+    only = set(filter(None, os.environ.get("LRA_BENCH_ONLY", "").split(",")))  # debugging aid: run only these side measurements
 
     def measure(name, fn):
         """A side measurement never breaks the contract line."""
-        if args.no_side:
+        if args.no_side or (only and name not in only):
             return
         try:
             side[name] = fn()
@@ -630,7 +632,7 @@ def main():
             per = e / args.steps
             return {"clips_per_gpu": b2, "value": b2 * n_frames / per, "unit": "frames/s", "ms_per_step": per * 1e3}
 
-        if batch != 512:
+        if batch != 512 and not args.no_scaling_base:
             measure("scaling_base", scaling_base)
 
         def public_numpy():
@@ -704,8 +706,8 @@ def main():
                                    "bound by the float64 transcendentals, not by HBM"}
             nb = min(64, batch)
             yc = y[:nb]
-            for key, rt in (("cqt_polyphase", "polyphase"), ("cqt_default", "soxr_hq")):
-                fn = lambda: L.cqt(yc, sr=SR, hop_length=HOP, res_type=rt)
+            for key, rt, cf in (("cqt_polyphase", "polyphase", True), ("cqt_default", "soxr_hq", True), ("cqt_polyphase_nocheck", "polyphase", False)):
+                fn = lambda: L.cqt(yc, sr=SR, hop_length=HOP, res_type=rt, check_finite=cf)
                 _, e = timed(fn, 5, 2, collective=False, ramp_ms=args.prewarm_ms / 4)
                 alg_bytes = nb * (n * 4 + 84 * n_frames * 8)  # PCM read once + the stacked complex64 result written once
                 out[key] = {"clips": nb, "ms_per_call": e / 5 * 1e3, "frames_per_s": nb * n_frames / (e / 5), "GBps_algorithmic": alg_bytes / (e / 5) / 1e9,

@@ -303,6 +303,21 @@ int lra_cqt_project_exec(lra_ctx* ctx, const void* D, void* out, const void* row
  * (:1168-1194) -- arguments as lra_cqt_project_exec, y [batch][y_stride] instead of D.  The frame spectra stay in LDS.  Raises the context's
  * non-finite flag like the forward kernels (a frame's DC bin is non-finite iff one of its samples is). */
 int lra_cqt_octave_supported(int n_fft);
+/* The whole octave recursion of one cqt / vqt call in ONE native call (round 5; constantq.py:1054-1099): for every octave lra_cqt_octave_exec on the
+ * current signal and -- where `halve` -- lra_fir_decimate_exec by two (taps / first as there, div = sqrt(1/2): audio.resample(scale=True)) into the
+ * next slice of `scratch` (>= the sum of the 256-byte-rounded halved signals).  overlap != 0: the octave transforms go to the context's side stream
+ * beside the chain of halvings (lra_ctx_side) and are joined before returning.  What the Python loop did with ~40 calls through ctypes per transform. */
+typedef struct lra_cqt_octave {
+    int n_fft, hop;             /* frame length and hop of the octave's transform */
+    int bin0, row0, n_rows;     /* its columns of the stacked result, its rows of the CSR basis */
+    int halve;                  /* != 0: the signal is halved behind this octave */
+    int64_t n;                  /* samples per clip of the octave's signal */
+    const void* row_ptr;        /* CSR basis of the octave (device): int32 row_ptr / col, complex val */
+    const void* col;
+    const void* val;
+} lra_cqt_octave;
+int lra_cqt_recursion_exec(lra_ctx* ctx, const void* y, int64_t batch, const lra_cqt_octave* octaves, int n_octaves, int pad_mode, const void* sqrt_len, void* out, int64_t n_frames,
+                           int n_total, const void* taps, int n_taps, int first, void* scratch, int64_t scratch_bytes, int overlap, int dtype);
 int lra_cqt_octave_exec(lra_ctx* ctx, const void* y, int64_t batch, int64_t n, int64_t y_stride, int n_fft, int hop, int pad_mode, const void* row_ptr, const void* col, const void* val,
                         const void* sqrt_len, void* out, int64_t n_frames, int n_total, int bin0, int row0, int n_rows, int dtype);
 

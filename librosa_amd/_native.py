@@ -71,6 +71,7 @@ SIGNATURES = {
     "lra_istft_exec_norm": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64]),
     "lra_transpose": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int]),
     "lra_probe_stream": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int64, c_int, c_int]),
+    "lra_cqt_recursion_exec": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_int, c_int]),
     "lra_pcg64_random_exec": (c_int, [c_void_p, POINTER(ctypes.c_uint64), ctypes.c_uint64, c_void_p, c_int64]),
     "lra_griffinlim_init_pcg64": (c_int, [c_void_p, POINTER(ctypes.c_uint64), c_void_p, c_void_p, c_int64, c_int, c_int64, c_int]),
     "lra_probe_stream_pitched": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int64, c_int, c_int, c_int64, c_int]),
@@ -220,6 +221,12 @@ class Event:
             self.ctx.lib.lra_event_destroy(self.handle)
         except Exception:
             pass
+
+
+class CqtOctave(ctypes.Structure):
+    """``lra_cqt_octave`` (``include/librosa_amd.h``)."""
+    _fields_ = [("n_fft", c_int), ("hop", c_int), ("bin0", c_int), ("row0", c_int), ("n_rows", c_int), ("halve", c_int), ("n", c_int64), ("row_ptr", c_void_p), ("col", c_void_p),
+                ("val", c_void_p)]
 
 
 class Context:
@@ -475,6 +482,12 @@ class Context:
         """One constant-Q octave in one launch (``include/librosa_amd.h``): STFT with a rectangular window + sparse projection + scaling + stacking."""
         _check(self.lib.lra_cqt_octave_exec(self.handle, c_void_p(y_ptr), batch, n, y_stride, n_fft, hop, PAD_MODES[pad_mode], c_void_p(row_ptr), c_void_p(col_ptr), c_void_p(val_ptr),
                                             c_void_p(sqrt_len_ptr) if sqrt_len_ptr else None, c_void_p(out_ptr), n_frames, n_total, bin0, row0, n_rows, dtype_code(dtype)))
+
+    def cqt_recursion_exec(self, y_ptr, batch, octaves, pad_mode, sqrt_len_ptr, out_ptr, n_frames, n_total, taps_ptr, n_taps, first, scratch_ptr, scratch_bytes, overlap, dtype):
+        """The octave recursion of one cqt / vqt call in one native call; ``octaves``: a ``CqtOctave`` ctypes array (``include/librosa_amd.h``: lra_cqt_octave)."""
+        _check(self.lib.lra_cqt_recursion_exec(self.handle, c_void_p(y_ptr), batch, ctypes.cast(octaves, c_void_p), len(octaves), PAD_MODES[pad_mode], c_void_p(sqrt_len_ptr) if sqrt_len_ptr else None,
+                                               c_void_p(out_ptr), n_frames, int(n_total), c_void_p(taps_ptr) if taps_ptr else None, int(n_taps), int(first), c_void_p(scratch_ptr) if scratch_ptr else None,
+                                               int(scratch_bytes), int(bool(overlap)), dtype_code(dtype)))
 
     def magnitude_exec(self, d_ptr, mag_ptr, count, dtype):
         _check(self.lib.lra_magnitude_exec(self.handle, c_void_p(d_ptr), c_void_p(mag_ptr), count, dtype_code(dtype)))

@@ -43,6 +43,8 @@ from .spectrum import _DEVICE_PAD_MODES, _all_finite, _as_like
 FUSED_OCTAVES = True
 # The octave transforms on the context's side stream, beside the chain of halvings (lra_ctx_side); False: everything on one stream.
 OVERLAP_OCTAVES = True
+# the whole octave recursion in one native call (lra_cqt_recursion_exec) where it applies; False = the per-octave calls from Python
+NATIVE_RECURSION = True
 
 __all__ = ["cqt", "vqt"]
 
@@ -138,11 +140,12 @@ def _plan(sr, hop_length, fmin, n_bins, intervals, gamma, bins_per_octave, filte
 
 
 def vqt(y, *, sr=22050, hop_length=512, fmin=None, n_bins=84, intervals="equal", gamma=None, bins_per_octave=12, tuning=0.0, filter_scale=1, norm=1, sparsity=0.01,
-        window="hann", scale=True, pad_mode="constant", res_type="soxr_hq", dtype=None):
+        window="hann", scale=True, pad_mode="constant", res_type="soxr_hq", dtype=None, check_finite=True):
     """Variable-Q transform; drop-in for ``librosa.vqt`` (``librosa/core/constantq.py:820-1122``).
 
     Returns ``(..., n_bins, n_frames)`` complex (complex64 for float32 audio).  ``y`` may be a device tensor (a device tensor is
-    returned).  Not provided: ``tuning=None`` (needs the pitch tracker behind ``estimate_tuning``), named just-intonation interval
+    returned; ``check_finite=False`` -- an extension, as for ``stft`` -- then skips ``valid_audio``'s finite test, whose device flag costs one
+    host synchronisation per call: back-to-back calls otherwise cannot overlap their launches with the previous call's kernels).  Not provided: ``tuning=None`` (needs the pitch tracker behind ``estimate_tuning``), named just-intonation interval
     sets (``intervals`` must be ``"equal"`` or an explicit list).  See the module docstring for ``res_type``.
     """
     if not isinstance(intervals, str):
@@ -201,7 +204,7 @@ def vqt(y, *, sr=22050, hop_length=512, fmin=None, n_bins=84, intervals="equal",
         ctx = sess.ctx
         overlapped = OVERLAP_OCTAVES
         y_ptr, batch, _, _ = sess.input_2d(y, real)
-        check = on_device
+        check = on_device and bool(check_finite)
         if check:
             ctx.nonfinite_reset()
 
@@ -231,7 +234,22 @@ def vqt(y, *, sr=22050, hop_length=512, fmin=None, n_bins=84, intervals="equal",
         out_ptr, handle = sess.output((batch, n_frames, n_bins), cplx)
         d_ptr = None  # spectrum scratch of the unfused octaves (frame lengths beyond the fused kernel's), allocated on first need
         sqrt_len_ptr = table("sqrt_len", plan["sqrt_len"], np.float64) if plan["sqrt_len"] is not None else None
-        for i, o in enumerate(octaves):
+        # One native call for the whole recursion where every octave has a fused kernel and the halvings are FIR decimations (round 5: the Python
+        # loop below spent 0.26 ms in ~40 ctypes calls per transform, more than half of what the 13 launches take on the device)
+        native = NATIVE_RECURSION and FUSED_OCTAVES and res_type not in _SPECTRAL and hasattr(ctx, "cqt_recursion_exec") and all(ctx.cqt_octave_supported(o["n_fft"]) for o in octaves)
+        if native:
+            for i, o in enumerate(octaves):
+                if o["n_fft"] > lens[i]:
+                    warnings.warn(f"n_fft={o['n_fft']} is too large for input signal of length={lens[i]}", stacklevel=3)
+            arr = (_arrays._native.CqtOctave * len(octaves))()
+            for i, o in enumerate(octaves):
+                arr[i].n_fft, arr[i].hop, arr[i].bin0, arr[i].row0, arr[i].n_rows = o["n_fft"], o["hop"], o["bin0"], o["row0"], o["n_rows"]
+                arr[i].halve, arr[i].n = int(bool(o["halve"]) and i + 1 < len(octaves)), lens[i]
+                arr[i].row_ptr, arr[i].col, arr[i].val = table(f"row_ptr{i}", o["row_ptr"], np.int32), table(f"col{i}", o["col"], np.int32), table(f"val{i}", o["val"], cplx)
+            need = sum(-(-batch * lens[i + 1] * real.itemsize // 256) * 256 for i in range(len(octaves) - 1) if arr[i].halve)
+            taps_ptr, n_taps, first = decimator(2) if need else (None, 0, 0)
+            ctx.cqt_recursion_exec(y_ptr, batch, arr, pad_mode, sqrt_len_ptr, out_ptr, n_frames, n_bins, taps_ptr, n_taps, first, sess.scratch(need) if need else None, need, OVERLAP_OCTAVES, real)
+        for i, o in enumerate(octaves if not native else ()):
             n_fft, hop = o["n_fft"], o["hop"]
             if n_fft > lens[i]:   # the warning of the reference's stft (core/spectrum.py:267-271), once per octave it applies to
                 warnings.warn(f"n_fft={n_fft} is too large for input signal of length={lens[i]}", stacklevel=3)
@@ -254,9 +272,9 @@ def vqt(y, *, sr=22050, hop_length=512, fmin=None, n_bins=84, intervals="equal",
                 ctx.side(ctx.SIDE_BACK)
             if o["halve"]:
                 y_ptr = shorten(y_ptr, lens[i], lens[i + 1], 2, 1.0)
-        if OVERLAP_OCTAVES:
+        if OVERLAP_OCTAVES and not native:
             ctx.side(ctx.SIDE_JOIN)
-            overlapped = False
+        overlapped = False
         if check and ctx.nonfinite_read() and not _all_finite(y):
             raise ParameterError("Audio buffer is not finite everywhere")
         res = sess.result(handle)
@@ -268,7 +286,7 @@ def vqt(y, *, sr=22050, hop_length=512, fmin=None, n_bins=84, intervals="equal",
 
 
 def cqt(y, *, sr=22050, hop_length=512, fmin=None, n_bins=84, bins_per_octave=12, tuning=0.0, filter_scale=1, norm=1, sparsity=0.01, window="hann", scale=True,
-        pad_mode="constant", res_type="soxr_hq", dtype=None):
+        pad_mode="constant", res_type="soxr_hq", dtype=None, check_finite=True):
     """Constant-Q transform; drop-in for ``librosa.cqt`` (``librosa/core/constantq.py:42-225``): the ``gamma=0`` case of :func:`vqt`."""
     return vqt(y, sr=sr, hop_length=hop_length, fmin=fmin, n_bins=n_bins, intervals="equal", gamma=0, bins_per_octave=bins_per_octave, tuning=tuning, filter_scale=filter_scale,
-               norm=norm, sparsity=sparsity, window=window, scale=scale, pad_mode=pad_mode, res_type=res_type, dtype=dtype)
+               norm=norm, sparsity=sparsity, window=window, scale=scale, pad_mode=pad_mode, res_type=res_type, dtype=dtype, check_finite=check_finite)

@@ -2604,6 +2604,54 @@ int lra_cqt_octave_exec(lra_ctx* ctx, const void* y, int64_t batch, int64_t n, i
     return LRA_OK;
 }
 
+int lra_cqt_recursion_exec(lra_ctx* ctx, const void* y, int64_t batch, const lra_cqt_octave* octaves, int n_octaves, int pad_mode, const void* sqrt_len, void* out, int64_t n_frames,
+                           int n_total, const void* taps, int n_taps, int first, void* scratch, int64_t scratch_bytes, int overlap, int dtype) {
+    if (!ctx) return fail(LRA_EINVAL, "null context");
+    if (n_octaves < 0 || (n_octaves > 0 && !octaves)) return fail(LRA_EINVAL, "cqt_recursion: null octave list");
+    if (dtype != LRA_F32 && dtype != LRA_F64) return fail(LRA_EINVAL, "cqt_recursion: dtype must be LRA_F32 or LRA_F64");
+    const int64_t es = dtype == LRA_F64 ? 8 : 4;
+    // the decimated signals live side by side in `scratch` (each until the call's join: its octave transform runs on the side stream)
+    int64_t need = 0;
+    for (int i = 0; i + 1 < n_octaves; ++i)
+        if (octaves[i].halve) {
+            if (octaves[i + 1].n != (octaves[i].n + 1) / 2) return fail(LRA_EINVAL, "cqt_recursion: a halved octave has ceil(n / 2) samples");
+            need += ((batch * octaves[i + 1].n * es + 255) / 256) * 256;
+        } else if (octaves[i + 1].n != octaves[i].n) {
+            return fail(LRA_EINVAL, "cqt_recursion: octaves without a halving in between share their signal");
+        }
+    if (need > scratch_bytes || (need > 0 && (!scratch || !taps))) return fail(LRA_EINVAL, "cqt_recursion: scratch too small / null");
+    for (int i = 0; i < n_octaves; ++i)
+        if (!lra_cqt_octave_supported(octaves[i].n_fft)) return fail(LRA_EINVAL, "cqt_recursion: frame length outside the fused octave kernel's list");
+    const char* cur = (const char*)y;
+    char* next = (char*)scratch;
+    const double sc = std::sqrt(0.5);
+    const double* sl = (const double*)sqrt_len;
+    int rc = LRA_OK;
+    bool forked = false;
+    for (int i = 0; i < n_octaves && rc == LRA_OK; ++i) {
+        const lra_cqt_octave& o = octaves[i];
+        // the octave's transform on the side stream (behind the halving that made its signal), the next halving on the main stream
+        if (overlap) { rc = lra_ctx_side(ctx, LRA_SIDE_FORK); forked = rc == LRA_OK; }
+        if (rc == LRA_OK)
+            rc = lra_cqt_octave_exec(ctx, cur, batch, o.n, o.n, o.n_fft, o.hop, pad_mode, o.row_ptr, o.col, o.val, sl ? sl + o.bin0 : nullptr, out, n_frames, n_total, o.bin0, o.row0, o.n_rows, dtype);
+        if (forked) {
+            const int rb = lra_ctx_side(ctx, LRA_SIDE_BACK);
+            forked = false;
+            if (rc == LRA_OK) rc = rb;
+        }
+        if (rc == LRA_OK && o.halve && i + 1 < n_octaves) {
+            rc = lra_fir_decimate_exec(ctx, cur, next, batch, o.n, octaves[i + 1].n, taps, n_taps, 2, first, sc, 1.0, dtype);
+            cur = next;
+            next += ((batch * octaves[i + 1].n * es + 255) / 256) * 256;
+        }
+    }
+    if (overlap) {
+        const int rj = lra_ctx_side(ctx, rc == LRA_OK ? LRA_SIDE_JOIN : LRA_SIDE_END);
+        if (rc == LRA_OK) rc = rj;
+    }
+    return rc;
+}
+
 int lra_magnitude_exec(lra_ctx* ctx, const void* D, void* mag, int64_t count, int dtype) {
     LRA_BIND(ctx);
     if (count <= 0) return LRA_OK;

@@ -1750,6 +1750,39 @@ def test_cqt_side_stream_overlap(L):
         constantq.FUSED_OCTAVES = constantq.OVERLAP_OCTAVES = True
 
 
+@pytest.mark.parametrize("overlap", [True, False])
+def test_cqt_native_recursion_equals_python_loop(L, monkeypatch, overlap):
+    """Round 5: the octave recursion as ONE native call (lra_cqt_recursion_exec) against the per-octave calls from Python: bit-identical for cqt and vqt,
+    odd lengths (ceil halving), partial lowest octave, stereo, float64, NumPy and device input, with and without the side stream; check_finite=False
+    skips only the flag read."""
+    import torch
+    from librosa_amd.core import constantq
+
+    monkeypatch.setattr(constantq, "OVERLAP_OCTAVES", overlap)
+    cases = [dict(y=golden_cases.make_signal("mix", 40001, 3, (2,), "float32"), kw=dict(sr=22050, res_type="polyphase")),
+             dict(y=golden_cases.make_signal("chirp", 30000, 4, (), "float32"), kw=dict(sr=22050, n_bins=40, bins_per_octave=12, hop_length=256, res_type="kaiser_fast")),
+             dict(y=golden_cases.make_signal("mix", 25000, 5, (3,), "float64"), kw=dict(sr=16000, n_bins=60, fmin=55.0, res_type="polyphase"))]
+    for c in cases:
+        for dev in (False, True):
+            y = torch.from_numpy(c["y"]).cuda() if dev else c["y"]
+            monkeypatch.setattr(constantq, "NATIVE_RECURSION", False)
+            a = L.cqt(y, **c["kw"])
+            av = L.vqt(y, gamma=5.0, **c["kw"])
+            monkeypatch.setattr(constantq, "NATIVE_RECURSION", True)
+            b = L.cqt(y, **c["kw"])
+            bv = L.vqt(y, gamma=5.0, **c["kw"])
+            if dev:
+                assert torch.equal(a, b) and torch.equal(av, bv)
+                assert torch.equal(L.cqt(y, check_finite=False, **c["kw"]), b)
+            else:
+                assert np.array_equal(a, b) and np.array_equal(av, bv)
+    bad = torch.from_numpy(cases[0]["y"]).cuda()
+    bad[1, 777] = float("nan")
+    with pytest.raises(L.ParameterError):
+        L.cqt(bad, **cases[0]["kw"])
+    L.cqt(bad, check_finite=False, **cases[0]["kw"])  # opt-out does not raise
+
+
 def test_cqt_many_short_octaves_fork_ring(L, monkeypatch):
     """every octave forks the side stream; each fork now takes its own event out of a ring (16 slots, reused only once the side
     stream is past its wait).  Many short calls with many octaves -- several times round the ring, poisoned outputs, no synchronisation in
