@@ -369,6 +369,10 @@ int lra_probe_stream(lra_ctx* ctx, int direction, const void* in, void* out, int
 int lra_probe_stream_pitched(lra_ctx* ctx, int direction, const void* in, void* out, int64_t batch, int64_t rows_per_clip, int n_fft, int hop, int64_t clip_samples,
                              int strip_rows, int waves_per_cu, int64_t row_pitch_bytes, int piece_bytes);
 
+/* ... the forward stream with strips of `strip_rows` rows dealt out in address order to n_cu x waves_per_cu persistent waves (all of them writing
+ * inside one moving window of the result): the locality experiment of profiles/r05_pitch.md. */
+int lra_probe_stream_window(lra_ctx* ctx, const void* in, void* out, int64_t batch, int64_t rows_per_clip, int n_fft, int hop, int64_t clip_samples, int strip_rows, int waves_per_cu);
+
 /* ---- layout helper: dst[b][c][r] = src[b][r][c], elem_bytes in {4, 8, 16} ------------------ */
 int lra_transpose(lra_ctx* ctx, const void* src, void* dst, int64_t batch, int64_t rows, int64_t cols, int elem_bytes);
 

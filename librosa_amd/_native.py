@@ -72,6 +72,7 @@ SIGNATURES = {
     "lra_transpose": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int]),
     "lra_probe_stream": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int64, c_int, c_int]),
     "lra_cqt_recursion_exec": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_void_p, c_int64, c_int, c_int]),
+    "lra_probe_stream_window": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int64, c_int, c_int]),
     "lra_pcg64_random_exec": (c_int, [c_void_p, POINTER(ctypes.c_uint64), ctypes.c_uint64, c_void_p, c_int64]),
     "lra_griffinlim_init_pcg64": (c_int, [c_void_p, POINTER(ctypes.c_uint64), c_void_p, c_void_p, c_int64, c_int, c_int64, c_int]),
     "lra_probe_stream_pitched": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int64, c_int, c_int, c_int64, c_int]),
@@ -525,6 +526,10 @@ class Context:
         """The transform's access stream without its arithmetic (measurement aid; ``include/librosa_amd.h``)."""
         _check(self.lib.lra_probe_stream_pitched(self.handle, int(direction), c_void_p(in_ptr), c_void_p(out_ptr), batch, rows_per_clip, n_fft, hop, clip_samples, strip_rows, waves_per_cu,
                                                  int(row_pitch_bytes), int(piece_bytes)))
+
+    def probe_stream_window(self, in_ptr, out_ptr, batch, rows_per_clip, n_fft, hop, clip_samples, strip_rows, waves_per_cu):
+        """The forward access stream with the strips dealt out in address order to persistent waves (``include/librosa_amd.h``)."""
+        _check(self.lib.lra_probe_stream_window(self.handle, c_void_p(in_ptr), c_void_p(out_ptr), batch, rows_per_clip, n_fft, hop, clip_samples, int(strip_rows), int(waves_per_cu)))
 
     def transpose(self, src_ptr, dst_ptr, batch, rows, cols, elem_bytes):
         _check(self.lib.lra_transpose(self.handle, c_void_p(src_ptr), c_void_p(dst_ptr), batch, rows, cols, elem_bytes))

@@ -2834,6 +2834,35 @@ int lra_probe_stream_pitched(lra_ctx* ctx, int direction, const void* in, void* 
     return LRA_OK;
 }
 
+int lra_probe_stream_window(lra_ctx* ctx, const void* in, void* out, int64_t batch, int64_t rows_per_clip, int n_fft, int hop, int64_t clip_samples, int strip_rows, int waves_per_cu) {
+    LRA_BIND(ctx);
+    if (batch <= 0 || rows_per_clip <= 0) return LRA_OK;
+    if (!in || !out) return fail(LRA_EINVAL, "null data pointer");
+    const int M = n_fft / 2;
+    if (n_fft < 256 || n_fft > 2048 || M % 128 != 0) return fail(LRA_EINVAL, "probe: n_fft must be 256 ... 2048, a multiple of 256");
+    if (hop <= 0 || hop > 1024 || hop % 128 != 0) return fail(LRA_EINVAL, "probe: hop must be a multiple of 128, at most 1024");
+    if (strip_rows < 1 || waves_per_cu < 1 || waves_per_cu > 32) return fail(LRA_EINVAL, "probe: strip_rows >= 1, 1 <= waves_per_cu <= 32");
+    ProbeArgs a;
+    a.in = (const char*)in;
+    a.out = (char*)out;
+    a.clip_in_bytes = (long long)clip_samples * 4;
+    a.rows_per_clip = (int)rows_per_clip;
+    a.strip_rows = strip_rows;
+    a.n_clips = (int)batch;
+    a.bins = M + 1;
+    a.row_pitch = (long long)(M + 1) * 8;
+    a.hop_bytes = hop * 4;
+    const long long pcm_rows = clip_samples / hop;
+    a.pcm_rows = (int)(pcm_rows < rows_per_clip ? pcm_rows : rows_per_clip);
+    a.xcd_chunk = 0;
+    const int n_workers = ctx->n_cu * waves_per_cu;
+    const int lds = waves_per_cu >= 32 ? 0 : ((160 * 1024 / waves_per_cu) & ~255);
+    if (lds > 65536) LRA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stream_probe_window_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL(stream_probe_window_kernel, dim3((unsigned)n_workers), dim3(64), lds, ctx->stream, a, (long long)batch * rows_per_clip, n_workers);
+    LRA_HIP(hipGetLastError());
+    return LRA_OK;
+}
+
 int lra_transpose(lra_ctx* ctx, const void* src, void* dst, int64_t batch, int64_t rows, int64_t cols, int elem_bytes) {
     LRA_BIND(ctx);
     if (batch <= 0 || rows <= 0 || cols <= 0) return LRA_OK;

@@ -120,4 +120,43 @@ template <int DIR, bool P16> __global__ __launch_bounds__(64) void stream_probe_
     }
 }
 
+// Round 5: the forward stream with the strips dealt out in ADDRESS ORDER to a fixed set of persistent waves -- worker w takes strips w, w + W, w + 2 W ... of
+// `strip_rows` consecutive rows over the flattened (clip, row) range -- so that at any moment all W waves write inside one moving window of
+// W x strip_rows x row_pitch bytes instead of 2 048 strips spread over the whole 2.7 GB result.  Question behind it (profiles/r05_pitch.md): is what makes
+// some allocations slow the number of distinct pages / DRAM rows the concurrent strips touch?
+__global__ __launch_bounds__(64) void stream_probe_window_kernel(ProbeArgs a, long long total_rows, int n_workers) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    extern __shared__ char probe_pad2[];
+    const int lane = threadIdx.x;
+    const int M = a.bins - 1, pieces = M / 128, pcm8 = a.hop_bytes / 512;
+    f2 v = {(float)lane, (float)blockIdx.x};
+    const long long n_strips = (total_rows + a.strip_rows - 1) / a.strip_rows;
+    for (long long s = blockIdx.x; s < n_strips; s += n_workers) {
+        const long long r0 = s * a.strip_rows;
+        const long long r1 = r0 + a.strip_rows < total_rows ? r0 + a.strip_rows : total_rows;
+        f2 cur[8], nx[8];
+        for (int c = 0; c < 8; ++c) cur[c] = v;
+        for (long long g = r0; g < r1; ++g) {
+            const long long clip = g / a.rows_per_clip;
+            const int row = (int)(g % a.rows_per_clip);
+            for (int c = 0; c < 8; ++c) nx[c] = cur[c];
+            if (row + 1 < a.pcm_rows) {
+                const f2* src = reinterpret_cast<const f2*>(a.in + clip * a.clip_in_bytes + (long long)(row + 1) * a.hop_bytes) + lane;
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if (c < pcm8) nx[c] = src[c * 64];
+            }
+            v.x += cur[0].x + cur[7].y;
+            f2* rp = reinterpret_cast<f2*>(a.out + g * a.row_pitch);
+            f2* pk = rp + lane;
+            f2* pm = rp + (M - lane);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < pieces) { pk[i * 64] = v; pm[-i * 64] = v; }
+            if (lane == 0) rp[M / 2] = v;
+            for (int c = 0; c < 8; ++c) cur[c] = nx[c];
+        }
+    }
+}
+
 }  // namespace lra

@@ -243,3 +243,21 @@ if "variant" in what:  # one library build per process (LIBROSA_AMD_LIBRARY): th
                 ref = view
             row.append(f"kernel wide {wide}: {ms:.3f} ({'==' if torch.equal(view, ref) else 'MISMATCH'})")
         print(f"variant {os.environ.get('LIBROSA_AMD_LIBRARY', 'product')} pitch {pitch}: " + "  ".join(row), flush=True)
+
+if "window" in what:  # concurrent strips inside one moving window (persistent waves, strips dealt in address order) vs the kernels' long private strips, several allocations
+    n_fft, hop, bins = 2048, 512, 1025
+    w = np.asarray(filters.get_window("hann", n_fft, fftbins=True), dtype=np.float32)
+    pl = ctx.stft_plan(n_fft, hop, w, True, "constant", np.float32)
+    T = ctx.stft_num_frames(pl, n)
+    by = batch * T * (bins * 8 + hop * 4)
+    held = []
+    for trial in range(5):
+        keep, dptr = aligned_buffer(batch * T * bins * 8 + trial * (3 << 20), align=1 << 21)
+        held.append(keep)
+        row = [f"kernel {timeit(lambda: ctx.stft_exec(pl, y.data_ptr(), batch, n, n, dptr), steps=15, prewarm=0.2):.3f}",
+               f"strips(162, 12/CU) {timeit(lambda: ctx.probe_stream(0, y.data_ptr(), dptr, batch, T, n_fft, hop, n, 162, 12), steps=15, prewarm=0.1):.3f}"]
+        for strip in (2, 4, 8, 16, 32):
+            for wpc in (8, 12, 16):
+                ms = timeit(lambda: ctx.probe_stream_window(y.data_ptr(), dptr, batch, T, n_fft, hop, n, strip, wpc), steps=15, prewarm=0.1)
+                row.append(f"win({strip},{wpc}) {ms:.3f}")
+        print(f"window allocation {trial}: " + "  ".join(row), flush=True)

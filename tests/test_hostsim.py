@@ -931,7 +931,7 @@ def test_hpss_shims_through_simulator(monkeypatch):
     # effects: the shim's own chaining (which istft arguments, which component), transforms by the oracle
     monkeypatch.setattr(_arrays, "Session", _SimSession)
     monkeypatch.setattr(effects, "_stage", lambda a: (a, False))
-    monkeypatch.setattr(spectrum, "stft", lambda a, check_finite=True, **kw: O.stft(a, **kw))
+    monkeypatch.setattr(spectrum, "stft", lambda a, check_finite=True, row_align=None, **kw: O.stft(a, **kw))
     monkeypatch.setattr(spectrum, "istft", lambda a, **kw: O.istft(np.ascontiguousarray(a), **kw))
     for kw in (dict(n_fft=512), dict(n_fft=256, hop_length=64, margin=(1.0, 3.0), kernel_size=(9, 17)), dict(n_fft=256, window="hamming", win_length=200)):
         eh, ep = O.effects_hpss(y, **kw)
