@@ -79,6 +79,7 @@ struct lra_ctx {
     int opt_generic_mel = 0;         // force the generic banded mel path (tests)
     int opt_lds_pad = 0;             // extra dynamic LDS per workgroup (occupancy experiments)
     int opt_v2 = 1;                  // second-generation forward kernel where it applies (lra_kernels2.h)
+    int opt_cqt_merge = 1;           // lra_cqt_recursion_exec: octaves 1 .. in one launch per frame length behind the chain of halvings (0: one launch per octave on the side stream)
     int opt_hpss_tile = 1;           // hpss: a thread per 4 x 4 tile with shared sorted cores (hpss_tile_kernel); 0: a thread per element (A/B)
     int opt_mixed_inv_pow2 = 1;      // inverse, n_fft = 256 / 512 / 1024 with a hop outside n_fft / {2, 4, 8, 16}: the fused gather kernel of lra_mixed.h (0: istft_kernel's general mode)
     int opt_mixed = 1;               // fused mixed-radix forward kernel for the listed non-power-of-two frame lengths (lra_mixed.h); 0: rocFFT path
@@ -1635,6 +1636,7 @@ int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value) {
     else if (!std::strcmp(key, "lds_pad")) ctx->opt_lds_pad = value;
     else if (!std::strcmp(key, "xcd_remap")) ctx->opt_xcd_remap = value != 0;
     else if (!std::strcmp(key, "v2")) ctx->opt_v2 = value != 0;
+    else if (!std::strcmp(key, "cqt_merge")) ctx->opt_cqt_merge = value != 0;
     else if (!std::strcmp(key, "direct")) ctx->opt_direct = value != 0;
     else if (!std::strcmp(key, "mixed")) ctx->opt_mixed = value != 0;
     else if (!std::strcmp(key, "hpss_tile")) ctx->opt_hpss_tile = value != 0;
@@ -2604,6 +2606,47 @@ int lra_cqt_octave_exec(lra_ctx* ctx, const void* y, int64_t batch, int64_t n, i
     return LRA_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// octaves [i0, i1) of one transform -- same frame length, each on its own (already decimated) signal ys[i] -- in ONE launch (mixed_cqt_multi_kernel)
+template <class T>
+int cqt_octaves_merged(lra_ctx* ctx, const lra_cqt_octave* octaves, const char* const* ys, int i0, int i1, int64_t batch, int pad_mode, const double* sqrt_len, void* out, int64_t n_frames,
+                       int n_total, int dtype) {
+    const int n_fft = octaves[i0].n_fft;
+    auto& tw = ctx->cqt_tw[std::make_pair(n_fft, dtype)];
+    if (!tw.first) LRA_TRY(mixed_tables(n_fft, dtype, &tw.first, &tw.second));
+    const int F = mixed::cqt_frames_per_group_of(n_fft, (int)sizeof(T));
+    mixed::CqtMultiArgs<T> m = mixed::CqtMultiArgs<T>();
+    m.n_oct = 0;
+    const int groups = (int)((n_frames + F - 1) / F);
+    if ((long long)batch * groups > 0x7fffffffLL) return fail(LRA_EINVAL, "cqt: too many workgroups");
+    m.blocks_per_octave = (unsigned)(batch * groups);
+    for (int i = i0; i < i1; ++i) {
+        const lra_cqt_octave& o = octaves[i];
+        if (o.n_rows == 0) continue;
+        if (o.hop < 1 || o.bin0 < 0 || o.row0 < 0 || o.n_rows < 0 || o.bin0 + o.n_rows > n_total) return fail(LRA_EINVAL, "cqt_octave: the octave's rows must fit the stacked result");
+        if (!o.row_ptr || !o.col || !o.val) return fail(LRA_EINVAL, "null data pointer");
+        if (n_frames > 1 + o.n / o.hop) return fail(LRA_EINVAL, "cqt_octave: more frames than the centred signal has");
+        mixed::CqtArgs<T>& a = m.oct[m.n_oct++];
+        a.y = (const T*)ys[i]; a.y_stride = o.n; a.n = o.n; a.hop = o.hop; a.pad = n_fft / 2; a.pad_mode = pad_mode;
+        a.tw_m = (const mixed::cpx<T>*)tw.first; a.tw_n = (const mixed::cpx<T>*)tw.second;
+        a.row_ptr = (const int*)o.row_ptr; a.col = (const int*)o.col; a.val = (const mixed::cpx<T>*)o.val; a.sqrt_len = sqrt_len ? sqrt_len + o.bin0 : nullptr;
+        a.out = (mixed::cpx<T>*)out; a.n_frames = (int)n_frames; a.n_total = n_total; a.bin0 = o.bin0; a.row0 = o.row0; a.n_rows = o.n_rows;
+        a.groups_per_clip = groups;
+        a.nonfinite_flag = ctx->d_flag;
+    }
+    if (m.n_oct == 0) return LRA_OK;
+    hipError_t e;
+    if constexpr (sizeof(T) == 8) e = mixed::launch_cqt_multi_f64(n_fft, m, ctx->stream);
+    else e = mixed::launch_cqt_multi_f32(n_fft, m, ctx->stream);
+    if (e != hipSuccess) return fail(LRA_EHIP, std::string("cqt merged octave kernel launch: ") + hipGetErrorString(e));
+    return LRA_OK;
+}
+}  // namespace
+
+extern "C" {
+
 int lra_cqt_recursion_exec(lra_ctx* ctx, const void* y, int64_t batch, const lra_cqt_octave* octaves, int n_octaves, int pad_mode, const void* sqrt_len, void* out, int64_t n_frames,
                            int n_total, const void* taps, int n_taps, int first, void* scratch, int64_t scratch_bytes, int overlap, int dtype) {
     if (!ctx) return fail(LRA_EINVAL, "null context");
@@ -2628,6 +2671,37 @@ int lra_cqt_recursion_exec(lra_ctx* ctx, const void* y, int64_t batch, const lra
     const double* sl = (const double*)sqrt_len;
     int rc = LRA_OK;
     bool forked = false;
+    if (overlap && ctx->opt_cqt_merge && n_octaves >= 3 && n_octaves <= 1 + mixed::kCqtMaxMerged && n_frames > 0 && batch > 0 && n_frames <= 0x7fffffffLL / 4) {
+        // Merged form: the first octave on the side stream beside the chain of halvings, then every further octave in one launch per run of equal frame
+        // lengths (their decimated signals all exist by then): the octaves' latency-bound launches overlap instead of queueing up on the side stream.
+        LRA_BIND(ctx);
+        std::vector<const char*> ys((size_t)n_octaves);
+        ys[0] = cur;
+        rc = lra_ctx_side(ctx, LRA_SIDE_FORK);
+        if (rc == LRA_OK) {
+            const lra_cqt_octave& o = octaves[0];
+            rc = lra_cqt_octave_exec(ctx, cur, batch, o.n, o.n, o.n_fft, o.hop, pad_mode, o.row_ptr, o.col, o.val, sl ? sl + o.bin0 : nullptr, out, n_frames, n_total, o.bin0, o.row0, o.n_rows, dtype);
+            const int rb = lra_ctx_side(ctx, LRA_SIDE_BACK);
+            if (rc == LRA_OK) rc = rb;
+        }
+        for (int i = 0; i + 1 < n_octaves && rc == LRA_OK; ++i) {
+            if (octaves[i].halve) {
+                rc = lra_fir_decimate_exec(ctx, cur, next, batch, octaves[i].n, octaves[i + 1].n, taps, n_taps, 2, first, sc, 1.0, dtype);
+                cur = next;
+                next += ((batch * octaves[i + 1].n * es + 255) / 256) * 256;
+            }
+            ys[(size_t)i + 1] = cur;
+        }
+        for (int i0 = 1; i0 < n_octaves && rc == LRA_OK;) {
+            int i1 = i0 + 1;
+            while (i1 < n_octaves && octaves[i1].n_fft == octaves[i0].n_fft) ++i1;
+            rc = dtype == LRA_F64 ? cqt_octaves_merged<double>(ctx, octaves, ys.data(), i0, i1, batch, pad_mode, sl, out, n_frames, n_total, dtype)
+                                  : cqt_octaves_merged<float>(ctx, octaves, ys.data(), i0, i1, batch, pad_mode, sl, out, n_frames, n_total, dtype);
+            i0 = i1;
+        }
+        const int rj = lra_ctx_side(ctx, rc == LRA_OK ? LRA_SIDE_JOIN : LRA_SIDE_END);
+        return rc == LRA_OK ? rj : rc;
+    }
     for (int i = 0; i < n_octaves && rc == LRA_OK; ++i) {
         const lra_cqt_octave& o = octaves[i];
         // the octave's transform on the side stream (behind the halving that made its signal), the next halving on the main stream

@@ -365,13 +365,12 @@ template <class T> __device__ __forceinline__ cpx<T> cmadd_exact(cpx<T> acc, cpx
 }
 #pragma clang fp contract(fast)
 
-template <class T, int N> __global__ __launch_bounds__(NT) void mixed_cqt_kernel(CqtArgs<T> a) {
+template <class T, int N> __device__ __forceinline__ void cqt_octave_body(const CqtArgs<T>& a, unsigned block, char* lds) {
     constexpr int M = N / 2, MP = M + 1, F = cqt_frames_per_group<T, N>(), HP = M / 2 + 1;
-    LRA_MIXED_DYN_LDS(lds);
     cpx<T>* buf0 = reinterpret_cast<cpx<T>*>(lds);
     cpx<T>* buf1 = buf0 + F * MP;
     cpx<T>* twm = buf1 + F * MP;
-    const int clip = (int)(blockIdx.x / (unsigned)a.groups_per_clip), group = (int)(blockIdx.x % (unsigned)a.groups_per_clip);
+    const int clip = (int)(block / (unsigned)a.groups_per_clip), group = (int)(block % (unsigned)a.groups_per_clip);
     const int f0 = group * F;
     const int frames = a.n_frames - f0 < F ? a.n_frames - f0 : F;
     const T* __restrict__ yb = a.y + (long long)clip * a.y_stride;
@@ -418,6 +417,27 @@ template <class T, int N> __global__ __launch_bounds__(NT) void mixed_cqt_kernel
         }
         a.out[((long long)clip * a.n_frames + f0 + f) * a.n_total + a.bin0 + r] = acc;
     }
+}
+
+template <class T, int N> __global__ __launch_bounds__(NT) void mixed_cqt_kernel(CqtArgs<T> a) {
+    LRA_MIXED_DYN_LDS(lds);
+    cqt_octave_body<T, N>(a, blockIdx.x, lds);
+}
+
+// Several octaves of one transform in ONE launch (round 5): they share the frame length and the frame grid (every octave has n_frames frames, its hop halving with
+// its signal), differ in signal, hop and basis rows, and are independent once their decimated signals exist.  As seven launches their ~50 us floors (a short
+// latency-bound kernel each: global loads, five barrier-separated stages, a CSR walk) add up to 0.4 of the transform's 0.66 ms; side by side they overlap.
+constexpr int kCqtMaxMerged = 8;
+template <class T> struct CqtMultiArgs {
+    CqtArgs<T> oct[kCqtMaxMerged];
+    int n_oct;
+    unsigned blocks_per_octave;  // batch x groups_per_clip (the same for every octave)
+};
+template <class T, int N> __global__ __launch_bounds__(NT) void mixed_cqt_multi_kernel(CqtMultiArgs<T> m) {
+    LRA_MIXED_DYN_LDS(lds);
+    const unsigned o = blockIdx.x / m.blocks_per_octave;
+    if ((int)o >= m.n_oct) return;
+    cqt_octave_body<T, N>(m.oct[o], blockIdx.x - o * m.blocks_per_octave, lds);
 }
 
 // =====================================================================================================================================

@@ -80,6 +80,31 @@ template <class T> hipError_t launch_cqt_t(int n_fft, const CqtArgs<T>& a, long 
         default: return hipErrorInvalidValue;
     }
 }
+template <class T, int N> hipError_t launch_cqt_multi_n(const CqtMultiArgs<T>& m, hipStream_t stream) {
+    constexpr int lds = cqt_lds_bytes<T, N>();
+    const long long grid = (long long)m.blocks_per_octave * m.n_oct;
+    if (grid <= 0) return hipSuccess;
+    if (grid > 0x7ffffff0LL) return hipErrorInvalidConfiguration;
+    void (*kern)(CqtMultiArgs<T>) = mixed_cqt_multi_kernel<T, N>;
+    if (lds > 65536) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, m);
+    return hipGetLastError();
+}
+template <class T> hipError_t launch_cqt_multi_t(int n_fft, const CqtMultiArgs<T>& m, hipStream_t stream) {
+    switch (n_fft) {
+#define LRA_MIXED_CASE(N) \
+    case N: return launch_cqt_multi_n<T, N>(m, stream);
+        LRA_CQT_SIZES(LRA_MIXED_CASE)
+#undef LRA_MIXED_CASE
+        default: return hipErrorInvalidValue;
+    }
+}
+hipError_t launch_cqt_multi_f32(int n_fft, const CqtMultiArgs<float>& m, hipStream_t stream) { return launch_cqt_multi_t<float>(n_fft, m, stream); }
+hipError_t launch_cqt_multi_f64(int n_fft, const CqtMultiArgs<double>& m, hipStream_t stream) { return launch_cqt_multi_t<double>(n_fft, m, stream); }
+
 int cqt_frames_per_group_of(int n_fft, int elem_bytes) {
     switch (n_fft) {
 #define LRA_MIXED_CASE(N) \

@@ -51,6 +51,8 @@ hipError_t launch_f64(int n_fft, int mode, const Args<double>& a, long long batc
 int cqt_frames_per_group_of(int n_fft, int elem_bytes);
 hipError_t launch_cqt_f32(int n_fft, const CqtArgs<float>& a, long long batch, hipStream_t stream);
 hipError_t launch_cqt_f64(int n_fft, const CqtArgs<double>& a, long long batch, hipStream_t stream);
+hipError_t launch_cqt_multi_f32(int n_fft, const CqtMultiArgs<float>& m, hipStream_t stream);
+hipError_t launch_cqt_multi_f64(int n_fft, const CqtMultiArgs<double>& m, hipStream_t stream);
 int inv_frames_max_of(int n_fft, int elem_bytes);  // frames (own + halo) the inverse kernel holds per workgroup
 hipError_t launch_inv_f32(int n_fft, const InvArgs<float>& a, long long batch, hipStream_t stream);
 hipError_t launch_inv_f64(int n_fft, const InvArgs<double>& a, long long batch, hipStream_t stream);

@@ -261,3 +261,29 @@ if "window" in what:  # concurrent strips inside one moving window (persistent w
                 ms = timeit(lambda: ctx.probe_stream_window(y.data_ptr(), dptr, batch, T, n_fft, hop, n, strip, wpc), steps=15, prewarm=0.1)
                 row.append(f"win({strip},{wpc}) {ms:.3f}")
         print(f"window allocation {trial}: " + "  ".join(row), flush=True)
+
+if "iters" in what:  # frames per strip = the distance between concurrently written rows: does the rate depend on it (bank / channel conflicts between the strips)?
+    n_fft, hop, bins = 2048, 512, 1025
+    w = np.asarray(filters.get_window("hann", n_fft, fftbins=True), dtype=np.float32)
+    pl = ctx.stft_plan(n_fft, hop, w, True, "constant", np.float32)
+    T = ctx.stft_num_frames(pl, n)
+    held = []
+    for trial in range(3):
+        keep, dptr = aligned_buffer(batch * T * bins * 8 + trial * (3 << 20), align=1 << 21)
+        held.append(keep)
+        row = []
+        for iters in [0] + list(range(120, 181, 4)) + [185, 216, 259, 323]:
+            ctx.set_option("stft_iters", iters)
+            ms = timeit(lambda: ctx.stft_exec(pl, y.data_ptr(), batch, n, n, dptr), steps=10, prewarm=0.08)
+            row.append(f"{iters}:{ms:.3f}")
+        ctx.set_option("stft_iters", 0)
+        print(f"iters allocation {trial}: " + " ".join(row), flush=True)
+    # ... and the input side: clips a different distance apart (y_stride), same output buffer
+    dptr = held[0].data_ptr() + ((-held[0].data_ptr()) % (1 << 21))
+    row = []
+    for pad in (0, 4, 64, 1024, 2500, 4096):
+        yp = torch.zeros((batch, n + pad), dtype=torch.float32, device=dev)
+        yp[:, :n] = y
+        ms = timeit(lambda: ctx.stft_exec(pl, yp.data_ptr(), batch, n, n + pad, dptr), steps=10, prewarm=0.08)
+        row.append(f"+{pad}:{ms:.3f}")
+    print("iters input clip stride n + pad: " + " ".join(row), flush=True)
