@@ -287,3 +287,44 @@ if "iters" in what:  # frames per strip = the distance between concurrently writ
         ms = timeit(lambda: ctx.stft_exec(pl, yp.data_ptr(), batch, n, n + pad, dptr), steps=10, prewarm=0.08)
         row.append(f"+{pad}:{ms:.3f}")
     print("iters input clip stride n + pad: " + " ".join(row), flush=True)
+
+if "power" in what:  # socket power / shader clock (rocm-smi, 2.5 s into a loop) beside the rate of every pitch / piece combination, ONE buffer
+    import re, shutil, subprocess, threading
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    n_fft, hop, bins = 2048, 512, 1025
+    w = np.asarray(filters.get_window("hann", n_fft, fftbins=True), dtype=np.float32)
+    pl = ctx.stft_plan(n_fft, hop, w, True, "constant", np.float32)
+    T = ctx.stft_num_frames(pl, n)
+    by = batch * T * (bins * 8 + hop * 4)
+    keep, dptr = aligned_buffer(batch * T * 1056 * 8, align=1 << 21)
+    yr = torch.empty((batch, n), dtype=torch.float32, device=dev)
+
+    def sample(fn):
+        stop = threading.Event()
+        def feed():
+            while not stop.is_set():
+                for _ in range(200): fn()
+                torch.cuda.synchronize()
+        th = threading.Thread(target=feed, daemon=True); th.start()
+        try:
+            time.sleep(2.5)
+            txt = subprocess.run([smi, "--showpower", "--showclocks"], capture_output=True, text=True, timeout=30).stdout
+        finally:
+            stop.set(); th.join(timeout=30); torch.cuda.synchronize()
+        pw = re.search(r"Power \(W\):\s*([0-9.]+)", txt); ck = re.search(r"sclk clock level:\s*\S+\s*\((\d+)Mhz\)", txt)
+        return (float(pw.group(1)) if pw else None, int(ck.group(1)) if ck else None)
+
+    print("power: one buffer; ms per launch, GB/s algorithmic, socket W, sclk MHz", flush=True)
+    for pitch in (1025, 1032, 1040, 1056):
+        for direction, name, src, dst in ((0, "forward stream", y.data_ptr(), dptr), (1, "inverse stream", dptr, yr.data_ptr())):
+            for piece in (8, 16):
+                if piece == 16 and pitch % 2: continue
+                for wpc in (12, 16):
+                    fn = lambda: ctx.probe_stream(direction, src, dst, batch, T, n_fft, hop, n, 162, wpc, pitch * 8, piece)
+                    ms = timeit(fn, steps=15, prewarm=0.15)
+                    p_w, clk = sample(fn)
+                    print(f"power pitch {pitch * 8} B {name} piece {piece:2d} waves/CU {wpc}: {ms:.3f} ms {by / ms / 1e6:5.0f} GB/s {p_w} W {clk} MHz", flush=True)
+        fn = lambda: ctx.stft_exec_strided(pl, 0, y.data_ptr(), batch, n, n, 1.0, dptr, pitch)
+        ms = timeit(fn, steps=15, prewarm=0.15)
+        p_w, clk = sample(fn)
+        print(f"power pitch {pitch * 8} B stft kernel: {ms:.3f} ms {by / ms / 1e6:5.0f} GB/s {p_w} W {clk} MHz", flush=True)
