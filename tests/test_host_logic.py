@@ -450,3 +450,39 @@ def test_row_pitch_and_frame_major_strides():
     assert SP._frame_major_strides(torch.zeros((3, 1025, 7), dtype=torch.complex64).transpose(-1, -2), 1025) is None  # bin axis not contiguous
     assert SP._frame_major_strides(buf[:, :, ::2][..., :300], 300) is None
     assert SP._frame_major_strides(buf[0, :, :1025], 1025) == (7 * 1040, 1040)   # no leading axis
+
+
+def test_bench_compact_line_keeps_the_contract_and_fits():
+    """bench.py prints ONE short line (the driver's record truncates long ones): contract keys, roofline with the path's fractions folded in, cpu_baseline; <= 4 KB."""
+    import importlib.util
+    import json
+
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    prose = "x" * 700
+    full = {"metric": "STFT+mel frames/sec (n_fft=2048 hop=512)", "value": 5.8e8, "unit": "frames/s", "n_gpus": 1, "steps": 50, "warmup": 10, "ms_per_step": 0.56, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": prose, "frames_per_step_per_gpu": 330752, "clips_per_gpu": 256, "prewarm_ms": 400.0, "parallelism": prose, "device": "gfx950"},
+            "roofline": {"bound": "valu/lds", "kernel": "k", "achieved": 1500.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.1875, "traffic": 8.6e8, "traffic_box": "profile", "bytes_per_frame": 2560,
+                         "launch_ms": 0.56, "note": prose, "limited_by": prose},
+            "roofline_valu": {"frac": 0.24}, "roofline_stft": {"frac": 0.57, "launch_ms": 0.74, "traffic": 3.4e9, "achievable_note": prose},
+            "roofline_istft": {"frac": 0.6, "launch_ms": 0.71, "round_trip_snr_db_min": 136.5, "call_note": prose},
+            "stream_ceiling": {"forward": {"frac": 0.59}, "inverse": {"frac": 0.6}, "what": prose}, "cqt_lite": {"frac_of_hbm": 0.51, "ms_total": 3.6, "per_n_fft": {"512": {"ms": 0.3}, "8192": {"ms": 2.6}}},
+            "placement": {"allocations": 5, "stft_frac_best": 0.61, "stft_frac_worst": 0.56, "istft_frac_best": 0.62, "stft_ms": [0.7] * 5},
+            "cpu_baseline": {"value": 154615.4, "unit": "frames/s", "cores": 1, "kind": "reference", "sample": prose, "host": {"cpu_model": "EPYC"}},
+            "cpu_baseline_all_cores": {"value": 1.9e6, "cores": 64}, "parity": {"mel_max_rel_err_vs_reference": 5e-6, "oracle_equals_reference": True, "bar": 1e-4, "sample": prose},
+            "scaling_base": {"clips_per_gpu": 512, "value": 5.9e8, "unit": "frames/s", "ms_per_step": 1.12}, "repeats": {"ms_per_step_min": 0.55, "ms_per_step_median": 0.56, "ms_per_step_all": [0.56] * 5},
+            "griffinlim": {"ms_per_iteration": 0.43, "ms_setup": 0.5, "what": prose}, "hpss": {"error": "boom"}, "dropin_torch": {"ms_per_call": 0.57, "what": prose}}
+    line = bench.compact_line(full)
+    text = json.dumps(line)
+    assert len(text) <= 4096
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line
+    assert line["roofline"]["bound"] == "valu/lds" and line["roofline"]["frac"] == 0.1875
+    path = line["roofline"]["path"]
+    assert path["stft_frac"] == 0.57 and path["istft_frac"] == 0.6 and path["stream_forward_frac"] == 0.59 and path["stream_inverse_frac"] == 0.6 and path["cqt_lite_frac"] == 0.51
+    assert path["stft_frac_best_placement"] == 0.61 and path["placements"] == 5
+    assert line["cpu_baseline"]["kind"] == "reference" and line["cpu_baseline"]["cores"] == 1 and line["cpu_baseline"]["all_cores"] == 64
+    assert line["scaling_base"]["clips_per_gpu"] == 512 and line["side"]["griffinlim_ms_setup"] == 0.5 and line["side_errors"] == ["hpss"]
+    assert "workload" in line["config"] and len(line["config"]["workload"]) < 300
