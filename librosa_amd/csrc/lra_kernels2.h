@@ -74,6 +74,15 @@ template <class Cfg> LRA_HD int v2_hop_divisor(int hop) {
 #ifndef LRA_V2_PRIO_CA
 #define LRA_V2_PRIO_CA -1
 #endif
+// |X|^p epilogue (round 5): PA = window + transform passes, PS = un-split + power stores.  Same box, alternating, 256 x 30 s:
+// none 0.518-0.521 ms, 3 / 2 0.499-0.501, 3 / 0 0.498-0.499 (profiles/r05_raw/z_prio_power.txt); the complex kernel with the same pair: inside its
+// allocation-to-allocation spread, left alone.
+#ifndef LRA_V2_PRIO_PA
+#define LRA_V2_PRIO_PA 3
+#endif
+#ifndef LRA_V2_PRIO_PS
+#define LRA_V2_PRIO_PS 2
+#endif
 #ifndef LRA_V2_PRIO_CS
 #define LRA_V2_PRIO_CS -1
 #endif
@@ -597,7 +606,7 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
         if (f_first + it >= a.n_frames) break;  // slot 0 has the smallest frame index: uniform exit
         // Wave priority per phase (s_setprio; LRA_V2_PRIO_A: window + transform passes, _S: un-split + stores / power row, _B: mel epilogue;
         // -1 = leave alone).  profiles/r04_experiments.md 10.
-        v2_setprio<MODE == OUT_MELR ? LRA_V2_PRIO_A : LRA_V2_PRIO_CA>();
+        v2_setprio<MODE == OUT_MELR ? LRA_V2_PRIO_A : (MODE == OUT_POWER ? LRA_V2_PRIO_PA : LRA_V2_PRIO_CA)>();
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
             RG& r = LRA_R(rg);
@@ -630,7 +639,7 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
         LRA_PHASE(Cfg::NT, tid) {
             v2_last_read<Cfg, HD>(LRA_R(rg), lds_sub(lds, slot_of<Cfg>(tid) * SB), lane_of<Cfg>(tid));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC || (LRA_SPLIT_ONE_BARRIER && MODE != OUT_MELR && !STAGED))  // (registers -> HBM next: see stft_block)
-        v2_setprio<MODE == OUT_MELR ? LRA_V2_PRIO_S : LRA_V2_PRIO_CS>();
+        v2_setprio<MODE == OUT_MELR ? LRA_V2_PRIO_S : (MODE == OUT_POWER ? LRA_V2_PRIO_PS : LRA_V2_PRIO_CS)>();
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
             v2_last_split_store<Cfg, HD, MODE, PM, STAGED>(a, clip, frame, frame < a.n_frames, tf, LRA_R(rg), lds_sub(lds, slot * SB));

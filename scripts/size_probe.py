@@ -40,6 +40,9 @@ elif what == "mel":
     mp = ctx.mel_plan(filters.mel(sr=22050, n_fft=n_fft, n_mels=n_mels))
     Mo = torch.empty((batch, n_mels, T), dtype=torch.float32, device=dev)
     fn = lambda: ctx.melspectrogram_exec(pl, mp, y.data_ptr(), batch, n, n, 2.0, Mo.data_ptr())
+elif what == "power":
+    S = torch.empty((batch, T, bins), dtype=torch.float32, device=dev)
+    fn = lambda: ctx.spectrogram_exec(pl, y.data_ptr(), batch, n, n, 2.0, S.data_ptr())
 else:
     fn = lambda: ctx.stft_exec(pl, y.data_ptr(), batch, n, n, D.data_ptr())
 if os.environ.get("PROBE_CHECK"):  # the kernel under test against torch.stft in float64 on two clips (probe builds of sizes the parity cases skip)
