@@ -233,6 +233,12 @@ template <int P> LRA_HD void lra_setprio() {
 #ifndef LRA_V1_PRIO_B3
 #define LRA_V1_PRIO_B3 1
 #endif
+#ifndef LRA_V1_PRIO_CA  // first-generation kernels, complex / power epilogues (experiment hooks; -1 = no instruction)
+#define LRA_V1_PRIO_CA -1
+#endif
+#ifndef LRA_V1_PRIO_CS
+#define LRA_V1_PRIO_CS -1
+#endif
 #ifndef LRA_I_PRIO_A
 #define LRA_I_PRIO_A -1
 #endif

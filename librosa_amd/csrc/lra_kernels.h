@@ -1238,6 +1238,7 @@ template <class Cfg, int MODE, int PM = POW_TWO, int RAM = 0> LRA_HD void stft_b
         LRA_TICK(0);
         if (!Cfg::HOIST) { LRA_LAUNDER(a.win); LRA_LAUNDER(a.tw); LRA_LAUNDER(a.twr); }
         if (MODE == OUT_MELR) lra_setprio<LRA_V1_PRIO_A>();  // wave priority per phase, as in stft2_kernel (lra_kernels2.h): transform / split / epilogue / band combine
+        else if (MODE == OUT_COMPLEX || MODE == OUT_POWER) lra_setprio<LRA_V1_PRIO_CA>();  // (complex / power epilogues: transform, then un-split + stores)
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
             const Lds sl = lds_sub(lds, slot * slot_bytes);
@@ -1267,6 +1268,7 @@ template <class Cfg, int MODE, int PM = POW_TWO, int RAM = 0> LRA_HD void stft_b
             LRA_PHASE(Cfg::NT, tid) {
                 LRA_HALF_SWAP8(rg, tid, Cfg::R / 2, mirror32_swaps<Cfg>(lane_of<Cfg>(tid)));
             } LRA_PHASE_END_SYNC(true)
+            if (MODE == OUT_COMPLEX || MODE == OUT_POWER) lra_setprio<LRA_V1_PRIO_CS>();
             LRA_PHASE(Cfg::NT, tid) {
                 const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
                 mirror32_split_store<Cfg, MODE, PM>(a, clip, frame, frame < a.n_frames, tf, LRA_R(rg));
@@ -1290,6 +1292,7 @@ template <class Cfg, int MODE, int PM = POW_TWO, int RAM = 0> LRA_HD void stft_b
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC || SPLIT_NO_LDS)
         LRA_TICK(8);
         if (MODE == OUT_MELR) lra_setprio<LRA_V1_PRIO_B>();
+        else if (MODE == OUT_COMPLEX || MODE == OUT_POWER) lra_setprio<LRA_V1_PRIO_CS>();
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
             if constexpr (MODE == OUT_MELR) melr_split_accumulate<Cfg, PM>(a, frame < a.n_frames, tf, LRA_R(rg), lds_sub(lds, slot * slot_bytes), lds_sub(lds, a.shared_off));

@@ -71,8 +71,10 @@ template <class Cfg> LRA_HD int v2_hop_divisor(int hop) {
 #ifndef LRA_V2_PRIO_A1
 #define LRA_V2_PRIO_A1 -1
 #endif
+// (round 5: 3 / 2 for the complex kernel too -- over seven allocations per process and two rounds its slow level reads 0.737-0.741 / 0.732-0.735 ms against
+// 0.742-0.746 / 0.739-0.745 without, profiles/r05_raw/aa_*: under 1 %, but the same sign every time; the inverse kernel's priorities (LRA_I_PRIO_*) move nothing)
 #ifndef LRA_V2_PRIO_CA
-#define LRA_V2_PRIO_CA -1
+#define LRA_V2_PRIO_CA 3
 #endif
 // |X|^p epilogue (round 5): PA = window + transform passes, PS = un-split + power stores.  Same box, alternating, 256 x 30 s:
 // none 0.518-0.521 ms, 3 / 2 0.499-0.501, 3 / 0 0.498-0.499 (profiles/r05_raw/z_prio_power.txt); the complex kernel with the same pair: inside its
@@ -84,7 +86,7 @@ template <class Cfg> LRA_HD int v2_hop_divisor(int hop) {
 #define LRA_V2_PRIO_PS 2
 #endif
 #ifndef LRA_V2_PRIO_CS
-#define LRA_V2_PRIO_CS -1
+#define LRA_V2_PRIO_CS 2
 #endif
 template <int P> LRA_HD void v2_setprio() { lra_setprio<P>(); }
 

@@ -328,3 +328,20 @@ if "power" in what:  # socket power / shader clock (rocm-smi, 2.5 s into a loop)
         ms = timeit(fn, steps=15, prewarm=0.15)
         p_w, clk = sample(fn)
         print(f"power pitch {pitch * 8} B stft kernel: {ms:.3f} ms {by / ms / 1e6:5.0f} GB/s {p_w} W {clk} MHz", flush=True)
+
+if "istft_lottery" in what:  # the inverse kernel over several allocations of its input (per-process distribution: builds compare by their sorted lists)
+    n_fft, hop, bins = 2048, 512, 1025
+    w = np.asarray(filters.get_window("hann", n_fft, fftbins=True), dtype=np.float32)
+    pl = ctx.stft_plan(n_fft, hop, w, True, "constant", np.float32)
+    ip = ctx.istft_plan(n_fft, hop, w, True, np.float32)
+    T = ctx.stft_num_frames(pl, n)
+    ww = filters.window_sumsquare(window="hann", n_frames=T, n_fft=n_fft, hop_length=hop, dtype=np.float32)[n_fft // 2:]
+    ww = torch.from_numpy(wss_to_norm(np.ascontiguousarray(np.pad(ww, (0, max(0, n - len(ww))))[:n], dtype=np.float32))).to(dev)
+    yr = torch.empty((batch, n), dtype=torch.float32, device=dev)
+    held, ms_i, ms_f = [], [], []
+    for trial in range(7):
+        keep, dptr = aligned_buffer(batch * T * bins * 8 + trial * (3 << 20), align=1 << 21)
+        held.append(keep)
+        ms_f.append(timeit(lambda: ctx.stft_exec(pl, y.data_ptr(), batch, n, n, dptr), steps=10, prewarm=0.15))
+        ms_i.append(timeit(lambda: ctx.istft_exec_norm(ip, dptr, batch, T * bins, bins, T, ww.data_ptr(), yr.data_ptr(), n, n), steps=10, prewarm=0.15))
+    print(f"istft_lottery {os.environ.get('LIBROSA_AMD_LIBRARY', 'product')}: istft sorted " + " ".join(f"{m:.3f}" for m in sorted(ms_i)) + " | stft sorted " + " ".join(f"{m:.3f}" for m in sorted(ms_f)), flush=True)
