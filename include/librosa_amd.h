@@ -352,6 +352,10 @@ int lra_comm_init(lra_ctx* ctx, int rank, int n_ranks, const void* id, lra_comm*
 /* recv_dev[r * bytes_per_rank ...] = rank r's send_dev[0 .. bytes_per_rank), enqueued on the context's stream (stream-ordered
  * after the kernels that produced send_dev); equal shard sizes -- the shim gathers unequal shards piecewise. */
 int lra_comm_allgather(lra_comm* comm, const void* send_dev, void* recv_dev, size_t bytes_per_rank);
+/* The same for UNEQUAL shards (clips % ranks != 0: librosa_amd.distributed.shard_range): rank r's bytes_per_rank[r] bytes land at recv_dev + recv_offsets[r] on
+ * every rank -- one ncclBroadcast per rank inside one ncclGroupStart / End, no padding, no staging copy.  Both tables are host arrays of n_ranks entries, the same
+ * on every rank. */
+int lra_comm_allgatherv(lra_comm* comm, const void* send_dev, void* recv_dev, const size_t* bytes_per_rank, const size_t* recv_offsets);
 void lra_comm_destroy(lra_comm* comm);
 
 /* ---- measurement aid (no reference counterpart): the transform's access stream without its arithmetic ------------------

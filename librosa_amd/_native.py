@@ -86,6 +86,7 @@ SIGNATURES = {
     "lra_comm_unique_id": (c_int, [c_void_p]),
     "lra_comm_init": (c_int, [c_void_p, c_int, c_int, c_void_p, POINTER(c_void_p)]),
     "lra_comm_allgather": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
+    "lra_comm_allgatherv": (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_size_t), POINTER(c_size_t)]),
     "lra_comm_destroy": (None, [c_void_p]),
     "lra_phase_vocoder_exec": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_int]),
     "lra_griffinlim_init": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int]),
@@ -562,6 +563,15 @@ class Comm:
 
     def allgather(self, send_ptr, recv_ptr, bytes_per_rank):
         _check(self.lib.lra_comm_allgather(self.handle, c_void_p(send_ptr), c_void_p(recv_ptr), int(bytes_per_rank)))
+
+    def allgatherv(self, send_ptr, recv_ptr, bytes_per_rank, recv_offsets):
+        """Unequal shards: rank r's ``bytes_per_rank[r]`` bytes land at ``recv_ptr + recv_offsets[r]`` on every rank (one grouped broadcast per rank)."""
+        n = self.n_ranks
+        if len(bytes_per_rank) != n or len(recv_offsets) != n:
+            raise ParameterError(f"allgatherv: size / offset tables must have one entry per rank ({n})")
+        sizes = (c_size_t * n)(*[int(v) for v in bytes_per_rank])
+        offs = (c_size_t * n)(*[int(v) for v in recv_offsets])
+        _check(self.lib.lra_comm_allgatherv(self.handle, c_void_p(send_ptr) if send_ptr else None, c_void_p(recv_ptr), sizes, offs))
 
     def close(self):
         if self.handle:

@@ -1429,6 +1429,9 @@ struct RcclApi {
     int (*GetUniqueId)(void*) = nullptr;
     int (*CommInitRank)(void**, int, Id, int) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;  // (optional: lra_comm_allgatherv)
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
@@ -1450,6 +1453,9 @@ RcclApi* rccl_api() {
         api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
         api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
         api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
+        api.Broadcast = (decltype(api.Broadcast))dlsym(api.lib, "ncclBroadcast");
+        api.GroupStart = (decltype(api.GroupStart))dlsym(api.lib, "ncclGroupStart");
+        api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.lib, "ncclGroupEnd");
         api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
         api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
     });
@@ -2855,6 +2861,30 @@ int lra_comm_allgather(lra_comm* comm, const void* send_dev, void* recv_dev, siz
     if (!api) return fail(LRA_ENODEV, "RCCL (librccl.so) is not available");
     const int rc = api->AllGather(send_dev, recv_dev, bytes_per_rank, /* ncclInt8 */ 0, comm->nccl, comm->ctx->stream);
     return rc == 0 ? LRA_OK : rccl_fail(api, "ncclAllGather", rc);
+}
+
+int lra_comm_allgatherv(lra_comm* comm, const void* send_dev, void* recv_dev, const size_t* bytes_per_rank, const size_t* recv_offsets) {
+    if (!comm) return fail(LRA_EINVAL, "null communicator");
+    LRA_BIND(comm->ctx);
+    if (!bytes_per_rank || !recv_offsets) return fail(LRA_EINVAL, "null size / offset table");
+    if (!recv_dev) return fail(LRA_EINVAL, "null data pointer");
+    RcclApi* api = rccl_api();
+    if (!api) return fail(LRA_ENODEV, "RCCL (librccl.so) is not available");
+    if (!api->Broadcast || !api->GroupStart || !api->GroupEnd) return fail(LRA_ENODEV, "this RCCL has no ncclBroadcast / ncclGroupStart / ncclGroupEnd");
+    if (bytes_per_rank[comm->rank] && !send_dev) return fail(LRA_EINVAL, "null data pointer");
+    // unequal shards: every rank broadcasts its own piece into its slice of the full buffer, all of them inside ONE group (one fused operation on the wire)
+    int rc = api->GroupStart();
+    if (rc != 0) return rccl_fail(api, "ncclGroupStart", rc);
+    int first_bad = 0;
+    for (int r = 0; r < comm->n_ranks; ++r) {
+        if (!bytes_per_rank[r]) continue;
+        char* slice = (char*)recv_dev + recv_offsets[r];
+        const int e = api->Broadcast(r == comm->rank ? send_dev : slice, slice, bytes_per_rank[r], /* ncclInt8 */ 0, r, comm->nccl, comm->ctx->stream);
+        if (e != 0 && !first_bad) first_bad = e;
+    }
+    rc = api->GroupEnd();
+    if (first_bad) return rccl_fail(api, "ncclBroadcast", first_bad);
+    return rc == 0 ? LRA_OK : rccl_fail(api, "ncclGroupEnd", rc);
 }
 
 void lra_comm_destroy(lra_comm* comm) {

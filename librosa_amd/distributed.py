@@ -112,7 +112,9 @@ class NativeGather:
     """The same gather through the C ABI's own RCCL binding (``lra_comm_*``, ``include/librosa_amd.h``) for host programs that
     do not run ``torch.distributed``: the caller distributes ``unique_id`` (from ``librosa_amd._native.comm_unique_id()`` on rank 0)
     by whatever channel it has; ``all_gather(local)`` enqueues ONE ncclAllGather on the context's stream -- stream-ordered after
-    the kernels that produced ``local`` -- and returns the full ``(world * clips, ...)`` device tensor.  Equal shards only."""
+    the kernels that produced ``local`` -- and returns the full ``(world * clips, ...)`` device tensor.  Unequal shards (``n_items`` given and not a
+    multiple of the world size: rank r holds ``shard_range(n_items, r, world)``): one grouped ncclBroadcast per rank straight into its rows of the full
+    tensor (``lra_comm_allgatherv``), no padding and no staging copy -- the layout of the unsharded result, as ``ShardedGather`` produces it."""
 
     def __init__(self, ctx, rank: int, world: int, unique_id: bytes):
         from . import _native
@@ -121,13 +123,26 @@ class NativeGather:
         self.world = int(world)
         self.comm = _native.Comm(ctx, rank, world, unique_id)
 
-    def all_gather(self, local):
+    def all_gather(self, local, n_items=None):
         import torch
 
         local = local.contiguous()
-        full = torch.empty((self.world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         self.ctx.set_stream(torch.cuda.current_stream(local.device).cuda_stream)
-        self.comm.allgather(local.data_ptr(), full.data_ptr(), local.numel() * local.element_size())
+        sizes = shard_sizes(n_items, self.world) if n_items is not None else [int(local.shape[0])] * self.world
+        if local.shape[0] != sizes[self.comm.rank]:
+            raise ValueError(f"rank {self.comm.rank} holds {local.shape[0]} items, shard_range({n_items}, {self.comm.rank}, {self.world}) says {sizes[self.comm.rank]}")
+        full = torch.empty((sum(sizes),) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        if len(set(sizes)) == 1:
+            self.comm.allgather(local.data_ptr(), full.data_ptr(), local.numel() * local.element_size())
+            return full
+        item = local.element_size()
+        for d in local.shape[1:]:
+            item *= int(d)
+        offs, acc = [], 0
+        for sz in sizes:
+            offs.append(acc * item)
+            acc += sz
+        self.comm.allgatherv(local.data_ptr() if local.numel() else 0, full.data_ptr(), [sz * item for sz in sizes], offs)
         return full
 
     def close(self):

@@ -1418,6 +1418,15 @@ def test_native_rccl_communicator(L):
     full = g.all_gather(M)
     torch.cuda.synchronize()
     assert full.shape == M.shape and torch.equal(full, M)
+    assert torch.equal(g.all_gather(M, n_items=3), M)
+    with pytest.raises(ValueError):
+        g.all_gather(M, n_items=5)  # this rank would hold 5 items, not 3
+    # the unequal-shard form (one grouped broadcast per rank into its slice), as far as one rank can exercise it: its piece lands at the given offset
+    big = torch.full((5,) + tuple(M.shape[1:]), float("nan"), device=M.device)
+    row = M[0].numel() * M.element_size()
+    g.comm.allgatherv(M.data_ptr(), big.data_ptr(), [3 * row], [2 * row])
+    torch.cuda.synchronize()
+    assert torch.equal(big[2:], M) and bool(torch.isnan(big[:2]).all())
     g.close()
     with pytest.raises(L.ParameterError):
         _native.Comm(ctx, 2, 1, uid)  # rank outside the world

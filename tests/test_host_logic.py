@@ -486,3 +486,47 @@ def test_bench_compact_line_keeps_the_contract_and_fits():
     assert line["cpu_baseline"]["kind"] == "reference" and line["cpu_baseline"]["cores"] == 1 and line["cpu_baseline"]["all_cores"] == 64
     assert line["scaling_base"]["clips_per_gpu"] == 512 and line["side"]["griffinlim_ms_setup"] == 0.5 and line["side_errors"] == ["hpss"]
     assert "workload" in line["config"] and len(line["config"]["workload"]) < 300
+
+
+def test_native_gather_unequal_shards_tables():
+    """NativeGather.all_gather with n_items % world != 0: the byte sizes / offsets handed to lra_comm_allgatherv are those of shard_range (the unsharded layout)."""
+    import torch
+
+    from librosa_amd.distributed import NativeGather
+
+    class _Ctx:
+        def set_stream(self, s):
+            pass
+
+    class _Comm:
+        rank = 1
+
+        def __init__(self):
+            self.calls = []
+
+        def allgather(self, *a):
+            self.calls.append(("equal",) + a)
+
+        def allgatherv(self, send, recv, sizes, offs):
+            self.calls.append(("v", list(sizes), list(offs)))
+
+    class _Stream:
+        cuda_stream = 0
+
+    g = NativeGather.__new__(NativeGather)
+    g.ctx, g.world, g.comm = _Ctx(), 3, _Comm()
+    orig = torch.cuda.current_stream
+    torch.cuda.current_stream = lambda dev=None: _Stream()
+    try:
+        local = torch.zeros((2, 4, 5), dtype=torch.float32)     # rank 1 of 3 holds 2 of 7 items
+        full = g.all_gather(local, n_items=7)
+        assert tuple(full.shape) == (7, 4, 5)
+        item = 4 * 5 * 4
+        assert g.comm.calls == [("v", [3 * item, 2 * item, 2 * item], [0, 3 * item, 5 * item])]
+        g.comm.calls.clear()
+        full = g.all_gather(local, n_items=6)                    # equal shards: the single all-gather
+        assert tuple(full.shape) == (6, 4, 5) and g.comm.calls[0][0] == "equal"
+        with pytest.raises(ValueError):
+            g.all_gather(torch.zeros((3, 4, 5)), n_items=7)
+    finally:
+        torch.cuda.current_stream = orig
