@@ -79,6 +79,7 @@ struct lra_ctx {
     int opt_generic_mel = 0;         // force the generic banded mel path (tests)
     int opt_lds_pad = 0;             // extra dynamic LDS per workgroup (occupancy experiments)
     int opt_v2 = 1;                  // second-generation forward kernel where it applies (lra_kernels2.h)
+    int opt_mel_many = 1;            // mel plans of n_fft = 512 with more than 64 bands are built for the eight-bands-per-thread kernel shape (read at lra_mel_plan_create)
     int opt_cqt_merge = 1;           // lra_cqt_recursion_exec: octaves 1 .. in one launch per frame length behind the chain of halvings (0: one launch per octave on the side stream)
     int opt_hpss_tile = 1;           // hpss: a thread per 4 x 4 tile with shared sorted cores (hpss_tile_kernel); 0: a thread per element (A/B)
     int opt_mixed_inv_pow2 = 1;      // inverse, n_fft = 256 / 512 / 1024 with a hop outside n_fft / {2, 4, 8, 16}: the fused gather kernel of lra_mixed.h (0: istft_kernel's general mode)
@@ -269,6 +270,7 @@ struct lra_mel_plan {
     int* d_melr_addr = nullptr;
     int melr_zero = 0, melr_mid = 0, melr_pmax = 0;
     bool melr_ok = false;
+    bool melr_many = false;  // the layout-0 tables were built for the many-bands kernel shape (lra_dispatch.h, MelManyCfgOf: eight bands, one hoisted piece per list)
     // the same for the second-generation kernel (lra_mel.h layout 1: both runs ascending, extra bin M)
     void* d_melr2_w = nullptr;
     void* d_melr2_keep = nullptr;
@@ -473,7 +475,24 @@ template <class T> struct StftLaunch {
                     }
                 }
             }
-            if (mel && mel->melr_ok && mel_runs && melr_fits<MC>() && MC::R == 16) {
+            if constexpr (mel_many_applies<Cfg>()) {
+                using MM = typename MelManyCfgOf<Cfg>::type;
+                if (mel && mel->melr_ok && mel->melr_many && mel_runs && melr_fits<MM>()) {
+                    const int shared_m = melr_shared_bytes<MM>(a.n_mels, mel->melr_pmax);
+                    if (MM::FPB * stft_slot_bytes<MM>(OUT_MELR, a.n_mels, 1) + shared_m <= 160 * 1024) {
+                        a.melr_w = (const T*)mel->d_melr_w;
+                        a.melr_keep = (const T*)mel->d_melr_keep;
+                        a.melr_addr = mel->d_melr_addr;
+                        a.melr_zero = mel->melr_zero;
+                        a.melr_mid = mel->melr_mid;
+                        a.melr_pmax = mel->melr_pmax;
+                        mel_tile_opt = 1;
+                        launch<MM, OUT_MELR>(shared_m);
+                        return;
+                    }
+                }
+            }
+            if (mel && mel->melr_ok && !mel->melr_many && mel_runs && melr_fits<MC>() && MC::R == 16) {
                 const int shared_r = melr_shared_bytes<MC>(a.n_mels, mel->melr_pmax);
                 // no LDS staging tile by default: the kernel keeps the last 8 frames of each band in registers and stores them as one burst
                 int tile_r = mel_tile_opt > 0 ? mel_tile_opt : 1;
@@ -1643,6 +1662,7 @@ int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value) {
     else if (!std::strcmp(key, "xcd_remap")) ctx->opt_xcd_remap = value != 0;
     else if (!std::strcmp(key, "v2")) ctx->opt_v2 = value != 0;
     else if (!std::strcmp(key, "cqt_merge")) ctx->opt_cqt_merge = value != 0;
+    else if (!std::strcmp(key, "mel_many")) ctx->opt_mel_many = value != 0;
     else if (!std::strcmp(key, "direct")) ctx->opt_direct = value != 0;
     else if (!std::strcmp(key, "mixed")) ctx->opt_mixed = value != 0;
     else if (!std::strcmp(key, "hpss_tile")) ctx->opt_hpss_tile = value != 0;
@@ -1958,7 +1978,10 @@ int lra_mel_plan_create(lra_ctx* ctx, int n_mels, int n_bins, const void* basis_
                     p->n_pieces[pi] = mp.n_pieces;
                 }
                 if (rc == LRA_OK && (n_bins - 1) % 16 == 0) {
-                    MelRuns<float> mr = build_mel_runs<float>(ts, (n_bins - 1) / 16, 8, MELR_PMAX, melr_ph_of_tf((n_bins - 1) / 16));  // (min list length = the hoisted prefix)
+                    // n_fft = 512 with MANY bands: eight bands per thread (MelManyCfgOf).  Same box: 128 bands 1.54 -> 1.04 ms, but 80 bands 0.75 -> 1.18 (their wider pair segments need
+                    // the longer hoisted lists of the four-band form; 97 bands 0.90 -> 1.02, 112 bands 1.23 -> 1.03): taken above 100 bands
+                    p->melr_many = ctx->opt_mel_many && (n_bins - 1) / 16 == 16 && n_mels > 100;
+                    MelRuns<float> mr = build_mel_runs<float>(ts, (n_bins - 1) / 16, 8, MELR_PMAX, melr_ph_of_tf((n_bins - 1) / 16, p->melr_many));  // (min list length = the hoisted prefix)
                     if (mr.ok) {
                         rc = upload(&p->d_melr_w, mr.w.data(), mr.w.size() * sizeof(float));
                         if (rc == LRA_OK) rc = upload(&p->d_melr_keep, mr.keep.data(), mr.keep.size() * sizeof(float));

@@ -106,6 +106,14 @@ template <class Cfg> struct MelCfgOf {
     static constexpr int MELNT = Cfg::TF <= 64 ? LRA_MELNT : (2 * Cfg::TF <= 1024 ? 2 * Cfg::TF : Cfg::TF);
     using type = typename Cfg::template with_nt<MELNT>;
 };
+// ... and the shape for MANY bands per frame thread (round 5): 128 threads = eight slots of 16 threads.  The thread count doubles as the tag by which
+// lra_kernels.h (melr_nb / melr_ph) sizes the per-thread band state: eight bands and one hoisted piece per list instead of four and three -- n_fft = 512 with more
+// than 100 bands, whose pair segments are a couple of bins wide (same box: 128 bands 1.54 -> 1.04 ms; with 80 bands or fewer the four-band form is faster by a third).
+constexpr int MELNT_MANY = 128;
+template <class Cfg> struct MelManyCfgOf {
+    using type = typename Cfg::template with_nt<MELNT_MANY>;
+};
+template <class Cfg> constexpr bool mel_many_applies() { return Cfg::TF == 16 && sizeof(typename Cfg::real) == 4; }
 
 
 }  // namespace lra

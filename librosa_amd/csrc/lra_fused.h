@@ -68,7 +68,7 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void istft_kernel(lra::Ist
 namespace lra {
 
 // ---- named configurations (macro arguments cannot carry the commas of template argument lists) ----------
-#define LRA_CFG_ALIAS(NAME, ...) using NAME = typename CfgSel<__VA_ARGS__>::type; using NAME##_mel = typename MelCfgOf<NAME>::type;
+#define LRA_CFG_ALIAS(NAME, ...) using NAME = typename CfgSel<__VA_ARGS__>::type; using NAME##_mel = typename MelCfgOf<NAME>::type; using NAME##_melmany = typename MelManyCfgOf<NAME>::type;
 LRA_CFG_ALIAS(cfg_f32_4, float, 4, 0)
 LRA_CFG_ALIAS(cfg_f32_5, float, 5, 0)
 LRA_CFG_ALIAS(cfg_f32_6, float, 6, 0)
@@ -119,7 +119,9 @@ LRA_CFG_ALIAS(cfg_f64_12, double, 12, 0)
 #define LRA_INST_GROUP_1(S, I) LRA_F32_CFG(S, I, cfg_f32_10v4, 2, 1)
 #define LRA_INST_GROUP_2(S, I) LRA_F32_CFG(S, I, cfg_f32_10v1, 2, 1)
 #define LRA_INST_GROUP_3(S, I) LRA_F32_CFG(S, I, cfg_f32_4, 4, 2) LRA_F32_CFG(S, I, cfg_f32_5, 4, 2) LRA_F32_CFG(S, I, cfg_f32_6, 4, 2)
-#define LRA_INST_GROUP_4(S, I) LRA_F32_CFG(S, I, cfg_f32_7, 4, 2) LRA_F32_CFG(S, I, cfg_f32_8, 4, 2) LRA_STFT_REGRING(S, cfg_f32_7) LRA_STFT_REGRING(S, cfg_f32_8)
+// (the many-bands shape of the run-ordered mel epilogue, n_fft = 512: lra_dispatch.h, MelManyCfgOf)
+#define LRA_STFT_MELMANY(S, C) S(lra::C##_melmany, 4, 1, 0) S(lra::C##_melmany, 4, 2, 0) S(lra::C##_melmany, 4, 3, 0) S(lra::C##_melmany, 4, 1, 1) S(lra::C##_melmany, 4, 2, 1) S(lra::C##_melmany, 4, 3, 1)
+#define LRA_INST_GROUP_4(S, I) LRA_F32_CFG(S, I, cfg_f32_7, 4, 2) LRA_F32_CFG(S, I, cfg_f32_8, 4, 2) LRA_STFT_REGRING(S, cfg_f32_7) LRA_STFT_REGRING(S, cfg_f32_8) LRA_STFT_MELMANY(S, cfg_f32_8)
 #define LRA_INST_GROUP_5(S, I) LRA_F32_CFG(S, I, cfg_f32_9, 4, 2) LRA_F32_CFG(S, I, cfg_f32_11, 4, 2)
 #define LRA_INST_GROUP_6(S, I) LRA_F32_CFG(S, I, cfg_f32_12, 4, 2) LRA_F32_CFG(S, I, cfg_f32_13, 4, 2) LRA_STFT_REGRING(S, cfg_f32_12) LRA_STFT_REGRING(S, cfg_f32_13)
 #define LRA_INST_GROUP_7(S, I) LRA_F64_CFG(S, I, cfg_f64_4) LRA_F64_CFG(S, I, cfg_f64_5) LRA_F64_CFG(S, I, cfg_f64_6) LRA_F64_CFG(S, I, cfg_f64_7) LRA_F64_CFG(S, I, cfg_f64_8)

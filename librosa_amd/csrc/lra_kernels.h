@@ -142,10 +142,12 @@ template <class Cfg> LRA_HD int lane_of(int tid) { return (int)((unsigned)tid % 
 #endif
 // (TF = 32, n_fft = 1024: four bands per thread with two hoisted pieces measured 0.79 against 0.83 ms at 128 bands but 0.78 against 0.68 ms at 80, whose
 // wider segments need the longer hoisted lists: it keeps two bands per thread)
-constexpr int melr_nb_of_tf(int tf) { return tf >= 32 ? 2 : LRA_MELR_NB_SMALL; }
-constexpr int melr_ph_of_tf(int tf) { return tf >= 32 ? 4 : LRA_MELR_PH_SMALL; }  // (also the minimum list length the host builds: lra_api.hip)
-template <class Cfg> constexpr int melr_nb() { return melr_nb_of_tf(Cfg::TF); }
-template <class Cfg> constexpr int melr_ph() { return melr_ph_of_tf(Cfg::TF); }
+// `many`: the 128-thread workgroup shape of lra_dispatch.h (MelManyCfgOf): eight bands, one hoisted piece per list
+constexpr int melr_nb_of_tf(int tf, bool many = false) { return tf >= 32 ? 2 : (many ? 8 : LRA_MELR_NB_SMALL); }
+constexpr int melr_ph_of_tf(int tf, bool many = false) { return tf >= 32 ? 4 : (many ? 1 : LRA_MELR_PH_SMALL); }  // (also the minimum list length the host builds: lra_api.hip)
+template <class Cfg> constexpr bool melr_many() { return Cfg::TF == 16 && Cfg::NT == 128; }
+template <class Cfg> constexpr int melr_nb() { return melr_nb_of_tf(Cfg::TF, melr_many<Cfg>()); }
+template <class Cfg> constexpr int melr_ph() { return melr_ph_of_tf(Cfg::TF, melr_many<Cfg>()); }
 template <class Cfg> constexpr int melr_tile_frames() { return melr_nb<Cfg>() == 2 ? 8 : 4; }  // (NB x TILE = 16 registers, or 32 at eight bands per thread)
 
 template <class Cfg> struct FftRegs {

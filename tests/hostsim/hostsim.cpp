@@ -117,6 +117,18 @@ template <class T> struct StftSim {
         } else if (mode == OUT_MELR) {
             using MC = typename MelCfgOf<Cfg>::type;
             TwoSlope<T> ts = build_two_slope<T>(dense_basis, a.n_mels, Cfg::M + 1);
+            if constexpr (mel_many_applies<Cfg>()) {  // n_fft = 512 with more than 64 bands: the eight-bands-per-thread shape, as lra_api.hip selects it
+                using MM = typename MelManyCfgOf<Cfg>::type;
+                if (ts.ok && melr_fits<MM>() && a.n_mels > 100 && !std::getenv("LRA_SIM_NO_MELMANY")) {
+                    MelRuns<T> mr = build_mel_runs<T>(ts, MM::TF, MM::R / 2, MELR_PMAX, FftRegs<MM>::MELR_PHOIST, 0);
+                    if (!mr.ok) { diag[7] = 2; return; }
+                    a.melr_w = mr.w.data(); a.melr_keep = mr.keep.data(); a.melr_addr = mr.addr.data(); a.melr_zero = mr.zero_addr; a.melr_mid = mr.mid_addr; a.melr_pmax = mr.pmax;
+                    diag[9] = mr.max_pieces;
+                    diag[11] = 1;
+                    run<MM, OUT_MELR>(iters, melr_shared_bytes<MM>(a.n_mels, mr.pmax));
+                    return;
+                }
+            }
             if (!ts.ok || !melr_fits<MC>()) { diag[7] = 1; return; }
             bool v2m = false;
             if constexpr (v2_cfg_ok<MC>()) v2m = use_v2 && v2_hop_divisor<MC>(a.hop) > 0;

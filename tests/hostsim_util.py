@@ -118,7 +118,7 @@ def stft(y, n_fft, hop, win, center=True, pad_mode="constant", mode=0, iters_per
     if mode == 4 and diag[7] != 0:
         return None, dict(unavailable=int(diag[7]))  # run-ordered form not applicable to this configuration (the library falls back too)
     assert diag[7] == 0, "two-slope mel form not applicable"
-    return out, dict(races=int(diag[0]), uninit=int(diag[1]), NT=int(diag[2]), FPB=int(diag[3]), P=int(diag[4]), lds=int(diag[5]), wave_sync=int(diag[6]), ring_aligned=int(diag[8]), max_pieces=int(diag[9]), v2=int(diag[10]))
+    return out, dict(races=int(diag[0]), uninit=int(diag[1]), NT=int(diag[2]), FPB=int(diag[3]), P=int(diag[4]), lds=int(diag[5]), wave_sync=int(diag[6]), ring_aligned=int(diag[8]), max_pieces=int(diag[9]), v2=int(diag[10]), mel_many=int(diag[11]))
 
 
 def istft(D, n_fft, hop, win, wss, out_len, n_used, center=True, strip_groups=4, variant=0):

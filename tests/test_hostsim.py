@@ -188,6 +188,7 @@ def test_mel_body_run_ordered_both_generations(n_fft, hop, power, n_mels, iters,
     M4, d4 = H.stft(y, n_fft, hop, win, mode=4, power=power, mel_basis=B, iters_per_wg=iters)
     assert M4 is not None, d4
     assert d4["v2"] == v2
+    assert d4["mel_many"] == int(n_fft == 512 and n_mels > 100)  # eight bands per thread (128-thread workgroups) exactly where lra_api.hip picks that shape
     _check_diag(d4)
     Mref = O.melspectrogram(y=y, sr=22050, n_fft=n_fft, hop_length=hop, power=power, n_mels=n_mels)
     assert np.all(np.abs(M4 - Mref) <= 1e-5 * np.abs(Mref) + 1e-5 * Mref.max())
