@@ -15,7 +15,13 @@ one kernel launch) -- over one batch of synthetic 22.05 kHz clips already reside
 Plans/tables are created outside the timed region.  The timed region is EXACTLY --steps steps bracketed by a
 barrier + device synchronize on both sides; the max over ranks is reported.
 
-Extra keys on the JSON line (rank 0):
+Output (rank 0): ONE short JSON line on stdout -- the contract's keys, `roofline` (timed kernel) with the path's other fractions folded in as `roofline.path`
+(stft_frac / istft_frac / stream_forward_frac / stream_inverse_frac / cqt_lite_frac, + the best / worst of `--placements` allocations of the 2.7 GB spectrum: its
+placement moves the store-bound transform 0.63-0.75 ms, profiles/r05_pitch.md), `cpu_baseline`, `parity`, `scaling_base` (N = 1 at 512 clips per GPU), one number per
+side measurement (`side`) -- and the FULL record on stderr (and in --detail / gpurun_out/bench_detail.json).  N > 1: `gathered.full_matches_unsharded` = every rank
+recomputed its neighbour's shard from that shard's seeded input and found it equal in the gathered tensor.
+
+Keys of the full record (rank 0):
   roofline        dominant kernel of the step (the fused mel kernel): algorithmic bytes / HIP-event time, + HBM traffic from
                   the newest profiles/*_traffic.json (rocprofv3 PMC passes, scripts/profile_round.sh)
   roofline_stft   the complex64-out STFT kernel on the same input (north-star bar: >= 70 % of HBM, 10 248 B/frame)
