@@ -15,6 +15,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -24,6 +25,12 @@
 #include <vector>
 
 #include "../../include/librosa_amd.h"
+#ifndef LRA_V3_DEFAULT
+#define LRA_V3_DEFAULT 0
+#endif
+#ifndef LRA_MEL_PC_DEFAULT
+#define LRA_MEL_PC_DEFAULT 0  // the producer / consumer fused mel kernel (lra_kernels_pc.h): ctx option "mel_pc"
+#endif
 #define LRA_FUSED_EXTERN  // the fused kernels are instantiated in lra_inst.hip (parallel build), see lra_fused.h
 #include "lra_fused.h"
 #include "lra_mel.h"
@@ -79,6 +86,8 @@ struct lra_ctx {
     int opt_generic_mel = 0;         // force the generic banded mel path (tests)
     int opt_lds_pad = 0;             // extra dynamic LDS per workgroup (occupancy experiments)
     int opt_v2 = 1;                  // second-generation forward kernel where it applies (lra_kernels2.h)
+    int opt_v3 = LRA_V3_DEFAULT;     // complex / power epilogues at n_fft = 2048 f32: the radix 16-16-4 form with 16-byte row pieces (variant 6, lra_kernels2.h third form)
+    int opt_mel_pc = LRA_MEL_PC_DEFAULT;  // fused mel, n_fft = 2048 f32: the producer / consumer kernel (lra_kernels_pc.h) instead of stft2_kernel<OUT_MELR>
     int opt_mel_many = 1;            // mel plans of n_fft = 512 with more than 64 bands are built for the eight-bands-per-thread kernel shape (read at lra_mel_plan_create)
     int opt_cqt_merge = 1;           // lra_cqt_recursion_exec: octaves 1 .. in one launch per frame length behind the chain of halvings (0: one launch per octave on the side stream)
     int opt_hpss_tile = 1;           // hpss: a thread per 4 x 4 tile with shared sorted cores (hpss_tile_kernel); 0: a thread per element (A/B)
@@ -330,6 +339,7 @@ template <class T> struct StftLaunch {
     bool use_v2 = true;
     bool use_direct = true;
     bool mel_v2 = false;  // OUT_MELR: the plan's layout-1 tables are bound, run the second-generation kernel
+    bool mel_pc = false;  // fused mel: the producer / consumer kernel where it applies (lra_kernels_pc.h)
     bool mel_runs = true;
     const lra_mel_plan* mel = nullptr;
     hipStream_t stream = nullptr;
@@ -338,7 +348,10 @@ template <class T> struct StftLaunch {
     template <class Cfg, int MODE> void launch(int shared_bytes) {
         static_assert(Cfg::P <= 4, "at most four Stockham passes are wired up");
         const int lds_probe_v1 = Cfg::FPB * stft_slot_bytes<Cfg>(MODE, a.n_mels, mel_tile_opt > 0 ? mel_tile_opt : 4) + shared_bytes + lds_pad;
-        void (*kern)(StftArgs<T>, const T*, void*) = stft_kernel<Cfg, MODE, POW_TWO, 0>;
+        void (*kern)(StftArgs<T>, const T*, void*) = nullptr;
+        bool direct = false;
+        if constexpr (Cfg::PLAN == 0) {  // (the radix 16-16-4 configuration has second-generation instances only)
+        kern = stft_kernel<Cfg, MODE, POW_TWO, 0>;
         if (MODE != OUT_COMPLEX && a.power_mode == POW_ONE) kern = stft_kernel<Cfg, MODE, POW_ONE, 0>;
         if (MODE != OUT_COMPLEX && a.power_mode == POW_GENERAL) kern = stft_kernel<Cfg, MODE, POW_GENERAL, 0>;
         if constexpr (sizeof(T) == 4) {  // row-aligned hops (n_fft/4, n_fft/8, ...): the fast ring addressing, f32 only
@@ -352,7 +365,6 @@ template <class T> struct StftLaunch {
             }
         }
         // hop >= n_fft (frames do not overlap): direct framing, no ring (complex / power epilogues)
-        bool direct = false;
         if constexpr (MODE == OUT_COMPLEX || MODE == OUT_POWER) {
             if (a.hop >= Cfg::N && use_direct) {
                 direct = true;
@@ -371,10 +383,11 @@ template <class T> struct StftLaunch {
             if (hd == 2) { direct = true; LRA_PICKR(3) } else if (hd == 4) { direct = true; LRA_PICKR(4) } else if (hd == 8) { direct = true; LRA_PICKR(5) } else if (hd == 16) { direct = true; LRA_PICKR(6) }
 #undef LRA_PICKR
         }
+        }
         // Second-generation kernel (lra_kernels2.h) where it applies: complex / power epilogues, 16 points per thread with
         // a two-butterfly last pass (n_fft 1024 / 2048 / 4096), hop = n_fft / {1, 2, 4, 8}.
         bool v2 = false;
-        if constexpr (v2_cfg_ok<Cfg>() && (MODE == OUT_COMPLEX || MODE == OUT_POWER || MODE == OUT_MELR)) {
+        if constexpr (v23_cfg_ok<Cfg>() && (MODE == OUT_COMPLEX || MODE == OUT_POWER || MODE == OUT_MELR)) {
             const int hd = (use_v2 && (MODE != OUT_MELR || mel_v2)) ? v2_hop_divisor<Cfg>(a.hop) : 0;
             if (hd) {
                 v2 = true;
@@ -386,6 +399,7 @@ template <class T> struct StftLaunch {
 #undef LRA_PICK2
             }
         }
+        if (!kern) { err = hipErrorInvalidValue; return; }
         const int lds_probe = v2 ? Cfg::FPB * stft2_slot_bytes<Cfg>() + shared_bytes + lds_pad : direct ? Cfg::FPB * Cfg::FRAME_BYTES + lds_pad : lds_probe_v1;
         // Frames per slot (`iters`).  A slot pays n_fft - hop extra sample loads for its first frame, so long
         // runs are cheap in HBM traffic; but the launch should also end evenly: the grid is sized to a whole
@@ -445,10 +459,60 @@ template <class T> struct StftLaunch {
         err = hipGetLastError();
     }
 
+    // Producer / consumer fused mel kernel (lra_kernels_pc.h): 192-thread workgroups [P, P, C], NP = 2 frame slots each.  Geometry as above:
+    // strips of 24..176 frames per slot, the grid a whole number of rounds of resident workgroups (four per CU).
+    template <class Cfg> void launch_pc(int hd) {
+        using PL = PcLayout<Cfg>;
+        void (*kern)(StftArgs<T>, const T*, void*) = nullptr;
+#define LRA_PICKP(HD)                                                        \
+    kern = stft_pc_kernel<Cfg, HD, POW_TWO>;                                 \
+    if (a.power_mode == POW_ONE) kern = stft_pc_kernel<Cfg, HD, POW_ONE>;    \
+    if (a.power_mode == POW_GENERAL) kern = stft_pc_kernel<Cfg, HD, POW_GENERAL>;
+        if (hd == 4) { LRA_PICKP(4) } else { LRA_PICKP(8) }
+#undef LRA_PICKP
+        const int lds = PL::BYTES + lds_pad;
+        constexpr int fpb = PL::NP;
+        int iters = iters_opt;
+        if (iters <= 0) {
+            const int per_cu = resident_workgroups(reinterpret_cast<const void*>(kern), PL::NT, lds);
+            const long long conc = (long long)n_cu * (per_cu > 0 ? per_cu : 1);
+            int best_iters = 0;
+            double best_fill = -1.0;
+            for (int cand = 176; cand >= 24; --cand) {
+                const int wgpc = (a.n_frames + fpb * cand - 1) / (fpb * cand);
+                const int it = (a.n_frames + fpb * wgpc - 1) / (fpb * wgpc);
+                const double rounds = (double)(batch * wgpc) / (double)conc;
+                const double fill = (rounds <= 1.0 && rounds >= 0.6) ? 1.0 : rounds / std::ceil(rounds);
+                if (fill > best_fill + 0.02) { best_fill = fill; best_iters = it; }
+            }
+            iters = best_iters;
+            while (iters > 4 && batch * ((a.n_frames + fpb * iters - 1) / (fpb * iters)) < 2LL * n_cu) iters /= 2;
+        }
+        if (iters < 1) iters = 1;
+        a.rot_uniform = 0;
+        a.mel_tile = 1;
+        a.frames_per_wg = fpb * iters;
+        a.wg_per_clip = (a.n_frames + a.frames_per_wg - 1) / a.frames_per_wg;
+        a.slot_bytes = PL::FRAME;
+        a.shared_off = 0;
+        const long long grid = batch * a.wg_per_clip;
+        if (grid > 0x7ffffff0LL) { err = hipErrorInvalidConfiguration; return; }
+        a.n_blocks = (int)grid;
+        a.xcd_chunk = (xcd_remap && grid >= 64) ? (int)((grid + 7) / 8) : 0;
+        const long long launch_grid = a.xcd_chunk ? 8LL * a.xcd_chunk : grid;
+        hipLaunchKernelGGL(kern, dim3((unsigned)launch_grid), dim3(PL::NT), lds, stream, a, a.y, out);
+        err = hipGetLastError();
+    }
+
     template <class Cfg> void operator()() {
         if constexpr (Cfg::REV) {  // the ascending-radix configurations exist for the inverse kernel only
             err = hipErrorInvalidValue;
             return;
+        } else if constexpr (Cfg::PLAN == 1) {  // radices 16, 16, 4: second-generation kernels only (stft_run selects the variant where they apply)
+            if (!use_v2 || v2_hop_divisor<Cfg>(a.hop) == 0) { err = hipErrorInvalidValue; return; }
+            if (mode == OUT_COMPLEX) launch<Cfg, OUT_COMPLEX>(0);
+            else if (mode == OUT_POWER) launch<Cfg, OUT_POWER>(0);
+            else err = hipErrorInvalidValue;
         } else {
             run<Cfg>();
         }
@@ -457,6 +521,20 @@ template <class T> struct StftLaunch {
         if (mode == OUT_MEL2) {
             // the two-slope mel kernel shares its filter tables across the slots of a larger workgroup
             using MC = typename MelCfgOf<Cfg>::type;
+            // n_fft = 2048, float32, banks of up to 128 bands with pair segments of at most four pieces: producer and consumer waves (lra_kernels_pc.h)
+            if constexpr (pc_cfg_ok<Cfg>()) {
+                const int hd_pc = v2_hop_divisor<Cfg>(a.hop);
+                if (mel_pc && mel && mel->melr2_ok && mel_runs && use_v2 && pc_bank_ok<Cfg>(a.n_mels, mel->melr2_pmax) && pc_fits_budget(hd_pc, a.power_mode)) {
+                    a.melr_w = (const T*)mel->d_melr2_w;
+                    a.melr_keep = (const T*)mel->d_melr2_keep;
+                    a.melr_addr = mel->d_melr2_addr;
+                    a.melr_zero = mel->melr2_zero;
+                    a.melr_mid = mel->melr2_mid;
+                    a.melr_pmax = mel->melr2_pmax;
+                    launch_pc<Cfg>(hd_pc);
+                    return;
+                }
+            }
             // first choice: the run-ordered form (no per-lane control flow, no (wA P, wB P) round trip through LDS)
             if constexpr (v2_cfg_ok<MC>()) {
                 if (mel && mel->melr2_ok && mel_runs && use_v2 && melr_fits<MC>() && v2_hop_divisor<MC>(a.hop) > 0) {
@@ -542,6 +620,14 @@ template <class T> struct IstftLaunch {
     hipStream_t stream = nullptr;
     hipError_t err = hipSuccess;
     template <class Cfg> void operator()() {
+        if constexpr (Cfg::PLAN == 1) {  // forward-only configuration (radices 16, 16, 4)
+            err = hipErrorInvalidValue;
+            return;
+        } else {
+            run<Cfg>();
+        }
+    }
+    template <class Cfg> void run() {
         static_assert(Cfg::P <= 4, "at most four Stockham passes are wired up");
         constexpr int FPB = Cfg::FPB, N = Cfg::N;
         const int H = a.hop;
@@ -978,6 +1064,7 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
         L.lds_pad = ctx->opt_lds_pad;
         L.xcd_remap = ctx->opt_xcd_remap != 0;
         L.use_v2 = ctx->opt_v2 != 0;
+        L.mel_pc = ctx->opt_mel_pc != 0;
         L.use_direct = ctx->opt_direct != 0;
         L.mel_runs = ctx->opt_mel_runs != 0;
         // Kernel variant (f32 n_fft = 2048 only): 0 = one wave per frame, 4 = two waves per frame.  Which one
@@ -1001,6 +1088,8 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
             if (tuned < 0 && batch * n_frames >= 65536) LRA_TRY(autotune_variant(ctx, launch, &tuned));
             if (tuned >= 0) variant = tuned;
         }
+        if (v2_applies && ctx->opt_v3 && (ctx->opt_variant < 0 || ctx->opt_variant == 6)) variant = 6;
+        else if (variant == 6) variant = 0;  // (the 16-16-4 form exists for the second-generation complex / power kernels only)
         return launch(variant);
     }
     // listed non-power-of-two frame lengths: one fused launch (lra_mixed.h)
@@ -1565,6 +1654,25 @@ int lra_ctx_create(int device, lra_ctx** out) {
         return fail(LRA_EHIP, std::string("flag allocation: ") + hipGetErrorString(e));
     }
     *out = c;
+    // LRA_CTX_OPTIONS="key=value,key=value": options applied to every context at creation (whole-suite runs with a kernel form switched on or off)
+    if (const char* env = std::getenv("LRA_CTX_OPTIONS")) {
+        std::string text(env);
+        size_t pos = 0;
+        while (pos < text.size()) {
+            size_t end = text.find(',', pos);
+            if (end == std::string::npos) end = text.size();
+            const std::string kv = text.substr(pos, end - pos);
+            pos = end + 1;
+            if (kv.empty()) continue;
+            const size_t eq = kv.find('=');
+            int rc = eq == std::string::npos ? fail(LRA_EINVAL, "LRA_CTX_OPTIONS: expected key=value, got " + kv) : lra_ctx_set_option(c, kv.substr(0, eq).c_str(), std::atoi(kv.c_str() + eq + 1));
+            if (rc != LRA_OK) {
+                *out = nullptr;
+                lra_ctx_destroy(c);
+                return rc;
+            }
+        }
+    }
     return LRA_OK;
 }
 
@@ -1661,6 +1769,8 @@ int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value) {
     else if (!std::strcmp(key, "lds_pad")) ctx->opt_lds_pad = value;
     else if (!std::strcmp(key, "xcd_remap")) ctx->opt_xcd_remap = value != 0;
     else if (!std::strcmp(key, "v2")) ctx->opt_v2 = value != 0;
+    else if (!std::strcmp(key, "mel_pc")) ctx->opt_mel_pc = value != 0;
+    else if (!std::strcmp(key, "v3")) ctx->opt_v3 = value != 0;
     else if (!std::strcmp(key, "cqt_merge")) ctx->opt_cqt_merge = value != 0;
     else if (!std::strcmp(key, "mel_many")) ctx->opt_mel_many = value != 0;
     else if (!std::strcmp(key, "direct")) ctx->opt_direct = value != 0;

@@ -30,7 +30,10 @@ namespace lra {
 // REV_: the radices in ascending order (8, 8, 16 instead of 16, 8, 8 at M = 1024): the inverse kernel wants the
 // two-butterfly pass FIRST (its Hermitian step is fused into the first pass, see istft_unsplit_pass0) and the one-butterfly
 // radix-16 pass last (fused with the overlap-add).
-template <int LOGM_, int LOGR_, class T_, int NTMIN_ = 256, int MINW_ = 0, bool HOIST_ = true, bool REV_ = false> struct FftCfg {
+// PLAN_: how LOGM is dealt to the passes.  0: balanced (16, 8, 8 at M = 1024).  1: largest radix first, the remainder last (16, 16, 4 at M = 1024): the
+// last pass then has FOUR butterflies per thread, and a thread that takes butterflies {2t, 2t + 1} and their mirrors {s - 2t - 1, s - 2t} ends up with
+// the bins 2t, 2t + 1 (+ j s) of every mirrored pair side by side in its registers -- 16-byte pieces of the spectrum row without any exchange (lra_kernels3.h).
+template <int LOGM_, int LOGR_, class T_, int NTMIN_ = 256, int MINW_ = 0, bool HOIST_ = true, bool REV_ = false, int PLAN_ = 0> struct FftCfg {
     using real = T_;
     using cplx = cx<T_>;
     static constexpr int LOGM = LOGM_;
@@ -43,7 +46,11 @@ template <int LOGM_, int LOGR_, class T_, int NTMIN_ = 256, int MINW_ = 0, bool 
     static constexpr int FPB = NT / TF;  // frames per workgroup iteration
     static constexpr int P = (LOGM + LOGR - 1) / LOGR;
     static constexpr bool REV = REV_;
-    static constexpr int logr(int p) { return LOGM / P + ((REV_ ? p >= P - LOGM % P : p < LOGM % P) ? 1 : 0); }
+    static constexpr int PLAN = PLAN_;
+    static constexpr int logr(int p) {
+        if (PLAN_ == 1) return (p + 1) * LOGR <= LOGM ? LOGR : LOGM - p * LOGR;
+        return LOGM / P + ((REV_ ? p >= P - LOGM % P : p < LOGM % P) ? 1 : 0);
+    }
     static constexpr int logs(int p) {
         int s = 0;
         for (int q = 0; q < p; ++q) s += logr(q);
@@ -72,7 +79,7 @@ template <int LOGM_, int LOGR_, class T_, int NTMIN_ = 256, int MINW_ = 0, bool 
     static constexpr int MIN_WAVES = MINW_ > 0 ? MINW_ : 2;
     static constexpr bool HOIST = HOIST_;
     // same transform, different workgroup size (the mel kernel shares its filter tables across slots)
-    template <int NT2> using with_nt = FftCfg<LOGM_, LOGR_, T_, NT2, MINW_, HOIST_, REV_>;
+    template <int NT2> using with_nt = FftCfg<LOGM_, LOGR_, T_, NT2, MINW_, HOIST_, REV_, PLAN_>;
     // a frame slot (TF threads) never spans two waves: slot-private LDS traffic needs no s_barrier
     static constexpr bool WAVE_SYNC = TF <= 64;
 };

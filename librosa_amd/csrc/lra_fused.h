@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include "lra_dispatch.h"
+#include "lra_kernels_pc.h"
 
 // The PCM input and the output travel as separate __restrict__ kernel parameters (not only inside the
 // argument struct): without the noalias guarantee hipcc must assume that the next frame's sample
@@ -35,8 +36,11 @@ __global__ __launch_bounds__(Cfg::NT, Cfg::MIN_WAVES) void stft_kernel(lra::Stft
 // Second-generation forward kernel (lra_kernels2.h): PCM ring in registers, mirrored last pass with the split step in
 // registers.  HD = n_fft / hop.  The register budget is sized for 3 waves per SIMD (12 slots of 8.7 KB per CU) where the
 // kernel fits it without spilling (n_fft = 2048 with hop <= n_fft/4, i.e. at most 4 sample pairs in flight per thread).
+#ifndef LRA_V3_WAVES
+#define LRA_V3_WAVES 3  // waves per SIMD the radix 16-16-4 form is compiled for
+#endif
 template <class Cfg, int HD, int MODE, int PM>
-__global__ __launch_bounds__(Cfg::NT, (Cfg::NT > 256 ? 1 : (Cfg::TF == 64 && HD >= 4 && PM != lra::POW_GENERAL && MODE != lra::OUT_MELR ? 3 : 2))) void stft2_kernel(lra::StftArgs<typename Cfg::real> a, const typename Cfg::real* __restrict__ y,
+__global__ __launch_bounds__(Cfg::NT, (Cfg::NT > 256 ? 1 : (Cfg::TF == 64 && HD >= 4 && PM != lra::POW_GENERAL && MODE != lra::OUT_MELR ? (Cfg::PLAN == 1 ? LRA_V3_WAVES : 3) : 2))) void stft2_kernel(lra::StftArgs<typename Cfg::real> a, const typename Cfg::real* __restrict__ y,
                                                                                   void* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char lra_smem[];
     lra::Lds lds;
@@ -48,6 +52,19 @@ __global__ __launch_bounds__(Cfg::NT, (Cfg::NT > 256 ? 1 : (Cfg::TF == 64 && HD 
     const int blk = lra::xcd_block((int)blockIdx.x, a.xcd_chunk);
     if (blk >= a.n_blocks) return;
     lra::stft_block2<Cfg, HD, MODE, PM>(a, blk, lds);
+}
+
+// Producer / consumer form of the fused mel kernel (lra_kernels_pc.h): 192-thread workgroups [P, P, C], three waves per SIMD.
+template <class Cfg, int HD, int PM>
+__global__ __launch_bounds__(lra::PcLayout<Cfg>::NT, 3) void stft_pc_kernel(lra::StftArgs<typename Cfg::real> a, const typename Cfg::real* __restrict__ y, void* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char lra_smem[];
+    lra::Lds lds;
+    lds.base = lra_smem;
+    a.y = y;
+    a.Mel = static_cast<typename Cfg::real*>(out);
+    const int blk = lra::xcd_block((int)blockIdx.x, a.xcd_chunk);
+    if (blk >= a.n_blocks) return;
+    lra::stft_pc_block<Cfg, HD, PM>(a, blk, lds);
 }
 
 template <class Cfg, int HC>
@@ -79,6 +96,7 @@ LRA_CFG_ALIAS(cfg_f32_10, float, 10, 0)
 LRA_CFG_ALIAS(cfg_f32_10v1, float, 10, 1)
 LRA_CFG_ALIAS(cfg_f32_10v4, float, 10, 4)
 LRA_CFG_ALIAS(cfg_f32_10r, float, 10, 5)
+LRA_CFG_ALIAS(cfg_f32_10g, float, 10, 6)
 LRA_CFG_ALIAS(cfg_f32_11, float, 11, 0)
 LRA_CFG_ALIAS(cfg_f32_12, float, 12, 0)
 LRA_CFG_ALIAS(cfg_f32_13, float, 13, 0)
@@ -134,8 +152,14 @@ LRA_CFG_ALIAS(cfg_f64_12, double, 12, 0)
 #define LRA_INST2_GROUP_9(T, I) LRA_STFT2_CFG(T, cfg_f32_10) LRA_STFT2_MEL(T, cfg_f32_10_mel)
 // ... and the inverse kernel on the ascending-radix configuration (Hermitian step fused into the first pass)
 #define LRA_INST2_GROUP_10(T, I) LRA_STFT2_CFG(T, cfg_f32_9) LRA_STFT2_CFG(T, cfg_f32_11) I(lra::cfg_f32_10r, 8) I(lra::cfg_f32_10r, 4) I(lra::cfg_f32_10r, 2) I(lra::cfg_f32_10r, 1)
-#define LRA_INST2_ALL(T, I) LRA_INST2_GROUP_9(T, I) LRA_INST2_GROUP_10(T, I)
-#define LRA_INST_NUM_GROUPS 11
+#define LRA_INST2_ALL(T, I) LRA_INST2_GROUP_9(T, I) LRA_INST2_GROUP_10(T, I) LRA_INST2_GROUP_12(T, I)
+// producer / consumer mel kernels: P(CFG, HD, PM)
+#define LRA_PC_HD(P, C, HD) P(lra::C, HD, 1) P(lra::C, HD, 2) P(lra::C, HD, 3)
+#define LRA_INST3_GROUP_11(P) LRA_PC_HD(P, cfg_f32_10, 4) LRA_PC_HD(P, cfg_f32_10, 8)
+#define LRA_INST3_ALL(P) LRA_INST3_GROUP_11(P)
+// the radix 16-16-4 form of the second-generation forward kernels (variant 6)
+#define LRA_INST2_GROUP_12(T, I) LRA_STFT2_CFG(T, cfg_f32_10g)
+#define LRA_INST_NUM_GROUPS 13
 #define LRA_INST_ALL(S, I)                                                                                                   \
     LRA_INST_GROUP_0(S, I) LRA_INST_GROUP_1(S, I) LRA_INST_GROUP_2(S, I) LRA_INST_GROUP_3(S, I) LRA_INST_GROUP_4(S, I)       \
     LRA_INST_GROUP_5(S, I) LRA_INST_GROUP_6(S, I) LRA_INST_GROUP_7(S, I) LRA_INST_GROUP_8(S, I)
@@ -150,7 +174,11 @@ LRA_CFG_ALIAS(cfg_f64_12, double, 12, 0)
 #define LRA_T_EXTERN(C, HD, MODE, PM) extern template __global__ void stft2_kernel<C, HD, MODE, PM>(LRA_STFT_SIG(C));
 #define LRA_T_DEFINE(C, HD, MODE, PM) template __global__ void stft2_kernel<C, HD, MODE, PM>(LRA_STFT_SIG(C));
 
+#define LRA_P_EXTERN(C, HD, PM) extern template __global__ void stft_pc_kernel<C, HD, PM>(LRA_STFT_SIG(C));
+#define LRA_P_DEFINE(C, HD, PM) template __global__ void stft_pc_kernel<C, HD, PM>(LRA_STFT_SIG(C));
+
 #if defined(LRA_FUSED_EXTERN) && !defined(LRA_PROBE_ONLY)
 LRA_INST_ALL(LRA_S_EXTERN, LRA_I_EXTERN)
 LRA_INST2_ALL(LRA_T_EXTERN, LRA_I_EXTERN)
+LRA_INST3_ALL(LRA_P_EXTERN)
 #endif

@@ -102,7 +102,7 @@ template <class Cfg, int HD> struct Regs2 {
     C pf[NEW];         // next frame's new sample pairs, in flight during the current frame
     C win2[R];         // window pairs (x 1/2, see split_pair), pass-0 order
     C treg[Cfg::TREG_TOTAL];
-    C twr[rl];         // split twiddles W_N^k of this thread's rl pair slots
+    C twr[R / 2];      // split twiddles W_N^k of this thread's R / 2 pair slots (= rl with a two-butterfly last pass)
     // OUT_MELR (run-ordered two-slope mel epilogue, lra_mel.h layout 1): this thread's two runs of R/2 power values, the
     // restart factors of its running sums, the first MELR_PHOIST piece addresses of its two mel bands and the last
     // MELR_TILE frames' values of those bands (stored as one burst per band, see FftRegs)
@@ -375,7 +375,7 @@ template <class Cfg> LRA_HD int v2_pw_index(int k) { return v2_pw_index_t<v2_pw_
 template <class Cfg> constexpr int v2_pw_bytes() { return (v2_pw_swz<Cfg>() ? Cfg::M + 8 : (Cfg::M >> 3) * 12 + 4) * (int)sizeof(typename Cfg::real); }
 
 // phase: last-pass butterflies, Hermitian split in registers, epilogue (complex spectrum or |X|^power) to HBM
-template <class Cfg, int HD, int MODE, int PM, bool STAGED>
+template <class Cfg, int HD, int MODE, int PM, bool STAGED, bool PIN = true>
 LRA_HD void v2_last_split_store(const StftArgs<typename Cfg::real>& a, int clip, int frame, bool valid, int tf, Regs2<Cfg, HD>& rg, Lds stage) {
     using T = typename Cfg::real;
     using C = typename Cfg::cplx;
@@ -403,7 +403,8 @@ LRA_HD void v2_last_split_store(const StftArgs<typename Cfg::real>& a, int clip,
             pwk[1][par] = v2_pw_index<Cfg>(tfh + par * s) * (int)sizeof(T);
             pwm[0][par] = v2_pw_index<Cfg>(M - tf - par * s) * (int)sizeof(T);
             pwm[1][par] = v2_pw_index<Cfg>(M - tfh - par * s) * (int)sizeof(T);
-            LRA_KEEP(pwk[0][par]); LRA_KEEP(pwk[1][par]); LRA_KEEP(pwm[0][par]); LRA_KEEP(pwm[1][par]);
+            // (PIN = false: the producer / consumer kernel, whose 168-VGPR producer spills a window pair with the pins and needs no more instructions without them)
+            if (PIN) { LRA_KEEP(pwk[0][par]); LRA_KEEP(pwk[1][par]); LRA_KEEP(pwm[0][par]); LRA_KEEP(pwm[1][par]); }
         }
     }
     LRA_UNROLL
@@ -552,12 +553,245 @@ template <class Cfg, int HD> LRA_HD void v2_mel_accumulate(const StftArgs<typena
     }
 }
 
+
+// ---- third form: radices 16, 16, 4 -- adjacent bins side by side in one thread (round 6) ---------------------------------------
+// FftCfg<..., PLAN = 1> at M = 1024.  The last pass has s = 256 butterflies of radix 4, four per thread: thread t takes
+//     E = 2t,   O = 2t + 1,   Om = s - 1 - 2t (the mirror of O),   Em = s - 2t (the mirror of E; thread 0: s / 2, the other self-mirrored one),
+// outputs of butterfly b at b + j s.  Every mirrored pair (Z[k], Z[M - k]) is still in ONE thread -- (E[j], Em[3 - j]) is k = 2t + j s and
+// (O[j], Om[3 - j]) is k = 2t + 1 + j s -- AND bins 2t, 2t + 1 (+ j s) are neighbours, as are M - 2t - 1, M - 2t (- j s): the spectrum row leaves as
+// 4 + 4 global_store_dwordx4 per thread, a wave instruction covering 1 KiB of the row, with no lane exchange and no staging (the lane-pair
+// exchange of round 5 cost ~85 instructions per frame, profiles/r05_pitch.md section 4).  Against the two-butterfly form: 22 instead of 48 lane-0
+// selects, 8 instead of 16 row stores; the transform's own arithmetic is the same within two instructions (42 twiddle products against 44,
+// 114 butterfly instructions against 112).
+// LDS hand-over middle pass -> last pass: element i at slot i + 16 (i >> 8) (blocks of 256 + 16 slots): the middle pass's stores (lanes 16 a + k
+// -> 256 a + k + 16 j) are conflict-free, the last pass reads (E, O)[j] as ONE aligned 16-byte piece at 16 t + 2176 j, Om / Em as 8-byte reads.
+#ifndef LRA_V3_DERIVE_TWR
+#define LRA_V3_DERIVE_TWR 1
+#endif
+template <class Cfg> constexpr bool v3_cfg_ok() {
+    return Cfg::PLAN == 1 && Cfg::P == 3 && Cfg::R == 16 && Cfg::HOIST && sizeof(typename Cfg::real) == 4 && Cfg::logr(0) == 4 && Cfg::logr(1) == 4 && Cfg::logr(2) == 2 &&
+           Cfg::TF == 64 && affine_tf<Cfg>();
+}
+template <class Cfg> constexpr bool v23_cfg_ok() { return v2_cfg_ok<Cfg>() || v3_cfg_ok<Cfg>(); }
+constexpr int V3_BLOCK = 256 + 16;  // slots per block of 256 elements in the middle -> last hand-over
+// last-pass butterfly i of thread tf (i = 0: E, 1: O, 2: Om, 3: Em)
+template <class Cfg> LRA_HD int v3_bfly(int tf, int i) {
+    constexpr int s = 4 * Cfg::TF;
+    return i == 0 ? 2 * tf : (i == 1 ? 2 * tf + 1 : (i == 2 ? s - 1 - 2 * tf : (tf == 0 ? s / 2 : s - 2 * tf)));
+}
+// bin of pair slot q: q < 4: the E slots (k = 2 tf + q s; thread 0's slots 2 and 3 hold butterfly s/2's pairs, bins s/2 and s/2 + s), q >= 4: the O slots
+template <class Cfg> LRA_HD int v3_slot_bin(int tf, int q) {
+    constexpr int s = 4 * Cfg::TF;
+    if (q >= 4) return 2 * tf + 1 + (q - 4) * s;
+    if (tf == 0 && q >= 2) return s / 2 + (q - 2) * s;
+    return 2 * tf + q * s;
+}
+template <class Cfg, int HD> LRA_HD void v3_hoist(Regs2<Cfg, HD>& rg, int tf, const typename Cfg::real* __restrict__ win, const typename Cfg::cplx* __restrict__ tw,
+                                                   const typename Cfg::cplx* __restrict__ twr_full) {
+    using C = typename Cfg::cplx;
+    using RG = Regs2<Cfg, HD>;
+    const C* __restrict__ win2 = reinterpret_cast<const C*>(win);
+    LRA_UNROLL
+    for (int e = 0; e < Cfg::R; ++e) rg.win2[e] = win2[RG::q_of(tf, e)];
+    load_pass_twiddles<Cfg, 1>(rg.treg, tf, tw);
+    {
+        constexpr int p = 2, lr = 2, s = 1 << Cfg::logs(p);
+        LRA_UNROLL
+        for (int i = 0; i < 4; ++i) {
+            const int k = v3_bfly<Cfg>(tf, i);
+            LRA_UNROLL
+            for (int t = 0; t < lr; ++t) rg.treg[Cfg::treg_off(p) + i * lr + t] = tw[Cfg::tw_off(p) + ((1 << t) - 1) * s + k];
+        }
+    }
+    // (the O slots' twiddles W_N^(2 tf + 1 + j s), j = 1 .. 3, are W_N^(2 tf + 1) times e^(-i pi j / 4): three or four instructions per frame in
+    // v3_last_split_store instead of six registers -- with all eight held the complex kernel needs 174 VGPRs, six more than three waves per SIMD allow)
+    LRA_UNROLL
+    for (int q = 0; q < (LRA_V3_DERIVE_TWR ? 5 : 8); ++q) rg.twr[q] = twr_full[v3_slot_bin<Cfg>(tf, q)];
+}
+// middle pass twiddles, register-lean.  pass_twiddle_dft_reg derives all fifteen W^(k j) from the four stored powers first (w[16] + q[16] live next to
+// v[16]: the complex kernel then needs ~206 VGPRs and spills 38 under the three-wave budget).  Here W^(k (8 + j)) v = W^(k j) (W^(8 k) v): the upper eight
+// inputs take W^(8 k) first, then each W^(k j), j = 1 .. 7, multiplies v[j] AND v[8 + j] and is dead -- the same 26 complex products, three twiddles live.
+template <class Cfg> LRA_HD void v3_mid_twiddle_dft(typename Cfg::cplx* v, const typename Cfg::cplx* treg) {
+    using T = typename Cfg::real;
+    using C = typename Cfg::cplx;
+    constexpr int o = Cfg::treg_off(1);
+    const C w1 = treg[o], w2 = treg[o + 1], w4 = treg[o + 2], w8 = treg[o + 3];
+    LRA_UNROLL
+    for (int h = 0; h < 2; ++h) {
+        C q[4];
+        LRA_UNROLL
+        for (int j = 0; j < 4; ++j) q[j] = cmul_p(v[8 + 4 * h + j], w8);
+        LRA_UNROLL
+        for (int j = 0; j < 4; ++j) v[8 + 4 * h + j] = cmul_f(v[8 + 4 * h + j], w8, q[j]);
+    }
+    // j = 1, 2, 4, 8 are the stored powers; 3 = 1 + 2, 7 = 3 + 4, 5 = 1 + 4, 6 = 2 + 4 are derived one at a time, each started (cmul_p) alongside the
+    // data products of the previous one and dead after its own two: at most two derived twiddles and five half-products live at any point
+#define LRA_V3_TW2(j, w)                                                    \
+    const C qa##j = cmul_p(v[j], w), qb##j = cmul_p(v[8 + j], w);
+#define LRA_V3_TW2F(j, w)                                                   \
+    v[j] = cmul_f(v[j], w, qa##j);                                          \
+    v[8 + j] = cmul_f(v[8 + j], w, qb##j);
+    const C q3 = cmul_p(w1, w2);
+    LRA_V3_TW2(1, w1) LRA_V3_TW2(2, w2)
+    const C w3 = cmul_f(w1, w2, q3);
+    LRA_V3_TW2F(1, w1) LRA_V3_TW2F(2, w2)
+    const C q7 = cmul_p(w3, w4);
+    LRA_V3_TW2(3, w3) LRA_V3_TW2(4, w4)
+    const C w7 = cmul_f(w3, w4, q7);
+    LRA_V3_TW2F(3, w3) LRA_V3_TW2F(4, w4)
+    const C q5 = cmul_p(w1, w4);
+    LRA_V3_TW2(7, w7)
+    const C w5 = cmul_f(w1, w4, q5);
+    LRA_V3_TW2F(7, w7)
+    const C q6 = cmul_p(w2, w4);
+    LRA_V3_TW2(5, w5)
+    const C w6 = cmul_f(w2, w4, q6);
+    LRA_V3_TW2F(5, w5)
+    LRA_V3_TW2(6, w6)
+    LRA_V3_TW2F(6, w6)
+#undef LRA_V3_TW2
+#undef LRA_V3_TW2F
+    Dft<16, T>::run(v);
+}
+// middle pass (radix 16, one butterfly per thread): output j of butterfly tf = 16 a + k -> element 256 a + k + 16 j
+template <class Cfg> LRA_HD void v3_mid_write(const typename Cfg::cplx* v, Lds fr, int tf) {
+    using C = typename Cfg::cplx;
+    const int base = (V3_BLOCK * (tf >> 4) + (tf & 15)) * (int)sizeof(C);
+    LRA_UNROLL
+    for (int j = 0; j < 16; ++j) lds_st<C>(fr, base + j * 16 * (int)sizeof(C), v[j]);
+}
+// inputs of the four last-pass butterflies: v[4 i + j] = input j of butterfly i (element b_i + 256 j)
+template <class Cfg, int HD> LRA_HD void v3_last_read(Regs2<Cfg, HD>& rg, Lds fr, int tf) {
+    using T = typename Cfg::real;
+    using C = typename Cfg::cplx;
+    constexpr int BB = V3_BLOCK * (int)sizeof(C);
+    LRA_UNROLL
+    for (int j = 0; j < 4; ++j) {
+        const V4<T> eo = lds_ld<V4<T>>(fr, 2 * (int)sizeof(C) * tf + j * BB);
+        rg.v[j] = mk<T>(eo.a, eo.b);
+        rg.v[4 + j] = mk<T>(eo.c, eo.d);
+    }
+    const int bo = v3_bfly<Cfg>(tf, 2) * (int)sizeof(C), be = v3_bfly<Cfg>(tf, 3) * (int)sizeof(C);
+    LRA_UNROLL
+    for (int j = 0; j < 4; ++j) {
+        rg.v[8 + j] = lds_ld<C>(fr, bo + j * BB);
+        rg.v[12 + j] = lds_ld<C>(fr, be + j * BB);
+    }
+}
+// two neighbouring elements as one store (global_store_dwordx4 / dwordx2: the pointer need only be element-aligned)
+template <class V> LRA_HD void store_pair(V* p, V lo, V hi) {
+#if !defined(LRA_HOSTSIM)
+    if constexpr (sizeof(V) == 8) {
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
+        const cx<float> l = __builtin_bit_cast(cx<float>, lo), h = __builtin_bit_cast(cx<float>, hi);
+        f4u v;
+        v.x = l.x; v.y = l.y; v.z = h.x; v.w = h.y;
+        *reinterpret_cast<f4u*>(p) = v;
+        return;
+    } else if constexpr (sizeof(V) == 4) {
+        typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+        f2u v;
+        v.x = __builtin_bit_cast(float, lo); v.y = __builtin_bit_cast(float, hi);
+        *reinterpret_cast<f2u*>(p) = v;
+        return;
+    }
+#endif
+    p[0] = lo;
+    p[1] = hi;
+}
+// phase: last-pass butterflies, Hermitian split in registers, epilogue
+template <class Cfg, int HD, int MODE, int PM, bool PIN = true>
+LRA_HD void v3_last_split_store(const StftArgs<typename Cfg::real>& a, int clip, int frame, bool valid, int tf, Regs2<Cfg, HD>& rg, Lds stage) {
+    using T = typename Cfg::real;
+    using C = typename Cfg::cplx;
+    constexpr int M = Cfg::M, s = 4 * Cfg::TF;
+    static_assert(4 * s == M, "last pass: four butterfly outputs s apart");
+    pass_twiddle_dft_reg<Cfg, 2>(rg.v, rg.treg);
+    const C* E = rg.v;        // E[j]  = Z[2 tf + j s]            (thread 0: Z[j s])
+    const C* O = rg.v + 4;    // O[j]  = Z[2 tf + 1 + j s]
+    const C* Om = rg.v + 8;   // Om[j] = Z[s - 1 - 2 tf + j s]
+    const C* Em = rg.v + 12;  // Em[j] = Z[s - 2 tf + j s]        (thread 0: Z[s / 2 + j s])
+    const bool l0 = tf == 0;
+    const LaneMask l0m = lane_mask(l0);
+    const C xmid = mk<T>((T)2 * E[2].x, (T)-2 * E[2].y);  // X[M/2] = conj(Z[M/2]) (Z pre-halved): thread 0's E[2]
+    const long long row = ((long long)clip * a.n_frames + frame) * a.row_pitch;
+    C* __restrict__ const D = MODE == OUT_COMPLEX ? a.D + row : nullptr;
+    T* __restrict__ const S = MODE == OUT_POWER ? a.S + row : nullptr;
+    int ia = 0, im1 = 0, im0 = 0;
+    if (MODE == OUT_MELR) {
+        // the power row (v2_pw_index: linear over steps of 256 bins, neighbours 2 t, 2 t + 1 in one 8-byte slot)
+        ia = v2_pw_index<Cfg>(2 * tf) * (int)sizeof(T); im1 = v2_pw_index<Cfg>(M - 1 - 2 * tf) * (int)sizeof(T); im0 = v2_pw_index<Cfg>(M - 2 * tf) * (int)sizeof(T);
+        if (PIN) { LRA_KEEP(ia); LRA_KEEP(im1); LRA_KEEP(im0); }
+    }
+    // Row pieces.  Ascending piece j = bins (2 tf + j s, + 1) = (X of E slot j, X of O slot j); mirrored piece j = bins (M - 2 tf - 1 - j s, + 1) =
+    // (X' of O slot j, X' of E slot j).  Thread 0's E slots: 0 is the DC / Nyquist pair; 1 pairs butterfly 0 with itself (Z[s], Z[3 s]); 2 and 3 take
+    // butterfly s/2's pairs (Z[s/2], Z[s/2 + 3 s]) and (Z[s/2 + s], Z[s/2 + 2 s]), whose four bins leave as single stores, while the E halves of its
+    // pieces 2 and 3 carry X[2 s] = xmid and X[3 s] / X[s] = slot 1's results -- bins s, 2 s, 3 s are written twice (ascending and mirrored piece) from
+    // the SAME register.  Slot 1 goes first because pieces 3 need it.
+    C x1k = mk<T>((T)0, (T)0), x1m = x1k;
+    LRA_UNROLL
+    for (int jo = 0; jo < 4; ++jo) {
+        const int j = jo == 0 ? 1 : (jo == 1 ? 0 : jo);  // 1, 0, 2, 3
+        C xkO, xmO, xkE, xmE;
+        C wO = rg.twr[LRA_V3_DERIVE_TWR ? 4 : 4 + j];
+        if (LRA_V3_DERIVE_TWR && j > 0) {
+            const T h = (T)0.70710678118654752440;
+            const C t = rg.twr[4];
+            if (j == 1) { const C u = add_mi(t, t); wO = mk<T>(h * u.x, h * u.y); }          // e^(-i pi / 4) = h (1 - i)
+            else if (j == 2) wO = cmul_mi(t);                                               // e^(-i pi / 2) = -i
+            else { const C u = sub_mi(t, t); wO = mk<T>(-h * u.x, -h * u.y); }              // e^(-3 i pi / 4) = -h (1 + i)
+        }
+        split_pair<T>(O[j], Om[3 - j], wO, xkO, xmO);
+        C zk = E[j], zm = Em[3 - j];
+        if (j == 1) zm = sel_mask(l0m, l0, E[3], Em[2]);
+        if (j == 2) { zk = sel_mask(l0m, l0, Em[0], E[2]); zm = sel_mask(l0m, l0, Em[3], Em[1]); }
+        if (j == 3) { zk = sel_mask(l0m, l0, Em[1], E[3]); zm = sel_mask(l0m, l0, Em[2], Em[0]); }
+        split_pair<T>(zk, zm, rg.twr[j], xkE, xmE);
+        if (j == 0) {
+            const C z0 = E[0];  // Z is pre-halved (see split_pair)
+            const C dc = mk<T>((T)2 * (z0.x + z0.y), (T)0), ny = mk<T>((T)2 * (z0.x - z0.y), (T)0);
+            xkE = sel_mask(l0m, l0, dc, xkE);
+            xmE = sel_mask(l0m, l0, ny, xmE);
+            if (LRA_UNLIKELY(l0 && valid && a.nonfinite_flag && !(std::fabs(dc.x) <= std::numeric_limits<T>::max()))) LRA_ATOMIC_OR(a.nonfinite_flag, 1u);
+        }
+        if (j == 1) { x1k = xkE; x1m = xmE; }
+        C ascE = xkE, mirE = xmE;  // the E halves of the two pieces
+        if (j == 2) { ascE = sel_mask(l0m, l0, xmid, xkE); mirE = sel_mask(l0m, l0, xmid, xmE); }
+        if (j == 3) { ascE = sel_mask(l0m, l0, x1m, xkE); mirE = sel_mask(l0m, l0, x1k, xmE); }
+        if (MODE == OUT_COMPLEX) {
+            if (valid) {
+                store_pair<C>(D + 2 * tf + j * s, ascE, xkO);
+                store_pair<C>(D + (M - 1 - 2 * tf) - j * s, xmO, mirE);
+                if (j >= 2 && l0) { D[s / 2 + (j - 2) * s] = xkE; D[M - s / 2 - (j - 2) * s] = xmE; }
+            }
+        } else if (MODE == OUT_POWER) {
+            const T pa0 = spec_power<T, PM>(ascE, a.power), pa1 = spec_power<T, PM>(xkO, a.power), pm0 = spec_power<T, PM>(xmO, a.power), pm1 = spec_power<T, PM>(mirE, a.power);
+            T q0 = (T)0, q1 = (T)0;
+            if (j >= 2) { q0 = spec_power<T, PM>(xkE, a.power); q1 = spec_power<T, PM>(xmE, a.power); }
+            if (valid) {
+                store_pair<T>(S + 2 * tf + j * s, pa0, pa1);
+                store_pair<T>(S + (M - 1 - 2 * tf) - j * s, pm0, pm1);
+                if (j >= 2 && l0) { S[s / 2 + (j - 2) * s] = q0; S[M - s / 2 - (j - 2) * s] = q1; }
+            }
+        } else {
+            static_assert(MODE != OUT_MELR || v2_pw_swz<Cfg>(), "swizzled power row");
+            lds_st<C>(stage, ia + j * s * (int)sizeof(T), mk<T>(spec_power<T, PM>(ascE, a.power), spec_power<T, PM>(xkO, a.power)));
+            lds_st<T>(stage, im1 - j * s * (int)sizeof(T), spec_power<T, PM>(xmO, a.power));
+            lds_st<T>(stage, im0 - j * s * (int)sizeof(T), spec_power<T, PM>(mirE, a.power));
+            if (j >= 2 && l0) {
+                lds_st<T>(stage, v2_pw_index<Cfg>(s / 2 + (j - 2) * s) * (int)sizeof(T), spec_power<T, PM>(xkE, a.power));
+                lds_st<T>(stage, v2_pw_index<Cfg>(M - s / 2 - (j - 2) * s) * (int)sizeof(T), spec_power<T, PM>(xmE, a.power));
+            }
+        }
+    }
+}
+
 // bytes of LDS one frame slot needs: the frame area only
 template <class Cfg> constexpr int stft2_slot_bytes() { return Cfg::FRAME_BYTES; }
 
 // One workgroup = FPB frame slots, slot s transforms frames f_first + s iters + it, it = 0 .. iters-1 (as stft_block).
 template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2(const StftArgs<typename Cfg::real>& a_in, const int blk, Lds lds) {
-    static_assert(v2_cfg_ok<Cfg>(), "configuration has no mirrored last pass");
+    static_assert(v23_cfg_ok<Cfg>(), "configuration has no mirrored last pass");
     static_assert(MODE == OUT_COMPLEX || MODE == OUT_POWER || MODE == OUT_MELR, "epilogues of the second-generation kernel");
     static_assert(MODE != OUT_MELR || (melr_fits<Cfg>() && v2_pw_bytes<Cfg>() <= Cfg::FRAME_BYTES && (Cfg::R * (Cfg::TF + LRA_MEL_RS_PITCH_EXTRA) + 2) * 2 * (int)sizeof(typename Cfg::real) <= Cfg::FRAME_BYTES),
                   "mel epilogue: running sums (pitch TF + 1) and power row live in the frame area");
@@ -575,11 +809,12 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
 #ifndef LRA_V2_STAGED
 #define LRA_V2_STAGED 0
 #endif
-    constexpr bool STAGED = MODE == OUT_COMPLEX && LRA_V2_STAGED && sizeof(typename Cfg::real) == 4 && (Cfg::M + 3) * (int)sizeof(typename Cfg::cplx) <= SB;
+    constexpr bool STAGED = Cfg::PLAN == 0 && MODE == OUT_COMPLEX && LRA_V2_STAGED && sizeof(typename Cfg::real) == 4 && (Cfg::M + 3) * (int)sizeof(typename Cfg::cplx) <= SB;
     LRA_REGS(RG, rg, Cfg::NT);
     LRA_PHASE(Cfg::NT, tid) {
         const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
-        v2_hoist<Cfg, HD>(LRA_R(rg), tf, a.win, a.tw, a.twr);
+        if constexpr (Cfg::PLAN == 1) v3_hoist<Cfg, HD>(LRA_R(rg), tf, a.win, a.tw, a.twr);
+        else v2_hoist<Cfg, HD>(LRA_R(rg), tf, a.win, a.tw, a.twr);
         v2_fill<Cfg, HD>(a, clip, f_first + slot * iters, tf, LRA_R(rg));
         if constexpr (v2_rotate_asm_ok<Cfg, HD>() && MODE != OUT_MELR) {
             // the fill's loads are waited for HERE, once: the frame loop's first consumer of the ring is an asm block whose operands are the ring
@@ -631,20 +866,27 @@ template <class Cfg, int HD, int MODE, int PM = POW_TWO> LRA_HD void stft_block2
                 pass_read<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(rg).v, lds_sub(lds, slot_of<Cfg>(tid) * SB), lane_of<Cfg>(tid)); \
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)                                                                          \
             LRA_PHASE(Cfg::NT, tid) {                                                                                     \
-                pass_twiddle_dft_reg<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(rg).v, LRA_R(rg).treg);                             \
-                pass_write<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(rg).v, lds_sub(lds, slot_of<Cfg>(tid) * SB), lane_of<Cfg>(tid)); \
+                if constexpr (Cfg::PLAN == 1) {                                                                           \
+                    v3_mid_twiddle_dft<Cfg>(LRA_R(rg).v, LRA_R(rg).treg);                                                 \
+                    v3_mid_write<Cfg>(LRA_R(rg).v, lds_sub(lds, slot_of<Cfg>(tid) * SB), lane_of<Cfg>(tid));              \
+                } else {                                                                                                  \
+                    pass_twiddle_dft_reg<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(rg).v, LRA_R(rg).treg);                         \
+                    pass_write<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(rg).v, lds_sub(lds, slot_of<Cfg>(tid) * SB), lane_of<Cfg>(tid)); \
+                }                                                                                                         \
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)                                                                          \
         }
         LRA_MID_PASS2(1)
         LRA_MID_PASS2(2)
 #undef LRA_MID_PASS2
         LRA_PHASE(Cfg::NT, tid) {
-            v2_last_read<Cfg, HD>(LRA_R(rg), lds_sub(lds, slot_of<Cfg>(tid) * SB), lane_of<Cfg>(tid));
+            if constexpr (Cfg::PLAN == 1) v3_last_read<Cfg, HD>(LRA_R(rg), lds_sub(lds, slot_of<Cfg>(tid) * SB), lane_of<Cfg>(tid));
+            else v2_last_read<Cfg, HD>(LRA_R(rg), lds_sub(lds, slot_of<Cfg>(tid) * SB), lane_of<Cfg>(tid));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC || (LRA_SPLIT_ONE_BARRIER && MODE != OUT_MELR && !STAGED))  // (registers -> HBM next: see stft_block)
         v2_setprio<MODE == OUT_MELR ? LRA_V2_PRIO_S : (MODE == OUT_POWER ? LRA_V2_PRIO_PS : LRA_V2_PRIO_CS)>();
         LRA_PHASE(Cfg::NT, tid) {
             const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid), frame = f_first + slot * iters + it;
-            v2_last_split_store<Cfg, HD, MODE, PM, STAGED>(a, clip, frame, frame < a.n_frames, tf, LRA_R(rg), lds_sub(lds, slot * SB));
+            if constexpr (Cfg::PLAN == 1) v3_last_split_store<Cfg, HD, MODE, PM>(a, clip, frame, frame < a.n_frames, tf, LRA_R(rg), lds_sub(lds, slot * SB));
+            else v2_last_split_store<Cfg, HD, MODE, PM, STAGED>(a, clip, frame, frame < a.n_frames, tf, LRA_R(rg), lds_sub(lds, slot * SB));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         if (STAGED) {
             LRA_PHASE(Cfg::NT, tid) {

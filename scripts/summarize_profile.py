@@ -23,7 +23,7 @@ os.makedirs(dst, exist_ok=True)
 
 def short(name):
     import re
-    cfg = re.search(r"FftCfg<(\d+), (\d), (\w+), (\d+), (\d), (\w+)(?:, (\w+))?>", name)
+    cfg = re.search(r"FftCfg<(\d+), (\d), (\w+), (\d+), (\d), (\w+)(?:, (\w+))?(?:, \d+)?>", name)
     tag = f" [n_fft={2 ** (int(cfg.group(1)) + 1)}, 2^{cfg.group(2)} pts/thread, NT={cfg.group(4)}{', ascending radices' if cfg.group(7) == 'true' else ''}]" if cfg else ""
     modes = {"0": "complex64 out", "1": "power out", "2": "mel, generic", "3": "mel, two-slope", "4": "mel, run-ordered two-slope"}
     if "istft_kernel" in name:

@@ -7,6 +7,7 @@
 // linked into, imported by, or used as a fallback for the product library.
 #define LRA_HOSTSIM 1
 #include "../../librosa_amd/csrc/lra_dispatch.h"
+#include "../../librosa_amd/csrc/lra_kernels_pc.h"
 #include "../../librosa_amd/csrc/lra_mel.h"
 
 #include <cstdlib>
@@ -46,7 +47,7 @@ template <class T> struct StftSim {
             if constexpr (sizeof(typename Cfg::real) == 4) ra = ring_rows_aligned<Cfg>(a.hop) && !std::getenv("LRA_SIM_NO_RA");
             // second-generation kernel body (lra_kernels2.h), same selection as StftLaunch::launch
             bool v2 = false;
-            if constexpr (v2_cfg_ok<Cfg>() && (MODE == OUT_COMPLEX || MODE == OUT_POWER || MODE == OUT_MELR)) {
+            if constexpr (v23_cfg_ok<Cfg>() && (MODE == OUT_COMPLEX || MODE == OUT_POWER || MODE == OUT_MELR)) {
                 const int hd = (use_v2 && (MODE != OUT_MELR || mel_v2)) ? v2_hop_divisor<Cfg>(a.hop) : 0;
                 if (hd) {
                     v2 = true;
@@ -104,8 +105,54 @@ template <class T> struct StftSim {
         }
         diag[2] = Cfg::NT; diag[3] = Cfg::FPB; diag[4] = Cfg::P; diag[5] = Cfg::FPB * a.slot_bytes + shared_bytes; diag[6] = Cfg::WAVE_SYNC;
     }
+    // producer / consumer mel kernel body (lra_kernels_pc.h), selected as StftLaunch::run does (LRA_SIM_PC = the ctx option "mel_pc")
+    template <class Cfg> void run_pc(int iters, int hd) {
+        using PL = PcLayout<Cfg>;
+        std::vector<cx<T>> tw(Cfg::TW_TOTAL), twr(split_tw_count<Cfg>());
+        build_pass_twiddles<Cfg>(tw.data());
+        build_split_twiddles<Cfg>(twr.data());
+        a.tw = tw.data();
+        a.twr = twr.data();
+        a.frames_per_wg = iters * PL::NP;
+        a.wg_per_clip = (a.n_frames + a.frames_per_wg - 1) / a.frames_per_wg;
+        a.mel_tile = 1;
+        a.slot_bytes = PL::FRAME;
+        a.shared_off = 0;
+        auto& st = sim::state();
+        const long long nblk = blocks * a.wg_per_clip;
+        for (long long blk = 0; blk < nblk; ++blk) {
+            st.resize(PL::BYTES);
+            Lds lds; lds.base = 0;
+#define SIM_PC(HD)                                                                                 \
+    if (a.power_mode == POW_TWO) stft_pc_block<Cfg, HD, POW_TWO>(a, (int)blk, lds);                \
+    else if (a.power_mode == POW_ONE) stft_pc_block<Cfg, HD, POW_ONE>(a, (int)blk, lds);           \
+    else stft_pc_block<Cfg, HD, POW_GENERAL>(a, (int)blk, lds);
+            if (hd == 4) { SIM_PC(4) } else { SIM_PC(8) }
+#undef SIM_PC
+            diag[0] += st.races; diag[1] += st.uninit;
+            st.races = st.uninit = 0;
+        }
+        diag[2] = PL::NT; diag[3] = PL::NP; diag[4] = Cfg::P; diag[5] = PL::BYTES; diag[6] = 1; diag[10] = 2;  // (v2 = 2: the producer / consumer body ran)
+    }
     template <class Cfg> void operator()() {
         const int iters = a.frames_per_wg;  // caller passes the iteration count
+        if (mode == OUT_MELR && std::getenv("LRA_SIM_PC")) {
+            if constexpr (pc_cfg_ok<Cfg>()) {
+                TwoSlope<T> ts = build_two_slope<T>(dense_basis, a.n_mels, Cfg::M + 1);
+                const int hd = v2_hop_divisor<Cfg>(a.hop);
+                if (ts.ok && (hd == 4 || hd == 8)) {
+                    MelRuns<T> mr = build_mel_runs<T>(ts, Cfg::TF, Cfg::R / 2, MELR_PMAX, 4, 1);
+                    if (mr.ok && pc_bank_ok<Cfg>(a.n_mels, mr.pmax)) {
+                        a.melr_w = mr.w.data(); a.melr_keep = mr.keep.data(); a.melr_addr = mr.addr.data(); a.melr_zero = mr.zero_addr; a.melr_mid = mr.mid_addr; a.melr_pmax = mr.pmax;
+                        diag[9] = mr.max_pieces;
+                        run_pc<Cfg>(iters, hd);
+                        return;
+                    }
+                }
+            }
+            diag[7] = 3;  // not applicable: the library keeps stft2_kernel<OUT_MELR>
+            return;
+        }
         if (mode == OUT_MEL2) {
             using MC = typename MelCfgOf<Cfg>::type;
             TwoSlope<T> ts = build_two_slope<T>(dense_basis, a.n_mels, Cfg::M + 1);
@@ -131,7 +178,7 @@ template <class T> struct StftSim {
             }
             if (!ts.ok || !melr_fits<MC>()) { diag[7] = 1; return; }
             bool v2m = false;
-            if constexpr (v2_cfg_ok<MC>()) v2m = use_v2 && v2_hop_divisor<MC>(a.hop) > 0;
+            if constexpr (v23_cfg_ok<MC>()) v2m = use_v2 && v2_hop_divisor<MC>(a.hop) > 0;
             mel_v2 = v2m;
             MelRuns<T> mr = build_mel_runs<T>(ts, MC::TF, MC::R / 2, MELR_PMAX, FftRegs<MC>::MELR_PHOIST, v2m ? 1 : 0);
             if (!mr.ok) { diag[7] = 2; return; }

@@ -1136,6 +1136,101 @@ def test_direct_framing(L, n_fft, hop, center, pad_mode, dtype):
         ctx.set_option("direct", 1)
 
 
+# ---- round 6: the two new forms of the n_fft = 2048 forward kernels, switched on by context options ---------------------------------------------
+@pytest.mark.parametrize("hop,power,n,batch", [(512, 2.0, 22050, 2), (512, 2.0, 9000, 3), (512, 2.0, 661500, 5), (256, 2.0, 100000, 4), (256, 1.0, 100000, 4), (512, 2.0, 2048, 1), (512, 2.0, 70001, 7)])
+def test_producer_consumer_mel_kernel(L, hop, power, n, batch):
+    """ctx option mel_pc (csrc/lra_kernels_pc.h: 192-thread workgroups [P, P, C], the power row handed from the FFT waves to the mel wave through LDS flags):
+    against the oracle at the pure-relative bar on noise-floored input, against the one-wave kernel at rounding level, every output element stored
+    (the result buffer starts as NaN).  librosa/feature/spectral.py:2158-2160."""
+    import torch
+    ctx = L.get_context(0)
+    y = O.config_input(batch, n=n)
+    ref = O.melspectrogram(y=y, sr=22050, n_fft=2048, hop_length=hop, n_mels=128, power=power)
+    yt = torch.from_numpy(y).to("cuda:0")
+    try:
+        outs = []
+        for pc in (0, 1):
+            ctx.set_option("mel_pc", pc)
+            M = L.feature.melspectrogram(y=yt, sr=22050, n_fft=2048, hop_length=hop, n_mels=128, power=power).cpu().numpy()
+            assert M.shape == ref.shape and not np.isnan(M).any()
+            assert np.all(np.abs(M - ref) <= 1e-4 * np.abs(ref)), (pc, float(np.max(np.abs(M - ref) / np.abs(ref))))
+            outs.append(M)
+        assert np.all(np.abs(outs[1] - outs[0]) <= 2e-5 * np.abs(outs[0]))  # (two float32 kernels: same operations, different fused-multiply-add contraction)
+        # NumPy drop-in through the host pipeline with the option on
+        ctx.set_option("mel_pc", 1)
+        Mh = L.feature.melspectrogram(y=y, sr=22050, n_fft=2048, hop_length=hop, n_mels=128, power=power)
+        assert np.array_equal(Mh, outs[1])
+    finally:
+        ctx.set_option("mel_pc", 0)
+
+
+def test_producer_consumer_mel_kernel_full_size(L):
+    """BASELINE configs[1] through the producer / consumer kernel: 256 clips x 30 s, four clips at the pure-relative bar, per-clip independence (clip i of the
+    batch == clip i alone), and banks it does not serve (40 bands: segments wider than its register lists) still answered by the one-wave kernel."""
+    import torch
+    ctx = L.get_context(0)
+    y = O.config_input(256)
+    yt = torch.from_numpy(y).to("cuda:0")
+    try:
+        ctx.set_option("mel_pc", 1)
+        M = L.feature.melspectrogram(y=yt, sr=22050, n_fft=2048, hop_length=512, n_mels=128)
+        assert not bool(torch.isnan(M).any())
+        for i in (0, 71, 128, 255):
+            ref = O.melspectrogram(y=y[i], sr=22050, n_fft=2048, hop_length=512, n_mels=128)
+            got = M[i].cpu().numpy()
+            assert np.all(np.abs(got - ref) <= 1e-4 * np.abs(ref)), i
+            assert np.array_equal(L.feature.melspectrogram(y=yt[i], sr=22050, n_fft=2048, hop_length=512, n_mels=128).cpu().numpy(), got)
+        M40 = L.feature.melspectrogram(y=yt[:3], sr=22050, n_fft=2048, hop_length=512, n_mels=40).cpu().numpy()
+        ctx.set_option("mel_pc", 0)
+        assert np.array_equal(M40, L.feature.melspectrogram(y=yt[:3], sr=22050, n_fft=2048, hop_length=512, n_mels=40).cpu().numpy())
+    finally:
+        ctx.set_option("mel_pc", 0)
+
+
+@pytest.mark.parametrize("hop,center,pad_mode,n", [(512, True, "constant", 22050), (512, True, "reflect", 9000), (256, True, "edge", 100000), (1024, False, "constant", 100000), (2048, True, "symmetric", 50000),
+                                                   (512, True, "constant", 2048), (512, False, "constant", 70001)])
+def test_radix_16_16_4_forward(L, hop, center, pad_mode, n):
+    """ctx option v3 (variant 6: radices 16, 16, 4 -- neighbouring bins side by side in one thread, the row leaving as 16-byte pieces): stft and
+    _spectrogram against the oracle, packed rows and rows padded to 128-byte lines, NaN-poisoned padding untouched.  librosa/core/spectrum.py:356, 380-390."""
+    import torch
+    ctx = L.get_context(0)
+    y = np.random.default_rng(hop + n).standard_normal((3, n)).astype(np.float32)
+    ref = O.stft(y, n_fft=2048, hop_length=hop, center=center, pad_mode=pad_mode)
+    try:
+        ctx.set_option("v3", 1)
+        D = L.stft(y, n_fft=2048, hop_length=hop, center=center, pad_mode=pad_mode)
+        assert D.shape == ref.shape and _stft_close(D, ref)
+        for power in (1.0, 2.0, 1.5):
+            S, _ = L._spectrogram(y=y, n_fft=2048, hop_length=hop, power=power, center=center, pad_mode=pad_mode)
+            assert np.all(np.abs(S - np.abs(ref) ** power) <= 4e-6 * (np.abs(ref) ** power).max())
+        Dp = L.stft(torch.from_numpy(y).to("cuda:0"), n_fft=2048, hop_length=hop, center=center, pad_mode=pad_mode, row_align=128)
+        assert Dp.stride(-1) == 1040 and _stft_close(Dp.cpu().numpy(), ref)
+        ctx.set_option("v3", 0)
+        D0 = L.stft(y, n_fft=2048, hop_length=hop, center=center, pad_mode=pad_mode)
+        assert np.abs(D - D0).max() <= 1e-6 * np.abs(D0).max()
+    finally:
+        ctx.set_option("v3", 0)
+
+
+def test_radix_16_16_4_forward_full_size(L):
+    """BASELINE configs[3]'s forward leg through variant 6: 256 x 30 s, sampled clips against the oracle, round trip through the inverse kernel >= 60 dB on every clip."""
+    import torch
+    ctx = L.get_context(0)
+    y = O.config_input(256)
+    yt = torch.from_numpy(y).to("cuda:0")
+    try:
+        ctx.set_option("v3", 1)
+        D = L.stft(yt, n_fft=2048, hop_length=512)
+        for i in (0, 100, 255):
+            assert _stft_close(D[i].cpu().numpy(), O.stft(y[i], n_fft=2048, hop_length=512))
+        yh = L.istft(D, hop_length=512, length=y.shape[-1])
+        err = ((yt - yh).double() ** 2).sum(-1)
+        snr = 10 * torch.log10((yt.double() ** 2).sum(-1) / err)
+        assert float(snr.min()) >= 60.0
+    finally:
+        ctx.set_option("v3", 0)
+
+
 # ---- phase vocoder / time stretch (SURVEY.md 8f rank 3; librosa/core/spectrum.py:1364-1519, effects.py:404-484) -------------
 def _pv_close(a, ref):
     tol = 1e-11 if a.dtype == np.complex128 else 3e-5

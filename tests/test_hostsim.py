@@ -194,6 +194,62 @@ def test_mel_body_run_ordered_both_generations(n_fft, hop, power, n_mels, iters,
     assert np.all(np.abs(M4 - Mref) <= 1e-5 * np.abs(Mref) + 1e-5 * Mref.max())
 
 
+@pytest.mark.parametrize("hop,power,n_mels,iters,n", [(512, 2.0, 128, 3, 9000), (512, 2.0, 128, 9, 30000), (256, 2.0, 128, 5, 9000), (256, 1.0, 128, 4, 9000), (512, 1.7, 128, 3, 5000), (512, 2.0, 120, 1, 4096)])
+def test_mel_body_producer_consumer(hop, power, n_mels, iters, n, monkeypatch):
+    """The producer / consumer fused mel kernel body (lra_kernels_pc.h: 192-thread workgroups [P, P, C]) against the oracle, and bit for bit against the
+    single-wave form it splits (the same operations in the same order; the simulator runs the phase bodies, the flag hand-over itself only runs on the device)."""
+    rng = np.random.default_rng(hop + n_mels)
+    y = rng.standard_normal((3, n)).astype(np.float32)
+    win = O.get_window("hann", 2048)
+    B = O.mel(sr=22050, n_fft=2048, n_mels=n_mels)
+    M4, d4 = H.stft(y, 2048, hop, win, mode=4, power=power, mel_basis=B, iters_per_wg=iters)
+    monkeypatch.setenv("LRA_SIM_PC", "1")
+    Mp, dp = H.stft(y, 2048, hop, win, mode=4, power=power, mel_basis=B, iters_per_wg=iters)
+    assert Mp is not None and dp["v2"] == 2 and dp["NT"] == 192 and dp["lds"] <= 40 * 1024, dp  # four workgroups per CU
+    _check_diag(dp)
+    assert not np.isnan(Mp).any()
+    assert np.array_equal(Mp, M4)
+    Mref = O.melspectrogram(y=y, sr=22050, n_fft=2048, hop_length=hop, power=power, n_mels=n_mels)
+    assert np.all(np.abs(Mp - Mref) <= 1e-5 * np.abs(Mref) + 1e-5 * Mref.max())
+
+
+def test_mel_body_producer_consumer_declines_wide_segments(monkeypatch):
+    """Banks whose pair segments need more than four pieces (40 / 80 bands at n_fft 2048) are not served by the consumer's register lists: the library keeps the one-wave form."""
+    monkeypatch.setenv("LRA_SIM_PC", "1")
+    y = np.random.default_rng(3).standard_normal((1, 5000)).astype(np.float32)
+    Mp, dp = H.stft(y, 2048, 512, O.get_window("hann", 2048), mode=4, power=2.0, mel_basis=O.mel(sr=22050, n_fft=2048, n_mels=40), iters_per_wg=3)
+    assert Mp is None and dp == dict(unavailable=3)
+
+
+@pytest.mark.parametrize("hop,center,pad_mode,iters,n", [(512, True, "constant", 3, 9000), (512, True, "reflect", 5, 20000), (256, True, "symmetric", 4, 9000), (1024, False, "constant", 3, 12000),
+                                                         (2048, True, "edge", 2, 9000), (512, False, "constant", 7, 30011)])
+def test_stft_body_radix_16_16_4(hop, center, pad_mode, iters, n):
+    """Variant 6 (FftCfg PLAN = 1: radices 16, 16, 4 -- four last-pass butterflies per thread, neighbouring bins side by side, 16-byte row pieces):
+    complex, |X|^p (also into padded rows) and the run-ordered mel epilogue on that core."""
+    rng = np.random.default_rng(hop + n)
+    y = rng.standard_normal((2, n)).astype(np.float32)
+    win = O.get_window("hann", 2048)
+    Dref = np.moveaxis(O.stft(y, n_fft=2048, hop_length=hop, center=center, pad_mode=pad_mode), -1, -2)
+    D, d = H.stft(y, 2048, hop, win, center=center, pad_mode=pad_mode, mode=0, iters_per_wg=iters, variant=6)
+    assert d["v2"] == 1
+    _check_diag(d)
+    assert not np.isnan(D).any() and np.abs(D - Dref).max() <= 4 * _tol(np.float32) * np.abs(Dref).max()
+    for power in (1.0, 2.0):
+        S, d = H.stft(y, 2048, hop, win, center=center, pad_mode=pad_mode, mode=1, power=power, iters_per_wg=iters, variant=6, row_pad=7)
+        _check_diag(d)
+        Sref = np.abs(Dref) ** power
+        assert np.isnan(S[..., 1025:]).all() and np.abs(S[..., :1025] - Sref).max() <= 8 * _tol(np.float32) * Sref.max()
+    Dp, d = H.stft(y, 2048, hop, win, center=center, pad_mode=pad_mode, mode=0, iters_per_wg=iters, variant=6, row_pad=15)
+    assert np.array_equal(Dp[..., :1025], D) and np.isnan(Dp[..., 1025:]).all()
+    if center and hop in (256, 512):
+        B = O.mel(sr=22050, n_fft=2048, n_mels=128)
+        M4, d4 = H.stft(y, 2048, hop, win, center=center, pad_mode=pad_mode, mode=4, power=2.0, mel_basis=B, iters_per_wg=iters, variant=6)
+        assert M4 is not None and d4["v2"] == 1
+        _check_diag(d4)
+        Mref = O.melspectrogram(y=y, sr=22050, n_fft=2048, hop_length=hop, power=2.0, n_mels=128, center=center, pad_mode=pad_mode)
+        assert np.all(np.abs(M4 - Mref) <= 1e-5 * np.abs(Mref) + 1e-5 * Mref.max())
+
+
 def _istft_inputs(y, n_fft, hop, center, length, window="hann", win_length=None):
     D = O.stft(y, n_fft=n_fft, hop_length=hop, center=center, window=window, win_length=win_length)
     ref = O.istft(D, hop_length=hop, n_fft=n_fft, center=center, length=length, window=window, win_length=win_length)
