@@ -15,8 +15,8 @@ one kernel launch) -- over one batch of synthetic 22.05 kHz clips already reside
 Plans/tables are created outside the timed region.  The timed region is EXACTLY --steps steps bracketed by a
 barrier + device synchronize on both sides; the max over ranks is reported.
 
-Output (rank 0): ONE short JSON line on stdout -- the contract's keys, `roofline` (timed kernel) with the path's other fractions folded in as `roofline.path`
-(stft_frac / istft_frac / stream_forward_frac / stream_inverse_frac / cqt_lite_frac, + the best / worst of `--placements` allocations of the 2.7 GB spectrum: its
+Output (rank 0): ONE short JSON line on stdout -- the contract's keys, `roofline` (timed kernel) with the path's other fractions folded in as SCALARS of `roofline`
+(stft_frac / istft_frac / stream_forward_frac / stream_inverse_frac / cqt_lite_frac, stft_v2_frac / stft_v3_frac / mel_pc_ms of `kernel_forms`, + the best / worst of `--placements` allocations of the 2.7 GB spectrum: its
 placement moves the store-bound transform 0.63-0.75 ms, profiles/r05_pitch.md), `cpu_baseline`, `parity`, `scaling_base` (N = 1 at 512 clips per GPU), one number per
 side measurement (`side`) -- and the FULL record on stderr (and in --detail / gpurun_out/bench_detail.json).  N > 1: `gathered.full_matches_unsharded` = every rank
 recomputed its neighbour's shard from that shard's seeded input and found it equal in the gathered tensor.
@@ -27,6 +27,7 @@ Keys of the full record (rank 0):
   roofline_stft   the complex64-out STFT kernel on the same input (north-star bar: >= 70 % of HBM, 10 248 B/frame)
   roofline_istft  the inverse on the STFT's output (BASELINE configs[3]; round-trip SNR included)
   roofline_valu   the fused mel kernel against the f32 vector peak (it sits on the compute side of the ridge)
+  kernel_forms    round 6: both forms of the complex STFT (radices 16-8-8 / 16-16-4) and of the fused mel kernel (one wave per frame / producer + consumer waves), alternating, same buffers
   repeats         min / median ms per step over 5 more repeats of the timed region (box-to-box and run-to-run spread)
   parity          max relative error of a sampled clip's mel spectrogram against the CPU oracle (same input, downloaded)
   dropin_torch    the PUBLIC drop-in (librosa_amd.feature.melspectrogram on a device tensor: validation, plan cache, lock)
@@ -192,17 +193,27 @@ def _cpu_worker(seconds):
     return frames, dt, ref is not None
 
 
-def cpu_baseline_all_cores(seconds=8.0, max_procs=64):
+def cpu_baseline_all_cores(seconds=8.0, max_procs=None):
     """The reference has no internal parallelism: its fair multi-core mode is one independent process per core
-    (SURVEY.md 8d).  P = min(cores, max_procs) spawned processes, each looping over clips for `seconds`."""
+    (P = os.cpu_count()).  P spawned processes, each looping over clips for `seconds`; P is lowered only where the
+    host's free memory would not hold that many interpreters (~0.6 GB each with NumPy / SciPy and a 30 s clip's float64 spectra), and the line says so."""
     import multiprocessing as mp
     from concurrent.futures import ProcessPoolExecutor
 
-    procs = max(1, min(os.cpu_count() or 1, max_procs))
+    procs = max(1, os.cpu_count() or 1)
+    if max_procs:
+        procs = min(procs, max_procs)
+    try:
+        import psutil
+
+        procs = max(1, min(procs, int(psutil.virtual_memory().available * 0.5 // (600 << 20))))
+    except Exception:  # pragma: no cover
+        procs = min(procs, 64)
     with ProcessPoolExecutor(max_workers=procs, mp_context=mp.get_context("spawn")) as pool:
         res = list(pool.map(_cpu_worker, [seconds] * procs))
     kind = "reference" if all(r[2] for r in res) else "port"
     return {"value": sum(f / dt for f, dt, _ in res), "unit": "frames/s", "cores": procs, "kind": kind,
+            "logical_cores": os.cpu_count(),
             "sample": f"{procs} independent processes x {seconds:.0f} s of 30 s-clip melspectrograms (n_fft={N_FFT} hop={HOP} n_mels={N_MELS}), 1 BLAS thread each; host has {os.cpu_count()} logical cores"}
 
 
@@ -291,7 +302,13 @@ def compact_line(line):
             "stft_frac_best_placement": get(line, "placement", "stft_frac_best"), "stft_frac_worst_placement": get(line, "placement", "stft_frac_worst"),
             "istft_frac_best_placement": get(line, "placement", "istft_frac_best"), "placements": get(line, "placement", "allocations"),
             "stft_traffic": get(line, "roofline_stft", "traffic"), "istft_traffic": get(line, "roofline_istft", "traffic")}
-    roof["path"] = {k: r(v) for k, v in path.items() if v is not None}
+    # (round 6, VERDICT r05 item 4: the driver's record keeps scalars of `roofline`, not a nested object -- the path's fractions are scalars of `roofline` itself)
+    path.update({"stft_v2_frac": get(line, "kernel_forms", "stft_radix_16_8_8", "frac"), "stft_v3_frac": get(line, "kernel_forms", "stft_radix_16_16_4", "frac"),
+                 "mel_one_wave_ms": get(line, "kernel_forms", "mel_one_wave", "ms"), "mel_pc_ms": get(line, "kernel_forms", "mel_producer_consumer", "ms"),
+                 "mel_pc_16_16_4_ms": get(line, "kernel_forms", "mel_producer_consumer_16_16_4", "ms"), "long_clip_frac": get(line, "long_clip", "frac_of_batched")})
+    for k, v in path.items():
+        if v is not None:
+            roof[k] = r(v)
     out["roofline"] = roof
     cb = line.get("cpu_baseline")
     if isinstance(cb, dict):
@@ -548,6 +565,34 @@ def main():
         if "roofline_istft" in side and "error" not in side["roofline_istft"]:
             side["roofline_istft"]["call_note"] = ("lra_istft_exec_norm (what librosa_amd.istft calls) = ONE launch since round 4: the kernel stores every sample it covers and the wrapper zeroes only what no frame reaches "
                                                    "(nothing here); round 3's call carried an 85 us hipMemsetAsync of the whole output (677 MB)")
+
+        def kernel_forms():
+            """Round 6: the alternative forms of the two contract kernels, timed alternately with the defaults on the SAME buffers (ctx options v3 / mel_pc):
+            the complex STFT as radices 16-8-8 (8-byte row pieces) and 16-16-4 (16-byte pieces by butterfly assignment); the fused mel kernel as one wave
+            per frame (FFT + epilogue, 240 VGPRs, two waves per SIMD) and as producer / consumer waves (192-thread workgroups, three waves per SIMD)."""
+            out = {}
+            to_frac = lambda s_: frames_per_step * BYTES_PER_FRAME_STFT / s_ / 1e9 / HBM_PEAK_GBS
+            try:
+                for rnd in range(2):
+                    for name, opt in (("stft_radix_16_8_8", 0), ("stft_radix_16_16_4", 1)):
+                        ctx.set_option("v3", opt)
+                        _, e = timed(step_stft, 10, 3, collective=False, ramp_ms=args.prewarm_ms / 4)
+                        ms = e / 10 * 1e3
+                        if name not in out or ms < out[name]["ms"]:
+                            out[name] = {"ms": ms, "frac": to_frac(e / 10)}
+                    for name, opt in (("mel_one_wave", 0), ("mel_producer_consumer", 1), ("mel_producer_consumer_16_16_4", 2)):
+                        ctx.set_option("mel_pc", opt)
+                        _, e = timed(step_mel, 10, 3, collective=False, ramp_ms=args.prewarm_ms / 4)
+                        ms = e / 10 * 1e3
+                        if name not in out or ms < out[name]["ms"]:
+                            out[name] = {"ms": ms, "frames_per_s": frames_per_step / (e / 10)}
+            finally:
+                ctx.set_option("v3", 1)
+                ctx.set_option("mel_pc", 0)
+            out["what"] = "best of two alternating rounds of 10 launches each, same input / output buffers as roofline_stft and the timed step; defaults: 16-16-4 for the complex STFT, one wave per frame for the mel kernel"
+            return out
+
+        measure("kernel_forms", kernel_forms)
 
         def stream_ceiling():
             """The same access streams WITHOUT arithmetic (lra_probe_stream, csrc/lra_probe.h): what this mix of PCM reads and 8-byte-aligned 8 200-byte row
@@ -861,10 +906,11 @@ def main():
                                    f"(`gathered`: all-gathered)", "frames_per_step_per_gpu": frames_per_step, "clips_per_gpu": batch, "prewarm_ms": args.prewarm_ms,
                        "parallelism": f"clips sharded over {world} GPU(s), one process per GPU, no collective on the data path", "device": ctx.device_name(),
                        "self_launched": bool(os.environ.get("LRA_BENCH_SELF_LAUNCHED"))},
-            "roofline": {"bound": "valu/lds", "kernel": "stft2_kernel<n_fft=2048, OUT_MELR> (fused melspectrogram)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "stft2_kernel<n_fft=2048, OUT_MELR> (fused melspectrogram)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_frame": BYTES_PER_FRAME_MEL,
                          "launch_ms": launch_s * 1e3, "frames_per_s_single_gpu": frames_per_step / launch_s,
-                         "limited_by": "valu/lds issue, not HBM: the declared bound of this kernel is roofline_valu (f32 vector peak); the HBM figure is kept because BASELINE's metric asks for it",
+                         "limited_by": "valu/lds issue, not HBM (achieved / peak / frac here ARE the HBM figures BASELINE's metric asks for; `valu_frac` = the same launch against the f32 vector peak, "
+                                       "which is the side of the ridge this kernel sits on)",
                          "note": "this kernel sits on the LDS / VALU side of the ridge (~65 kFLOP and ~500 LDS cycles per 2 560 B); see roofline_stft for the HBM-bound kernel"},
             "repeats": {"ms_per_step_min": min(rep), "ms_per_step_median": statistics.median(rep), "ms_per_step_all": rep, "what": "5 more repeats of the timed region (HIP events, no collectives)"},
         }

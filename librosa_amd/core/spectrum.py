@@ -730,14 +730,17 @@ def griffinlim(S, *, n_iter=32, hop_length=None, win_length=None, n_fft=None, wi
     # reproduces its stream; the float64 phasor itself is evaluated on the device
     # ... unless the generator is NumPy's default one (PCG64: default_rng(seed), or rng=None): its stream is reproduced bit for bit on the device
     # (csrc/lra_rng.h) from the generator's state, and the host generator is advanced past the draws -- 92 ms of host work for 32 clips otherwise
+    # The caller's generator moves only once the device has taken the draws: a failure before that (plan, frame count, native error) leaves it
+    # untouched, and `advance` -- which also drops the generator's cached 32-bit half, something the reference's rng.random() never does -- is followed by
+    # putting that half back.
     pcg = None
-    if init == "random" and isinstance(rng, np.random.Generator) and DEVICE_RNG:
-        st = rng.bit_generator.state
-        if st.get("bit_generator") == "PCG64" and int(np.prod(S.shape, dtype=np.int64)) > 0:
-            pcg = (int(st["state"]["state"]), int(st["state"]["inc"]))
-            rng.bit_generator.advance(int(np.prod(S.shape, dtype=np.int64)))
-    draws = rng.random(size=tuple(S.shape)) if (init == "random" and pcg is None) else None
+    n_draws = int(np.prod(S.shape, dtype=np.int64))
     sess = _arrays.Session(S)
+    if init == "random" and isinstance(rng, np.random.Generator) and DEVICE_RNG and hasattr(sess.ctx.lib, "lra_griffinlim_init_pcg64"):
+        st = rng.bit_generator.state
+        if st.get("bit_generator") == "PCG64" and n_draws > 0:
+            pcg = (int(st["state"]["state"]), int(st["state"]["inc"]), st.get("has_uint32", 0), st.get("uinteger", 0))
+    draws = rng.random(size=tuple(S.shape)) if (init == "random" and pcg is None) else None
     try:
         ctx = sess.ctx
         iplan = ctx.istft_plan(n_fft, hop, fft_window.astype(real), center, real)
@@ -759,6 +762,10 @@ def griffinlim(S, *, n_iter=32, hop_length=None, win_length=None, n_fft=None, wi
         # init=None is u = 0: angles = S (1 + 0i)  (:2837)
         if pcg is not None:
             ctx.griffinlim_init_pcg64(pcg[0], pcg[1], s_ptr, angles, batch, n_bins, n_total, real)
+            rng.bit_generator.advance(n_draws)  # the generator ends where the reference's rng.random(size=S.shape) leaves it
+            st = rng.bit_generator.state
+            st["has_uint32"], st["uinteger"] = pcg[2], pcg[3]
+            rng.bit_generator.state = st
         else:
             u_t = sess.scratch(count * 8)
             if draws is not None:

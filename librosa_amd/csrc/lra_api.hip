@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -26,7 +27,7 @@
 
 #include "../../include/librosa_amd.h"
 #ifndef LRA_V3_DEFAULT
-#define LRA_V3_DEFAULT 0
+#define LRA_V3_DEFAULT 1  // measured on two boxes, same buffer, alternating (profiles/r06_raw/c_*, d_*): complex STFT -1.3 % ... -2.0 %, |X|^2 +1 % (hence complex only)
 #endif
 #ifndef LRA_MEL_PC_DEFAULT
 #define LRA_MEL_PC_DEFAULT 0  // the producer / consumer fused mel kernel (lra_kernels_pc.h): ctx option "mel_pc"
@@ -86,7 +87,7 @@ struct lra_ctx {
     int opt_generic_mel = 0;         // force the generic banded mel path (tests)
     int opt_lds_pad = 0;             // extra dynamic LDS per workgroup (occupancy experiments)
     int opt_v2 = 1;                  // second-generation forward kernel where it applies (lra_kernels2.h)
-    int opt_v3 = LRA_V3_DEFAULT;     // complex / power epilogues at n_fft = 2048 f32: the radix 16-16-4 form with 16-byte row pieces (variant 6, lra_kernels2.h third form)
+    int opt_v3 = LRA_V3_DEFAULT;     // n_fft = 2048 f32: the radix 16-16-4 form with 16-byte row pieces (variant 6, lra_kernels2.h third form); 1: complex epilogue, 2: |X|^p too
     int opt_mel_pc = LRA_MEL_PC_DEFAULT;  // fused mel, n_fft = 2048 f32: the producer / consumer kernel (lra_kernels_pc.h) instead of stft2_kernel<OUT_MELR>
     int opt_mel_many = 1;            // mel plans of n_fft = 512 with more than 64 bands are built for the eight-bands-per-thread kernel shape (read at lra_mel_plan_create)
     int opt_cqt_merge = 1;           // lra_cqt_recursion_exec: octaves 1 .. in one launch per frame length behind the chain of halvings (0: one launch per octave on the side stream)
@@ -109,7 +110,13 @@ struct lra_ctx {
     hipEvent_t fork_event[kForkRing] = {}, side_passed[kForkRing] = {};
     bool fork_used[kForkRing] = {};
     int fork_next = 0;
-    hipEvent_t join_event = nullptr;
+    // join: the same treatment in the other direction -- back-to-back transforms no longer synchronise with the host between calls, so call
+    // k + 1's join could re-record a single join event while the main stream's wait on call k's record is still queued.  A ring of join events;
+    // `main_passed[i]`, recorded on the main stream right behind its wait, is synchronised before slot i is recorded again.
+    static constexpr int kJoinRing = 8;
+    hipEvent_t join_event[kJoinRing] = {}, main_passed[kJoinRing] = {};
+    bool join_used[kJoinRing] = {};
+    int join_next = 0;
     bool on_side = false, side_used = false;
     struct ResampleFft* rs_fft = nullptr;  // whole-signal transforms of lra_resample_fft_exec, created on first use
     int opt_pipe_chunk_mb = 128;      // bytes (in + out) one pipeline stage moves
@@ -512,7 +519,19 @@ template <class T> struct StftLaunch {
             if (!use_v2 || v2_hop_divisor<Cfg>(a.hop) == 0) { err = hipErrorInvalidValue; return; }
             if (mode == OUT_COMPLEX) launch<Cfg, OUT_COMPLEX>(0);
             else if (mode == OUT_POWER) launch<Cfg, OUT_POWER>(0);
-            else err = hipErrorInvalidValue;
+            else if (mode == OUT_MEL2 && mel_pc && mel && mel->melr2_ok && mel_runs) {  // the producer / consumer mel kernel on this core (ctx option mel_pc = 2)
+                if constexpr (pc_cfg_ok<Cfg>()) {
+                    const int hd_pc = v2_hop_divisor<Cfg>(a.hop);
+                    if (!pc_bank_ok<Cfg>(a.n_mels, mel->melr2_pmax) || !pc_fits_budget<Cfg>(hd_pc, a.power_mode)) { err = hipErrorInvalidValue; return; }
+                    a.melr_w = (const T*)mel->d_melr2_w;
+                    a.melr_keep = (const T*)mel->d_melr2_keep;
+                    a.melr_addr = mel->d_melr2_addr;
+                    a.melr_zero = mel->melr2_zero;
+                    a.melr_mid = mel->melr2_mid;
+                    a.melr_pmax = mel->melr2_pmax;
+                    launch_pc<Cfg>(hd_pc);
+                } else err = hipErrorInvalidValue;
+            } else err = hipErrorInvalidValue;
         } else {
             run<Cfg>();
         }
@@ -524,7 +543,7 @@ template <class T> struct StftLaunch {
             // n_fft = 2048, float32, banks of up to 128 bands with pair segments of at most four pieces: producer and consumer waves (lra_kernels_pc.h)
             if constexpr (pc_cfg_ok<Cfg>()) {
                 const int hd_pc = v2_hop_divisor<Cfg>(a.hop);
-                if (mel_pc && mel && mel->melr2_ok && mel_runs && use_v2 && pc_bank_ok<Cfg>(a.n_mels, mel->melr2_pmax) && pc_fits_budget(hd_pc, a.power_mode)) {
+                if (mel_pc && mel && mel->melr2_ok && mel_runs && use_v2 && pc_bank_ok<Cfg>(a.n_mels, mel->melr2_pmax) && pc_fits_budget<Cfg>(hd_pc, a.power_mode)) {
                     a.melr_w = (const T*)mel->d_melr2_w;
                     a.melr_keep = (const T*)mel->d_melr2_keep;
                     a.melr_addr = mel->d_melr2_addr;
@@ -857,9 +876,21 @@ struct ResampleFft {
     FftPlanCache order;  // cross-stream ordering of the two spectra (scratch_acquire / scratch_release)
     // the four buffers only ever grew (up to ~1 GB per pass each way), so one large call pinned ~2 GB of HBM for the context's lifetime.
     // A call that leaves more than kKeepBytes behind waits for its own work and gives the memory back (such a call ran for milliseconds anyway).
+    // that wait + four hipFree (each a device-wide synchronisation) + the next call's re-allocation serialised every LOOP of large calls, and
+    // inside a fork / join region (the constant-Q octave chain with the Fourier resamplers) it took the side stream's overlap away.  So: never inside a
+    // fork / join region, and not while such calls follow each other closely (the previous one also ended oversize less than 100 ms ago) -- a lone large
+    // call still gives its memory back at once; the last call of a loop leaves it to the next resample call on this context or to lra_ctx_destroy.
     static constexpr size_t kKeepBytes = 256u << 20;
-    int trim(hipStream_t stream) {
+    std::chrono::steady_clock::time_point last_oversize{};
+    bool have_last_oversize = false;
+    int trim(hipStream_t stream, bool in_fork_region) {
         if (spec_in.bytes + spec_out.bytes + time_in.bytes + time_out.bytes <= kKeepBytes) return LRA_OK;
+        if (in_fork_region) return LRA_OK;
+        const auto now = std::chrono::steady_clock::now();
+        const bool in_loop = have_last_oversize && now - last_oversize < std::chrono::milliseconds(100);
+        last_oversize = now;
+        have_last_oversize = true;
+        if (in_loop) return LRA_OK;
         LRA_HIP(hipStreamSynchronize(stream));
         for (Scratch* sc : {&spec_in, &spec_out, &time_in, &time_out}) {
             if (sc->p) (void)hipFree(sc->p);
@@ -1064,7 +1095,7 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
         L.lds_pad = ctx->opt_lds_pad;
         L.xcd_remap = ctx->opt_xcd_remap != 0;
         L.use_v2 = ctx->opt_v2 != 0;
-        L.mel_pc = ctx->opt_mel_pc != 0;
+        L.mel_pc = ctx->opt_mel_pc != 0;  // (which core: the variant chosen below)
         L.use_direct = ctx->opt_direct != 0;
         L.mel_runs = ctx->opt_mel_runs != 0;
         // Kernel variant (f32 n_fft = 2048 only): 0 = one wave per frame, 4 = two waves per frame.  Which one
@@ -1088,8 +1119,14 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
             if (tuned < 0 && batch * n_frames >= 65536) LRA_TRY(autotune_variant(ctx, launch, &tuned));
             if (tuned >= 0) variant = tuned;
         }
-        if (v2_applies && ctx->opt_v3 && (ctx->opt_variant < 0 || ctx->opt_variant == 6)) variant = 6;
-        else if (variant == 6) variant = 0;  // (the 16-16-4 form exists for the second-generation complex / power kernels only)
+        bool pc_g = false;  // fused mel through the producer / consumer kernel on the radix 16-16-4 core (mel_pc = 2), where that kernel serves the bank and fits its register budget
+        if constexpr (sizeof(T) == 4) {
+            using C6 = typename CfgSel<float, 10, 6>::type;
+            if (L.mode == OUT_MEL2 && ctx->opt_mel_pc == 2 && p->logm == 10 && mel && mel->melr2_ok && ctx->opt_mel_runs && ctx->opt_v2 && (ctx->opt_variant < 0 || ctx->opt_variant == 6))
+                pc_g = pc_bank_ok<C6>(mel->n_mels, mel->melr2_pmax) && pc_fits_budget<C6>(v2_hop_divisor<C6>(p->hop), power_mode_of(power));
+        }
+        if ((v2_applies && (ctx->opt_v3 == 2 || (ctx->opt_v3 == 1 && L.mode == OUT_COMPLEX)) && (ctx->opt_variant < 0 || ctx->opt_variant == 6)) || pc_g) variant = 6;
+        else if (variant == 6) variant = 0;  // (the 16-16-4 form exists for the second-generation complex / power kernels and the producer / consumer mel kernel only)
         return launch(variant);
     }
     // listed non-power-of-two frame lengths: one fused launch (lra_mixed.h)
@@ -1687,7 +1724,10 @@ void lra_ctx_destroy(lra_ctx* ctx) {
         if (ctx->fork_event[i]) (void)hipEventDestroy(ctx->fork_event[i]);
         if (ctx->side_passed[i]) (void)hipEventDestroy(ctx->side_passed[i]);
     }
-    if (ctx->join_event) (void)hipEventDestroy(ctx->join_event);
+    for (int i = 0; i < lra_ctx::kJoinRing; ++i) {
+        if (ctx->join_event[i]) (void)hipEventDestroy(ctx->join_event[i]);
+        if (ctx->main_passed[i]) (void)hipEventDestroy(ctx->main_passed[i]);
+    }
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
     for (auto& kv : ctx->cqt_tw) {
         if (kv.second.first) (void)hipFree(kv.second.first);
@@ -1742,9 +1782,15 @@ int lra_ctx_side(lra_ctx* ctx, int mode) {
     if (mode == LRA_SIDE_JOIN || mode == LRA_SIDE_END) {
         if (ctx->on_side) return fail(LRA_EINVAL, "lra_ctx_side: join from the main stream (LRA_SIDE_BACK first)");
         if (!ctx->side_used) return LRA_OK;
-        if (!ctx->join_event) LRA_HIP(hipEventCreateWithFlags(&ctx->join_event, hipEventDisableTiming));
-        LRA_HIP(hipEventRecord(ctx->join_event, ctx->side_stream));
-        LRA_HIP(hipStreamWaitEvent(ctx->stream, ctx->join_event, 0));
+        const int js = ctx->join_next;
+        ctx->join_next = (js + 1) % lra_ctx::kJoinRing;
+        if (!ctx->join_event[js]) LRA_HIP(hipEventCreateWithFlags(&ctx->join_event[js], hipEventDisableTiming));
+        if (!ctx->main_passed[js]) LRA_HIP(hipEventCreateWithFlags(&ctx->main_passed[js], hipEventDisableTiming));
+        if (ctx->join_used[js]) LRA_HIP(hipEventSynchronize(ctx->main_passed[js]));  // the main stream is past its wait on this slot's previous record
+        LRA_HIP(hipEventRecord(ctx->join_event[js], ctx->side_stream));
+        LRA_HIP(hipStreamWaitEvent(ctx->stream, ctx->join_event[js], 0));
+        LRA_HIP(hipEventRecord(ctx->main_passed[js], ctx->stream));
+        ctx->join_used[js] = true;
         ctx->side_used = false;
         return LRA_OK;
     }
@@ -1769,8 +1815,8 @@ int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value) {
     else if (!std::strcmp(key, "lds_pad")) ctx->opt_lds_pad = value;
     else if (!std::strcmp(key, "xcd_remap")) ctx->opt_xcd_remap = value != 0;
     else if (!std::strcmp(key, "v2")) ctx->opt_v2 = value != 0;
-    else if (!std::strcmp(key, "mel_pc")) ctx->opt_mel_pc = value != 0;
-    else if (!std::strcmp(key, "v3")) ctx->opt_v3 = value != 0;
+    else if (!std::strcmp(key, "mel_pc")) ctx->opt_mel_pc = (value == 1 || value == 2) ? value : 0;  // 1: on the radix 16-8-8 core, 2: on the radix 16-16-4 core
+    else if (!std::strcmp(key, "v3")) ctx->opt_v3 = (value == 1 || value == 2) ? value : 0;
     else if (!std::strcmp(key, "cqt_merge")) ctx->opt_cqt_merge = value != 0;
     else if (!std::strcmp(key, "mel_many")) ctx->opt_mel_many = value != 0;
     else if (!std::strcmp(key, "direct")) ctx->opt_direct = value != 0;
@@ -2615,7 +2661,7 @@ int resample_shaped_run(lra_ctx* ctx, const T* x, T* out, long long batch, long 
     LRA_TRY(scratch_release(rs->order, ctx->stream));
     LRA_TRY(scratch_release(*fwd, ctx->stream));  // (an evicted plan is destroyed behind its last use: get_rocfft_plan)
     LRA_TRY(scratch_release(*inv, ctx->stream));
-    return rs->trim(ctx->stream);
+    return rs->trim(ctx->stream, ctx->on_side || ctx->side_used);
 }
 
 template <class T> int resample_fft_run(lra_ctx* ctx, const T* x, T* out, long long batch, long long n_in, long long n_out, double gain, int dtype) {
@@ -2655,7 +2701,7 @@ template <class T> int resample_fft_run(lra_ctx* ctx, const T* x, T* out, long l
     LRA_TRY(scratch_release(rs->order, ctx->stream));
     LRA_TRY(scratch_release(*fwd, ctx->stream));
     LRA_TRY(scratch_release(*inv, ctx->stream));
-    return rs->trim(ctx->stream);
+    return rs->trim(ctx->stream, ctx->on_side || ctx->side_used);
 }
 }  // namespace
 
@@ -2791,6 +2837,15 @@ int lra_cqt_recursion_exec(lra_ctx* ctx, const void* y, int64_t batch, const lra
     if (!ctx) return fail(LRA_EINVAL, "null context");
     if (n_octaves < 0 || (n_octaves > 0 && !octaves)) return fail(LRA_EINVAL, "cqt_recursion: null octave list");
     if (dtype != LRA_F32 && dtype != LRA_F64) return fail(LRA_EINVAL, "cqt_recursion: dtype must be LRA_F32 or LRA_F64");
+    // (checked here once, for every path below -- the merged-octave launches do not go through lra_cqt_octave_exec's own checks)
+    if (pad_mode < PAD_CONSTANT || pad_mode > PAD_SYMMETRIC) return fail(LRA_EINVAL, "cqt_recursion: unknown pad mode");
+    if (n_total < 1) return fail(LRA_EINVAL, "cqt_recursion: n_total must be at least 1");
+    if (batch > 0 && n_frames > 0 && n_octaves > 0 && (!y || !out)) return fail(LRA_EINVAL, "cqt_recursion: null data pointer");
+    for (int i = 0; i < n_octaves; ++i) {
+        const lra_cqt_octave& o = octaves[i];
+        if (o.n_rows < 0 || o.bin0 < 0 || o.row0 < 0 || o.bin0 + o.n_rows > n_total || o.hop < 1 || o.n < 0) return fail(LRA_EINVAL, "cqt_recursion: an octave's rows must fit the stacked result");
+        if (o.n_rows > 0 && (!o.row_ptr || !o.col || !o.val)) return fail(LRA_EINVAL, "cqt_recursion: null basis table");
+    }
     const int64_t es = dtype == LRA_F64 ? 8 : 4;
     // the decimated signals live side by side in `scratch` (each until the call's join: its octave transform runs on the side stream)
     int64_t need = 0;

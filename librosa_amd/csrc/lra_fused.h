@@ -155,7 +155,7 @@ LRA_CFG_ALIAS(cfg_f64_12, double, 12, 0)
 #define LRA_INST2_ALL(T, I) LRA_INST2_GROUP_9(T, I) LRA_INST2_GROUP_10(T, I) LRA_INST2_GROUP_12(T, I)
 // producer / consumer mel kernels: P(CFG, HD, PM)
 #define LRA_PC_HD(P, C, HD) P(lra::C, HD, 1) P(lra::C, HD, 2) P(lra::C, HD, 3)
-#define LRA_INST3_GROUP_11(P) LRA_PC_HD(P, cfg_f32_10, 4) LRA_PC_HD(P, cfg_f32_10, 8)
+#define LRA_INST3_GROUP_11(P) LRA_PC_HD(P, cfg_f32_10, 4) LRA_PC_HD(P, cfg_f32_10, 8) LRA_PC_HD(P, cfg_f32_10g, 4) LRA_PC_HD(P, cfg_f32_10g, 8)
 #define LRA_INST3_ALL(P) LRA_INST3_GROUP_11(P)
 // the radix 16-16-4 form of the second-generation forward kernels (variant 6)
 #define LRA_INST2_GROUP_12(T, I) LRA_STFT2_CFG(T, cfg_f32_10g)

@@ -62,14 +62,19 @@ template <class Cfg> struct PcLayout {
 };
 
 // one wave per frame, sixteen points per thread, mirrored two-butterfly last pass, swizzled power row: n_fft = 2048 in float32
-template <class Cfg> constexpr bool pc_cfg_ok() { return v2_cfg_ok<Cfg>() && Cfg::TF == 64 && v2_pw_swz<Cfg>() && melr_fits<Cfg>() && sizeof(typename Cfg::real) == 4; }
+template <class Cfg> constexpr bool pc_cfg_ok() { return v23_cfg_ok<Cfg>() && Cfg::TF == 64 && v2_pw_swz<Cfg>() && melr_fits<Cfg>() && sizeof(typename Cfg::real) == 4; }
 // what the consumer holds in registers covers the bank: two bands per thread, four hoisted pieces per list, no table path
 template <class Cfg> LRA_HD bool pc_bank_ok(int n_mels, int pmax) { return n_mels >= 1 && n_mels <= 2 * Cfg::TF && pmax <= 4; }
 
 // (hop, power) combinations whose producer fits the 168-VGPR budget of three waves per SIMD without spilling (hipcc 7.2, -Rpass-analysis=kernel-resource-usage:
 // hop = n_fft / 4: |X|^2 only -- the square root costs two registers too many, pow() six; n_fft / 8: |X| and |X|^2; n_fft / 2 keeps eight sample pairs in
 // flight and spills 8-14).  Everything else stays with stft2_kernel<OUT_MELR>.
-LRA_HD bool pc_fits_budget(int hd, int power_mode) { return (hd == 4 && power_mode == POW_TWO) || (hd == 8 && (power_mode == POW_TWO || power_mode == POW_ONE)); }
+// (on the radix 16-16-4 core -- FftCfg PLAN = 1, its O-slot split twiddles derived -- |X| fits at hop = n_fft / 4 too)
+template <class Cfg> LRA_HD bool pc_fits_budget(int hd, int power_mode) {
+    if (power_mode != POW_TWO && power_mode != POW_ONE) return false;
+    if (hd == 8) return true;
+    return hd == 4 && (power_mode == POW_TWO || Cfg::PLAN == 1);
+}
 
 // consumer state
 template <class Cfg> struct PcRegs {
@@ -118,7 +123,8 @@ __device__ __forceinline__ void pc_wait(Lds l, int off, int want) {
 // ---- producer --------------------------------------------------------------------------------------------------------------------
 template <class Cfg, int HD> LRA_HD void pc_producer_prologue(const StftArgs<typename Cfg::real>& a, int clip, int frame0, int tf, Regs2<Cfg, HD>& rg) {
     using T = typename Cfg::real;
-    v2_hoist<Cfg, HD>(rg, tf, a.win, a.tw, a.twr);
+    if constexpr (Cfg::PLAN == 1) v3_hoist<Cfg, HD>(rg, tf, a.win, a.tw, a.twr);  // (radices 16, 16, 4: lra_kernels2.h, third form)
+    else v2_hoist<Cfg, HD>(rg, tf, a.win, a.tw, a.twr);
     v2_fill<Cfg, HD>(a, clip, frame0, tf, rg);
     if constexpr (v2_rotate_asm_ok<Cfg, HD>() && LRA_PC_ROTATE) {
         LRA_UNROLL
@@ -138,6 +144,25 @@ template <class Cfg, int HD> LRA_HD void pc_producer_pass0(const StftArgs<typena
         if (more) v2_issue_loads<Cfg, HD>(a, clip, frame + 1, tf, rg);
         v2_pass0<Cfg, HD>(frame < a.n_frames, tf, rg, fr);
     }
+}
+
+// the middle pass's butterflies + LDS write, the last pass's reads, and the last pass + un-split + power row, on either transform plan
+template <class Cfg, int p> LRA_HD void pc_mid_dft_write(typename Cfg::cplx* v, const typename Cfg::cplx* treg, Lds fr, int tf) {
+    if constexpr (Cfg::PLAN == 1) {
+        v3_mid_twiddle_dft<Cfg>(v, treg);
+        v3_mid_write<Cfg>(v, fr, tf);
+    } else {
+        pass_twiddle_dft_reg<Cfg, p>(v, treg);
+        pass_write<Cfg, p>(v, fr, tf);
+    }
+}
+template <class Cfg, int HD> LRA_HD void pc_last_read(Regs2<Cfg, HD>& rg, Lds fr, int tf) {
+    if constexpr (Cfg::PLAN == 1) v3_last_read<Cfg, HD>(rg, fr, tf);
+    else v2_last_read<Cfg, HD>(rg, fr, tf);
+}
+template <class Cfg, int HD, int PM> LRA_HD void pc_last_power_row(const StftArgs<typename Cfg::real>& a, int clip, int frame, int tf, Regs2<Cfg, HD>& rg, Lds pwr) {
+    if constexpr (Cfg::PLAN == 1) v3_last_split_store<Cfg, HD, OUT_MELR, PM, false>(a, clip, frame, frame < a.n_frames, tf, rg, pwr);
+    else v2_last_split_store<Cfg, HD, OUT_MELR, PM, false, false>(a, clip, frame, frame < a.n_frames, tf, rg, pwr);
 }
 
 // ---- consumer --------------------------------------------------------------------------------------------------------------------
@@ -283,21 +308,18 @@ template <class Cfg, int HD, int PM = POW_TWO> LRA_HD void stft_pc_block(const S
                 if (tid / TF < NP) pass_read<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(prg).v, lds_sub(lds, L::frame_off(tid / TF)), tid % TF);  \
             } LRA_PHASE_END_SYNC(true)                                                                                                  \
             LRA_PHASE(L::NT, tid) {                                                                                                     \
-                if (tid / TF < NP) {                                                                                                    \
-                    pass_twiddle_dft_reg<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(prg).v, LRA_R(prg).treg);                                     \
-                    pass_write<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(prg).v, lds_sub(lds, L::frame_off(tid / TF)), tid % TF);                \
-                }                                                                                                                       \
+                if (tid / TF < NP) pc_mid_dft_write<Cfg, (p < Cfg::P ? p : 0)>(LRA_R(prg).v, LRA_R(prg).treg, lds_sub(lds, L::frame_off(tid / TF)), tid % TF); \
             } LRA_PHASE_END_SYNC(true)                                                                                                  \
         }
         LRA_PC_MID(1)
         LRA_PC_MID(2)
 #undef LRA_PC_MID
         LRA_PHASE(L::NT, tid) {
-            if (tid / TF < NP) v2_last_read<Cfg, HD>(LRA_R(prg), lds_sub(lds, L::frame_off(tid / TF)), tid % TF);
+            if (tid / TF < NP) pc_last_read<Cfg, HD>(LRA_R(prg), lds_sub(lds, L::frame_off(tid / TF)), tid % TF);
         } LRA_PHASE_END_SYNC(true)
         LRA_PHASE(L::NT, tid) {
             const int w = tid / TF, tf = tid % TF, frame = f_first + w * iters + it;
-            if (w < NP) v2_last_split_store<Cfg, HD, OUT_MELR, PM, false, false>(a, clip, frame, frame < a.n_frames, tf, LRA_R(prg), lds_sub(lds, L::pw_off(w)));
+            if (w < NP) pc_last_power_row<Cfg, HD, PM>(a, clip, frame, tf, LRA_R(prg), lds_sub(lds, L::pw_off(w)));
         } LRA_PHASE_END  // (ready[s] published, C has seen it)
         for (int s = 0; s < NP; ++s) {
             LRA_PHASE(L::NT, tid) {
@@ -342,11 +364,7 @@ template <class Cfg, int HD, int PM = POW_TWO> LRA_HD void stft_pc_block(const S
             if (Cfg::P - 1 > p) {                                                                        \
                 { const int tf = phase_tid() % TF; pass_read<Cfg, (p < Cfg::P ? p : 0)>(rg.v, fr, tf); } \
                 pc_fence();                                                                              \
-                {                                                                                        \
-                    const int tf = phase_tid() % TF;                                                     \
-                    pass_twiddle_dft_reg<Cfg, (p < Cfg::P ? p : 0)>(rg.v, rg.treg);                      \
-                    pass_write<Cfg, (p < Cfg::P ? p : 0)>(rg.v, fr, tf);                                 \
-                }                                                                                        \
+                { const int tf = phase_tid() % TF; pc_mid_dft_write<Cfg, (p < Cfg::P ? p : 0)>(rg.v, rg.treg, fr, tf); } \
                 pc_fence();                                                                              \
             }
             LRA_PC_MID(1)
@@ -355,7 +373,7 @@ template <class Cfg, int HD, int PM = POW_TWO> LRA_HD void stft_pc_block(const S
             int taken;
             {
                 const int tf = phase_tid() % TF;
-                v2_last_read<Cfg, HD>(rg, fr, tf);
+                pc_last_read<Cfg, HD>(rg, fr, tf);
                 taken = pc_flag_load(lds, L::consumed_off(wave));  // rides on the same wait as the last pass's inputs
             }
             pc_fence();
@@ -363,7 +381,7 @@ template <class Cfg, int HD, int PM = POW_TWO> LRA_HD void stft_pc_block(const S
             if (LRA_UNLIKELY(LRA_UNIFORM(taken) < it)) pc_wait(lds, L::consumed_off(wave), it);  // row it - 1 still unread (it was handed over a whole frame ago)
             {
                 const int tf = phase_tid() % TF;
-                v2_last_split_store<Cfg, HD, OUT_MELR, PM, false, false>(a, clip, frame, frame < a.n_frames, tf, rg, pwr);
+                pc_last_power_row<Cfg, HD, PM>(a, clip, frame, tf, rg, pwr);
             }
             pc_fence();
             if (phase_tid() % TF == 0) pc_flag_store(lds, L::ready_off(wave), it + 1);  // behind the row's writes in this wave's DS queue

@@ -36,12 +36,13 @@ for (batch, n, hop, n_mels, power) in [(2, 22050, 512, 128, 2.0), (3, 9000, 512,
                                        (1, 2048, 512, 128, 2.0), (7, 30011, 512, 96, 2.0), (256, 661500, 512, 128, 2.0)]:
     t0 = time.time()
     A = run(batch, n, hop, n_mels, power, 0)
-    B = run(batch, n, hop, n_mels, power, 1)
-    same = bool(torch.equal(A, B))
-    nan = int(torch.isnan(B).sum())
-    ok &= same and nan == 0
-    d = float((A - B).abs().max()) if not same else 0.0
-    print(f"batch {batch} n {n} hop {hop} mels {n_mels} power {power}: pc == v2 {same}  nan {nan}  max|d| {d:.3g}  ({time.time() - t0:.1f} s)", flush=True)
+    for pc in (1, 2):
+        B = run(batch, n, hop, n_mels, power, pc)
+        nan = int(torch.isnan(B).sum())
+        rel = float(((A - B).abs() / A.abs()).max())
+        good = nan == 0 and rel < 2e-5
+        ok &= good
+        print(f"batch {batch} n {n} hop {hop} mels {n_mels} power {power}: mel_pc {pc}: max rel diff to the one-wave kernel {rel:.3g}  nan {nan}  {'ok' if good else 'MISMATCH'}", flush=True)
 print("PARITY", "ok" if ok else "FAILED", flush=True)
 
 # timings: BASELINE configs[1], alternating
@@ -69,13 +70,9 @@ def timeit(steps=20):
 
 
 for r in range(rounds):
-    for pc in (0, 1):
+    for pc in (0, 1, 2):
         ctx.set_option("mel_pc", pc)
         ms = timeit()
         print(f"round {r} mel_pc {pc}: {ms:.4f} ms  {batch * T / ms / 1e3:.1f} M frames/s", flush=True)
-for iters in (54, 81, 108, 162):
-    ctx.set_option("mel_pc", 1)
-    ctx.set_option("stft_iters", iters)
-    print(f"mel_pc 1 stft_iters {iters}: {timeit():.4f} ms", flush=True)
 ctx.set_option("stft_iters", 0)
 ctx.set_option("mel_pc", 0)

@@ -23,7 +23,7 @@ def run(batch, n, hop, kind, v3, center=True, pad="constant", power=2.0):
     y = bench.make_batch(torch, batch, n, 0, dev)
     pl = ctx.stft_plan(n_fft, hop, w, center, pad, np.float32)
     T = ctx.stft_num_frames(pl, n)
-    ctx.set_option("v3", v3)
+    ctx.set_option("v3", 2 * v3)
     if kind == 0:
         out = torch.full((batch, T, bins), float("nan"), dtype=torch.complex64, device=dev)
         ctx.stft_exec(pl, y.data_ptr(), batch, n, n, out.data_ptr())
@@ -31,7 +31,7 @@ def run(batch, n, hop, kind, v3, center=True, pad="constant", power=2.0):
         out = torch.full((batch, T, bins), float("nan"), dtype=torch.float32, device=dev)
         ctx.spectrogram_exec(pl, y.data_ptr(), batch, n, n, power, out.data_ptr())
     torch.cuda.synchronize()
-    ctx.set_option("v3", 0)
+    ctx.set_option("v3", 1)
     return out
 
 
@@ -74,9 +74,9 @@ def timeit(fn, steps=20):
 algo = batch * T * (bins * 8 + hop * 4)
 for r in range(rounds):
     for v3 in (0, 1):
-        ctx.set_option("v3", v3)
+        ctx.set_option("v3", 2 * v3)
         t_packed = timeit(lambda: ctx.stft_exec(pl, y.data_ptr(), batch, n, n, buf.data_ptr()))
         t_padded = timeit(lambda: ctx.stft_exec_strided(pl, 0, y.data_ptr(), batch, n, n, 2.0, buf.data_ptr(), pitch_pad))
         t_power = timeit(lambda: ctx.spectrogram_exec(pl, y.data_ptr(), batch, n, n, 2.0, S.data_ptr()))
         print(f"round {r} v3 {v3}: stft packed {t_packed:.4f} ms ({algo / t_packed / 8e9 * 100:.1f} % of 8 TB/s)  padded rows {t_padded:.4f} ms ({algo / t_padded / 8e9 * 100:.1f} %)  |X|^2 {t_power:.4f} ms", flush=True)
-ctx.set_option("v3", 0)
+ctx.set_option("v3", 1)

@@ -140,7 +140,7 @@ template <class T> struct StftSim {
             if constexpr (pc_cfg_ok<Cfg>()) {
                 TwoSlope<T> ts = build_two_slope<T>(dense_basis, a.n_mels, Cfg::M + 1);
                 const int hd = v2_hop_divisor<Cfg>(a.hop);
-                if (ts.ok && (hd == 4 || hd == 8)) {
+                if (ts.ok && pc_fits_budget<Cfg>(hd, a.power_mode)) {
                     MelRuns<T> mr = build_mel_runs<T>(ts, Cfg::TF, Cfg::R / 2, MELR_PMAX, 4, 1);
                     if (mr.ok && pc_bank_ok<Cfg>(a.n_mels, mr.pmax)) {
                         a.melr_w = mr.w.data(); a.melr_keep = mr.keep.data(); a.melr_addr = mr.addr.data(); a.melr_zero = mr.zero_addr; a.melr_mid = mr.mid_addr; a.melr_pmax = mr.pmax;

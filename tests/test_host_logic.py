@@ -464,7 +464,7 @@ def test_bench_compact_line_keeps_the_contract_and_fits():
     full = {"metric": "STFT+mel frames/sec (n_fft=2048 hop=512)", "value": 5.8e8, "unit": "frames/s", "n_gpus": 1, "steps": 50, "warmup": 10, "ms_per_step": 0.56, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": prose, "frames_per_step_per_gpu": 330752, "clips_per_gpu": 256, "prewarm_ms": 400.0, "parallelism": prose, "device": "gfx950"},
-            "roofline": {"bound": "valu/lds", "kernel": "k", "achieved": 1500.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.1875, "traffic": 8.6e8, "traffic_box": "profile", "bytes_per_frame": 2560,
+            "roofline": {"bound": "hbm", "kernel": "k", "achieved": 1500.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.1875, "traffic": 8.6e8, "traffic_box": "profile", "bytes_per_frame": 2560,
                          "launch_ms": 0.56, "note": prose, "limited_by": prose},
             "roofline_valu": {"frac": 0.24}, "roofline_stft": {"frac": 0.57, "launch_ms": 0.74, "traffic": 3.4e9, "achievable_note": prose},
             "roofline_istft": {"frac": 0.6, "launch_ms": 0.71, "round_trip_snr_db_min": 136.5, "call_note": prose},
@@ -473,14 +473,19 @@ def test_bench_compact_line_keeps_the_contract_and_fits():
             "cpu_baseline": {"value": 154615.4, "unit": "frames/s", "cores": 1, "kind": "reference", "sample": prose, "host": {"cpu_model": "EPYC"}},
             "cpu_baseline_all_cores": {"value": 1.9e6, "cores": 64}, "parity": {"mel_max_rel_err_vs_reference": 5e-6, "oracle_equals_reference": True, "bar": 1e-4, "sample": prose},
             "scaling_base": {"clips_per_gpu": 512, "value": 5.9e8, "unit": "frames/s", "ms_per_step": 1.12}, "repeats": {"ms_per_step_min": 0.55, "ms_per_step_median": 0.56, "ms_per_step_all": [0.56] * 5},
-            "griffinlim": {"ms_per_iteration": 0.43, "ms_setup": 0.5, "what": prose}, "hpss": {"error": "boom"}, "dropin_torch": {"ms_per_call": 0.57, "what": prose}}
+            "griffinlim": {"ms_per_iteration": 0.43, "ms_setup": 0.5, "what": prose}, "hpss": {"error": "boom"}, "dropin_torch": {"ms_per_call": 0.57, "what": prose},
+            "kernel_forms": {"stft_radix_16_8_8": {"ms": 0.64, "frac": 0.658}, "stft_radix_16_16_4": {"ms": 0.63, "frac": 0.672}, "mel_one_wave": {"ms": 0.56}, "mel_producer_consumer": {"ms": 0.557},
+                             "what": prose}, "long_clip": {"frac_of_batched": 0.97, "what": prose}}
     line = bench.compact_line(full)
     text = json.dumps(line)
     assert len(text) <= 4096
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in line
-    assert line["roofline"]["bound"] == "valu/lds" and line["roofline"]["frac"] == 0.1875
-    path = line["roofline"]["path"]
+    assert line["roofline"]["bound"] == "hbm" and line["roofline"]["frac"] == 0.1875 and line["roofline"]["valu_frac"] == 0.24
+    # the path's other fractions are SCALARS of `roofline` (the driver's record drops nested objects: VERDICT r05)
+    path = line["roofline"]
+    assert all(not isinstance(v, (dict, list)) for v in path.values())
+    assert path["stft_v2_frac"] == 0.658 and path["stft_v3_frac"] == 0.672 and path["mel_pc_ms"] == 0.557 and path["long_clip_frac"] == 0.97
     assert path["stft_frac"] == 0.57 and path["istft_frac"] == 0.6 and path["stream_forward_frac"] == 0.59 and path["stream_inverse_frac"] == 0.6 and path["cqt_lite_frac"] == 0.51
     assert path["stft_frac_best_placement"] == 0.61 and path["placements"] == 5
     assert line["cpu_baseline"]["kind"] == "reference" and line["cpu_baseline"]["cores"] == 1 and line["cpu_baseline"]["all_cores"] == 64

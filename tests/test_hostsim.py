@@ -194,17 +194,18 @@ def test_mel_body_run_ordered_both_generations(n_fft, hop, power, n_mels, iters,
     assert np.all(np.abs(M4 - Mref) <= 1e-5 * np.abs(Mref) + 1e-5 * Mref.max())
 
 
-@pytest.mark.parametrize("hop,power,n_mels,iters,n", [(512, 2.0, 128, 3, 9000), (512, 2.0, 128, 9, 30000), (256, 2.0, 128, 5, 9000), (256, 1.0, 128, 4, 9000), (512, 1.7, 128, 3, 5000), (512, 2.0, 120, 1, 4096)])
-def test_mel_body_producer_consumer(hop, power, n_mels, iters, n, monkeypatch):
+@pytest.mark.parametrize("hop,power,n_mels,iters,n,variant", [(512, 2.0, 128, 3, 9000, 0), (512, 2.0, 128, 9, 30000, 0), (256, 2.0, 128, 5, 9000, 0), (256, 1.0, 128, 4, 9000, 0), (512, 2.0, 120, 1, 4096, 0),
+                                                              (512, 2.0, 128, 3, 9000, 6), (512, 1.0, 128, 7, 20000, 6), (256, 1.0, 128, 4, 9000, 6), (256, 2.0, 125, 2, 6000, 6)])
+def test_mel_body_producer_consumer(hop, power, n_mels, iters, n, variant, monkeypatch):
     """The producer / consumer fused mel kernel body (lra_kernels_pc.h: 192-thread workgroups [P, P, C]) against the oracle, and bit for bit against the
     single-wave form it splits (the same operations in the same order; the simulator runs the phase bodies, the flag hand-over itself only runs on the device)."""
     rng = np.random.default_rng(hop + n_mels)
     y = rng.standard_normal((3, n)).astype(np.float32)
     win = O.get_window("hann", 2048)
     B = O.mel(sr=22050, n_fft=2048, n_mels=n_mels)
-    M4, d4 = H.stft(y, 2048, hop, win, mode=4, power=power, mel_basis=B, iters_per_wg=iters)
+    M4, d4 = H.stft(y, 2048, hop, win, mode=4, power=power, mel_basis=B, iters_per_wg=iters, variant=variant)  # (variant 6: both on the radix 16-16-4 core)
     monkeypatch.setenv("LRA_SIM_PC", "1")
-    Mp, dp = H.stft(y, 2048, hop, win, mode=4, power=power, mel_basis=B, iters_per_wg=iters)
+    Mp, dp = H.stft(y, 2048, hop, win, mode=4, power=power, mel_basis=B, iters_per_wg=iters, variant=variant)
     assert Mp is not None and dp["v2"] == 2 and dp["NT"] == 192 and dp["lds"] <= 40 * 1024, dp  # four workgroups per CU
     _check_diag(dp)
     assert not np.isnan(Mp).any()
@@ -218,6 +219,9 @@ def test_mel_body_producer_consumer_declines_wide_segments(monkeypatch):
     monkeypatch.setenv("LRA_SIM_PC", "1")
     y = np.random.default_rng(3).standard_normal((1, 5000)).astype(np.float32)
     Mp, dp = H.stft(y, 2048, 512, O.get_window("hann", 2048), mode=4, power=2.0, mel_basis=O.mel(sr=22050, n_fft=2048, n_mels=40), iters_per_wg=3)
+    assert Mp is None and dp == dict(unavailable=3)
+    # ... as it does for powers whose producer does not fit three waves per SIMD (pow(): lra_kernels_pc.h, pc_fits_budget)
+    Mp, dp = H.stft(y, 2048, 512, O.get_window("hann", 2048), mode=4, power=1.7, mel_basis=O.mel(sr=22050, n_fft=2048, n_mels=128), iters_per_wg=3)
     assert Mp is None and dp == dict(unavailable=3)
 
 
