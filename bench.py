@@ -588,8 +588,9 @@ def main():
                             out[name] = {"ms": ms, "frames_per_s": frames_per_step / (e / 10)}
             finally:
                 ctx.set_option("v3", 1)
-                ctx.set_option("mel_pc", 0)
-            out["what"] = "best of two alternating rounds of 10 launches each, same input / output buffers as roofline_stft and the timed step; defaults: 16-16-4 for the complex STFT, one wave per frame for the mel kernel"
+                ctx.set_option("mel_pc", 1)
+            out["what"] = ("best of two alternating rounds of 10 launches each, same input / output buffers as roofline_stft and the timed step; the library's defaults: 16-16-4 for the "
+                           "complex STFT, producer / consumer waves on the 16-8-8 core for the fused mel kernel (= the timed step)")
             return out
 
         measure("kernel_forms", kernel_forms)
@@ -712,6 +713,42 @@ def main():
                             "upload / kernel / download overlapped); steady state, `first_calls_ms` = the two calls that sized the staging buffers; informative only"}
 
         measure("end_to_end_numpy", public_numpy)
+
+        def long_clip():
+            """ONE long clip (1 x 1 h @ 22.05 kHz = 79.4 M samples) through the NumPy drop-in: a call with fewer clips than devices shards by FRAMES
+            (librosa_amd.distributed.shard_frames; opt-in LRA_DEVICES).  On this 1-GPU box the two frame ranges both run on device 0 -- what is checked is that
+            the sharded result equals the unsharded one bit for bit, and what is timed is the long clip against the same number of samples as a batch of clips."""
+            from librosa_amd.core import spectrum as SP
+
+            secs = 3600
+            rng = np.random.default_rng(440)
+            yl = (0.1 * rng.standard_normal(SR * secs, dtype=np.float32) + 0.5 * np.sin(2 * np.pi * 440.0 / SR * np.arange(SR * secs, dtype=np.float32))).astype(np.float32)[None, :]
+            kw = dict(sr=SR, n_fft=N_FFT, hop_length=HOP, n_mels=N_MELS)
+            old = os.environ.get("LRA_DEVICES")
+            try:
+                os.environ["LRA_DEVICES"] = "0"
+                L.feature.melspectrogram(y=yl, **kw)
+                t0 = time.perf_counter()
+                M1 = L.feature.melspectrogram(y=yl, **kw)
+                dt1 = time.perf_counter() - t0
+                os.environ["LRA_DEVICES"] = "0,0"
+                assert SP._frame_shard_plan(yl.shape[-1], M1.shape[-1], 1, yl.nbytes, N_FFT, HOP, True) is not None
+                L.feature.melspectrogram(y=yl, **kw)
+                t0 = time.perf_counter()
+                M2 = L.feature.melspectrogram(y=yl, **kw)
+                dt2 = time.perf_counter() - t0
+            finally:
+                if old is None:
+                    os.environ.pop("LRA_DEVICES", None)
+                else:
+                    os.environ["LRA_DEVICES"] = old
+            batched = side.get("end_to_end_numpy", {}).get("melspectrogram", {}).get("frames_per_s")
+            fps = M1.shape[-1] / dt1
+            return {"seconds_of_audio": secs, "frames": int(M1.shape[-1]), "ms_unsharded": dt1 * 1e3, "ms_two_frame_ranges_on_one_device": dt2 * 1e3, "frames_per_s": fps,
+                    "sharded_equals_unsharded": bool(np.array_equal(M1, M2)), "frac_of_batched": (fps / batched) if batched else None,
+                    "what": "feature.melspectrogram(y=<(1, 79.38 M) np.ndarray>) end to end through the host pipeline; `frac_of_batched` = its frames/s over end_to_end_numpy's 64 x 30 s batch"}
+
+        measure("long_clip", long_clip)
 
         def db_and_mfcc():
             out = {}
@@ -906,7 +943,7 @@ def main():
                                    f"(`gathered`: all-gathered)", "frames_per_step_per_gpu": frames_per_step, "clips_per_gpu": batch, "prewarm_ms": args.prewarm_ms,
                        "parallelism": f"clips sharded over {world} GPU(s), one process per GPU, no collective on the data path", "device": ctx.device_name(),
                        "self_launched": bool(os.environ.get("LRA_BENCH_SELF_LAUNCHED"))},
-            "roofline": {"bound": "hbm", "kernel": "stft2_kernel<n_fft=2048, OUT_MELR> (fused melspectrogram)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "stft_pc_kernel<n_fft=2048> (fused melspectrogram: producer / consumer waves, csrc/lra_kernels_pc.h)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_frame": BYTES_PER_FRAME_MEL,
                          "launch_ms": launch_s * 1e3, "frames_per_s_single_gpu": frames_per_step / launch_s,
                          "limited_by": "valu/lds issue, not HBM (achieved / peak / frac here ARE the HBM figures BASELINE's metric asks for; `valu_frac` = the same launch against the f32 vector peak, "

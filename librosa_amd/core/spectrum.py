@@ -241,6 +241,92 @@ def _sharded_host_exec(sess, batch, nbytes, run):
     return any(flags)
 
 
+# A batch with fewer clips than devices cannot shard by clips; ONE long clip (hours of audio: SURVEY.md 8(e), the reference's own answer is block-wise
+# `stream`, core/audio.py:223-533) shards by FRAMES instead: device i takes frames shard_range(n_frames, i, n) of every clip, computed as the uncentred
+# transform of its sample range plus the n_fft - hop halo, the centre padding going to the first / last shard (distributed.shard_frames).  Same
+# opt-in as the clip sharding (LRA_DEVICES); below this many frames per device it is not worth it.
+_FRAME_SHARD_MIN_FRAMES = 256
+
+
+def _frame_shard_plan(n, n_frames, batch, nbytes, n_fft, hop, center):
+    """[(device, shard)] when this call is to be sharded by frames, else None."""
+    from .. import _native
+    from ..distributed import shard_frames
+
+    devs = _native.host_devices()
+    if len(devs) <= 1 or batch >= 2 * len(devs) or batch < 1:
+        return None
+    if n_frames < _FRAME_SHARD_MIN_FRAMES * len(devs) or nbytes < _MULTI_DEVICE_MIN_BYTES * len(devs):
+        return None
+    pad = n_fft // 2 if center else 0
+    if n < 2 * pad + 2:  # (centre padding longer than the clip: repeated reflection does not split)
+        return None
+    shards = [(d, shard_frames(n, i, len(devs), n_fft, hop, center)) for i, d in enumerate(devs)]
+    return [(d, sh) for d, sh in shards if sh["frame_hi"] > sh["frame_lo"]]
+
+
+def _istft_sample_shards(expected, n_used, batch, nbytes, n_fft, hop, center):
+    """[(device, (s0, s1, fa, fb))]: output samples [s0, s1) of the final signal and the frames [fa, fb) that reach into them; None = do not shard."""
+    from .. import _native
+    from ..distributed import shard_range
+
+    devs = _native.host_devices()
+    if len(devs) <= 1 or batch >= 2 * len(devs) or batch < 1 or n_used < _FRAME_SHARD_MIN_FRAMES * len(devs) or nbytes < _MULTI_DEVICE_MIN_BYTES * len(devs):
+        return None
+    drop = n_fft // 2 if center else 0
+    out = []
+    for i, d in enumerate(devs):
+        s0, s1 = shard_range(expected, i, len(devs))
+        if s1 <= s0:
+            continue
+        u0, u1 = s0 + drop, s1 + drop  # positions in the untrimmed overlap-add buffer
+        fa = max(0, (u0 - n_fft) // hop + 1)
+        fb = min(n_used, (u1 - 1) // hop + 1)
+        if fb <= fa:  # samples beyond the last frame (length= longer than the frames reach): zeros, left to the unsharded call's semantics
+            return None
+        out.append((d, (s0, s1, fa, fb)))
+    return out
+
+
+def _frame_sharded_host_exec(sess, shards, run):
+    """``run(ctx, shard)`` for every (device, shard), the session's own device on the calling thread and one thread per further device (several shards
+    of one device run one after the other on its thread); returns whether any shard saw a non-finite sample."""
+    from .. import _native
+
+    by_dev = collections.OrderedDict()
+    for d, sh in shards:
+        by_dev.setdefault(d, []).append(sh)
+    flags, errors = [], []
+
+    def serve(ctx, items, lock):
+        try:
+            if lock:
+                ctx.call_lock.acquire()
+            try:
+                if lock:
+                    ctx.use_own_stream()
+                for sh in items:
+                    flags.append(bool(run(ctx, sh)))
+            finally:
+                if lock:
+                    ctx.call_lock.release()
+        except BaseException as exc:  # noqa: BLE001 - re-raised on the calling thread
+            errors.append(exc)
+
+    mine = by_dev.pop(sess.ctx.device, [])
+    threads = []
+    for d, items in by_dev.items():
+        th = threading.Thread(target=serve, args=(_native.get_context(d), items, True), name=f"lra-dev{d}", daemon=True)
+        th.start()
+        threads.append(th)
+    serve(sess.ctx, mine, False)
+    for th in threads:
+        th.join()
+    if errors:
+        raise errors[0]
+    return any(flags)
+
+
 def wss_to_norm(wss):
     """Window sum-square envelope -> the factors the inverse kernels multiply by: ``1 / wss`` where ``wss > tiny(wss)``, else 1 -- the
     reference's ``y[approx_nonzero_indices] /= ifft_window_sum[approx_nonzero_indices]`` (``core/spectrum.py:622-624``) as a product, in the
@@ -383,7 +469,30 @@ def _run_stft_family(kind, y, *, n_fft, hop_length, win_length, window, center, 
                 return c.stft_exec_host(pl, mp, {"stft": 0, "power": 1, "mel": 2}[kind], a.ctypes.data + b * n * a.itemsize, e - b, n, n, power,
                                         host.ctypes.data + b * item_out, stride)
 
-            flagged = _sharded_host_exec(sess, batch, a.nbytes + host.nbytes, run)
+            fshards = _frame_shard_plan(n, n_frames, batch, a.nbytes + host.nbytes, n_fft, hop, center)
+            if fshards is not None:
+                from ..distributed import frame_shard_input
+
+                def run_frames(c, sh):
+                    # the shard's frames = the UNCENTRED frames of its sample range (+ its share of the centre padding): distributed.shard_frames
+                    piece = frame_shard_input(a, sh, pad_mode)
+                    m, f0, nf = int(piece.shape[-1]), sh["frame_lo"], sh["frame_hi"] - sh["frame_lo"]
+                    pl = c.stft_plan(n_fft, hop, win, False, "constant", real)
+                    assert c.stft_num_frames(pl, m) == nf
+                    y_stride = piece.strides[0] // piece.itemsize if piece.ndim == 2 and piece.shape[0] > 1 else m
+                    if kind == "mel":
+                        part = np.empty((batch, n_mels, nf), dtype=real)
+                        flag = c.stft_exec_host(pl, c.mel_plan(basis), 2, piece.ctypes.data, batch, m, y_stride, power, part.ctypes.data, 0)
+                        host[:, :, f0 : f0 + nf] = part
+                        return flag
+                    per_frame = n_bins * (2 if kind == "stft" else 1)  # reals per frame row
+                    item = stride if stride else n_frames * per_frame   # reals between the results of consecutive clips
+                    return c.stft_exec_host(pl, None, 0 if kind == "stft" else 1, piece.ctypes.data, batch, m, y_stride, power,
+                                            host.ctypes.data + f0 * per_frame * real.itemsize, item)
+
+                flagged = _frame_sharded_host_exec(sess, fshards, run_frames)
+            else:
+                flagged = _sharded_host_exec(sess, batch, a.nbytes + host.nbytes, run)
             if flagged:  # util.valid_audio's scan (util/utils.py:305), done by the staging threads on the samples they copy
                 raise ParameterError("Audio buffer is not finite everywhere")
             if kind == "mel":
@@ -572,7 +681,31 @@ def istft(stft_matrix, *, hop_length=None, win_length=None, n_fft=None, window="
                     c.istft_exec_host(pl, Dt.ctypes.data + b * d_item, e - b, n_total, n_used, wss.ctypes.data, yh.ctypes.data + b * int(expected) * real.itemsize, int(expected), int(expected))
                     return False
 
-                _sharded_host_exec(sess, batch, Dt.nbytes + yh.nbytes, run)
+                ishards = _istft_sample_shards(int(expected), n_used, batch, Dt.nbytes + yh.nbytes, n_fft, int(hop_length), bool(center))
+                if ishards is not None:
+                    # ONE long spectrogram, fewer clips than devices: device i rebuilds OUTPUT samples shard_range(expected, i, n) from every frame that
+                    # reaches into them (its own and the n_fft / hop - 1 on either side), as an uncentred inverse of that run of frames with the matching
+                    # piece of the window sum-square envelope; contributions still add in increasing frame order (core/spectrum.py:593-603, 629-643)
+                    drop = n_fft // 2 if center else 0
+
+                    def run_samples(c, sh):
+                        s0, s1, fa, fb = sh
+                        m = n_fft + int(hop_length) * (fb - fa - 1)
+                        pl = c.istft_plan(n_fft, int(hop_length), win, False, real)
+                        first = fa * int(hop_length) - drop  # final-output coordinate of the shard's first rebuilt sample
+                        w_sh = np.ones(m, dtype=real)
+                        lo, hi = max(first, 0), min(first + m, int(expected))
+                        w_sh[lo - first : hi - first] = wss[lo:hi]
+                        part = np.empty((batch, m), dtype=real)
+                        c.istft_exec_host(pl, Dt.ctypes.data + fa * n_bins * cplx.itemsize, batch, n_total, fb - fa, w_sh.ctypes.data, part.ctypes.data, m, m)
+                        reach = min(s1, first + m)  # (`length` beyond the last frame's end: zeros there, core/spectrum.py:553-555)
+                        yh[:, s0:reach] = part[:, s0 - first : reach - first]
+                        yh[:, reach:s1] = 0
+                        return False
+
+                    _frame_sharded_host_exec(sess, ishards, run_samples)
+                else:
+                    _sharded_host_exec(sess, batch, Dt.nbytes + yh.nbytes, run)
                 if yh is out:
                     return out
                 y = _arrays.cast(yh.reshape(shape), out_dtype)

@@ -30,7 +30,7 @@
 #define LRA_V3_DEFAULT 1  // measured on two boxes, same buffer, alternating (profiles/r06_raw/c_*, d_*): complex STFT -1.3 % ... -2.0 %, |X|^2 +1 % (hence complex only)
 #endif
 #ifndef LRA_MEL_PC_DEFAULT
-#define LRA_MEL_PC_DEFAULT 0  // the producer / consumer fused mel kernel (lra_kernels_pc.h): ctx option "mel_pc"
+#define LRA_MEL_PC_DEFAULT 1  // the producer / consumer fused mel kernel (lra_kernels_pc.h), ctx option "mel_pc": -0.8 ... -1.9 % against the one-wave kernel on four boxes (profiles/r06_raw), never slower
 #endif
 #define LRA_FUSED_EXTERN  // the fused kernels are instantiated in lra_inst.hip (parallel build), see lra_fused.h
 #include "lra_fused.h"

@@ -24,6 +24,46 @@ def shard_range(n_items: int, rank: int, world_size: int):
     return begin, begin + base + (1 if rank < extra else 0)
 
 
+def stft_num_frames(n: int, n_fft: int, hop: int, center: bool) -> int:
+    """Frames of a clip of ``n`` samples (``1 + n // hop`` centred, ``1 + (n - n_fft) // hop`` otherwise: reference ``tests/test_core.py:270-273``)."""
+    return 1 + (n + (2 * (n_fft // 2) if center else 0) - n_fft) // hop
+
+
+def shard_frames(n: int, rank: int, world_size: int, n_fft: int, hop: int, center: bool = True):
+    """Frame-granularity shard of ONE long clip: rank ``rank`` of ``world_size`` computes frames
+    ``[frame_lo, frame_hi)`` of the clip's STFT / mel spectrogram from the samples ``[sample_lo, sample_hi)`` -- its hop samples per frame plus the
+    ``n_fft - hop`` halo that the last frame reaches into the neighbour's range.  ``sample_lo`` / ``sample_hi`` are clip coordinates and may lie
+    outside ``[0, n)``: ``pad_left`` / ``pad_right`` samples of the reference's centre padding (``np.pad``, ``core/spectrum.py:273-328``) belong to the
+    first / last shard and to nobody else.  The shard's frames are exactly the UNCENTRED frames of that (padded) slice:
+    ``stft(slice, center=False)[..., k] == stft(y, center=True)[..., frame_lo + k]`` (the block property of ``core/spectrum.py:380-390`` and of
+    ``core/audio.py:223-533``, ``stream``).  Returns a dict; ``frame_hi == frame_lo`` for a rank that gets nothing (more ranks than frames)."""
+    n_frames = stft_num_frames(n, n_fft, hop, center)
+    if n_frames < 1:
+        raise ValueError(f"a clip of {n} samples has no frame of length {n_fft}")
+    f0, f1 = shard_range(n_frames, rank, world_size)
+    pad = n_fft // 2 if center else 0
+    lo = f0 * hop - pad
+    hi = (f1 - 1) * hop + n_fft - pad if f1 > f0 else lo
+    return {"frame_lo": f0, "frame_hi": f1, "n_frames": n_frames, "sample_lo": lo, "sample_hi": hi, "pad_left": max(0, -lo), "pad_right": max(0, hi - n),
+            "read_lo": min(max(lo, 0), n), "read_hi": min(max(hi, 0), n)}
+
+
+def frame_shard_input(y, shard, pad_mode: str = "constant"):
+    """The samples a frame shard transforms with ``center=False``: ``y[..., read_lo:read_hi]`` -- a VIEW for interior shards -- with the shard's own
+    share of the centre padding attached (first / last shard only; ``np.pad`` with the reference's mode, whose sources lie inside the slice as long as
+    the shard holds a frame or two: checked)."""
+    import numpy as np
+
+    piece = y[..., shard["read_lo"] : shard["read_hi"]]
+    pl, pr = shard["pad_left"], shard["pad_right"]
+    if pl == 0 and pr == 0:
+        return piece
+    need = max(pl, pr) + (1 if pad_mode == "reflect" else 0)
+    if pad_mode != "constant" and piece.shape[-1] < need:
+        raise ValueError(f"frame shard of {piece.shape[-1]} samples cannot supply {max(pl, pr)} samples of {pad_mode!r} padding")
+    return np.pad(piece, [(0, 0)] * (piece.ndim - 1) + [(pl, pr)], mode=pad_mode)
+
+
 def shard_sizes(n_items: int, world_size: int):
     return [shard_range(n_items, r, world_size)[1] - shard_range(n_items, r, world_size)[0] for r in range(world_size)]
 

@@ -1151,6 +1151,58 @@ def test_direct_framing(L, n_fft, hop, center, pad_mode, dtype):
         ctx.set_option("direct", 1)
 
 
+def test_long_clip_shards_by_frames_in_process(L, monkeypatch):
+    """a call with fewer clips than devices shards ONE long clip by FRAMES (distributed.shard_frames: each device the uncentred
+    transform of its sample range + halo, the centre padding on the first / last shard).  On the 1-GPU box both ranges run on device 0; stft (incl.
+    out= with spare columns), _spectrogram and melspectrogram must equal the unsharded call bit for bit, for every pad mode, and a non-finite sample in the
+    last shard must still raise.  Reference: core/spectrum.py:273-328, 380-390."""
+    from librosa_amd.core import spectrum
+
+    y = golden_cases.make_signal("noise", 22050 * 8, 21, (1,))
+    n_dev = L.device_count()
+    two = ",".join(str(i % n_dev) for i in range(2)) if n_dev < 2 else "all"
+    for n_fft, hop, center, pad_mode in ((2048, 512, True, "constant"), (2048, 512, True, "reflect"), (1024, 256, False, "constant"), (512, 160, True, "symmetric"), (400, 160, True, "edge")):
+        kw = dict(n_fft=n_fft, hop_length=hop, center=center, pad_mode=pad_mode)
+        monkeypatch.setenv("LRA_DEVICES", "0")
+        D1 = L.stft(y, **kw)
+        S1, _ = spectrum._spectrogram(y=y, power=2, **kw)
+        M1 = L.feature.melspectrogram(y=y, sr=22050, n_mels=64, **kw)
+        monkeypatch.setattr(spectrum, "_MULTI_DEVICE_MIN_BYTES", 0)
+        monkeypatch.setattr(spectrum, "_FRAME_SHARD_MIN_FRAMES", 8)
+        monkeypatch.setenv("LRA_DEVICES", two)
+        served = []
+        orig = spectrum._frame_sharded_host_exec
+        monkeypatch.setattr(spectrum, "_frame_sharded_host_exec", lambda sess, shards, run: (served.extend(sh for _, sh in shards), orig(sess, shards, run))[1])
+        D2 = L.stft(y, **kw)
+        assert len(served) >= 2 and served[0]["frame_lo"] == 0 and served[-1]["frame_hi"] == D1.shape[-1]
+        assert np.array_equal(D1, D2)
+        assert np.array_equal(S1, spectrum._spectrogram(y=y, power=2, **kw)[0])
+        assert np.array_equal(M1, L.feature.melspectrogram(y=y, sr=22050, n_mels=64, **kw))
+        out = np.swapaxes(np.zeros((1, D1.shape[-1] + 5, D1.shape[-2]), dtype=np.complex64), -1, -2)
+        got = L.stft(y, out=out, **kw)
+        assert np.array_equal(got, D1) and np.shares_memory(got, out)
+        # the inverse by OUTPUT-sample ranges (each device: the frames that reach into its samples, its piece of the window sum-square envelope)
+        ikw = dict(hop_length=hop, n_fft=n_fft, center=center)
+        for length in (None, y.shape[-1], y.shape[-1] - 777):
+            monkeypatch.setenv("LRA_DEVICES", "0")
+            y1 = L.istft(D1, length=length, **ikw)
+            monkeypatch.setenv("LRA_DEVICES", "0,0,0")
+            assert spectrum._istft_sample_shards(y1.shape[-1], D1.shape[-1], 1, 1 << 40, n_fft, hop, center) is not None
+            assert np.array_equal(y1, L.istft(D1, length=length, **ikw)), (n_fft, hop, center, length)
+        monkeypatch.setenv("LRA_DEVICES", two)
+        y2 = np.stack([y[0], -y[0][::-1]])  # two clips on three "devices": still fewer than two per device
+        monkeypatch.setenv("LRA_DEVICES", "0,0,0")
+        D3 = L.stft(y2, **kw)
+        monkeypatch.setenv("LRA_DEVICES", "0")
+        assert np.array_equal(D3, L.stft(y2, **kw))
+        monkeypatch.setattr(spectrum, "_frame_sharded_host_exec", orig)
+    monkeypatch.setenv("LRA_DEVICES", two)
+    bad = y.copy()
+    bad[0, -5] = np.inf
+    with pytest.raises(L.ParameterError):
+        L.stft(bad, n_fft=2048, hop_length=512)
+
+
 # ---- round 6: the two new forms of the n_fft = 2048 forward kernels, switched on by context options ---------------------------------------------
 @pytest.mark.parametrize("hop,power,n,batch", [(512, 2.0, 22050, 2), (512, 2.0, 9000, 3), (512, 2.0, 661500, 5), (256, 2.0, 100000, 4), (256, 1.0, 100000, 4), (512, 2.0, 2048, 1), (512, 2.0, 70001, 7)])
 def test_producer_consumer_mel_kernel(L, hop, power, n, batch):
@@ -1176,22 +1228,21 @@ def test_producer_consumer_mel_kernel(L, hop, power, n, batch):
         Mh = L.feature.melspectrogram(y=y, sr=22050, n_fft=2048, hop_length=hop, n_mels=128, power=power)
         assert np.array_equal(Mh, outs[1])
     finally:
-        ctx.set_option("mel_pc", 0)
+        ctx.set_option("mel_pc", 1)  # (the library's default)
 
 
-def test_producer_consumer_mel_kernel_full_size(L):
+def test_producer_consumer_mel_kernel_full_size(L, full_batch):
     """BASELINE configs[1] through the producer / consumer kernel: 256 clips x 30 s, four clips at the pure-relative bar, per-clip independence (clip i of the
     batch == clip i alone), and banks it does not serve (40 bands: segments wider than its register lists) still answered by the one-wave kernel."""
     import torch
     ctx = L.get_context(0)
-    y = O.config_input(256)
-    yt = torch.from_numpy(y).to("cuda:0")
+    yt = full_batch
     try:
         ctx.set_option("mel_pc", 1)
         M = L.feature.melspectrogram(y=yt, sr=22050, n_fft=2048, hop_length=512, n_mels=128)
         assert not bool(torch.isnan(M).any())
         for i in (0, 71, 128, 255):
-            ref = O.melspectrogram(y=y[i], sr=22050, n_fft=2048, hop_length=512, n_mels=128)
+            ref = O.melspectrogram(y=yt[i].cpu().numpy(), sr=22050, n_fft=2048, hop_length=512, n_mels=128)
             got = M[i].cpu().numpy()
             assert np.all(np.abs(got - ref) <= 1e-4 * np.abs(ref)), i
             assert np.array_equal(L.feature.melspectrogram(y=yt[i], sr=22050, n_fft=2048, hop_length=512, n_mels=128).cpu().numpy(), got)
@@ -1199,7 +1250,7 @@ def test_producer_consumer_mel_kernel_full_size(L):
         ctx.set_option("mel_pc", 0)
         assert np.array_equal(M40, L.feature.melspectrogram(y=yt[:3], sr=22050, n_fft=2048, hop_length=512, n_mels=40).cpu().numpy())
     finally:
-        ctx.set_option("mel_pc", 0)
+        ctx.set_option("mel_pc", 1)  # (the library's default)
 
 
 @pytest.mark.parametrize("hop,center,pad_mode,n", [(512, True, "constant", 22050), (512, True, "reflect", 9000), (256, True, "edge", 100000), (1024, False, "constant", 100000), (2048, True, "symmetric", 50000),
@@ -1227,18 +1278,17 @@ def test_radix_16_16_4_forward(L, hop, center, pad_mode, n):
         ctx.set_option("v3", 1)  # (the library's default: complex epilogue only)
 
 
-def test_radix_16_16_4_forward_full_size(L):
+def test_radix_16_16_4_forward_full_size(L, full_batch):
     """BASELINE configs[3]'s forward leg through variant 6: 256 x 30 s, sampled clips against the oracle, round trip through the inverse kernel >= 60 dB on every clip."""
     import torch
     ctx = L.get_context(0)
-    y = O.config_input(256)
-    yt = torch.from_numpy(y).to("cuda:0")
+    yt = full_batch
     try:
         ctx.set_option("v3", 1)
         D = L.stft(yt, n_fft=2048, hop_length=512)
         for i in (0, 100, 255):
-            assert _stft_close(D[i].cpu().numpy(), O.stft(y[i], n_fft=2048, hop_length=512))
-        yh = L.istft(D, hop_length=512, length=y.shape[-1])
+            assert _stft_close(D[i].cpu().numpy(), O.stft(yt[i].cpu().numpy(), n_fft=2048, hop_length=512))
+        yh = L.istft(D, hop_length=512, length=yt.shape[-1])
         err = ((yt - yh).double() ** 2).sum(-1)
         snr = 10 * torch.log10((yt.double() ** 2).sum(-1) / err)
         assert float(snr.min()) >= 60.0

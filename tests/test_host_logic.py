@@ -340,6 +340,70 @@ def test_small_jobs_stay_on_one_device_and_errors_surface(monkeypatch):
     assert ctxs[1].call_lock.acquire(blocking=False)  # released on the error path
 
 
+@pytest.mark.parametrize("n,n_fft,hop,center,mode,world", [(50000, 2048, 512, True, "constant", 3), (50000, 2048, 512, True, "reflect", 4), (30011, 1024, 256, False, "constant", 5),
+                                                           (9000, 512, 128, True, "symmetric", 7), (9000, 512, 100, True, "edge", 2), (3000, 2048, 512, True, "reflect", 2), (2048, 2048, 512, True, "constant", 8)])
+def test_shard_frames_are_column_slices_of_the_whole_transform(n, n_fft, hop, center, mode, world):
+    """distributed.shard_frames: the uncentred transform of a rank's sample range (+ halo, + its share of the centre padding) IS that
+    rank's block of columns of the whole clip's STFT -- bit for bit on the oracle -- and the ranks' blocks tile the frame axis without gaps or overlap.
+    Reference property: core/spectrum.py:273-328 (padding belongs to the clip's ends), :380-390 (frames are independent), core/audio.py:223-533 (stream)."""
+    from librosa_amd.distributed import frame_shard_input, shard_frames, stft_num_frames
+
+    y = np.random.default_rng(n).standard_normal((2, n)).astype(np.float32)
+    D = O.stft(y, n_fft=n_fft, hop_length=hop, center=center, pad_mode=mode)
+    assert stft_num_frames(n, n_fft, hop, center) == D.shape[-1]
+    nxt = 0
+    for r in range(world):
+        sh = shard_frames(n, r, world, n_fft, hop, center)
+        assert sh["frame_lo"] == nxt and sh["n_frames"] == D.shape[-1]
+        nxt = sh["frame_hi"]
+        if sh["frame_hi"] == sh["frame_lo"]:
+            continue
+        assert (sh["pad_left"] > 0) <= (r == 0 or sh["frame_lo"] * hop < n_fft // 2) and sh["sample_hi"] - sh["sample_lo"] == n_fft + hop * (sh["frame_hi"] - sh["frame_lo"] - 1)
+        piece = frame_shard_input(y, sh, mode)
+        if sh["pad_left"] == 0 and sh["pad_right"] == 0:
+            assert np.shares_memory(piece, y)  # interior shards are views: no copy of a ten-hour clip
+        d = O.stft(piece, n_fft=n_fft, hop_length=hop, center=False)
+        assert np.array_equal(d, D[..., sh["frame_lo"] : sh["frame_hi"]])
+    assert nxt == D.shape[-1]
+
+
+def test_frame_shard_plan_and_threads(monkeypatch):
+    """Which calls shard by frames (fewer clips than two per device, enough frames per device, LRA_DEVICES opted in) and who serves what."""
+    import threading
+
+    ctxs = _fake_devices(monkeypatch, [0, 1, 2, 3])
+    n = 4 * 3600 * 22050  # a four-hour clip
+    nf = 1 + n // 512
+    plan = spectrum._frame_shard_plan(n, nf, 1, 1 << 40, 2048, 512, True)
+    assert [d for d, _ in plan] == [0, 1, 2, 3] and plan[0][1]["pad_left"] == 1024 and plan[-1][1]["pad_right"] > 0 and plan[1][1]["pad_left"] == 0
+    assert sum(sh["frame_hi"] - sh["frame_lo"] for _, sh in plan) == nf
+    assert spectrum._frame_shard_plan(n, nf, 8, 1 << 40, 2048, 512, True) is None      # two clips per device: sharded by clips instead
+    assert spectrum._frame_shard_plan(22050, 44, 1, 1 << 40, 2048, 512, True) is None  # too few frames per device
+    assert spectrum._frame_shard_plan(n, nf, 1, 1 << 20, 2048, 512, True) is None      # too little data
+    _fake_devices(monkeypatch, [0])
+    assert spectrum._frame_shard_plan(n, nf, 1, 1 << 40, 2048, 512, True) is None      # one device
+    ctxs = _fake_devices(monkeypatch, [0, 1, 1])
+    plan = spectrum._frame_shard_plan(n, nf, 1, 1 << 40, 2048, 512, True)
+    who = {}
+
+    def run(c, sh):
+        who.setdefault(c.device, []).append((threading.current_thread().name, sh["frame_lo"]))
+        return sh["frame_lo"] > 0 and c.device == 1
+
+    assert spectrum._frame_sharded_host_exec(_FakeSess(ctxs[0]), plan, run) is True
+    assert [t for t, _ in who[0]] == [threading.current_thread().name] and [t for t, _ in who[1]] == ["lra-dev1", "lra-dev1"] and ctxs[1].streams == 1
+    assert [f for _, f in who[1]] == sorted(f for _, f in who[1])
+
+    def boom(c, sh):
+        if c.device == 1:
+            raise L.ParameterError("x")
+        return False
+
+    with pytest.raises(L.ParameterError):
+        spectrum._frame_sharded_host_exec(_FakeSess(ctxs[0]), plan, boom)
+    assert ctxs[1].call_lock.acquire(blocking=False)
+
+
 def test_host_devices_env(monkeypatch):
     from librosa_amd import _native
 
