@@ -108,11 +108,24 @@ class Session:
         return buf.ptr
 
     # ---- outputs --------------------------------------------------------------------------------
-    def output(self, shape, dtype):
-        """Allocate a device result; returns (ptr, handle) where handle is finalised by ``result``."""
+    def output(self, shape, dtype, rows=False):
+        """Allocate a device result; returns (ptr, handle) where handle is finalised by ``result``.
+
+        ``rows=True``: a large frame-major spectrum ``(batch, n_frames, row)``.  With the context's ``placement_retry`` option on, such a result of at
+        least 256 MB comes from ``lra_malloc_placed`` -- the best of a few candidate allocations under the kernels' own write stream, because where this
+        buffer lands moves the store-bound transforms by up to 15 % on some boxes (``profiles/r05_pitch.md``) -- wrapped as a tensor that hands the
+        buffer back to the context when it dies, so a loop of calls allocates once."""
         dtype = np.dtype(dtype)
         if self.is_torch:
-            t = _torch().empty(tuple(int(s) for s in shape), dtype=torch_dtype(dtype), device=self.device)
+            nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+            t = None
+            if rows and self.ctx.placement_retry > 0 and nbytes >= self.ctx.PLACED_MIN_BYTES and len(shape) == 3 and int(shape[0]) * int(shape[1]) >= 4096:
+                try:
+                    t = _placed_tensor(self.ctx, tuple(int(s) for s in shape), dtype, self.device)
+                except _native.NativeError:  # (no room for a candidate next to torch's cached blocks, or no virtual-memory API: an ordinary allocation serves)
+                    t = None
+            if t is None:
+                t = _torch().empty(tuple(int(s) for s in shape), dtype=torch_dtype(dtype), device=self.device)
             if POISON_OUTPUTS and t.numel():
                 _torch().as_strided(t, (t.numel(),), (1,)).view(_torch().uint8).fill_(0xFF)
             return t.data_ptr(), t
@@ -150,6 +163,30 @@ class Session:
             if self._locked:
                 self._locked = False
                 self.ctx.call_lock.release()
+
+
+class _PlacedHolder:
+    """Owner of one lra_malloc_placed buffer behind a torch tensor (``__cuda_array_interface__``): torch keeps a reference to this object for as long
+    as any view of the tensor lives; after that the buffer goes back to its context (recycled for the next result of the same shape)."""
+
+    def __init__(self, ctx, nbytes, row_bytes):
+        self.ctx, self.nbytes, self.row_bytes = ctx, int(nbytes), int(row_bytes)
+        self.ptr = ctx.placed_take(self.nbytes, self.row_bytes)
+        self.__cuda_array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (int(self.ptr), False), "version": 3, "strides": None}
+
+    def __del__(self):
+        try:
+            self.ctx.placed_give(self.nbytes, self.row_bytes, self.ptr)
+        except Exception:  # pragma: no cover - interpreter shutdown
+            pass
+
+
+def _placed_tensor(ctx, shape, dtype, device):
+    torch = _torch()
+    nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+    holder = _PlacedHolder(ctx, nbytes, shape[-1] * np.dtype(dtype).itemsize)
+    flat = torch.as_tensor(holder, device=device)
+    return flat.view(torch_dtype(dtype)).reshape(shape)
 
 
 def swap_last_two(x):

@@ -49,6 +49,8 @@ SIGNATURES = {
     "lra_istft_plan_tuned_variant": (c_int, [c_void_p]),
     "lra_malloc": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
     "lra_free": (c_int, [c_void_p, c_void_p]),
+    "lra_malloc_placed": (c_int, [c_void_p, c_size_t, c_int, c_int, POINTER(c_void_p), POINTER(c_float), POINTER(c_int)]),
+    "lra_free_placed": (c_int, [c_void_p, c_void_p]),
     "lra_memset": (c_int, [c_void_p, c_void_p, c_int, c_size_t]),
     "lra_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
     "lra_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
@@ -248,6 +250,13 @@ class Context:
         self._tables = {}  # pool name -> OrderedDict (see device_table)
         self._lock = threading.RLock()
         self.call_lock = threading.RLock()  # held by _arrays.Session for the duration of one public call
+        # placement-aware result buffers (lra_malloc_placed): `placement_retry` candidates per new buffer (0 = off; env LRA_PLACEMENT_RETRY), and the
+        # buffers whose tensors have been dropped, kept for the next call of the same shape (their placement is already known to be a good one)
+        # (default 4: on a box with the placement lottery the worst of five such buffers ran the complex STFT within 0.3 % of the best, 15 % between torch.empty ones;
+        #  a box without it stops after two candidates, ~12 ms per new shape: profiles/r06b_bench_line.json)
+        self.placement_retry = max(0, min(8, int(os.environ.get("LRA_PLACEMENT_RETRY", "4") or 0)))
+        self._placed_free = {}   # (nbytes, row_bytes) -> [ptr]
+        self._placed_log = []    # (nbytes, row_bytes, probe_ms, candidates tried) of every fresh allocation
 
     # -- context ------------------------------------------------------------------------------
     def device_name(self):
@@ -273,6 +282,47 @@ class Context:
 
     def set_option(self, key, value):
         _check(self.lib.lra_ctx_set_option(self.handle, key.encode(), int(value)))
+        if key == "placement_retry":
+            self.placement_retry = max(0, min(8, int(value)))
+
+    # -- placement-aware result buffers (include/librosa_amd.h, lra_malloc_placed) -----------------
+    PLACED_MIN_BYTES = 256 << 20
+    PLACED_KEEP_PER_SHAPE = 2
+
+    def placed_take(self, nbytes, row_bytes):
+        """Device pointer of a buffer of ``nbytes`` (rows of ``row_bytes``): a recycled one of that shape if there is one, else the best of
+        ``placement_retry`` fresh candidates."""
+        key = (int(nbytes), int(row_bytes))
+        with self._lock:
+            free = self._placed_free.get(key)
+            if free:
+                return free.pop()
+        p, ms, tried = c_void_p(), c_float(0), c_int(0)
+        _check(self.lib.lra_malloc_placed(self.handle, key[0], key[1], int(self.placement_retry), byref(p), byref(ms), byref(tried)))
+        with self._lock:
+            self._placed_log.append((key[0], key[1], float(ms.value), int(tried.value)))
+            del self._placed_log[:-64]
+        return p.value
+
+    def placed_give(self, nbytes, row_bytes, ptr):
+        """A placed buffer whose tensor is gone: kept for the next result of that shape, or released when enough are waiting."""
+        key = (int(nbytes), int(row_bytes))
+        with self._lock:
+            free = self._placed_free.setdefault(key, [])
+            if len(free) < self.PLACED_KEEP_PER_SHAPE:
+                free.append(ptr)
+                return
+        try:
+            self.lib.lra_free_placed(self.handle, c_void_p(ptr))
+        except Exception:  # pragma: no cover - interpreter shutdown
+            pass
+
+    def placed_release_all(self):
+        with self._lock:
+            ptrs = [p for v in self._placed_free.values() for p in v]
+            self._placed_free.clear()
+        for p in ptrs:
+            _check(self.lib.lra_free_placed(self.handle, c_void_p(p)))
 
     def nonfinite_reset(self):
         _check(self.lib.lra_ctx_nonfinite_reset(self.handle))

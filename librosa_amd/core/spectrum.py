@@ -251,7 +251,7 @@ _FRAME_SHARD_MIN_FRAMES = 256
 def _frame_shard_plan(n, n_frames, batch, nbytes, n_fft, hop, center):
     """[(device, shard)] when this call is to be sharded by frames, else None."""
     from .. import _native
-    from ..distributed import shard_frames
+    from ..distributed import shard_frames, split_padded_edges
 
     devs = _native.host_devices()
     if len(devs) <= 1 or batch >= 2 * len(devs) or batch < 1:
@@ -262,7 +262,8 @@ def _frame_shard_plan(n, n_frames, batch, nbytes, n_fft, hop, center):
     if n < 2 * pad + 2:  # (centre padding longer than the clip: repeated reflection does not split)
         return None
     shards = [(d, shard_frames(n, i, len(devs), n_fft, hop, center)) for i, d in enumerate(devs)]
-    return [(d, sh) for d, sh in shards if sh["frame_hi"] > sh["frame_lo"]]
+    # (the frames that touch the centre padding run on their own: the padded copy is then a frame or two long, the rest of an edge shard a view)
+    return [(d, run) for d, sh in shards if sh["frame_hi"] > sh["frame_lo"] for run in split_padded_edges(n, sh, n_fft, hop, center)]
 
 
 def _istft_sample_shards(expected, n_used, batch, nbytes, n_fft, hop, center):
@@ -508,13 +509,13 @@ def _run_stft_family(kind, y, *, n_fft, hop_length, win_length, window, center, 
         if kind != "mel" and sess.is_torch and fused:  # device-resident result: rows padded to whole cache lines behind the view (see row_pitch)
             pitch = row_pitch(n_bins, np.dtype(util.dtype_r2c(real) if kind == "stft" else real).itemsize, row_align)
         if kind == "stft":
-            ptr, handle = sess.output((batch, n_frames, pitch), util.dtype_r2c(real))
+            ptr, handle = sess.output((batch, n_frames, pitch), util.dtype_r2c(real), rows=True)
             if pitch == n_bins:
                 ctx.stft_exec(plan, y_ptr, batch, n, y_stride, ptr)
             else:
                 ctx.stft_exec_strided(plan, 0, y_ptr, batch, n, y_stride, 1.0, ptr, pitch)
         elif kind == "power":
-            ptr, handle = sess.output((batch, n_frames, pitch), real)
+            ptr, handle = sess.output((batch, n_frames, pitch), real, rows=True)
             if pitch == n_bins:
                 ctx.spectrogram_exec(plan, y_ptr, batch, n, y_stride, power, ptr)
             else:

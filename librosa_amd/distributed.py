@@ -41,11 +41,30 @@ def shard_frames(n: int, rank: int, world_size: int, n_fft: int, hop: int, cente
     if n_frames < 1:
         raise ValueError(f"a clip of {n} samples has no frame of length {n_fft}")
     f0, f1 = shard_range(n_frames, rank, world_size)
+    return frame_run(n, f0, f1, n_fft, hop, center)
+
+
+def frame_run(n: int, f0: int, f1: int, n_fft: int, hop: int, center: bool = True):
+    """The sample range (and its share of the centre padding) behind frames ``[f0, f1)`` of a clip of ``n`` samples: see ``shard_frames``."""
+    n_frames = stft_num_frames(n, n_fft, hop, center)
     pad = n_fft // 2 if center else 0
     lo = f0 * hop - pad
     hi = (f1 - 1) * hop + n_fft - pad if f1 > f0 else lo
     return {"frame_lo": f0, "frame_hi": f1, "n_frames": n_frames, "sample_lo": lo, "sample_hi": hi, "pad_left": max(0, -lo), "pad_right": max(0, hi - n),
             "read_lo": min(max(lo, 0), n), "read_hi": min(max(hi, 0), n)}
+
+
+def split_padded_edges(n: int, shard, n_fft: int, hop: int, center: bool = True):
+    """A shard as runs of frames: the few frames that reach into the centre padding (``pad / hop`` at either end of the CLIP) on their own, so that
+    attaching the padding copies a frame or two of samples and the bulk of an edge shard stays a view of the input (``frame_shard_input``)."""
+    f0, f1 = shard["frame_lo"], shard["frame_hi"]
+    pad = n_fft // 2 if center else 0
+    if f1 <= f0 or pad == 0:
+        return [shard]
+    left_end = min(f1, max(f0, -(-pad // hop)))                       # frames f < ceil(pad / hop) start before sample 0
+    right_start = max(left_end, min(f1, (n + pad - n_fft) // hop + 1))  # frames f > (n + pad - n_fft) / hop end beyond sample n
+    runs = [(f0, left_end), (left_end, right_start), (right_start, f1)]
+    return [frame_run(n, a, b, n_fft, hop, center) for a, b in runs if b > a]
 
 
 def frame_shard_input(y, shard, pad_mode: str = "constant"):

@@ -24,10 +24,13 @@ os.makedirs(dst, exist_ok=True)
 def short(name):
     import re
     cfg = re.search(r"FftCfg<(\d+), (\d), (\w+), (\d+), (\d), (\w+)(?:, (\w+))?(?:, \d+)?>", name)
-    tag = f" [n_fft={2 ** (int(cfg.group(1)) + 1)}, 2^{cfg.group(2)} pts/thread, NT={cfg.group(4)}{', ascending radices' if cfg.group(7) == 'true' else ''}]" if cfg else ""
+    plan1 = bool(cfg and re.search(r"FftCfg<[^>]*, 1>", name))
+    tag = f" [n_fft={2 ** (int(cfg.group(1)) + 1)}, 2^{cfg.group(2)} pts/thread, NT={cfg.group(4)}{', ascending radices' if cfg.group(7) == 'true' else ''}{', radices 16-16-4' if plan1 else ''}]" if cfg else ""
     modes = {"0": "complex64 out", "1": "power out", "2": "mel, generic", "3": "mel, two-slope", "4": "mel, run-ordered two-slope"}
     if "istft_kernel" in name:
         return "istft_kernel" + tag
+    if "stft_pc_kernel" in name:  # producer / consumer fused mel kernel: <Cfg, n_fft / hop, PM>
+        return "stft_pc_kernel<mel, producer / consumer waves>" + tag
     if "stft2_kernel" in name:  # second generation: <Cfg, n_fft / hop, MODE, PM>
         m = re.search(r">, (\d+), (\d), (\d)>\(", name)
         return f"stft2_kernel<{modes.get(m.group(2), '?') if m else '?'}>" + tag
@@ -85,7 +88,7 @@ for k, v in write.items():
         calib["write_kb_per_true_byte"] = mean(v["WRITE_SIZE"]) * 1024 / known
 traffic = {"tag": tag, "calibration": calib, "kernels": {}}
 for k in set(list(fetch) + list(write)):
-    if "stft_kernel" not in k and "stft2_kernel" not in k:
+    if "stft_kernel" not in k and "stft2_kernel" not in k and "stft_pc_kernel" not in k:
         continue
     f_raw = mean(fetch[k]["FETCH_SIZE"]) * 1024 if "FETCH_SIZE" in fetch.get(k, {}) else None
     w_raw = mean(write[k]["WRITE_SIZE"]) * 1024 if "WRITE_SIZE" in write.get(k, {}) else None
@@ -159,19 +162,19 @@ for k, v in sorted(traffic["kernels"].items()):
 lines.append("")
 for sub in ("sq1", "sq2"):
     agg = counters(sub)
-    keys = sorted({c for k, v in agg.items() if ("stft_kernel" in k or "stft2_kernel" in k) for c in v})
+    keys = sorted({c for k, v in agg.items() if ("stft_kernel" in k or "stft2_kernel" in k or "stft_pc_kernel" in k) for c in v})
     if not keys:
         continue
     lines += [f"## SQ counters, pass `{sub}` (mean per launch)", "", "| kernel | " + " | ".join(keys) + " |", "|---|" + "---|" * len(keys)]
     for k, v in agg.items():
-        if "stft_kernel" in k or "stft2_kernel" in k:
+        if "stft_kernel" in k or "stft2_kernel" in k or "stft_pc_kernel" in k:
             lines.append(f"| {short(k)} | " + " | ".join(f"{mean(v[c]):.4g}" if c in v else "-" for c in keys) + " |")
     lines.append("")
 # derived per-frame figures of the three BASELINE kernels (330 752 frames per launch): vector instructions, LDS instructions, bank-conflict share
 sq1, sq2 = counters("sq1"), counters("sq2")
 der = []
 for k in sq1:
-    if not ("stft2_kernel" in k or "istft_kernel" in k) or "Li10ELi4Ef" not in k and "10, 4, float" not in k:
+    if not ("stft2_kernel" in k or "istft_kernel" in k or "stft_pc_kernel" in k) or "Li10ELi4Ef" not in k and "10, 4, float" not in k:
         continue
     a, b = sq1[k], sq2.get(k, {})
     g = lambda d, c: mean(d[c]) if c in d else float("nan")

@@ -1172,7 +1172,7 @@ def test_long_clip_shards_by_frames_in_process(L, monkeypatch):
         monkeypatch.setenv("LRA_DEVICES", two)
         served = []
         orig = spectrum._frame_sharded_host_exec
-        monkeypatch.setattr(spectrum, "_frame_sharded_host_exec", lambda sess, shards, run: (served.extend(sh for _, sh in shards), orig(sess, shards, run))[1])
+        monkeypatch.setattr(spectrum, "_frame_sharded_host_exec", lambda sess, shards, run: (served.extend(sh for _, sh in shards if isinstance(sh, dict)), orig(sess, shards, run))[1])
         D2 = L.stft(y, **kw)
         assert len(served) >= 2 and served[0]["frame_lo"] == 0 and served[-1]["frame_hi"] == D1.shape[-1]
         assert np.array_equal(D1, D2)
@@ -1201,6 +1201,50 @@ def test_long_clip_shards_by_frames_in_process(L, monkeypatch):
     bad[0, -5] = np.inf
     with pytest.raises(L.ParameterError):
         L.stft(bad, n_fft=2048, hop_length=512)
+
+
+def test_placed_result_buffers(L):
+    """ctx option placement_retry (include/librosa_amd.h, lra_malloc_placed): a large stft(<device tensor>) result comes from the best of a few candidate
+    allocations, wrapped as an ordinary tensor; the values are those of an ordinary result, the buffer is recycled when the tensor dies (same pointer for the
+    next call of that shape), and the raw API refuses what it cannot judge."""
+    import ctypes
+    import gc
+
+    import torch
+    ctx = L.get_context(0)
+    y = torch.from_numpy(O.config_input(48, n=22050 * 30)).to("cuda:0")   # 48 x 1292 x 1025 complex64 = 508 MB
+    old = ctx.placement_retry
+    ctx.set_option("placement_retry", 0)
+    ref = L.stft(y, n_fft=2048, hop_length=512)   # torch's allocator
+    try:
+        ctx.set_option("placement_retry", 3)
+        D = L.stft(y, n_fft=2048, hop_length=512)
+        assert ctx._placed_log and ctx._placed_log[-1][0] == 48 * 1292 * 1025 * 8 and 1 <= ctx._placed_log[-1][3] <= 3 and ctx._placed_log[-1][2] > 0
+        assert torch.equal(D, ref) and D.shape == ref.shape and D.dtype == ref.dtype
+        n_alloc = len(ctx._placed_log)
+        ptr = D.data_ptr()
+        S = D.abs().sum()  # ordinary tensor arithmetic on the placed buffer
+        assert torch.isfinite(S)
+        del D
+        gc.collect()
+        D2 = L.stft(y, n_fft=2048, hop_length=512)
+        assert D2.data_ptr() == ptr and len(ctx._placed_log) == n_alloc and torch.equal(D2, ref)   # recycled, not re-allocated
+        view = D2[3]            # a view keeps the buffer alive
+        del D2
+        gc.collect()
+        D3 = L.stft(y, n_fft=2048, hop_length=512)
+        assert D3.data_ptr() != ptr and torch.equal(view, ref[3])
+        del D3, view
+        gc.collect()
+        small = L.stft(y[:2], n_fft=2048, hop_length=512)    # below 256 MB: torch's allocator as before
+        assert len(ctx._placed_log) == n_alloc + 1 and torch.equal(small, ref[:2])
+        p = ctypes.c_void_p()
+        assert ctx.lib.lra_malloc_placed(ctx.handle, 1 << 20, 8200, 2, ctypes.byref(p), None, None) != 0   # too few rows to judge
+        assert ctx.lib.lra_free_placed(ctx.handle, ctypes.c_void_p(12345)) != 0
+    finally:
+        ctx.set_option("placement_retry", old)
+        gc.collect()
+        ctx.placed_release_all()
 
 
 # ---- round 6: the two new forms of the n_fft = 2048 forward kernels, switched on by context options ---------------------------------------------

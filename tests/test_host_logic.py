@@ -375,8 +375,10 @@ def test_frame_shard_plan_and_threads(monkeypatch):
     n = 4 * 3600 * 22050  # a four-hour clip
     nf = 1 + n // 512
     plan = spectrum._frame_shard_plan(n, nf, 1, 1 << 40, 2048, 512, True)
-    assert [d for d, _ in plan] == [0, 1, 2, 3] and plan[0][1]["pad_left"] == 1024 and plan[-1][1]["pad_right"] > 0 and plan[1][1]["pad_left"] == 0
-    assert sum(sh["frame_hi"] - sh["frame_lo"] for _, sh in plan) == nf
+    # the frames that touch the centre padding are runs of their own (two frames at either end of the clip): the padded copies stay tiny
+    assert [d for d, _ in plan] == [0, 0, 1, 2, 3, 3] and plan[0][1]["pad_left"] == 1024 and plan[0][1]["frame_hi"] == 2 and plan[-1][1]["pad_right"] > 0
+    assert all(sh["pad_left"] == 0 and sh["pad_right"] == 0 for _, sh in plan[1:-1]) and plan[-1][1]["frame_hi"] - plan[-1][1]["frame_lo"] <= 3
+    assert sum(sh["frame_hi"] - sh["frame_lo"] for _, sh in plan) == nf and all(a[1]["frame_hi"] == b[1]["frame_lo"] for a, b in zip(plan, plan[1:]))
     assert spectrum._frame_shard_plan(n, nf, 8, 1 << 40, 2048, 512, True) is None      # two clips per device: sharded by clips instead
     assert spectrum._frame_shard_plan(22050, 44, 1, 1 << 40, 2048, 512, True) is None  # too few frames per device
     assert spectrum._frame_shard_plan(n, nf, 1, 1 << 20, 2048, 512, True) is None      # too little data
@@ -391,7 +393,7 @@ def test_frame_shard_plan_and_threads(monkeypatch):
         return sh["frame_lo"] > 0 and c.device == 1
 
     assert spectrum._frame_sharded_host_exec(_FakeSess(ctxs[0]), plan, run) is True
-    assert [t for t, _ in who[0]] == [threading.current_thread().name] and [t for t, _ in who[1]] == ["lra-dev1", "lra-dev1"] and ctxs[1].streams == 1
+    assert set(t for t, _ in who[0]) == {threading.current_thread().name} and set(t for t, _ in who[1]) == {"lra-dev1"} and len(who[1]) >= 2 and ctxs[1].streams == 1
     assert [f for _, f in who[1]] == sorted(f for _, f in who[1])
 
     def boom(c, sh):
