@@ -287,6 +287,11 @@ def vqt(y, *, sr=22050, hop_length=512, fmin=None, n_bins=84, intervals="equal",
 
 def cqt(y, *, sr=22050, hop_length=512, fmin=None, n_bins=84, bins_per_octave=12, tuning=0.0, filter_scale=1, norm=1, sparsity=0.01, window="hann", scale=True,
         pad_mode="constant", res_type="soxr_hq", dtype=None, check_finite=True):
-    """Constant-Q transform; drop-in for ``librosa.cqt`` (``librosa/core/constantq.py:42-225``): the ``gamma=0`` case of :func:`vqt`."""
+    """Constant-Q transform; drop-in for ``librosa.cqt`` (``librosa/core/constantq.py:42-225``): the ``gamma=0`` case of :func:`vqt`.
+    Not provided: ``tuning=None`` -- the reference estimates the tuning with its pitch tracker
+    (``core/constantq.py:318-319, 985-986`` -> ``estimate_tuning``), which is outside this library's scope: pass a number (default 0.0).
+    Unpinned: the reference's DEFAULT ``res_type="soxr_hq"`` runs this library's own band-limited design (see ``resample``); ``"polyphase"`` /
+    ``"fft"`` / ``"scipy"`` are pinned against the reference.
+    """
     return vqt(y, sr=sr, hop_length=hop_length, fmin=fmin, n_bins=n_bins, intervals="equal", gamma=0, bins_per_octave=bins_per_octave, tuning=tuning, filter_scale=filter_scale,
                norm=norm, sparsity=sparsity, window=window, scale=scale, pad_mode=pad_mode, res_type=res_type, dtype=dtype, check_finite=check_finite)

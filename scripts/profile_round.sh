@@ -18,6 +18,21 @@ timeout 150 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$O
 timeout 150 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU -d "$OUT/sq1" -o r -- $BENCH --steps 3 --warmup 1 > "$OUT/sq1.log" 2>&1
 timeout 150 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d "$OUT/sq2" -o r -- $BENCH --steps 3 --warmup 1 > "$OUT/sq2.log" 2>&1
 grep -h '"metric"' "$OUT/stats.log" | tail -1 > "$OUT/bench_line.json"
-# keep only the small CSVs (the driver merges <= 64 MiB back)
+# keep only the small CSVs (gpurun merges <= 64 MiB back): the PMC passes' own kernel traces repeat what their counter files carry, and of the
+# counter rows only the path's kernels (+ torch's clamp_, the FETCH_SIZE / WRITE_SIZE calibration) are read by scripts/summarize_profile.py
 find "$OUT" -name '*_agent_info.csv' -delete
+for d in fetch write sq1 sq2; do rm -f "$OUT/$d"/*kernel_trace.csv; done
+python - "$OUT" <<'PY'
+import csv, glob, os, sys
+for f in glob.glob(os.path.join(sys.argv[1], "*", "*counter_collection.csv")):
+    rows = list(csv.DictReader(open(f)))
+    if not rows:
+        continue
+    keep = [r for r in rows if any(t in r["Kernel_Name"] for t in ("stft", "clamp", "stream_probe", "placed_probe"))]
+    with open(f, "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(keep)
+PY
+du -sh "$OUT"
 ls -la "$OUT"/*/ | head -40

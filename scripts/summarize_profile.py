@@ -105,7 +105,7 @@ json.dump(traffic, open(os.path.join(dst, f"{tag}_traffic.json"), "w"), indent=1
 lines = [f"# rocprofv3 summary, round tag `{tag}`", "", "Command: `scripts/profile_round.sh` (bench.py workload: 256 clips x 30 s, n_fft=2048 hop=512 n_mels=128).", ""]
 if bench_line:
     lines += [f"bench line under `rocprofv3 --kernel-trace --stats`: value {bench_line.get('value', 0) / 1e6:.1f} Mframes/s, "
-              f"mel kernel {bench_line.get('roofline', {}).get('launch_ms')} ms/launch, stft kernel {bench_line.get('roofline_stft', {}).get('launch_ms')} ms/launch", ""]
+              f"mel kernel {bench_line.get('roofline', {}).get('launch_ms')} ms/launch, stft kernel {bench_line.get('roofline_stft', {}).get('launch_ms') or bench_line.get('roofline', {}).get('stft_ms')} ms/launch", ""]
 if os.path.exists(stats_csv):
     lines += ["## kernel stats (top 6 by total time)", "", "| kernel | calls | avg (us) | min (us) | max (us) | % |", "|---|---|---|---|---|---|"]
     rows = list(csv.DictReader(open(stats_csv)))[:6]

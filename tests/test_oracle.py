@@ -593,3 +593,15 @@ def test_normalize_matches_the_live_reference():
                             assert a == b == "ParameterError", (norm, axis, fill, thr, a, b)
                         else:
                             assert a.dtype == b.dtype and np.array_equal(a, b, equal_nan=True), (norm, axis, fill, thr)
+
+
+def test_soxr_golden_placeholder():
+    """The reference's DEFAULT resampler (``res_type="soxr_hq"``: ``core/audio.py:1100, 1162``, reached from every default ``cqt`` / ``vqt`` / ``pitch_shift``) cannot be
+    pinned here: the ``soxr`` package is neither installed nor vendored under the reference tree, so the reference itself cannot run its default, and this library serves
+    those names with its own band-limited design (parity UNPINNED).  The moment ``import soxr`` works this test stops xfailing and must be turned into the
+    golden comparison: generate ``tests/golden/resample_soxr.npz`` with ``oracle/make_golden.py`` from the unmodified reference and compare ``librosa_amd.resample`` to it."""
+    try:
+        import soxr  # noqa: F401
+    except Exception:
+        pytest.xfail("soxr is not installed: the soxr_* resamplers stay unpinned (own band-limited design); nothing to compare against")
+    assert os.path.exists(os.path.join(GOLDEN_DIR, "resample_soxr.npz")), "soxr is importable now: generate the golden with oracle/make_golden.py and pin librosa_amd.resample(res_type='soxr_hq') to it"
