@@ -106,9 +106,11 @@ int lra_free(lra_ctx* ctx, void* dptr);
  * frame-major, `row_bytes` per frame).  Where such a buffer lands in HBM moves the store-bound transforms by up to 15 % on some boxes
  * (profiles/r05_pitch.md); this call builds up to `tries` candidates (ctx option "placement_retry" overrides; 1..8) from 64 MiB physical handles
  * mapped in order, times the kernels' write stream on each (~1 ms per candidate), keeps the best and releases the rest.  It stops early where two
- * candidates agree within 1.5 % (no lottery on this box) or one matches the best this context has seen.  probe_ms / tried: optional outputs.
+ * candidates agree within 1.5 % (no lottery on this box) or one matches the best this context has seen.  rows_per_item: rows of one clip (its
+ * frames; 0 = no item structure) -- the probe cuts the buffer into per-clip strips of rows exactly as the kernels do, because WHICH rows are written
+ * at the same time is what the placement levels depend on.  probe_ms / tried: optional outputs.
  * Free with lra_free_placed only.  bytes >= 4096 rows; row_bytes a multiple of 8, >= 512. */
-int lra_malloc_placed(lra_ctx* ctx, size_t bytes, int row_bytes, int tries, void** dptr, float* probe_ms, int* tried);
+int lra_malloc_placed(lra_ctx* ctx, size_t bytes, int row_bytes, int64_t rows_per_item, int tries, void** dptr, float* probe_ms, int* tried);
 int lra_free_placed(lra_ctx* ctx, void* dptr);
 int lra_memset(lra_ctx* ctx, void* dptr, int value, size_t bytes);
 int lra_memcpy_h2d(lra_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes); /* synchronous */

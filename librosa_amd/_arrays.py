@@ -111,7 +111,9 @@ class Session:
     def output(self, shape, dtype, rows=False):
         """Allocate a device result; returns (ptr, handle) where handle is finalised by ``result``.
 
-        ``rows=True``: a large frame-major spectrum ``(batch, n_frames, row)``.  With the context's ``placement_retry`` option on, such a result of at
+        ``rows=True``: a large frame-major spectrum ``(batch, n_frames, row)``; ``rows="flat"``: any other large result the store-bound kernels write (the inverse
+        transform's signals: its rate follows where its OUTPUT lands, 0.67-0.71 -> 0.63-0.65 ms for 256 x 30 s, ``profiles/r06_raw/o_istft_placement.txt``), judged as
+        8 KiB rows.  With the context's ``placement_retry`` option on, such a result of at
         least 256 MB comes from ``lra_malloc_placed`` -- the best of a few candidate allocations under the kernels' own write stream, because where this
         buffer lands moves the store-bound transforms by up to 15 % on some boxes (``profiles/r05_pitch.md``) -- wrapped as a tensor that hands the
         buffer back to the context when it dies, so a loop of calls allocates once."""
@@ -119,9 +121,9 @@ class Session:
         if self.is_torch:
             nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
             t = None
-            if rows and self.ctx.placement_retry > 0 and nbytes >= self.ctx.PLACED_MIN_BYTES and len(shape) == 3 and int(shape[0]) * int(shape[1]) >= 4096:
+            if rows and self.ctx.placement_retry > 0 and nbytes >= self.ctx.PLACED_MIN_BYTES and (rows == "flat" or (len(shape) == 3 and int(shape[0]) * int(shape[1]) >= 4096)):
                 try:
-                    t = _placed_tensor(self.ctx, tuple(int(s) for s in shape), dtype, self.device)
+                    t = _placed_tensor(self.ctx, tuple(int(s) for s in shape), dtype, self.device, flat=rows == "flat")
                 except _native.NativeError:  # (no room for a candidate next to torch's cached blocks, or no virtual-memory API: an ordinary allocation serves)
                     t = None
             if t is None:
@@ -169,24 +171,28 @@ class _PlacedHolder:
     """Owner of one lra_malloc_placed buffer behind a torch tensor (``__cuda_array_interface__``): torch keeps a reference to this object for as long
     as any view of the tensor lives; after that the buffer goes back to its context (recycled for the next result of the same shape)."""
 
-    def __init__(self, ctx, nbytes, row_bytes):
-        self.ctx, self.nbytes, self.row_bytes = ctx, int(nbytes), int(row_bytes)
-        self.ptr = ctx.placed_take(self.nbytes, self.row_bytes)
+    def __init__(self, ctx, nbytes, row_bytes, rows_per_item=0):
+        self.ctx, self.nbytes, self.row_bytes, self.rows_per_item = ctx, int(nbytes), int(row_bytes), int(rows_per_item)
+        self.ptr = ctx.placed_take(self.nbytes, self.row_bytes, self.rows_per_item)
         self.__cuda_array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (int(self.ptr), False), "version": 3, "strides": None}
 
     def __del__(self):
         try:
-            self.ctx.placed_give(self.nbytes, self.row_bytes, self.ptr)
+            self.ctx.placed_give(self.nbytes, self.row_bytes, self.ptr, self.rows_per_item)
         except Exception:  # pragma: no cover - interpreter shutdown
             pass
 
 
-def _placed_tensor(ctx, shape, dtype, device):
+def _placed_tensor(ctx, shape, dtype, device, flat=False):
+    """A tensor of ``shape`` over a buffer from ``lra_malloc_placed``; ``flat``: no row structure of its own -- the buffer is sized and judged as rows of 8 KiB."""
     torch = _torch()
     nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
-    holder = _PlacedHolder(ctx, nbytes, shape[-1] * np.dtype(dtype).itemsize)
-    flat = torch.as_tensor(holder, device=device)
-    return flat.view(torch_dtype(dtype)).reshape(shape)
+    if flat:
+        row = 8192
+        holder = _PlacedHolder(ctx, (nbytes + row - 1) // row * row, row)
+        return torch.as_tensor(holder, device=device)[:nbytes].view(torch_dtype(dtype)).reshape(shape)
+    holder = _PlacedHolder(ctx, nbytes, shape[-1] * np.dtype(dtype).itemsize, shape[-2] if len(shape) >= 2 else 0)  # (rows per clip: the probe cuts strips as the kernels do)
+    return torch.as_tensor(holder, device=device).view(torch_dtype(dtype)).reshape(shape)
 
 
 def swap_last_two(x):

@@ -49,7 +49,7 @@ SIGNATURES = {
     "lra_istft_plan_tuned_variant": (c_int, [c_void_p]),
     "lra_malloc": (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
     "lra_free": (c_int, [c_void_p, c_void_p]),
-    "lra_malloc_placed": (c_int, [c_void_p, c_size_t, c_int, c_int, POINTER(c_void_p), POINTER(c_float), POINTER(c_int)]),
+    "lra_malloc_placed": (c_int, [c_void_p, c_size_t, c_int, c_int64, c_int, POINTER(c_void_p), POINTER(c_float), POINTER(c_int)]),
     "lra_free_placed": (c_int, [c_void_p, c_void_p]),
     "lra_memset": (c_int, [c_void_p, c_void_p, c_int, c_size_t]),
     "lra_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t]),
@@ -289,24 +289,24 @@ class Context:
     PLACED_MIN_BYTES = 256 << 20
     PLACED_KEEP_PER_SHAPE = 2
 
-    def placed_take(self, nbytes, row_bytes):
-        """Device pointer of a buffer of ``nbytes`` (rows of ``row_bytes``): a recycled one of that shape if there is one, else the best of
-        ``placement_retry`` fresh candidates."""
-        key = (int(nbytes), int(row_bytes))
+    def placed_take(self, nbytes, row_bytes, rows_per_item=0):
+        """Device pointer of a buffer of ``nbytes`` (rows of ``row_bytes``, ``rows_per_item`` of them per clip): a recycled one of that shape if there is
+        one, else the best of ``placement_retry`` fresh candidates."""
+        key = (int(nbytes), int(row_bytes), int(rows_per_item))
         with self._lock:
             free = self._placed_free.get(key)
             if free:
                 return free.pop()
         p, ms, tried = c_void_p(), c_float(0), c_int(0)
-        _check(self.lib.lra_malloc_placed(self.handle, key[0], key[1], int(self.placement_retry), byref(p), byref(ms), byref(tried)))
+        _check(self.lib.lra_malloc_placed(self.handle, key[0], key[1], key[2], int(self.placement_retry), byref(p), byref(ms), byref(tried)))
         with self._lock:
             self._placed_log.append((key[0], key[1], float(ms.value), int(tried.value)))
             del self._placed_log[:-64]
         return p.value
 
-    def placed_give(self, nbytes, row_bytes, ptr):
+    def placed_give(self, nbytes, row_bytes, ptr, rows_per_item=0):
         """A placed buffer whose tensor is gone: kept for the next result of that shape, or released when enough are waiting."""
-        key = (int(nbytes), int(row_bytes))
+        key = (int(nbytes), int(row_bytes), int(rows_per_item))
         with self._lock:
             free = self._placed_free.setdefault(key, [])
             if len(free) < self.PLACED_KEEP_PER_SHAPE:

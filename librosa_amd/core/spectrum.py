@@ -721,7 +721,7 @@ def istft(stft_matrix, *, hop_length=None, win_length=None, n_fft=None, window="
                 d_ptr = sess.scratch(batch * n_total * n_bins * cplx.itemsize)
                 _transpose_batched(ctx, src_ptr, d_ptr, batch, n_bins, n_total, cplx.itemsize)
         norm_ptr = _device_norm(sess, wss, wss_key, real)
-        y_ptr, handle = sess.output((batch, int(expected)), real)
+        y_ptr, handle = sess.output((batch, int(expected)), real, rows="flat")
         ctx.istft_exec_norm(plan, d_ptr, batch, d_batch_stride, d_frame_stride, n_used, norm_ptr, y_ptr, int(expected), int(expected))
         y = sess.result(handle)
     finally:

@@ -1888,17 +1888,21 @@ int lra_free(lra_ctx* ctx, void* dptr) {
 // pages would come straight back), time the write stream on each, keep the best, release the others.  Early exits keep boxes without the lottery cheap: two
 // candidates within 1.5 % of each other, or a candidate within 1.5 % of the best rate this context has ever seen, end the search.
 namespace {
-__global__ __launch_bounds__(64) void placed_probe_kernel(char* __restrict__ out, long long rows, int row_bytes, int strip, int xcd_chunk) {
+// (the kernels' geometry: an item -- a clip's frames -- is cut into strips of `strip` consecutive rows, the last one shorter, one wave per strip, workgroup b -> strip
+//  (b mod 8) chunk + b / 8 as xcd_block does; which strips are written at the same time is what the placement levels are about, so the probe cuts the same way)
+__global__ __launch_bounds__(64) void placed_probe_kernel(char* __restrict__ out, long long rows, int row_bytes, long long rows_per_item, int strip, int strips_per_item, int xcd_chunk) {
     typedef float f2p __attribute__((ext_vector_type(2)));
     extern __shared__ char placed_probe_pad[];  // (sized by the launch so that twelve waves share a CU, the forward kernel's residency)
     const int lane = threadIdx.x;
     long long b = blockIdx.x;
     if (xcd_chunk > 0) b = (b % 8) * (long long)xcd_chunk + b / 8;
-    const long long first = b * strip;
-    if (first >= rows) return;
+    const long long item = b / strips_per_item, part = b % strips_per_item;
+    const long long first = item * rows_per_item + part * strip;
+    if (first >= rows || part * strip >= rows_per_item) return;
+    const long long last = (item + 1) * rows_per_item < rows ? (item + 1) * rows_per_item : rows;
     const int pieces = row_bytes / 512;  // wave-wide instructions of 8 bytes per lane
     f2p v = {(float)lane, (float)b};
-    for (int it = 0; it < strip && first + it < rows; ++it) {
+    for (int it = 0; it < strip && first + it < last; ++it) {
         f2p* rp = reinterpret_cast<f2p*>(out + (first + it) * (long long)row_bytes);
         for (int i = 0; i < pieces; ++i) rp[i * 64 + lane] = v;
         const int rest = (row_bytes - pieces * 512) / 8;
@@ -1966,10 +1970,15 @@ void placed_release(void* ptr, lra_ctx::PlacedAlloc& pa) {
     (void)hipMemAddressFree(ptr, pa.padded);
 }
 
-int placed_probe_ms(lra_ctx* ctx, void* ptr, size_t bytes, int row_bytes, float* ms) {
+int placed_probe_ms(lra_ctx* ctx, void* ptr, size_t bytes, int row_bytes, long long rows_per_item, float* ms) {
     const long long rows = (long long)(bytes / (size_t)row_bytes);
-    const int strip = 162;
-    const long long strips = (rows + strip - 1) / strip, grid = (strips + 7) / 8 * 8;
+    if (rows_per_item <= 0 || rows_per_item > rows) rows_per_item = rows;
+    // strips as StftLaunch::launch cuts them: equal shares of at most 176 rows per strip, a whole number of strips per item
+    const int target = 162;
+    const int spi = (int)((rows_per_item + target - 1) / target);
+    const int strip = (int)((rows_per_item + spi - 1) / spi);
+    const long long items = (rows + rows_per_item - 1) / rows_per_item;
+    const long long strips = items * spi, grid = (strips + 7) / 8 * 8;
     const int lds = (160 * 1024 / 12) & ~255;
     hipEvent_t e0, e1;
     LRA_HIP(hipEventCreate(&e0));
@@ -1977,7 +1986,7 @@ int placed_probe_ms(lra_ctx* ctx, void* ptr, size_t bytes, int row_bytes, float*
     float best = 0.f;
     for (int rep = 0; rep < 3; ++rep) {  // (the first repeat doubles as the warm-up: pages touched, clocks up)
         (void)hipEventRecord(e0, ctx->stream);
-        for (int r = 0; r < 4; ++r) hipLaunchKernelGGL(placed_probe_kernel, dim3((unsigned)grid), dim3(64), lds, ctx->stream, (char*)ptr, rows, row_bytes, strip, (int)(grid / 8));
+        for (int r = 0; r < 4; ++r) hipLaunchKernelGGL(placed_probe_kernel, dim3((unsigned)grid), dim3(64), lds, ctx->stream, (char*)ptr, rows, row_bytes, rows_per_item, strip, spi, (int)(grid / 8));
         (void)hipEventRecord(e1, ctx->stream);
         if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) {
             (void)hipEventDestroy(e0);
@@ -1995,7 +2004,7 @@ int placed_probe_ms(lra_ctx* ctx, void* ptr, size_t bytes, int row_bytes, float*
 }
 }  // namespace
 
-int lra_malloc_placed(lra_ctx* ctx, size_t bytes, int row_bytes, int tries, void** dptr, float* probe_ms, int* tried) {
+int lra_malloc_placed(lra_ctx* ctx, size_t bytes, int row_bytes, int64_t rows_per_item, int tries, void** dptr, float* probe_ms, int* tried) {
     LRA_BIND(ctx);
     if (!dptr) return fail(LRA_EINVAL, "null dptr");
     *dptr = nullptr;
@@ -2008,12 +2017,13 @@ int lra_malloc_placed(lra_ctx* ctx, size_t bytes, int row_bytes, int tries, void
     int rc = LRA_OK, best = -1;
     for (int i = 0; i < tries; ++i) {
         Cand c{nullptr, {}, 0.f};
-        rc = placed_create(ctx->device, bytes, (size_t)64 << 20, &c.p, &c.pa);
+        static const size_t chunk_mb = []() { const char* e = std::getenv("LRA_PLACED_CHUNK_MB"); const long v = e ? std::atol(e) : 0; return (size_t)(v >= 2 && v <= 4096 ? v : 64); }();  // (development knob)
+        rc = placed_create(ctx->device, bytes, chunk_mb << 20, &c.p, &c.pa);
         if (rc != LRA_OK) {
             if (!cands.empty()) { rc = LRA_OK; (void)hipGetLastError(); }  // (out of memory for one more candidate: keep the best so far)
             break;
         }
-        rc = placed_probe_ms(ctx, c.p, bytes, row_bytes, &c.ms);
+        rc = placed_probe_ms(ctx, c.p, bytes, row_bytes, (long long)rows_per_item, &c.ms);
         cands.push_back(c);
         if (rc != LRA_OK) break;
         if (best < 0 || c.ms < cands[best].ms) best = (int)cands.size() - 1;

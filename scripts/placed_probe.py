@@ -22,7 +22,7 @@ def timeit(fn, steps=10):
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_ms(e1) / steps)
     return best
-for nf in (512, 2048, 8192):
+for nf in [int(v) for v in os.environ.get("PROBE_NFFT", "512,2048,8192").split(",")]:
     w = np.asarray(filters.get_window("hann", nf, fftbins=True), dtype=np.float32)
     pl = ctx.stft_plan(nf, hop, w, True, "constant", np.float32)
     T = ctx.stft_num_frames(pl, n)
@@ -30,7 +30,7 @@ for nf in (512, 2048, 8192):
     for kind in ("torch.empty", "placed"):
         res = []
         keep = []
-        for a in range(3):
+        for a in range(int(os.environ.get("PROBE_ALLOCS", "3"))):
             if kind == "placed":
                 ctx.set_option("placement_retry", 4)
                 t0 = time.perf_counter(); D = _arrays._placed_tensor(ctx, shape, np.dtype(np.complex64), dev); dt = (time.perf_counter() - t0) * 1e3

@@ -1238,8 +1238,21 @@ def test_placed_result_buffers(L):
         gc.collect()
         small = L.stft(y[:2], n_fft=2048, hop_length=512)    # below 256 MB: torch's allocator as before
         assert len(ctx._placed_log) == n_alloc + 1 and torch.equal(small, ref[:2])
+        # the inverse transform's output is placed too (its rate follows where its OUTPUT lands): a result without a row structure, judged as 8 KiB rows
+        y2 = torch.cat([y, y, y[:8]])                                  # 104 clips: 275 MB of samples
+        D104 = L.stft(y2, n_fft=2048, hop_length=512)
+        n_alloc = len(ctx._placed_log)
+        yh = L.istft(D104, hop_length=512, length=y2.shape[-1])
+        assert len(ctx._placed_log) == n_alloc + 1 and ctx._placed_log[-1][1] == 8192 and yh.shape == y2.shape and yh.is_contiguous()
+        err = ((y2 - yh).double() ** 2).sum(-1)
+        assert float((10 * torch.log10((y2.double() ** 2).sum(-1) / err)).min()) >= 60.0
+        ctx.set_option("placement_retry", 0)
+        assert torch.equal(yh, L.istft(D104, hop_length=512, length=y2.shape[-1]))
+        ctx.set_option("placement_retry", 3)
+        del D104, yh, y2
+        gc.collect()
         p = ctypes.c_void_p()
-        assert ctx.lib.lra_malloc_placed(ctx.handle, 1 << 20, 8200, 2, ctypes.byref(p), None, None) != 0   # too few rows to judge
+        assert ctx.lib.lra_malloc_placed(ctx.handle, 1 << 20, 8200, 0, 2, ctypes.byref(p), None, None) != 0   # too few rows to judge
         assert ctx.lib.lra_free_placed(ctx.handle, ctypes.c_void_p(12345)) != 0
     finally:
         ctx.set_option("placement_retry", old)
