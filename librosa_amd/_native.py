@@ -288,6 +288,7 @@ class Context:
     # -- placement-aware result buffers (include/librosa_amd.h, lra_malloc_placed) -----------------
     PLACED_MIN_BYTES = 256 << 20
     PLACED_KEEP_PER_SHAPE = 2
+    PLACED_KEEP_BYTES = 12 << 30   # all recycled buffers together (variable-length inputs make a new shape per call: the oldest shapes go first)
 
     def placed_take(self, nbytes, row_bytes, rows_per_item=0):
         """Device pointer of a buffer of ``nbytes`` (rows of ``row_bytes``, ``rows_per_item`` of them per clip): a recycled one of that shape if there is
@@ -307,15 +308,32 @@ class Context:
     def placed_give(self, nbytes, row_bytes, ptr, rows_per_item=0):
         """A placed buffer whose tensor is gone: kept for the next result of that shape, or released when enough are waiting."""
         key = (int(nbytes), int(row_bytes), int(rows_per_item))
+        drop = []
         with self._lock:
-            free = self._placed_free.setdefault(key, [])
-            if len(free) < self.PLACED_KEEP_PER_SHAPE:
+            free = self._placed_free.pop(key, [])   # (re-inserted below: dict order = least recently returned shape first)
+            if len(free) < self.PLACED_KEEP_PER_SHAPE and key[0] <= self.PLACED_KEEP_BYTES:
                 free.append(ptr)
-                return
-        try:
-            self.lib.lra_free_placed(self.handle, c_void_p(ptr))
-        except Exception:  # pragma: no cover - interpreter shutdown
-            pass
+            else:
+                drop.append(ptr)
+            if free:
+                self._placed_free[key] = free
+            held = sum(k[0] * len(v) for k, v in self._placed_free.items())
+            for k in list(self._placed_free):
+                if held <= self.PLACED_KEEP_BYTES:
+                    break
+                if k == key and len(self._placed_free) > 1:
+                    continue
+                v = self._placed_free[k]
+                while v and held > self.PLACED_KEEP_BYTES:
+                    drop.append(v.pop(0))
+                    held -= k[0]
+                if not v:
+                    del self._placed_free[k]
+        for p in drop:
+            try:
+                self.lib.lra_free_placed(self.handle, c_void_p(p))
+            except Exception:  # pragma: no cover - interpreter shutdown
+                pass
 
     def placed_release_all(self):
         with self._lock:

@@ -601,3 +601,33 @@ def test_native_gather_unequal_shards_tables():
             g.all_gather(torch.zeros((3, 4, 5)), n_items=7)
     finally:
         torch.cuda.current_stream = orig
+
+
+def test_placed_buffer_pool_is_bounded():
+    """Context.placed_give (the recycling side of lra_malloc_placed results): at most two waiting buffers per shape and PLACED_KEEP_BYTES in all -- a stream of
+    variable-length inputs (a new result shape per call) releases the oldest shapes instead of pinning HBM."""
+    import threading
+
+    from librosa_amd import _native
+
+    class FakeLib:
+        def __init__(self):
+            self.freed = []
+
+        def lra_free_placed(self, h, p):
+            self.freed.append(p.value)
+            return 0
+
+    c = _native.Context.__new__(_native.Context)
+    c._lock, c._placed_free, c.lib, c.handle = threading.RLock(), {}, FakeLib(), None
+    GB = 1 << 30
+    for ptr in (1, 2, 3):
+        c.placed_give(5 * GB, 8200, ptr, 1292)
+    assert c._placed_free == {(5 * GB, 8200, 1292): [1, 2]} and c.lib.freed == [3]
+    c.placed_give(4 * GB, 8192, 4)                      # 14 GB waiting > 12: the oldest shape gives one up
+    assert c._placed_free == {(5 * GB, 8200, 1292): [2], (4 * GB, 8192, 0): [4]} and c.lib.freed == [3, 1]
+    c.placed_give(20 * GB, 8192, 5)                     # larger than the whole budget: released at once
+    assert c.lib.freed == [3, 1, 5] and (20 * GB, 8192, 0) not in c._placed_free
+    for i in range(40):                                 # forty different shapes of 1 GB each: never more than the budget waiting
+        c.placed_give(GB + i * 8192, 8192, 100 + i)
+        assert sum(k[0] * len(v) for k, v in c._placed_free.items()) <= c.PLACED_KEEP_BYTES
