@@ -26,6 +26,9 @@
 #include <vector>
 
 #include "../../include/librosa_amd.h"
+#ifndef LRA_ISTFT16_DEFAULT
+#define LRA_ISTFT16_DEFAULT 0
+#endif
 #ifndef LRA_V3_DEFAULT
 #define LRA_V3_DEFAULT 1  // measured on two boxes, same buffer, alternating (profiles/r06_raw/c_*, d_*): complex STFT -1.3 % ... -2.0 %, |X|^2 +1 % (hence complex only)
 #endif
@@ -87,12 +90,14 @@ struct lra_ctx {
     int opt_generic_mel = 0;         // force the generic banded mel path (tests)
     int opt_lds_pad = 0;             // extra dynamic LDS per workgroup (occupancy experiments)
     int opt_v2 = 1;                  // second-generation forward kernel where it applies (lra_kernels2.h)
+    int opt_istft16 = LRA_ISTFT16_DEFAULT;  // inverse, n_fft = 2048 f32, hop = n_fft / {2, 4, 8, 16}: radices 4, 16, 16 with 16-byte spectrum loads (variant 7) instead of 8, 8, 16
     int opt_placement_retry = 0;     // lra_malloc_placed: candidate allocations to time before keeping the best (0 = its `tries` argument decides)
     struct PlacedAlloc {             // one lra_malloc_placed result: a reserved virtual range backed by physical handles created and mapped in order
         size_t padded = 0;
         std::vector<hipMemGenericAllocationHandle_t> handles;
     };
     std::map<void*, PlacedAlloc> placed;
+    std::mutex placed_mu;            // lra_free_placed may arrive from a finaliser thread while another call allocates
     double placed_best_gbps = 0.0;   // best write-stream rate any candidate of this context has shown (the early-exit yardstick)
     int opt_v3 = LRA_V3_DEFAULT;     // n_fft = 2048 f32: the radix 16-16-4 form with 16-byte row pieces (variant 6, lra_kernels2.h third form); 1: complex epilogue, 2: |X|^p too
     int opt_mel_pc = LRA_MEL_PC_DEFAULT;  // fused mel, n_fft = 2048 f32: the producer / consumer kernel (lra_kernels_pc.h) instead of stft2_kernel<OUT_MELR>
@@ -646,9 +651,12 @@ template <class T> struct IstftLaunch {
     hipStream_t stream = nullptr;
     hipError_t err = hipSuccess;
     template <class Cfg> void operator()() {
-        if constexpr (Cfg::PLAN == 1) {  // forward-only configuration (radices 16, 16, 4)
+        if constexpr (Cfg::PLAN == 1 && !Cfg::REV) {  // forward-only configuration (radices 16, 16, 4)
             err = hipErrorInvalidValue;
             return;
+        } else if constexpr (Cfg::PLAN == 1) {  // radices 4, 16, 16: the row-aligned overlap-add forms only (instances: HC = 8, 4, 2, 1)
+            if (istft_rows_hc<Cfg>(a.hop) == 0) { err = hipErrorInvalidValue; return; }
+            run<Cfg>();
         } else {
             run<Cfg>();
         }
@@ -1319,7 +1327,7 @@ int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_s
         bool fused_first_pass = false;
         if constexpr (sizeof(T) == 4)
             fused_first_pass = ctx->opt_v2 && ctx->opt_variant < 0 && p->logm == 10 && istft_rows_hc<typename CfgSel<float, 10, 5>::type>(p->hop) > 0;
-        if (fused_first_pass) variant = 5;
+        if (fused_first_pass) variant = ctx->opt_istft16 ? 7 : 5;  // 7: the same with 16-byte spectrum loads (radices 4, 16, 16)
         bool too_big = false;
         auto launch = [&](int v) -> int {
             IstftLaunch<T> Lv = L;
@@ -1829,6 +1837,7 @@ int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value) {
     else if (!std::strcmp(key, "xcd_remap")) ctx->opt_xcd_remap = value != 0;
     else if (!std::strcmp(key, "v2")) ctx->opt_v2 = value != 0;
     else if (!std::strcmp(key, "mel_pc")) ctx->opt_mel_pc = (value == 1 || value == 2) ? value : 0;  // 1: on the radix 16-8-8 core, 2: on the radix 16-16-4 core
+    else if (!std::strcmp(key, "istft16")) ctx->opt_istft16 = value != 0;
     else if (!std::strcmp(key, "placement_retry")) ctx->opt_placement_retry = value < 0 ? 0 : (value > 8 ? 8 : value);
     else if (!std::strcmp(key, "v3")) ctx->opt_v3 = (value == 1 || value == 2) ? value : 0;
     else if (!std::strcmp(key, "cqt_merge")) ctx->opt_cqt_merge = value != 0;
@@ -2042,7 +2051,10 @@ int lra_malloc_placed(lra_ctx* ctx, size_t bytes, int row_bytes, int64_t rows_pe
     for (int i = 0; i < (int)cands.size(); ++i)
         if (i != best) placed_release(cands[i].p, cands[i].pa);
     ctx->placed_best_gbps = std::max(ctx->placed_best_gbps, (double)bytes / (cands[best].ms * 1e-3) / 1e9);
-    ctx->placed[cands[best].p] = cands[best].pa;
+    {
+        std::lock_guard<std::mutex> lk(ctx->placed_mu);
+        ctx->placed[cands[best].p] = cands[best].pa;
+    }
     *dptr = cands[best].p;
     if (probe_ms) *probe_ms = cands[best].ms;
     if (tried) *tried = (int)cands.size();
@@ -2052,11 +2064,16 @@ int lra_malloc_placed(lra_ctx* ctx, size_t bytes, int row_bytes, int64_t rows_pe
 int lra_free_placed(lra_ctx* ctx, void* dptr) {
     LRA_BIND(ctx);
     if (!dptr) return LRA_OK;
-    auto it = ctx->placed.find(dptr);
-    if (it == ctx->placed.end()) return fail(LRA_EINVAL, "lra_free_placed: not a pointer from lra_malloc_placed of this context");
+    lra_ctx::PlacedAlloc pa;
+    {
+        std::lock_guard<std::mutex> lk(ctx->placed_mu);
+        auto it = ctx->placed.find(dptr);
+        if (it == ctx->placed.end()) return fail(LRA_EINVAL, "lra_free_placed: not a pointer from lra_malloc_placed of this context");
+        pa = it->second;
+        ctx->placed.erase(it);
+    }
     LRA_HIP(hipDeviceSynchronize());  // (unmapping under running work faults; these are large, long-lived buffers)
-    placed_release(dptr, it->second);
-    ctx->placed.erase(it);
+    placed_release(dptr, pa);
     return LRA_OK;
 }
 

@@ -10,7 +10,7 @@ namespace lra {
 constexpr int kMinLogM = 4;     // n_fft = 32
 constexpr int kMaxLogM = 13;    // n_fft = 16384 (M = 8192 complex: 68 KiB of LDS per frame in f32)
 constexpr int kMaxLogM64 = 12;  // f64: n_fft <= 8192
-constexpr int kNumVariants = 7; // tuning variants exist for f32 n_fft = 2048 only
+constexpr int kNumVariants = 8; // tuning variants exist for f32 n_fft = 2048 only
 
 // Compile-time configuration per (dtype, log2 M, variant).  Variant 0 is the default:
 //   f32: 16 complex points per thread, 256-VGPR budget (2 waves/SIMD), window/twiddle values kept
@@ -40,6 +40,10 @@ template <> struct CfgSel<float, 10, 5> {
 
 template <> struct CfgSel<float, 10, 6> {
     using type = FftCfg<10, 4, float, 64, 2, true, false, 1>;  // radices 16, 16, 4: adjacent bins per thread (lra_kernels2.h, third form); second-generation forward kernels only
+};
+
+template <> struct CfgSel<float, 10, 7> {
+    using type = FftCfg<10, 4, float, 64, 2, true, true, 1>;  // inverse kernel only: radices 4, 16, 16 -- four first-pass butterflies per thread, 16-byte spectrum loads (round 6)
 };
 
 // true when n_fft is a power of two handled by the fused LDS kernels
@@ -88,6 +92,7 @@ template <class T, class F> inline bool dispatch_logm(int logm, int variant, F&&
                 if (variant == 4) { f.template operator()<typename CfgSel<T, 10, 4>::type>(); return true; }
                 if (variant == 5) { f.template operator()<typename CfgSel<T, 10, 5>::type>(); return true; }
                 if (variant == 6) { f.template operator()<typename CfgSel<T, 10, 6>::type>(); return true; }
+                if (variant == 7) { f.template operator()<typename CfgSel<T, 10, 7>::type>(); return true; }
             }
             f.template operator()<typename CfgSel<T, 10, 0>::type>();
             return true;

@@ -48,6 +48,7 @@ template <int LOGM_, int LOGR_, class T_, int NTMIN_ = 256, int MINW_ = 0, bool 
     static constexpr bool REV = REV_;
     static constexpr int PLAN = PLAN_;
     static constexpr int logr(int p) {
+        if (PLAN_ == 1 && REV_) return p == 0 ? LOGM - (P - 1) * LOGR : LOGR;   // ascending: the remainder first (4, 16, 16 at M = 1024: the inverse kernel's form)
         if (PLAN_ == 1) return (p + 1) * LOGR <= LOGM ? LOGR : LOGM - p * LOGR;
         return LOGM / P + ((REV_ ? p >= P - LOGM % P : p < LOGM % P) ? 1 : 0);
     }

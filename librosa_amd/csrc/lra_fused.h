@@ -97,6 +97,7 @@ LRA_CFG_ALIAS(cfg_f32_10v1, float, 10, 1)
 LRA_CFG_ALIAS(cfg_f32_10v4, float, 10, 4)
 LRA_CFG_ALIAS(cfg_f32_10r, float, 10, 5)
 LRA_CFG_ALIAS(cfg_f32_10g, float, 10, 6)
+LRA_CFG_ALIAS(cfg_f32_10q, float, 10, 7)
 LRA_CFG_ALIAS(cfg_f32_11, float, 11, 0)
 LRA_CFG_ALIAS(cfg_f32_12, float, 12, 0)
 LRA_CFG_ALIAS(cfg_f32_13, float, 13, 0)
@@ -158,7 +159,7 @@ LRA_CFG_ALIAS(cfg_f64_12, double, 12, 0)
 #define LRA_INST3_GROUP_11(P) LRA_PC_HD(P, cfg_f32_10, 4) LRA_PC_HD(P, cfg_f32_10, 8) LRA_PC_HD(P, cfg_f32_10g, 4) LRA_PC_HD(P, cfg_f32_10g, 8)
 #define LRA_INST3_ALL(P) LRA_INST3_GROUP_11(P)
 // the radix 16-16-4 form of the second-generation forward kernels (variant 6)
-#define LRA_INST2_GROUP_12(T, I) LRA_STFT2_CFG(T, cfg_f32_10g)
+#define LRA_INST2_GROUP_12(T, I) LRA_STFT2_CFG(T, cfg_f32_10g) I(lra::cfg_f32_10q, 8) I(lra::cfg_f32_10q, 4) I(lra::cfg_f32_10q, 2) I(lra::cfg_f32_10q, 1)
 #define LRA_INST_NUM_GROUPS 13
 #define LRA_INST_ALL(S, I)                                                                                                   \
     LRA_INST_GROUP_0(S, I) LRA_INST_GROUP_1(S, I) LRA_INST_GROUP_2(S, I) LRA_INST_GROUP_3(S, I) LRA_INST_GROUP_4(S, I)       \

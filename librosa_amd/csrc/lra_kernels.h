@@ -1583,6 +1583,128 @@ template <class Cfg> LRA_HD void istft_unsplit_pass0(int tf, FftRegs<Cfg>& rg, L
     }
 }
 
+// ---- the same with FOUR first-pass butterflies per thread (FftCfg REV + PLAN 1: radices 4, 16, 16 at M = 1024; round 6) --------------------------
+// The inverse of the forward kernels' third form (lra_kernels2.h): thread t takes first-pass butterflies 2t, 2t + 1 and their mirrors 255 - 2t,
+// 256 - 2t (thread 0: 128), whose inputs Z'[b + 256 j] are the un-split of the bin pairs (k, M - k), k = 2t + 256 q (E slots) and 2t + 1 + 256 q
+// (O slots): bins 2t, 2t + 1 and M - 2t - 1, M - 2t are NEIGHBOURS, so the spectrum row is read as 4 + 4 global_load_dwordx4 per thread (1 KiB per wave
+// instruction) instead of 16 x dwordx2 -- the inverse stream gains 3.5 % from 16-byte pieces (profiles/r05_pitch.md 3b).  Thread 0's E slots 2 and 3 hold
+// butterfly 128's pairs (bins 128 / 896 and 384 / 640): those four bins are read by every lane (one address per wave: a broadcast) and selected in.
+// Pass 0 -> pass 1 hand-over: element i at slot i + (i >> 3) (a thread's eight outputs of E and O are contiguous: lanes nine slots apart, conflict-free).
+template <class Cfg> constexpr bool istft_mir4_ok() {
+    return Cfg::REV && Cfg::PLAN == 1 && Cfg::HOIST && sizeof(typename Cfg::real) == 4 && Cfg::R == 16 && Cfg::P == 3 && Cfg::logr(0) == 2 && Cfg::logr(1) == 4 && Cfg::TF == 64 &&
+           affine_tf<Cfg>() && (Cfg::M + (Cfg::M >> 3)) * (int)sizeof(typename Cfg::cplx) <= Cfg::FRAME_BYTES;
+}
+// bin of pair slot q (q < 4: E slots, k = 2 tf + 256 q -- thread 0's slots 2, 3: 128, 384 --; q >= 4: O slots, k = 2 tf + 1 + 256 (q - 4))
+template <class Cfg> LRA_HD int mir4_slot_bin(int tf, int q) {
+    constexpr int s = 4 * Cfg::TF;
+    if (q >= 4) return 2 * tf + 1 + (q - 4) * s;
+    if (tf == 0 && q >= 2) return s / 2 + (q - 2) * s;
+    return 2 * tf + q * s;
+}
+template <class C> LRA_HD void load_pair(const C* __restrict__ p, C& lo, C& hi) {
+#if !defined(LRA_HOSTSIM)
+    if constexpr (sizeof(C) == 8) {
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
+        const f4u v = *reinterpret_cast<const f4u*>(p);
+        lo = __builtin_bit_cast(C, __builtin_shufflevector(v, v, 0, 1));
+        hi = __builtin_bit_cast(C, __builtin_shufflevector(v, v, 2, 3));
+        return;
+    }
+#endif
+    lo = p[0];
+    hi = p[1];
+}
+// xk[q] / xm[q]: q < 4 the E slots, q >= 4 the O slots (general addressing for every lane); nxt[0 .. 3] = X[128], X[896], X[384], X[640] (butterfly 128's bins)
+template <class Cfg> LRA_HD void istft_spec_load_mir4(const IstftArgs<typename Cfg::real>& a, long long clip, int frame, bool valid, int tf, FftRegs<Cfg>& rg) {
+    using T = typename Cfg::real;
+    using C = typename Cfg::cplx;
+    constexpr int M = Cfg::M, s = 4 * Cfg::TF;
+    const C zero = mk<T>((T)0, (T)0);
+    if (!valid) {
+        LRA_UNROLL
+        for (int q = 0; q < 8; ++q) { rg.xk[q] = zero; rg.xm[q] = zero; }
+        LRA_UNROLL
+        for (int q = 0; q < 4; ++q) rg.nxt[q] = zero;
+        return;
+    }
+    const C* __restrict__ X = a.D + clip * a.d_batch_stride + (long long)frame * a.d_frame_stride;
+    const C* __restrict__ pa = X + 2 * tf;
+    const C* __restrict__ pm = X + (M - 1 - 2 * tf);
+    LRA_UNROLL
+    for (int q = 0; q < 4; ++q) {
+        load_pair<C>(pa + q * s, rg.xk[q], rg.xk[4 + q]);   // X[2 tf + q s], X[2 tf + 1 + q s]
+        load_pair<C>(pm - q * s, rg.xm[4 + q], rg.xm[q]);   // X[M - 2 tf - 1 - q s], X[M - 2 tf - q s]
+    }
+    rg.nxt[0] = X[s / 2];
+    rg.nxt[1] = X[M - s / 2];
+    rg.nxt[2] = X[s / 2 + s];
+    rg.nxt[3] = X[M - s / 2 - s];
+}
+// phase: pairs -> conj Z' in first-pass order, the four first-pass butterflies, first LDS write of the frame
+template <class Cfg> LRA_HD void istft_unsplit_pass0_mir4(int tf, FftRegs<Cfg>& rg, Lds fr) {
+    using T = typename Cfg::real;
+    using C = typename Cfg::cplx;
+    const bool l0 = tf == 0;
+    const LaneMask l0m = lane_mask(l0);
+    // thread 0: bin M/2 came in as the E half of ascending piece 2; its E slots 2 and 3 take butterfly 128's pairs
+    const C mid2 = mk<T>((T)2 * rg.xk[2].x, (T)2 * rg.xk[2].y);
+    C xk[8], xm[8];
+    LRA_UNROLL
+    for (int q = 0; q < 8; ++q) { xk[q] = rg.xk[q]; xm[q] = rg.xm[q]; }
+    xk[2] = sel_mask(l0m, l0, rg.nxt[0], xk[2]);
+    xm[2] = sel_mask(l0m, l0, rg.nxt[1], xm[2]);
+    xk[3] = sel_mask(l0m, l0, rg.nxt[2], xk[3]);
+    xm[3] = sel_mask(l0m, l0, rg.nxt[3], xm[3]);
+    C zk[8], zm[8];
+    LRA_UNROLL
+    for (int q = 0; q < 8; ++q) {
+        const C E = add_conj(xk[q], xm[q]);
+        const C O = cmul2_conj(sub_conj(xk[q], xm[q]), rg.twr[q]);
+        zk[q] = conj_add_mi_neg(E, O);  // conj Z'[k]
+        zm[q] = add_mi(E, O);           // conj Z'[M - k]
+    }
+    // thread 0, slot 0: (X[0], X[M]) -> conj Z'[0] (their imaginary parts are ignored, as pocketfft's c2r does)
+    const C z0 = mk<T>(xk[0].x + xm[0].x, -(xk[0].x - xm[0].x));
+    C* E = rg.v;        // butterfly 2 tf:        inputs Z'[2 tf + j s] = zk[j]                     thread 0: Z'[0], Z'[s], Z'[2 s] (= M/2), Z'[3 s]
+    C* O = rg.v + 4;    // butterfly 2 tf + 1:    inputs zk[4 + j]
+    C* Om = rg.v + 8;   // butterfly s - 1 - 2 tf: inputs Z'[M - (2 tf + 1 + (3 - j) s)] = zm[4 + 3 - j]
+    C* Em = rg.v + 12;  // butterfly s - 2 tf:    inputs zm[3 - j]                                   thread 0 (butterfly s/2): Z'[s/2], Z'[s/2 + s], Z'[M - s/2 - s], Z'[M - s/2]
+    E[0] = sel_mask(l0m, l0, z0, zk[0]);
+    E[1] = zk[1];
+    E[2] = sel_mask(l0m, l0, mid2, zk[2]);
+    E[3] = sel_mask(l0m, l0, zm[1], zk[3]);
+    LRA_UNROLL
+    for (int j = 0; j < 4; ++j) { O[j] = zk[4 + j]; Om[j] = zm[7 - j]; }
+    Em[0] = sel_mask(l0m, l0, zk[2], zm[3]);
+    Em[1] = sel_mask(l0m, l0, zk[3], zm[2]);
+    Em[2] = sel_mask(l0m, l0, zm[3], zm[1]);
+    Em[3] = sel_mask(l0m, l0, zm[2], zm[0]);
+    LRA_UNROLL
+    for (int i = 0; i < 4; ++i) Dft<4, T>::run(rg.v + 4 * i);
+    // pass 0 (s = 1): output j of butterfly b is element 4 b + j, at slot i + (i >> 3): E and O fill elements 8 tf .. 8 tf + 7, Om and Em elements
+    // 1020 - 8 tf .. 1027 - 8 tf (thread 0's second half: butterfly 128, elements 512 .. 515)
+    constexpr int sz = (int)sizeof(C), M = Cfg::M;
+    const int bA = 9 * tf * sz;
+    const int bOm = (M - 4 - 8 * tf + ((M - 4 - 8 * tf) >> 3)) * sz;
+    const int em0 = l0 ? M / 2 : M - 8 * tf;
+    const int bEm = (em0 + (em0 >> 3)) * sz;
+    LRA_UNROLL
+    for (int j = 0; j < 4; ++j) {
+        lds_st<C>(fr, bA + j * sz, E[j]);
+        lds_st<C>(fr, bA + (4 + j) * sz, O[j]);
+        lds_st<C>(fr, bOm + j * sz, Om[j]);
+        lds_st<C>(fr, bEm + j * sz, Em[j]);
+    }
+}
+// phase: inputs of the middle pass (radix 16, butterfly tf: elements tf + 64 j) from that layout
+template <class Cfg> LRA_HD void istft_mir4_mid_read(FftRegs<Cfg>& rg, Lds fr, int tf) {
+    using C = typename Cfg::cplx;
+    constexpr int sin = Cfg::M >> Cfg::logr(1);
+    const int base = (tf + (tf >> 3)) * (int)sizeof(C);
+    LRA_UNROLL
+    for (int j = 0; j < 16; ++j) rg.v[j] = lds_ld<C>(fr, base + j * (sin + (sin >> 3)) * (int)sizeof(C));
+}
+
 // ---- phase: last pass butterflies, then windowed time-domain frame -> LDS (natural order) ------
 template <class Cfg> LRA_HD void istft_last_write(const IstftArgs<typename Cfg::real>& a, FftRegs<Cfg>& rg, int tf, Lds fr) {
     using T = typename Cfg::real;
@@ -1897,7 +2019,8 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
     using T = typename Cfg::real;
     constexpr int FPB = Cfg::FPB;
     constexpr bool ROWS = HC > 0;
-    constexpr bool MIR = ROWS && istft_mir_ok<Cfg>();  // Hermitian step in registers, fused into the first pass
+    constexpr bool MIR4 = ROWS && istft_mir4_ok<Cfg>();                // ... with four first-pass butterflies per thread and 16-byte spectrum loads (radices 4, 16, 16)
+    constexpr bool MIR = (ROWS && istft_mir_ok<Cfg>()) || MIR4;      // Hermitian step in registers, fused into the first pass
     constexpr int SB = istft_slot_bytes<Cfg, HC>();
     // uniform step count: drain steps only when one of this workgroup's slots owns a clip's last strip
     bool has_last = false;
@@ -1912,7 +2035,10 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
     LRA_PHASE(Cfg::NT, tid) {
         const int slot = slot_of<Cfg>(tid), tf = lane_of<Cfg>(tid);
         hoist_tables<Cfg>(LRA_R(rg), tf, a.win_scaled, a.tw, a.twr, true);
-        if constexpr (MIR) {
+        if constexpr (MIR4) {
+            LRA_UNROLL
+            for (int q = 0; q < Cfg::R / 2; ++q) LRA_R(rg).twr[q] = a.twr[mir4_slot_bin<Cfg>(tf, q)];
+        } else if constexpr (MIR) {
             LRA_UNROLL
             for (int q = 0; q < Cfg::R / 2; ++q) LRA_R(rg).twr[q] = a.twr[mir_slot_bin<Cfg>(tf, q)];
         }
@@ -1925,7 +2051,8 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
         LRA_R(sl) = istft_slot<Cfg>(a, blk, slot_of<Cfg>(LRA_RAW_TID(tid)));
         const IstftSlot<Cfg> s = LRA_R(sl);
         const int t = s.t0 - a.warm_frames;
-        if constexpr (MIR) istft_spec_load_mir<Cfg>(a, s.clip, t, s.active && t >= 0 && t < s.t1, tf, LRA_R(rg));
+        if constexpr (MIR4) istft_spec_load_mir4<Cfg>(a, s.clip, t, s.active && t >= 0 && t < s.t1, tf, LRA_R(rg));
+        else if constexpr (MIR) istft_spec_load_mir<Cfg>(a, s.clip, t, s.active && t >= 0 && t < s.t1, tf, LRA_R(rg));
         else istft_spec_load<Cfg>(a, s.clip, t, s.active && t >= 0 && t < s.t1, tf, LRA_R(rg));
     } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
     for (int j = 0; j < steps; ++j) {
@@ -1943,7 +2070,8 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
                 for (int q = 0; q < Cfg::R; ++q) { LRA_KEEP(LRA_R(rg).nxt[q].x); LRA_KEEP(LRA_R(rg).nxt[q].y); }
             }
 #endif
-            if constexpr (MIR) istft_unsplit_pass0<Cfg>(tf, LRA_R(rg), lds_sub(lds, slot * SB));
+            if constexpr (MIR4) istft_unsplit_pass0_mir4<Cfg>(tf, LRA_R(rg), lds_sub(lds, slot * SB));
+            else if constexpr (MIR) istft_unsplit_pass0<Cfg>(tf, LRA_R(rg), lds_sub(lds, slot * SB));
             else istft_split_write<Cfg>(a, tf, LRA_R(rg), lds_sub(lds, slot * SB));
 #ifndef LRA_ISTFT_ABLATE  // timing experiments (scripts/ab_run.sh): bit 0 = no spectrum loads in the frame loop, bit 1 = no output stores
 #define LRA_ISTFT_ABLATE 0
@@ -1954,7 +2082,8 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
 #endif
             auto prefetch = [&]() {
                 if (j + 1 < steps && (!(LRA_ISTFT_ABLATE & 1) || ablate_never)) {
-                    if constexpr (MIR) istft_spec_load_mir<Cfg>(a, s.clip, t + 1, s.active && t + 1 >= 0 && t + 1 < s.t1, tf, LRA_R(rg));
+                    if constexpr (MIR4) istft_spec_load_mir4<Cfg>(a, s.clip, t + 1, s.active && t + 1 >= 0 && t + 1 < s.t1, tf, LRA_R(rg));
+                    else if constexpr (MIR) istft_spec_load_mir<Cfg>(a, s.clip, t + 1, s.active && t + 1 >= 0 && t + 1 < s.t1, tf, LRA_R(rg));
                     else istft_spec_load<Cfg>(a, s.clip, t + 1, s.active && t + 1 >= 0 && t + 1 < s.t1, tf, LRA_R(rg));
                 }
             };
@@ -1999,8 +2128,18 @@ template <class Cfg, int HC = 0> LRA_HD void istft_block(const IstftArgs<typenam
                 pass_write<Cfg, 0>(LRA_R(rg).v, lds_sub(lds, (slot_of<Cfg>(tid)) * SB), lane_of<Cfg>(tid));
             } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
         }
-        if (Cfg::P > 2) { LRA_MID_PASS(Cfg, 1, rg, lds, a.tw, SB) }
-        if (Cfg::P > 3) { LRA_MID_PASS(Cfg, 2, rg, lds, a.tw, SB) }
+        if constexpr (MIR4) {  // the middle pass reads the first pass's own layout (istft_unsplit_pass0_mir4)
+            LRA_PHASE(Cfg::NT, tid) {
+                istft_mir4_mid_read<Cfg>(LRA_R(rg), lds_sub(lds, (slot_of<Cfg>(tid)) * SB), lane_of<Cfg>(tid));
+            } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+            LRA_PHASE(Cfg::NT, tid) {
+                pass_dft<Cfg, 1>(LRA_R(rg), lane_of<Cfg>(tid), a.tw);
+                pass_write<Cfg, 1>(LRA_R(rg).v, lds_sub(lds, (slot_of<Cfg>(tid)) * SB), lane_of<Cfg>(tid));
+            } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)
+        } else {
+            if (Cfg::P > 2) { LRA_MID_PASS(Cfg, 1, rg, lds, a.tw, SB) }
+            if (Cfg::P > 3) { LRA_MID_PASS(Cfg, 2, rg, lds, a.tw, SB) }
+        }
         LRA_PHASE(Cfg::NT, tid) {
             pass_read<Cfg, Cfg::P - 1>(LRA_R(rg).v, lds_sub(lds, (slot_of<Cfg>(tid)) * SB), lane_of<Cfg>(tid));
         } LRA_PHASE_END_SYNC(Cfg::WAVE_SYNC)

@@ -1203,6 +1203,30 @@ def test_long_clip_shards_by_frames_in_process(L, monkeypatch):
         L.stft(bad, n_fft=2048, hop_length=512)
 
 
+@pytest.mark.parametrize("hop,center,length", [(512, True, "n"), (512, True, None), (1024, False, None), (256, True, 50000), (128, True, "n")])
+def test_istft_16_byte_loads(L, hop, center, length):
+    """ctx option istft16 (variant 7: the inverse as radices 4, 16, 16 -- four first-pass butterflies per thread, the spectrum row read as 16-byte pieces; csrc/lra_kernels.h
+    istft_unsplit_pass0_mir4): against the oracle like the default form, NaN-prefilled output, and against the default form.  librosa/core/spectrum.py:506-626."""
+    import torch
+    ctx = L.get_context(0)
+    y = np.random.default_rng(hop).standard_normal((3, 70001)).astype(np.float32)
+    D = O.stft(y, n_fft=2048, hop_length=hop, center=center)
+    ln = y.shape[-1] if length == "n" else length
+    ref = O.istft(D, hop_length=hop, n_fft=2048, center=center, length=ln)
+    wss = _wss_for(dict(n_fft=2048, hop_length=hop, center=center), D.shape[-1], ref.shape[-1], ln, ref.dtype)
+    try:
+        ctx.set_option("istft16", 1)
+        yh = L.istft(D, hop_length=hop, n_fft=2048, center=center, length=ln)
+        assert yh.shape == ref.shape and _istft_close(yh, ref, wss)
+        yt = L.istft(torch.from_numpy(D).to("cuda:0"), hop_length=hop, n_fft=2048, center=center, length=ln).cpu().numpy()
+        assert np.array_equal(yt, yh)
+        ctx.set_option("istft16", 0)
+        y0 = L.istft(D, hop_length=hop, n_fft=2048, center=center, length=ln)
+        assert _istft_close(yh, y0, wss)
+    finally:
+        ctx.set_option("istft16", 0)
+
+
 def test_placed_result_buffers(L):
     """ctx option placement_retry (include/librosa_amd.h, lra_malloc_placed): a large stft(<device tensor>) result comes from the best of a few candidate
     allocations, wrapped as an ordinary tensor; the values are those of an ordinary result, the buffer is recycled when the tensor dies (same pointer for the

@@ -305,6 +305,12 @@ def _istft_inputs(y, n_fft, hop, center, length, window="hann", win_length=None)
         (64, 16, 1000, True, "n", np.float32, 1, "hann", None, 0),
         (1024, 256, 12000, True, "n", np.float32, 2, "blackmanharris", None, 0),
         (512, 100, 5000, True, "n", np.float32, 2, "hann", 400, 0),
+        # round 6: radices 4, 16, 16 (variant 7: four first-pass butterflies per thread, the spectrum row read as 16-byte pieces), every row-aligned hop
+        (2048, 512, 9000, True, "n", np.float32, 3, "hann", None, 7),
+        (2048, 512, 30011, True, None, np.float32, 7, "hann", None, 7),
+        (2048, 1024, 12000, False, "n", np.float32, 2, "hann", None, 7),
+        (2048, 256, 9000, True, "n", np.float32, 5, "hamming", None, 7),
+        (2048, 128, 5000, True, "n", np.float32, 4, "hann", 1500, 7),
     ],
 )
 def test_istft_body(n_fft, hop, n, center, length, dtype, strip_groups, window, win_length, variant):
