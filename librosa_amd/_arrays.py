@@ -31,7 +31,7 @@ def _torch():
     if not _NP2TORCH:
         _NP2TORCH.update({np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
                           np.dtype(np.complex64): torch.complex64, np.dtype(np.complex128): torch.complex128,
-                          np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64})   # integers: index tables (CSR bases) and integer-valued inputs
+                          np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64, np.dtype(np.uint8): torch.uint8})   # integers: index tables (CSR bases) and integer-valued inputs
     return torch
 
 
@@ -124,7 +124,7 @@ class Session:
             if rows and self.ctx.placement_retry > 0 and nbytes >= self.ctx.PLACED_MIN_BYTES and (rows == "flat" or (len(shape) == 3 and int(shape[0]) * int(shape[1]) >= 4096)):
                 try:
                     t = _placed_tensor(self.ctx, tuple(int(s) for s in shape), dtype, self.device, flat=rows == "flat")
-                except _native.NativeError:  # (no room for a candidate next to torch's cached blocks, or no virtual-memory API: an ordinary allocation serves)
+                except (_native.NativeError, ParameterError):  # (no room for a candidate next to torch's cached blocks, or no virtual-memory API: an ordinary allocation serves)
                     t = None
             if t is None:
                 t = _torch().empty(tuple(int(s) for s in shape), dtype=torch_dtype(dtype), device=self.device)
@@ -148,6 +148,8 @@ class Session:
 
     def scratch(self, nbytes):
         if self.is_torch:
+            # (scratch and the results of the other rows -- hpss, griffinlim, the vocoder -- stay with torch's allocator: measured, placement moves them by 1 % (decompose.hpss
+            #  1.179 -> 1.170 ms for 48 clips, scripts/placed_probe3.py), not worth a second allocator's churn under variable shapes)
             t = _torch().empty(int(max(nbytes, 16)), dtype=_torch().uint8, device=self.device)
             self._keep.append(t)
             return t.data_ptr()
@@ -187,7 +189,7 @@ def _placed_tensor(ctx, shape, dtype, device, flat=False):
     """A tensor of ``shape`` over a buffer from ``lra_malloc_placed``; ``flat``: no row structure of its own -- the buffer is sized and judged as rows of 8 KiB."""
     torch = _torch()
     nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
-    if flat:
+    if flat or (shape[-1] * np.dtype(dtype).itemsize) % 8 or shape[-1] * np.dtype(dtype).itemsize < 512:   # (|X|^p rows of 1025 floats: no 8-byte row structure)
         row = 8192
         holder = _PlacedHolder(ctx, (nbytes + row - 1) // row * row, row)
         return torch.as_tensor(holder, device=device)[:nbytes].view(torch_dtype(dtype)).reshape(shape)
