@@ -109,7 +109,9 @@ int lra_free(lra_ctx* ctx, void* dptr);
  * candidates agree within 1.5 % (no lottery on this box) or one matches the best this context has seen.  rows_per_item: rows of one clip (its
  * frames; 0 = no item structure) -- the probe cuts the buffer into per-clip strips of rows exactly as the kernels do, because WHICH rows are written
  * at the same time is what the placement levels depend on.  probe_ms / tried: optional outputs.
- * Free with lra_free_placed only.  bytes >= 4096 rows; row_bytes a multiple of 8, >= 512. */
+ * Free with lra_free_placed only.  bytes >= 4096 rows; row_bytes a multiple of 8, >= 512.
+ * Address ranges are never re-used or freed while the context lives (on ROCm 7.0 / gfx950 that leaves other live ranges with stale translations:
+ * scripts/vmm_coherence.hip); a context spends at most 4 TiB of address space this way, then the call fails with LRA_ENOMEM and callers allocate normally. */
 int lra_malloc_placed(lra_ctx* ctx, size_t bytes, int row_bytes, int64_t rows_per_item, int tries, void** dptr, float* probe_ms, int* tried);
 int lra_free_placed(lra_ctx* ctx, void* dptr);
 int lra_memset(lra_ctx* ctx, void* dptr, int value, size_t bytes);

@@ -98,6 +98,13 @@ struct lra_ctx {
     };
     std::map<void*, PlacedAlloc> placed;
     std::mutex placed_mu;            // lra_free_placed may arrive from a finaliser thread while another call allocates
+    // ROCm 7.0 / gfx950, measured (scripts/vmm_coherence.hip, profiles/r06_experiments.md 3): hipMemAddressFree of one reserved range -- or mapping new physical
+    // memory into a range that was mapped before -- leaves OTHER live ranges with stale translations (kernels and hipMemcpy read old data: silent corruption).
+    // Ranges that are reserved once, never re-used and never freed while anything of this context is alive are clean under any amount of churn.  So: every
+    // candidate gets a fresh reservation, a released buffer keeps its (now empty) range until lra_ctx_destroy, and the address space spent that way is budgeted.
+    std::vector<std::pair<void*, size_t>> placed_retired;   // reserved ranges whose physical memory is gone: freed at lra_ctx_destroy
+    size_t placed_va_spent = 0;
+    static constexpr size_t kPlacedVaBudget = (size_t)4 << 40;  // 4 TiB of address space per context, then lra_malloc_placed declines (callers fall back to an ordinary allocation)
     double placed_best_gbps = 0.0;   // best write-stream rate any candidate of this context has shown (the early-exit yardstick)
     int opt_v3 = LRA_V3_DEFAULT;     // n_fft = 2048 f32: the radix 16-16-4 form with 16-byte row pieces (variant 6, lra_kernels2.h third form); 1: complex epilogue, 2: |X|^p too
     int opt_mel_pc = LRA_MEL_PC_DEFAULT;  // fused mel, n_fft = 2048 f32: the producer / consumer kernel (lra_kernels_pc.h) instead of stft2_kernel<OUT_MELR>
@@ -1729,7 +1736,7 @@ int lra_ctx_create(int device, lra_ctx** out) {
 }
 
 namespace {
-void placed_release(void* ptr, lra_ctx::PlacedAlloc& pa);  // (defined with lra_malloc_placed below)
+void placed_release(lra_ctx* ctx, void* ptr, lra_ctx::PlacedAlloc& pa);  // (defined with lra_malloc_placed below)
 }
 
 void lra_ctx_destroy(lra_ctx* ctx) {
@@ -1749,7 +1756,13 @@ void lra_ctx_destroy(lra_ctx* ctx) {
     }
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
     if (!ctx->placed.empty()) (void)hipDeviceSynchronize();
-    for (auto& kv : ctx->placed) placed_release(kv.first, kv.second);
+    {
+        std::map<void*, lra_ctx::PlacedAlloc> live;
+        { std::lock_guard<std::mutex> lk(ctx->placed_mu); live.swap(ctx->placed); }
+        for (auto& kv : live) placed_release(ctx, kv.first, kv.second);
+        for (auto& r : ctx->placed_retired) (void)hipMemAddressFree(r.first, r.second);   // nothing of this context is mapped any more
+        ctx->placed_retired.clear();
+    }
     for (auto& kv : ctx->cqt_tw) {
         if (kv.second.first) (void)hipFree(kv.second.first);
         if (kv.second.second) (void)hipFree(kv.second.second);
@@ -1920,7 +1933,8 @@ __global__ __launch_bounds__(64) void placed_probe_kernel(char* __restrict__ out
     }
 }
 
-int placed_create(int device, size_t bytes, size_t chunk, void** ptr_out, lra_ctx::PlacedAlloc* pa) {
+int placed_create(lra_ctx* ctx, size_t bytes, size_t chunk, void** ptr_out, lra_ctx::PlacedAlloc* pa) {
+    const int device = ctx->device;
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
@@ -1930,6 +1944,11 @@ int placed_create(int device, size_t bytes, size_t chunk, void** ptr_out, lra_ct
     if (gran == 0) gran = 2u << 20;
     chunk = (chunk + gran - 1) / gran * gran;
     const size_t padded = (bytes + chunk - 1) / chunk * chunk;
+    {
+        std::lock_guard<std::mutex> lk(ctx->placed_mu);
+        if (ctx->placed_va_spent + padded > lra_ctx::kPlacedVaBudget) return fail(LRA_ENOMEM, "lra_malloc_placed: this context's address-space budget for placed buffers is spent (ranges are never re-used: see lra_ctx)");
+        ctx->placed_va_spent += padded;
+    }
     void* ptr = nullptr;
     hipError_t e = hipMemAddressReserve(&ptr, padded, 0, nullptr, 0);
     if (e != hipSuccess) return fail(LRA_EHIP, std::string("hipMemAddressReserve: ") + hipGetErrorString(e));
@@ -1940,7 +1959,8 @@ int placed_create(int device, size_t bytes, size_t chunk, void** ptr_out, lra_ct
             (void)hipMemRelease(pa->handles[i]);
         }
         pa->handles.clear();
-        (void)hipMemAddressFree(ptr, padded);
+        std::lock_guard<std::mutex> lk(ctx->placed_mu);
+        ctx->placed_retired.push_back({ptr, padded});  // (never hipMemAddressFree while the context lives)
     };
     for (size_t off = 0; off < padded; off += chunk) {
         hipMemGenericAllocationHandle_t h;
@@ -1968,7 +1988,8 @@ int placed_create(int device, size_t bytes, size_t chunk, void** ptr_out, lra_ct
     return LRA_OK;
 }
 
-void placed_release(void* ptr, lra_ctx::PlacedAlloc& pa) {
+// physical memory back to the device; the (now empty) address range stays reserved and is never used again (see lra_ctx::placed_retired)
+void placed_release(lra_ctx* ctx, void* ptr, lra_ctx::PlacedAlloc& pa) {
     if (!ptr) return;
     const size_t chunk = pa.handles.empty() ? pa.padded : pa.padded / pa.handles.size();
     for (size_t i = 0; i < pa.handles.size(); ++i) {
@@ -1976,7 +1997,8 @@ void placed_release(void* ptr, lra_ctx::PlacedAlloc& pa) {
         (void)hipMemRelease(pa.handles[i]);
     }
     pa.handles.clear();
-    (void)hipMemAddressFree(ptr, pa.padded);
+    std::lock_guard<std::mutex> lk(ctx->placed_mu);
+    ctx->placed_retired.push_back({ptr, pa.padded});
 }
 
 int placed_probe_ms(lra_ctx* ctx, void* ptr, size_t bytes, int row_bytes, long long rows_per_item, float* ms) {
@@ -2027,7 +2049,7 @@ int lra_malloc_placed(lra_ctx* ctx, size_t bytes, int row_bytes, int64_t rows_pe
     for (int i = 0; i < tries; ++i) {
         Cand c{nullptr, {}, 0.f};
         static const size_t chunk_mb = []() { const char* e = std::getenv("LRA_PLACED_CHUNK_MB"); const long v = e ? std::atol(e) : 0; return (size_t)(v >= 2 && v <= 4096 ? v : 64); }();  // (development knob)
-        rc = placed_create(ctx->device, bytes, chunk_mb << 20, &c.p, &c.pa);
+        rc = placed_create(ctx, bytes, chunk_mb << 20, &c.p, &c.pa);
         if (rc != LRA_OK) {
             if (!cands.empty()) { rc = LRA_OK; (void)hipGetLastError(); }  // (out of memory for one more candidate: keep the best so far)
             break;
@@ -2045,11 +2067,11 @@ int lra_malloc_placed(lra_ctx* ctx, size_t bytes, int row_bytes, int64_t rows_pe
         }
     }
     if (rc != LRA_OK || best < 0) {
-        for (Cand& c : cands) placed_release(c.p, c.pa);
+        for (Cand& c : cands) placed_release(ctx, c.p, c.pa);
         return rc != LRA_OK ? rc : fail(LRA_ENOMEM, "lra_malloc_placed: no candidate");
     }
     for (int i = 0; i < (int)cands.size(); ++i)
-        if (i != best) placed_release(cands[i].p, cands[i].pa);
+        if (i != best) placed_release(ctx, cands[i].p, cands[i].pa);
     ctx->placed_best_gbps = std::max(ctx->placed_best_gbps, (double)bytes / (cands[best].ms * 1e-3) / 1e9);
     {
         std::lock_guard<std::mutex> lk(ctx->placed_mu);
@@ -2073,7 +2095,7 @@ int lra_free_placed(lra_ctx* ctx, void* dptr) {
         ctx->placed.erase(it);
     }
     LRA_HIP(hipDeviceSynchronize());  // (unmapping under running work faults; these are large, long-lived buffers)
-    placed_release(dptr, pa);
+    placed_release(ctx, dptr, pa);
     return LRA_OK;
 }
 

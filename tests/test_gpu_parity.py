@@ -1227,6 +1227,50 @@ def test_istft_16_byte_loads(L, hop, center, length):
         ctx.set_option("istft16", 0)
 
 
+def test_placed_buffers_stay_coherent_under_churn(L):
+    """Regression (round 6): with losing candidates' address ranges freed (hipMemAddressFree) or re-used, OTHER live placed buffers were read with stale contents on ROCm 7.0 --
+    the fourth of four live tensors gave back its placement probe's values after fill_, two live stft results differed from the torch.empty result in 10^8 values
+    (scripts/vmm_coherence.hip reproduces it without this library).  lra_malloc_placed now never re-uses or frees a range while the context lives.  Several placed tensors
+    alive at once, released and re-allocated in between, every one must keep exactly what was written to it -- read by kernels AND by a device-to-host copy."""
+    import gc
+
+    import torch
+    from librosa_amd import _arrays
+    ctx = L.get_context(0)
+    old = ctx.placement_retry
+    try:
+        ctx.set_option("placement_retry", 4)
+        shape = (24, 2584, 1025)   # 508 MB each
+        live = []
+        for rnd in range(4):
+            for _ in range(3):
+                t = _arrays._placed_tensor(ctx, shape, np.dtype(np.complex64), "cuda:0")
+                t.fill_(complex(len(live) + 1 + 10 * rnd, 0))
+                live.append((t, len(live) + 1 + 10 * rnd))
+            torch.cuda.synchronize()
+            for t, v in live:
+                assert float(t.real.min()) == v and float(t.real.max()) == v and float(t.imag.abs().max()) == 0.0, (rnd, v)
+                assert complex(t[0, 0, 0].cpu()) == complex(v, 0) and complex(t[-1, -1, -1].cpu()) == complex(v, 0)
+            del live[::2]
+            gc.collect()
+            ctx.placed_release_all()     # their physical memory goes back: the survivors must not notice
+            live = [(t, v) for t, v in live]
+            for t, v in live:
+                t.fill_(complex(v, 0))
+        # the public path: results on placed buffers, several alive at once, against the torch.empty path
+        y = torch.from_numpy(O.config_input(48, n=22050 * 30)).to("cuda:0")
+        ctx.set_option("placement_retry", 0)
+        ref = L.stft(y, n_fft=2048, hop_length=512)
+        ctx.set_option("placement_retry", 4)
+        outs = [L.stft(y, n_fft=2048, hop_length=512) for _ in range(4)]
+        assert all(torch.equal(o, ref) for o in outs)
+    finally:
+        ctx.set_option("placement_retry", old)
+        live = outs = None
+        gc.collect()
+        ctx.placed_release_all()
+
+
 def test_placed_result_buffers(L):
     """ctx option placement_retry (include/librosa_amd.h, lra_malloc_placed): a large stft(<device tensor>) result comes from the best of a few candidate
     allocations, wrapped as an ordinary tensor; the values are those of an ordinary result, the buffer is recycled when the tensor dies (same pointer for the
