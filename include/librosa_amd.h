@@ -104,8 +104,9 @@ int lra_malloc(lra_ctx* ctx, size_t bytes, void** dptr);
 int lra_free(lra_ctx* ctx, void* dptr);
 /* Placement-aware allocation of a LARGE, long-lived result buffer of rows (a spectrum: the Fortran-ordered array of core/spectrum.py:356 seen
  * frame-major, `row_bytes` per frame).  Where such a buffer lands in HBM moves the store-bound transforms by up to 15 % on some boxes
- * (profiles/r05_pitch.md); this call builds up to `tries` candidates (ctx option "placement_retry" overrides; 1..8) from 64 MiB physical handles
- * mapped in order, times the kernels' write stream on each (~1 ms per candidate), keeps the best and releases the rest.  It stops early where two
+ * (profiles/r05_pitch.md); this call builds up to `tries` candidates (ctx option "placement_retry" overrides; 1..8) -- alternately an ordinary hipMalloc
+ * block and a range assembled from 64 MiB physical handles mapped in order: which kind lands better differs from box to box -- times the kernels' write
+ * stream on each (~1 ms per candidate), keeps the best and releases the rest.  It stops early where two
  * candidates agree within 1.5 % (no lottery on this box) or one matches the best this context has seen.  rows_per_item: rows of one clip (its
  * frames; 0 = no item structure) -- the probe cuts the buffer into per-clip strips of rows exactly as the kernels do, because WHICH rows are written
  * at the same time is what the placement levels depend on.  probe_ms / tried: optional outputs.
