@@ -1879,7 +1879,11 @@ int lra_ctx_nonfinite_read(lra_ctx* ctx, int* flag) {
     unsigned int h = 0;
     LRA_HIP(hipMemcpyAsync(&h, ctx->d_flag, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     LRA_HIP(hipStreamSynchronize(ctx->stream));
-    *flag = (int)h;
+    if (h & 2u) {  // a wave of the producer / consumer mel kernel gave up waiting for its partner (lra_kernels_pc.h, pc_wait): the result is not to be trusted
+        (void)hipMemsetAsync(ctx->d_flag, 0, sizeof(unsigned int), ctx->stream);
+        return fail(LRA_EHIP, "fused mel kernel: a producer / consumer hand-over timed out (results invalid); ctx option mel_pc = 0 selects the one-wave kernel");
+    }
+    *flag = (int)(h & 1u);
     return LRA_OK;
 }
 

@@ -679,6 +679,9 @@ template <class Cfg, int HD> LRA_HD void v3_last_read(Regs2<Cfg, HD>& rg, Lds fr
     }
 }
 // two neighbouring elements as one store (global_store_dwordx4 / dwordx2: the pointer need only be element-aligned)
+#ifndef LRA_V3_NT
+#define LRA_V3_NT 0  // non-temporal 16-byte row pieces (experiment)
+#endif
 template <class V> LRA_HD void store_pair(V* p, V lo, V hi) {
 #if !defined(LRA_HOSTSIM)
     if constexpr (sizeof(V) == 8) {
@@ -686,7 +689,11 @@ template <class V> LRA_HD void store_pair(V* p, V lo, V hi) {
         const cx<float> l = __builtin_bit_cast(cx<float>, lo), h = __builtin_bit_cast(cx<float>, hi);
         f4u v;
         v.x = l.x; v.y = l.y; v.z = h.x; v.w = h.y;
+#if LRA_V3_NT
+        __builtin_nontemporal_store(v, reinterpret_cast<f4u*>(p));
+#else
         *reinterpret_cast<f4u*>(p) = v;
+#endif
         return;
     } else if constexpr (sizeof(V) == 4) {
         typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));

@@ -98,7 +98,7 @@ template <class Cfg> struct PcTile {
 #ifdef LRA_HOSTSIM
 LRA_HD int pc_flag_load(Lds l, int off) { return lds_ld<int>(l, off); }
 LRA_HD void pc_flag_store(Lds l, int off, int v) { lds_st<int>(l, off, v); }
-LRA_HD void pc_wait(Lds, int, int) {}
+LRA_HD void pc_wait(Lds, int, int, unsigned int*) {}
 LRA_HD void pc_fence() {}
 #else
 __device__ __forceinline__ void pc_fence() {
@@ -109,11 +109,17 @@ __device__ __forceinline__ void pc_fence() {
 __device__ __forceinline__ int pc_flag_load(Lds l, int off) { return *(const volatile __attribute__((address_space(3))) int*)(l.base + off); }
 __device__ __forceinline__ void pc_flag_store(Lds l, int off, int v) { *(volatile __attribute__((address_space(3))) int*)(l.base + off) = v; }
 // until flag >= want (every lane reads the same word: a broadcast; the value is wave-uniform, so the loop is scalar)
-__device__ __forceinline__ void pc_wait(Lds l, int off, int want) {
+// A wait that gives up (a protocol bug, a partner wave that never came) raises bit 1 of the context's sticky device flag: the host turns that into an error
+// (lra_ctx_nonfinite_read) instead of returning whatever the row buffers held.
+__device__ __forceinline__ void pc_wait(Lds l, int off, int want, unsigned int* sticky) {
     int spins = 0;
     while (true) {
         const int v = LRA_UNIFORM(pc_flag_load(l, off));
-        if (LRA_LIKELY(v >= want) || ++spins > LRA_PC_SPIN_LIMIT) break;
+        if (LRA_LIKELY(v >= want)) break;
+        if (LRA_UNLIKELY(++spins > LRA_PC_SPIN_LIMIT)) {
+            if (sticky && (threadIdx.x & 63) == 0) atomicOr(sticky, 2u);
+            break;
+        }
         __builtin_amdgcn_s_sleep(2);
     }
     pc_fence();
@@ -378,7 +384,7 @@ template <class Cfg, int HD, int PM = POW_TWO> LRA_HD void stft_pc_block(const S
             }
             pc_fence();
             v2_setprio<LRA_PC_PRIO_PS>();
-            if (LRA_UNLIKELY(LRA_UNIFORM(taken) < it)) pc_wait(lds, L::consumed_off(wave), it);  // row it - 1 still unread (it was handed over a whole frame ago)
+            if (LRA_UNLIKELY(LRA_UNIFORM(taken) < it)) pc_wait(lds, L::consumed_off(wave), it, a.nonfinite_flag);  // row it - 1 still unread (it was handed over a whole frame ago)
             {
                 const int tf = phase_tid() % TF;
                 pc_last_power_row<Cfg, HD, PM>(a, clip, frame, tf, rg, pwr);
@@ -400,7 +406,7 @@ template <class Cfg, int HD, int PM = POW_TWO> LRA_HD void stft_pc_block(const S
             {                                                                                                                  \
                 const int frame = f_first + S * iters + it;                                                                   \
                 v2_setprio<LRA_PC_PRIO_CA>();                                                                                  \
-                pc_wait(lds, L::ready_off(S), it + 1);                                                                         \
+                pc_wait(lds, L::ready_off(S), it + 1, a.nonfinite_flag);                                                                        \
                 { const int tf = phase_tid() % TF; pc_runs_read<Cfg>(rg, lds_sub(lds, L::pw_off(S)), tf); }                    \
                 pc_fence();                                                                                                    \
                 if (phase_tid() % TF == 0) pc_flag_store(lds, L::consumed_off(S), it + 1); /* behind the run reads */          \

@@ -601,7 +601,10 @@ def test_soxr_golden_placeholder():
     those names with its own band-limited design (parity UNPINNED).  The moment ``import soxr`` works this test stops xfailing and must be turned into the
     golden comparison: generate ``tests/golden/resample_soxr.npz`` with ``oracle/make_golden.py`` from the unmodified reference and compare ``librosa_amd.resample`` to it."""
     try:
-        import soxr  # noqa: F401
+        import soxr
+        real = hasattr(soxr, "resample")  # oracle/ref_shim.py leaves an EMPTY stand-in module of that name behind when a test imported the reference in this process
     except Exception:
+        real = False
+    if not real:
         pytest.xfail("soxr is not installed: the soxr_* resamplers stay unpinned (own band-limited design); nothing to compare against")
     assert os.path.exists(os.path.join(GOLDEN_DIR, "resample_soxr.npz")), "soxr is importable now: generate the golden with oracle/make_golden.py and pin librosa_amd.resample(res_type='soxr_hq') to it"
