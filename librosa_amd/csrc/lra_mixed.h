@@ -204,7 +204,13 @@ template <class T> struct Dft<8, T> {
 // PITCH: complex slots between consecutive frames of a buffer (M, or M + 1 where the epilogue wants whole spectra of M + 1 bins per frame)
 template <class T, int N, int R, int S, int F, int PITCH = N / 2> __device__ __forceinline__ void pass(const cpx<T>* src, cpx<T>* dst, const cpx<T>* twm, int frames) {
     constexpr int M = N / 2, NB = M / R, TWS = M / (S * R);
-    for (int w = (int)threadIdx.x; w < frames * NB; w += NT) {
+    // (trip count known at compile time, the partial group's bound as a predicate: unrolled, so that the LDS reads of one work item are in flight
+    // while the previous one is in its butterfly -- round 6; the runtime-bounded loop ran its items strictly one after the other)
+    constexpr int IT = (F * NB + NT - 1) / NT;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int w = (int)threadIdx.x + it * NT;
+        if (w >= frames * NB) break;
         const int f = w / NB, b = w - f * NB, k = b % S;
         const cpx<T>* s = src + f * PITCH + b;
         cpx<T> v[R];
@@ -253,21 +259,48 @@ template <class T, int N, int MODE> __global__ __launch_bounds__(NT) void mixed_
     const int f0 = group * F;
     const int frames = a.n_frames - f0 < F ? a.n_frames - f0 : F;
     const T* __restrict__ yb = a.y + (long long)clip * a.y_stride;
-    // (1) W_M table -> LDS; frames -> buf0 as window-multiplied sample pairs
+    // (1) W_M table -> LDS; frames -> buf0 as window-multiplied sample pairs.  Every global load of the stage -- the table, the samples, the window
+    // pairs and the split step's W_N^k (which depend on nothing) -- is issued before the first use: with runtime loop bounds hipcc ran the items one after
+    // the other, a global round trip each (round 6: 6-10 of them per workgroup at n_fft 3200; scripts/mixed_counters.sh: waves waiting 0.71-0.75 of their
+    // cycles, the vector pipe busy 0.39-0.59).
     LRA_MIXED_SETPRIO(LRA_MIXED_PRIO_L);
-    for (int t = (int)threadIdx.x; t < M; t += NT) twm[t] = a.tw_m[t];
+    constexpr int HP = M / 2 + 1;         // pairs (k, M - k) per frame
+    constexpr int IT0 = (M + NT - 1) / NT, IT1 = (F * M + NT - 1) / NT, IT3 = (F * HP + NT - 1) / NT;
     const cpx<T>* __restrict__ win2 = reinterpret_cast<const cpx<T>*>(a.win);
-    for (int w = (int)threadIdx.x; w < frames * M; w += NT) {
-        const int f = w / M, i = w - f * M;
-        const long long g = (long long)(f0 + f) * a.hop - a.pad + 2 * i;  // clip position of the pair's first sample
-        cpx<T> x;
-        if (g >= 0 && g + 1 < a.n) {
-            x = mkc<T>(yb[g], yb[g + 1]);
-        } else {
-            x = mkc<T>(fetch<T>(yb, g, a.n, a.pad_mode), fetch<T>(yb, g + 1, a.n, a.pad_mode));
+    // sample pairs as ONE 8-byte load where every pair of the launch is aligned (even hop, padding and clip pitch, aligned base: uniform)
+    const bool pair_aligned = ((a.hop | a.pad) & 1) == 0 && (a.y_stride & 1) == 0 && (reinterpret_cast<unsigned long long>(a.y) & (2 * sizeof(T) - 1)) == 0;
+    cpx<T> tw0[IT0], xs[IT1], wv[IT1], twn[IT3];
+#pragma unroll
+    for (int it = 0; it < IT0; ++it) {
+        const int t = (int)threadIdx.x + it * NT;
+        tw0[it] = a.tw_m[t < M ? t : 0];
+    }
+#pragma unroll
+    for (int it = 0; it < IT1; ++it) {
+        const int w = (int)threadIdx.x + it * NT;
+        if (w < frames * M) {
+            const int f = w / M, i = w - f * M;
+            const long long g = (long long)(f0 + f) * a.hop - a.pad + 2 * i;  // clip position of the pair's first sample
+            if (g >= 0 && g + 1 < a.n) {
+                if (pair_aligned) xs[it] = *reinterpret_cast<const cpx<T>*>(yb + g);
+                else xs[it] = mkc<T>(yb[g], yb[g + 1]);
+            } else {
+                xs[it] = mkc<T>(fetch<T>(yb, g, a.n, a.pad_mode), fetch<T>(yb, g + 1, a.n, a.pad_mode));
+            }
+            wv[it] = win2[i];
         }
-        const cpx<T> wv = win2[i];
-        buf0[w] = mkc<T>(x.x * wv.x, x.y * wv.y);
+    }
+#pragma unroll
+    for (int it = 0; it < IT3; ++it) twn[it] = a.tw_n[((int)threadIdx.x + it * NT) % HP];
+#pragma unroll
+    for (int it = 0; it < IT0; ++it) {
+        const int t = (int)threadIdx.x + it * NT;
+        if (t < M) twm[t] = tw0[it];
+    }
+#pragma unroll
+    for (int it = 0; it < IT1; ++it) {
+        const int w = (int)threadIdx.x + it * NT;
+        if (w < frames * M) buf0[w] = mkc<T>(xs[it].x * wv[it].x, xs[it].y * wv[it].y);
     }
     __syncthreads();
     // (2) M-point complex FFT of every frame
@@ -281,12 +314,14 @@ template <class T, int N, int MODE> __global__ __launch_bounds__(NT) void mixed_
     // so one work item per pair (k, M - k), k = 0 .. M/2, reads its two points once and writes both bins (k = 0: the DC and Nyquist bins
     // from Z[0]; k = M/2, M even: one self-paired bin).
     T* prow = reinterpret_cast<T*>(dst);  // MIXED_MEL: the power rows go to the buffer the FFT no longer needs ((M + 1) values per frame <= 2 M)
-    constexpr int HP = M / 2 + 1;         // pairs per frame
-    for (int w = (int)threadIdx.x; w < frames * HP; w += NT) {
+#pragma unroll
+    for (int it = 0; it < IT3; ++it) {
+        const int w = (int)threadIdx.x + it * NT;
+        if (w >= frames * HP) break;
         const int f = w / HP, k = w - f * HP;
         const cpx<T> zk = src[f * M + k], zr = src[f * M + (k == 0 ? 0 : M - k)];
         const cpx<T> e = mkc<T>((T)0.5 * (zk.x + zr.x), (T)0.5 * (zk.y - zr.y)), o = mkc<T>((T)0.5 * (zk.x - zr.x), (T)0.5 * (zk.y + zr.y));
-        const cpx<T> pw = mul(o, a.tw_n[k]);
+        const cpx<T> pw = mul(o, twn[it]);
         cpx<T> xk = mkc<T>(e.x + pw.y, e.y - pw.x), xm = mkc<T>(e.x - pw.y, -e.y - pw.x);
         if (k == 0) { xk.y = (T)0; xm.y = (T)0; }  // DC and Nyquist: purely real by construction (rounding leaves -0 / +0 differences otherwise)
         const long long row = ((long long)clip * a.n_frames + f0 + f) * (M + 1);
@@ -313,8 +348,26 @@ template <class T, int N, int MODE> __global__ __launch_bounds__(NT) void mixed_
             const int c0 = a.mel_c0[m], len = a.mel_len[m];
             const T* __restrict__ val = a.mel_val + a.mel_off[m];
             const T* p = prow + f * (M + 1) + c0;
+            // the band's weights eight (then four) at a time ahead of their use, the sum still in bin order: one dependent global load per bin was
+            // what this loop waited for
             T acc = (T)0;
-            for (int i = 0; i < len; ++i) acc += val[i] * p[i];
+            int i = 0;
+            for (; i + 8 <= len; i += 8) {
+                T vv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) vv[q] = val[i + q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc += vv[q] * p[i + q];
+            }
+            if (i + 4 <= len) {
+                T vv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) vv[q] = val[i + q];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc += vv[q] * p[i + q];
+                i += 4;
+            }
+            for (; i < len; ++i) acc += val[i] * p[i];
             a.Mel[((long long)clip * a.n_mels + m) * a.n_frames + f0 + f] = acc;
         }
     }
@@ -374,26 +427,58 @@ template <class T, int N> __device__ __forceinline__ void cqt_octave_body(const 
     const int f0 = group * F;
     const int frames = a.n_frames - f0 < F ? a.n_frames - f0 : F;
     const T* __restrict__ yb = a.y + (long long)clip * a.y_stride;
-    for (int t = (int)threadIdx.x; t < M; t += NT) twm[t] = a.tw_m[t];
+    // every global load of the frame stage (table, samples, the split step's W_N^k) ahead of its first use, as in mixed_stft_kernel above
+    constexpr int IT0 = (M + NT - 1) / NT, IT1 = (F * M + NT - 1) / NT, IT3 = (F * HP + NT - 1) / NT;
+    const bool pair_aligned = ((a.hop | a.pad) & 1) == 0 && (a.y_stride & 1) == 0 && (reinterpret_cast<unsigned long long>(a.y) & (2 * sizeof(T) - 1)) == 0;
+    cpx<T> tw0[IT0], xs[IT1], twn[IT3];
+#pragma unroll
+    for (int it = 0; it < IT0; ++it) {
+        const int t = (int)threadIdx.x + it * NT;
+        tw0[it] = a.tw_m[t < M ? t : 0];
+    }
     // frames -> buf0 (rectangular window: window="ones", constantq.py:1201)
-    for (int w = (int)threadIdx.x; w < frames * M; w += NT) {
-        const int f = w / M, i = w - f * M;
-        const long long g = (long long)(f0 + f) * a.hop - a.pad + 2 * i;
-        cpx<T> x;
-        if (g >= 0 && g + 1 < a.n) x = mkc<T>(yb[g], yb[g + 1]);
-        else x = mkc<T>(fetch<T>(yb, g, a.n, a.pad_mode), fetch<T>(yb, g + 1, a.n, a.pad_mode));
-        buf0[f * MP + i] = x;
+#pragma unroll
+    for (int it = 0; it < IT1; ++it) {
+        const int w = (int)threadIdx.x + it * NT;
+        if (w < frames * M) {
+            const int f = w / M, i = w - f * M;
+            const long long g = (long long)(f0 + f) * a.hop - a.pad + 2 * i;
+            if (g >= 0 && g + 1 < a.n) {
+                if (pair_aligned) xs[it] = *reinterpret_cast<const cpx<T>*>(yb + g);
+                else xs[it] = mkc<T>(yb[g], yb[g + 1]);
+            } else {
+                xs[it] = mkc<T>(fetch<T>(yb, g, a.n, a.pad_mode), fetch<T>(yb, g + 1, a.n, a.pad_mode));
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < IT3; ++it) twn[it] = a.tw_n[((int)threadIdx.x + it * NT) % HP];
+#pragma unroll
+    for (int it = 0; it < IT0; ++it) {
+        const int t = (int)threadIdx.x + it * NT;
+        if (t < M) twm[t] = tw0[it];
+    }
+#pragma unroll
+    for (int it = 0; it < IT1; ++it) {
+        const int w = (int)threadIdx.x + it * NT;
+        if (w < frames * M) {
+            const int f = w / M, i = w - f * M;
+            buf0[f * MP + i] = xs[it];
+        }
     }
     __syncthreads();
     cpx<T>* src = buf0;
     cpx<T>* dst = buf1;
     Passes<T, N, 0, F, MP>::run(src, dst, twm, frames);
     // Hermitian split by pairs, whole spectra (M + 1 bins) -> dst
-    for (int w = (int)threadIdx.x; w < frames * HP; w += NT) {
+#pragma unroll
+    for (int it = 0; it < IT3; ++it) {
+        const int w = (int)threadIdx.x + it * NT;
+        if (w >= frames * HP) break;
         const int f = w / HP, k = w - f * HP;
         const cpx<T> zk = src[f * MP + k], zr = src[f * MP + (k == 0 ? 0 : M - k)];
         const cpx<T> e = mkc<T>((T)0.5 * (zk.x + zr.x), (T)0.5 * (zk.y - zr.y)), o = mkc<T>((T)0.5 * (zk.x - zr.x), (T)0.5 * (zk.y + zr.y));
-        const cpx<T> pw = mul(o, a.tw_n[k]);
+        const cpx<T> pw = mul(o, twn[it]);
         cpx<T> xk = mkc<T>(e.x + pw.y, e.y - pw.x), xm = mkc<T>(e.x - pw.y, -e.y - pw.x);
         if (k == 0) {
             xk.y = (T)0;
@@ -404,13 +489,26 @@ template <class T, int N> __device__ __forceinline__ void cqt_octave_body(const 
         if (2 * k != M) dst[f * MP + M - k] = xm;
     }
     __syncthreads();
-    // projection: a work item per (frame, row), rows fastest (consecutive output elements)
+    // projection: a work item per (frame, row), rows fastest (consecutive output elements).  A row's entries are fetched eight at a time (columns and
+    // values: sixteen independent global loads, then eight LDS reads) ahead of the eight multiply-adds, which still run in CSR order with one rounding per
+    // operation -- the walk of round 4 paid one global round trip per entry (~80 entries per row).
     for (int w = (int)threadIdx.x; w < frames * a.n_rows; w += NT) {
         const int f = w / a.n_rows, r = w - f * a.n_rows;
         const cpx<T>* d = dst + f * MP;
         cpx<T> acc = mkc<T>((T)0, (T)0);
         const int j1 = a.row_ptr[a.row0 + r + 1];
-        for (int j = a.row_ptr[a.row0 + r]; j < j1; ++j) acc = cmadd_exact(acc, a.val[j], d[a.col[j]]);
+        int j = a.row_ptr[a.row0 + r];
+        for (; j + 8 <= j1; j += 8) {
+            int cc[8];
+            cpx<T> vv[8], dd[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { cc[q] = a.col[j + q]; vv[q] = a.val[j + q]; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dd[q] = d[cc[q]];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc = cmadd_exact(acc, vv[q], dd[q]);
+        }
+        for (; j < j1; ++j) acc = cmadd_exact(acc, a.val[j], d[a.col[j]]);
         if (a.sqrt_len) {
             const double scl = 1.0 / a.sqrt_len[r];
             acc = mkc<T>((T)((double)acc.x * scl), (T)((double)acc.y * scl));
