@@ -110,7 +110,7 @@ struct lra_ctx {
     int opt_v3 = LRA_V3_DEFAULT;     // n_fft = 2048 f32: the radix 16-16-4 form with 16-byte row pieces (variant 6, lra_kernels2.h third form); 1: complex epilogue, 2: |X|^p too
     int opt_mel_pc = LRA_MEL_PC_DEFAULT;  // fused mel, n_fft = 2048 f32: the producer / consumer kernel (lra_kernels_pc.h) instead of stft2_kernel<OUT_MELR>
     int opt_mel_many = 1;            // mel plans of n_fft = 512 with more than 64 bands are built for the eight-bands-per-thread kernel shape (read at lra_mel_plan_create)
-    int opt_cqt_merge = 1;           // lra_cqt_recursion_exec: octaves 1 .. in one launch per frame length behind the chain of halvings (0: one launch per octave on the side stream)
+    int opt_cqt_merge = 1;           // lra_cqt_recursion_exec: 1 = octaves 1-2 in one launch beside the later halvings, 3 .. in one launch behind the chain (round 6); 2 = octaves 1 .. in one launch per frame length behind the chain (round 5); 0 = one launch per octave on the side stream
     int opt_hpss_tile = 1;           // hpss: a thread per 4 x 4 tile with shared sorted cores (hpss_tile_kernel); 0: a thread per element (A/B)
     int opt_mixed_inv_pow2 = 1;      // inverse, n_fft = 256 / 512 / 1024 with a hop outside n_fft / {2, 4, 8, 16}: the fused gather kernel of lra_mixed.h (0: istft_kernel's general mode)
     int opt_mixed = 1;               // fused mixed-radix forward kernel for the listed non-power-of-two frame lengths (lra_mixed.h); 0: rocFFT path
@@ -1854,7 +1854,7 @@ int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value) {
     else if (!std::strcmp(key, "istft16")) ctx->opt_istft16 = value != 0;
     else if (!std::strcmp(key, "placement_retry")) ctx->opt_placement_retry = value < 0 ? 0 : (value > 8 ? 8 : value);
     else if (!std::strcmp(key, "v3")) ctx->opt_v3 = (value == 1 || value == 2) ? value : 0;
-    else if (!std::strcmp(key, "cqt_merge")) ctx->opt_cqt_merge = value != 0;
+    else if (!std::strcmp(key, "cqt_merge")) ctx->opt_cqt_merge = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else if (!std::strcmp(key, "mel_many")) ctx->opt_mel_many = value != 0;
     else if (!std::strcmp(key, "direct")) ctx->opt_direct = value != 0;
     else if (!std::strcmp(key, "mixed")) ctx->opt_mixed = value != 0;
@@ -3132,6 +3132,9 @@ int lra_cqt_recursion_exec(lra_ctx* ctx, const void* y, int64_t batch, const lra
             const int rb = lra_ctx_side(ctx, LRA_SIDE_BACK);
             if (rc == LRA_OK) rc = rb;
         }
+        // Round 6: with five or more octaves, octaves 1 and 2 go out in a launch of their own on the side stream as soon as their signals exist, beside the
+        // remaining (short) halvings, which cannot fill the chip; the rest follows the chain as before (cqt_merge = 2: everything behind the chain).
+        const int early_end = (ctx->opt_cqt_merge == 1 && n_octaves >= 5 && octaves[1].n_fft == octaves[2].n_fft) ? 3 : 1;
         for (int i = 0; i + 1 < n_octaves && rc == LRA_OK; ++i) {
             if (octaves[i].halve) {
                 rc = lra_fir_decimate_exec(ctx, cur, next, batch, octaves[i].n, octaves[i + 1].n, taps, n_taps, 2, first, sc, 1.0, dtype);
@@ -3139,8 +3142,17 @@ int lra_cqt_recursion_exec(lra_ctx* ctx, const void* y, int64_t batch, const lra
                 next += ((batch * octaves[i + 1].n * es + 255) / 256) * 256;
             }
             ys[(size_t)i + 1] = cur;
+            if (rc == LRA_OK && early_end > 1 && i + 2 == early_end) {
+                rc = lra_ctx_side(ctx, LRA_SIDE_FORK);
+                if (rc == LRA_OK) {
+                    rc = dtype == LRA_F64 ? cqt_octaves_merged<double>(ctx, octaves, ys.data(), 1, early_end, batch, pad_mode, sl, out, n_frames, n_total, dtype)
+                                          : cqt_octaves_merged<float>(ctx, octaves, ys.data(), 1, early_end, batch, pad_mode, sl, out, n_frames, n_total, dtype);
+                    const int rb = lra_ctx_side(ctx, LRA_SIDE_BACK);
+                    if (rc == LRA_OK) rc = rb;
+                }
+            }
         }
-        for (int i0 = 1; i0 < n_octaves && rc == LRA_OK;) {
+        for (int i0 = early_end; i0 < n_octaves && rc == LRA_OK;) {
             int i1 = i0 + 1;
             while (i1 < n_octaves && octaves[i1].n_fft == octaves[i0].n_fft) ++i1;
             rc = dtype == LRA_F64 ? cqt_octaves_merged<double>(ctx, octaves, ys.data(), i0, i1, batch, pad_mode, sl, out, n_frames, n_total, dtype)

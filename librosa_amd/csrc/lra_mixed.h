@@ -83,23 +83,46 @@ constexpr int stride_before(const Radices& f, int p) {
 // CU: every stage ends in a workgroup barrier and starts with loads, so what hides the latencies is OTHER workgroups in other stages.
 // Measured on the MI355X, n_fft 400 / hop 160 / 80 mels, 256 x 30 s (profiles/r04_experiments.md section 5): 16 frames per workgroup (51 KB,
 // three workgroups per CU) 1.39 ms, 12: 1.16, 8: 1.08, 6: 0.94, 4: 0.99; 64- or 128-thread workgroups 1.45-2.5 ms.
+#ifndef LRA_MIXED_NT
+#define LRA_MIXED_NT 256
+#endif
 #ifndef LRA_MIXED_FMAX
 #define LRA_MIXED_FMAX 8
 #endif
 #ifndef LRA_MIXED_LDS_KB
 #define LRA_MIXED_LDS_KB 24
 #endif
+// Among the frame counts the budget allows (and down to half of that), the one whose stages waste the fewest lanes: a stage of `items` work items per
+// frame runs ceil(F items / NT) rounds of the whole workgroup, each costing about the same whether its last round is full or not -- at n_fft = 400 the
+// budget's 7 frames put 280 radix-5 butterflies into 2 rounds of 256 lanes, 6 frames put 240 into one (round 6, after the global loads stopped being what
+// the kernel waited for: the vector pipe is busy 0.76 of the time; measured 400 / 160: stft 0.518 -> 0.505 ms).  Weights ~ vector instructions per work item.
+#ifndef LRA_MIXED_FTUNE
+#define LRA_MIXED_FTUNE 1
+#endif
+constexpr int stage_rounds_cost(int M, int F, int nt) {
+    const Radices f = factor(M);
+    int cost = ((F * M + nt - 1) / nt) * 15 + ((F * (M / 2 + 1) + nt - 1) / nt) * 40;  // frame load, Hermitian split
+    for (int p = 0; p < f.n; ++p) {
+        const int r = f.r[p], w = r == 8 ? 100 : (r == 5 ? 75 : (r == 2 ? 20 : 40));
+        cost += ((F * (M / r) + nt - 1) / nt) * w;
+    }
+    return cost;
+}
 template <class T, int N> constexpr int frames_per_group() {
     constexpr int M = N / 2;
     int f = (int)((LRA_MIXED_LDS_KB * 1024 - M * 2 * (int)sizeof(T)) / (2 * M * 2 * (int)sizeof(T)));
-    return f < 1 ? 1 : (f > LRA_MIXED_FMAX ? LRA_MIXED_FMAX : f);
+    f = f < 1 ? 1 : (f > LRA_MIXED_FMAX ? LRA_MIXED_FMAX : f);
+    if (LRA_MIXED_FTUNE) {
+        int best = f;
+        for (int c = f - 1; c >= 1 && 2 * c >= f; --c)
+            if ((long long)stage_rounds_cost(M, c, LRA_MIXED_NT) * best < (long long)stage_rounds_cost(M, best, LRA_MIXED_NT) * c) best = c;  // cost per frame
+        f = best;
+    }
+    return f;
 }
 template <class T, int N> constexpr int lds_bytes() { return (2 * frames_per_group<T, N>() * (N / 2) + N / 2) * 2 * (int)sizeof(T); }
 
 enum { MIXED_COMPLEX = 0, MIXED_POWER = 1, MIXED_MEL = 2 };
-#ifndef LRA_MIXED_NT
-#define LRA_MIXED_NT 256
-#endif
 constexpr int NT = LRA_MIXED_NT;  // threads per workgroup
 
 template <class T> struct Args {
@@ -412,6 +435,20 @@ template <class T, int N> constexpr int cqt_lds_bytes() { return (2 * cqt_frames
 
 #pragma clang fp contract(off)
 template <class T> __device__ __forceinline__ cpx<T> cmadd_exact(cpx<T> acc, cpx<T> a, cpx<T> b) {  // acc + a b, as scipy.sparse's complex wrapper evaluates it
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LRA_MIXED_NO_PK_ASM)
+    // float: the same six roundings as four packed instructions on the (re, im) register pairs -- hipcc's own packing of the lines below takes six
+    // (a sum AND a difference of the two product pairs, then a move to splice their halves); this product is the octave kernel's inner loop
+    if constexpr (sizeof(T) == 4) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 va = __builtin_bit_cast(f2, a), vb = __builtin_bit_cast(f2, b), vacc = __builtin_bit_cast(f2, acc);
+        f2 p1, p2, sm, r;
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(p1) : "v"(va), "v"(vb));  // (a.x b.x, a.x b.y)
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(p2) : "v"(va), "v"(vb));  // (a.y b.y, a.y b.x)
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(sm) : "v"(p1), "v"(p2));                   // (a.x b.x - a.y b.y, a.x b.y + a.y b.x)
+        asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(vacc), "v"(sm));
+        return __builtin_bit_cast(cpx<T>, r);
+    }
+#endif
     const T re = a.x * b.x - a.y * b.y;
     const T im = a.x * b.y + a.y * b.x;
     return mkc<T>(acc.x + re, acc.y + im);

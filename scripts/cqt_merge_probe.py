@@ -20,7 +20,7 @@ def timeit(fn, steps=20):
     return best * 1e3
 ref = {}
 for rt in ("polyphase", "soxr_hq"):
-    for merge in (0, 1, 0, 1):
+    for merge in (2, 1, 2, 1, 0):
         ctx.set_option("cqt_merge", merge)
         out = L.cqt(y, sr=22050, res_type=rt)
         key = rt

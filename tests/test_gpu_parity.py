@@ -2070,6 +2070,18 @@ def test_cqt_native_recursion_equals_python_loop(L, monkeypatch, overlap):
                 assert torch.equal(L.cqt(y, check_finite=False, **c["kw"]), b)
             else:
                 assert np.array_equal(a, b) and np.array_equal(av, bv)
+    # the three launch orders of the native recursion (ctx option cqt_merge: 1 = octaves 1-2 early on the side stream, round 6; 2 = all behind the chain; 0 = per octave)
+    if overlap:
+        ctx = L.get_context(0)
+        yd = torch.from_numpy(cases[0]["y"]).cuda()
+        try:
+            outs = []
+            for merge in (1, 2, 0, 1):
+                ctx.set_option("cqt_merge", merge)
+                outs.append(L.cqt(yd, **cases[0]["kw"]))
+            assert all(torch.equal(o, outs[0]) for o in outs)
+        finally:
+            ctx.set_option("cqt_merge", 1)
     bad = torch.from_numpy(cases[0]["y"]).cuda()
     bad[1, 777] = float("nan")
     with pytest.raises(L.ParameterError):
