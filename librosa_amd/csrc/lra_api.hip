@@ -2813,9 +2813,9 @@ int lra_fir_decimate_exec(lra_ctx* ctx, const void* x, void* out, int64_t batch,
     const int opt = four ? 4 : 1;
     const long long blocks_per_clip = (n_out + 256 * opt - 1) / (256 * opt);
     if (blocks_per_clip * batch > 0x7fffffffLL) return fail(LRA_EINVAL, "fir_decimate: array too large for one launch");
-    if (four && down == 2 && n_taps >= 6) {  // the octave recursion's halving: four consecutive outputs per thread, padded span (fir_halve4_kernel)
-        const size_t span2 = (size_t)1023 * 2 + n_taps;
-        const size_t lds2 = (span2 + span2 / 8 + 1) * elem;
+    const size_t span2 = (size_t)1023 * 2 + n_taps;
+    const size_t lds2 = (span2 + span2 / 8 + 1) * 2 * elem;  // (sample, sample + 2) pairs, one pad entry per eight
+    if (four && down == 2 && lds2 <= 64 * 1024) {  // the octave recursion's halving: four consecutive outputs per thread, padded span of pairs (fir_halve4_kernel)
         const unsigned grid2 = (unsigned)(blocks_per_clip * batch);
         if (dtype == LRA_F64)
             hipLaunchKernelGGL(fir_halve4_kernel<double>, dim3(grid2), dim3(256), lds2, ctx->stream, (const double*)x, (double*)out, (const double*)taps, (long long)n_in, (long long)n_out,

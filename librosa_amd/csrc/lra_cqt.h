@@ -29,6 +29,24 @@ template <class T> struct CqtOps {
         return r;
     }
 };
+// two running sums at once: acc + v h per half, product and sum rounded separately (as madd above); float on the device: v_pk_mul_f32 + v_pk_add_f32
+template <class T> struct Pair2 {
+    T lo, hi;
+};
+template <class T> __device__ __forceinline__ Pair2<T> fma2_exact(Pair2<T> acc, Pair2<T> v, T h) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (sizeof(T) == 4) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2 hv = {h, h};
+        const f2 prod = __builtin_bit_cast(f2, v) * hv;
+        const f2 r = __builtin_bit_cast(f2, acc) + prod;
+        return __builtin_bit_cast(Pair2<T>, r);
+    }
+#endif
+    acc.lo = acc.lo + v.lo * h;
+    acc.hi = acc.hi + v.hi * h;
+    return acc;
+}
 #pragma clang fp contract(fast)
 
 // ---- FIR decimator: scipy.signal.resample_poly(x, 1, down) with zero padding (librosa/core/audio.py:676-693, the resampler behind
@@ -146,7 +164,7 @@ template <class T> __global__ __launch_bounds__(256) void repitch_rows_kernel(co
 #define LRA_DYN_LDS(T, name) T* name = reinterpret_cast<T*>(g_postsim_dyn_lds)
 #else
 #define LRA_DYN_LDS(T, name)                         \
-    extern __shared__ unsigned char lra_dyn_lds_raw[]; \
+    extern __shared__ __attribute__((aligned(16))) unsigned char lra_dyn_lds_raw[]; \
     T* name = reinterpret_cast<T*>(lra_dyn_lds_raw)
 #endif
 
@@ -194,16 +212,21 @@ __global__ __launch_bounds__(256) void fir_decimate_kernel(const T* __restrict__
 template <class T>
 __global__ __launch_bounds__(256) void fir_halve4_kernel(const T* __restrict__ x, T* __restrict__ out, const T* __restrict__ h, long long n_in, long long n_out, int blocks_per_clip, int n_taps,
                                                          int first, double div, double mul) {
-    LRA_DYN_LDS(T, xs);
+    LRA_DYN_LDS(Pair2<T>, xs);  // entry e(s) = s + s / 8 holds the pair (x[s], x[s + 2]) of staged samples
     const long long clip = blockIdx.x / blocks_per_clip;
     const long long n0 = (long long)(blockIdx.x % blocks_per_clip) * 1024;
     const int t = threadIdx.x;
     const T* __restrict__ xc = x + clip * n_in;
     const long long base = (n0 + first) * 2 - (n_taps - 1);  // input index of staged sample 0
     const int span = 1023 * 2 + n_taps;
-    // the span's first 2 560 samples as ten loads per thread issued together (index clamped into the clip, the value masked: nothing for a load to wait
-    // on), then the LDS writes -- with its runtime bound the staging loop ran as nine dependent global round trips (round 6: the first halving of a
-    // 64 x 30 s batch 148 us = 1.7 TB/s); longer filters finish in the loop below
+    // Staging: sample s is the first half of pair s and the second half of pair s - 2 (every sample is written twice, so that the walk below reads a
+    // (sample, sample + 2) pair as ONE aligned 8-byte LDS read straight into a register pair).  The span's first 2 560 samples as ten loads per thread
+    // issued together (index clamped into the clip, the value masked: nothing for a load to wait on), then the LDS writes -- with its runtime bound the
+    // staging loop ran as nine dependent global round trips; longer filters finish in the loop below.
+    auto put = [&](int s, T v) {
+        xs[s + (s >> 3)].lo = v;
+        if (s >= 2) xs[s - 2 + ((s - 2) >> 3)].hi = v;
+    };
     {
         constexpr int IT = 10;
         T st[IT];
@@ -217,52 +240,52 @@ __global__ __launch_bounds__(256) void fir_halve4_kernel(const T* __restrict__ x
         for (int it = 0; it < IT; ++it) {
             const int s = t + it * 256;
             const long long gi = base + s;
-            if (s < span) xs[s + (s >> 3)] = (gi >= 0 && gi < n_in) ? st[it] : (T)0;
+            if (s < span) put(s, (gi >= 0 && gi < n_in) ? st[it] : (T)0);
         }
         for (int s = t + IT * 256; s < span; s += 256) {
             const long long gi = base + s;
-            xs[s + (s >> 3)] = (gi >= 0 && gi < n_in) ? xc[gi] : (T)0;
+            put(s, (gi >= 0 && gi < n_in) ? xc[gi] : (T)0);
         }
     }
     __syncthreads();
-    const T* __restrict__ w = xs + t * 9;  // this thread's window: sample j of it at w[j + j / 8]
-    T a0 = (T)0, a1 = (T)0, a2 = (T)0, a3 = (T)0;
-    const int walk = n_taps + 6;
-    auto edge = [&](int j) {  // the first and last six samples of the walk reach only some of the four outputs (position k = j - 2 q in output q's window)
-        const T v = w[j + (j >> 3)];
-        if (j < n_taps) a0 = CqtOps<T>::madd(a0, v, h[n_taps - 1 - j]);
-        if (j >= 2 && j - 2 < n_taps) a1 = CqtOps<T>::madd(a1, v, h[n_taps + 1 - j]);
-        if (j >= 4 && j - 4 < n_taps) a2 = CqtOps<T>::madd(a2, v, h[n_taps + 3 - j]);
-        if (j >= 6 && j - 6 < n_taps) a3 = CqtOps<T>::madd(a3, v, h[n_taps + 5 - j]);
-    };
-    int j = 0;
-    for (; j < 6 && j < walk; ++j) edge(j);
-    // every sample of the middle feeds all four sums; eight samples per trip with their fourteen taps fetched in one go (the tap index is the
-    // same for all lanes: scalar loads, and one dependent scalar load per sample was what the loop waited for)
-    for (; j + 8 <= n_taps; j += 8) {
-        const T* __restrict__ hp = h + (n_taps - 8 - j);  // taps of positions j + 7 (lowest index) ... j, + 6
-        T hh[14];
+    const Pair2<T>* __restrict__ w = xs + t * 9;  // this thread's window: the pair (sample j, sample j + 2) of it at w[j + j / 8]
+    // Output q of the thread takes window samples 2 q .. 2 q + n_taps - 1, sample 2 q + k with tap h[n_taps - 1 - k]: step k of ONE walk over the taps
+    // feeds (v[k], v[k + 2], v[k + 4], v[k + 6]) h[n_taps - 1 - k] to the four running sums -- per sum the same products in the same (ascending-input)
+    // order as scipy's upfirdn, one rounding per operation, and no edge steps.  As two (sample, sample + 2) pairs times one tap the step is two packed
+    // multiplies and two packed adds (round 6: the halvings of a transform ran at the vector pipe's limit, eight instructions per step); the pair
+    // (v[k + 4], v[k + 6]) of step k is step k + 4's first pair, so every step reads ONE new pair from the staged span (which holds every sample twice,
+    // as the first half of its own pair and the second half of the pair two samples back: left to itself hipcc reads each sample once and splices the
+    // pairs with moves, which cost what the packing saves).
+    auto pair_at = [&](int j) { return w[j + (j >> 3)]; };
+    Pair2<T> a01 = {(T)0, (T)0}, a23 = {(T)0, (T)0};
+    Pair2<T> p[4];
 #pragma unroll
-        for (int i = 0; i < 14; ++i) hh[i] = hp[i];
+    for (int i = 0; i < 4; ++i) p[i] = pair_at(i);
+    int k = 0;
+    for (; k + 8 <= n_taps; k += 8) {
+        const T* __restrict__ hp = h + (n_taps - 8 - k);  // taps of steps k + 7 (lowest index) ... k: the same for all lanes, scalar loads
+        T hh[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) hh[i] = hp[i];
+        Pair2<T> nw[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) nw[u] = pair_at(k + u + 4);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int jj = j + u;
-            const T v = w[jj + (jj >> 3)];
-            a0 = CqtOps<T>::madd(a0, v, hh[7 - u]);
-            a1 = CqtOps<T>::madd(a1, v, hh[9 - u]);
-            a2 = CqtOps<T>::madd(a2, v, hh[11 - u]);
-            a3 = CqtOps<T>::madd(a3, v, hh[13 - u]);
+            a01 = fma2_exact(a01, u < 4 ? p[u] : nw[u - 4], hh[7 - u]);
+            a23 = fma2_exact(a23, nw[u], hh[7 - u]);
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[i] = nw[4 + i];
     }
-    for (; j < n_taps; ++j) {
-        const T v = w[j + (j >> 3)];
-        const int c = n_taps - 1 - j;
-        a0 = CqtOps<T>::madd(a0, v, h[c]);
-        a1 = CqtOps<T>::madd(a1, v, h[c + 2]);
-        a2 = CqtOps<T>::madd(a2, v, h[c + 4]);
-        a3 = CqtOps<T>::madd(a3, v, h[c + 6]);
+    for (; k < n_taps; ++k) {
+        const T hk = h[n_taps - 1 - k];
+        const Pair2<T> nwp = pair_at(k + 4);
+        a01 = fma2_exact(a01, p[0], hk);
+        a23 = fma2_exact(a23, nwp, hk);
+        p[0] = p[1]; p[1] = p[2]; p[2] = p[3]; p[3] = nwp;
     }
-    for (; j < walk; ++j) edge(j);
+    const T a0 = a01.lo, a1 = a01.hi, a2 = a23.lo, a3 = a23.hi;
     const T acc[4] = {a0, a1, a2, a3};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {

@@ -167,7 +167,8 @@ int postsim_fir_decimate(const void* x, void* out, long long batch, long long n_
     const bool four = n_out >= 8192 && ((size_t)(1023 * (long long)down + n_taps)) * elem <= 32 * 1024;
     const int opt = four ? 4 : 1;
     const int blocks_per_clip = (int)((n_out + 256 * opt - 1) / (256 * opt));
-    if (four && down == 2 && n_taps >= 6) {
+    const size_t span2 = (size_t)1023 * 2 + n_taps;
+    if (four && down == 2 && (span2 + span2 / 8 + 1) * 2 * elem <= 64 * 1024) {
         const unsigned grid2 = (unsigned)(blocks_per_clip * batch);
         if (is_f64) run_grid(grid2, 256, [=] { lra::fir_halve4_kernel<double>((const double*)x, (double*)out, (const double*)taps, n_in, n_out, blocks_per_clip, n_taps, first, div, mul); });
         else run_grid(grid2, 256, [=] { lra::fir_halve4_kernel<float>((const float*)x, (float*)out, (const float*)taps, n_in, n_out, blocks_per_clip, n_taps, first, div, mul); });
