@@ -1789,7 +1789,16 @@ int lra_ctx_side(lra_ctx* ctx, int mode) {
     LRA_BIND(ctx);
     if (mode == LRA_SIDE_FORK) {
         if (ctx->on_side) return fail(LRA_EINVAL, "lra_ctx_side: already on the side stream");
-        if (!ctx->side_stream) LRA_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+        if (!ctx->side_stream) {
+            // the side stream carries work that runs BESIDE a dependent chain on the caller's stream (octave transforms beside the halvings): lowest
+            // priority, so that the chain's short kernels are dispatched ahead of it (LRA_SIDE_PRIO=0: default priority, development A/B)
+            int least = 0, greatest = 0;
+            const char* knob = std::getenv("LRA_SIDE_PRIO");
+            if ((!knob || std::atoi(knob) != 0) && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+                LRA_HIP(hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, least));
+            else
+                LRA_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+        }
         const int slot = ctx->fork_next;
         ctx->fork_next = (slot + 1) % lra_ctx::kForkRing;
         if (!ctx->fork_event[slot]) LRA_HIP(hipEventCreateWithFlags(&ctx->fork_event[slot], hipEventDisableTiming));
