@@ -52,7 +52,11 @@ template <class T> struct alignas(2 * sizeof(T)) cpx {
 template <class T> __device__ __forceinline__ cpx<T> mkc(T x, T y) { cpx<T> r; r.x = x; r.y = y; return r; }
 template <class T> __device__ __forceinline__ cpx<T> add(cpx<T> a, cpx<T> b) { return mkc<T>(a.x + b.x, a.y + b.y); }
 template <class T> __device__ __forceinline__ cpx<T> sub(cpx<T> a, cpx<T> b) { return mkc<T>(a.x - b.x, a.y - b.y); }
-template <class T> __device__ __forceinline__ cpx<T> mul(cpx<T> a, cpx<T> b) { return mkc<T>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// a b + c in one rounding, spelled out wherever a sum of two products could be contracted either way: the stages are unrolled over their work items
+// (round 6), and a frame's bits must not depend on which copy of the body it lands in (a clip sharded by frames equals the unsharded call bit for bit)
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <class T> __device__ __forceinline__ cpx<T> mul(cpx<T> a, cpx<T> b) { return mkc<T>(fma_t(-a.y, b.y, a.x * b.x), fma_t(a.y, b.x, a.x * b.y)); }
 template <class T> __device__ __forceinline__ cpx<T> mul_mi(cpx<T> a) { return mkc<T>(a.y, -a.x); }  // a * (-i)
 template <class T> __device__ __forceinline__ cpx<T> scale(cpx<T> a, T k) { return mkc<T>(a.x * k, a.y * k); }
 
@@ -168,7 +172,7 @@ template <class T> struct Dft<3, T> {
     static __device__ __forceinline__ void run(cpx<T>* v) {
         const T s = (T)0.86602540378443864676;  // sin(2 pi / 3)
         const cpx<T> t1 = add(v[1], v[2]), d = scale(mul_mi(sub(v[1], v[2])), s);  // -i s (b - c)
-        const cpx<T> m = mkc<T>(v[0].x - (T)0.5 * t1.x, v[0].y - (T)0.5 * t1.y);
+        const cpx<T> m = mkc<T>(fma_t((T)-0.5, t1.x, v[0].x), fma_t((T)-0.5, t1.y, v[0].y));
         v[0] = add(v[0], t1);
         v[1] = add(m, d);
         v[2] = sub(m, d);
@@ -188,10 +192,10 @@ template <class T> struct Dft<5, T> {
         const T c1 = (T)0.30901699437494742410, c2 = (T)-0.80901699437494742410;  // cos(2 pi / 5), cos(4 pi / 5)
         const T s1 = (T)0.95105651629515357212, s2 = (T)0.58778525229247312917;   // sin(2 pi / 5), sin(4 pi / 5)
         const cpx<T> t1 = add(v[1], v[4]), t2 = add(v[2], v[3]), t3 = sub(v[1], v[4]), t4 = sub(v[2], v[3]);
-        const cpx<T> m1 = mkc<T>(v[0].x + c1 * t1.x + c2 * t2.x, v[0].y + c1 * t1.y + c2 * t2.y);
-        const cpx<T> m2 = mkc<T>(v[0].x + c2 * t1.x + c1 * t2.x, v[0].y + c2 * t1.y + c1 * t2.y);
-        const cpx<T> n1 = mul_mi(mkc<T>(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y));  // -i (s1 t3 + s2 t4)
-        const cpx<T> n2 = mul_mi(mkc<T>(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y));  // -i (s2 t3 - s1 t4)
+        const cpx<T> m1 = mkc<T>(fma_t(c2, t2.x, fma_t(c1, t1.x, v[0].x)), fma_t(c2, t2.y, fma_t(c1, t1.y, v[0].y)));
+        const cpx<T> m2 = mkc<T>(fma_t(c1, t2.x, fma_t(c2, t1.x, v[0].x)), fma_t(c1, t2.y, fma_t(c2, t1.y, v[0].y)));
+        const cpx<T> n1 = mul_mi(mkc<T>(fma_t(s1, t3.x, s2 * t4.x), fma_t(s1, t3.y, s2 * t4.y)));    // -i (s1 t3 + s2 t4)
+        const cpx<T> n2 = mul_mi(mkc<T>(fma_t(s2, t3.x, -(s1 * t4.x)), fma_t(s2, t3.y, -(s1 * t4.y))));  // -i (s2 t3 - s1 t4)
         v[0] = add(v[0], add(t1, t2));
         v[1] = add(m1, n1);
         v[4] = sub(m1, n1);
@@ -264,7 +268,7 @@ template <class T, int N, int P, int F, int PITCH = N / 2> struct Passes {
 };
 
 template <class T> __device__ __forceinline__ T spec_pow(cpx<T> x, int mode, T p) {
-    const T m2 = x.x * x.x + x.y * x.y;
+    const T m2 = fma_t(x.y, x.y, x.x * x.x);
     if (mode == 2) return m2;
     const T m = sqrt(m2);
     if (mode == 1) return m;

@@ -1161,7 +1161,8 @@ def test_long_clip_shards_by_frames_in_process(L, monkeypatch):
     y = golden_cases.make_signal("noise", 22050 * 8, 21, (1,))
     n_dev = L.device_count()
     two = ",".join(str(i % n_dev) for i in range(2)) if n_dev < 2 else "all"
-    for n_fft, hop, center, pad_mode in ((2048, 512, True, "constant"), (2048, 512, True, "reflect"), (1024, 256, False, "constant"), (512, 160, True, "symmetric"), (400, 160, True, "edge")):
+    for n_fft, hop, center, pad_mode in ((2048, 512, True, "constant"), (2048, 512, True, "reflect"), (1024, 256, False, "constant"), (512, 160, True, "symmetric"), (400, 160, True, "edge"), (1200, 300, True, "reflect")):
+        # (the mixed-radix kernels unroll their stages over work items: a frame's bits must not depend on the copy of the body it lands in -- 400 / 160 and 1200 / 300)
         kw = dict(n_fft=n_fft, hop_length=hop, center=center, pad_mode=pad_mode)
         monkeypatch.setenv("LRA_DEVICES", "0")
         D1 = L.stft(y, **kw)
