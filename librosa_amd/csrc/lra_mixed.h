@@ -632,19 +632,45 @@ template <class T, int N> __global__ __launch_bounds__(NT) void mixed_istft_kern
     int t_end = t_own + a.group_hops;                             // one past the last frame transformed here
     if (t_end > a.n_used || last) t_end = a.n_used;
     const int frames = t_end - t_first;                           // <= group_hops + halo <= FMAX (host)
-    for (int t = (int)threadIdx.x; t < M; t += NT) twm[t] = a.tw_m[t];
-    // (1) Hermitian un-split: buf0[f][k] = conj Z'[k],  Z'[k] = E' + i O',  E' = X[k] + conj X[M-k],  O' = (X[k] - conj X[M-k]) conj W_N^k
-    for (int w = (int)threadIdx.x; w < frames * HP; w += NT) {
-        const int f = w / HP, k = w - f * HP;
-        const cpx<T>* __restrict__ X = a.D + clip * a.d_batch_stride + (long long)(t_first + f) * a.d_frame_stride;
-        cpx<T> xk = X[k], xm = X[M - k];
-        if (k == 0) { xk.y = (T)0; xm.y = (T)0; }
-        const cpx<T> e = mkc<T>(xk.x + xm.x, xk.y - xm.y), d = mkc<T>(xk.x - xm.x, xk.y + xm.y);
-        const cpx<T> wc = a.tw_n[k];
-        const cpx<T> o = mkc<T>(d.x * wc.x + d.y * wc.y, d.y * wc.x - d.x * wc.y);  // d * conj(w)
-        // conj Z'[k] = conj(E') - i conj(O') = (e.x - o.y, -e.y - o.x);  conj Z'[M-k] = E' - i O' = (e.x + o.y, e.y - o.x)
-        buf0[f * M + k] = mkc<T>(e.x - o.y, -e.y - o.x);
-        if (k > 0 && 2 * k != M) buf0[f * M + M - k] = mkc<T>(e.x + o.y, e.y - o.x);
+    // (1) Hermitian un-split: buf0[f][k] = conj Z'[k],  Z'[k] = E' + i O',  E' = X[k] + conj X[M-k],  O' = (X[k] - conj X[M-k]) conj W_N^k.
+    // The table, both bins of every pair and its W_N^k are loaded ahead of the first use (compile-time trip counts, round 6: see mixed_stft_kernel).
+    constexpr int IT0 = (M + NT - 1) / NT, IT1 = (FMAX * HP + NT - 1) / NT;
+    {
+        cpx<T> tw0[IT0], xk[IT1], xm[IT1], wc[IT1];
+#pragma unroll
+        for (int it = 0; it < IT0; ++it) {
+            const int t = (int)threadIdx.x + it * NT;
+            tw0[it] = a.tw_m[t < M ? t : 0];
+        }
+#pragma unroll
+        for (int it = 0; it < IT1; ++it) {
+            const int w = (int)threadIdx.x + it * NT;
+            if (w < frames * HP) {
+                const int f = w / HP, k = w - f * HP;
+                const cpx<T>* __restrict__ X = a.D + clip * a.d_batch_stride + (long long)(t_first + f) * a.d_frame_stride;
+                xk[it] = X[k];
+                xm[it] = X[M - k];
+                wc[it] = a.tw_n[k];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < IT0; ++it) {
+            const int t = (int)threadIdx.x + it * NT;
+            if (t < M) twm[t] = tw0[it];
+        }
+#pragma unroll
+        for (int it = 0; it < IT1; ++it) {
+            const int w = (int)threadIdx.x + it * NT;
+            if (w >= frames * HP) break;
+            const int f = w / HP, k = w - f * HP;
+            cpx<T> x0 = xk[it], x1 = xm[it];
+            if (k == 0) { x0.y = (T)0; x1.y = (T)0; }
+            const cpx<T> e = mkc<T>(x0.x + x1.x, x0.y - x1.y), d = mkc<T>(x0.x - x1.x, x0.y + x1.y);
+            const cpx<T> o = mkc<T>(fma_t(d.y, wc[it].y, d.x * wc[it].x), fma_t(-d.x, wc[it].y, d.y * wc[it].x));  // d * conj(w)
+            // conj Z'[k] = conj(E') - i conj(O') = (e.x - o.y, -e.y - o.x);  conj Z'[M-k] = E' - i O' = (e.x + o.y, e.y - o.x)
+            buf0[f * M + k] = mkc<T>(e.x - o.y, -e.y - o.x);
+            if (k > 0 && 2 * k != M) buf0[f * M + M - k] = mkc<T>(e.x + o.y, e.y - o.x);
+        }
     }
     __syncthreads();
     // (2) forward passes: Y = FFT(conj Z') = conj(M z)
@@ -653,10 +679,18 @@ template <class T, int N> __global__ __launch_bounds__(NT) void mixed_istft_kern
     Passes<T, N, 0, FMAX>::run(src, dst, twm, frames);
     // (3) window / N in place: sample pair m of a frame = (Y.x ws[2m], -Y.y ws[2m+1])
     const cpx<T>* __restrict__ ws2 = reinterpret_cast<const cpx<T>*>(a.win_scaled);
-    for (int w = (int)threadIdx.x; w < frames * M; w += NT) {
-        const int i = w % M;
-        const cpx<T> v = src[w], wv = ws2[i];
-        src[w] = mkc<T>(v.x * wv.x, -v.y * wv.y);
+    {
+        constexpr int IT3 = (FMAX * M + NT - 1) / NT;
+        cpx<T> wv[IT3];
+#pragma unroll
+        for (int it = 0; it < IT3; ++it) wv[it] = ws2[((int)threadIdx.x + it * NT) % M];
+#pragma unroll
+        for (int it = 0; it < IT3; ++it) {
+            const int w = (int)threadIdx.x + it * NT;
+            if (w >= frames * M) break;
+            const cpx<T> v = src[w];
+            src[w] = mkc<T>(v.x * wv[it].x, -v.y * wv[it].y);
+        }
     }
     __syncthreads();
     // (4) overlap-add by gathering, increasing frame order; padded position p, output index s = p - drop
@@ -671,9 +705,10 @@ template <class T, int N> __global__ __launch_bounds__(NT) void mixed_istft_kern
         tl = tl <= 0 ? 0 : (tl + a.hop - 1) / a.hop;
         long long th = p / a.hop;
         if (th > a.n_used - 1) th = a.n_used - 1;
+        const T nrm = a.norm[s];  // (in flight while the contributions are gathered)
         T acc = (T)0;
         for (long long t = tl; t <= th; ++t) acc += fr[(t - t_first) * N + (p - t * a.hop)];
-        a.y[clip * a.y_stride + s] = acc * a.norm[s];
+        a.y[clip * a.y_stride + s] = acc * nrm;
     }
 }
 
