@@ -113,7 +113,7 @@ struct lra_ctx {
     int opt_cqt_merge = 1;           // lra_cqt_recursion_exec: 1 = octaves 1-2 in one launch beside the later halvings, 3 .. in one launch behind the chain (round 6); 2 = octaves 1 .. in one launch per frame length behind the chain (round 5); 0 = one launch per octave on the side stream
     int opt_hpss_tile = 1;           // hpss: a thread per 4 x 4 tile with shared sorted cores (hpss_tile_kernel); 0: a thread per element (A/B)
     int opt_mixed_inv_pow2 = 1;      // inverse, n_fft = 256 / 512 / 1024 with a hop outside n_fft / {2, 4, 8, 16}: the fused gather kernel of lra_mixed.h (0: istft_kernel's general mode)
-    int opt_mixed = 1;               // fused mixed-radix forward kernel for the listed non-power-of-two frame lengths (lra_mixed.h); 0: rocFFT path
+    int opt_mixed = 1;               // fused mixed-radix forward kernel for the listed non-power-of-two frame lengths (lra_mixed.h); 0: rocFFT path; 2: fused, mel band table read through the caches instead of staged in LDS (A/B)
     int opt_direct = 1;              // direct framing (no ring) for hop >= n_fft
     int opt_xcd_remap = 1;           // workgroup -> work item map that keeps neighbouring strips on one XCD (lra_kernels.h, xcd_block)
     unsigned int* d_flag = nullptr;  // non-finite input flag (device)
@@ -296,6 +296,7 @@ struct lra_mel_plan {
     int* d_len = nullptr;
     int* d_off = nullptr;
     void* d_val = nullptr;
+    int nnz = 0;  // weights in d_val
     // two-slope form (lra_mel.h); two_slope == false -> only the generic banded path is available
     bool two_slope = false;
     void* d_wAB = nullptr;
@@ -1182,6 +1183,7 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
             a.mel_off = mel->d_off;
             a.mel_val = (const T*)mel->d_val;
             a.n_mels = mel->n_mels;
+            a.mel_nnz = (ctx->opt_mixed != 2 && mixed::mel_lds_fits(mel->n_mels, mel->nnz)) ? mel->nnz : 0;  // band table staged in LDS (mixed = 2: cached reads, A/B)
             mm = mixed::MIXED_MEL;
         }
         hipError_t e;
@@ -1866,7 +1868,7 @@ int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value) {
     else if (!std::strcmp(key, "cqt_merge")) ctx->opt_cqt_merge = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else if (!std::strcmp(key, "mel_many")) ctx->opt_mel_many = value != 0;
     else if (!std::strcmp(key, "direct")) ctx->opt_direct = value != 0;
-    else if (!std::strcmp(key, "mixed")) ctx->opt_mixed = value != 0;
+    else if (!std::strcmp(key, "mixed")) ctx->opt_mixed = value == 2 ? 2 : (value != 0);
     else if (!std::strcmp(key, "hpss_tile")) ctx->opt_hpss_tile = value != 0;
     else if (!std::strcmp(key, "mixed_inv_pow2")) ctx->opt_mixed_inv_pow2 = value != 0;
     else if (!std::strcmp(key, "autotune")) ctx->opt_autotune = value != 0;
@@ -2343,6 +2345,7 @@ int lra_mel_plan_create(lra_ctx* ctx, int n_mels, int n_bins, const void* basis_
     if (rc == LRA_OK) rc = upload((void**)&p->d_len, len.data(), len.size() * sizeof(int));
     if (rc == LRA_OK) rc = upload((void**)&p->d_off, off.data(), off.size() * sizeof(int));
     if (rc == LRA_OK) rc = upload(&p->d_val, vals.data(), vals.size());
+    p->nnz = (int)(vals.size() / (dtype == LRA_F64 ? 8 : 4));
     if (rc == LRA_OK) {
         if (dtype == LRA_F64) {
             TwoSlope<double> ts = build_two_slope<double>((const double*)basis_host, n_mels, n_bins);

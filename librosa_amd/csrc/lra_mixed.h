@@ -126,6 +126,16 @@ template <class T, int N> constexpr int frames_per_group() {
 }
 template <class T, int N> constexpr int lds_bytes() { return (2 * frames_per_group<T, N>() * (N / 2) + N / 2) * 2 * (int)sizeof(T); }
 
+// The mel stage's band table in LDS (round 6): a (band, frame) work item needs its band's (c0, len, off) and then its weights -- two dependent global round trips
+// per round of work items, at the very end of a workgroup's life where nothing hides them.  Up to 256 bands and 1 536 weights (one and six loads per thread,
+// issued with the frame stage's loads) go behind the W_M table for up to 9 KB; larger banks keep the cached reads.  Measured (256 x 30 s, mel): 400 / 160 / 80
+// 0.70-0.73 -> 0.615 ms, 480 / 120 / 40 1.07 -> 0.93, 800 / 200 / 80 1.05 -> 0.94, 1200 / 300 / 128 1.49 -> 1.34; a cap of 768 misses the last two, 2 560 is 1 % slower.
+#ifndef LRA_MIXED_MEL_NNZ
+#define LRA_MIXED_MEL_NNZ 1536
+#endif
+constexpr int kMelLdsMaxBands = 256, kMelLdsMaxNnz = LRA_MIXED_MEL_NNZ;
+template <class T> constexpr int mel_lds_bytes(int n_mels, int nnz) { return nnz * (int)sizeof(T) + 3 * n_mels * (int)sizeof(int); }
+inline bool mel_lds_fits(int n_mels, int nnz) { return n_mels >= 1 && n_mels <= kMelLdsMaxBands && nnz >= 1 && nnz <= kMelLdsMaxNnz; }
 enum { MIXED_COMPLEX = 0, MIXED_POWER = 1, MIXED_MEL = 2 };
 constexpr int NT = LRA_MIXED_NT;  // threads per workgroup
 
@@ -147,6 +157,8 @@ template <class T> struct Args {
     const T* mel_val;
     int n_mels;
     int groups_per_clip;   // ceil(n_frames / F)
+    int mel_nnz;           // MIXED_MEL: > 0 = the band table (3 n_mels descriptors + mel_nnz weights) is staged in LDS behind the W_M table (the host adds
+                           // mel_lds_bytes<T>(n_mels, mel_nnz) to the launch's LDS); 0 = read through the caches
 };
 
 // sample g of a clip of n samples under np.pad's modes; matches lra::pad_index (lra_common.h) and np.pad incl. repeated reflection
@@ -319,6 +331,39 @@ template <class T, int N, int MODE> __global__ __launch_bounds__(NT) void mixed_
     }
 #pragma unroll
     for (int it = 0; it < IT3; ++it) twn[it] = a.tw_n[((int)threadIdx.x + it * NT) % HP];
+    // MIXED_MEL with the band table in LDS: weights [mel_nnz], then c0 / len / off [n_mels each], behind the W_M table
+    T* lval = reinterpret_cast<T*>(twm + M);
+    int* lc0 = reinterpret_cast<int*>(lval + a.mel_nnz);
+    int* llen = lc0 + a.n_mels;
+    int* loff = llen + a.n_mels;
+    const bool mel_lds = MODE == MIXED_MEL && a.mel_nnz > 0;
+    if (mel_lds) {
+        constexpr int ITV = (kMelLdsMaxNnz + NT - 1) / NT, ITB = (kMelLdsMaxBands + NT - 1) / NT;
+        T mv[ITV];
+        int b0[ITB], b1[ITB], b2[ITB];
+#pragma unroll
+        for (int it = 0; it < ITV; ++it) {
+            const int i = (int)threadIdx.x + it * NT;
+            mv[it] = a.mel_val[i < a.mel_nnz ? i : 0];
+        }
+#pragma unroll
+        for (int it = 0; it < ITB; ++it) {
+            const int m = (int)threadIdx.x + it * NT, mm = m < a.n_mels ? m : 0;
+            b0[it] = a.mel_c0[mm];
+            b1[it] = a.mel_len[mm];
+            b2[it] = a.mel_off[mm];
+        }
+#pragma unroll
+        for (int it = 0; it < ITV; ++it) {
+            const int i = (int)threadIdx.x + it * NT;
+            if (i < a.mel_nnz) lval[i] = mv[it];
+        }
+#pragma unroll
+        for (int it = 0; it < ITB; ++it) {
+            const int m = (int)threadIdx.x + it * NT;
+            if (m < a.n_mels) { lc0[m] = b0[it]; llen[m] = b1[it]; loff[m] = b2[it]; }
+        }
+    }
 #pragma unroll
     for (int it = 0; it < IT0; ++it) {
         const int t = (int)threadIdx.x + it * NT;
@@ -372,6 +417,15 @@ template <class T, int N, int MODE> __global__ __launch_bounds__(NT) void mixed_
         for (int w = (int)threadIdx.x; w < a.n_mels * F; w += NT) {
             const int m = w / F, f = w - m * F;
             if (f >= frames) continue;
+            if (mel_lds) {  // band table in LDS: no global round trip at all
+                const int c0 = lc0[m], len = llen[m];
+                const T* val = lval + loff[m];
+                const T* p = prow + f * (M + 1) + c0;
+                T acc = (T)0;
+                for (int i = 0; i < len; ++i) acc += val[i] * p[i];
+                a.Mel[((long long)clip * a.n_mels + m) * a.n_frames + f0 + f] = acc;
+                continue;
+            }
             const int c0 = a.mel_c0[m], len = a.mel_len[m];
             const T* __restrict__ val = a.mel_val + a.mel_off[m];
             const T* p = prow + f * (M + 1) + c0;

@@ -9,7 +9,7 @@ namespace mixed {
 namespace {
 
 template <class T, int N> hipError_t launch_n(int mode, const Args<T>& a, long long batch, hipStream_t stream) {
-    constexpr int lds = lds_bytes<T, N>();
+    const int lds = lds_bytes<T, N>() + (mode == MIXED_MEL && a.mel_nnz > 0 ? mel_lds_bytes<T>(a.n_mels, a.mel_nnz) : 0);
     const long long grid = batch * a.groups_per_clip;
     if (grid <= 0) return hipSuccess;
     if (grid > 0x7ffffff0LL) return hipErrorInvalidConfiguration;

@@ -295,6 +295,9 @@ extern "C" int postsim_mixed_stft(int n_fft, int mode, int is_f64, const void* y
         a.D = (lra::mixed::cpx<T>*)out; a.S = (T*)out; a.Mel = (T*)out;
         a.power_mode = power_mode; a.power = (T)power;
         a.mel_c0 = mel_c0; a.mel_len = mel_len; a.mel_off = mel_off; a.mel_val = (const T*)mel_val; a.n_mels = n_mels;
+        int nnz = 0;  // as stft_run (lra_api.hip): the band table is staged in LDS where it fits
+        for (int m = 0; mel_off && m < n_mels; ++m) nnz = mel_off[m] + mel_len[m] > nnz ? mel_off[m] + mel_len[m] : nnz;
+        a.mel_nnz = lra::mixed::mel_lds_fits(n_mels, nnz) ? nnz : 0;
     };
     if (is_f64) {
         lra::mixed::Args<double> a = lra::mixed::Args<double>();
