@@ -130,6 +130,12 @@ template <class T, int N> constexpr int lds_bytes() { return (2 * frames_per_gro
 // per round of work items, at the very end of a workgroup's life where nothing hides them.  Up to 256 bands and 1 536 weights (one and six loads per thread,
 // issued with the frame stage's loads) go behind the W_M table for up to 9 KB; larger banks keep the cached reads.  Measured (256 x 30 s, mel): 400 / 160 / 80
 // 0.70-0.73 -> 0.615 ms, 480 / 120 / 40 1.07 -> 0.93, 800 / 200 / 80 1.05 -> 0.94, 1200 / 300 / 128 1.49 -> 1.34; a cap of 768 misses the last two, 2 560 is 1 % slower.
+#ifndef LRA_MIXED_MEL_WAVES
+#define LRA_MIXED_MEL_WAVES 6   // waves per SIMD the forward kernels are compiled for (80 VGPRs): what the LDS budget keeps resident
+#endif
+#ifndef LRA_MIXED_MEL_CHUNK8
+#define LRA_MIXED_MEL_CHUNK8 0
+#endif
 #ifndef LRA_MIXED_MEL_NNZ
 #define LRA_MIXED_MEL_NNZ 1536
 #endif
@@ -288,7 +294,7 @@ template <class T> __device__ __forceinline__ T spec_pow(cpx<T> x, int mode, T p
 }
 
 // grid = batch * groups_per_clip workgroups of NT threads; dynamic LDS = lds_bytes<T, N>()
-template <class T, int N, int MODE> __global__ __launch_bounds__(NT) void mixed_stft_kernel(Args<T> a) {
+template <class T, int N, int MODE> __global__ __launch_bounds__(NT, (sizeof(T) == 4 && N <= 3200) ? LRA_MIXED_MEL_WAVES : 1) void mixed_stft_kernel(Args<T> a) {
     constexpr int M = N / 2, F = frames_per_group<T, N>();
     LRA_MIXED_DYN_LDS(lds);
     cpx<T>* buf0 = reinterpret_cast<cpx<T>*>(lds);
@@ -433,6 +439,7 @@ template <class T, int N, int MODE> __global__ __launch_bounds__(NT) void mixed_
             // what this loop waited for
             T acc = (T)0;
             int i = 0;
+#if LRA_MIXED_MEL_CHUNK8
             for (; i + 8 <= len; i += 8) {
                 T vv[8];
 #pragma unroll
@@ -441,12 +448,17 @@ template <class T, int N, int MODE> __global__ __launch_bounds__(NT) void mixed_
                 for (int q = 0; q < 8; ++q) acc += vv[q] * p[i + q];
             }
             if (i + 4 <= len) {
+#else
+            for (; i + 4 <= len; i += 4) {
+#endif
                 T vv[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) vv[q] = val[i + q];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc += vv[q] * p[i + q];
+#if LRA_MIXED_MEL_CHUNK8
                 i += 4;
+#endif
             }
             for (; i < len; ++i) acc += val[i] * p[i];
             a.Mel[((long long)clip * a.n_mels + m) * a.n_frames + f0 + f] = acc;
