@@ -764,17 +764,32 @@ template <class T, int N> __global__ __launch_bounds__(NT) void mixed_istft_kern
     const long long p0 = (long long)t_own * a.hop;
     long long p1 = (long long)(t_own + a.group_hops) * a.hop;
     if (last) p1 = (long long)(a.n_used - 1) * a.hop + N > p1 ? (long long)(a.n_used - 1) * a.hop + N : p1;  // the clip's tail: up to the last frame's end
-    for (long long p = p0 + (long long)threadIdx.x; p < p1; p += NT) {
-        const long long s = p - a.drop;
-        if (s < 0 || s >= a.out_len) continue;
-        long long tl = p - N + 1;
-        tl = tl <= 0 ? 0 : (tl + a.hop - 1) / a.hop;
-        long long th = p / a.hop;
-        if (th > a.n_used - 1) th = a.n_used - 1;
-        const T nrm = a.norm[s];  // (in flight while the contributions are gathered)
-        T acc = (T)0;
-        for (long long t = tl; t <= th; ++t) acc += fr[(t - t_first) * N + (p - t * a.hop)];
-        a.y[clip * a.y_stride + s] = acc * nrm;
+    // Positions relative to the first resident frame fit 32 bits (the 64-bit divisions of the absolute form were a third of this stage's instructions);
+    // four positions per trip with their normalisation factors loaded together (round 6).
+    const long long pbase = (long long)t_first * a.hop;
+    const unsigned r0 = (unsigned)(p0 - pbase), r1 = (unsigned)(p1 - pbase), uhop = (unsigned)a.hop;
+    const unsigned t_cap = (unsigned)(a.n_used - 1 - t_first);
+    for (unsigned rb = r0 + threadIdx.x; rb < r1; rb += 4 * NT) {
+        T nrm[4];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned r = rb + u * NT;
+            const long long sidx = pbase + r - a.drop;
+            ok[u] = r < r1 && sidx >= 0 && sidx < a.out_len;
+            nrm[u] = a.norm[ok[u] ? sidx : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!ok[u]) continue;
+            const unsigned r = rb + u * NT;
+            const unsigned tl = r + 1 <= (unsigned)N ? 0u : (r + 1 - (unsigned)N + uhop - 1) / uhop;
+            unsigned th = r / uhop;
+            if (th > t_cap) th = t_cap;
+            T acc = (T)0;
+            for (unsigned t = tl; t <= th; ++t) acc += fr[t * N + (r - t * uhop)];
+            a.y[clip * a.y_stride + (pbase + r - a.drop)] = acc * nrm[u];
+        }
     }
 }
 
