@@ -1262,7 +1262,11 @@ int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_s
         if (p->d_mtw && ctx->opt_mixed) {
             const int fmax = mixed::inv_frames_max_of(N, (int)sizeof(T));
             const int halo = (N + p->hop - 1) / p->hop - 1;
-            if (fmax - halo >= 1 && fmax - halo >= 2 * halo) {  // (halo frames are recomputed by the neighbouring group: worth it while they are a third of the work at most)
+            // halo frames are recomputed by the neighbouring group: worth it while they are half of the work at most (round 6, with the faster kernel and LDS tiers up to
+            // 64 KB: 480 / 120 2.84 -> 1.73 ms, 640 / 160 3.05 -> 1.78, 800 / 200 2.77 -> 2.51, 1200 / 300 4.8 -> 4.2 against the rocFFT path; LRA_MIXED_INV_RULE_X2=4 restores
+            // round 4's own >= 2 halo for A/B)
+            static const int rule_x2 = std::getenv("LRA_MIXED_INV_RULE_X2") ? std::atoi(std::getenv("LRA_MIXED_INV_RULE_X2")) : 2;
+            if (fmax - halo >= 1 && 2 * (fmax - halo) >= rule_x2 * halo) {
                 const void* nrm = wss;
                 if (!wss_is_norm) {
                     LRA_TRY(p->norm.ensure((size_t)out_len * sizeof(T)));

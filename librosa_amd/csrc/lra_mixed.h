@@ -670,13 +670,15 @@ template <class T> struct InvArgs {
 };
 // Frames resident per workgroup (own + halo).  The halo frames are recomputed work, so the group must be long against the halo (the host
 // takes this kernel only when own >= 2 halo, lra_api.hip), but LDS per workgroup is residency (measured, 400 / 160, 256 x 30 s: 24 KB 1.00 ms,
-// 32 KB 1.02, 48 KB 1.21, 64 KB 1.55; 800 / 200 at 64 KB: 2.89 ms against 2.79 for the rocFFT path): 24 KB, or 32 KB where that is what holds
-// nine frames (six own + the three halo frames of a 4 x overlap); larger frames fail the host's rule and keep the rocFFT path.
+// 32 KB 1.02, 48 KB 1.21, 64 KB 1.55; 800 / 200 at 64 KB: 2.89 ms against 2.79 for the rocFFT path): the smallest of 24 / 32 / 48 / 64 KB that holds
+// nine frames (six own + the three halo frames of a 4 x overlap), else what 64 KB holds (round 6: the larger tiers pay now that the kernel's loads are
+// batched -- 480 / 120 at 48 KB 1.73 ms against 2.84 for the rocFFT path, 800 / 200 at 64 KB 2.51 against 2.77); frames that fail the host's rule keep
+// the rocFFT path.
 template <class T, int N> constexpr int inv_frames_max() {
     constexpr int M = N / 2;
     constexpr int per_frame = 2 * M * 2 * (int)sizeof(T), table = M * 2 * (int)sizeof(T);
     int f = 0;
-    for (int kb : {24, 32}) {
+    for (int kb : {24, 32, 48, 64}) {
         f = (kb * 1024 - table) / per_frame;
         if (f >= 9) break;
     }
