@@ -1557,11 +1557,13 @@ int host_pipeline(lra_ctx* ctx, int64_t batch, size_t in_item, size_t in_stride,
             if (c >= 2) LRA_HIP(hipStreamWaitEvent(compute, hp->ev_out[s], 0));  // dev_out[s] still being downloaded (stage c - 2)
             LRA_TRY(launch(hp->dev_in[s], hp->dev_out[s], b0, nb));
             LRA_HIP(hipEventRecord(hp->ev_comp[s], compute));
-            // the previous stage's download has been running meanwhile: hand it to the caller before its pinned slot is reused
-            if (c >= 1) LRA_TRY(drain(c - 1));
+            // this stage's download is queued BEFORE the previous stage is handed to the caller (round 6): it fills the other pinned slot while the host threads
+            // empty that one -- queued after the hand-over, download and host copy took turns (64 x 30 s stft: 20.7 ms = 13.5 of download + 8 of host copy)
             LRA_HIP(hipStreamWaitEvent(hp->s_out, hp->ev_comp[s], 0));
             LRA_HIP(hipMemcpyAsync(hp->pin_out[s], hp->dev_out[s], (size_t)nb * out_item, hipMemcpyDeviceToHost, hp->s_out));
             LRA_HIP(hipEventRecord(hp->ev_out[s], hp->s_out));
+            // the previous stage's download (slot 1 - s) has been running meanwhile: hand it to the caller before the next stage reuses its pinned slot
+            if (c >= 1) LRA_TRY(drain(c - 1));
         }
         LRA_TRY(drain(chunks - 1));
         if (bad_out) *bad_out = bad;
