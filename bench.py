@@ -305,7 +305,7 @@ def compact_line(line):
     # (round 6, VERDICT r05 item 4: the driver's record keeps scalars of `roofline`, not a nested object -- the path's fractions are scalars of `roofline` itself)
     path.update({"stft_v2_frac": get(line, "kernel_forms", "stft_radix_16_8_8", "frac"), "stft_v3_frac": get(line, "kernel_forms", "stft_radix_16_16_4", "frac"),
                  "mel_one_wave_ms": get(line, "kernel_forms", "mel_one_wave", "ms"), "mel_pc_ms": get(line, "kernel_forms", "mel_producer_consumer", "ms"),
-                 "mel_pc_16_16_4_ms": get(line, "kernel_forms", "mel_producer_consumer_16_16_4", "ms"), "long_clip_frac": get(line, "long_clip", "frac_of_batched"),
+                 "mel_pc_16_16_4_ms": get(line, "kernel_forms", "mel_producer_consumer_16_16_4", "ms"), "long_clip_vs_batched": get(line, "long_clip", "frac_of_batched"),
                  "stft_frac_best_placed": get(line, "placement_placed", "stft_frac_best"), "stft_frac_worst_placed": get(line, "placement_placed", "stft_frac_worst"),
                  "stft_frac_median_placed": get(line, "placement_placed", "stft_frac_median")})
     for k, v in path.items():

@@ -551,7 +551,7 @@ def test_bench_compact_line_keeps_the_contract_and_fits():
     # the path's other fractions are SCALARS of `roofline` (the driver's record drops nested objects: VERDICT r05)
     path = line["roofline"]
     assert all(not isinstance(v, (dict, list)) for v in path.values())
-    assert path["stft_v2_frac"] == 0.658 and path["stft_v3_frac"] == 0.672 and path["mel_pc_ms"] == 0.557 and path["long_clip_frac"] == 0.97
+    assert path["stft_v2_frac"] == 0.658 and path["stft_v3_frac"] == 0.672 and path["mel_pc_ms"] == 0.557 and path["long_clip_vs_batched"] == 0.97
     assert path["stft_frac"] == 0.57 and path["istft_frac"] == 0.6 and path["stream_forward_frac"] == 0.59 and path["stream_inverse_frac"] == 0.6 and path["cqt_lite_frac"] == 0.51
     assert path["stft_frac_best_placement"] == 0.61 and path["placements"] == 5
     assert line["cpu_baseline"]["kind"] == "reference" and line["cpu_baseline"]["cores"] == 1 and line["cpu_baseline"]["all_cores"] == 64
