@@ -133,9 +133,6 @@ template <class T, int N> constexpr int lds_bytes() { return (2 * frames_per_gro
 #ifndef LRA_MIXED_MEL_WAVES
 #define LRA_MIXED_MEL_WAVES 6   // waves per SIMD the forward kernels are compiled for (80 VGPRs): what the LDS budget keeps resident
 #endif
-#ifndef LRA_MIXED_MEL_CHUNK8
-#define LRA_MIXED_MEL_CHUNK8 0
-#endif
 #ifndef LRA_MIXED_MEL_NNZ
 #define LRA_MIXED_MEL_NNZ 1536
 #endif
@@ -435,32 +432,26 @@ template <class T, int N, int MODE> __global__ __launch_bounds__(NT, (sizeof(T) 
             const int c0 = a.mel_c0[m], len = a.mel_len[m];
             const T* __restrict__ val = a.mel_val + a.mel_off[m];
             const T* p = prow + f * (M + 1) + c0;
-            // the band's weights eight (then four) at a time ahead of their use, the sum still in bin order: one dependent global load per bin was
-            // what this loop waited for
+            // the band's weights four at a time ahead of their use, the sum still in bin order (one dependent global load per bin was what this loop waited
+            // for); whole batches with plain consecutive loads (hipcc merges them), then ONE partial batch that loads the band's last weight again instead and
+            // skips the surplus products (clamped indices in every batch cost the merged loads: 3200 / 800 / 128 1.63 -> 2.76 ms)
             T acc = (T)0;
             int i = 0;
-#if LRA_MIXED_MEL_CHUNK8
-            for (; i + 8 <= len; i += 8) {
-                T vv[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) vv[q] = val[i + q];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) acc += vv[q] * p[i + q];
-            }
-            if (i + 4 <= len) {
-#else
             for (; i + 4 <= len; i += 4) {
-#endif
                 T vv[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) vv[q] = val[i + q];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc += vv[q] * p[i + q];
-#if LRA_MIXED_MEL_CHUNK8
-                i += 4;
-#endif
             }
-            for (; i < len; ++i) acc += val[i] * p[i];
+            if (i < len) {
+                T vv[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) vv[q] = val[i + q < len ? i + q : len - 1];
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (i + q < len) acc += vv[q] * p[i + q];
+            }
             a.Mel[((long long)clip * a.n_mels + m) * a.n_frames + f0 + f] = acc;
         }
     }
@@ -615,7 +606,21 @@ template <class T, int N> __device__ __forceinline__ void cqt_octave_body(const 
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc = cmadd_exact(acc, vv[q], dd[q]);
         }
-        for (; j < j1; ++j) acc = cmadd_exact(acc, a.val[j], d[a.col[j]]);
+        if (j < j1) {  // ONE partial batch (it loads the row's last entry again instead and skips the surplus products): no entry-by-entry tail of dependent loads
+            int cc[7];
+            cpx<T> vv[7], dd[7];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                const int jq = j + q < j1 ? j + q : j1 - 1;
+                cc[q] = a.col[jq];
+                vv[q] = a.val[jq];
+            }
+#pragma unroll
+            for (int q = 0; q < 7; ++q) dd[q] = d[cc[q]];
+#pragma unroll
+            for (int q = 0; q < 7; ++q)
+                if (j + q < j1) acc = cmadd_exact(acc, vv[q], dd[q]);
+        }
         if (a.sqrt_len) {
             const double scl = 1.0 / a.sqrt_len[r];
             acc = mkc<T>((T)((double)acc.x * scl), (T)((double)acc.y * scl));
