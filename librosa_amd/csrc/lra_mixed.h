@@ -1,4 +1,4 @@
-// lra_mixed.h -- fused forward transform for frame lengths that are not powers of two: n_fft = 2 M with M = 2^a 3^b 5^c
+// lra_mixed.h -- fused forward transform for frame lengths that are not powers of two: n_fft = 2 M with M = 2^a 3^b 5^c 7^d
 // (400 = the 25 ms frame of 16 kHz speech front ends, 320, 480, 640, 800, 960, 1200, 1600, ...).
 //
 // Reference semantics: librosa/core/spectrum.py:57-391 (stft: centre padding :287, framing :330-350, window multiply + rfft of the
@@ -74,6 +74,7 @@ constexpr Radices factor(int M) {
     if (M % 2 == 0) { f.r[f.n++] = 2; M /= 2; }
     while (M % 5 == 0) { f.r[f.n++] = 5; M /= 5; }
     while (M % 3 == 0) { f.r[f.n++] = 3; M /= 3; }
+    while (M % 7 == 0) { f.r[f.n++] = 7; M /= 7; }  // (round 6: 882 and 1764 samples = 20 / 40 ms at 44.1 kHz, M = 3^2 7^2 and 2 3^2 7^2)
     if (M != 1) f.n = 0;  // another prime: not served here
     return f;
 }
@@ -107,7 +108,7 @@ constexpr int stage_rounds_cost(int M, int F, int nt) {
     const Radices f = factor(M);
     int cost = ((F * M + nt - 1) / nt) * 15 + ((F * (M / 2 + 1) + nt - 1) / nt) * 40;  // frame load, Hermitian split
     for (int p = 0; p < f.n; ++p) {
-        const int r = f.r[p], w = r == 8 ? 100 : (r == 5 ? 75 : (r == 2 ? 20 : 40));
+        const int r = f.r[p], w = r == 8 ? 100 : (r == 7 ? 110 : (r == 5 ? 75 : (r == 2 ? 20 : 40)));
         cost += ((F * (M / r) + nt - 1) / nt) * w;
     }
     return cost;
@@ -216,6 +217,24 @@ template <class T> struct Dft<5, T> {
         v[4] = sub(m1, n1);
         v[2] = add(m2, n2);
         v[3] = sub(m2, n2);
+    }
+};
+template <class T> struct Dft<7, T> {
+    static __device__ __forceinline__ void run(cpx<T>* v) {
+        // X[k] = a_k - i b_k, X[7 - k] = a_k + i b_k with a_k = v0 + sum_n cos(2 pi n k / 7) (v[n] + v[7 - n]), b_k = sum_n sin(2 pi n k / 7) (v[n] - v[7 - n]), n = 1 .. 3
+        const T c1 = (T)0.62348980185873353053, c2 = (T)-0.22252093395631440429, c3 = (T)-0.90096886790241912624;  // cos(2 pi / 7), cos(4 pi / 7), cos(6 pi / 7)
+        const T n1 = (T)0.78183148246802980871, n2 = (T)0.97492791218182360702, n3 = (T)0.43388373911755812048;   // sin(2 pi / 7), sin(4 pi / 7), sin(6 pi / 7)
+        const cpx<T> t1 = add(v[1], v[6]), t2 = add(v[2], v[5]), t3 = add(v[3], v[4]), s1 = sub(v[1], v[6]), s2 = sub(v[2], v[5]), s3 = sub(v[3], v[4]);
+        const cpx<T> a1 = mkc<T>(fma_t(c3, t3.x, fma_t(c2, t2.x, fma_t(c1, t1.x, v[0].x))), fma_t(c3, t3.y, fma_t(c2, t2.y, fma_t(c1, t1.y, v[0].y))));
+        const cpx<T> a2 = mkc<T>(fma_t(c1, t3.x, fma_t(c3, t2.x, fma_t(c2, t1.x, v[0].x))), fma_t(c1, t3.y, fma_t(c3, t2.y, fma_t(c2, t1.y, v[0].y))));
+        const cpx<T> a3 = mkc<T>(fma_t(c2, t3.x, fma_t(c1, t2.x, fma_t(c3, t1.x, v[0].x))), fma_t(c2, t3.y, fma_t(c1, t2.y, fma_t(c3, t1.y, v[0].y))));
+        const cpx<T> b1 = mul_mi(mkc<T>(fma_t(n3, s3.x, fma_t(n2, s2.x, n1 * s1.x)), fma_t(n3, s3.y, fma_t(n2, s2.y, n1 * s1.y))));     // -i (n1 s1 + n2 s2 + n3 s3)
+        const cpx<T> b2 = mul_mi(mkc<T>(fma_t(-n1, s3.x, fma_t(-n3, s2.x, n2 * s1.x)), fma_t(-n1, s3.y, fma_t(-n3, s2.y, n2 * s1.y))));  // -i (n2 s1 - n3 s2 - n1 s3)
+        const cpx<T> b3 = mul_mi(mkc<T>(fma_t(n2, s3.x, fma_t(-n1, s2.x, n3 * s1.x)), fma_t(n2, s3.y, fma_t(-n1, s2.y, n3 * s1.y))));   // -i (n3 s1 - n1 s2 + n2 s3)
+        v[0] = add(v[0], add(t1, add(t2, t3)));
+        v[1] = add(a1, b1); v[6] = sub(a1, b1);
+        v[2] = add(a2, b2); v[5] = sub(a2, b2);
+        v[3] = add(a3, b3); v[4] = sub(a3, b3);
     }
 };
 template <class T> struct Dft<8, T> {

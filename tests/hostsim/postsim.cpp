@@ -280,6 +280,7 @@ template <class T> int sim_mixed_n(int n_fft, int mode, const lra::mixed::Args<T
         case 1000: return sim_mixed<T, 1000>(mode, a, batch);
         case 1200: return sim_mixed<T, 1200>(mode, a, batch);
         case 1280: return sim_mixed<T, 1280>(mode, a, batch);
+        case 882: return sim_mixed<T, 882>(mode, a, batch);    // 3 x 3 x 7 x 7 (round 6: radix 7)
         default: return 1;
     }
 }
@@ -329,6 +330,7 @@ template <class T> int sim_mixed_inv_n(int n_fft, const lra::mixed::InvArgs<T>& 
         case 480: return sim_mixed_inv<T, 480>(a, batch);
         case 1000: return sim_mixed_inv<T, 1000>(a, batch);
         case 1200: return sim_mixed_inv<T, 1200>(a, batch);
+        case 882: return sim_mixed_inv<T, 882>(a, batch);
         case 256: return sim_mixed_inv<T, 256>(a, batch);   // LRA_MIXED_INV_POW2: powers of two with a hop the register-tiled inverse does not take
         case 512: return sim_mixed_inv<T, 512>(a, batch);
         case 1024: return sim_mixed_inv<T, 1024>(a, batch);

@@ -1035,6 +1035,8 @@ def test_hpss_shims_through_simulator(monkeypatch):
         (1000, 250, 5000, True, "reflect", np.float32),    # 4 x 5 x 5 x 5
         (1200, 300, 6100, True, "constant", np.float32),   # 8 x 5 x 5 x 3: several frames per workgroup, a partial last group
         (1280, 320, 5000, True, "constant", np.float32),   # 8 x 8 x 2 x 5
+        (882, 441, 4500, True, "reflect", np.float32),     # 3 x 3 x 7 x 7: 20 ms / 10 ms at 44.1 kHz (odd M, odd padding: no 8-byte sample pairs)
+        (882, 220, 3000, False, "constant", np.float64),
     ],
 )
 def test_mixed_radix_stft_body(n_fft, hop, n, center, pad_mode, dtype):
@@ -1058,7 +1060,7 @@ def test_mixed_radix_stft_body(n_fft, hop, n, center, pad_mode, dtype):
     assert np.all(np.abs(S1 - np.abs(ref[:1])) <= (1e-11 if dtype == np.float64 else 1e-5) * np.abs(ref).max())
 
 
-@pytest.mark.parametrize("n_fft,hop,n_mels,sr,dtype", [(400, 160, 80, 16000, np.float32), (1200, 300, 64, 48000, np.float32), (240, 120, 20, 8000, np.float64)])
+@pytest.mark.parametrize("n_fft,hop,n_mels,sr,dtype", [(400, 160, 80, 16000, np.float32), (1200, 300, 64, 48000, np.float32), (240, 120, 20, 8000, np.float64), (882, 441, 64, 44100, np.float32)])
 def test_mixed_radix_mel_body(n_fft, hop, n_mels, sr, dtype):
     """librosa/feature/spectral.py:2022-2161 through the same launch (banded basis from LDS power rows); the reference's float32 basis values."""
     rng = np.random.default_rng(n_mels)
@@ -1084,6 +1086,7 @@ def test_mixed_radix_mel_body(n_fft, hop, n_mels, sr, dtype):
         (480, 240, 3000, True, "n", np.float64),      # (larger frames hold three per workgroup: the fused form needs hop >= n_fft / 2 there)
         (1000, 500, 9000, True, "n", np.float32),     # several groups per clip with a halo frame
         (1200, 600, 7000, True, "n", np.float32),
+        (882, 441, 6000, True, "n", np.float32),      # radix 7
         (512, 160, 5000, True, "n", np.float32),      # powers of two with a hop outside n_fft / {2, 4, 8, 16}: the same kernel (LRA_MIXED_INV_POW2)
         (512, 200, 4100, False, 4000, np.float64),
         (256, 100, 3000, True, 3300, np.float32),
