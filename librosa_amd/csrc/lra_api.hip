@@ -113,6 +113,8 @@ struct lra_ctx {
     int opt_cqt_merge = 1;           // lra_cqt_recursion_exec: 1 = octaves 1-2 in one launch beside the later halvings, 3 .. in one launch behind the chain (round 6); 2 = octaves 1 .. in one launch per frame length behind the chain (round 5); 0 = one launch per octave on the side stream
     int opt_hpss_tile = 1;           // hpss: a thread per 4 x 4 tile with shared sorted cores (hpss_tile_kernel); 0: a thread per element (A/B)
     int opt_mixed_inv_pow2 = 1;      // inverse, n_fft = 256 / 512 / 1024 with a hop outside n_fft / {2, 4, 8, 16}: the fused gather kernel of lra_mixed.h (0: istft_kernel's general mode)
+    int opt_ola4 = 1;                // general inverse path: four output samples per thread in the gather kernel (0: one, A/B)
+    int opt_mixed_irfft = 1;         // listed mixed-radix lengths too long for the fused gather kernel: mixed_irfft_kernel + ola_gather_kernel instead of spec_pack + rocFFT + ola_gather (0: A/B)
     int opt_mixed = 1;               // fused mixed-radix forward kernel for the listed non-power-of-two frame lengths (lra_mixed.h); 0: rocFFT path; 2: fused, mel band table read through the caches instead of staged in LDS (A/B)
     int opt_direct = 1;              // direct framing (no ring) for hop >= n_fft
     int opt_xcd_remap = 1;           // workgroup -> work item map that keeps neighbouring strips on one XCD (lra_kernels.h, xcd_block)
@@ -864,6 +866,54 @@ __global__ void ola_gather_kernel(const T* __restrict__ x, int N, int hop, int n
     y[(clip0 + c) * y_stride + s] = wss_is_norm ? acc * w : ((w > tinyv) ? acc / w : acc);
 }
 
+// The same sums, four output samples per thread (256 apart: every load instruction stays coalesced) with 32-bit position arithmetic, the frames of all four walked
+// together so that up to eight loads are in flight per trip, the normalisation factors fetched up front (round 6: the one-sample form waited 0.79 of its wave cycles
+// and ran at 1.5 TB/s; it stays for signals of 2^31 samples and more).
+template <class T>
+__global__ __launch_bounds__(256) void ola_gather4_kernel(const T* __restrict__ x, int N, int hop, int n_used, int drop, const T* __restrict__ ws, const T* __restrict__ wss, int wss_is_norm,
+                                                          T tinyv, long long clip0, long long clips, T* __restrict__ y, long long y_stride, unsigned out_len, unsigned chunks) {
+    const long long c = blockIdx.x / chunks;
+    const unsigned s0 = (blockIdx.x % chunks) * 1024u + threadIdx.x;
+    if (c >= clips) return;
+    const T* __restrict__ xc = x + c * (long long)n_used * N;
+    unsigned t_lo[4], cnt[4];
+    T w[4], acc[4];
+    unsigned most = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const unsigned s = s0 + u * 256u;
+        const bool ok = s < out_len;
+        const unsigned sp = (ok ? s : 0u) + (unsigned)drop;
+        const unsigned lo = sp + 1u <= (unsigned)N ? 0u : (sp + 1u - (unsigned)N + (unsigned)hop - 1u) / (unsigned)hop;
+        unsigned hi = sp / (unsigned)hop;
+        if (hi > (unsigned)n_used - 1u) hi = (unsigned)n_used - 1u;
+        t_lo[u] = lo;
+        cnt[u] = ok && hi >= lo ? hi - lo + 1u : 0u;
+        most = cnt[u] > most ? cnt[u] : most;
+        w[u] = wss[ok ? s : 0u];
+        acc[u] = (T)0;
+    }
+    for (unsigned j = 0; j < most; ++j) {
+        T a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool on = j < cnt[u];  // (a finished or empty sum re-reads element 0 of frame 0: always there, never used)
+            const unsigned t = on ? t_lo[u] + j : 0u;
+            const unsigned off = on ? s0 + u * 256u + (unsigned)drop - t * (unsigned)hop : 0u;
+            a[u] = ws[off];
+            b[u] = xc[(long long)t * N + off];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (j < cnt[u]) acc[u] += a[u] * b[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const unsigned s = s0 + u * 256u;
+        if (s < out_len) y[(clip0 + c) * y_stride + s] = wss_is_norm ? acc[u] * w[u] : ((w[u] > tinyv) ? acc[u] / w[u] : acc[u]);
+    }
+}
+
 template <class E> __global__ void transpose_kernel(const E* __restrict__ src, E* __restrict__ dst, long long rows, long long cols) {
     __shared__ E tile[32][33];
     const long long b = blockIdx.z;
@@ -1262,10 +1312,10 @@ int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_s
         if (p->d_mtw && ctx->opt_mixed) {
             const int fmax = mixed::inv_frames_max_of(N, (int)sizeof(T));
             const int halo = (N + p->hop - 1) / p->hop - 1;
-            // halo frames are recomputed by the neighbouring group: worth it while they are half of the work at most (round 6, with the faster kernel and LDS tiers up to
-            // 64 KB: 480 / 120 2.84 -> 1.73 ms, 640 / 160 3.05 -> 1.78, 800 / 200 2.77 -> 2.51, 1200 / 300 4.8 -> 4.2 against the rocFFT path; LRA_MIXED_INV_RULE_X2=4 restores
-            // round 4's own >= 2 halo for A/B)
-            static const int rule_x2 = std::getenv("LRA_MIXED_INV_RULE_X2") ? std::atoi(std::getenv("LRA_MIXED_INV_RULE_X2")) : 2;
+            // halo frames are recomputed by the neighbouring group: worth it while they are a third of the work at most; everything else takes the inverse transform alone
+            // (mixed_irfft_kernel) + the gather kernel below, which beats both the recomputing kernel at larger LDS tiers and the rocFFT path (round 6: 480 / 120 2.84 ->
+            // 1.62 ms, 800 / 200 2.77 -> 1.63, 1200 / 300 4.8 -> 2.25, 3200 / 800 4.75 -> 2.52; LRA_MIXED_INV_RULE_X2 moves the border for A/B)
+            static const int rule_x2 = std::getenv("LRA_MIXED_INV_RULE_X2") ? std::atoi(std::getenv("LRA_MIXED_INV_RULE_X2")) : 4;
             if (fmax - halo >= 1 && 2 * (fmax - halo) >= rule_x2 * halo) {
                 const void* nrm = wss;
                 if (!wss_is_norm) {
@@ -1373,14 +1423,39 @@ int istft_run(lra_istft_plan* p, const void* D, int64_t batch, int64_t d_batch_s
         const long long clips = std::min<long long>(group, batch - c0);
         const long long total = clips * n_used;
         const int chunks = (bins + 255) / 256;
+        if (!p->pow2 && p->d_mtw && ctx->opt_mixed && ctx->opt_mixed_irfft) {
+            // listed mixed-radix lengths whose frames are too long for the fused gather kernel: the inverse real transform as ONE launch (lra_mixed.h, mixed_irfft_kernel)
+            // instead of spec_pack + rocFFT C2R (round 6)
+            mixed::IrArgs<T> ia = mixed::IrArgs<T>();
+            ia.D = (const mixed::cpx<T>*)D + c0 * d_batch_stride;
+            ia.d_batch_stride = d_batch_stride;
+            ia.d_frame_stride = d_frame_stride;
+            ia.n_used = (int)n_used;
+            ia.tw_m = (const mixed::cpx<T>*)p->d_mtw;
+            ia.tw_n = (const mixed::cpx<T>*)p->d_mtwn;
+            ia.frames = (T*)p->frames.p;
+            const int F = mixed::frames_per_group_of(N, (int)sizeof(T));
+            ia.groups_per_clip = (int)((n_used + F - 1) / F);
+            hipError_t e;
+            if constexpr (sizeof(T) == 8) e = mixed::launch_irfft_f64(N, ia, clips, ctx->stream);
+            else e = mixed::launch_irfft_f32(N, ia, clips, ctx->stream);
+            if (e != hipSuccess) return fail(LRA_EHIP, std::string("mixed-radix inverse transform launch: ") + hipGetErrorString(e));
+        } else {
         hipLaunchKernelGGL(spec_pack_kernel<T>, dim3((unsigned)(total * chunks)), dim3(256), 0, ctx->stream, (const cx<T>*)D, (long long)d_batch_stride,
                            (long long)d_frame_stride, (int)n_used, bins, (N % 2) == 0 ? 1 : 0, c0, total, (cx<T>*)p->spec.p);
         LRA_HIP(hipGetLastError());
         LRA_TRY(run_rocfft_chunked(p->fft, ctx, rocfft_transform_type_real_inverse, p->dtype, N, total, (char*)p->spec.p, (size_t)bins * sizeof(cx<T>),
                                    (char*)p->frames.p, (size_t)N * sizeof(T)));
+        }
         const long long ochunks = (out_len + 255) / 256;
-        hipLaunchKernelGGL(ola_gather_kernel<T>, dim3((unsigned)(clips * ochunks)), dim3(256), 0, ctx->stream, (const T*)p->frames.p, N, p->hop, (int)n_used,
-                           p->center ? N / 2 : 0, (const T*)p->d_win_scaled, (const T*)wss, wss_is_norm, tinyv, c0, clips, (T*)y, (long long)y_stride, (long long)out_len);
+        const long long ochunks4 = (out_len + 1023) / 1024;
+        if (ctx->opt_ola4 && out_len + (long long)N + 2048 < 0x7fffffffLL && n_used >= 1 && clips * ochunks4 < 0x7fffffffLL)
+            hipLaunchKernelGGL(ola_gather4_kernel<T>, dim3((unsigned)(clips * ochunks4)), dim3(256), 0, ctx->stream, (const T*)p->frames.p, N, p->hop, (int)n_used,
+                               p->center ? N / 2 : 0, (const T*)p->d_win_scaled, (const T*)wss, wss_is_norm, tinyv, c0, clips, (T*)y, (long long)y_stride, (unsigned)out_len,
+                               (unsigned)ochunks4);
+        else
+            hipLaunchKernelGGL(ola_gather_kernel<T>, dim3((unsigned)(clips * ochunks)), dim3(256), 0, ctx->stream, (const T*)p->frames.p, N, p->hop, (int)n_used,
+                               p->center ? N / 2 : 0, (const T*)p->d_win_scaled, (const T*)wss, wss_is_norm, tinyv, c0, clips, (T*)y, (long long)y_stride, (long long)out_len);
         LRA_HIP(hipGetLastError());
     }
     return scratch_release(p->fft, ctx->stream);
@@ -1876,6 +1951,8 @@ int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value) {
     else if (!std::strcmp(key, "direct")) ctx->opt_direct = value != 0;
     else if (!std::strcmp(key, "mixed")) ctx->opt_mixed = value == 2 ? 2 : (value != 0);
     else if (!std::strcmp(key, "hpss_tile")) ctx->opt_hpss_tile = value != 0;
+    else if (!std::strcmp(key, "ola4")) ctx->opt_ola4 = value != 0;
+    else if (!std::strcmp(key, "mixed_irfft")) ctx->opt_mixed_irfft = value != 0;
     else if (!std::strcmp(key, "mixed_inv_pow2")) ctx->opt_mixed_inv_pow2 = value != 0;
     else if (!std::strcmp(key, "autotune")) ctx->opt_autotune = value != 0;
     else if (!std::strcmp(key, "mel_runs")) ctx->opt_mel_runs = value != 0;

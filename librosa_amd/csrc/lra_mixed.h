@@ -694,15 +694,15 @@ template <class T> struct InvArgs {
 };
 // Frames resident per workgroup (own + halo).  The halo frames are recomputed work, so the group must be long against the halo (the host
 // takes this kernel only when own >= 2 halo, lra_api.hip), but LDS per workgroup is residency (measured, 400 / 160, 256 x 30 s: 24 KB 1.00 ms,
-// 32 KB 1.02, 48 KB 1.21, 64 KB 1.55; 800 / 200 at 64 KB: 2.89 ms against 2.79 for the rocFFT path): the smallest of 24 / 32 / 48 / 64 KB that holds
-// nine frames (six own + the three halo frames of a 4 x overlap), else what 64 KB holds (round 6: the larger tiers pay now that the kernel's loads are
-// batched -- 480 / 120 at 48 KB 1.73 ms against 2.84 for the rocFFT path, 800 / 200 at 64 KB 2.51 against 2.77); frames that fail the host's rule keep
-// the rocFFT path.
+// 32 KB 1.02, 48 KB 1.21, 64 KB 1.55; 800 / 200 at 64 KB: 2.89 ms against 2.79 for the rocFFT path): 24 KB, or 32 KB where that is what holds
+// nine frames (six own + the three halo frames of a 4 x overlap); larger frames fail the host's rule and take mixed_irfft_kernel + ola_gather_kernel
+// (round 6: with this kernel's loads batched, 48 / 64 KB tiers were measured too -- 480 / 120 at 48 KB 1.73 ms, 800 / 200 at 64 KB 2.51 -- and lose to
+// that pair: 1.62 / 1.63 ms).
 template <class T, int N> constexpr int inv_frames_max() {
     constexpr int M = N / 2;
     constexpr int per_frame = 2 * M * 2 * (int)sizeof(T), table = M * 2 * (int)sizeof(T);
     int f = 0;
-    for (int kb : {24, 32, 48, 64}) {
+    for (int kb : {24, 32}) {
         f = (kb * 1024 - table) / per_frame;
         if (f >= 9) break;
     }
@@ -710,8 +710,90 @@ template <class T, int N> constexpr int inv_frames_max() {
 }
 template <class T, int N> constexpr int inv_lds_bytes() { return (2 * inv_frames_max<T, N>() * (N / 2) + N / 2) * 2 * (int)sizeof(T); }
 
+// Stage (1) of both inverse kernels: the W_M table -> LDS and the Hermitian un-split of `frames` spectra (X0: the first one, d_frame_stride apart, M + 1 bins each) into
+// buf0[f][k] = conj Z'[k],  Z'[k] = E' + i O',  E' = X[k] + conj X[M-k],  O' = (X[k] - conj X[M-k]) conj W_N^k (the imaginary parts of X[0] and X[M] are ignored, as pocketfft's
+// c2r does).  The table, both bins of every pair and its W_N^k are loaded ahead of the first use (compile-time trip counts, round 6: see mixed_stft_kernel).
+template <class T, int N, int FR>
+__device__ __forceinline__ void unsplit_stage(cpx<T>* buf0, cpx<T>* twm, const cpx<T>* __restrict__ X0, long long d_frame_stride, int frames, const cpx<T>* __restrict__ tw_m,
+                                              const cpx<T>* __restrict__ tw_n) {
+    constexpr int M = N / 2, HP = M / 2 + 1;
+    constexpr int IT0 = (M + NT - 1) / NT, IT1 = (FR * HP + NT - 1) / NT;
+    cpx<T> tw0[IT0], xk[IT1], xm[IT1], wc[IT1];
+#pragma unroll
+    for (int it = 0; it < IT0; ++it) {
+        const int t = (int)threadIdx.x + it * NT;
+        tw0[it] = tw_m[t < M ? t : 0];
+    }
+#pragma unroll
+    for (int it = 0; it < IT1; ++it) {
+        const int w = (int)threadIdx.x + it * NT;
+        if (w < frames * HP) {
+            const int f = w / HP, k = w - f * HP;
+            const cpx<T>* __restrict__ X = X0 + (long long)f * d_frame_stride;
+            xk[it] = X[k];
+            xm[it] = X[M - k];
+            wc[it] = tw_n[k];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < IT0; ++it) {
+        const int t = (int)threadIdx.x + it * NT;
+        if (t < M) twm[t] = tw0[it];
+    }
+#pragma unroll
+    for (int it = 0; it < IT1; ++it) {
+        const int w = (int)threadIdx.x + it * NT;
+        if (w >= frames * HP) break;
+        const int f = w / HP, k = w - f * HP;
+        cpx<T> x0 = xk[it], x1 = xm[it];
+        if (k == 0) { x0.y = (T)0; x1.y = (T)0; }
+        const cpx<T> e = mkc<T>(x0.x + x1.x, x0.y - x1.y), d = mkc<T>(x0.x - x1.x, x0.y + x1.y);
+        const cpx<T> o = mkc<T>(fma_t(d.y, wc[it].y, d.x * wc[it].x), fma_t(-d.x, wc[it].y, d.y * wc[it].x));  // d * conj(w)
+        // conj Z'[k] = conj(E') - i conj(O') = (e.x - o.y, -e.y - o.x);  conj Z'[M-k] = E' - i O' = (e.x + o.y, e.y - o.x)
+        buf0[f * M + k] = mkc<T>(e.x - o.y, -e.y - o.x);
+        if (k > 0 && 2 * k != M) buf0[f * M + M - k] = mkc<T>(e.x + o.y, e.y - o.x);
+    }
+}
+
+// The inverse real transform ALONE (round 6): frames too long for the gather kernel below (its own frames must outnumber the recomputed halo in 64 KB of LDS) used to go
+// spec_pack_kernel -> rocFFT C2R -> ola_gather_kernel; this launch replaces the first two -- un-split, the forward passes on the conjugate, and every frame's N samples
+// (N irfft, what rocFFT's unnormalised C2R leaves: the gather kernel multiplies by window / N) written once, 8 bytes per lane -- with the forward kernel's geometry.
+template <class T> struct IrArgs {
+    const cpx<T>* D;            // clip c of this launch at D + c * d_batch_stride; frames d_frame_stride apart, M + 1 bins each
+    long long d_batch_stride, d_frame_stride;
+    int n_used;
+    const cpx<T>* tw_m;
+    const cpx<T>* tw_n;
+    T* frames;                  // [clip][n_used][N]
+    int groups_per_clip;        // ceil(n_used / frames_per_group)
+};
+template <class T, int N> __global__ __launch_bounds__(NT) void mixed_irfft_kernel(IrArgs<T> a) {
+    constexpr int M = N / 2, F = frames_per_group<T, N>();
+    LRA_MIXED_DYN_LDS(lds);
+    cpx<T>* buf0 = reinterpret_cast<cpx<T>*>(lds);
+    cpx<T>* buf1 = buf0 + F * M;
+    cpx<T>* twm = buf1 + F * M;
+    const long long clip = (long long)(blockIdx.x / (unsigned)a.groups_per_clip);
+    const int f0 = (int)(blockIdx.x % (unsigned)a.groups_per_clip) * F;
+    const int frames = a.n_used - f0 < F ? a.n_used - f0 : F;
+    unsplit_stage<T, N, F>(buf0, twm, a.D + clip * a.d_batch_stride + (long long)f0 * a.d_frame_stride, a.d_frame_stride, frames, a.tw_m, a.tw_n);
+    __syncthreads();
+    cpx<T>* src = buf0;
+    cpx<T>* dst = buf1;
+    Passes<T, N, 0, F>::run(src, dst, twm, frames);  // Y = FFT(conj Z') = conj(M z): sample pair m of a frame = (Y.x, -Y.y)
+    cpx<T>* __restrict__ out = reinterpret_cast<cpx<T>*>(a.frames + (clip * a.n_used + f0) * (long long)N);
+    constexpr int IT = (F * M + NT - 1) / NT;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int w = (int)threadIdx.x + it * NT;
+        if (w >= frames * M) break;
+        const cpx<T> v = src[w];
+        out[w] = mkc<T>(v.x, -v.y);  // (frames of a group are consecutive: position w of the group is pair w of its first frame's row)
+    }
+}
+
 template <class T, int N> __global__ __launch_bounds__(NT) void mixed_istft_kernel(InvArgs<T> a) {
-    constexpr int M = N / 2, FMAX = inv_frames_max<T, N>(), HP = M / 2 + 1;
+    constexpr int M = N / 2, FMAX = inv_frames_max<T, N>();
     LRA_MIXED_DYN_LDS(lds);
     cpx<T>* buf0 = reinterpret_cast<cpx<T>*>(lds);
     cpx<T>* buf1 = buf0 + FMAX * M;
@@ -724,46 +806,8 @@ template <class T, int N> __global__ __launch_bounds__(NT) void mixed_istft_kern
     int t_end = t_own + a.group_hops;                             // one past the last frame transformed here
     if (t_end > a.n_used || last) t_end = a.n_used;
     const int frames = t_end - t_first;                           // <= group_hops + halo <= FMAX (host)
-    // (1) Hermitian un-split: buf0[f][k] = conj Z'[k],  Z'[k] = E' + i O',  E' = X[k] + conj X[M-k],  O' = (X[k] - conj X[M-k]) conj W_N^k.
-    // The table, both bins of every pair and its W_N^k are loaded ahead of the first use (compile-time trip counts, round 6: see mixed_stft_kernel).
-    constexpr int IT0 = (M + NT - 1) / NT, IT1 = (FMAX * HP + NT - 1) / NT;
-    {
-        cpx<T> tw0[IT0], xk[IT1], xm[IT1], wc[IT1];
-#pragma unroll
-        for (int it = 0; it < IT0; ++it) {
-            const int t = (int)threadIdx.x + it * NT;
-            tw0[it] = a.tw_m[t < M ? t : 0];
-        }
-#pragma unroll
-        for (int it = 0; it < IT1; ++it) {
-            const int w = (int)threadIdx.x + it * NT;
-            if (w < frames * HP) {
-                const int f = w / HP, k = w - f * HP;
-                const cpx<T>* __restrict__ X = a.D + clip * a.d_batch_stride + (long long)(t_first + f) * a.d_frame_stride;
-                xk[it] = X[k];
-                xm[it] = X[M - k];
-                wc[it] = a.tw_n[k];
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < IT0; ++it) {
-            const int t = (int)threadIdx.x + it * NT;
-            if (t < M) twm[t] = tw0[it];
-        }
-#pragma unroll
-        for (int it = 0; it < IT1; ++it) {
-            const int w = (int)threadIdx.x + it * NT;
-            if (w >= frames * HP) break;
-            const int f = w / HP, k = w - f * HP;
-            cpx<T> x0 = xk[it], x1 = xm[it];
-            if (k == 0) { x0.y = (T)0; x1.y = (T)0; }
-            const cpx<T> e = mkc<T>(x0.x + x1.x, x0.y - x1.y), d = mkc<T>(x0.x - x1.x, x0.y + x1.y);
-            const cpx<T> o = mkc<T>(fma_t(d.y, wc[it].y, d.x * wc[it].x), fma_t(-d.x, wc[it].y, d.y * wc[it].x));  // d * conj(w)
-            // conj Z'[k] = conj(E') - i conj(O') = (e.x - o.y, -e.y - o.x);  conj Z'[M-k] = E' - i O' = (e.x + o.y, e.y - o.x)
-            buf0[f * M + k] = mkc<T>(e.x - o.y, -e.y - o.x);
-            if (k > 0 && 2 * k != M) buf0[f * M + M - k] = mkc<T>(e.x + o.y, e.y - o.x);
-        }
-    }
+    // (1) Hermitian un-split + W_M table (unsplit_stage above)
+    unsplit_stage<T, N, FMAX>(buf0, twm, a.D + clip * a.d_batch_stride + (long long)t_first * a.d_frame_stride, a.d_frame_stride, frames, a.tw_m, a.tw_n);
     __syncthreads();
     // (2) forward passes: Y = FFT(conj Z') = conj(M z)
     cpx<T>* src = buf0;

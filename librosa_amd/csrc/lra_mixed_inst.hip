@@ -58,6 +58,31 @@ template <class T> hipError_t launch_inv_t(int n_fft, const InvArgs<T>& a, long 
     }
 }
 
+template <class T, int N> hipError_t launch_irfft_n(const IrArgs<T>& a, long long clips, hipStream_t stream) {
+    constexpr int lds = lds_bytes<T, N>();
+    const long long grid = clips * a.groups_per_clip;
+    if (grid <= 0) return hipSuccess;
+    if (grid > 0x7ffffff0LL) return hipErrorInvalidConfiguration;
+    void (*kern)(IrArgs<T>) = mixed_irfft_kernel<T, N>;
+    if (lds > 65536) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, stream, a);
+    return hipGetLastError();
+}
+template <class T> hipError_t launch_irfft_t(int n_fft, const IrArgs<T>& a, long long clips, hipStream_t stream) {
+    switch (n_fft) {
+#define LRA_MIXED_CASE(N) \
+    case N: return launch_irfft_n<T, N>(a, clips, stream);
+        LRA_MIXED_SIZES(LRA_MIXED_CASE)
+#undef LRA_MIXED_CASE
+        default: return hipErrorInvalidValue;
+    }
+}
+hipError_t launch_irfft_f32(int n_fft, const IrArgs<float>& a, long long clips, hipStream_t stream) { return launch_irfft_t<float>(n_fft, a, clips, stream); }
+hipError_t launch_irfft_f64(int n_fft, const IrArgs<double>& a, long long clips, hipStream_t stream) { return launch_irfft_t<double>(n_fft, a, clips, stream); }
+
 template <class T, int N> hipError_t launch_cqt_n(const CqtArgs<T>& a, long long batch, hipStream_t stream) {
     constexpr int lds = cqt_lds_bytes<T, N>();
     const long long grid = batch * a.groups_per_clip;

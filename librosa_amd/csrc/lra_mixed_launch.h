@@ -54,6 +54,8 @@ hipError_t launch_cqt_f32(int n_fft, const CqtArgs<float>& a, long long batch, h
 hipError_t launch_cqt_f64(int n_fft, const CqtArgs<double>& a, long long batch, hipStream_t stream);
 hipError_t launch_cqt_multi_f32(int n_fft, const CqtMultiArgs<float>& m, hipStream_t stream);
 hipError_t launch_cqt_multi_f64(int n_fft, const CqtMultiArgs<double>& m, hipStream_t stream);
+hipError_t launch_irfft_f32(int n_fft, const IrArgs<float>& a, long long clips, hipStream_t stream);   // the inverse real transform alone (frames -> HBM), forward geometry
+hipError_t launch_irfft_f64(int n_fft, const IrArgs<double>& a, long long clips, hipStream_t stream);
 int inv_frames_max_of(int n_fft, int elem_bytes);  // frames (own + halo) the inverse kernel holds per workgroup
 hipError_t launch_inv_f32(int n_fft, const InvArgs<float>& a, long long batch, hipStream_t stream);
 hipError_t launch_inv_f64(int n_fft, const InvArgs<double>& a, long long batch, hipStream_t stream);

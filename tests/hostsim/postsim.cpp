@@ -360,6 +360,42 @@ extern "C" int postsim_mixed_istft(int n_fft, int is_f64, const void* D, long lo
     return sim_mixed_inv_n<float>(n_fft, a, batch);
 }
 
+// the inverse real transform alone (mixed_irfft_kernel: what lra_api.hip's general inverse path launches for listed lengths too long for the gather kernel)
+namespace {
+template <class T, int N> int sim_mixed_irfft(lra::mixed::IrArgs<T> a, long long batch) {
+    using namespace lra::mixed;
+    constexpr int F = frames_per_group<T, N>();
+    a.groups_per_clip = (a.n_used + F - 1) / F;
+    run_grid((unsigned)(batch * a.groups_per_clip), NT, [=] { mixed_irfft_kernel<T, N>(a); });
+    return 0;
+}
+template <class T> int sim_mixed_irfft_n(int n_fft, const lra::mixed::IrArgs<T>& a, long long batch) {
+    switch (n_fft) {
+        case 400: return sim_mixed_irfft<T, 400>(a, batch);
+        case 882: return sim_mixed_irfft<T, 882>(a, batch);
+        case 1200: return sim_mixed_irfft<T, 1200>(a, batch);
+        case 1280: return sim_mixed_irfft<T, 1280>(a, batch);
+        default: return 1;
+    }
+}
+}  // namespace
+extern "C" int postsim_mixed_irfft(int n_fft, int is_f64, const void* D, long long batch, int n_used, const void* tw_m, const void* tw_n, void* frames) {
+    auto fill = [&](auto& a, auto tag) {
+        using T = decltype(tag);
+        const int M = n_fft / 2;
+        a.D = (const lra::mixed::cpx<T>*)D; a.d_frame_stride = M + 1; a.d_batch_stride = (long long)n_used * (M + 1); a.n_used = n_used;
+        a.tw_m = (const lra::mixed::cpx<T>*)tw_m; a.tw_n = (const lra::mixed::cpx<T>*)tw_n; a.frames = (T*)frames;
+    };
+    if (is_f64) {
+        lra::mixed::IrArgs<double> a = lra::mixed::IrArgs<double>();
+        fill(a, double());
+        return sim_mixed_irfft_n<double>(n_fft, a, batch);
+    }
+    lra::mixed::IrArgs<float> a = lra::mixed::IrArgs<float>();
+    fill(a, float());
+    return sim_mixed_irfft_n<float>(n_fft, a, batch);
+}
+
 namespace {
 template <class T, int N> int sim_cqt_octave(lra::mixed::CqtArgs<T> a, long long batch) {
     using namespace lra::mixed;

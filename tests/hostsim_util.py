@@ -304,6 +304,26 @@ def mixed_stft(y, n_fft, hop, window, *, mode="stft", center=True, pad_mode="con
     return out
 
 
+def mixed_irfft(D, n_fft):
+    """mixed_irfft_kernel (csrc/lra_mixed.h) through the simulator: D (batch, T, M + 1) complex, frame-major -> (batch, T, n_fft) real = n_fft * irfft (rocFFT's
+    unnormalised C2R); the output arrives full of NaN."""
+    D = np.ascontiguousarray(D)
+    f64 = D.dtype == np.complex128
+    rt = np.float64 if f64 else np.float32
+    batch, T, bins = D.shape
+    M = n_fft // 2
+    assert bins == M + 1
+    tw_m = np.ascontiguousarray(np.exp(-2j * np.pi * np.arange(M, dtype=np.float64) / M).astype(D.dtype))
+    tw_n = np.ascontiguousarray(np.exp(-2j * np.pi * np.arange(M + 1, dtype=np.float64) / n_fft).astype(D.dtype))
+    out = np.full((batch, T, n_fft), np.nan, dtype=rt)
+    fn = post_lib().postsim_mixed_irfft
+    c = ctypes
+    fn.argtypes = [c.c_int, c.c_int, c.c_void_p, c.c_longlong, c.c_int, c.c_void_p, c.c_void_p, c.c_void_p]
+    rc = fn(n_fft, int(f64), _p(D), batch, T, _p(tw_m), _p(tw_n), _p(out))
+    assert rc == 0, f"simulator: n_fft={n_fft} not served (rc {rc})"
+    return out
+
+
 def mixed_istft(D, n_fft, hop, win, wss, out_len, n_used, center=True):
     """The fused mixed-radix inverse kernel (csrc/lra_mixed.h) through the simulator; D: (batch, T, M + 1) complex, frame-major.  The output arrives full of NaN and
     only what lra_api.hip's wrapper clears (samples past the last frame's end) is zeroed: every other sample must be stored by the kernel."""

@@ -1073,6 +1073,20 @@ def test_mixed_radix_mel_body(n_fft, hop, n_mels, sr, dtype):
     assert np.all(np.abs(got - ref) <= (1e-11 if dtype == np.float64 else 1e-4) * np.abs(ref) + (1e-12 if dtype == np.float64 else 1e-6) * ref.max())
 
 
+@pytest.mark.parametrize("n_fft,frames,dtype", [(400, 13, np.float32), (882, 5, np.float32), (1200, 7, np.float64), (1280, 3, np.float32)])
+def test_mixed_radix_irfft_body(n_fft, frames, dtype):
+    """The inverse real transform alone (mixed_irfft_kernel, round 6: listed lengths too long for the gather kernel; replaces spec_pack + rocFFT C2R of the general
+    inverse path, librosa/core/spectrum.py:598): n_fft * irfft of every frame, the imaginary parts of the DC / Nyquist bins ignored as pocketfft's c2r does,
+    NaN-prefilled output, partial last group."""
+    rng = np.random.default_rng(n_fft)
+    ct = np.complex128 if dtype == np.float64 else np.complex64
+    D = (rng.standard_normal((2, frames, n_fft // 2 + 1)) + 1j * rng.standard_normal((2, frames, n_fft // 2 + 1))).astype(ct)
+    got = H.mixed_irfft(D, n_fft)
+    ref = np.fft.irfft(D.astype(np.complex128), n=n_fft, axis=-1) * n_fft
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= (1e-11 if dtype == np.float64 else 3e-6) * np.abs(ref).max()
+
+
 @pytest.mark.parametrize(
     "n_fft,hop,n,center,length,dtype",
     [
