@@ -9,7 +9,7 @@
 // frame lengths n_fft = 2 M, M = 2^a 3^b 5^c 7^d, served by one fused launch (everything else that is not a power of two keeps the rocFFT
 // path): the 15 / 20 / 25 / 30 / 40 / 50 / 60 ms frames of 8, 16, 22.05 (rounded), 32 and 48 kHz front ends and their doubles; round 6: radix 7 for the
 // 20 / 40 / 60 / 80 ms frames of 44.1 kHz (882 = 2 3^2 7^2, 1764, 2646, 3528 samples)
-#define LRA_MIXED_SIZES(X) X(160) X(200) X(240) X(320) X(400) X(480) X(640) X(800) X(882) X(960) X(1000) X(1200) X(1280) X(1440) X(1600) X(1764) X(1920) X(2000) X(2400) X(2646) X(3200) X(3528) X(4800)
+#define LRA_MIXED_SIZES(X) X(160) X(200) X(240) X(320) X(400) X(480) X(600) X(640) X(720) X(800) X(882) X(960) X(1000) X(1200) X(1280) X(1440) X(1600) X(1764) X(1920) X(2000) X(2400) X(2646) X(3200) X(3528) X(4800)
 
 // INVERSE only: power-of-two frame lengths whose hop does not divide them the way the register-tiled inverse wants (n_fft / {2, 4, 8, 16}) --
 // n_fft = 512 with hop 160 (25 ms windows padded to 512 at 16 kHz), 1024 with 441, ... -- take the fused gather kernel of this file instead of

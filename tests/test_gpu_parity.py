@@ -1614,7 +1614,7 @@ def test_numpy_batch_shards_in_process(L, monkeypatch):
 
 @pytest.mark.parametrize("n_fft,hop,sr,n_mels", [(400, 160, 16000, 80), (320, 160, 16000, 40), (480, 120, 48000, 64), (800, 200, 16000, 128), (960, 480, 48000, 80),
                                                  (1200, 300, 48000, 128), (1600, 400, 16000, 80), (2400, 600, 48000, 128), (240, 80, 8000, 20), (4800, 1200, 48000, 128),
-                                                 (882, 441, 44100, 64), (1764, 441, 44100, 128), (2646, 882, 44100, 128), (3528, 882, 44100, 128)])
+                                                 (882, 441, 44100, 64), (1764, 441, 44100, 128), (2646, 882, 44100, 128), (3528, 882, 44100, 128), (600, 240, 24000, 80), (720, 180, 48000, 64)])
 def test_mixed_radix_frames_fused(L, n_fft, hop, sr, n_mels):
     """Frame lengths 2^a 3^b 5^c (400 / 160 = the 25 ms / 10 ms front end of 16 kHz speech models; reference sizes: tests/test_core.py:256-292) run ONE fused
     launch (csrc/lra_mixed.h) instead of framing + rocFFT + transpose + banded product: stft, |X|^p and melspectrogram against the oracle, the pad modes,
