@@ -113,6 +113,7 @@ struct lra_ctx {
     int opt_cqt_merge = 1;           // lra_cqt_recursion_exec: 1 = octaves 1-2 in one launch beside the later halvings, 3 .. in one launch behind the chain (round 6); 2 = octaves 1 .. in one launch per frame length behind the chain (round 5); 0 = one launch per octave on the side stream
     int opt_hpss_tile = 1;           // hpss: a thread per 4 x 4 tile with shared sorted cores (hpss_tile_kernel); 0: a thread per element (A/B)
     int opt_mixed_inv_pow2 = 1;      // inverse, n_fft = 256 / 512 / 1024 with a hop outside n_fft / {2, 4, 8, 16}: the fused gather kernel of lra_mixed.h (0: istft_kernel's general mode)
+    int opt_mixed_pow2_mel = 1;      // fused mel at n_fft 128 / 256: the flat-index kernel of lra_mixed.h instead of the register-tiled one (0: A/B)
     int opt_ola4 = 1;                // general inverse path: four output samples per thread in the gather kernel (0: one, A/B)
     int opt_mixed_irfft = 1;         // listed mixed-radix lengths too long for the fused gather kernel: mixed_irfft_kernel + ola_gather_kernel instead of spec_pack + rocFFT + ola_gather (0: A/B)
     int opt_mixed = 1;               // fused mixed-radix forward kernel for the listed non-power-of-two frame lengths (lra_mixed.h); 0: rocFFT path; 2: fused, mel band table read through the caches instead of staged in LDS (A/B)
@@ -281,6 +282,7 @@ struct lra_stft_plan {
     bool pow2 = false;
     int logm = 0;
     void* d_win = nullptr;
+    void* d_win_full = nullptr;  // powers of two in lra_mixed_launch.h's forward list: the window itself (d_win holds 0.5 x window there), for the flat-index mel kernel
     void* d_tw[kNumVariants] = {};
     int tuned_variant[4] = {-1, -1, -1, -1};  // per epilogue mode (autotune), -1 = not measured yet  // pass-twiddle tables; their layout depends on the kernel configuration
     void* d_twr = nullptr;
@@ -1132,7 +1134,12 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
         if (mel->n_bins != bins) return fail(LRA_EINVAL, "mel basis has " + std::to_string(mel->n_bins) + " bins, stft has " + std::to_string(bins));
         if (mel->dtype != p->dtype) return fail(LRA_EINVAL, "mel plan dtype differs from stft plan dtype");
     }
-    if (p->pow2) {
+    // (powers of two in lra_mixed_launch.h's forward list: the fused mel goes to the flat-index kernel further down, everything else stays here)
+    // where it wins, measured on 256 x 30 s: n_fft 256 from 56 bands (80 bands at hop 64: 2.02 -> 1.28 ms; 48 bands 0.92 against 1.15: stays), n_fft 128 from 40
+    // (64 bands at hop 32: 3.63 -> 2.06; 32 bands 1.51 against 1.71: stays)
+    const bool pow2_mel_mixed = p->pow2 && mode == OUT_MEL && p->d_mtw && ctx->opt_mixed && ctx->opt_mixed_pow2_mel && row_pitch == bins && mel &&
+                                mel->n_mels >= (p->n_fft >= 256 ? 56 : 40);
+    if (p->pow2 && !pow2_mel_mixed) {
         StftLaunch<T> L;
         L.a = StftArgs<T>();
         L.a.y = (const T*)y;
@@ -1213,7 +1220,7 @@ int stft_run(lra_stft_plan* p, int mode, const void* y, int64_t batch, int64_t n
         a.hop = p->hop;
         a.pad = p->center ? p->n_fft / 2 : 0;
         a.pad_mode = p->pad_mode;
-        a.win = (const T*)p->d_win;
+        a.win = (const T*)(p->pow2 ? p->d_win_full : p->d_win);
         a.tw_m = (const mixed::cpx<T>*)p->d_mtw;
         a.tw_n = (const mixed::cpx<T>*)p->d_mtwn;
         a.power_mode = power_mode_of(power);
@@ -1951,6 +1958,7 @@ int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value) {
     else if (!std::strcmp(key, "direct")) ctx->opt_direct = value != 0;
     else if (!std::strcmp(key, "mixed")) ctx->opt_mixed = value == 2 ? 2 : (value != 0);
     else if (!std::strcmp(key, "hpss_tile")) ctx->opt_hpss_tile = value != 0;
+    else if (!std::strcmp(key, "mixed_pow2_mel")) ctx->opt_mixed_pow2_mel = value != 0;
     else if (!std::strcmp(key, "ola4")) ctx->opt_ola4 = value != 0;
     else if (!std::strcmp(key, "mixed_irfft")) ctx->opt_mixed_irfft = value != 0;
     else if (!std::strcmp(key, "mixed_inv_pow2")) ctx->opt_mixed_inv_pow2 = value != 0;
@@ -2323,7 +2331,8 @@ int lra_stft_plan_create(lra_ctx* ctx, int n_fft, int hop_length, const void* wi
     } else {
         rc = upload(&p->d_win, window_host, (size_t)n_fft * real_bytes(dtype));
     }
-    if (rc == LRA_OK && !p->pow2 && mixed::in_size_list(n_fft)) rc = mixed_tables(n_fft, dtype, &p->d_mtw, &p->d_mtwn);
+    if (rc == LRA_OK && ((!p->pow2 && mixed::in_size_list(n_fft)) || (p->pow2 && mixed::in_fwd_pow2_list(n_fft)))) rc = mixed_tables(n_fft, dtype, &p->d_mtw, &p->d_mtwn);
+    if (rc == LRA_OK && p->pow2 && mixed::in_fwd_pow2_list(n_fft)) rc = upload(&p->d_win_full, window_host, (size_t)n_fft * real_bytes(dtype));
     if (rc == LRA_OK && p->pow2) {
         p->logm = log2_exact(n_fft) - 1;
         rc = dtype == LRA_F64 ? build_tables<double>(p->logm, p->d_tw, &p->d_twr) : build_tables<float>(p->logm, p->d_tw, &p->d_twr);
@@ -2340,6 +2349,7 @@ void lra_stft_plan_destroy(lra_stft_plan* p) {
     if (!p) return;
     DeviceGuard device_guard__(p->ctx->device);
     if (p->d_win) (void)hipFree(p->d_win);
+    if (p->d_win_full) (void)hipFree(p->d_win_full);
     for (int v = 0; v < kNumVariants; ++v)
         if (p->d_tw[v]) (void)hipFree(p->d_tw[v]);
     if (p->d_twr) (void)hipFree(p->d_twr);

@@ -27,6 +27,7 @@ template <class T> hipError_t launch_t(int n_fft, int mode, const Args<T>& a, lo
 #define LRA_MIXED_CASE(N) \
     case N: return launch_n<T, N>(mode, a, batch, stream);
         LRA_MIXED_SIZES(LRA_MIXED_CASE)
+        LRA_MIXED_FWD_POW2(LRA_MIXED_CASE)
 #undef LRA_MIXED_CASE
         default: return hipErrorInvalidValue;
     }
@@ -160,6 +161,7 @@ int frames_per_group_of(int n_fft, int elem_bytes) {
 #define LRA_MIXED_CASE(N) \
     case N: return elem_bytes == 8 ? frames_per_group<double, N>() : frames_per_group<float, N>();
         LRA_MIXED_SIZES(LRA_MIXED_CASE)
+        LRA_MIXED_FWD_POW2(LRA_MIXED_CASE)
 #undef LRA_MIXED_CASE
         default: return 0;
     }

@@ -1612,6 +1612,34 @@ def test_numpy_batch_shards_in_process(L, monkeypatch):
         L.stft(bad, n_fft=1024, hop_length=256)
 
 
+@pytest.mark.parametrize("n_fft,hop,sr,n_mels", [(256, 64, 8000, 80), (256, 100, 8000, 56), (128, 32, 8000, 64), (128, 50, 8000, 40)])
+def test_small_pow2_mel_many_bands_flat_index(L, n_fft, hop, sr, n_mels):
+    """Round 6: the fused mel at n_fft 128 / 256 with many bands (from 40 / 56) runs the flat-index kernel of csrc/lra_mixed.h instead of the register-tiled one (whose
+    8- and 4-thread frames leave the band combine to too few lanes: 256 / 64 / 80 bands 2.02 -> 1.28 ms over 256 x 30 s); both against the oracle at the usual bars, every
+    pad mode, float64, and each other (ctx option mixed_pow2_mel).  Reference: feature/spectral.py:2022-2161."""
+    rng = np.random.default_rng(n_fft + hop)
+    y = (0.1 * rng.standard_normal((3, 40 * n_fft + 11))).astype(np.float32)
+    ctx = L.get_context(0)
+    outs = {}
+    try:
+        for opt in (1, 0):
+            ctx.set_option("mixed_pow2_mel", opt)
+            for center, pad_mode in ((True, "constant"), (True, "reflect"), (False, "constant")):
+                Mref = O.melspectrogram(y=y, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=n_mels, center=center, pad_mode=pad_mode)
+                M = L.feature.melspectrogram(y=y, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=n_mels, center=center, pad_mode=pad_mode)
+                assert M.shape == Mref.shape and _mel_close(M, Mref), (opt, center, pad_mode)
+                assert np.all(np.abs(M - Mref) <= 1e-4 * np.abs(Mref) + 1e-7 * Mref.max())
+                outs[(opt, center, pad_mode)] = M
+            y64 = y[:2].astype(np.float64)
+            assert _mel_close(L.feature.melspectrogram(y=y64, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=n_mels), O.melspectrogram(y=y64, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=n_mels))
+            S1 = L.feature.melspectrogram(y=y, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=n_mels, power=1.0)
+            assert _mel_close(S1, O.melspectrogram(y=y, sr=sr, n_fft=n_fft, hop_length=hop, n_mels=n_mels, power=1.0))
+    finally:
+        ctx.set_option("mixed_pow2_mel", 1)
+    # (the stft / |X|^p of these sizes stay on the register-tiled kernels either way)
+    assert _stft_close(L.stft(y, n_fft=n_fft, hop_length=hop), O.stft(y, n_fft=n_fft, hop_length=hop))
+
+
 @pytest.mark.parametrize("n_fft,hop,sr,n_mels", [(400, 160, 16000, 80), (320, 160, 16000, 40), (480, 120, 48000, 64), (800, 200, 16000, 128), (960, 480, 48000, 80),
                                                  (1200, 300, 48000, 128), (1600, 400, 16000, 80), (2400, 600, 48000, 128), (240, 80, 8000, 20), (4800, 1200, 48000, 128),
                                                  (882, 441, 44100, 64), (1764, 441, 44100, 128), (2646, 882, 44100, 128), (3528, 882, 44100, 128), (600, 240, 24000, 80), (720, 180, 48000, 64)])
