@@ -83,7 +83,14 @@ int lra_ctx_use_own_stream(lra_ctx* ctx);
 int lra_ctx_side(lra_ctx* ctx, int mode);
 int lra_ctx_sync(lra_ctx* ctx);
 /* Tuning knobs: "stft_iters" (frames per slot, 0 = auto), "istft_strip_groups" (frames per strip, 0 = auto),
-   "variant" (-1 = auto), "autotune" (1/0). */
+   "variant" (-1 = auto), "autotune" (1/0).  Kernel-form switches kept for same-box A/B runs (defaults in brackets; DESIGN.md 4.2 / 4.4b / 4.6d say what
+   each form is): "v2" [1], "v3" [1: radices 16-16-4 for the complex epilogue; 2: for |X|^p and mel too], "mel_pc" [1: producer / consumer mel kernel; 2: on the
+   16-16-4 core], "istft16" [0], "direct" [1], "mixed" [1: fused mixed-radix kernels; 2: the same with the mel band table read through the caches; 0: rocFFT path],
+   "mixed_inv_pow2" [1], "mixed_irfft" [1: inverse transform of long mixed-radix frames as one launch in front of the gather kernel; 0: spec_pack + rocFFT C2R],
+   "ola4" [1: four samples per thread in the gather kernel], "mixed_pow2_mel" [1: n_fft 128 / 256 with many bands on the flat-index kernel],
+   "cqt_merge" [1: octaves 1-2 beside the later halvings; 2: all octaves behind the chain; 0: one launch per octave], "mel_many" [1], "hpss_tile" [1],
+   "placement_retry" [4; 0 = off], "pipe_chunk_mb" [128], "pipe_threads" [8], "xcd_remap" [1].  Unknown keys are an error.  The same keys can be preset for
+   every context of a process through the environment: LRA_CTX_OPTIONS="key=value,key=value". */
 int lra_ctx_set_option(lra_ctx* ctx, const char* key, int value);
 int lra_ctx_device_name(lra_ctx* ctx, char* buf, size_t buflen);
 /* Device-side half of util.valid_audio (librosa/util/utils.py:294-306): the fused power-of-two STFT
