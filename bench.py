@@ -335,7 +335,8 @@ def compact_line(line):
             "cqt_polyphase_ms_64clips": get(line, "pcen_cqt", "cqt_polyphase", "ms_per_call"), "cqt_default_ms_64clips": get(line, "pcen_cqt", "cqt_default", "ms_per_call"), "cqt_polyphase_nocheck_ms_64clips": get(line, "pcen_cqt", "cqt_polyphase_nocheck", "ms_per_call"),
             "pcen_ms": get(line, "pcen_cqt", "pcen", "ms_per_call"), "hpss_ms_32clips": get(line, "hpss", "ms_per_call"), "mixed_400_mel_ms": get(line, "mixed_radix_400", "fused", "mel_ms"),
             "mixed_400_stft_ms": get(line, "mixed_radix_400", "fused", "stft_ms"), "mixed_1200_stft_GBps": get(line, "mixed_radix_1200", "stft_GBps_algorithmic"), "mixed_1200_mel_ms": get(line, "mixed_radix_1200", "mel_ms"),
-            "mixed_3200_stft_GBps": get(line, "mixed_radix_3200", "stft_GBps_algorithmic"), "mixed_3200_mel_ms": get(line, "mixed_radix_3200", "mel_ms"), "speech_512_mel_ms": get(line, "speech_512", "mel_ms"), "cqt_lite_512_ms": get(line, "cqt_lite", "per_n_fft", "512", "ms"),
+            "mixed_3200_stft_GBps": get(line, "mixed_radix_3200", "stft_GBps_algorithmic"), "mixed_3200_mel_ms": get(line, "mixed_radix_3200", "mel_ms"),
+            "mixed_1200_istft_ms": get(line, "mixed_radix_1200", "istft_ms"), "mixed_3200_istft_ms": get(line, "mixed_radix_3200", "istft_ms"), "speech_512_mel_ms": get(line, "speech_512", "mel_ms"), "cqt_lite_512_ms": get(line, "cqt_lite", "per_n_fft", "512", "ms"),
             "cqt_lite_8192_ms": get(line, "cqt_lite", "per_n_fft", "8192", "ms"), "cqt_lite_default_hop_ms": get(line, "cqt_lite", "default_hop_variant", "ms_total"),
             "stft_power_w": get(line, "board_power", "stft", "socket_power_w"), "stft_sclk_mhz": get(line, "board_power", "stft", "sclk_mhz"),
             "mel_power_w": get(line, "board_power", "mel", "socket_power_w"), "mel_variant": get(line, "kernel_variants", "melspectrogram")}
@@ -935,7 +936,12 @@ def main():
                 _, e2 = timed(fs, 5, 2, collective=False, ramp_ms=args.prewarm_ms / 4)
                 fm = lambda: L.feature.melspectrogram(y=y, sr=SR, n_fft=nf, hop_length=hp, n_mels=N_MELS, check_finite=False)
                 _, e = timed(fm, 5, 2, collective=False, ramp_ms=args.prewarm_ms / 4)
+                Dm = fs()
+                fi = lambda: L.istft(Dm, hop_length=hp, n_fft=nf, length=y.shape[-1])
+                _, e3 = timed(fi, 5, 2, collective=False, ramp_ms=args.prewarm_ms / 4)
+                del Dm
                 return {"stft_ms": e2 / 5 * 1e3, "stft_GBps_algorithmic": batch * T2 * (hp * 4 + (nf // 2 + 1) * 8) / (e2 / 5) / 1e9, "mel_ms": e / 5 * 1e3, "mel_frames_per_s": batch * T2 / (e / 5),
+                        "istft_ms": e3 / 5 * 1e3, "istft_GBps_algorithmic": batch * T2 * (hp * 4 + (nf // 2 + 1) * 8) / (e3 / 5) / 1e9,
                         "mel_GBps_algorithmic": batch * T2 * (hp * 4 + N_MELS * 4) / (e / 5) / 1e9, "frames": batch * T2,
                         "workload": f"stft / feature.melspectrogram, n_fft={nf} hop={hp} n_mels={N_MELS} @ {SR} Hz, {batch} clips x {CLIP_SECONDS} s (device tensors, public drop-in; csrc/lra_mixed.h)"}
             return run
