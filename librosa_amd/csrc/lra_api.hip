@@ -3239,7 +3239,10 @@ int lra_cqt_recursion_exec(lra_ctx* ctx, const void* y, int64_t batch, const lra
         }
         // Round 6: with five or more octaves, octaves 1 and 2 go out in a launch of their own on the side stream as soon as their signals exist, beside the
         // remaining (short) halvings, which cannot fill the chip; the rest follows the chain as before (cqt_merge = 2: everything behind the chain).
-        const int early_end = (ctx->opt_cqt_merge == 1 && n_octaves >= 5 && octaves[1].n_fft == octaves[2].n_fft) ? 3 : 1;
+        static const int early_knob = std::getenv("LRA_CQT_EARLY") ? std::atoi(std::getenv("LRA_CQT_EARLY")) : 3;  // (development: one past the last early octave)
+        int early_end = (ctx->opt_cqt_merge == 1 && n_octaves >= 5) ? std::min(std::max(early_knob, 2), n_octaves - 1) : 1;
+        for (int i = 2; i < early_end; ++i)
+            if (octaves[i].n_fft != octaves[1].n_fft) early_end = 1;  // (one launch serves one frame length)
         for (int i = 0; i + 1 < n_octaves && rc == LRA_OK; ++i) {
             if (octaves[i].halve) {
                 rc = lra_fir_decimate_exec(ctx, cur, next, batch, octaves[i].n, octaves[i + 1].n, taps, n_taps, 2, first, sc, 1.0, dtype);
